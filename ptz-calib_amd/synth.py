@@ -1,0 +1,323 @@
+"""Deterministic synthetic PTZ rigs and relocalization queries.
+
+The reference's datasets (README.md:25) are not available, so every BASELINE config is synthetic.
+Generation is bit-reproducible across machines: SplitMix64 counters + Box-Muller, no numpy RNG.
+
+Scene s uses seed 0x50545A00 + s.  Output is the packed form the C-ABI takes (include/ptz_calib_amd.h):
+observations sorted (track asc, image asc) as PTZRayOptimizer::AddConstraints2d2d iterates them
+(ptzray_optimizer.cc:801-850), float32 pixels (data_io.cc:40), camera 15-vectors (types.cc:32-73).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+SEED_BASE = 0x50545A00
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+class SplitMix64:
+    """Counter-based SplitMix64 stream; draw(n) returns the next n outputs."""
+
+    def __init__(self, seed: int):
+        self.seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        self.count = 0
+
+    def u64(self, n: int) -> np.ndarray:
+        idx = np.arange(self.count + 1, self.count + n + 1, dtype=np.uint64)
+        self.count += n
+        with np.errstate(over="ignore"):
+            z = self.seed + idx * _GOLDEN
+            z = (z ^ (z >> np.uint64(30))) * _M1
+            z = (z ^ (z >> np.uint64(27))) * _M2
+            z = z ^ (z >> np.uint64(31))
+        return z
+
+    def uniform(self, n: int, lo: float = 0.0, hi: float = 1.0) -> np.ndarray:
+        u = (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return lo + (hi - lo) * u
+
+    def normal(self, n: int, sigma: float = 1.0) -> np.ndarray:
+        m = (n + 1) // 2
+        u1 = 1.0 - self.uniform(m)  # (0, 1]
+        u2 = self.uniform(m)
+        r = np.sqrt(-2.0 * np.log(u1))
+        z = np.concatenate([r * np.cos(2.0 * math.pi * u2), r * np.sin(2.0 * math.pi * u2)])[:n]
+        return sigma * z
+
+    def permutation_keys(self, n: int) -> np.ndarray:
+        return self.u64(n)
+
+
+def rodrigues(rvec: np.ndarray) -> np.ndarray:
+    """Vector -> rotation matrix (same formula as cv::Rodrigues)."""
+    rvec = np.asarray(rvec, dtype=np.float64)
+    theta = float(np.linalg.norm(rvec))
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3)
+    c, s = math.cos(theta), math.sin(theta)
+    r = rvec / theta
+    rx = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    return c * np.eye(3) + (1 - c) * np.outer(r, r) + s * rx
+
+
+def rodrigues_inv(R: np.ndarray) -> np.ndarray:
+    """Rotation matrix -> vector (angle in [0, pi])."""
+    R = np.asarray(R, dtype=np.float64)
+    c = max(-1.0, min(1.0, (np.trace(R) - 1.0) * 0.5))
+    theta = math.acos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = 0.5 * np.linalg.norm(v)
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        t = np.sqrt(np.maximum((np.diag(R) + 1) * 0.5, 0.0))
+        t[1] *= -1.0 if R[0, 1] < 0 else 1.0
+        t[2] *= -1.0 if (R[0, 2] < 0) != (R[1, 2] < 0) else 1.0
+        return t * (theta / np.linalg.norm(t))
+    return v * (theta / (2.0 * s))
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+@dataclass
+class Scene:
+    """One packed PTZ-IBA problem + ground truth."""
+
+    n_cam: int
+    n_ray: int
+    width: int
+    height: int
+    factor_type: int
+    obs_uv: np.ndarray       # float32 [n_obs, 2]
+    obs_cam: np.ndarray      # int32 [n_obs]
+    obs_ray: np.ndarray      # int32 [n_obs] non-decreasing
+    ray_weight: np.ndarray   # float64 [n_ray]  (= track length)
+    cam_gt: np.ndarray       # float64 [n_cam, 15]
+    cam_init: np.ndarray     # float64 [n_cam, 15]
+    ray_gt: np.ndarray       # float64 [n_ray, 3]
+    ray_init: np.ndarray     # float64 [n_ray, 3] (Pix2Ray of cam_init)
+    seed: int = 0
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.obs_cam.shape[0])
+
+
+def pix2ray(obs_uv, obs_cam, obs_ray, n_ray, cam):
+    """Pix2Ray, ptzray_optimizer.cc:768-797 (vectorised; same formula as oracle orc_pix2ray)."""
+    R = np.stack([rodrigues(c[4:7]) for c in cam])  # [n_cam,3,3]
+    q = np.stack([
+        (obs_uv[:, 0].astype(np.float64) - cam[obs_cam, 2]) / cam[obs_cam, 0],
+        (obs_uv[:, 1].astype(np.float64) - cam[obs_cam, 3]) / cam[obs_cam, 1],
+        np.ones(len(obs_cam)),
+    ], axis=1)
+    Rinv = np.linalg.inv(R)[obs_cam]
+    t = np.einsum("nij,nj->ni", Rinv, q)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    acc = np.zeros((n_ray, 3))
+    np.add.at(acc, obs_ray, t)
+    cnt = np.bincount(obs_ray, minlength=n_ray).astype(np.float64)
+    acc /= cnt[:, None]
+    acc /= np.linalg.norm(acc, axis=1, keepdims=True)
+    return acc
+
+
+def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, factor_type: int = 0,
+               width: int = 1920, height: int = 1080, pan_range_deg: float | None = None,
+               noise_px: float = 0.5, init_rot_sigma_deg: float = 0.5, init_focal: float | None = None,
+               min_track_len: int = 4) -> Scene:
+    """Synthetic PTZ rig.  C1: n_views=20, obs_per_view=100.  C2: 200 x 500.
+
+    pan_range_deg=None picks min(360, 6 * n_views): a full 360-degree ring needs ~1.8-degree pan spacing for
+    tracks of >= 4 views (Filter(4), ptzray_optimizer.cc:541) to exist, so small rigs sweep a sector instead."""
+    if pan_range_deg is None:
+        pan_range_deg = min(360.0, 6.0 * n_views)
+    seed = SEED_BASE + scene_id
+    rng = SplitMix64(seed)
+    cx, cy = 0.5 * width, 0.5 * height
+    N = n_views
+    # --- ground-truth cameras
+    pan = np.deg2rad(pan_range_deg * np.arange(N) / N + rng.uniform(N, -0.2, 0.2))
+    if pan_range_deg < 360.0:
+        pan -= np.deg2rad(pan_range_deg) * 0.5
+    tilt = np.deg2rad(np.array([-10.0, 0.0, 10.0])[np.arange(N) % 3] + rng.uniform(N, -0.2, 0.2))
+    focal = rng.uniform(N, 1800.0, 3200.0) * (width / 1920.0)
+    k1 = rng.uniform(N, -0.05, 0.05) if factor_type != 0 else np.zeros(N)
+    Rgt = np.stack([_rot_x(tilt[i]) @ _rot_y(pan[i]) for i in range(N)])
+    cam_gt = np.zeros((N, 15))
+    cam_gt[:, 0] = focal
+    cam_gt[:, 1] = focal
+    cam_gt[:, 2] = cx
+    cam_gt[:, 3] = cy
+    cam_gt[:, 10] = k1
+    for i in range(N):
+        cam_gt[i, 4:7] = rodrigues_inv(Rgt[i])
+
+    # --- candidate world rays, uniform in the band |elevation| <= 35 deg.  The ray count P is sized
+    #     (deterministic fixed point) so that ~2.2x the target observations are visible: keeping ~45 %
+    #     of them per view then gives tracks of mean length ~5 after Filter(4).
+    target_total = N * obs_per_view
+    half = math.pi if pan_range_deg >= 360.0 else math.radians(0.5 * pan_range_deg + 30.0)
+    P = int(round(target_total / 3.2))
+    for _attempt in range(4):
+        az = rng.uniform(P, -half, half)
+        sin_el = rng.uniform(P, -math.sin(math.radians(35.0)), math.sin(math.radians(35.0)))
+        cos_el = np.sqrt(1.0 - sin_el ** 2)
+        X = np.stack([cos_el * np.sin(az), sin_el, cos_el * np.cos(az)], axis=1)  # unit, z forward at pan 0
+        # exact projections and visibility (>= 8 px inside the frame)
+        Pc = np.einsum("nij,pj->npi", Rgt, X)  # [N,P,3]
+        z = Pc[:, :, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = Pc[:, :, 0] / z
+            y = Pc[:, :, 1] / z
+            r2 = x * x + y * y
+            rad = 1.0 + k1[:, None] * r2
+            u = focal[:, None] * x * rad + cx
+            v = focal[:, None] * y * rad + cy
+        vis = (z > 0.1) & (u >= 8) & (u <= width - 8) & (v >= 8) & (v <= height - 8) & (r2 < 1.5)
+        ratio = 2.2 * target_total / max(int(vis.sum()), 1)
+        if 0.92 < ratio < 1.08:
+            break
+        P = max(16, int(round(P * ratio)))
+
+    # --- per view keep a seeded random subset; tune the per-view quota so that, after dropping
+    #     tracks shorter than min_track_len, the mean is ~obs_per_view (deterministic fixed point)
+    keys = rng.permutation_keys(N * P).reshape(N, P)
+    keys = np.where(vis, keys >> np.uint64(1), np.uint64(0xFFFFFFFFFFFFFFFF))
+    order = np.argsort(keys, axis=1, kind="stable")  # visible ones first, in random order
+    nvis = vis.sum(axis=1)
+    quota = float(obs_per_view) * 1.15
+    keep = None
+    for _ in range(6):
+        keep = np.zeros_like(vis)
+        q = np.minimum(nvis, int(round(quota)))
+        for i in range(N):
+            keep[i, order[i, : q[i]]] = True
+        tl = keep.sum(axis=0)
+        keep &= (tl >= min_track_len)[None, :]
+        mean_obs = keep.sum() / N
+        if abs(mean_obs - obs_per_view) < 0.01 * obs_per_view:
+            break
+        quota *= obs_per_view / max(mean_obs, 1.0)
+    ray_ids = np.nonzero(keep.any(axis=0))[0]
+    n_ray = len(ray_ids)
+    keep = keep[:, ray_ids]
+    # observation list sorted (ray asc, cam asc)
+    rr, cc = np.nonzero(keep.T)
+    n_obs = len(rr)
+    uu = u[:, ray_ids][cc, rr] + rng.normal(n_obs, noise_px)
+    vv = v[:, ray_ids][cc, rr] + rng.normal(n_obs, noise_px)
+    obs_uv = np.stack([uu, vv], axis=1).astype(np.float32)
+    obs_cam = cc.astype(np.int32)
+    obs_ray = rr.astype(np.int32)
+    ray_weight = np.bincount(obs_ray, minlength=n_ray).astype(np.float64)
+    ray_gt = X[ray_ids]
+
+    # --- initial guess as the reference would hand it to the global BA
+    f0 = init_focal if init_focal is not None else 1.2 * max(width, height)  # ptz_incremental_optimizer.cc:324
+    cam_init = cam_gt.copy()
+    cam_init[:, 0] = f0
+    cam_init[:, 1] = f0
+    cam_init[:, 10] = 0.0
+    sig = math.radians(init_rot_sigma_deg)
+    pert = rng.normal(3 * N, sig).reshape(N, 3)
+    for i in range(N):
+        cam_init[i, 4:7] = rodrigues_inv(rodrigues(pert[i]) @ Rgt[i])
+    ray_init = pix2ray(obs_uv, obs_cam, obs_ray, n_ray, cam_init)
+    return Scene(n_cam=N, n_ray=n_ray, width=width, height=height, factor_type=factor_type, obs_uv=obs_uv,
+                 obs_cam=obs_cam, obs_ray=obs_ray, ray_weight=ray_weight, cam_gt=cam_gt, cam_init=cam_init,
+                 ray_gt=ray_gt, ray_init=ray_init, seed=seed,
+                 meta={"obs_per_view_mean": n_obs / N, "track_len_mean": n_obs / max(n_ray, 1)})
+
+
+@dataclass
+class RelocBatch:
+    """Batched single-view relocalization queries (run_ptz_reloc.cc:68-118) in packed form."""
+
+    n_query: int
+    match_ptr: np.ndarray   # int64 [n_query + 1]
+    uv_ref: np.ndarray      # float32 [n_match_total, 2]
+    uv_cur: np.ndarray      # float32 [n_match_total, 2]
+    cam_ref: np.ndarray     # float64 [n_query, 15]  reference camera of each query (world frame)
+    cam_init: np.ndarray    # float64 [n_query, 15]  initial current camera, world frame (run_ptz_reloc.cc:96-104)
+    cam_gt: np.ndarray      # float64 [n_query, 15]
+    factor_type: int = 0
+
+
+def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_type: int = 0,
+                     rig: np.ndarray | None = None, width: int = 1920, height: int = 1080,
+                     noise_px: float = 0.5) -> RelocBatch:
+    """C5: queries with pan/tilt over the covered band, f ~ U(1500, 4000), n_match matches against the
+    nearest reference view, 0.5 px noise, init = (f_ref, R_ref)."""
+    rng = SplitMix64(SEED_BASE + 0x100000 + seed_id)
+    cx, cy = 0.5 * width, 0.5 * height
+    if rig is None:
+        rig = make_scene(0, 200, 20).cam_gt  # only the cameras matter
+    n_ref = rig.shape[0]
+    Rref = np.stack([rodrigues(c[4:7]) for c in rig])
+    fwd = Rref[:, 2, :]  # optical axis of each reference view in world coordinates (R maps world->cam)
+    cam_ref = np.zeros((n_query, 15))
+    cam_gt = np.zeros((n_query, 15))
+    cam_init = np.zeros((n_query, 15))
+    uv_ref = np.zeros((n_query * n_match, 2), dtype=np.float32)
+    uv_cur = np.zeros((n_query * n_match, 2), dtype=np.float32)
+    pan = rng.uniform(n_query, -math.pi, math.pi)
+    tilt = np.deg2rad(rng.uniform(n_query, -10.0, 10.0))
+    fq = rng.uniform(n_query, 1500.0, 4000.0)
+    k1q = rng.uniform(n_query, -0.05, 0.05) if factor_type == 1 else np.zeros(n_query)
+    over = 3  # oversampling factor for candidate pixels
+    for q in range(n_query):
+        Rq = _rot_x(tilt[q]) @ _rot_y(pan[q])
+        ref = int(np.argmax(fwd @ Rq[2, :]))
+        cr = rig[ref]
+        # sample pixels in the reference image, keep those that land inside the query frame
+        cand = n_match * over * 4
+        pu = rng.uniform(cand, 8.0, width - 8.0)
+        pv = rng.uniform(cand, 8.0, height - 8.0)
+        ray_c = np.stack([(pu - cr[2]) / cr[0], (pv - cr[3]) / cr[1], np.ones(cand)], axis=1)
+        ray_w = ray_c @ Rref[ref]  # R^T applied: world = R^-1 cam
+        pc = ray_w @ Rq.T
+        zz = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = pc[:, 0] / zz
+            y = pc[:, 1] / zz
+            rad = 1.0 + k1q[q] * (x * x + y * y)
+            qu = fq[q] * x * rad + cx
+            qv = fq[q] * y * rad + cy
+        ok = np.nonzero((zz > 0.1) & (qu >= 8) & (qu <= width - 8) & (qv >= 8) & (qv <= height - 8))[0]
+        if len(ok) < n_match:
+            # degenerate overlap: fall back to pixels near the reference centre
+            ok = np.argsort((pu - cx) ** 2 + (pv - cy) ** 2)[:n_match]
+        ok = ok[:n_match]
+        s = slice(q * n_match, (q + 1) * n_match)
+        uv_ref[s, 0] = (pu[ok] + rng.normal(n_match, noise_px)).astype(np.float32)
+        uv_ref[s, 1] = (pv[ok] + rng.normal(n_match, noise_px)).astype(np.float32)
+        uv_cur[s, 0] = (qu[ok] + rng.normal(n_match, noise_px)).astype(np.float32)
+        uv_cur[s, 1] = (qv[ok] + rng.normal(n_match, noise_px)).astype(np.float32)
+        cam_ref[q] = cr
+        cam_gt[q] = cr
+        cam_gt[q, 0] = cam_gt[q, 1] = fq[q]
+        cam_gt[q, 2], cam_gt[q, 3] = cx, cy
+        cam_gt[q, 4:7] = rodrigues_inv(Rq)
+        cam_gt[q, 10] = k1q[q]
+        # init: K = diag(f_ref) with the test image centre, R = R_ref, t = t_ref, dist = dist_ref
+        cam_init[q] = cr
+        cam_init[q, 1] = cr[0]
+        cam_init[q, 2], cam_init[q, 3] = cx, cy
+    match_ptr = (np.arange(n_query + 1, dtype=np.int64) * n_match)
+    return RelocBatch(n_query=n_query, match_ptr=match_ptr, uv_ref=uv_ref, uv_cur=uv_cur, cam_ref=cam_ref,
+                      cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
