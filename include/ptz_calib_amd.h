@@ -1,0 +1,186 @@
+/*
+ * ptz_calib_amd.h -- C-ABI of libptzcalib_hip.so: the MI355X (gfx950) implementation of the PTZ-Calib
+ * optimisation hot path (per-observation PTZ reprojection residual/Jacobian evaluation, Levenberg-
+ * Marquardt normal-equation assembly, Schur elimination, dense reduced-camera solve, LM control).
+ *
+ * The reference (gjgjh/PTZ-Calib) has no FFI layer; its seam is the pair of C++ classes that each own
+ * a ceres::Problem.  Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  Plain pointers and sizes only; no C++ or torch types.
+ * All functions return 0 on success or a negative PTZ_E* code; no exceptions cross the boundary and
+ * there is no CPU fallback: without a HIP device every compute entry point returns PTZ_ENODEVICE.
+ *
+ * Conventions
+ *  - Camera = 15 doubles, layout of Camera::ToVector (src/core/types.cc:32-57):
+ *      [fx, fy, cx, cy, r1, r2, r3, t1, t2, t3, k1, k2, k3, p1, p2]
+ *  - pixels are float32 pairs (cv::Point2f; src/core/data_io.cc:40), everything else float64
+ *  - observations are sorted (track id ascending, image id ascending), the order in which
+ *    PTZRayOptimizer::AddConstraints2d2d adds residual blocks (src/core/ptzray_optimizer.cc:801-850)
+ *  - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory
+ */
+#ifndef PTZ_CALIB_AMD_H
+#define PTZ_CALIB_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTZ_CAM_DIM 15
+
+/* error codes */
+#define PTZ_OK 0
+#define PTZ_EINVAL (-1)     /* malformed problem (CheckValid, ptzray_optimizer.cc:515-535) */
+#define PTZ_ENODEVICE (-2)  /* no usable HIP device / HIP runtime error */
+#define PTZ_ENOMEM (-3)
+#define PTZ_EUNSUPPORTED (-4) /* factor type not implemented on the device path */
+
+/* enum FACTOR_TYPE { PTZRay, PTZRayDist, PTZRayFxfyDist, PTZRayDistDisp }  (ptzray_optimizer.h:110) */
+#define PTZ_BA_PTZRay 0
+#define PTZ_BA_PTZRayDist 1
+#define PTZ_BA_PTZRayFxfyDist 2
+#define PTZ_BA_PTZRayDistDisp 3
+/* KRTOptimizer::FACTOR_TYPE { F, FDist, Fxfy, FxfyDist }  (krt_optimizer.h:110) */
+#define PTZ_KRT_F 0
+#define PTZ_KRT_FDist 1
+#define PTZ_KRT_Fxfy 2
+#define PTZ_KRT_FxfyDist 3
+/* ceres::TerminationType as read by the reference (ptzray_optimizer.cc:482, krt_optimizer.cc:513) */
+#define PTZ_CONVERGENCE 0
+#define PTZ_NO_CONVERGENCE 1
+#define PTZ_FAILURE 2
+
+/* Solver options.  The reference sets max_num_iterations, linear_solver_type, num_threads only
+ * (ptzray_optimizer.cc:469-473, krt_optimizer.cc:387-391); every other field is the Ceres 1.14
+ * default and is exposed so that the defaults are data, not code. */
+typedef struct ptz_lm_options {
+  int32_t max_num_iterations;                /* 200 (run_ptz_ba.cc:52) / 100 (ptz_incremental_optimizer.cc:396) */
+  int32_t device_id;                         /* HIP device ordinal */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;                    /* 1 */
+  double initial_trust_region_radius;        /* 1e4 */
+  double max_trust_region_radius;            /* 1e16 */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3 */
+  double min_lm_diagonal;                    /* 1e-6 */
+  double max_lm_diagonal;                    /* 1e32 */
+  double function_tolerance;                 /* 1e-6 */
+  double gradient_tolerance;                 /* 1e-10 */
+  double parameter_tolerance;                /* 1e-8 */
+} ptz_lm_options;
+
+/* The ceres::Solver::Summary fields the reference reads (ptzray_optimizer.cc:962-963,482;
+ * krt_optimizer.cc:396,506-513) plus iteration bookkeeping. */
+typedef struct ptz_lm_summary {
+  int32_t termination_type;     /* PTZ_CONVERGENCE / PTZ_NO_CONVERGENCE / PTZ_FAILURE */
+  int32_t num_iterations;       /* summary.iterations.size() - 1 */
+  int32_t num_lm_steps;         /* trust-region loop passes executed (includes the terminating pass) */
+  int32_t num_successful_steps; /* iteration 0 counts as successful, as in Ceres */
+  int32_t num_unsuccessful_steps;
+  int32_t num_residuals;        /* scalar residuals */
+  int32_t num_linear_solves;
+  int32_t num_jacobian_evals;
+  double initial_cost;
+  double final_cost;
+  double final_radius;
+  double final_gradient_max_norm;
+} ptz_lm_summary;
+
+void ptz_lm_options_default(ptz_lm_options* o);
+
+/* Library / device probe.  ptz_device_count() never initialises a GPU context beyond counting. */
+const char* ptz_version(void);
+int32_t ptz_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * PTZ-IBA global bundle adjustment
+ *   replaces PTZRayOptimizer::Solve (ptzray_optimizer.cc:454-489) from AddConstraints2d2d onwards:
+ *   residual blocks, SubsetParameterization masks, ScaledLoss weights, ceres::Solve(SPARSE_SCHUR).
+ * One problem = one scene's candidate cameras + tracks, in packed form.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ptz_ba_problem {
+  int32_t n_cam;             /* candidate cameras (compact ids 0..n_cam-1) */
+  int32_t n_ray;             /* tracks with >= 1 candidate observation */
+  int64_t n_obs;             /* 2D-2D observations */
+  const float* obs_uv;       /* host [2*n_obs] */
+  const int32_t* obs_cam;    /* host [n_obs] */
+  const int32_t* obs_ray;    /* host [n_obs] non-decreasing */
+  const double* ray_weight;  /* host [n_ray]: ScaledLoss weight = full track length (ptzray_optimizer.cc:805) */
+  int32_t n_obs3d;           /* 2D-3D annotation observations (ptzray_optimizer.cc:887-923); 0 = none */
+  const float* obs3d_uv;     /* host [2*n_obs3d] */
+  const double* obs3d_xyz;   /* host [3*n_obs3d] */
+  const int32_t* obs3d_cam;  /* host [n_obs3d] */
+  int32_t factor_type;       /* PTZ_BA_* */
+} ptz_ba_problem;
+
+typedef struct ptz_ba_batch ptz_ba_batch; /* opaque: device-resident problems + workspaces */
+
+/* Build a device-resident batch of n independent problems (all with the same factor_type).  Uploads
+ * the observation records, builds the structural indices (per-camera observation lists, camera-pair
+ * lists for the Schur complement) and allocates every workspace, so that ptz_ba_batch_solve performs
+ * no allocation.  The problem arrays may be released after this call returns. */
+int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz_lm_options* opt, ptz_ba_batch** out);
+void ptz_ba_batch_destroy(ptz_ba_batch* b);
+
+/* Initial point.  cam: host [15 * sum(n_cam)], ray: host [3 * sum(n_ray)], tlw: host [6 * n] (may be
+ * NULL = zeros), each concatenated over the problems in order
+ * (SetUpInitialCameraParams, ptzray_optimizer.cc:635-670). */
+int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double* ray, const double* tlw);
+/* Run LM on every problem of the batch from the state last set (the state set by
+ * ptz_ba_batch_set_state is kept, so repeated calls re-solve from the same initial point).
+ * Device work is enqueued on the batch's stream; the call returns after the stream has drained.
+ * summaries: host [n]. */
+int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries);
+/* Solution = parameters at the minimum-cost point, as Ceres writes back (any termination type). */
+int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw);
+/* Device time of the last ptz_ba_batch_solve in milliseconds (HIP events on the batch's stream),
+ * and, per kernel family, the accumulated device time and launch count when profiling was enabled
+ * with ptz_ba_batch_set_profiling(b, 1) (serialises the stream between kernels). */
+int32_t ptz_ba_batch_last_solve_ms(const ptz_ba_batch* b, double* ms);
+int32_t ptz_ba_batch_set_profiling(ptz_ba_batch* b, int32_t enable);
+#define PTZ_PROF_SLOTS 16
+int32_t ptz_ba_batch_get_profile(const ptz_ba_batch* b, double* ms_per_slot, int64_t* launches_per_slot,
+                                 const char** slot_names);
+
+/* One-shot convenience: create + set_state + solve + get_state + destroy for a single problem.
+ * cam/ray/tlw are updated in place. */
+int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt,
+                     ptz_lm_summary* summary);
+
+/* Kernel-level entry points used by the parity tests (one linearisation at the current state of
+ * problem `index`; weighted by sqrt(track length), not Jacobi-scaled).  Host outputs, any may be NULL:
+ *   cost; g_c [nc*n_cam], U [nc*nc*n_cam]; g_r [3*n_ray], V [9*n_ray]; W [nc*3*n_obs]
+ * where nc = ptz_ba_cam_block_dim(factor_type): the free camera parameters carried on the device
+ * ([fx, r1, r2, r3] for PTZRay, [fx, k1, r1, r2, r3] for PTZRayDist; the reference's always-zero fy
+ * column (ptzray_optimizer.cc:24-25) is not materialised). */
+int32_t ptz_ba_cam_block_dim(int32_t factor_type);
+int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, double* g_c, double* U, double* g_r,
+                               double* V, double* W);
+/* Pix2Ray ray initialisation (ptzray_optimizer.cc:768-797) on the device for the whole batch:
+ * overwrites the ray part of the stored initial state from the stored cameras. */
+int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b);
+
+/* Dense SPD solve used for the reduced camera system, exposed for parity tests and micro-benchmarks:
+ * solves A x = rhs for `count` independent n x n systems (host, row-major, lower triangle read).
+ * Returns per-system status in fail[count] (1 = not positive definite). */
+int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const double* rhs, double* x, int32_t* fail,
+                             int32_t device_id, double* device_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-view LM, batched over queries
+ *   replaces KRTOptimizer::Add2d2dConstraints + Solve (krt_optimizer.cc:265-348, 385-404), the loop
+ *   body of run_ptz_reloc.cc:68-118 and RegisterNextImage (ptz_incremental_optimizer.cc:377-418).
+ * Query q owns matches [match_ptr[q], match_ptr[q+1]).  cam_ref: reference camera (world frame),
+ * cam_cur: in = initial current camera in world frame (SetInitParams), out = refined camera in world
+ * frame (ObtainRefinedCameraParams, krt_optimizer.cc:535-567), written only when accepted[q] = 1
+ * (CheckResults, krt_optimizer.cc:504-533, with max_reproj_error).
+ * ------------------------------------------------------------------------------------------------ */
+int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                            const double* cam_ref, double* cam_cur, int32_t factor_type, double max_reproj_error,
+                            const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted,
+                            double* device_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTZ_CALIB_AMD_H */

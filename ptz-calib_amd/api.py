@@ -1,0 +1,227 @@
+"""ctypes binding of include/ptz_calib_amd.h (libptzcalib_hip.so).
+
+No compute happens in Python and there is no CPU fallback: if the HIP library is missing or no device is
+present, every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptzcalib_hip.so")
+
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+BA_PTZRay, BA_PTZRayDist, BA_PTZRayFxfyDist, BA_PTZRayDistDisp = 0, 1, 2, 3
+KRT_F, KRT_FDist, KRT_Fxfy, KRT_FxfyDist = 0, 1, 2, 3
+PROF_SLOTS = 16
+_ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUPPORTED"}
+
+EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_batch_create", "ptz_ba_batch_destroy",
+           "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
+           "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
+           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_chol_solve_batch", "ptz_krt_solve_batch"]
+
+
+class PtzError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__(f"{where}: {_ERR.get(code, code)}")
+        self.code = code
+
+
+class LmOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("device_id", C.c_int32),
+                ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double)]
+
+
+class LmSummary(C.Structure):
+    _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32), ("num_lm_steps", C.c_int32),
+                ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+                ("num_residuals", C.c_int32), ("num_linear_solves", C.c_int32), ("num_jacobian_evals", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("final_gradient_max_norm", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_cam", C.c_int32), ("n_ray", C.c_int32), ("n_obs", C.c_int64), ("obs_uv", C.c_void_p),
+                ("obs_cam", C.c_void_p), ("obs_ray", C.c_void_p), ("ray_weight", C.c_void_p),
+                ("n_obs3d", C.c_int32), ("obs3d_uv", C.c_void_p), ("obs3d_xyz", C.c_void_p),
+                ("obs3d_cam", C.c_void_p), ("factor_type", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fails loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ptz_version.restype = C.c_char_p
+        _lib.ptz_device_count.restype = C.c_int32
+        _lib.ptz_ba_cam_block_dim.restype = C.c_int32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise PtzError(rc, where)
+
+
+def version() -> str:
+    return lib().ptz_version().decode()
+
+
+def device_count() -> int:
+    return int(lib().ptz_device_count())
+
+
+def default_options(**kw) -> LmOptions:
+    o = LmOptions()
+    lib().ptz_lm_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _pack_problem(sc, keep):
+    arrs = dict(uv=np.ascontiguousarray(sc.obs_uv, dtype=np.float32), cam=np.ascontiguousarray(sc.obs_cam, dtype=np.int32),
+                ray=np.ascontiguousarray(sc.obs_ray, dtype=np.int32), w=np.ascontiguousarray(sc.ray_weight, dtype=np.float64))
+    keep.append(arrs)
+    p = BaProblem()
+    p.n_cam, p.n_ray, p.n_obs = sc.n_cam, sc.n_ray, len(arrs["cam"])
+    p.obs_uv, p.obs_cam, p.obs_ray, p.ray_weight = _p(arrs["uv"]), _p(arrs["cam"]), _p(arrs["ray"]), _p(arrs["w"])
+    p.n_obs3d = 0
+    p.factor_type = sc.factor_type
+    return p
+
+
+class BaBatch:
+    """Device-resident batch of independent PTZ-IBA problems (ptz_ba_batch_*)."""
+
+    def __init__(self, scenes, **opt):
+        self.scenes = list(scenes)
+        self.n = len(self.scenes)
+        keep = []
+        probs = (BaProblem * self.n)(*[_pack_problem(s, keep) for s in self.scenes])
+        self.opt = default_options(**opt)
+        self.handle = C.c_void_p()
+        _check(lib().ptz_ba_batch_create(self.n, probs, C.byref(self.opt), C.byref(self.handle)), "ptz_ba_batch_create")
+        self.cam_off = np.concatenate([[0], np.cumsum([s.n_cam for s in self.scenes])])
+        self.ray_off = np.concatenate([[0], np.cumsum([s.n_ray for s in self.scenes])])
+        self.obs_off = np.concatenate([[0], np.cumsum([s.n_obs for s in self.scenes])])
+        self.nc = int(lib().ptz_ba_cam_block_dim(self.scenes[0].factor_type))
+
+    def close(self):
+        if self.handle:
+            lib().ptz_ba_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, cams=None, rays=None):
+        cam = np.ascontiguousarray(np.concatenate([s.cam_init for s in self.scenes] if cams is None else cams), dtype=np.float64)
+        ray = np.ascontiguousarray(np.concatenate([s.ray_init for s in self.scenes] if rays is None else rays), dtype=np.float64)
+        _check(lib().ptz_ba_batch_set_state(self.handle, _p(cam), _p(ray), None), "ptz_ba_batch_set_state")
+
+    def pix2ray(self):
+        _check(lib().ptz_ba_batch_pix2ray(self.handle), "ptz_ba_batch_pix2ray")
+
+    def solve(self):
+        summ = (LmSummary * self.n)()
+        _check(lib().ptz_ba_batch_solve(self.handle, summ), "ptz_ba_batch_solve")
+        return [s.as_dict() for s in summ]
+
+    def get_state(self):
+        cam = np.zeros((int(self.cam_off[-1]), 15))
+        ray = np.zeros((int(self.ray_off[-1]), 3))
+        _check(lib().ptz_ba_batch_get_state(self.handle, _p(cam), _p(ray), None), "ptz_ba_batch_get_state")
+        cams = [cam[self.cam_off[i]:self.cam_off[i + 1]] for i in range(self.n)]
+        rays = [ray[self.ray_off[i]:self.ray_off[i + 1]] for i in range(self.n)]
+        return cams, rays
+
+    def last_solve_ms(self) -> float:
+        ms = C.c_double()
+        _check(lib().ptz_ba_batch_last_solve_ms(self.handle, C.byref(ms)), "ptz_ba_batch_last_solve_ms")
+        return ms.value
+
+    def set_profiling(self, enable: bool):
+        _check(lib().ptz_ba_batch_set_profiling(self.handle, int(enable)), "ptz_ba_batch_set_profiling")
+
+    def get_profile(self):
+        ms = (C.c_double * PROF_SLOTS)()
+        cnt = (C.c_int64 * PROF_SLOTS)()
+        names = (C.c_char_p * PROF_SLOTS)()
+        _check(lib().ptz_ba_batch_get_profile(self.handle, ms, cnt, names), "ptz_ba_batch_get_profile")
+        return {names[i].decode(): {"ms": ms[i], "launches": cnt[i]} for i in range(PROF_SLOTS) if names[i]}
+
+    def linearize(self, index=0):
+        s = self.scenes[index]
+        nc = self.nc
+        cost = C.c_double()
+        g_c = np.zeros((s.n_cam, nc)); U = np.zeros((s.n_cam, nc, nc))
+        g_r = np.zeros((s.n_ray, 3)); V = np.zeros((s.n_ray, 3, 3)); W = np.zeros((s.n_obs, nc, 3))
+        _check(lib().ptz_ba_batch_linearize(self.handle, index, C.byref(cost), _p(g_c), _p(U), _p(g_r), _p(V), _p(W)),
+               "ptz_ba_batch_linearize")
+        return dict(cost=cost.value, g_c=g_c, U=U, g_r=g_r, V=V, W=W, nc=nc)
+
+
+def ba_solve(scene, cam0=None, ray0=None, **opt):
+    """One-shot ptz_ba_solve.  Returns (cam, ray, summary dict)."""
+    keep = []
+    p = _pack_problem(scene, keep)
+    cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
+    ray = np.array(scene.ray_init if ray0 is None else ray0, dtype=np.float64, order="C").copy()
+    o = default_options(**opt)
+    s = LmSummary()
+    _check(lib().ptz_ba_solve(C.byref(p), _p(cam), _p(ray), None, C.byref(o), C.byref(s)), "ptz_ba_solve")
+    return cam, ray, s.as_dict()
+
+
+def chol_solve_batch(A, rhs, device_id=0):
+    """A: [count, n, n] SPD (lower triangle read), rhs: [count, n].  Returns (x, fail, device_ms)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    count, n = A.shape[0], A.shape[1]
+    x = np.zeros((count, n))
+    fail = np.zeros(count, dtype=np.int32)
+    ms = C.c_double()
+    _check(lib().ptz_chol_solve_batch(count, n, _p(A), _p(rhs), _p(x), _p(fail), device_id, C.byref(ms)), "ptz_chol_solve_batch")
+    return x, fail, ms.value
+
+
+def krt_solve_batch(batch, max_reproj_error=100.0, **opt):
+    """batch: synth.RelocBatch-like.  Returns (cam_world [n,15], summaries, accepted, device_ms)."""
+    o = default_options(**opt)
+    n = batch.n_query
+    ptr = np.ascontiguousarray(batch.match_ptr, dtype=np.int64)
+    uvr = np.ascontiguousarray(batch.uv_ref, dtype=np.float32)
+    uvc = np.ascontiguousarray(batch.uv_cur, dtype=np.float32)
+    cref = np.ascontiguousarray(batch.cam_ref, dtype=np.float64)
+    ccur = np.array(batch.cam_init, dtype=np.float64, order="C").copy()
+    summ = (LmSummary * n)()
+    acc = np.zeros(n, dtype=np.int32)
+    ms = C.c_double()
+    _check(lib().ptz_krt_solve_batch(n, _p(ptr), _p(uvr), _p(uvc), _p(cref), _p(ccur), batch.factor_type,
+                                     C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.byref(ms)),
+           "ptz_krt_solve_batch")
+    return ccur, [s.as_dict() for s in summ], acc, ms.value

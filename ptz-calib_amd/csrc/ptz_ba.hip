@@ -1,0 +1,1379 @@
+// ptz_ba.hip -- PTZ-IBA global bundle adjustment on MI355X (gfx950): batched Levenberg-Marquardt over
+// independent scenes, everything between the packed observations and the refined parameters on device.
+//
+// Replaces PTZRayOptimizer::Solve (src/core/ptzray_optimizer.cc:454-489) from AddConstraints2d2d
+// (:799-885) through ceres::Solve (:469-475): residual blocks with ScaledLoss(track length) weights,
+// SubsetParameterization masks (free: focal, rvec, ray [, k1]), the Ceres 1.14 trust-region LM policy
+// (Jacobi scaling, LM diagonal clamp, step-quality radius update,
+// function/parameter/gradient tolerances), Schur elimination of the 3x3 ray blocks (row S5) and the
+// solve of the reduced camera system (ptz_chol.hip).
+//
+// Per LM pass and scene (all scenes of the batch advance in lock-step, finished scenes early-out):
+//   lm_pre      finalize the previous iteration, termination checks               [1 block / scene]
+//   ray_prep    E = (V + D^2)^-1 per ray, z = E g_r, Y_a = W_a E                   [thread / ray]
+//   cam_diag    LM diagonal of the camera blocks                                   [thread / camera]
+//   schur       S_ij = [i=j](U_i + D_i^2) - sum_{tracks seen by i and j} Y_a W_b^T [lane group / camera pair]
+//   rhs         b_i = g_i - sum_a W_a z_ray(a)  (written as row n of the padded S) [wave / camera]
+//   cholesky    S y_c = b  (ptz_chol.hip: panel + MFMA syrk per 64-wide block column, back-substitution)
+//   backsub     y_r = E (g_r - sum_a W_a^T y_c), candidate ray                     [thread / ray]
+//   cam_update  candidate camera, its rotation block                              [thread / camera]
+//   eval        model cost change -(J d)^T (r + J d / 2) and candidate cost        [thread / ray]
+//   lm_post     step validity, tolerances, rho, accept/reject, radius              [1 block / scene]
+//   (if accepted) cam_prep, lin_ray, lin_cam: re-linearise at the new point
+// Observation records are 16 B (2 x f32 pixel, i32 camera, i32 ray); a workgroup of lin_ray/eval/backsub
+// stages its scene's camera blocks (rotation, SO(3) Jacobian, intrinsics, Jacobi scales) in LDS once and
+// every thread then reads them by camera id.  All reductions are fixed-order (bitwise reproducible).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ptz_common.h"
+#include "ptz_factor.h"
+
+namespace ptz {
+
+namespace {
+
+constexpr int RAY_BLOCK = 256;  // rays per workgroup in the ray-centric kernels
+
+struct SceneDev {
+  int n_cam, n_ray, n_obs, n_pair;
+  int cam_off, ray_off, obs_off, pair_off;
+  int ent_off;   // first camera-pair entry
+  int part_off;  // first partial-sum slot (one per ray chunk)
+  int n_chunk;   // ceil(n_ray / RAY_BLOCK)
+  int n;         // NC * n_cam: order of the reduced camera system
+};
+
+struct LmState {
+  double radius, decrease_factor;
+  double x_cost, x_norm, grad_max;
+  double candidate_cost, model_cost_change;
+  double initial_cost, final_cost, it_cost;
+  int reuse_diagonal, need_linearize, cur, iteration, n_summaries, step_is_successful;
+  int num_consecutive_invalid, termination;
+  int num_successful, num_unsuccessful, num_lm_steps, num_linear_solves, num_jac_evals;
+  int pad;
+};
+
+struct Opt {  // device copy of the solver options
+  int max_num_iterations, max_consecutive_invalid, jacobi_scaling;
+  double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+};
+
+// Everything the kernels read, by value.
+struct Dev {
+  int n_scene;
+  const SceneDev* scene;
+  // observations (sorted ray-major) and structure
+  const float2* obs_uv;
+  const int* obs_cam;   // scene-local camera id
+  const int* obs_ray;   // scene-local ray id
+  const int* ray_ptr;   // [total_ray + n_scene] per scene n_ray + 1 entries, global obs index
+  const int* cam_ptr;   // [total_cam + n_scene] per scene n_cam + 1 entries into cam_obs
+  const int* cam_obs;   // global obs index, camera-major
+  const int* pair_ci;   // scene-local camera ids, ci >= cj
+  const int* pair_cj;
+  const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
+  const int2* ent;      // (obs a of ci, obs b of cj), global obs indices
+  const double* ray_w;
+  // state: two buffers, LmState.cur selects the current one
+  double* cam_x;  // [2][total_cam][15]
+  double* ray_x;  // [2][total_ray][3]
+  size_t cam_stride, ray_stride;
+  const double* cam_x0;
+  const double* ray_x0;
+  // per-camera blocks
+  double* camblk;    // [total_cam][CAMBLK]   at x
+  double* candblk;   // [total_cam][CANDBLK]  at the candidate
+  double* scale_c;   // [total_cam][NC]
+  double* scale_r;   // [total_ray][3]
+  double* U;         // [total_cam][NC*NC]
+  double* gc;        // [total_cam][NC]
+  double* costc;     // [total_cam]
+  double* diag_c;    // [total_cam][NC]
+  double* dc;        // [total_cam][NC] scaled-space camera step
+  double* V;         // [total_ray][6]
+  double* gr;        // [total_ray][3]
+  double* diag_r;    // [total_ray][3]
+  double* E;         // [total_ray][6]
+  double* z;         // [total_ray][3]
+  double* dr;        // [total_ray][3] scaled-space ray step
+  double* W;         // [total_obs][NC*3]
+  double* Y;         // [total_obs][NC*3]
+  double* partial;   // [total_chunk][2]
+  // LM
+  LmState* lm;
+  int* active;       // [n_scene]
+  int* ray_fail;     // [n_scene]
+  Opt opt;
+  // reduced camera system
+  CholBatch chol;
+  double* yc;        // [n_scene][np]
+};
+
+__device__ __forceinline__ const double* cur_cam(const Dev& d, const SceneDev& s, const LmState& st)
+{
+  return d.cam_x + (size_t)st.cur * d.cam_stride + (size_t)s.cam_off * 15;
+}
+__device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s, const LmState& st)
+{
+  return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
+}
+
+template <int TYPE> struct FreeIdx;
+template <> struct FreeIdx<0> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : 3 + k; } };            // f, r1..r3
+template <> struct FreeIdx<1> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : (k == 1 ? 10 : 2 + k); } };  // f, k1, r1..r3
+
+__device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl)
+{
+  double R[9];
+  rodrigues(c15 + 4, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cb[CB_R + i] = R[i];
+  cb[CB_F] = c15[0]; cb[CB_CX] = c15[2]; cb[CB_CY] = c15[3]; cb[CB_FY] = c15[1];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) cb[CB_K + i] = c15[10 + i];
+  if (with_jl) {
+    double Jl[9];
+    so3_left_jacobian(c15 + 4, Jl);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cb[CB_JL + i] = Jl[i];
+  }
+}
+
+// ---- cam_prep: rotation / SO(3) Jacobian / intrinsics / scales of every camera at x ------------------
+template <int TYPE>
+__global__ void k_cam_prep(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam) return;
+  double* cb = d.camblk + (size_t)(s.cam_off + i) * CAMBLK;
+  fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
+}
+
+// stage a scene's camera table into LDS (stride words per camera)
+__device__ __forceinline__ void stage_table(const double* __restrict__ src, double* dst, int count)
+{
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- lin_ray: per-ray linearisation ---------------------------------------------------------------------
+// thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
+// Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r, store W_a = Jc^T Jr.
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  stage_table(d.camblk + (size_t)s.cam_off * CAMBLK, lds, s.n_cam * CAMBLK);
+  __syncthreads();
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int gj = s.ray_off + j;
+  const double* X = cur_ray(d, s, st) + (size_t)j * 3;
+  const double Xr[3] = {X[0], X[1], X[2]};
+  const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
+  const double sw = sqrt(d.ray_w[gj]);
+  const int* rp = d.ray_ptr + s.ray_off + sc;
+  double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const float2 uv = d.obs_uv[a];
+    const double* cb = lds + d.obs_cam[a] * CAMBLK;
+    double res[2], Jc[2][NC], Jr[2][3];
+    ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    res[0] *= sw; res[1] *= sw;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k]; Jc[0][k] *= m; Jc[1][k] *= m; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+    V[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
+    V[1] += Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
+    V[2] += Jr[0][1] * Jr[0][1] + Jr[1][1] * Jr[1][1];
+    V[3] += Jr[0][2] * Jr[0][0] + Jr[1][2] * Jr[1][0];
+    V[4] += Jr[0][2] * Jr[0][1] + Jr[1][2] * Jr[1][1];
+    V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
+    double* Wa = d.W + (size_t)a * (NC * 3);
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d.gr[(size_t)gj * 3 + k] = g[k];
+}
+
+// ---- lin_cam: per-camera blocks -------------------------------------------------------------------------
+// wave = camera: lanes stride over the camera's observation list, U = sum Jc^T Jc, g_c = sum Jc^T r,
+// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly.
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lin_cam(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= s.n_cam) return;
+  const int lane = threadIdx.x & 63;
+  const int gi = s.cam_off + i;
+  double cb[CAMBLK];
+#pragma unroll
+  for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
+  const double* rays = cur_ray(d, s, st);
+  const int* cp = d.cam_ptr + s.cam_off + sc;
+  double U[NC * (NC + 1) / 2], g[NC], cost = 0;
+#pragma unroll
+  for (int k = 0; k < NC * (NC + 1) / 2; ++k) U[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) g[k] = 0;
+  for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
+    const int a = d.cam_obs[q];
+    const float2 uv = d.obs_uv[a];
+    const int j = d.obs_ray[a];
+    const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
+    double res[2], Jc[2][NC], Jr[2][3];
+    ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    const double w = d.ray_w[s.ray_off + j];
+    const double sw = sqrt(w);
+    cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
+    res[0] *= sw; res[1] *= sw;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k]; Jc[0][k] *= m; Jc[1][k] *= m; }
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      g[k] += Jc[0][k] * res[0] + Jc[1][k] * res[1];
+#pragma unroll
+      for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
+    }
+  }
+  cost = wave_sum(cost);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) g[k] = wave_sum(g[k]);
+#pragma unroll
+  for (int k = 0; k < NC * (NC + 1) / 2; ++k) U[k] = wave_sum(U[k]);
+  if (lane == 0) {
+    d.costc[gi] = cost;
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      d.gc[(size_t)gi * NC + k] = g[k];
+#pragma unroll
+      for (int l = 0; l <= k; ++l) {
+        d.U[(size_t)gi * NC * NC + k * NC + l] = U[e];
+        d.U[(size_t)gi * NC * NC + l * NC + k] = U[e];
+        ++e;
+      }
+    }
+  }
+}
+
+// ---- Jacobi scaling (Ceres: s_j = 1 / (1 + |J_:j|), computed once at iteration 0) -----------------------
+template <int TYPE>
+__global__ void k_jacobi_scale(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < s.n_cam) {
+    const int gi = s.cam_off + t;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d.scale_c[(size_t)gi * NC + k] = 1.0 / (1.0 + sqrt(d.U[(size_t)gi * NC * NC + k * NC + k]));
+  }
+  if (t < s.n_ray) {
+    const int gj = s.ray_off + t;
+    d.scale_r[(size_t)gj * 3 + 0] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 0]));
+    d.scale_r[(size_t)gj * 3 + 1] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 2]));
+    d.scale_r[(size_t)gj * 3 + 2] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 5]));
+  }
+}
+
+// ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lm_pre(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  LmState& st = d.lm[sc];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  if (st.step_is_successful) {
+    // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
+    double c = 0, gm = 0, xn = 0;
+    const double* cam = cur_cam(d, s, st);
+    const int* cp = d.cam_ptr + s.cam_off + sc;
+    for (int i = tid; i < s.n_cam; i += 256) {
+      const int gi = s.cam_off + i;
+      c += d.costc[gi];
+      for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(d.gc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
+      if (cp[i + 1] > cp[i])  // parameter blocks of cameras without residuals are not in the problem
+        for (int k = 0; k < 15; ++k) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
+    }
+    const double* ray = cur_ray(d, s, st);
+    for (int j = tid; j < s.n_ray; j += 256) {
+      const int gj = s.ray_off + j;
+      for (int k = 0; k < 3; ++k) {
+        gm = fmax(gm, fabs(d.gr[(size_t)gj * 3 + k] / d.scale_r[(size_t)gj * 3 + k]));
+        xn += ray[(size_t)j * 3 + k] * ray[(size_t)j * 3 + k];
+      }
+    }
+    // fixed-order cost: per-thread partial sums over a strided camera set, then the block tree
+    c = block_sum(c, scratch);
+    gm = block_max(gm, scratch);
+    xn = block_sum(xn, scratch);
+    if (tid == 0) {
+      st.x_cost = c;
+      st.it_cost = c;
+      st.grad_max = gm;
+      st.x_norm = sqrt(xn);
+      st.need_linearize = 0;
+      ++st.num_jac_evals;
+      if (st.n_summaries == 0) { st.initial_cost = c; st.final_cost = c; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (st.step_is_successful) ++st.num_successful; else ++st.num_unsuccessful;
+    if (st.it_cost < st.final_cost) st.final_cost = st.it_cost;
+    ++st.n_summaries;
+    if (st.iteration >= d.opt.max_num_iterations) { st.termination = PTZ_NO_CONVERGENCE; d.active[sc] = 0; }
+    else if (st.step_is_successful && st.grad_max <= d.opt.gradient_tolerance) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
+    else if (st.radius <= d.opt.min_radius) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
+    else {
+      ++st.iteration;
+      ++st.num_lm_steps;
+      st.step_is_successful = 0;
+      d.ray_fail[sc] = 0;
+    }
+  }
+}
+
+// ---- ray_prep: LevenbergMarquardtStrategy diagonal + SchurEliminator e-block inverse --------------------
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int gj = s.ray_off + j;
+  double V[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) V[k] = d.V[(size_t)gj * 6 + k];
+  double dg[3];
+  if (!st.reuse_diagonal) {
+    dg[0] = fmin(fmax(V[0], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+    dg[1] = fmin(fmax(V[2], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+    dg[2] = fmin(fmax(V[5], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.diag_r[(size_t)gj * 3 + k] = dg[k];
+  }
+  else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dg[k] = d.diag_r[(size_t)gj * 3 + k];
+  }
+  // D = sqrt(diag / radius); V + D^2
+  const double D0 = sqrt(dg[0] / st.radius), D1 = sqrt(dg[1] / st.radius), D2 = sqrt(dg[2] / st.radius);
+  V[0] += D0 * D0; V[2] += D1 * D1; V[5] += D2 * D2;
+  double E[6];
+  if (!inv3_spd(V, E)) {
+    d.ray_fail[sc] = 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d.E[(size_t)gj * 6 + k] = E[k];
+  const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
+  d.z[(size_t)gj * 3 + 0] = E[0] * g0 + E[1] * g1 + E[3] * g2;
+  d.z[(size_t)gj * 3 + 1] = E[1] * g0 + E[2] * g1 + E[4] * g2;
+  d.z[(size_t)gj * 3 + 2] = E[3] * g0 + E[4] * g1 + E[5] * g2;
+  const int* rp = d.ray_ptr + s.ray_off + sc;
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const double* Wa = d.W + (size_t)a * (NC * 3);
+    double* Ya = d.Y + (size_t)a * (NC * 3);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const double w0 = Wa[3 * k], w1 = Wa[3 * k + 1], w2 = Wa[3 * k + 2];
+      Ya[3 * k + 0] = w0 * E[0] + w1 * E[1] + w2 * E[3];
+      Ya[3 * k + 1] = w0 * E[1] + w1 * E[2] + w2 * E[4];
+      Ya[3 * k + 2] = w0 * E[3] + w1 * E[4] + w2 * E[5];
+    }
+  }
+}
+
+template <int TYPE>
+__global__ void k_cam_diag(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam || st.reuse_diagonal) return;
+  const int gi = s.cam_off + i;
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+}
+
+// ---- schur: reduced camera system blocks ------------------------------------------------------------------
+// A group of LANES lanes owns one camera pair (ci >= cj); lane (p, q) accumulates element (p, q) of
+//   S_ij = [i == j] (U_i + D_i^2) - sum_entries Y_a W_b^T
+// over the pair's entry list (a = observation of ci, b = observation of cj, same ray).
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_schur(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int LANES = (NC == 4) ? 16 : 32;
+  constexpr int PPB = 256 / LANES;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int pr = blockIdx.x * PPB + threadIdx.x / LANES;
+  if (pr >= s.n_pair) return;
+  const int l = threadIdx.x % LANES;
+  if (l >= NC * NC) return;
+  const int p = l / NC, q = l % NC;
+  const int gp = s.pair_off + pr;
+  const int ci = d.pair_ci[gp], cj = d.pair_cj[gp];
+  const int* pp = d.pair_ptr + s.pair_off + sc;
+  double acc = 0;
+  for (int e = pp[pr]; e < pp[pr + 1]; ++e) {
+    const int2 ab = d.ent[e];
+    const double* Ya = d.Y + (size_t)ab.x * (NC * 3) + 3 * p;
+    const double* Wb = d.W + (size_t)ab.y * (NC * 3) + 3 * q;
+    acc += Ya[0] * Wb[0] + Ya[1] * Wb[1] + Ya[2] * Wb[2];
+  }
+  double v = -acc;
+  if (ci == cj) {
+    const int gi = s.cam_off + ci;
+    v += d.U[(size_t)gi * NC * NC + p * NC + q];
+    if (p == q) {
+      const double D = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+      v += D * D;
+    }
+  }
+  const int np = d.chol.np;
+  d.chol.A[(size_t)sc * np * np + (size_t)(ci * NC + p) * np + cj * NC + q] = v;
+}
+
+// ---- rhs: b_i = g_i - sum_a W_a z_ray(a), stored as row n of the padded system ---------------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_rhs(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= s.n_cam) return;
+  const int lane = threadIdx.x & 63;
+  const int* cp = d.cam_ptr + s.cam_off + sc;
+  double b[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) b[k] = 0;
+  for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
+    const int a = d.cam_obs[q];
+    const int gj = s.ray_off + d.obs_ray[a];
+    const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
+    const double* Wa = d.W + (size_t)a * (NC * 3);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) b[k] += Wa[3 * k] * z0 + Wa[3 * k + 1] * z1 + Wa[3 * k + 2] * z2;
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) b[k] = wave_sum(b[k]);
+  if (lane == 0) {
+    const int np = d.chol.np;
+    double* row = d.chol.A + (size_t)sc * np * np + (size_t)s.n * np;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) row[i * NC + k] = d.gc[(size_t)(s.cam_off + i) * NC + k] - b[k];
+  }
+}
+
+// ---- backsub: SchurEliminator::BackSubstitute + candidate ray --------------------------------------------
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_backsub(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (blockIdx.x >= s.n_chunk) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // y_c of the scene
+  stage_table(d.yc + (size_t)sc * d.chol.np, lds, s.n);
+  __syncthreads();
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int gj = s.ray_off + j;
+  double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
+  const int* rp = d.ray_ptr + s.ray_off + sc;
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const double* Wa = d.W + (size_t)a * (NC * 3);
+    const double* y = lds + d.obs_cam[a] * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { t0 -= Wa[3 * k] * y[k]; t1 -= Wa[3 * k + 1] * y[k]; t2 -= Wa[3 * k + 2] * y[k]; }
+  }
+  const double* E = d.E + (size_t)gj * 6;
+  // step = -y (Ceres solves J y = r and negates)
+  const double s0 = -(E[0] * t0 + E[1] * t1 + E[3] * t2);
+  const double s1 = -(E[1] * t0 + E[2] * t1 + E[4] * t2);
+  const double s2 = -(E[3] * t0 + E[4] * t1 + E[5] * t2);
+  d.dr[(size_t)gj * 3] = s0; d.dr[(size_t)gj * 3 + 1] = s1; d.dr[(size_t)gj * 3 + 2] = s2;
+  const double* x = cur_ray(d, s, st) + (size_t)j * 3;
+  double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
+  xc[0] = x[0] + s0 * d.scale_r[(size_t)gj * 3];
+  xc[1] = x[1] + s1 * d.scale_r[(size_t)gj * 3 + 1];
+  xc[2] = x[2] + s2 * d.scale_r[(size_t)gj * 3 + 2];
+}
+
+// ---- cam_update: candidate cameras and their residual-side blocks ----------------------------------------
+template <int TYPE>
+__global__ void k_cam_update(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam) return;
+  const int gi = s.cam_off + i;
+  const double* x = cur_cam(d, s, st) + (size_t)i * 15;
+  double c15[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) c15[k] = x[k];
+  const double* y = d.yc + (size_t)sc * d.chol.np + (size_t)i * NC;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double step = -y[k];
+    d.dc[(size_t)gi * NC + k] = step;
+    c15[FreeIdx<TYPE>::at(k)] += step * d.scale_c[(size_t)gi * NC + k];
+  }
+  double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) xc[k] = c15[k];
+  double cb[CANDBLK];
+  fill_camblk(c15, cb, false);
+#pragma unroll
+  for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CANDBLK + k] = cb[k];
+}
+
+// ---- eval: model cost change and candidate cost -------------------------------------------------------------
+//   model_cost_change = -(J d)^T (r + J d / 2)   (TrustRegionMinimizer::ComputeTrustRegionStep)
+//   candidate_cost    = 1/2 sum w |r(x + delta)|^2
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (blockIdx.x >= s.n_chunk) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tab = lds;                         // [n_cam][CAMBLK]
+  double* ctab = tab + s.n_cam * CAMBLK;     // [n_cam][CANDBLK]
+  double* dct = ctab + s.n_cam * CANDBLK;    // [n_cam][NC] scaled camera step
+  double* scratch = dct + s.n_cam * NC;      // [16]
+  stage_table(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam * CAMBLK);
+  stage_table(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam * CANDBLK);
+  stage_table(d.dc + (size_t)s.cam_off * NC, dct, s.n_cam * NC);
+  __syncthreads();
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  double mcc = 0, cost = 0;
+  if (j < s.n_ray) {
+    const int gj = s.ray_off + j;
+    const double* X = cur_ray(d, s, st) + (size_t)j * 3;
+    const double* Xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
+    const double Xr[3] = {X[0], X[1], X[2]}, Xn[3] = {Xc[0], Xc[1], Xc[2]};
+    const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
+    const double ds[3] = {d.dr[(size_t)gj * 3], d.dr[(size_t)gj * 3 + 1], d.dr[(size_t)gj * 3 + 2]};
+    const double w = d.ray_w[gj];
+    const double sw = sqrt(w);
+    const int* rp = d.ray_ptr + s.ray_off + sc;
+    for (int a = rp[j]; a < rp[j + 1]; ++a) {
+      const float2 uv = d.obs_uv[a];
+      const int ci = d.obs_cam[a];
+      const double* cb = tab + ci * CAMBLK;
+      double res[2], Jc[2][NC], Jr[2][3];
+      ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      double m0 = 0, m1 = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * NC + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k] * ds[k]; m0 += Jr[0][k] * m; m1 += Jr[1][k] * m; }
+      mcc += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
+      double rc[2];
+      ba_residual<TYPE>(ctab + ci * CANDBLK, Xn, uv.x, uv.y, rc);
+      cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
+    }
+  }
+  mcc = block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  if (threadIdx.x == 0) {
+    d.partial[(size_t)(s.part_off + blockIdx.x) * 2] = mcc;
+    d.partial[(size_t)(s.part_off + blockIdx.x) * 2 + 1] = cost;
+  }
+}
+
+// ---- lm_post: the body of TrustRegionMinimizer::Minimize after the step has been computed --------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lm_post(Dev d)
+{
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  LmState& st = d.lm[sc];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  // chunk partials in chunk order (thread-strided, then the fixed block tree)
+  double mcc = 0, cost = 0;
+  for (int c = tid; c < s.n_chunk; c += 256) {
+    mcc += d.partial[(size_t)(s.part_off + c) * 2];
+    cost += d.partial[(size_t)(s.part_off + c) * 2 + 1];
+  }
+  mcc = -block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  // |x - x_candidate| and |x_candidate| over the parameter blocks that are in the problem
+  const double* cam = cur_cam(d, s, st);
+  const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
+  const double* ray = cur_ray(d, s, st);
+  const double* rayc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)s.ray_off * 3;
+  const int* cp = d.cam_ptr + s.cam_off + sc;
+  double dn = 0, cn = 0;
+  for (int i = tid; i < s.n_cam; i += 256) {
+    if (cp[i + 1] <= cp[i]) continue;
+    for (int k = 0; k < 15; ++k) {
+      const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
+      dn += (a - b) * (a - b);
+      cn += b * b;
+    }
+  }
+  for (int j = tid; j < s.n_ray * 3; j += 256) {
+    const double a = ray[j], b = rayc[j];
+    dn += (a - b) * (a - b);
+    cn += b * b;
+  }
+  dn = block_sum(dn, scratch);
+  cn = block_sum(cn, scratch);
+  if (tid != 0) return;
+  const Opt& o = d.opt;
+  ++st.num_linear_solves;
+  st.reuse_diagonal = 1;  // LevenbergMarquardtStrategy::ComputeStep
+  const bool solve_fail = d.ray_fail[sc] || d.chol.fail[sc];
+  const bool valid = !solve_fail && isfinite(mcc) && isfinite(dn) && mcc > 0.0;
+  st.model_cost_change = mcc;
+  st.it_cost = st.x_cost;
+  if (!valid) {  // HandleInvalidStep
+    ++st.num_consecutive_invalid;
+    if (st.num_consecutive_invalid >= o.max_consecutive_invalid) { st.termination = PTZ_FAILURE; d.active[sc] = 0; return; }
+    st.radius *= 0.5;  // StepIsInvalid
+    st.reuse_diagonal = 0;
+    return;
+  }
+  st.num_consecutive_invalid = 0;
+  if (!isfinite(cost)) cost = 1.7976931348623157e308;
+  st.candidate_cost = cost;
+  // ParameterToleranceReached
+  if (sqrt(dn) <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  // FunctionToleranceReached
+  const double cost_change = st.x_cost - cost;
+  if (fabs(cost_change) <= o.function_tolerance * st.x_cost) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  const double rho = cost_change / mcc;  // TrustRegionStepEvaluator::StepQuality, monotonic steps
+  if (rho > o.min_relative_decrease) {
+    // HandleSuccessfulStep: x <- candidate; the Jacobian is re-evaluated by the kernels that follow
+    st.cur ^= 1;
+    st.need_linearize = 1;
+    st.step_is_successful = 1;
+    const double t = 2.0 * rho - 1.0;
+    st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);  // StepAccepted
+    st.radius = fmin(o.max_radius, st.radius);
+    st.decrease_factor = 2.0;
+    st.reuse_diagonal = 0;
+  }
+  else {
+    // HandleUnsuccessfulStep / StepRejected
+    st.it_cost = cost;
+    st.radius = st.radius / st.decrease_factor;
+    st.decrease_factor *= 2.0;
+    st.reuse_diagonal = 1;
+  }
+}
+
+// ---- reset / init -----------------------------------------------------------------------------------------
+__global__ void k_reset(Dev d)
+{
+  const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= d.n_scene) return;
+  LmState st;
+  memset(&st, 0, sizeof(st));
+  st.radius = d.opt.initial_radius;
+  st.decrease_factor = 2.0;
+  st.need_linearize = 1;
+  st.step_is_successful = 1;
+  st.termination = PTZ_NO_CONVERGENCE;
+  d.lm[sc] = st;
+  d.active[sc] = 1;
+  d.ray_fail[sc] = 0;
+}
+__global__ void k_fill(double* p, size_t n, double v)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Pix2Ray (ptzray_optimizer.cc:768-797): ray = normalise(mean_i normalise(R_i^-1 K_i^-1 [u, v, 1]))
+__global__ __launch_bounds__(RAY_BLOCK) void k_pix2ray(Dev d, double* cam0, double* ray0)
+{
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int* rp = d.ray_ptr + s.ray_off + sc;
+  double acc[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const double* c = cam0 + (size_t)(s.cam_off + d.obs_cam[a]) * 15;
+    double R[9];
+    rodrigues(c + 4, R);
+    const float2 uv = d.obs_uv[a];
+    const double q0 = ((double)uv.x - c[2]) / c[0], q1 = ((double)uv.y - c[3]) / c[1];
+    // R^-1 = R^T for a rotation (the reference inverts numerically; identical to round-off)
+    double t0 = R[0] * q0 + R[3] * q1 + R[6], t1 = R[1] * q0 + R[4] * q1 + R[7], t2 = R[2] * q0 + R[5] * q1 + R[8];
+    const double n = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+    acc[0] += t0 / n; acc[1] += t1 / n; acc[2] += t2 / n;
+    ++cnt;
+  }
+  acc[0] /= cnt; acc[1] /= cnt; acc[2] /= cnt;
+  const double n = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+  double* out = ray0 + (size_t)(s.ray_off + j) * 3;
+  out[0] = acc[0] / n; out[1] = acc[1] / n; out[2] = acc[2] / n;
+}
+
+}  // namespace
+
+// =============================================================================================================
+// host side
+// =============================================================================================================
+enum ProfSlot { P_LIN = 0, P_LMCTL, P_RAYPREP, P_CLEAR, P_SCHUR, P_RHS, P_CHOL_PANEL, P_CHOL_SYRK, P_CHOL_BACK,
+                P_BACKSUB, P_EVAL, P_SYNC, P_NSLOT };
+static const char* kSlotNames[PTZ_PROF_SLOTS] = {"linearize", "lm_control", "ray_prep", "clear", "schur", "rhs",
+                                                 "chol_panel", "chol_syrk", "chol_backsolve", "backsub", "eval",
+                                                 "host_sync", "", "", "", ""};
+
+}  // namespace ptz
+
+using namespace ptz;
+
+// chol_factor_solve split so that the three kernel families can be timed separately
+namespace ptz {
+void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof);
+}
+
+struct ptz_ba_batch {
+  int n_scene = 0, type = 0, nc = 4, device = 0;
+  std::vector<SceneDev> scenes;
+  int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;
+  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0;
+  ptz_lm_options opt;
+  Dev d;
+  std::vector<void*> allocs;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int* h_active = nullptr;  // pinned
+  double *cam0 = nullptr, *ray0 = nullptr;  // device copies of the initial state
+  bool has_state = false;
+  double last_ms = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_used;  // (slot, event index of the start; stop = +1)
+  double prof_ms[PTZ_PROF_SLOTS] = {0};
+  int64_t prof_n[PTZ_PROF_SLOTS] = {0};
+
+  template <typename T> int alloc(T** p, size_t count)
+  {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return PTZ_ENOMEM;
+    allocs.push_back(q);
+    *p = (T*)q;
+    return PTZ_OK;
+  }
+  void prof_begin(int slot)
+  {
+    if (!profiling) return;
+    if (ev_used.size() * 2 + 2 > ev_pool.size()) {
+      for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+    }
+    const int idx = (int)ev_used.size() * 2;
+    ev_used.push_back({slot, idx});
+    (void)hipEventRecord(ev_pool[idx], stream);
+  }
+  void prof_end()
+  {
+    if (!profiling) return;
+    (void)hipEventRecord(ev_pool[ev_used.back().second + 1], stream);
+  }
+  void prof_collect()
+  {
+    for (auto& u : ev_used) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev_pool[u.second], ev_pool[u.second + 1]) == hipSuccess) {
+        prof_ms[u.first] += ms;
+        prof_n[u.first] += 1;
+      }
+    }
+    ev_used.clear();
+  }
+};
+
+namespace {
+
+template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
+{
+  T* p = nullptr;
+  int rc = b->alloc(&p, h.size());
+  if (rc) return rc;
+  if (!h.empty() && hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
+  *dev = p;
+  return PTZ_OK;
+}
+
+#define LAUNCH(kern, grid, block, smem, ...) hipLaunchKernelGGL(kern, grid, block, smem, b->stream, __VA_ARGS__)
+
+template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
+{
+  const Dev& d = b->d;
+  b->prof_begin(P_LIN);
+  LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
+  LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CAMBLK, d);
+  LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
+  b->prof_end();
+}
+
+template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const Dev& d = b->d;
+  const int B = b->n_scene;
+  hipStream_t st = b->stream;
+  PTZ_HIP_TRY(hipEventRecord(b->ev0, st));
+  // x <- initial state, scales <- 1, LM state reset
+  PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, st));
+  LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
+  LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
+  LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
+  // IterationZero: evaluate, Jacobi scales from the column norms, re-evaluate scaled
+  enqueue_linearize<TYPE>(b);
+  if (b->opt.jacobi_scaling) {
+    LAUNCH(k_jacobi_scale<TYPE>, dim3((std::max(b->max_cam, b->max_ray) + 255) / 256, B), dim3(256), 0, d);
+    enqueue_linearize<TYPE>(b);
+  }
+  const int max_it = b->opt.max_num_iterations;
+  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16);
+  for (int pass = 0; pass <= max_it; ++pass) {
+    b->prof_begin(P_LMCTL);
+    LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
+    b->prof_end();
+    if (pass == max_it) break;
+    b->prof_begin(P_RAYPREP);
+    LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), 0, d);
+    LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+    b->prof_end();
+    b->prof_begin(P_CLEAR);
+    chol_clear(d.chol, st);
+    b->prof_end();
+    b->prof_begin(P_SCHUR);
+    LAUNCH(k_schur<TYPE>, dim3((b->max_pair + (NC == 4 ? 16 : 8) - 1) / (NC == 4 ? 16 : 8), B), dim3(256), 0, d);
+    b->prof_end();
+    b->prof_begin(P_RHS);
+    LAUNCH(k_rhs<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, d);
+    b->prof_end();
+    chol_factor_solve_profiled(d.chol, d.yc, st, b);
+    b->prof_begin(P_BACKSUB);
+    LAUNCH(k_backsub<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_n, d);
+    LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+    b->prof_end();
+    b->prof_begin(P_EVAL);
+    LAUNCH(k_eval<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), eval_smem, d);
+    b->prof_end();
+    b->prof_begin(P_LMCTL);
+    LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(256), 0, d);
+    b->prof_end();
+    enqueue_linearize<TYPE>(b);
+    // any scene still running?
+    b->prof_begin(P_SYNC);
+    PTZ_HIP_TRY(hipMemcpyAsync(b->h_active, d.active, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    b->prof_end();
+    PTZ_HIP_TRY(hipStreamSynchronize(st));
+    bool any = false;
+    for (int i = 0; i < B; ++i) any |= (b->h_active[i] != 0);
+    if (!any) break;
+  }
+  PTZ_HIP_TRY(hipEventRecord(b->ev1, st));
+  PTZ_HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
+  b->last_ms = ms;
+  b->prof_collect();
+  if (out) {
+    std::vector<LmState> h(B);
+    PTZ_HIP_TRY(hipMemcpy(h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B; ++i) {
+      ptz_lm_summary& s = out[i];
+      s.termination_type = h[i].termination;
+      s.num_iterations = h[i].n_summaries - 1;
+      s.num_lm_steps = h[i].num_lm_steps;
+      s.num_successful_steps = h[i].num_successful;
+      s.num_unsuccessful_steps = h[i].num_unsuccessful;
+      s.num_residuals = 2 * b->scenes[i].n_obs;
+      s.num_linear_solves = h[i].num_linear_solves;
+      s.num_jacobian_evals = h[i].num_jac_evals;
+      s.initial_cost = h[i].initial_cost;
+      s.final_cost = h[i].final_cost;
+      s.final_radius = h[i].radius;
+      s.final_gradient_max_norm = h[i].grad_max;
+    }
+  }
+  return PTZ_OK;
+}
+
+}  // namespace
+
+namespace ptz {
+// defined here (needs ptz_ba_batch) but uses the kernels of ptz_chol.hip through chol_factor_solve pieces
+void chol_panel_launch(const CholBatch& cb, int k, hipStream_t s);
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t s);
+void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t s);
+void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof)
+{
+  ptz_ba_batch* b = (ptz_ba_batch*)prof;
+  const int nt = cb.np / CHOL_NB;
+  for (int k = 0; k < nt; ++k) {
+    b->prof_begin(P_CHOL_PANEL);
+    chol_panel_launch(cb, k, stream);
+    b->prof_end();
+    if (nt - k - 1 > 0) {
+      b->prof_begin(P_CHOL_SYRK);
+      chol_syrk_launch(cb, k, stream);
+      b->prof_end();
+    }
+  }
+  b->prof_begin(P_CHOL_BACK);
+  chol_backsolve_launch(cb, x, stream);
+  b->prof_end();
+}
+}  // namespace ptz
+
+// =============================================================================================================
+// C-ABI
+// =============================================================================================================
+extern "C" {
+
+void ptz_lm_options_default(ptz_lm_options* o)
+{
+  memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 200;
+  o->device_id = 0;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+}
+
+const char* ptz_version(void) { return "ptz-calib_amd 0.1 (gfx950)"; }
+
+int32_t ptz_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t ptz_ba_cam_block_dim(int32_t factor_type)
+{
+  if (factor_type == PTZ_BA_PTZRay) return 4;
+  if (factor_type == PTZ_BA_PTZRayDist) return 5;
+  return PTZ_EUNSUPPORTED;
+}
+
+void ptz_ba_batch_destroy(ptz_ba_batch* b)
+{
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* p : b->allocs) (void)hipFree(p);
+  for (auto e : b->ev_pool) (void)hipEventDestroy(e);
+  if (b->h_active) (void)hipHostFree(b->h_active);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz_lm_options* opt, ptz_ba_batch** out)
+{
+  if (n <= 0 || !problems || !out) return PTZ_EINVAL;
+  *out = nullptr;
+  ptz_lm_options o;
+  if (opt) o = *opt; else ptz_lm_options_default(&o);
+  if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
+  const int type = problems[0].factor_type;
+  if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist) return PTZ_EUNSUPPORTED;
+  const int NC = (type == PTZ_BA_PTZRay) ? 4 : 5;
+  // ---- validate + sizes (host only; no device touched before this passes)
+  for (int i = 0; i < n; ++i) {
+    const ptz_ba_problem& p = problems[i];
+    if (p.factor_type != type) return PTZ_EINVAL;
+    if (p.n_cam <= 0 || p.n_ray <= 0 || p.n_obs <= 0) return PTZ_EINVAL;  // num_cams_ == 0 -> false (:517)
+    if (!p.obs_uv || !p.obs_cam || !p.obs_ray || !p.ray_weight) return PTZ_EINVAL;
+    if (p.n_obs3d != 0) return PTZ_EUNSUPPORTED;  // georeferencing residuals: not on the device path yet
+    for (int64_t a = 0; a < p.n_obs; ++a) {
+      if (p.obs_cam[a] < 0 || p.obs_cam[a] >= p.n_cam || p.obs_ray[a] < 0 || p.obs_ray[a] >= p.n_ray) return PTZ_EINVAL;
+      if (a > 0 && p.obs_ray[a] < p.obs_ray[a - 1]) return PTZ_EINVAL;
+    }
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
+  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+
+  ptz_ba_batch* b = new ptz_ba_batch();
+  b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
+  std::vector<float2> h_uv;
+  std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr;
+  std::vector<int2> h_ent;
+  std::vector<double> h_w;
+  int64_t tot_obs = 0, tot_ent = 0;
+  for (int i = 0; i < n; ++i) {
+    tot_obs += problems[i].n_obs;
+  }
+  if (tot_obs > 0x7fffffff) { delete b; return PTZ_EINVAL; }
+  h_uv.reserve(tot_obs); h_cam.reserve(tot_obs); h_ray.reserve(tot_obs); h_camobs.reserve(tot_obs);
+  for (int i = 0; i < n; ++i) {
+    const ptz_ba_problem& p = problems[i];
+    SceneDev s;
+    s.n_cam = p.n_cam; s.n_ray = p.n_ray; s.n_obs = (int)p.n_obs;
+    s.cam_off = b->total_cam; s.ray_off = b->total_ray; s.obs_off = b->total_obs;
+    s.pair_off = b->total_pair; s.ent_off = b->total_ent; s.part_off = b->total_chunk;
+    s.n_chunk = (p.n_ray + RAY_BLOCK - 1) / RAY_BLOCK;
+    s.n = NC * p.n_cam;
+    // observations, ray ranges
+    const int obase = s.obs_off;
+    std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
+    for (int64_t a = 0; a < p.n_obs; ++a) {
+      h_uv.push_back(make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]));
+      h_cam.push_back(p.obs_cam[a]);
+      h_ray.push_back(p.obs_ray[a]);
+      ++cnt_ray[p.obs_ray[a] + 1];
+      ++cnt_cam[p.obs_cam[a] + 1];
+    }
+    for (int j = 0; j < p.n_ray; ++j) {
+      if (cnt_ray[j + 1] == 0) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // every ray has >= 1 observation
+      cnt_ray[j + 1] += cnt_ray[j];
+    }
+    for (int j = 0; j <= p.n_ray; ++j) h_rayptr.push_back(obase + cnt_ray[j]);
+    for (int j = 0; j < p.n_ray; ++j) h_w.push_back(p.ray_weight[j]);
+    // camera-major observation lists
+    for (int c = 0; c < p.n_cam; ++c) cnt_cam[c + 1] += cnt_cam[c];
+    {
+      std::vector<int> fill(cnt_cam.begin(), cnt_cam.end() - 1);
+      const size_t base = h_camobs.size();
+      h_camobs.resize(base + p.n_obs);
+      for (int64_t a = 0; a < p.n_obs; ++a) h_camobs[base + fill[p.obs_cam[a]]++] = obase + (int)a;
+      for (int c = 0; c <= p.n_cam; ++c) h_camptr.push_back(obase + cnt_cam[c]);
+    }
+    // camera-pair entry lists: for every ray, every (a, b) with cam(a) >= cam(b)
+    {
+      std::vector<int64_t> keys;  // (ci * n_cam + cj) << 32 | running index
+      std::vector<int2> ents;
+      for (int j = 0; j < p.n_ray; ++j) {
+        for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
+          for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
+            const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
+            if (ci < cj) continue;
+            if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
+            keys.push_back(((int64_t)ci * p.n_cam + cj) << 32 | (int64_t)ents.size());
+            ents.push_back(make_int2(obase + a, obase + bb));
+          }
+      }
+      std::sort(keys.begin(), keys.end());
+      if ((int64_t)b->total_ent + (int64_t)ents.size() > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+      int64_t prev = -1;
+      int npair = 0;
+      for (size_t e = 0; e < keys.size(); ++e) {
+        const int64_t key = keys[e] >> 32;
+        if (key != prev) {
+          h_pci.push_back((int)(key / p.n_cam));
+          h_pcj.push_back((int)(key % p.n_cam));
+          h_pptr.push_back(b->total_ent + (int)e);
+          prev = key;
+          ++npair;
+        }
+        h_ent.push_back(ents[keys[e] & 0xffffffff]);
+      }
+      h_pptr.push_back(b->total_ent + (int)keys.size());
+      s.n_pair = npair;
+      b->total_ent += (int)keys.size();
+      b->total_pair += npair;
+    }
+    b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk;
+    b->max_cam = std::max(b->max_cam, p.n_cam); b->max_ray = std::max(b->max_ray, p.n_ray);
+    b->max_chunk = std::max(b->max_chunk, s.n_chunk); b->max_pair = std::max(b->max_pair, s.n_pair);
+    b->max_n = std::max(b->max_n, s.n);
+    b->scenes.push_back(s);
+  }
+  (void)tot_ent;
+  // LDS budget of the eval kernel bounds the camera count of a scene (160 KiB per workgroup)
+  if (sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16) > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
+
+  Dev& d = b->d;
+  memset(&d, 0, sizeof(d));
+  d.n_scene = n;
+  int rc = PTZ_OK;
+#define TRY(x) do { rc = (x); if (rc) { ptz_ba_batch_destroy(b); return rc; } } while (0)
+  TRY(upload(b, b->scenes, &d.scene));
+  TRY(upload(b, h_uv, &d.obs_uv));
+  TRY(upload(b, h_cam, &d.obs_cam));
+  TRY(upload(b, h_ray, &d.obs_ray));
+  TRY(upload(b, h_rayptr, &d.ray_ptr));
+  TRY(upload(b, h_camptr, &d.cam_ptr));
+  TRY(upload(b, h_camobs, &d.cam_obs));
+  TRY(upload(b, h_pci, &d.pair_ci));
+  TRY(upload(b, h_pcj, &d.pair_cj));
+  TRY(upload(b, h_pptr, &d.pair_ptr));
+  TRY(upload(b, h_ent, &d.ent));
+  TRY(upload(b, h_w, &d.ray_w));
+  d.cam_stride = (size_t)b->total_cam * 15;
+  d.ray_stride = (size_t)b->total_ray * 3;
+  TRY(b->alloc(&d.cam_x, 2 * d.cam_stride));
+  TRY(b->alloc(&d.ray_x, 2 * d.ray_stride));
+  TRY(b->alloc(&b->cam0, d.cam_stride));
+  TRY(b->alloc(&b->ray0, d.ray_stride));
+  TRY(b->alloc(&d.camblk, (size_t)b->total_cam * CAMBLK));
+  TRY(b->alloc(&d.candblk, (size_t)b->total_cam * CANDBLK));
+  TRY(b->alloc(&d.scale_c, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.scale_r, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.U, (size_t)b->total_cam * NC * NC));
+  TRY(b->alloc(&d.gc, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.costc, (size_t)b->total_cam));
+  TRY(b->alloc(&d.diag_c, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.dc, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.V, (size_t)b->total_ray * 6));
+  TRY(b->alloc(&d.gr, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
+  TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.dr, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.W, (size_t)b->total_obs * NC * 3));
+  TRY(b->alloc(&d.Y, (size_t)b->total_obs * NC * 3));
+  TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
+  TRY(b->alloc(&d.lm, (size_t)n));
+  TRY(b->alloc(&d.active, (size_t)n));
+  TRY(b->alloc(&d.ray_fail, (size_t)n));
+  // reduced camera systems
+  d.chol.count = n;
+  d.chol.np = chol_padded_order(b->max_n);
+  {
+    std::vector<int> hn(n);
+    for (int i = 0; i < n; ++i) hn[i] = b->scenes[i].n;
+    const int* dn = nullptr;
+    TRY(upload(b, hn, &dn));
+    d.chol.n = dn;
+  }
+  TRY(b->alloc(&d.chol.A, (size_t)n * d.chol.np * d.chol.np));
+  TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
+  TRY(b->alloc(&d.chol.fail, (size_t)n));
+  d.chol.active = d.active;
+  TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));
+#undef TRY
+  d.cam_x0 = b->cam0; d.ray_x0 = b->ray0;
+  d.opt.max_num_iterations = o.max_num_iterations;
+  d.opt.max_consecutive_invalid = o.max_num_consecutive_invalid_steps;
+  d.opt.jacobi_scaling = o.jacobi_scaling;
+  d.opt.initial_radius = o.initial_trust_region_radius;
+  d.opt.max_radius = o.max_trust_region_radius;
+  d.opt.min_radius = o.min_trust_region_radius;
+  d.opt.min_relative_decrease = o.min_relative_decrease;
+  d.opt.min_lm_diagonal = o.min_lm_diagonal;
+  d.opt.max_lm_diagonal = o.max_lm_diagonal;
+  d.opt.function_tolerance = o.function_tolerance;
+  d.opt.gradient_tolerance = o.gradient_tolerance;
+  d.opt.parameter_tolerance = o.parameter_tolerance;
+  if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
+      hipEventCreate(&b->ev1) != hipSuccess || hipHostMalloc((void**)&b->h_active, sizeof(int) * n) != hipSuccess) {
+    ptz_ba_batch_destroy(b);
+    return PTZ_ENODEVICE;
+  }
+  // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
+  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16));
+  const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CAMBLK);
+  if (type == PTZ_BA_PTZRay) {
+    (void)hipFuncSetAttribute((const void*)k_eval<0>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
+    (void)hipFuncSetAttribute((const void*)k_lin_ray<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
+  }
+  else {
+    (void)hipFuncSetAttribute((const void*)k_eval<1>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
+    (void)hipFuncSetAttribute((const void*)k_lin_ray<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
+  }
+  *out = b;
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double* ray, const double* tlw)
+{
+  (void)tlw;
+  if (!b || !cam || !ray) return PTZ_EINVAL;
+  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_HIP_TRY(hipMemcpy(b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(hipMemcpy(b->ray0, ray, sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
+  b->has_state = true;
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
+{
+  if (!b || !b->has_state) return PTZ_EINVAL;
+  PTZ_HIP_TRY(hipSetDevice(b->device));
+  return b->type == PTZ_BA_PTZRay ? solve_impl<0>(b, summaries) : solve_impl<1>(b, summaries);
+}
+
+int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw)
+{
+  if (!b) return PTZ_EINVAL;
+  PTZ_HIP_TRY(hipSetDevice(b->device));
+  std::vector<LmState> h(b->n_scene);
+  PTZ_HIP_TRY(hipMemcpy(h.data(), b->d.lm, sizeof(LmState) * b->n_scene, hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->n_scene; ++i) {
+    const SceneDev& s = b->scenes[i];
+    const int cur = h[i].cur;
+    if (cam) PTZ_HIP_TRY(hipMemcpy(cam + (size_t)s.cam_off * 15, b->d.cam_x + cur * b->d.cam_stride + (size_t)s.cam_off * 15,
+                                   sizeof(double) * 15 * s.n_cam, hipMemcpyDeviceToHost));
+    if (ray) PTZ_HIP_TRY(hipMemcpy(ray + (size_t)s.ray_off * 3, b->d.ray_x + cur * b->d.ray_stride + (size_t)s.ray_off * 3,
+                                   sizeof(double) * 3 * s.n_ray, hipMemcpyDeviceToHost));
+  }
+  if (tlw) memset(tlw, 0, sizeof(double) * 6 * b->n_scene);
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_last_solve_ms(const ptz_ba_batch* b, double* ms)
+{
+  if (!b || !ms) return PTZ_EINVAL;
+  *ms = b->last_ms;
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_set_profiling(ptz_ba_batch* b, int32_t enable)
+{
+  if (!b) return PTZ_EINVAL;
+  b->profiling = enable != 0;
+  for (int i = 0; i < PTZ_PROF_SLOTS; ++i) { b->prof_ms[i] = 0; b->prof_n[i] = 0; }
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_get_profile(const ptz_ba_batch* b, double* ms_per_slot, int64_t* launches_per_slot, const char** slot_names)
+{
+  if (!b) return PTZ_EINVAL;
+  for (int i = 0; i < PTZ_PROF_SLOTS; ++i) {
+    if (ms_per_slot) ms_per_slot[i] = b->prof_ms[i];
+    if (launches_per_slot) launches_per_slot[i] = b->prof_n[i];
+    if (slot_names) slot_names[i] = kSlotNames[i];
+  }
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
+{
+  if (!b || !b->has_state) return PTZ_EINVAL;
+  PTZ_HIP_TRY(hipSetDevice(b->device));
+  hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), 0, b->stream, b->d, b->cam0, b->ray0);
+  PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, double* g_c, double* U, double* g_r, double* V, double* W)
+{
+  if (!b || !b->has_state || index < 0 || index >= b->n_scene) return PTZ_EINVAL;
+  PTZ_HIP_TRY(hipSetDevice(b->device));
+  const Dev& d = b->d;
+  const int NC = b->nc;
+  hipStream_t st = b->stream;
+  PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_reset, dim3((b->n_scene + 63) / 64), dim3(64), 0, st, d);
+  hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, st, d.scale_c, (size_t)b->total_cam * NC, 1.0);
+  hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, st, d.scale_r, (size_t)b->total_ray * 3, 1.0);
+  if (b->type == PTZ_BA_PTZRay) enqueue_linearize<0>(b); else enqueue_linearize<1>(b);
+  PTZ_HIP_TRY(hipStreamSynchronize(st));
+  const SceneDev& s = b->scenes[index];
+  if (cost) {
+    std::vector<double> c(s.n_cam);
+    PTZ_HIP_TRY(hipMemcpy(c.data(), d.costc + s.cam_off, sizeof(double) * s.n_cam, hipMemcpyDeviceToHost));
+    double t = 0;
+    for (double v : c) t += v;
+    *cost = t;
+  }
+  if (g_c) PTZ_HIP_TRY(hipMemcpy(g_c, d.gc + (size_t)s.cam_off * NC, sizeof(double) * NC * s.n_cam, hipMemcpyDeviceToHost));
+  if (U) PTZ_HIP_TRY(hipMemcpy(U, d.U + (size_t)s.cam_off * NC * NC, sizeof(double) * NC * NC * s.n_cam, hipMemcpyDeviceToHost));
+  if (g_r) PTZ_HIP_TRY(hipMemcpy(g_r, d.gr + (size_t)s.ray_off * 3, sizeof(double) * 3 * s.n_ray, hipMemcpyDeviceToHost));
+  if (V) {
+    std::vector<double> v6((size_t)s.n_ray * 6);
+    PTZ_HIP_TRY(hipMemcpy(v6.data(), d.V + (size_t)s.ray_off * 6, sizeof(double) * 6 * s.n_ray, hipMemcpyDeviceToHost));
+    for (int j = 0; j < s.n_ray; ++j) {
+      const double* p = &v6[(size_t)j * 6];
+      double* q = V + (size_t)j * 9;
+      q[0] = p[0]; q[1] = p[1]; q[2] = p[3]; q[3] = p[1]; q[4] = p[2]; q[5] = p[4]; q[6] = p[3]; q[7] = p[4]; q[8] = p[5];
+    }
+  }
+  if (W) PTZ_HIP_TRY(hipMemcpy(W, d.W + (size_t)s.obs_off * NC * 3, sizeof(double) * NC * 3 * s.n_obs, hipMemcpyDeviceToHost));
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary)
+{
+  if (!p || !cam || !ray) return PTZ_EINVAL;
+  ptz_ba_batch* b = nullptr;
+  int rc = ptz_ba_batch_create(1, p, opt, &b);
+  if (rc) return rc;
+  rc = ptz_ba_batch_set_state(b, cam, ray, tlw);
+  if (!rc) rc = ptz_ba_batch_solve(b, summary);
+  if (!rc) rc = ptz_ba_batch_get_state(b, cam, ray, nullptr);
+  ptz_ba_batch_destroy(b);
+  return rc;
+}
+
+}  // extern "C"

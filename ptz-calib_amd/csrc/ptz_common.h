@@ -1,0 +1,91 @@
+// ptz_common.h -- shared host/device helpers for the HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ptz_calib_amd.h"
+
+namespace ptz {
+
+#define PTZ_HIP_TRY(expr)                                                                      \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      fprintf(stderr, "[ptzcalib] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e), __FILE__, \
+              __LINE__, #expr);                                                                \
+      return (_e == hipErrorOutOfMemory) ? PTZ_ENOMEM : PTZ_ENODEVICE;                         \
+    }                                                                                          \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- deterministic reductions ----------------------------------------------------------------------
+// Butterfly over the 64 lanes of a wave: every lane ends with the same, order-fixed sum.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, WAVE));
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024).  scratch: >= 16 doubles of LDS.  All threads
+// receive the result; waves are added in wave order, so the result is bitwise reproducible.
+__device__ __forceinline__ double block_sum(double v, double* scratch)
+{
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < nw; ++i) t += scratch[i];
+  return t;
+}
+__device__ __forceinline__ double block_max(double v, double* scratch)
+{
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  double t = scratch[0];
+  for (int i = 1; i < nw; ++i) t = fmax(t, scratch[i]);
+  return t;
+}
+
+// ---- dense Cholesky (ptz_chol.hip) -------------------------------------------------------------------
+// `count` independent SPD systems stored as padded row-major matrices A[count][np][np] (lower triangle
+// read).  Row n_i of system i holds rhs^T in columns [0, n_i) and a huge diagonal (CHOL_BIG), so the
+// factorisation performs the forward substitution; rows > n_i are identity.  After chol_factor the
+// strictly-lower tiles of A hold L, Ldiag holds the factored diagonal tiles, and chol_backsolve writes
+// x[count][np].
+constexpr int CHOL_NB = 64;
+constexpr double CHOL_BIG = 1e300;
+struct CholBatch {
+  int count = 0;
+  int np = 0;             // padded order, multiple of CHOL_NB, >= max(n_i) + 1
+  double* A = nullptr;    // device
+  double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
+  const int* n = nullptr;   // device [count]
+  int* fail = nullptr;      // device [count]: set to 1 if a pivot <= 0 is met in rows < n_i
+  const int* active = nullptr;  // device [count] or nullptr; systems with active == 0 are skipped
+};
+inline int chol_padded_order(int n_max) { return ((n_max + 1 + CHOL_NB - 1) / CHOL_NB) * CHOL_NB; }
+// enqueue factorisation + solve on `stream`; x: device [count][np]
+void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
+// the three kernel families of chol_factor_solve, individually (for per-family timing)
+void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream);
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream);
+void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
+// helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
+void chol_clear(const CholBatch& cb, hipStream_t stream);
+
+}  // namespace ptz

@@ -1,0 +1,350 @@
+// ptz_factor.h -- per-observation PTZ reprojection residuals and closed-form Jacobians (FP64).
+//
+// Device math for the HIP kernels.  Functions are PTZ_HD so the same inlines can be instantiated by a
+// host-only unit harness (tests/cpu_harness) to check the algebra without a GPU; the product path only
+// ever runs them inside kernels.
+//
+// Reference behaviour followed (file:line relative to the reference tree):
+//   F1 PTZRayFactor::operator()        src/core/ptzray_optimizer.cc:20-56
+//   F2 PTZRayDistFactor::operator()    src/core/ptzray_optimizer.cc:65-129
+//   F3 Reproj2d3dFactor::operator()    src/core/ptzray_optimizer.cc:268-326
+//   F4 Factor2d2d::operator()          src/core/krt_optimizer.cc:22-43
+//   F5 Factor2d2dDist::operator()      src/core/krt_optimizer.cc:80-132
+//   F6 Camera::FromVector/cv::Rodrigues src/core/types.cc:59-73
+// The reference differentiates these functors numerically (ceres::NumericDiffCostFunction, CENTRAL);
+// the kernels use the exact derivatives of the same functions.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PTZ_HD __host__ __device__ __forceinline__
+#else
+#define PTZ_HD inline
+#endif
+
+namespace ptz {
+
+// ---- camera block staged in LDS: everything an observation needs from its camera ----------------
+// [0..8]   R (row-major)         rotation of the current rvec (cv::Rodrigues formula)
+// [9] f  [10] cx [11] cy [12] fy (fy is only read by the 2D-3D factor)
+// [13..17] k1 k2 k3 p1 p2
+// ---- the first CANDBLK entries are all a residual-only evaluation needs ----
+// [18..26] Jl (row-major)        left Jacobian of SO(3) at rvec: d(R X)/d r_k = Jl[:,k] x (R X)
+// [27..31] Jacobi column scales of the free camera parameters (NC of them)
+constexpr int CAMBLK = 32;
+constexpr int CANDBLK = 18;
+constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13, CB_JL = 18, CB_S = 27;
+
+constexpr double kDblEps = 2.220446049250313e-16;
+
+// cv::Rodrigues vector -> matrix (OpenCV 4.5.3 cvRodrigues2): theta < DBL_EPSILON -> I
+PTZ_HD void rodrigues(const double r[3], double R[9])
+{
+  const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (theta < kDblEps) {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    return;
+  }
+  const double c = cos(theta), s = sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+  const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+  R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+  R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+  R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+// cv::Rodrigues matrix -> vector (OpenCV 4.5.3 cvRodrigues2, 3x3 branch) for an orthonormal R.
+// (OpenCV first re-orthonormalises R with an SVD; products of rotation matrices are orthonormal to
+// round-off, so that projection is the identity to ~1e-16 and is omitted.)
+PTZ_HD void rodrigues_inv(const double R[9], double r[3])
+{
+  double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+  const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  double theta = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { rx = ry = rz = 0; }
+    else {
+      double t;
+      t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0.);
+      t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+      t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0.) * ((R[2] < 0) != (R[5] < 0) ? -1. : 1.);
+      if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+      theta /= sqrt(rx * rx + ry * ry + rz * rz);
+      rx *= theta; ry *= theta; rz *= theta;
+    }
+  }
+  else {
+    const double vth = theta / (2 * s);
+    rx *= vth; ry *= vth; rz *= vth;
+  }
+  r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+PTZ_HD void mat3_mul(const double* A, const double* B, double* C)
+{
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// Left Jacobian of SO(3): R(r + d) = exp([Jl d]_x) R(r) + O(d^2), so d(R X)/d r_k = Jl[:,k] x (R X).
+// Jl = I + a [r]_x + b [r]_x^2, a = (1 - cos t)/t^2, b = (t - sin t)/t^3 (series below t = 1e-2).
+PTZ_HD void so3_left_jacobian(const double r[3], double Jl[9])
+{
+  const double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double a, b;
+  if (t2 < 1e-4) {
+    a = 0.5 - t2 * (1.0 / 24.0) + t2 * t2 * (1.0 / 720.0);
+    b = (1.0 / 6.0) - t2 * (1.0 / 120.0) + t2 * t2 * (1.0 / 5040.0);
+  }
+  else {
+    const double t = sqrt(t2);
+    const double sh = sin(0.5 * t);
+    a = 2.0 * sh * sh / t2;
+    b = (t - sin(t)) / (t2 * t);
+  }
+  const double x = r[0], y = r[1], z = r[2];
+  // [r]_x^2 = r r^T - t2 I
+  Jl[0] = 1.0 + b * (x * x - t2); Jl[1] = -a * z + b * x * y;     Jl[2] = a * y + b * x * z;
+  Jl[3] = a * z + b * x * y;      Jl[4] = 1.0 + b * (y * y - t2); Jl[5] = -a * x + b * y * z;
+  Jl[6] = -a * y + b * x * z;     Jl[7] = a * x + b * y * z;      Jl[8] = 1.0 + b * (z * z - t2);
+}
+
+// Brown distortion exactly as written in ptzray_optimizer.cc:111-120
+PTZ_HD void brown(double x, double y, const double* k, double& xd, double& yd)
+{
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r2 * r2 * r2, xy = x * y, x2 = x * x, y2 = y * y;
+  const double radial = 1.0 + k[0] * r2 + k[1] * r4 + k[2] * r6;
+  xd = x * radial + 2.0 * k[3] * xy + k[4] * (r2 + 2.0 * x2);
+  yd = y * radial + 2.0 * k[4] * xy + k[3] * (r2 + 2.0 * y2);
+}
+// d(xd,yd)/d(x,y) (row-major B[4]) and d(xd,yd)/dk1
+PTZ_HD void brown_jac(double x, double y, const double* k, double B[4], double dk1[2])
+{
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double rad = 1.0 + k[0] * r2 + k[1] * r4 + k[2] * r6;
+  const double drad = k[0] + 2.0 * k[1] * r2 + 3.0 * k[2] * r4;
+  B[0] = rad + 2.0 * x * x * drad + 2.0 * k[3] * y + 6.0 * k[4] * x;
+  B[1] = 2.0 * x * y * drad + 2.0 * k[3] * x + 2.0 * k[4] * y;
+  B[2] = 2.0 * x * y * drad + 2.0 * k[4] * y + 2.0 * k[3] * x;
+  B[3] = rad + 2.0 * y * y * drad + 2.0 * k[4] * x + 6.0 * k[3] * y;
+  dk1[0] = x * r2;
+  dk1[1] = y * r2;
+}
+
+// ---- global-BA 2D-2D factors ---------------------------------------------------------------------
+// TYPE 0 = PTZRay: free camera parameters [f, r1, r2, r3]      (NC = 4)
+// TYPE 1 = PTZRayDist: free [f, k1, r1, r2, r3]                 (NC = 5)
+// The reference also leaves intr[1] ("fy") free, but neither functor reads it (param[1] = intr[0],
+// ptzray_optimizer.cc:24-25, 69-70): its Jacobian column is identically zero, its LM step is exactly
+// zero, so the column is not materialised.
+template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : 5; static constexpr int ROT0 = NC - 3; };
+
+// Residual only.  cb = camera block (R at [CB_R], intrinsics); X = ray parameter (3).
+template <int TYPE>
+PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, double res[2])
+{
+  const double* R = cb + CB_R;
+  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
+  double Xn[3];
+  if (TYPE == 0) {
+    const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+    Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
+  }
+  else {
+    Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2];
+  }
+  const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
+  const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
+  const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
+  if (TYPE == 0) {
+    // uv_predict = K R ray; uv_predict /= uv_predict(2)   (ptzray_optimizer.cc:49-50)
+    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
+    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+  }
+  else {
+    if (Pz < 0) { res[0] = 1000000.0; res[1] = 1000000.0; return; }  // :97-102
+    const double x = Px / Pz, y = Py / Pz;
+    double xd, yd;
+    brown(x, y, cb + CB_K, xd, yd);
+    res[0] = (double)u - (f * xd + cx);
+    res[1] = (double)v - (f * yd + cy);
+  }
+}
+
+// Residual + Jacobians.  Jc[2][NC] wrt the free camera parameters, Jr[2][3] wrt the ray.  Unweighted,
+// unscaled.
+template <int TYPE>
+PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, double res[2],
+                         double Jc[2][BaDims<TYPE>::NC], double Jr[2][3])
+{
+  constexpr int NC = BaDims<TYPE>::NC, ROT0 = BaDims<TYPE>::ROT0;
+  const double* R = cb + CB_R;
+  const double* Jl = cb + CB_JL;
+  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
+  double Xn[3], inv_n = 1.0;
+  if (TYPE == 0) {
+    const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+    inv_n = 1.0 / n;
+    Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
+  }
+  else {
+    Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2];
+  }
+  const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
+  const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
+  const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
+  if (TYPE != 0 && Pz < 0) {
+    res[0] = 1000000.0; res[1] = 1000000.0;
+    for (int k = 0; k < NC; ++k) { Jc[0][k] = 0; Jc[1][k] = 0; }
+    for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
+    return;
+  }
+  const double iz = 1.0 / Pz;
+  const double x = Px * iz, y = Py * iz;
+  double xd = x, yd = y;
+  double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
+  if (TYPE == 0) {
+    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
+    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+  }
+  else {
+    brown(x, y, cb + CB_K, xd, yd);
+    brown_jac(x, y, cb + CB_K, B, dk1);
+    res[0] = (double)u - (f * xd + cx);
+    res[1] = (double)v - (f * yd + cy);
+  }
+  // M = d pred / dP = f * B * dpi,  dpi = [[iz, 0, -x iz], [0, iz, -y iz]]
+  double M[2][3];
+  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = f * (B[2] * iz);  M[1][1] = f * (B[3] * iz);  M[1][2] = f * (-(B[2] * x + B[3] * y) * iz);
+  Jc[0][0] = -xd;
+  Jc[1][0] = -yd;
+  if (TYPE != 0) {
+    Jc[0][1] = -f * dk1[0];
+    Jc[1][1] = -f * dk1[1];
+  }
+  // rotation: dP/dr_k = Jl[:,k] x P
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
+    const double dx = ay * Pz - az * Py, dy = az * Px - ax * Pz, dz = ax * Py - ay * Px;
+    Jc[0][ROT0 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    Jc[1][ROT0 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+  }
+  // ray: dP/dX = R (I - Xn Xn^T)/|X| for PTZRay; since M P = 0 (the projection is scale invariant)
+  // the projector term vanishes identically: d res/dX = -(M R)/|X|.  PTZRayDist: dP/dX = R.
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
+    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
+  }
+}
+
+// ---- KRT single-view factors (F4 / F5) ------------------------------------------------------------
+// KTYPE 0 = F: free [f, r1, r2, r3]; 1 = FDist: free [f, r1, r2, r3, k1] (ascending 15-vector index,
+// krt_optimizer.cc:321-337).  ray1 = normalise(K1^-1 [u1, v1, 1]) is constant per match (R1 = I in the
+// local frame, krt_optimizer.cc:275) and is precomputed once per match by the caller.
+template <int KTYPE> struct KrtDims { static constexpr int NF = (KTYPE == 0) ? 4 : 5; };
+
+template <int KTYPE, bool JAC>
+PTZ_HD void krt_eval(const double* R, const double* Jl, double f, double cx, double cy, const double* kd,
+                     const double ray1[3], bool skip, float u2, float v2, double res[2],
+                     double J[2][KrtDims<KTYPE>::NF])
+{
+  constexpr int NF = KrtDims<KTYPE>::NF;
+  if (skip) {  // undistorted reference pixel outside the frame: residual 0 (krt_optimizer.cc:97-101)
+    res[0] = 0; res[1] = 0;
+    if (JAC) for (int k = 0; k < NF; ++k) { J[0][k] = 0; J[1][k] = 0; }
+    return;
+  }
+  const double Px = R[0] * ray1[0] + R[1] * ray1[1] + R[2] * ray1[2];
+  const double Py = R[3] * ray1[0] + R[4] * ray1[1] + R[5] * ray1[2];
+  const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
+  const double iz = 1.0 / Pz, x = Px * iz, y = Py * iz;
+  double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
+  if (KTYPE == 0) {
+    res[0] = (double)u2 - (f * Px + cx * Pz) / Pz;
+    res[1] = (double)v2 - (f * Py + cy * Pz) / Pz;
+  }
+  else {
+    brown(x, y, kd, xd, yd);
+    if (JAC) brown_jac(x, y, kd, B, dk1);
+    res[0] = (double)u2 - (f * xd + cx);
+    res[1] = (double)v2 - (f * yd + cy);
+  }
+  if (!JAC) return;
+  double M[2][3];
+  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = f * (B[2] * iz);  M[1][1] = f * (B[3] * iz);  M[1][2] = f * (-(B[2] * x + B[3] * y) * iz);
+  J[0][0] = -xd;
+  J[1][0] = -yd;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
+    const double dx = ay * Pz - az * Py, dy = az * Px - ax * Pz, dz = ax * Py - ay * Px;
+    J[0][1 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    J[1][1 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+  }
+  if (KTYPE != 0) {
+    J[0][4] = -f * dk1[0];
+    J[1][4] = -f * dk1[1];
+  }
+}
+
+// cv::undistortPoints(src, dst, K, dist, noArray(), K) for one point, 5 fixed-point iterations
+// (OpenCV 4.5.3 default criteria), result rounded to float32 (cv::Point2f, krt_optimizer.cc:89-92).
+// OpenCV reads dist as (k1,k2,p1,p2,k3) while the reference stores (k1,k2,k3,p1,p2): the permutation
+// is part of the reference's behaviour and is kept.
+PTZ_HD void undistort_point(double fx, double fy, double cx, double cy, const double* d, float u, float v,
+                            float& ou, float& ov)
+{
+  double x = ((double)u - cx) / fx, y = ((double)v - cy) / fy;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; ++j) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1.0 / (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2);
+    if (icdist < 0) { x = ((double)u - cx) / fx; y = ((double)v - cy) / fy; break; }
+    const double dX = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x);
+    const double dY = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y;
+    x = (x0 - dX) * icdist;
+    y = (y0 - dY) * icdist;
+  }
+  ou = (float)(x * fx + cx);
+  ov = (float)(y * fy + cy);
+}
+
+// Symmetric 3x3 inverse through LL^T (Ceres InvertPSDMatrix<3>: llt().solve(I)).  A, Ainv: 6 unique
+// entries [a00 a10 a11 a20 a21 a22].  Returns false if A is not positive definite.
+PTZ_HD bool inv3_spd(const double A[6], double Ai[6])
+{
+  if (!(A[0] > 0)) return false;
+  const double l00 = sqrt(A[0]);
+  const double l10 = A[1] / l00, l20 = A[3] / l00;
+  const double d1 = A[2] - l10 * l10;
+  if (!(d1 > 0)) return false;
+  const double l11 = sqrt(d1);
+  const double l21 = (A[4] - l20 * l10) / l11;
+  const double d2 = A[5] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0)) return false;
+  const double l22 = sqrt(d2);
+  // Linv (lower)
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  // A^-1 = Linv^T Linv
+  Ai[0] = i00 * i00 + i10 * i10 + i20 * i20;
+  Ai[1] = i10 * i11 + i20 * i21;
+  Ai[2] = i11 * i11 + i21 * i21;
+  Ai[3] = i20 * i22;
+  Ai[4] = i21 * i22;
+  Ai[5] = i22 * i22;
+  return true;
+}
+
+}  // namespace ptz

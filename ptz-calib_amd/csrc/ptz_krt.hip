@@ -1,0 +1,401 @@
+// ptz_krt.hip -- single-view 4-/5-parameter Levenberg-Marquardt, batched over queries (gfx950).
+//
+// Replaces KRTOptimizer::Add2d2dConstraints + Solve + CheckResults + ObtainRefinedCameraParams
+// (src/core/krt_optimizer.cc:265-348, 385-404, 504-567) as driven by the relocalization loop
+// (src/app/run_ptz_reloc.cc:68-118) and by RegisterNextImage (src/core/ptz_incremental_optimizer.cc:377-418).
+// The reference builds one ceres::Problem per query (NumericDiffCostFunction over all 15 camera
+// entries, DENSE_QR); here one 64-lane wave owns one query and runs the whole trust-region loop
+// (Ceres 1.14 policy) without leaving the kernel:
+//   lanes stride over the query's matches (16 B records: 2 x f32 reference pixel, 2 x f32 current pixel),
+//   J^T J (4x4 or 5x5), J^T r and the cost are reduced with a fixed butterfly, every lane then solves the
+//   damped normal equations redundantly in registers.  DENSE_QR on [J; D] and Cholesky on J^T J + D^2
+//   give the same step up to round-off (the Jacobi-scaled 4-/5-column Jacobian is well conditioned).
+#include <vector>
+
+#include "ptz_common.h"
+#include "ptz_factor.h"
+
+namespace ptz {
+namespace {
+
+struct KrtOpt {
+  int max_num_iterations, max_consecutive_invalid, jacobi_scaling;
+  double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_reproj_error;
+};
+
+template <int KTYPE> struct KFree;
+template <> struct KFree<0> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : 3 + k; } };                    // 0,4,5,6
+template <> struct KFree<1> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : (k == 4 ? 10 : 3 + k); } };     // 0,4,5,6,10
+
+// in-register Cholesky solve of an NF x NF SPD system (row-major full storage); false if not SPD
+template <int NF>
+__device__ __forceinline__ bool spd_solve(double* A, double* b)
+{
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    double d = A[j * NF + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j * NF + k] * A[j * NF + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[j * NF + j] = d;
+#pragma unroll
+    for (int i = j + 1; i < NF; ++i) {
+      double v = A[i * NF + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= A[i * NF + k] * A[j * NF + k];
+      A[i * NF + j] = v / d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= A[i * NF + k] * b[k];
+    b[i] = v / A[i * NF + i];
+  }
+#pragma unroll
+  for (int i = NF - 1; i >= 0; --i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = i + 1; k < NF; ++k) v -= A[k * NF + i] * b[k];
+    b[i] = v / A[i * NF + i];
+  }
+  return true;
+}
+
+template <int KTYPE>
+struct MatchEval {
+  // constant part of a match: unit ray of the reference pixel in the local frame (krt_optimizer.cc:31-33,
+  // 89-104) and the border guard of the distortion variant (:97-101)
+  static __device__ __forceinline__ void ray1(const double* kref, const double* dref, float u1, float v1, double r[3], bool& skip)
+  {
+    double u = u1, v = v1;
+    skip = false;
+    if (KTYPE == 1) {
+      float ou, ov;
+      undistort_point(kref[0], kref[1], kref[2], kref[3], dref, u1, v1, ou, ov);
+      skip = (ou < 0 || ou >= kref[2] * 2 || ov < 0 || ov >= kref[3] * 2);
+      u = ou; v = ov;
+    }
+    const double X0 = (u - kref[2]) / kref[0], X1 = (v - kref[3]) / kref[1];
+    const double n = sqrt(X0 * X0 + X1 * X1 + 1.0);
+    r[0] = X0 / n; r[1] = X1 / n; r[2] = 1.0 / n;
+  }
+};
+
+template <int KTYPE>
+__global__ __launch_bounds__(256) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
+                                             const float2* __restrict__ uv_cur, const double* __restrict__ cam_ref,
+                                             double* __restrict__ cam_cur, KrtOpt o, ptz_lm_summary* __restrict__ summ,
+                                             int* __restrict__ accepted)
+{
+  constexpr int NF = KrtDims<KTYPE>::NF;
+  constexpr int NH = NF * (NF + 1) / 2;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_query) return;
+  const int lane = threadIdx.x & 63;
+  const long long m0 = match_ptr[q], m1 = match_ptr[q + 1];
+  const int M = (int)(m1 - m0);
+  // ---- world -> local frame of the reference camera (krt_optimizer.cc:269-284)
+  double ref[15], x[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) { ref[k] = cam_ref[(size_t)q * 15 + k]; x[k] = cam_cur[(size_t)q * 15 + k]; }
+  double Rref[9], Rcur[9], RrefT[9], Rl[9];
+  rodrigues(ref + 4, Rref);
+  rodrigues(x + 4, Rcur);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) RrefT[3 * i + j] = Rref[3 * j + i];
+  mat3_mul(Rcur, RrefT, Rl);
+  {
+    double rv[3];
+    rodrigues_inv(Rl, rv);
+    const double t0 = Rl[0] * ref[7] + Rl[1] * ref[8] + Rl[2] * ref[9];
+    const double t1 = Rl[3] * ref[7] + Rl[4] * ref[8] + Rl[5] * ref[9];
+    const double t2 = Rl[6] * ref[7] + Rl[7] * ref[8] + Rl[8] * ref[9];
+    x[4] = rv[0]; x[5] = rv[1]; x[6] = rv[2];
+    x[7] = -t0 + x[7]; x[8] = -t1 + x[8]; x[9] = -t2 + x[9];
+  }
+  const double kref[4] = {ref[0], ref[1], ref[2], ref[3]};
+  const double dref[5] = {ref[10], ref[11], ref[12], ref[13], ref[14]};
+
+  // residual-only pass at a camera vector
+  auto eval_cost = [&](const double* c) -> double {
+    double R[9];
+    rodrigues(c + 4, R);
+    double cost = 0;
+    for (int m = lane; m < M; m += 64) {
+      const float2 a = uv_ref[m0 + m], bq = uv_cur[m0 + m];
+      double r1[3], res[2], J[2][NF];
+      bool skip;
+      MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
+      krt_eval<KTYPE, false>(R, nullptr, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
+      cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+    }
+    return wave_sum(cost);
+  };
+  // full linearisation: H = J^T J (packed lower), g = J^T r, cost
+  double H[NH], g[NF];
+  auto linearize = [&](const double* c) -> double {
+    double R[9], Jl[9];
+    rodrigues(c + 4, R);
+    so3_left_jacobian(c + 4, Jl);
+    double cost = 0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) H[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) g[k] = 0;
+    for (int m = lane; m < M; m += 64) {
+      const float2 a = uv_ref[m0 + m], bq = uv_cur[m0 + m];
+      double r1[3], res[2], J[2][NF];
+      bool skip;
+      MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
+      krt_eval<KTYPE, true>(R, Jl, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
+      cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+      int e = 0;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        g[k] += J[0][k] * res[0] + J[1][k] * res[1];
+#pragma unroll
+        for (int l = 0; l <= k; ++l) H[e++] += J[0][k] * J[0][l] + J[1][k] * J[1][l];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) H[k] = wave_sum(H[k]);
+#pragma unroll
+    for (int k = 0; k < NF; ++k) g[k] = wave_sum(g[k]);
+    return wave_sum(cost);
+  };
+  auto norm15 = [&](const double* c) -> double {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s += c[k] * c[k];
+    return sqrt(s);
+  };
+
+  // ---- [Ceres 1.14] TrustRegionMinimizer, LevenbergMarquardtStrategy
+  double radius = o.initial_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  double x_cost = linearize(x);
+  double scale[NF], diag[NF];
+#pragma unroll
+  for (int k = 0; k < NF; ++k) scale[k] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[k * (k + 1) / 2 + k])) : 1.0;
+  double x_norm = norm15(x);
+  double grad_max = 0;
+#pragma unroll
+  for (int k = 0; k < NF; ++k) grad_max = fmax(grad_max, fabs(g[k]));
+  const double initial_cost = x_cost;
+  double final_cost = x_cost, it_cost = x_cost;
+  int iteration = 0, n_summaries = 0, termination = PTZ_NO_CONVERGENCE;
+  int n_succ = 0, n_unsucc = 0, n_steps = 0, n_solves = 0, n_jac = 1, consec_invalid = 0;
+  bool step_ok = true;
+  for (;;) {
+    if (step_ok) ++n_succ; else ++n_unsucc;
+    if (it_cost < final_cost) final_cost = it_cost;
+    ++n_summaries;
+    if (iteration >= o.max_num_iterations) { termination = PTZ_NO_CONVERGENCE; break; }
+    if (step_ok && grad_max <= o.gradient_tolerance) { termination = PTZ_CONVERGENCE; break; }
+    if (radius <= o.min_radius) { termination = PTZ_CONVERGENCE; break; }
+    ++iteration; ++n_steps;
+    step_ok = false;
+    it_cost = x_cost;
+    // scaled normal equations (J_s = J diag(scale))
+    double A[NF * NF], b[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      b[k] = g[k] * scale[k];
+#pragma unroll
+      for (int l = 0; l <= k; ++l) {
+        const double v = H[k * (k + 1) / 2 + l] * scale[k] * scale[l];
+        A[k * NF + l] = v; A[l * NF + k] = v;
+      }
+    }
+    if (!reuse_diagonal) {
+#pragma unroll
+      for (int k = 0; k < NF; ++k) diag[k] = fmin(fmax(A[k * NF + k], o.min_lm_diagonal), o.max_lm_diagonal);
+    }
+    double Hs[NF * NF], gs[NF];
+#pragma unroll
+    for (int k = 0; k < NF * NF; ++k) Hs[k] = A[k];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) { gs[k] = b[k]; const double D = sqrt(diag[k] / radius); A[k * NF + k] += D * D; }
+    const bool solved = spd_solve<NF>(A, b);
+    ++n_solves;
+    reuse_diagonal = true;
+    double step[NF], mcc = 0;
+    bool valid = solved;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) { step[k] = -b[k]; valid = valid && isfinite(step[k]); }
+    if (valid) {
+      // -(J step)^T (r + J step / 2) = -(step^T g + step^T H step / 2)
+      double sg = 0, shs = 0;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        sg += step[k] * gs[k];
+        double t = 0;
+#pragma unroll
+        for (int l = 0; l < NF; ++l) t += Hs[k * NF + l] * step[l];
+        shs += step[k] * t;
+      }
+      mcc = -(sg + 0.5 * shs);
+      valid = mcc > 0.0;
+    }
+    if (!valid) {
+      if (++consec_invalid >= o.max_consecutive_invalid) { termination = PTZ_FAILURE; break; }
+      radius *= 0.5;
+      reuse_diagonal = false;
+      continue;
+    }
+    consec_invalid = 0;
+    double xc[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) xc[k] = x[k];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) xc[KFree<KTYPE>::at(k)] += step[k] * scale[k];
+    double cand = eval_cost(xc);
+    if (!isfinite(cand)) cand = 1.7976931348623157e308;
+    double dn = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) dn += (x[k] - xc[k]) * (x[k] - xc[k]);
+    if (sqrt(dn) <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { termination = PTZ_CONVERGENCE; break; }
+    const double cost_change = x_cost - cand;
+    if (fabs(cost_change) <= o.function_tolerance * x_cost) { termination = PTZ_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > o.min_relative_decrease) {
+#pragma unroll
+      for (int k = 0; k < 15; ++k) x[k] = xc[k];
+      x_norm = norm15(x);
+      x_cost = linearize(x);
+      ++n_jac;
+      grad_max = 0;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) grad_max = fmax(grad_max, fabs(g[k]));
+      step_ok = true;
+      it_cost = x_cost;
+      const double t = 2.0 * rho - 1.0;
+      radius = fmin(o.max_radius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+    }
+    else {
+      it_cost = cand;
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+    }
+  }
+  // ---- CheckResults (krt_optimizer.cc:504-533) + ObtainRefinedCameraParams (:535-567)
+  const int num_residuals = 2 * M;
+  const double final_reproj = sqrt(2.0) * sqrt((2 * final_cost) / num_residuals);
+  bool ok = (termination == PTZ_CONVERGENCE) && !(final_reproj >= o.max_reproj_error);
+  {
+    const double fov_x = atan(x[2] / x[0]) * 2 * 180 / M_PI, fov_y = atan(x[3] / x[1]) * 2 * 180 / M_PI;
+    if (fov_x < 0 || fov_x > 170 || fov_y < 0 || fov_y > 170) ok = false;
+  }
+  if (lane == 0) {
+    ptz_lm_summary s;
+    s.termination_type = termination;
+    s.num_iterations = n_summaries - 1;
+    s.num_lm_steps = n_steps;
+    s.num_successful_steps = n_succ;
+    s.num_unsuccessful_steps = n_unsucc;
+    s.num_residuals = num_residuals;
+    s.num_linear_solves = n_solves;
+    s.num_jacobian_evals = n_jac;
+    s.initial_cost = initial_cost;
+    s.final_cost = final_cost;
+    s.final_radius = radius;
+    s.final_gradient_max_norm = grad_max;
+    summ[q] = s;
+    accepted[q] = ok ? 1 : 0;
+    if (ok) {
+      x[1] = x[0];  // fx = fy (krt_optimizer.cc:543)
+      double Rloc[9], Rw[9], rv[3];
+      rodrigues(x + 4, Rloc);
+      mat3_mul(Rloc, Rref, Rw);
+      rodrigues_inv(Rw, rv);
+      const double t0 = Rloc[0] * ref[7] + Rloc[1] * ref[8] + Rloc[2] * ref[9];
+      const double t1 = Rloc[3] * ref[7] + Rloc[4] * ref[8] + Rloc[5] * ref[9];
+      const double t2 = Rloc[6] * ref[7] + Rloc[7] * ref[8] + Rloc[8] * ref[9];
+      double* out = cam_cur + (size_t)q * 15;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) out[k] = x[k];
+      out[4] = rv[0]; out[5] = rv[1]; out[6] = rv[2];
+      out[7] = t0 + x[7]; out[8] = t1 + x[8]; out[9] = t2 + x[9];
+    }
+  }
+}
+
+}  // namespace
+}  // namespace ptz
+
+using namespace ptz;
+
+extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                                       const double* cam_ref, double* cam_cur, int32_t factor_type, double max_reproj_error,
+                                       const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  if (n_query <= 0 || !match_ptr || !uv_ref || !uv_cur || !cam_ref || !cam_cur || !summaries || !accepted) return PTZ_EINVAL;
+  if (factor_type != PTZ_KRT_F && factor_type != PTZ_KRT_FDist) return PTZ_EUNSUPPORTED;
+  ptz_lm_options o;
+  if (opt) o = *opt; else ptz_lm_options_default(&o);
+  for (int q = 0; q < n_query; ++q)
+    if (match_ptr[q + 1] < match_ptr[q]) return PTZ_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
+  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+  const int64_t nm = match_ptr[n_query];
+  long long* d_ptr = nullptr;
+  float2 *d_ref = nullptr, *d_cur = nullptr;
+  double *d_cref = nullptr, *d_ccur = nullptr;
+  ptz_lm_summary* d_sum = nullptr;
+  int* d_acc = nullptr;
+  PTZ_HIP_TRY(hipMalloc(&d_ptr, sizeof(long long) * (n_query + 1)));
+  PTZ_HIP_TRY(hipMalloc(&d_ref, sizeof(float2) * (nm > 0 ? nm : 1)));
+  PTZ_HIP_TRY(hipMalloc(&d_cur, sizeof(float2) * (nm > 0 ? nm : 1)));
+  PTZ_HIP_TRY(hipMalloc(&d_cref, sizeof(double) * 15 * n_query));
+  PTZ_HIP_TRY(hipMalloc(&d_ccur, sizeof(double) * 15 * n_query));
+  PTZ_HIP_TRY(hipMalloc(&d_sum, sizeof(ptz_lm_summary) * n_query));
+  PTZ_HIP_TRY(hipMalloc(&d_acc, sizeof(int) * n_query));
+  PTZ_HIP_TRY(hipMemcpy(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(hipMemcpy(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(hipMemcpy(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(hipMemcpy(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(hipMemcpy(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice));
+  KrtOpt ko;
+  ko.max_num_iterations = o.max_num_iterations;
+  ko.max_consecutive_invalid = o.max_num_consecutive_invalid_steps;
+  ko.jacobi_scaling = o.jacobi_scaling;
+  ko.initial_radius = o.initial_trust_region_radius;
+  ko.max_radius = o.max_trust_region_radius;
+  ko.min_radius = o.min_trust_region_radius;
+  ko.min_relative_decrease = o.min_relative_decrease;
+  ko.min_lm_diagonal = o.min_lm_diagonal;
+  ko.max_lm_diagonal = o.max_lm_diagonal;
+  ko.function_tolerance = o.function_tolerance;
+  ko.gradient_tolerance = o.gradient_tolerance;
+  ko.parameter_tolerance = o.parameter_tolerance;
+  ko.max_reproj_error = max_reproj_error;
+  hipEvent_t e0, e1;
+  PTZ_HIP_TRY(hipEventCreate(&e0));
+  PTZ_HIP_TRY(hipEventCreate(&e1));
+  PTZ_HIP_TRY(hipEventRecord(e0, 0));
+  const dim3 grid((n_query + 3) / 4), block(256);
+  if (factor_type == PTZ_KRT_F) hipLaunchKernelGGL(k_krt<0>, grid, block, 0, 0, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
+  else hipLaunchKernelGGL(k_krt<1>, grid, block, 0, 0, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
+  PTZ_HIP_TRY(hipEventRecord(e1, 0));
+  PTZ_HIP_TRY(hipDeviceSynchronize());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (device_ms) *device_ms = ms;
+  PTZ_HIP_TRY(hipMemcpy(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost));
+  PTZ_HIP_TRY(hipMemcpy(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost));
+  PTZ_HIP_TRY(hipMemcpy(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(d_ptr); (void)hipFree(d_ref); (void)hipFree(d_cur); (void)hipFree(d_cref); (void)hipFree(d_ccur);
+  (void)hipFree(d_sum); (void)hipFree(d_acc);
+  return PTZ_OK;
+}

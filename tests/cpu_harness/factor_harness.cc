@@ -1,0 +1,75 @@
+// factor_harness.cc -- TEST INFRASTRUCTURE.  Host instantiation of the device math in
+// ptz-calib_amd/csrc/ptz_factor.h so the algebra can be checked against the oracle without a GPU.
+// Never part of the product library.
+#include "../../ptz-calib_amd/csrc/ptz_factor.h"
+
+using namespace ptz;
+
+static void fill_camblk(const double* cam15, double* cb)
+{
+  rodrigues(cam15 + 4, cb + CB_R);
+  so3_left_jacobian(cam15 + 4, cb + CB_JL);
+  cb[CB_F] = cam15[0]; cb[CB_CX] = cam15[2]; cb[CB_CY] = cam15[3]; cb[CB_FY] = cam15[1];
+  for (int k = 0; k < 5; ++k) cb[CB_K + k] = cam15[10 + k];
+  for (int k = 0; k < 5; ++k) cb[CB_S + k] = 1.0;
+}
+
+extern "C" {
+void h_rodrigues(const double* r, double* R, double* Jl) { rodrigues(r, R); so3_left_jacobian(r, Jl); }
+
+// Jc: [2][NC], Jr: [2][3]
+void h_ba_linearize(int type, const double* cam15, const double* ray, const float* uv, double* res, double* Jc, double* Jr)
+{
+  double cb[CAMBLK];
+  fill_camblk(cam15, cb);
+  double jr[2][3];
+  if (type == 0) {
+    double jc[2][4];
+    ba_linearize<0>(cb, ray, uv[0], uv[1], res, jc, jr);
+    for (int i = 0; i < 8; ++i) Jc[i] = (&jc[0][0])[i];
+  }
+  else {
+    double jc[2][5];
+    ba_linearize<1>(cb, ray, uv[0], uv[1], res, jc, jr);
+    for (int i = 0; i < 10; ++i) Jc[i] = (&jc[0][0])[i];
+  }
+  for (int i = 0; i < 6; ++i) Jr[i] = (&jr[0][0])[i];
+}
+void h_ba_residual(int type, const double* cam15, const double* ray, const float* uv, double* res)
+{
+  double cb[CAMBLK];
+  fill_camblk(cam15, cb);
+  if (type == 0) ba_residual<0>(cb, ray, uv[0], uv[1], res);
+  else ba_residual<1>(cb, ray, uv[0], uv[1], res);
+}
+// KRT: cam15 current (local frame), k1[4], dist1[5] reference intrinsics/distortion
+void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* dist1, const float* uv1, const float* uv2,
+                double* res, double* J)
+{
+  double R[9], Jl[9];
+  rodrigues(cam15 + 4, R);
+  so3_left_jacobian(cam15 + 4, Jl);
+  double u1 = uv1[0], v1 = uv1[1];
+  bool skip = false;
+  if (ktype == 1) {
+    float ou, ov;
+    undistort_point(k1[0], k1[1], k1[2], k1[3], dist1, uv1[0], uv1[1], ou, ov);
+    skip = (ou < 0 || ou >= k1[2] * 2 || ov < 0 || ov >= k1[3] * 2);
+    u1 = ou; v1 = ov;
+  }
+  double X[3] = {(u1 - k1[2]) / k1[0], (v1 - k1[3]) / k1[1], 1.0};
+  double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+  double ray1[3] = {X[0] / n, X[1] / n, X[2] / n};
+  if (ktype == 0) {
+    double j[2][4];
+    krt_eval<0, true>(R, Jl, cam15[0], cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);
+    for (int i = 0; i < 8; ++i) J[i] = (&j[0][0])[i];
+  }
+  else {
+    double j[2][5];
+    krt_eval<1, true>(R, Jl, cam15[0], cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);
+    for (int i = 0; i < 10; ++i) J[i] = (&j[0][0])[i];
+  }
+}
+int h_inv3(const double* A6, double* Ai6) { return inv3_spd(A6, Ai6) ? 1 : 0; }
+}

@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
+inputs.  Tolerances are stated per test.  BASELINE north_star: parameters within 1e-6 relative of the
+reference CPU solver, bit-exact track indexing."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _rot_angle_between(orc, cam_a, cam_b):
+    """max over cameras of the angle of R_a R_b^T (radians); gauge-dependent."""
+    out = 0.0
+    for a, b in zip(cam_a, cam_b):
+        Ra, Rb = orc.rodrigues(a[4:7]), orc.rodrigues(b[4:7])
+        c = (np.trace(Ra @ Rb.T) - 1) * 0.5
+        out = max(out, float(np.arccos(np.clip(c, -1, 1))))
+    return out
+
+
+def _relative_rotations(orc, cam):
+    R = [orc.rodrigues(c[4:7]) for c in cam]
+    return np.stack([R[i] @ R[0].T for i in range(len(R))])
+
+
+def test_device_present(pkg):
+    assert pkg.api.device_count() >= 1
+
+
+@pytest.mark.parametrize("n,count", [(8, 3), (63, 2), (64, 2), (65, 2), (200, 2), (800, 2), (1000, 1)])
+def test_chol_solve_vs_numpy(pkg, n, count):
+    """Dense SPD solve (panel + MFMA syrk + back-substitution).  Tolerance: residual |Ax-b|/(|A||x|) <= 1e-13
+    and x within 1e-9 relative of numpy's LAPACK solve for cond(A) ~ 1e4."""
+    rng = np.random.default_rng(1234 + n)
+    A = np.zeros((count, n, n)); b = rng.standard_normal((count, n))
+    for s in range(count):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        ev = np.logspace(0, 4, n)
+        A[s] = (Q * ev) @ Q.T
+        A[s] = 0.5 * (A[s] + A[s].T)
+    x, fail, ms = pkg.api.chol_solve_batch(A, b)
+    assert not fail.any()
+    for s in range(count):
+        ref = np.linalg.solve(A[s], b[s])
+        res = np.linalg.norm(A[s] @ x[s] - b[s]) / (np.linalg.norm(A[s]) * np.linalg.norm(x[s]))
+        assert res < 1e-13, res
+        assert _rel(x[s], ref) < 1e-9
+
+
+def test_chol_reports_indefinite(pkg):
+    n = 100
+    A = np.eye(n)[None].copy(); A[0, 50, 50] = -1.0
+    x, fail, _ = pkg.api.chol_solve_batch(A, np.ones((1, n)))
+    assert fail[0] == 1
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_linearize_vs_oracle(pkg, orc, ftype):
+    """One linearisation (K1): cost, U, g_c, V, g_r, W against the oracle's closed-form mode.
+    Tolerance 1e-11 relative to the largest entry of each quantity (FP64, different summation order)."""
+    sc = pkg.synth.make_scene(1, 20, 100, factor_type=ftype)
+    cam = sc.cam_init.copy()
+    if ftype == 1:
+        cam[:, 10] = 0.01
+    ray = sc.ray_init * (1.3 if ftype == 0 else 1.0)
+    b = pkg.api.BaBatch([sc])
+    b.set_state([cam], [ray])
+    g = b.linearize(0)
+    o = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_ANALYTIC)
+    sel = [0, 2, 3, 4] if ftype == 0 else [0, 2, 3, 4, 5]  # oracle keeps the dummy fy column (index 1)
+    assert abs(g["cost"] - o["cost"]) / o["cost"] < 1e-12
+    assert _rel(g["U"], o["U"][:, sel][:, :, sel]) < 1e-11
+    assert _rel(g["g_c"], o["g_c"][:, sel]) < 1e-11
+    assert _rel(g["V"], o["V"]) < 1e-11
+    assert _rel(g["g_r"], o["g_r"]) < 1e-11
+    assert _rel(g["W"], o["W"][:, sel, :]) < 1e-11
+    assert np.abs(o["W"][:, 1, :]).max() == 0.0  # the fy column the device drops is exactly zero
+    # and against the reference-faithful central-difference Jacobian: 1e-6 relative
+    on = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_NUMERIC)
+    assert _rel(g["W"], on["W"][:, sel, :]) < 1e-6
+    b.close()
+
+
+def test_pix2ray_vs_oracle(pkg, orc, scene_c1):
+    b = pkg.api.BaBatch([scene_c1])
+    b.set_state(None, [np.zeros_like(scene_c1.ray_init)])
+    b.pix2ray()
+    # read back through a linearize-free path: solve() starts from the stored state, so compare via get after 0 work
+    want = orc.pix2ray(scene_c1, scene_c1.cam_init)
+    assert _rel(scene_c1.ray_init, want) < 1e-12  # generator vs oracle
+    # device result: run a solve and check it matches a solve started from the oracle's rays
+    s1 = b.solve()
+    b2 = pkg.api.BaBatch([scene_c1]); b2.set_state(None, [want]); s2 = b2.solve()
+    assert s1[0]["num_iterations"] == s2[0]["num_iterations"]
+    assert abs(s1[0]["final_cost"] - s2[0]["final_cost"]) / s2[0]["final_cost"] < 1e-9
+    b.close(); b2.close()
+
+
+def _check_ba_parity(pkg, orc, sc, tol_param=1e-6):
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    # (1) against the oracle with the same (closed-form) Jacobians: tight
+    ocam, oray, _, osumm, otr = orc.ba_solve(sc, jacobian_mode=orc.JAC_ANALYTIC, trace=True, num_threads=8)
+    assert summ["termination_type"] == osumm["termination_type"]
+    assert summ["num_iterations"] == osumm["num_iterations"]
+    assert summ["num_lm_steps"] == osumm["num_lm_steps"]
+    assert summ["num_successful_steps"] == osumm["num_successful_steps"]
+    assert abs(summ["initial_cost"] - osumm["initial_cost"]) / osumm["initial_cost"] < 1e-12
+    assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-9
+    # (2) against the reference-faithful oracle (central differences, as Ceres NumericDiffCostFunction):
+    #     north_star tolerance 1e-6 relative on focal lengths and on relative rotations (gauge invariant)
+    ncam, nray, _, nsumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, num_threads=8)
+    assert summ["termination_type"] == nsumm["termination_type"]
+    assert summ["num_iterations"] == nsumm["num_iterations"]
+    for ref in (ocam, ncam):
+        assert _rel(cam[:, 0], ref[:, 0]) < tol_param
+        assert np.abs(_relative_rotations(orc, cam) - _relative_rotations(orc, ref)).max() < tol_param
+        if sc.factor_type == 1:
+            assert np.abs(cam[:, 10] - ref[:, 10]).max() < tol_param
+    # constant parameters untouched, fy mirrors nothing (stays at its initial value in the packed state)
+    assert np.array_equal(cam[:, [1, 2, 3, 7, 8, 9, 11, 12, 13, 14]], sc.cam_init[:, [1, 2, 3, 7, 8, 9, 11, 12, 13, 14]])
+    return cam, summ
+
+
+def test_ba_c1_parity(pkg, orc, scene_c1):
+    """BASELINE C1 (20 views x ~100 obs): identical LM trajectory bookkeeping, parameters within 1e-6."""
+    cam, summ = _check_ba_parity(pkg, orc, scene_c1)
+    assert summ["termination_type"] == 0
+
+
+def test_ba_c1_dist_parity(pkg, orc, scene_c1_dist):
+    """PTZRayDist factor (k1 free, behind-camera penalty branch compiled in)."""
+    _check_ba_parity(pkg, orc, scene_c1_dist)
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_ba_medium_parity(pkg, orc, seed):
+    """60 views x 300 obs/view (C3-shaped stand-in), several seeds; exercises rejected steps."""
+    sc = pkg.synth.make_scene(seed, 60, 300)
+    _check_ba_parity(pkg, orc, sc)
+
+
+def test_ba_c2_parity(pkg, orc):
+    """BASELINE C2 at full size: 200 views x 500 obs/view, one scene."""
+    sc = pkg.synth.make_scene(0, 200, 500)
+    cam, summ = _check_ba_parity(pkg, orc, sc)
+    assert summ["termination_type"] == 0
+    # accuracy yardstick (eval_synthetic.py metrics): focal error vs ground truth at noise level
+    assert np.abs(cam[:, 0] - sc.cam_gt[:, 0]).mean() < 2.0
+
+
+def test_ba_batch_matches_single(pkg, scene_c1):
+    """A batch of different scenes gives, per scene, bit-identical results to solving it alone
+    (fixed-order reductions; scenes never interact)."""
+    scenes = [pkg.synth.make_scene(s, 20 + 4 * s, 100) for s in range(4)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state()
+    for i, sc in enumerate(scenes):
+        cam1, ray1, s1 = pkg.api.ba_solve(sc)
+        assert s1["num_iterations"] == summ[i]["num_iterations"]
+        assert s1["final_cost"] == summ[i]["final_cost"]
+        assert np.array_equal(cam1, cams[i]) and np.array_equal(ray1, rays[i])
+    # idempotence of the stored initial state: solving twice gives the same answer
+    summ2 = b.solve(); cams2, _ = b.get_state()
+    assert all(np.array_equal(a, c) for a, c in zip(cams, cams2))
+    b.close()
+
+
+def test_ba_max_iterations_is_no_convergence(pkg, scene_c1):
+    """Hitting max_num_iterations is NO_CONVERGENCE (the reference then returns false, ptzray_optimizer.cc:482)."""
+    cam, ray, summ = pkg.api.ba_solve(scene_c1, max_num_iterations=2)
+    assert summ["termination_type"] == pkg.api.NO_CONVERGENCE
+    assert summ["num_iterations"] == 2
+
+
+def test_ba_invalid_inputs(pkg, scene_c1):
+    import copy
+    bad = copy.copy(scene_c1)
+    bad.obs_cam = scene_c1.obs_cam.copy(); bad.obs_cam[0] = scene_c1.n_cam + 3
+    with pytest.raises(pkg.api.PtzError) as e:
+        pkg.api.BaBatch([bad])
+    assert e.value.code == -1
+    with pytest.raises(pkg.api.PtzError):
+        pkg.api.BaBatch([scene_c1], max_num_iterations=0)  # CheckValid: max_iter_ <= 0
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_krt_batch_parity(pkg, orc, ftype):
+    """Batched single-view LM (K6) vs the oracle's KRT solve (numeric-diff Jacobian + Householder QR, as the
+    reference's NumericDiffCostFunction + DENSE_QR): same termination and iteration counts, refined f and
+    rotation within 1e-6 relative."""
+    rb = pkg.synth.make_reloc_batch(48, 128, seed_id=ftype, factor_type=ftype)
+    cam_w, summ, acc, ms = pkg.api.krt_solve_batch(rb)
+    n_acc = 0
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype,
+                                      jacobian_mode=orc.JAC_NUMERIC)
+        ok = orc.krt_check(osumm, loc, 100.0)
+        assert summ[q]["termination_type"] == osumm["termination_type"]
+        assert summ[q]["num_iterations"] == osumm["num_iterations"]
+        assert bool(acc[q]) == ok
+        if ok:
+            n_acc += 1
+            want = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
+            assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
+            assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
+            assert cam_w[q, 1] == cam_w[q, 0]
+            if ftype == 1:
+                assert abs(cam_w[q, 10] - want[10]) < 1e-6
+            # ground truth recovered at noise level
+            assert abs(cam_w[q, 0] - rb.cam_gt[q, 0]) / rb.cam_gt[q, 0] < 0.02
+        else:
+            assert np.array_equal(cam_w[q], rb.cam_init[q])  # outputs untouched on failure
+    assert n_acc >= rb.n_query * 0.8
+
+
+def test_krt_ragged_and_degenerate(pkg, orc):
+    """Ragged match counts, including a query with too few matches to constrain 4 parameters."""
+    rb = pkg.synth.make_reloc_batch(6, 64, seed_id=9)
+    keep = [64, 1, 17, 64, 5, 33]
+    idx = np.concatenate([np.arange(rb.match_ptr[q], rb.match_ptr[q] + k) for q, k in enumerate(keep)])
+    rb.uv_ref, rb.uv_cur = rb.uv_ref[idx], rb.uv_cur[idx]
+    rb.match_ptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, jacobian_mode=orc.JAC_ANALYTIC)
+        assert summ[q]["num_residuals"] == 2 * keep[q]
+        if keep[q] >= 5:
+            assert summ[q]["termination_type"] == osumm["termination_type"]
+            assert summ[q]["num_iterations"] == osumm["num_iterations"]
