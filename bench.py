@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- PTZ-IBA LM throughput on MI355X (BASELINE.json metric: LM iterations/sec + views calibrated/sec,
+200-view synthetic PTZ rig).
+
+A "step" is one pass of the hot path over one batch: every scene of the per-GPU shard is solved from its
+initial guess to Ceres-style termination (ptz_ba_batch_solve).  Inputs (observations, structure, initial
+state) are resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, backend
+nccl = RCCL), each rank owns its own scenes (weak scaling, no data-path collective); the timed region is
+bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--views 200] [--obs 500]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; the in-repo guide lists no f64 figure
+
+
+def kernel_models(scenes, nc):
+    """Algorithmic bytes / flops per kernel family and per LM pass, summed over the scenes of one batch
+    (SURVEY.md section 8(d) per-unit figures; DESIGN.md 'Roofline accounting')."""
+    m = {}
+    n_obs = sum(s.n_obs for s in scenes)
+    n_ray = sum(s.n_ray for s in scenes)
+    ent = sum(int((s.ray_weight_local * (s.ray_weight_local + 1) // 2).sum()) for s in scenes)
+    syrk_flops = 0.0
+    chol_flops = 0.0
+    s_bytes = 0.0
+    for s in scenes:
+        n = nc * s.n_cam
+        chol_flops += n ** 3 / 3.0 + 2.0 * n * n
+        s_bytes += 8.0 * n * (n + 1) / 2
+        k = 0
+        while 64 * (k + 1) < n + 1:
+            r = n + 1 - 64 * (k + 1)
+            syrk_flops += float(r) * r * 64.0
+            k += 1
+    m["linearize"] = dict(bound="hbm", bytes=16.0 * n_obs + 104.0 * n_ray)
+    m["eval"] = dict(bound="hbm", bytes=16.0 * n_obs + 96.0 * n_ray)
+    m["ray_prep"] = dict(bound="hbm", bytes=96.0 * n_ray)
+    m["backsub"] = dict(bound="hbm", bytes=96.0 * n_ray)
+    m["schur"] = dict(bound="hbm", bytes=s_bytes + 2.0 * 8.0 * nc * 3 * n_obs, flops=ent * 2.0 * nc * 3 * nc)
+    m["chol_syrk"] = dict(bound="mfma", flops=syrk_flops)
+    m["chol_panel"] = dict(bound="mfma", flops=max(chol_flops - syrk_flops, 0.0))
+    m["chol_total_flops"] = chol_flops
+    return m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="scenes per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct seeded scenes generated per GPU (cycled to fill the batch)")
+    ap.add_argument("--views", type=int, default=200)
+    ap.add_argument("--obs", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-scene", action="store_true", help="also time one scene alone (latency-bound C2)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = ge.load_package()
+    B = args.batch
+    distinct = max(1, min(B, args.distinct))
+    base = [pkg.synth.make_scene(rank * distinct + i, args.views, args.obs) for i in range(distinct)]
+    scenes = [base[i % distinct] for i in range(B)]
+    for s in base:
+        s.ray_weight_local = np.bincount(s.obs_ray, minlength=s.n_ray).astype(np.int64)
+    batch = pkg.api.BaBatch(scenes, device_id=local_rank)
+    batch.set_state()  # observations, structure and the initial state are now resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        summ = batch.solve()
+    batch.set_profiling(True)  # HIP events around every kernel family on the solver's own stream
+    barrier()
+    t0 = time.perf_counter()
+    lm_steps = 0
+    for _ in range(args.steps):
+        summ = batch.solve()
+        lm_steps += sum(s["num_lm_steps"] for s in summ)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = batch.get_profile()
+    batch.set_profiling(False)
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ws = torch.tensor([float(lm_steps), float(B * args.views * args.steps),
+                       float(sum(1 for s in summ if s["termination_type"] == 0))], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ws, op=dist.ReduceOp.SUM)
+    t_max = float(tt.item())
+    total_steps, total_views, n_conv = (float(v) for v in ws.tolist())
+
+    out = None
+    if rank == 0:
+        models = kernel_models(scenes, batch.nc)
+        per = {k: v for k, v in prof.items() if v["launches"] > 0}
+        # dominant kernel family = largest device time among the families whose work scales with the batch
+        cand = [k for k in per if k in models and k != "chol_total_flops"]
+        dom = max(cand, key=lambda k: per[k]["ms"])
+        passes = lm_steps / max(len(scenes), 1) / args.steps  # mean LM passes per scene
+        launches = per[dom]["launches"]
+        avg_ms = per[dom]["ms"] / launches
+        mdl = models[dom]
+        n_pass_launches = per["ray_prep"]["launches"]  # one ray_prep launch per LM pass
+        if mdl["bound"] == "mfma":
+            per_launch = mdl["flops"] * (n_pass_launches / launches)  # family flops per pass spread over its launches
+            # only scenes still active do work: scale by the mean active fraction
+            active_frac = (lm_steps / args.steps) / (len(scenes) * (n_pass_launches / args.steps))
+            achieved = per_launch * active_frac / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, avg_launch_ms=avg_ms, launches=launches)
+        else:
+            per_launch = mdl["bytes"] * (n_pass_launches / launches)
+            active_frac = (lm_steps / args.steps) / (len(scenes) * (n_pass_launches / args.steps))
+            achieved = per_launch * active_frac / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms, launches=launches)
+        out = {
+            "metric": "LM iterations/sec (PTZ-IBA global BA, 200-view synthetic PTZ rig)",
+            "value": total_steps / t_max,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C2-shaped PTZ-IBA scenes ({args.views} views x {args.obs} obs/view, PTZRay factor), "
+                                   f"{B} scenes per GPU solved concurrently ({distinct} distinct seeds per GPU)",
+                       "scenes_per_gpu": B, "views": args.views, "obs_per_view": args.obs,
+                       "n_obs_per_scene": base[0].n_obs, "n_ray_per_scene": base[0].n_ray,
+                       "parallelism": f"scene-sharded x{world}"},
+            "views_per_s": total_views / t_max,
+            "lm_steps_per_solve": total_steps / args.steps / world,
+            "converged_scenes": int(n_conv), "scenes_total": B * world,
+            "roofline": roof,
+            "kernel_ms_per_solve": {k: round(v["ms"] / args.steps, 3) for k, v in per.items()},
+        }
+        if args.single_scene:
+            b1 = pkg.api.BaBatch([base[0]], device_id=local_rank)
+            b1.set_state(); b1.solve()
+            t1 = time.perf_counter(); s1 = b1.solve(); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+            out["single_scene"] = {"lm_iterations_per_s": s1[0]["num_lm_steps"] / d1, "ms_per_solve": 1e3 * d1,
+                                   "lm_steps": s1[0]["num_lm_steps"]}
+            b1.close()
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline: the reference-faithful oracle (central-difference Jacobians over all 18 block
+            # parameters as ceres::NumericDiffCostFunction, Ceres-1.14 LM policy, dense Schur) on ONE scene of the
+            # same workload, all host cores.  A restatement ("port"), not the Ceres/OpenCV binary.
+            orc = ge.load_oracle()
+            orc.build()
+            cores = orc.usable_cores()
+            t1 = time.perf_counter()
+            _, _, _, osumm, _ = orc.ba_solve(base[0], jacobian_mode=orc.JAC_NUMERIC, num_threads=cores)
+            d1 = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": osumm["num_lm_steps"] / d1, "unit": "LM iterations/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": f"1 scene of the same workload (seed {base[0].seed:#x}), {osumm['num_lm_steps']} LM "
+                                             f"iterations to termination, {d1:.2f} s, numeric-diff oracle with OpenMP"}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

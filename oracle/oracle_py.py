@@ -58,6 +58,19 @@ class KrtProblem(C.Structure):
                 ("factor_type", C.c_int32)]
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: min(affinity, cgroup quota).  The GPU box shows 256 logical
+    CPUs but caps the container at a CFS quota; oversubscribed spinning OpenMP threads stall for minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle (and oracle/_ref when /root/reference is mounted).  Building the checker is
     not using it."""
@@ -76,6 +89,8 @@ def lib():
         so = os.path.join(_HERE, "libptz_oracle.so")
         if not os.path.exists(so):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # before libgomp initialises
+        os.environ.setdefault("GOMP_SPINCOUNT", "0")
         _LIB = C.CDLL(so)
         _LIB.orc_ba_cam_free_dim.restype = C.c_int32
         _LIB.orc_tracks_build.restype = C.c_int32
@@ -140,6 +155,7 @@ def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, **
     ray = np.array(scene.ray_init if ray0 is None else ray0, dtype=np.float64, order="C").copy()
     tlw = np.zeros(6) if tlw0 is None else np.array(tlw0, dtype=np.float64).copy()
     o = default_options(**opt)
+    o.num_threads = max(1, min(o.num_threads, usable_cores()))
     s = LmSummary()
     t, arrs = _mk_trace(o.max_num_iterations + 2) if trace else (None, None)
     rc = lib().orc_ba_solve(C.byref(p), _p(cam), _p(ray), _p(tlw), C.byref(o), C.byref(s),
