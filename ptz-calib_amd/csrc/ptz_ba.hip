@@ -10,10 +10,11 @@
 //
 // Per LM pass and scene (all scenes of the batch advance in lock-step, finished scenes early-out):
 //   lm_pre      finalize the previous iteration, termination checks               [1 block / scene]
-//   ray_prep    E = (V + D^2)^-1 per ray, z = E g_r, Y_a = W_a E                   [thread / ray]
+//   ray_prep    E = (V + D^2)^-1 per ray, z = E g_r                                [thread / ray]
 //   cam_diag    LM diagonal of the camera blocks                                   [thread / camera]
-//   schur       S_ij = [i=j](U_i + D_i^2) - sum_{tracks seen by i and j} Y_a W_b^T [lane group / camera pair]
-//   rhs         b_i = g_i - sum_a W_a z_ray(a)  (written as row n of the padded S) [wave / camera]
+//   schur       row-block i of the reduced system: T_a = W_a E staged in LDS, S_ii, b_i, then
+//               S_ij = - sum_{tracks seen by i and j} T_a W_b^T for j < i          [workgroup / camera]
+//               (b is written as row n of the padded S)
 //   cholesky    S y_c = b  (ptz_chol.hip: panel + MFMA syrk per 64-wide block column, back-substitution)
 //   backsub     y_r = E (g_r - sum_a W_a^T y_c), candidate ray                     [thread / ray]
 //   cam_update  candidate camera, its rotation block                              [thread / camera]
@@ -35,7 +36,8 @@ namespace ptz {
 
 namespace {
 
-constexpr int RAY_BLOCK = 256;  // rays per workgroup in the ray-centric kernels
+constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
+constexpr int WS = 16;           // doubles per observation row of W (NC*3 used): one aligned 128-B line
 
 struct SceneDev {
   int n_cam, n_ray, n_obs, n_pair;
@@ -77,7 +79,8 @@ struct Dev {
   const int* pair_ci;   // scene-local camera ids, ci >= cj
   const int* pair_cj;
   const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
-  const int2* ent;      // (obs a of ci, obs b of cj), global obs indices
+  const int* cam_pair;  // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local pair range of each camera ci
+  const int2* ent;      // (position of obs a in ci's observation list, global obs index b of cj); ci > cj only
   const double* ray_w;
   // state: two buffers, LmState.cur selects the current one
   double* cam_x;  // [2][total_cam][15]
@@ -101,8 +104,7 @@ struct Dev {
   double* E;         // [total_ray][6]
   double* z;         // [total_ray][3]
   double* dr;        // [total_ray][3] scaled-space ray step
-  double* W;         // [total_obs][NC*3]
-  double* Y;         // [total_obs][NC*3]
+  double* W;         // [total_obs][WS] (NC*3 used)
   double* partial;   // [total_chunk][2]
   // LM
   LmState* lm;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
-    double* Wa = d.W + (size_t)a * (NC * 3);
+    double* Wa = d.W + (size_t)a * WS;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
@@ -374,7 +376,6 @@ __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
@@ -412,18 +413,6 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
   d.z[(size_t)gj * 3 + 0] = E[0] * g0 + E[1] * g1 + E[3] * g2;
   d.z[(size_t)gj * 3 + 1] = E[1] * g0 + E[2] * g1 + E[4] * g2;
   d.z[(size_t)gj * 3 + 2] = E[3] * g0 + E[4] * g1 + E[5] * g2;
-  const int* rp = d.ray_ptr + s.ray_off + sc;
-  for (int a = rp[j]; a < rp[j + 1]; ++a) {
-    const double* Wa = d.W + (size_t)a * (NC * 3);
-    double* Ya = d.Y + (size_t)a * (NC * 3);
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const double w0 = Wa[3 * k], w1 = Wa[3 * k + 1], w2 = Wa[3 * k + 2];
-      Ya[3 * k + 0] = w0 * E[0] + w1 * E[1] + w2 * E[3];
-      Ya[3 * k + 1] = w0 * E[1] + w1 * E[2] + w2 * E[4];
-      Ya[3 * k + 2] = w0 * E[3] + w1 * E[4] + w2 * E[5];
-    }
-  }
 }
 
 template <int TYPE>
@@ -442,78 +431,120 @@ __global__ void k_cam_diag(Dev d)
     d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
 }
 
-// ---- schur: reduced camera system blocks ------------------------------------------------------------------
-// A group of LANES lanes owns one camera pair (ci >= cj); lane (p, q) accumulates element (p, q) of
-//   S_ij = [i == j] (U_i + D_i^2) - sum_entries Y_a W_b^T
-// over the pair's entry list (a = observation of ci, b = observation of cj, same ray).
+// ---- schur: one workgroup per camera ci -------------------------------------------------------------------
+// Phase 1 (all threads, strided over ci's observations a): T_a = W_a E_ray(a) into LDS; at the same time the
+//   diagonal block S_ii = U_i + D_i^2 - sum_a T_a W_a^T and the right-hand side b_i = g_i - sum_a W_a z_ray(a)
+//   (z = E g_r) are reduced over the workgroup.  b is stored as row n of the padded system.
+// Phase 2 (16-lane groups over ci's camera pairs (ci, cj < ci)): each lane takes entries e = lane, lane+16, ...
+//   of the pair (T_a from LDS, W_b = one aligned 128-B line from L2), accumulates the whole NC x NC product in
+//   registers, the group is reduced with a fixed butterfly and lane 0 stores S_ij = -sum.
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_schur(Dev d)
 {
   constexpr int NC = BaDims<TYPE>::NC;
-  constexpr int LANES = (NC == 4) ? 16 : 32;
-  constexpr int PPB = 256 / LANES;
+  constexpr int NU = NC * (NC + 1) / 2;
+  constexpr int NT = NC * 3;
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
+  const int ci = blockIdx.x;
+  if (ci >= s.n_cam) return;
   const LmState& st = d.lm[sc];
-  const int pr = blockIdx.x * PPB + threadIdx.x / LANES;
-  if (pr >= s.n_pair) return;
-  const int l = threadIdx.x % LANES;
-  if (l >= NC * NC) return;
-  const int p = l / NC, q = l % NC;
-  const int gp = s.pair_off + pr;
-  const int ci = d.pair_ci[gp], cj = d.pair_cj[gp];
-  const int* pp = d.pair_ptr + s.pair_off + sc;
-  double acc = 0;
-  for (int e = pp[pr]; e < pp[pr + 1]; ++e) {
-    const int2 ab = d.ent[e];
-    const double* Ya = d.Y + (size_t)ab.x * (NC * 3) + 3 * p;
-    const double* Wb = d.W + (size_t)ab.y * (NC * 3) + 3 * q;
-    acc += Ya[0] * Wb[0] + Ya[1] * Wb[1] + Ya[2] * Wb[2];
-  }
-  double v = -acc;
-  if (ci == cj) {
-    const int gi = s.cam_off + ci;
-    v += d.U[(size_t)gi * NC * NC + p * NC + q];
-    if (p == q) {
-      const double D = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
-      v += D * D;
-    }
-  }
-  const int np = d.chol.np;
-  d.chol.A[(size_t)sc * np * np + (size_t)(ci * NC + p) * np + cj * NC + q] = v;
-}
-
-// ---- rhs: b_i = g_i - sum_a W_a z_ray(a), stored as row n of the padded system ---------------------------
-template <int TYPE>
-__global__ __launch_bounds__(256) void k_rhs(Dev d)
-{
-  constexpr int NC = BaDims<TYPE>::NC;
-  const int sc = blockIdx.y;
-  if (!d.active[sc]) return;
-  const SceneDev s = d.scene[sc];
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= s.n_cam) return;
-  const int lane = threadIdx.x & 63;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int* cp = d.cam_ptr + s.cam_off + sc;
-  double b[NC];
+  const int o0 = cp[ci], no = cp[ci + 1] - o0;
+  double* T = lds;                 // [no][NT]
+  double* scratch = lds + (size_t)no * NT;  // [16]
+  double bsum[NC], D[NU];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) b[k] = 0;
-  for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
-    const int a = d.cam_obs[q];
+  for (int k = 0; k < NC; ++k) bsum[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) D[k] = 0;
+  for (int q = threadIdx.x; q < no; q += 256) {
+    const int a = d.cam_obs[o0 + q];
     const int gj = s.ray_off + d.obs_ray[a];
     const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
-    const double* Wa = d.W + (size_t)a * (NC * 3);
+    const double* E = d.E + (size_t)gj * 6;
+    const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
+    double w[NT];
+    const double* Wa = d.W + (size_t)a * WS;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) b[k] += Wa[3 * k] * z0 + Wa[3 * k + 1] * z1 + Wa[3 * k + 2] * z2;
+    for (int k = 0; k < NT; ++k) w[k] = Wa[k];
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+      const double w0 = w[3 * p], w1 = w[3 * p + 1], w2 = w[3 * p + 2];
+      bsum[p] += w0 * z0 + w1 * z1 + w2 * z2;
+      const double t0 = w0 * e0 + w1 * e1 + w2 * e3, t1 = w0 * e1 + w1 * e2 + w2 * e4, t2 = w0 * e3 + w1 * e4 + w2 * e5;
+      T[q * NT + 3 * p] = t0; T[q * NT + 3 * p + 1] = t1; T[q * NT + 3 * p + 2] = t2;
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
+    }
   }
 #pragma unroll
-  for (int k = 0; k < NC; ++k) b[k] = wave_sum(b[k]);
-  if (lane == 0) {
-    const int np = d.chol.np;
-    double* row = d.chol.A + (size_t)sc * np * np + (size_t)s.n * np;
+  for (int k = 0; k < NC; ++k) bsum[k] = block_sum(bsum[k], scratch);
 #pragma unroll
-    for (int k = 0; k < NC; ++k) row[i * NC + k] = d.gc[(size_t)(s.cam_off + i) * NC + k] - b[k];
+  for (int k = 0; k < NU; ++k) D[k] = block_sum(D[k], scratch);   // (also orders the T stores before phase 2)
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  if (threadIdx.x == 0) {
+    const int gi = s.cam_off + ci;
+    double* row = A + (size_t)s.n * np;
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+      row[ci * NC + p] = d.gc[(size_t)gi * NC + p] - bsum[p];
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) {
+        double v = d.U[(size_t)gi * NC * NC + p * NC + qq] - D[e++];
+        if (p == qq) {
+          const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+          v += Dd * Dd;
+        }
+        A[(size_t)(ci * NC + p) * np + ci * NC + qq] = v;
+        A[(size_t)(ci * NC + qq) * np + ci * NC + p] = v;
+      }
+    }
+  }
+  // ---- phase 2: off-diagonal blocks of row-block ci
+  const int* cpair = d.cam_pair + s.cam_off + sc;
+  const int* pp = d.pair_ptr + s.pair_off + sc;
+  const int l = threadIdx.x & 15;
+  for (int pr = cpair[ci] + (threadIdx.x >> 4); pr < cpair[ci + 1]; pr += 16) {
+    double acc[NC * NC];
+#pragma unroll
+    for (int k = 0; k < NC * NC; ++k) acc[k] = 0;
+    for (int e = pp[pr] + l; e < pp[pr + 1]; e += 16) {
+      const int2 ab = d.ent[e];
+      const double* Ta = T + ab.x * NT;
+      const double* Wb = d.W + (size_t)ab.y * WS;
+      double wb[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) wb[k] = Wb[k];
+#pragma unroll
+      for (int p = 0; p < NC; ++p) {
+        const double t0 = Ta[3 * p], t1 = Ta[3 * p + 1], t2 = Ta[3 * p + 2];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[p * NC + q] += t0 * wb[3 * q] + t1 * wb[3 * q + 1] + t2 * wb[3 * q + 2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC * NC; ++k) {
+      double v = acc[k];
+      v += __shfl_xor(v, 8, 16);
+      v += __shfl_xor(v, 4, 16);
+      v += __shfl_xor(v, 2, 16);
+      v += __shfl_xor(v, 1, 16);
+      acc[k] = v;
+    }
+    if (l == 0) {
+      const int cj = d.pair_cj[s.pair_off + pr];
+      double* S = A + (size_t)(ci * NC) * np + cj * NC;
+#pragma unroll
+      for (int p = 0; p < NC; ++p)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) S[(size_t)p * np + q] = -acc[p * NC + q];
+    }
   }
 }
 
@@ -536,7 +567,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_backsub(Dev d)
   double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
   const int* rp = d.ray_ptr + s.ray_off + sc;
   for (int a = rp[j]; a < rp[j + 1]; ++a) {
-    const double* Wa = d.W + (size_t)a * (NC * 3);
+    const double* Wa = d.W + (size_t)a * WS;
     const double* y = lds + d.obs_cam[a] * NC;
 #pragma unroll
     for (int k = 0; k < NC; ++k) { t0 -= Wa[3 * k] * y[k]; t1 -= Wa[3 * k + 1] * y[k]; t2 -= Wa[3 * k + 2] * y[k]; }
@@ -802,7 +833,7 @@ struct ptz_ba_batch {
   int n_scene = 0, type = 0, nc = 4, device = 0;
   std::vector<SceneDev> scenes;
   int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;
-  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0;
+  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0;
   ptz_lm_options opt;
   Dev d;
   std::vector<void*> allocs;
@@ -900,6 +931,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   }
   const int max_it = b->opt.max_num_iterations;
   const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16);
+  const size_t schur_smem = sizeof(double) * ((size_t)b->max_cam_obs * NC * 3 + 16);
   for (int pass = 0; pass <= max_it; ++pass) {
     b->prof_begin(P_LMCTL);
     LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
@@ -913,10 +945,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     chol_clear(d.chol, st);
     b->prof_end();
     b->prof_begin(P_SCHUR);
-    LAUNCH(k_schur<TYPE>, dim3((b->max_pair + (NC == 4 ? 16 : 8) - 1) / (NC == 4 ? 16 : 8), B), dim3(256), 0, d);
-    b->prof_end();
-    b->prof_begin(P_RHS);
-    LAUNCH(k_rhs<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, d);
+    LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(256), schur_smem, d);
     b->prof_end();
     chol_factor_solve_profiled(d.chol, d.yc, st, b);
     b->prof_begin(P_BACKSUB);
@@ -1077,6 +1106,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<float2> h_uv;
   std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr;
   std::vector<int2> h_ent;
+  std::vector<int> h_campair;
   std::vector<double> h_w;
   int64_t tot_obs = 0, tot_ent = 0;
   for (int i = 0; i < n; ++i) {
@@ -1117,36 +1147,50 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       for (int64_t a = 0; a < p.n_obs; ++a) h_camobs[base + fill[p.obs_cam[a]]++] = obase + (int)a;
       for (int c = 0; c <= p.n_cam; ++c) h_camptr.push_back(obase + cnt_cam[c]);
     }
-    // camera-pair entry lists: for every ray, every (a, b) with cam(a) >= cam(b)
+    // camera-pair entry lists (off-diagonal blocks): for every ray, every (a, b) with cam(a) > cam(b);
+    // a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur)
     {
+      std::vector<int> pos(p.n_obs);
+      {
+        std::vector<int> fill(p.n_cam, 0);
+        for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
+        for (int c = 0; c < p.n_cam; ++c) b->max_cam_obs = std::max(b->max_cam_obs, fill[c]);
+      }
       std::vector<int64_t> keys;  // (ci * n_cam + cj) << 32 | running index
       std::vector<int2> ents;
       for (int j = 0; j < p.n_ray; ++j) {
         for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
           for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
             const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
-            if (ci < cj) continue;
             if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
+            if (ci <= cj) continue;
             keys.push_back(((int64_t)ci * p.n_cam + cj) << 32 | (int64_t)ents.size());
-            ents.push_back(make_int2(obase + a, obase + bb));
+            ents.push_back(make_int2(pos[a], obase + bb));
           }
       }
       std::sort(keys.begin(), keys.end());
       if ((int64_t)b->total_ent + (int64_t)ents.size() > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
       int64_t prev = -1;
       int npair = 0;
+      std::vector<int> cam_first(p.n_cam + 1, -1);
       for (size_t e = 0; e < keys.size(); ++e) {
         const int64_t key = keys[e] >> 32;
         if (key != prev) {
-          h_pci.push_back((int)(key / p.n_cam));
+          const int ci = (int)(key / p.n_cam);
+          h_pci.push_back(ci);
           h_pcj.push_back((int)(key % p.n_cam));
           h_pptr.push_back(b->total_ent + (int)e);
+          if (cam_first[ci] < 0) cam_first[ci] = npair;
           prev = key;
           ++npair;
         }
         h_ent.push_back(ents[keys[e] & 0xffffffff]);
       }
       h_pptr.push_back(b->total_ent + (int)keys.size());
+      // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
+      cam_first[p.n_cam] = npair;
+      for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
+      for (int c = 0; c <= p.n_cam; ++c) h_campair.push_back(cam_first[c]);
       s.n_pair = npair;
       b->total_ent += (int)keys.size();
       b->total_pair += npair;
@@ -1176,6 +1220,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(upload(b, h_pci, &d.pair_ci));
   TRY(upload(b, h_pcj, &d.pair_cj));
   TRY(upload(b, h_pptr, &d.pair_ptr));
+  TRY(upload(b, h_campair, &d.cam_pair));
   TRY(upload(b, h_ent, &d.ent));
   TRY(upload(b, h_w, &d.ray_w));
   d.cam_stride = (size_t)b->total_cam * 15;
@@ -1199,8 +1244,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.dr, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.W, (size_t)b->total_obs * NC * 3));
-  TRY(b->alloc(&d.Y, (size_t)b->total_obs * NC * 3));
+  TRY(b->alloc(&d.W, (size_t)b->total_obs * WS));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
@@ -1217,6 +1261,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   TRY(b->alloc(&d.chol.A, (size_t)n * d.chol.np * d.chol.np));
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
+  TRY(b->alloc(&d.chol.Dinv, (size_t)n * (d.chol.np / CHOL_NB) * 4 * 16 * 16));
   TRY(b->alloc(&d.chol.fail, (size_t)n));
   d.chol.active = d.active;
   TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));
@@ -1242,11 +1287,17 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
   const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16));
   const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CAMBLK);
+  const int schur_smem = (int)(sizeof(double) * ((size_t)b->max_cam_obs * NC * 3 + 16));
+  if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
   if (type == PTZ_BA_PTZRay) {
+    (void)hipFuncSetAttribute((const void*)k_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
+    (void)hipFuncSetAttribute((const void*)k_backsub<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * b->max_n));
     (void)hipFuncSetAttribute((const void*)k_eval<0>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
     (void)hipFuncSetAttribute((const void*)k_lin_ray<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
   }
   else {
+    (void)hipFuncSetAttribute((const void*)k_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
+    (void)hipFuncSetAttribute((const void*)k_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * b->max_n));
     (void)hipFuncSetAttribute((const void*)k_eval<1>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
     (void)hipFuncSetAttribute((const void*)k_lin_ray<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
   }
@@ -1359,7 +1410,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
       q[0] = p[0]; q[1] = p[1]; q[2] = p[3]; q[3] = p[1]; q[4] = p[2]; q[5] = p[4]; q[6] = p[3]; q[7] = p[4]; q[8] = p[5];
     }
   }
-  if (W) PTZ_HIP_TRY(hipMemcpy(W, d.W + (size_t)s.obs_off * NC * 3, sizeof(double) * NC * 3 * s.n_obs, hipMemcpyDeviceToHost));
+  if (W) PTZ_HIP_TRY(hipMemcpy2D(W, sizeof(double) * NC * 3, d.W + (size_t)s.obs_off * WS, sizeof(double) * WS, sizeof(double) * NC * 3, s.n_obs, hipMemcpyDeviceToHost));
   return PTZ_OK;
 }
 

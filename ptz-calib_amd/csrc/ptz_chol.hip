@@ -6,11 +6,11 @@
 // 360-degree rig the reduced system is ~30 % dense at camera-block level, so it is factored densely.
 //
 // Layout: right-looking, 64 x 64 tiles, lower triangle, in place in A[count][np][np] (row-major).
-//   step k:  chol_panel  : one wave per tile of block column k.  Tile (k,k) is factored in registers
-//                          (lane = row, left-looking, L rows broadcast through LDS); every off-diagonal
-//                          tile redoes that 64 x 64 factorisation locally (no inter-workgroup wait) and
-//                          then solves X L_kk^T = A_ik by substitution.  The factored diagonal tile is
-//                          written to Ldiag, never back into A, so concurrent readers see A_kk intact.
+//   step k:  chol_diag   : one 4-wave workgroup factors tile (k,k) (left-looking, lane = row, the inner sum
+//                          split over the waves) and inverts its four 16x16 diagonal blocks.  L_kk goes to
+//                          Ldiag, never back into A.
+//            chol_trsm   : one workgroup per off-diagonal tile of block column k: X L_kk^T = A_ik, blocked by
+//                          16 columns, v_mfma_f64_16x16x4_f64 with the block inverses.
 //            chol_syrk   : one 256-thread workgroup per trailing tile (i >= j > k):
 //                          A_ij -= L_ik L_jk^T with v_mfma_f64_16x16x4_f64, operands staged through LDS.
 //   The right-hand side rides along as row n of the padded matrix (diagonal = CHOL_BIG), so the forward
@@ -25,6 +25,15 @@ constexpr int NB = CHOL_NB;
 constexpr int LD = NB + 2;  // LDS row stride in doubles: 16-byte aligned rows, conflict-free fragment reads
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// 1/sqrt(d): hardware seed (v_rsq_f64) + two Newton steps; d <= 0 propagates NaN/inf (flagged by the caller)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
 
 // coalesced 64x64 tile copy global (row stride ld) -> LDS (row stride LD); nthreads * 16 B per pass
 template <int NTHREADS, bool NEGATE>
@@ -62,74 +71,151 @@ __global__ void chol_pad_kernel(CholBatch cb)
   if (i == n) cb.fail[sys] = 0;
 }
 
-// ---- panel: potrf of the diagonal tile + triangular solve of one off-diagonal tile --------------------
-__global__ __launch_bounds__(64) void chol_panel_kernel(CholBatch cb, int k)
+// ---- diag: Cholesky of the diagonal tile by one 4-wave workgroup ----------------------------------------
+// lane = row i in every wave; wave w owns the columns q with (q >> 1) & 3 == w (pairs, so its LDS reads of
+// L[j][q] are 16-byte reads) and accumulates its share of  sum_{q<j} L[i][q] L[j][q];  the four partial sums
+// meet in LDS.  Then the four 16x16 diagonal blocks of L are inverted (64 lanes = 4 blocks x 16 columns) for the
+// MFMA triangular solve of chol_trsm.  Outputs: Ldiag[sys][k] = L_kk (upper part zero), Dinv[sys][k][4][16x16].
+constexpr int DB = 16;              // diagonal sub-block order
+constexpr int LDD = DB + 2;         // LDS row stride of a 16x16 block
+__global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __restrict__ Dinv, int k)
 {
   const int sys = blockIdx.y;
   if (cb.active && !cb.active[sys]) return;
-  const int r = blockIdx.x;  // 0: diagonal tile; r >= 1: tile (k + r, k)
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  if (k * NB > n) return;             // whole block column is padding (identity)
-  if (r >= 1 && (k + r) * NB > n) return;  // tile rows are all padding (zero below the diagonal)
-  double* A = cb.A + (size_t)sys * np * np;
-  __shared__ __attribute__((aligned(16))) double Ls[NB * LD];  // L_kk rows (broadcast reads)
-  __shared__ __attribute__((aligned(16))) double St[NB * LD];  // staging
+  if (k * NB > n) return;  // whole block column is padding (identity)
+  const double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double Ls[NB * LD];
+  __shared__ double part[4][NB];
   __shared__ double rinv[NB];
-  const int lane = threadIdx.x;
-
-  tile_g2s<64, false>(A + (size_t)(k * NB) * np + k * NB, np, St);
+  __shared__ int okflag;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, Ls);
+  if (threadIdx.x == 0) okflag = 1;
   __syncthreads();
-  double a[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = St[lane * LD + c];
-  __syncthreads();
-
-  // left-looking Cholesky, lane = row i:  L[i][j] = (A[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j]
-  bool ok = true;
+  double aw[NB / 4];  // L[i][q] for this wave's columns q = 8 * (t >> 1) + 2 * w + (t & 1)
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    double s = a[j];
+    double p0 = 0, p1 = 0;
 #pragma unroll
-    for (int q = 0; q < j; ++q) s -= a[q] * Ls[j * LD + q];
-    const double d = __shfl(s, j, WAVE);
-    // pivots of padding rows (>= n) are 1 or CHOL_BIG - |y|^2 and never count as failures
-    if (!(d > 0.0) && (k * NB + j) < n) ok = false;
-    const double ird = 1.0 / sqrt(d);
-    const double l = (lane == j) ? d * ird : ((lane > j) ? s * ird : 0.0);
-    a[j] = l;
-    Ls[lane * LD + j] = l;
-    if (lane == j) rinv[j] = ird;
+    for (int t = 0; t < NB / 4; t += 2) {
+      const int q = 8 * (t >> 1) + 2 * w;  // first column of the pair; w is wave-uniform
+      if (q + 1 < j) {
+        const double2 l2 = *reinterpret_cast<const double2*>(Ls + j * LD + q);
+        p0 += aw[t] * l2.x;
+        p1 += aw[t + 1] * l2.y;
+      }
+      else if (q < j) {
+        p0 += aw[t] * Ls[j * LD + q];
+      }
+    }
+    part[w][lane] = p0 + p1;
+    __syncthreads();
+    const double sres = Ls[lane * LD + j] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    const double d = __shfl(sres, j, WAVE);
+    if (!(d > 0.0) && (k * NB + j) < n && threadIdx.x == 0) okflag = 0;
+    const double ird = rsqrt_nr(d);
+    const double l = (lane == j) ? d * ird : ((lane > j) ? sres * ird : 0.0);
+    if (((j >> 1) & 3) == w) aw[2 * (j >> 3) + (j & 1)] = l;
+    __syncthreads();  // everyone has read column j of A and the partials
+    if (w == 0) {
+      Ls[lane * LD + j] = l;
+      if (lane == j) rinv[j] = ird;
+    }
+    __syncthreads();
+  }
+  // zero the strict upper triangle (it still holds A) and publish L_kk
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    if (c > r) Ls[r * LD + c] = 0.0;
   }
   __syncthreads();
+  tile_s2g<256>(Ls, cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB);
+  if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
+  // inverses of the four 16x16 diagonal blocks: lane -> (block b, column c), forward substitution on e_c
+  if (w == 0) {
+    const int b = lane >> 4, c = lane & 15;
+    const double* Lb = Ls + (b * DB) * LD + b * DB;
+    double x[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+      double acc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < i; ++q) acc -= Lb[i * LD + q] * x[q];
+      x[i] = (i >= c) ? acc * rinv[b * DB + i] : 0.0;
+    }
+    double* out = Dinv + (((size_t)sys * nt + k) * 4 + b) * (DB * DB);
+#pragma unroll
+    for (int i = 0; i < DB; ++i) out[i * DB + c] = x[i];
+  }
+}
 
-  if (r == 0) {
-    // publish the factored diagonal tile (upper part zero) to Ldiag
-    double* Ld = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
-    tile_s2g<64>(Ls, Ld, NB);
-    if (!ok && lane == 0) cb.fail[sys] = 1;
-    return;
+// ---- trsm: X L_kk^T = A_ik for one off-diagonal tile, blocked by 16 columns, on the matrix cores --------
+// wave w owns rows [16w, 16w+16) of the tile and walks the four column blocks:
+//   X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T
+// with v_mfma_f64_16x16x4_f64; finished X_q blocks pass from accumulator layout to operand layout through a
+// wave-private LDS strip, so the four waves never synchronise after the initial load.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const double* __restrict__ Dinv, int k)
+{
+  const int sys = blockIdx.y;
+  if (cb.active && !cb.active[sys]) return;
+  const int np = cb.np, nt = np / NB;
+  const int n = cb.n[sys];
+  const int ti = k + 1 + blockIdx.x;
+  if (k * NB > n || ti * NB > n) return;  // padding
+  double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
+  __shared__ __attribute__((aligned(16))) double Di[4 * DB * LDD];
+  __shared__ __attribute__((aligned(16))) double Xs[4][DB * LD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+  {
+    const double* Dg = Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+    for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) {
+      const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+      Di[b * DB * LDD + r * LDD + c] = Dg[idx];
+    }
   }
-
-  // X L_kk^T = A_ik  ->  x[c] = (a_ik[c] - sum_{q<c} x[q] L[c][q]) / L[c][c], lane = row of the tile
-  double* T = A + (size_t)((k + r) * NB) * np + k * NB;
-  tile_g2s<64, false>(T, np, St);
+  double* T = A + (size_t)(ti * NB + 16 * w) * np + k * NB;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = T[(size_t)(fq + 4 * i) * np + 16 * c + fr];
   __syncthreads();
-  double x[NB];
+  double* xs = Xs[w];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = St[lane * LD + c];
-  __syncthreads();
+  for (int c = 0; c < 4; ++c) {
+    // acc[c] -= X_q L_cq^T for the finished blocks q < c
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double s = x[c];
+    for (int q = 0; q < c; ++q)
 #pragma unroll
-    for (int q = 0; q < c; ++q) s -= x[q] * Ls[c * LD + q];
-    x[c] = s * rinv[c];
+      for (int ks = 0; ks < 4; ++ks) {
+        const double av = -xs[fr * LD + 16 * q + 4 * ks + fq];
+        const double bv = Lk[(16 * c + fr) * LD + 16 * q + 4 * ks + fq];
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
+      }
+    // T_c to operand layout (reuse column block c of the strip), then X_c = T_c Dinv_c^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[(fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is private to this wave
+    d4 xc = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double av = xs[fr * LD + 16 * c + 4 * ks + fq];
+      const double bv = Di[c * DB * LDD + fr * LDD + 4 * ks + fq];
+      xc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xc, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xs[(fq + 4 * i) * LD + 16 * c + fr] = xc[i];
+      T[(size_t)(fq + 4 * i) * np + 16 * c + fr] = xc[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
   }
-#pragma unroll
-  for (int c = 0; c < NB; ++c) St[lane * LD + c] = x[c];
-  __syncthreads();
-  tile_s2g<64>(St, T, np);
 }
 
 // ---- trailing update: A_ij -= L_ik L_jk^T on the matrix cores ---------------------------------------
@@ -179,7 +265,10 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k)
 }
 
 // ---- back substitution L^T x = y (y = row n of the factored matrix) ---------------------------------
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(CholBatch cb, double* xout)
+// Column-oriented: for k = last..first  { x_k = L_kk^-T y_k ;  y_j -= L[k-tile rows][j] x_k for all j < k*NB }.
+// The update reads the row panel of tile k, one thread per column -> fully coalesced row reads.
+constexpr int BS_THREADS = 1024;
+__global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb, double* xout)
 {
   const int sys = blockIdx.y;
   if (cb.active && !cb.active[sys]) return;
@@ -187,35 +276,29 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(CholBatch cb, doubl
   const int n = cb.n[sys];
   const double* A = cb.A + (size_t)sys * np * np;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* xs = smem;              // [np]
+  double* xs = smem;              // [np]  y, overwritten by x
   double* Lt = xs + np;           // [NB * LD]
-  double* part = Lt + NB * LD;    // [4 * NB]
+  double* xk = Lt + NB * LD;      // [NB]
   const int tid = threadIdx.x;
   // y = row n of L: its entries in block columns left of the diagonal tile were updated in place, the
   // ones inside the diagonal tile of row n live in Ldiag (diagonal tiles are never written back to A)
   {
     const int kt = n / NB;
     const double* Ldn = cb.Ldiag + ((size_t)sys * nt + kt) * (NB * NB) + (size_t)(n - kt * NB) * NB;
-    for (int j = tid; j < np; j += 256) xs[j] = (j < n) ? ((j >= kt * NB) ? Ldn[j - kt * NB] : A[(size_t)n * np + j]) : 0.0;
+    for (int j = tid; j < np; j += BS_THREADS) xs[j] = (j < n) ? ((j >= kt * NB) ? Ldn[j - kt * NB] : A[(size_t)n * np + j]) : 0.0;
   }
   __syncthreads();
   for (int k = nt - 1; k >= 0; --k) {
     const int c0 = k * NB;
     if (c0 >= n) continue;
-    const int c = tid & 63, g = tid >> 6;
-    double p = 0;
-    for (int j = c0 + NB + g; j < n; j += 4) p += A[(size_t)j * np + c0 + c] * xs[j];
-    part[g * NB + c] = p;
     const double* Ld = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
-#pragma unroll
-    for (int q = 0; q < (NB * NB / 2) / 256; ++q) {
-      const int idx = q * 256 + tid;
+    for (int idx = tid; idx < NB * NB / 2; idx += BS_THREADS) {
       const int row = idx >> 5, c2 = (idx & 31) * 2;
       *reinterpret_cast<double2*>(Lt + row * LD + c2) = *reinterpret_cast<const double2*>(Ld + row * NB + c2);
     }
     __syncthreads();
     if (tid < 64) {
-      double rc = xs[c0 + tid] - (part[tid] + part[NB + tid] + part[2 * NB + tid] + part[3 * NB + tid]);
+      double rc = xs[c0 + tid];
       const double inv = 1.0 / Lt[tid * LD + tid];
       double xc = 0;
       for (int i = NB - 1; i >= 0; --i) {
@@ -225,10 +308,25 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(CholBatch cb, doubl
         if (tid < i) rc -= Lt[i * LD + tid] * xi;
       }
       xs[c0 + tid] = xc;
+      xk[tid] = xc;
+    }
+    __syncthreads();
+    // y_j -= sum_r L[c0 + r][j] x_k[r], j < c0
+    for (int j = tid; j < c0; j += BS_THREADS) {
+      const double* col = A + (size_t)c0 * np + j;
+      double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll 4
+      for (int r = 0; r < NB; r += 4) {
+        p0 += col[(size_t)r * np] * xk[r];
+        p1 += col[(size_t)(r + 1) * np] * xk[r + 1];
+        p2 += col[(size_t)(r + 2) * np] * xk[r + 2];
+        p3 += col[(size_t)(r + 3) * np] * xk[r + 3];
+      }
+      xs[j] -= (p0 + p1) + (p2 + p3);
     }
     __syncthreads();
   }
-  for (int j = tid; j < np; j += 256) xout[(size_t)sys * np + j] = (j < n) ? xs[j] : 0.0;
+  for (int j = tid; j < np; j += BS_THREADS) xout[(size_t)sys * np + j] = (j < n) ? xs[j] : 0.0;
 }
 
 }  // namespace
@@ -242,7 +340,9 @@ void chol_clear(const CholBatch& cb, hipStream_t stream)
 
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
-  hipLaunchKernelGGL(chol_panel_kernel, dim3(cb.np / NB - k, cb.count), dim3(64), 0, stream, cb, k);
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, cb.Dinv, k);
+  const int m = cb.np / NB - k - 1;
+  if (m > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, (const double*)cb.Dinv, k);
 }
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
@@ -251,8 +351,8 @@ void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream)
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
-  const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + 4 * NB);
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1, cb.count), dim3(256), smem, stream, cb, x);
+  const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + NB);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1, cb.count), dim3(BS_THREADS), smem, stream, cb, x);
 }
 
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
@@ -280,14 +380,15 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   cb.count = count;
   cb.np = chol_padded_order(n);
   const int np = cb.np, nt = np / CHOL_NB;
-  double *dA = nullptr, *dL = nullptr, *dx = nullptr;
+  double *dA = nullptr, *dL = nullptr, *dx = nullptr, *dD = nullptr;
   int *dn = nullptr, *dfail = nullptr;
   PTZ_HIP_TRY(hipMalloc(&dA, sizeof(double) * (size_t)count * np * np));
   PTZ_HIP_TRY(hipMalloc(&dL, sizeof(double) * (size_t)count * nt * CHOL_NB * CHOL_NB));
   PTZ_HIP_TRY(hipMalloc(&dx, sizeof(double) * (size_t)count * np));
+  PTZ_HIP_TRY(hipMalloc(&dD, sizeof(double) * (size_t)count * nt * 4 * 16 * 16));
   PTZ_HIP_TRY(hipMalloc(&dn, sizeof(int) * count));
   PTZ_HIP_TRY(hipMalloc(&dfail, sizeof(int) * count));
-  cb.A = dA; cb.Ldiag = dL; cb.n = dn; cb.fail = dfail;
+  cb.A = dA; cb.Ldiag = dL; cb.Dinv = dD; cb.n = dn; cb.fail = dfail;
   {
     int* hn = new int[count];
     for (int i = 0; i < count; ++i) hn[i] = n;
@@ -317,6 +418,6 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
     PTZ_HIP_TRY(hipMemcpy(x + (size_t)s * n, dx + (size_t)s * np, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (fail) PTZ_HIP_TRY(hipMemcpy(fail, dfail, sizeof(int) * count, hipMemcpyDeviceToHost));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
-  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
+  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
   return PTZ_OK;
 }

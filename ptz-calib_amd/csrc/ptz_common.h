@@ -74,6 +74,7 @@ struct CholBatch {
   int np = 0;             // padded order, multiple of CHOL_NB, >= max(n_i) + 1
   double* A = nullptr;    // device
   double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
+  double* Dinv = nullptr;   // device [count][np/NB][4][16*16]: inverses of the 16x16 diagonal blocks of L_kk
   const int* n = nullptr;   // device [count]
   int* fail = nullptr;      // device [count]: set to 1 if a pivot <= 0 is met in rows < n_i
   const int* active = nullptr;  // device [count] or nullptr; systems with active == 0 are skipped
