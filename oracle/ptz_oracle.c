@@ -837,6 +837,7 @@ typedef struct {
   double* Jc;   /* [n_obs][2][ncf] */
   double* Jr;   /* [n_obs][2][3]   */
   double* r;    /* [n_obs][2]      */
+  double* cterm; /* [n_obs] per-observation cost terms */
   double* Jc3;  /* [n_obs3d][2][ncf] */
   double* Jt3;  /* [n_obs3d][2][6]  */
   double* r3;   /* [n_obs3d][2]     */
@@ -957,7 +958,7 @@ static void block2d2d_analytic(int type, const double* cam, const double* ray, c
     return;
   }
   double iz = 1.0 / P[2];
-  double x = P[0] * iz, y = P[1] * iz;
+  double x = P[0] / P[2], y = P[1] / P[2]; /* same arithmetic as the functor */
   /* d(x,y)/dP */
   double dpi[6] = {iz, 0, -x * iz, 0, iz, -y * iz};
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
@@ -1059,7 +1060,7 @@ static void block2d3d_analytic(const double* cam, const double* tlw, const float
   mat3_mul_vec(Rlw, xyz, Xl);
   Xl[0] += tlw[3]; Xl[1] += tlw[4]; Xl[2] += tlw[5];
   mat3_mul_vec(R, Xl, P);
-  double iz = 1.0 / P[2], x = P[0] * iz, y = P[1] * iz;
+  double iz = 1.0 / P[2], x = P[0] / P[2], y = P[1] / P[2]; /* same arithmetic as the functor */
   double dpi[6] = {iz, 0, -x * iz, 0, iz, -y * iz};
   double xd, yd, B[4], dk1[2];
   brown(x, y, cam[10], cam[11], cam[12], cam[13], cam[14], &xd, &yd);
@@ -1128,6 +1129,7 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
   c->Jc = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 2 * c->ncf + 1));
   c->Jr = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 6 + 1));
   c->r = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 2 + 1));
+  c->cterm = (double*)malloc(sizeof(double) * (size_t)(p->n_obs + 1));
   c->Jc3 = (double*)malloc(sizeof(double) * (size_t)(p->n_obs3d * 2 * c->ncf + 1));
   c->Jt3 = (double*)malloc(sizeof(double) * (size_t)(p->n_obs3d * 12 + 1));
   c->r3 = (double*)malloc(sizeof(double) * (size_t)(p->n_obs3d * 2 + 1));
@@ -1142,7 +1144,7 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
 
 static void ba_ctx_free(ba_ctx* c)
 {
-  free(c->cam_active); free(c->Jc); free(c->Jr); free(c->r); free(c->Jc3); free(c->Jt3); free(c->r3);
+  free(c->cterm); free(c->cam_active); free(c->Jc); free(c->Jr); free(c->r); free(c->Jc3); free(c->Jt3); free(c->r3);
   free(c->S); free(c->E); free(c->yr); free(c->ray_ptr);
 }
 
@@ -1151,14 +1153,16 @@ static double ba_cost(void* vc, const double* x)
   ba_ctx* c = (ba_ctx*)vc;
   const orc_ba_problem* p = c->p;
   double cost = 0;
-#pragma omp parallel for schedule(static) reduction(+ : cost)
+  /* per-observation terms in parallel, then a serial sum: bitwise reproducible for any thread count */
+#pragma omp parallel for schedule(static)
   for (int64_t a = 0; a < p->n_obs; ++a) {
     double intr[9], extr[6], res[2];
     cam_to_blocks(X_cam(c, x, p->obs_cam[a]), intr, extr);
     res2d2d(p->factor_type, intr, extr, X_ray(c, x, p->obs_ray[a]), p->obs_uv + 2 * a, res);
     /* ScaledLoss(NULL, w): cost = 0.5 * w * |r|^2  (ptzray_optimizer.cc:805-806) */
-    cost += 0.5 * (p->ray_weight[p->obs_ray[a]] * (res[0] * res[0] + res[1] * res[1]));
+    c->cterm[a] = 0.5 * (p->ray_weight[p->obs_ray[a]] * (res[0] * res[0] + res[1] * res[1]));
   }
+  for (int64_t a = 0; a < p->n_obs; ++a) cost += c->cterm[a];
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     double intr[9], extr[6], res[2];
     cam_to_blocks(X_cam(c, x, p->obs3d_cam[a]), intr, extr);
@@ -1174,7 +1178,7 @@ static double ba_linearize(void* vc, const double* x, double* g)
   const orc_ba_problem* p = c->p;
   const int ncf = c->ncf;
   double cost = 0;
-#pragma omp parallel for schedule(static) reduction(+ : cost)
+#pragma omp parallel for schedule(static)
   for (int64_t a = 0; a < p->n_obs; ++a) {
     double res[2], J15[30], Jray[6];
     const double* cam = X_cam(c, x, p->obs_cam[a]);
@@ -1183,7 +1187,7 @@ static double ba_linearize(void* vc, const double* x, double* g)
     else block2d2d_analytic(p->factor_type, cam, ray, p->obs_uv + 2 * a, res, J15, Jray);
     double w = p->ray_weight[p->obs_ray[a]];
     double sw = sqrt(w); /* Corrector: residuals, jacobians *= sqrt(rho') */
-    cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
+    c->cterm[a] = 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
     c->r[2 * a] = res[0] * sw;
     c->r[2 * a + 1] = res[1] * sw;
     for (int k = 0; k < ncf; ++k) {
@@ -1192,6 +1196,7 @@ static double ba_linearize(void* vc, const double* x, double* g)
     }
     for (int k = 0; k < 6; ++k) c->Jr[6 * a + k] = Jray[k] * sw;
   }
+  for (int64_t a = 0; a < p->n_obs; ++a) cost += c->cterm[a];
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     double res[2], J15[30], Jt[12];
     const double* cam = X_cam(c, x, p->obs3d_cam[a]);
@@ -1686,7 +1691,7 @@ static void krt_block_analytic(const krt_ctx* c, const double* cam, int m, doubl
   krt_ray1(c->k1, u1, v1, X);
   mat3_mul_vec(R, X, P);
   double fx = cam[0], fy = fxfy ? cam[1] : cam[0], cx = cam[2], cy = cam[3];
-  double iz = 1.0 / P[2], x = P[0] * iz, y = P[1] * iz;
+  double iz = 1.0 / P[2], x = P[0] / P[2], y = P[1] / P[2]; /* same arithmetic as the functor */
   double dpi[6] = {iz, 0, -x * iz, 0, iz, -y * iz};
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (dist) {
@@ -1732,7 +1737,6 @@ static double krt_linearize(void* vc, const double* x, double* g)
   krt_ctx* c = (krt_ctx*)vc;
   const int nf = c->nf, M = c->p->n_match;
   double cost = 0;
-#pragma omp parallel for schedule(static) reduction(+ : cost)
   for (int m = 0; m < M; ++m) {
     double res[2], J15[30];
     if (c->jac_mode == ORC_JAC_NUMERIC) {

@@ -205,7 +205,7 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
     return;
   }
   const double iz = 1.0 / Pz;
-  const double x = Px * iz, y = Py * iz;
+  const double x = Px / Pz, y = Py / Pz;  // same arithmetic as the reference functor
   double xd = x, yd = y;
   double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (TYPE == 0) {
@@ -265,7 +265,7 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double f, double cx, dou
   const double Px = R[0] * ray1[0] + R[1] * ray1[1] + R[2] * ray1[2];
   const double Py = R[3] * ray1[0] + R[4] * ray1[1] + R[5] * ray1[2];
   const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
-  const double iz = 1.0 / Pz, x = Px * iz, y = Py * iz;
+  const double iz = 1.0 / Pz, x = Px / Pz, y = Py / Pz;  // same arithmetic as the reference functor
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (KTYPE == 0) {
     res[0] = (double)u2 - (f * Px + cx * Pz) / Pz;

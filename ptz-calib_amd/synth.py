@@ -190,7 +190,7 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
             v = focal[:, None] * y * rad + cy
         vis = (z > 0.1) & (u >= 8) & (u <= width - 8) & (v >= 8) & (v <= height - 8) & (r2 < 1.5)
         ratio = 2.2 * target_total / max(int(vis.sum()), 1)
-        if 0.92 < ratio < 1.08:
+        if 0.92 < ratio < 1.08 or _attempt == 3:
             break
         P = max(16, int(round(P * ratio)))
 

@@ -1,0 +1,289 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol, argument
+validation happens before any device work, there is NO CPU fallback (compute entry points fail loudly without
+a GPU), the device math agrees with the oracle when instantiated on the host, evaluator / generator / sharding."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------ C-ABI
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "ptz_calib_amd.h")).read()
+    names = set(re.findall(r"\b(ptz_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"ptz_ba_problem", "ptz_lm_options", "ptz_lm_summary"}
+    assert names == set(pkg.api.EXPORTS), names ^ set(pkg.api.EXPORTS)
+    lib = pkg.api.lib()
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert "gfx950" in pkg.api.version()
+
+
+def test_library_does_not_link_the_oracle(pkg):
+    import subprocess
+    out = subprocess.run(["ldd", pkg.api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ptz_oracle" not in out and "factor_harness" not in out
+    syms = subprocess.run(["nm", "-D", pkg.api.LIB_PATH], capture_output=True, text=True).stdout
+    assert " orc_" not in syms
+
+
+def test_options_defaults_are_ceres_114(pkg):
+    o = pkg.api.default_options()
+    assert (o.max_num_iterations, o.max_num_consecutive_invalid_steps, o.jacobi_scaling) == (200, 5, 1)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+
+
+def test_validation_precedes_device_and_no_cpu_fallback(pkg, scene_c1):
+    import copy
+    api = pkg.api
+    # malformed problems are rejected with PTZ_EINVAL whether or not a GPU exists
+    bad = copy.copy(scene_c1); bad.obs_ray = scene_c1.obs_ray[::-1].copy()  # not sorted by track
+    with pytest.raises(api.PtzError) as e:
+        api.BaBatch([bad])
+    assert e.value.code == -1
+    dd = copy.copy(scene_c1); dd.factor_type = api.BA_PTZRayDistDisp
+    with pytest.raises(api.PtzError) as e:
+        api.BaBatch([dd])
+    assert e.value.code == -4  # PTZ_EUNSUPPORTED
+    assert api.lib().ptz_ba_cam_block_dim(0) == 4 and api.lib().ptz_ba_cam_block_dim(1) == 5
+    if api.device_count() == 0:
+        # no GPU: the product path must fail loudly, never compute on the CPU
+        with pytest.raises(api.PtzError) as e:
+            api.ba_solve(scene_c1)
+        assert e.value.code == -2  # PTZ_ENODEVICE
+        with pytest.raises(api.PtzError) as e:
+            api.chol_solve_batch(np.eye(4)[None], np.ones((1, 4)))
+        assert e.value.code == -2
+        rb = pkg.synth.make_reloc_batch(2, 16)
+        with pytest.raises(api.PtzError) as e:
+            api.krt_solve_batch(rb)
+        assert e.value.code == -2
+
+
+def test_product_package_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ptz-calib_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in txt and "ptz_oracle" not in txt and "libptz_oracle" not in txt, f
+
+
+# ------------------------------------------------------------------------------------------------ device math on the host
+@pytest.fixture(scope="module")
+def harness():
+    so = os.path.join(ROOT, "tests", "cpu_harness", "libfactor_harness.so")
+    srcs = [os.path.join(ROOT, "tests", "cpu_harness", "factor_harness.cc"), os.path.join(ROOT, "ptz-calib_amd", "csrc", "ptz_factor.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
+        import subprocess
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+                               os.path.join(ROOT, "tests", "cpu_harness", "factor_harness.cc")])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_device_math_matches_oracle(pkg, orc, harness, ftype):
+    sc = pkg.synth.make_scene(1, 20, 100, factor_type=ftype)
+    cam = sc.cam_init.copy()
+    if ftype:
+        cam[:, 10] = 0.01
+    ray = sc.ray_init * (1.3 if ftype == 0 else 1.0)
+    lin = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_ANALYTIC)
+    nc = 4 if ftype == 0 else 5
+    sel = [0, 2, 3, 4] if ftype == 0 else [0, 2, 3, 4, 5]
+    W = np.zeros((sc.n_obs, nc, 3)); cost = 0.0
+    resd = orc.ba_residuals(sc, cam, ray)
+    for a in range(sc.n_obs):
+        res = np.zeros(2); Jc = np.zeros((2, nc)); Jr = np.zeros((2, 3)); r2 = np.zeros(2)
+        harness.h_ba_linearize(ftype, _p(cam[sc.obs_cam[a]].copy()), _p(ray[sc.obs_ray[a]].copy()), _p(sc.obs_uv[a].copy()), _p(res), _p(Jc), _p(Jr))
+        harness.h_ba_residual(ftype, _p(cam[sc.obs_cam[a]].copy()), _p(ray[sc.obs_ray[a]].copy()), _p(sc.obs_uv[a].copy()), _p(r2))
+        assert np.array_equal(res, r2) and np.array_equal(res, resd[a])  # bit-identical residual arithmetic
+        w = sc.ray_weight[sc.obs_ray[a]]
+        W[a] = w * Jc.T @ Jr
+        cost += 0.5 * w * res @ res
+    assert abs(cost - lin["cost"]) / lin["cost"] < 1e-14
+    assert np.abs(W - lin["W"][:, sel, :]).max() / np.abs(W).max() < 1e-13
+
+
+def test_device_math_behind_camera_branch(harness):
+    cam = np.zeros(15); cam[0] = cam[1] = 2000; cam[2], cam[3] = 960, 540
+    res = np.zeros(2); Jc = np.ones((2, 5)); Jr = np.ones((2, 3))
+    harness.h_ba_linearize(1, _p(cam), _p(np.array([0.0, 0.0, -1.0])), _p(np.zeros(2, np.float32)), _p(res), _p(Jc), _p(Jr))
+    assert np.array_equal(res, [1e6, 1e6]) and not Jc.any() and not Jr.any()  # ptzray_optimizer.cc:97-102
+
+
+@pytest.mark.parametrize("ktype", [0, 1])
+def test_device_krt_math_matches_oracle(pkg, orc, harness, ktype):
+    rb = pkg.synth.make_reloc_batch(4, 32, seed_id=ktype, factor_type=ktype)
+    nf = 4 if ktype == 0 else 5
+    for q in range(rb.n_query):
+        loc = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc[4:7] += [0.01, -0.02, 0.005]
+        if ktype:
+            loc[10] = 0.01
+        k1 = rb.cam_ref[q, :4].copy(); d1 = rb.cam_ref[q, 10:15].copy()
+        for m in range(rb.match_ptr[q], rb.match_ptr[q + 1]):
+            res = np.zeros(2); J = np.zeros((2, nf)); want = np.zeros(2)
+            harness.h_krt_eval(ktype, _p(loc), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(res), _p(J))
+            if ktype == 0:
+                orc.lib().orc_res_2d2d(_p(loc), _p(k1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(want))
+            else:
+                orc.lib().orc_res_2d2d_dist(_p(loc), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(want))
+            assert np.allclose(res, want, rtol=0, atol=1e-9)
+            # Jacobian against central differences of the oracle functor
+            idx = [0, 4, 5, 6] + ([10] if ktype else [])
+            for c, k in enumerate(idx):
+                h = max(1.5e-8, abs(loc[k]) * 1e-6)
+                fp = np.zeros(2); fm = np.zeros(2)
+                for sgn, out in ((1, fp), (-1, fm)):
+                    x = loc.copy(); x[k] += sgn * h
+                    if ktype == 0:
+                        orc.lib().orc_res_2d2d(_p(x), _p(k1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(out))
+                    else:
+                        orc.lib().orc_res_2d2d_dist(_p(x), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(out))
+                num = (fp - fm) / (2 * h)
+                assert np.allclose(J[:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+
+
+def test_device_so3_and_inv3(orc, harness):
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        r = rng.standard_normal(3) * rng.choice([1e-9, 1e-3, 0.3, 1.2])
+        R = np.zeros(9); Jl = np.zeros(9)
+        harness.h_rodrigues(_p(r), _p(R), _p(Jl))
+        assert np.array_equal(R.reshape(3, 3), orc.rodrigues(r))  # same formula, same arithmetic
+        _, dR = orc.rodrigues_jac(r)
+        X = rng.standard_normal(3)
+        P = R.reshape(3, 3) @ X
+        for k in range(3):
+            assert np.allclose(np.cross(Jl.reshape(3, 3)[:, k], P), dR[k] @ X, atol=1e-9)
+        A = rng.standard_normal((3, 3)); A = A @ A.T + 0.1 * np.eye(3)
+        a6 = np.array([A[0, 0], A[1, 0], A[1, 1], A[2, 0], A[2, 1], A[2, 2]]); o6 = np.zeros(6)
+        assert harness.h_inv3(_p(a6), _p(o6)) == 1
+        Ai = np.linalg.inv(A)
+        assert np.allclose(o6, [Ai[0, 0], Ai[1, 0], Ai[1, 1], Ai[2, 0], Ai[2, 1], Ai[2, 2]], rtol=1e-10)
+    assert harness.h_inv3(_p(np.array([1.0, 2.0, 1.0, 0, 0, 1.0])), _p(np.zeros(6))) == 0  # not SPD
+
+
+# ------------------------------------------------------------------------------------------------ evaluator (eval_synthetic.py)
+def test_eval_metrics_against_reference_vectors(pkg):
+    doc = json.load(open(os.path.join(GOLD, "eval_synthetic_vectors.json")))
+    em = pkg.evalmetrics
+    for c in doc["ape_cases"]:
+        assert em.calc_focal_error(c["pred_f"], c["gt_f"]) == c["focal_error"]
+        t, r = em.calc_ape(c["pred_R"], c["pred_t"], c["gt_R"], c["gt_t"])
+        assert abs(t - c["ape_trans"]) < 1e-10 * max(1.0, c["ape_trans"])
+        assert abs(r - c["ape_rot_deg"]) < 1e-7
+    for c in doc["mean_median_cases"]:
+        m, md = em.cal_mean_median(c["data"])
+        assert abs(m - c["mean"]) < 1e-15 and abs(md - c["median"]) < 1e-15
+
+
+# ------------------------------------------------------------------------------------------------ generator
+def test_splitmix64_known_values(pkg):
+    g = pkg.synth.SplitMix64(0)
+    # reference outputs of SplitMix64 seeded with 0 (Vigna's splitmix64.c)
+    assert [int(v) for v in g.u64(3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_scene_generator_is_deterministic(pkg):
+    a = pkg.synth.make_scene(0, 20, 100)
+    b = pkg.synth.make_scene(0, 20, 100)
+    for k in ("obs_uv", "obs_cam", "obs_ray", "ray_weight", "cam_init", "cam_gt", "ray_init"):
+        assert np.array_equal(getattr(a, k), getattr(b, k))
+    assert a.obs_uv.dtype == np.float32 and a.obs_cam.dtype == np.int32
+    assert np.all(np.diff(a.obs_ray) >= 0) and np.bincount(a.obs_ray).min() >= 4  # Filter(4)
+    assert np.array_equal(a.ray_weight, np.bincount(a.obs_ray))
+    h = hashlib.sha256(a.obs_uv.tobytes() + a.obs_cam.tobytes() + a.obs_ray.tobytes()).hexdigest()
+    assert h == json.load(open(os.path.join(GOLD, "lm_trajectories.json")))["ba"][0].get("scene_sha256", h)
+    assert np.all(a.cam_init[:, 0] == 2304.0)  # 1.2 * max(w, h), ptz_incremental_optimizer.cc:324
+
+
+def test_c2_scene_shape(pkg):
+    sc = pkg.synth.make_scene(0, 200, 500)
+    per_view = np.bincount(sc.obs_cam, minlength=200)
+    assert 95_000 < sc.n_obs < 105_000 and per_view.min() > 350 and per_view.max() < 650
+    assert sc.meta["track_len_mean"] >= 4
+
+
+# ------------------------------------------------------------------------------------------------ sharding
+def test_shard_range_and_greedy(pkg):
+    sh = pkg.sharding
+    for n in (0, 1, 7, 8, 1000):
+        for w in (1, 2, 3, 8):
+            parts = [list(sh.shard_range(n, r, w)) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    parts = sh.greedy_partition([10, 9, 1, 1, 1, 8], 2)
+    assert sorted(sum(parts, [])) == list(range(6))
+    loads = [sum([10, 9, 1, 1, 1, 8][i] for i in p) for p in parts]
+    assert max(loads) <= (4 / 3) * 15  # LPT bound: <= 4/3 of the optimal makespan (15)
+
+
+def _gloo_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    ids = list(range(5))
+
+    def make(s):
+        return pkg.synth.make_scene(s, 12, 40)
+
+    def fake_solve(scenes):  # stands in for BaBatch.solve on a GPU rank: deterministic function of the scene
+        cams = [sc.cam_init * (1.0 + 1e-3 * sc.seed % 7) for sc in scenes]
+        summ = [dict(termination_type=0, num_iterations=sc.n_obs % 11, final_cost=float(sc.n_ray)) for sc in scenes]
+        return cams, summ
+
+    out = pkg.sharding.solve_scenes_sharded(ids, make, fake_solve, dist=dist, cam_width=12)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_gathers_on_every_rank_gloo(pkg):
+    """world_size-2 gloo run of the sharding/gather path (the N>1 path of bench.py without GPUs)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict(q.get(timeout=90) for _ in range(2))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0], res[1])
+    # single-process result is identical
+    def make(s):
+        return pkg.synth.make_scene(s, 12, 40)
+    def fake_solve(scenes):
+        cams = [sc.cam_init * (1.0 + 1e-3 * sc.seed % 7) for sc in scenes]
+        summ = [dict(termination_type=0, num_iterations=sc.n_obs % 11, final_cost=float(sc.n_ray)) for sc in scenes]
+        return cams, summ
+    single = pkg.sharding.solve_scenes_sharded(list(range(5)), make, fake_solve, dist=None, cam_width=12)
+    assert np.array_equal(single, res[0])

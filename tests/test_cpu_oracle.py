@@ -1,0 +1,319 @@
+"""CPU tests of the oracle (the checker): golden vectors, known answers, internal consistency.
+These run without a GPU."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- tracks: bit-exact against the reference's union-find
+def _load_tracks():
+    return json.load(open(os.path.join(GOLD, "tracks_reference.json")))["cases"]
+
+
+@pytest.mark.parametrize("name", sorted(_load_tracks().keys()))
+def test_tracks_match_reference_golden(orc, name):
+    case = _load_tracks()[name]
+    pairs = [(i, j, [tuple(m) for m in ms]) for i, j, ms in case["pairs"]]
+    got = orc.tracks_build(pairs, case["min_track_length"])
+    want = {int(t): {int(i): f for i, f in v.items()} for t, v in case["tracks"].items()}
+    assert got == want  # track ids (union-find roots), membership and ordering are bit-exact
+
+
+def test_tracks_against_live_reference_build(orc):
+    """Where oracle/_ref exists (built from /root/reference's own headers) compare on fresh random graphs."""
+    if not orc.ref_tracks_available():
+        pytest.skip("oracle/_ref/ref_tracks not built (reference tree absent)")
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        n_img = int(rng.integers(4, 20))
+        pairs = []
+        for _ in range(int(rng.integers(1, 60))):
+            i, j = rng.choice(n_img, 2, replace=False)
+            k = int(rng.integers(0, 40))
+            # mostly consistent matches (feature id = track id) plus noise
+            ms = [(int(t), int(t if rng.random() < 0.9 else rng.integers(0, 50))) for t in rng.integers(0, 50, k)]
+            pairs.append((int(i), int(j), ms))
+        ml = int(rng.integers(2, 5))
+        assert orc.tracks_build(pairs, ml) == orc.ref_tracks_build(pairs, ml)
+
+
+def test_tracks_empty_input(orc):
+    assert orc.tracks_build([(0, 1, [])], 4) == {}
+
+
+# ---------------------------------------------------------------- Rodrigues (types.cc:41,68 -> cv::Rodrigues)
+def test_rodrigues_known_values(orc):
+    assert np.array_equal(orc.rodrigues([0, 0, 0]), np.eye(3))
+    assert np.array_equal(orc.rodrigues([1e-17, 0, 0]), np.eye(3))  # theta < DBL_EPSILON -> exactly I
+    R = orc.rodrigues([0, 0, math.pi / 2])
+    assert np.allclose(R, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    R = orc.rodrigues([1e-9, 0, 0])  # OpenCV's formula with c1 = 1 - cos(theta) (no series branch)
+    assert abs(R[2, 1] - 1e-9) < 1e-24 and R[0, 0] == 1.0
+    R = orc.rodrigues([math.pi, 0, 0])
+    assert np.allclose(R, np.diag([1, -1, -1]), atol=1e-15)
+
+
+def test_rodrigues_roundtrip_and_jacobian(orc):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        r = rng.standard_normal(3)
+        r *= rng.uniform(0.01, 3.0) / np.linalg.norm(r)  # angle in (0, pi): the inverse returns the principal value
+        R, dR = orc.rodrigues_jac(r)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14)
+        assert np.allclose(orc.rodrigues_inv(R), r, atol=1e-12)
+        for k in range(3):
+            h = 1e-6
+            e = np.zeros(3); e[k] = h
+            num = (orc.rodrigues(r + e) - orc.rodrigues(r - e)) / (2 * h)
+            assert np.allclose(dR[k], num, atol=1e-9)
+    _, dR0 = orc.rodrigues_jac([0, 0, 0])  # theta -> 0 branch: [e_k]_x
+    assert np.allclose(dR0[0], [[0, 0, 0], [0, 0, -1], [0, 1, 0]])
+
+
+# ---------------------------------------------------------------- residual known answers
+def _cam(f=2000.0, rvec=(0.1, -0.2, 0.05), k1=0.0):
+    c = np.zeros(15)
+    c[0] = c[1] = f; c[2], c[3] = 960, 540; c[4:7] = rvec; c[10] = k1
+    return c
+
+
+def _res(orc, name, *args):
+    out = np.zeros(2)
+    getattr(orc.lib(), name)(*[_p(np.ascontiguousarray(a)) for a in args], _p(out))
+    return out
+
+
+def _blocks(cam):
+    intr = np.array([cam[0], cam[1], cam[2], cam[3], *cam[10:15]])
+    extr = cam[4:10].copy()
+    return intr, extr
+
+
+def test_f1_zero_residual_at_exact_projection(orc):
+    cam = _cam()
+    intr, extr = _blocks(cam)
+    R = orc.rodrigues(cam[4:7])
+    X = np.array([0.1, -0.05, 1.0]); X /= np.linalg.norm(X)
+    P = R @ X
+    uv = np.array([cam[0] * P[0] / P[2] + 960, cam[0] * P[1] / P[2] + 540], dtype=np.float32)
+    r = _res(orc, "orc_res_ptzray", intr, extr, X * 3.7, uv)  # ray scale is irrelevant (normalised, :45-46)
+    assert np.abs(r).max() < 2e-4  # float32 rounding of the pixel
+    intr2 = intr.copy(); intr2[1] = 999.0  # "fy" is ignored by PTZRayFactor (:24-25)
+    assert np.array_equal(r, _res(orc, "orc_res_ptzray", intr2, extr, X * 3.7, uv))
+
+
+def test_f2_penalty_branch_and_distortion(orc):
+    cam = _cam(k1=0.03)
+    intr, extr = _blocks(cam)
+    R = orc.rodrigues(cam[4:7])
+    behind = R.T @ np.array([0.0, 0.0, -1.0])
+    r = _res(orc, "orc_res_ptzray_dist", intr, extr, behind, np.zeros(2, dtype=np.float32))
+    assert np.array_equal(r, [1e6, 1e6])  # ptzray_optimizer.cc:97-102
+    X = R.T @ np.array([0.2, 0.1, 1.0])
+    x, y = 0.2, 0.1
+    rad = 1 + 0.03 * (x * x + y * y)
+    uv = np.array([2000 * x * rad + 960, 2000 * y * rad + 540], dtype=np.float32)
+    assert np.abs(_res(orc, "orc_res_ptzray_dist", intr, extr, X, uv)).max() < 2e-4
+    assert np.abs(_res(orc, "orc_res_ptzray_dist", intr, extr, 2.5 * X, uv)).max() < 2e-4  # scale invariant after /z
+
+
+def test_f3_ignores_extrinsic_translation_and_reads_fy(orc):
+    cam = _cam()
+    intr, extr = _blocks(cam)
+    tlw = np.array([0.02, -0.01, 0.03, 1.0, 2.0, 30.0])
+    xyz = np.array([0.5, -0.3, 2.0]); uv = np.array([1000, 500], dtype=np.float32)
+    out = np.zeros(2)
+    def f3(i, e):
+        orc.lib().orc_res_reproj2d3d(_p(i), _p(e), _p(tlw), _p(uv), _p(xyz), _p(out)); return out.copy()
+    r0 = f3(intr, extr)
+    e2 = extr.copy(); e2[3:] = [5, 6, 7]
+    assert np.array_equal(r0, f3(intr, e2))  # extr t unused (ptzray_optimizer.cc:300)
+    i2 = intr.copy(); i2[1] *= 1.1
+    r1 = f3(i2, extr)
+    assert r1[0] == r0[0] and r1[1] != r0[1]  # fy is live in the 2D-3D factor (:273,320)
+
+
+def test_f4_f5_known_answers(orc):
+    ref = _cam(f=2100.0, rvec=(0, 0, 0))
+    cur = _cam(f=2500.0, rvec=(0.02, 0.1, -0.01))
+    k1 = ref[:4].copy()
+    R = orc.rodrigues(cur[4:7])
+    uv1 = np.array([700.0, 400.0], dtype=np.float32)
+    ray = np.array([(700 - 960) / 2100, (400 - 540) / 2100, 1.0]); ray /= np.linalg.norm(ray)
+    P = R @ ray
+    uv2 = np.array([2500 * P[0] / P[2] + 960, 2500 * P[1] / P[2] + 540], dtype=np.float32)
+    assert np.abs(_res(orc, "orc_res_2d2d", cur, k1, uv1, uv2)).max() < 2e-4
+    # FDist with zero distortion equals F up to the float32 rounding of the undistorted pixel
+    d0 = np.zeros(5)
+    assert np.abs(_res(orc, "orc_res_2d2d_dist", cur, k1, d0, uv1, uv2)).max() < 2e-4
+    # border guard: a reference pixel that undistorts outside [0, 2cx) x [0, 2cy) gives residual 0 (krt_optimizer.cc:97-101)
+    dist = np.array([0.8, 0, 0, 0, 0])
+    und = np.zeros(2, dtype=np.float32)
+    corner = np.array([5.0, 5.0], dtype=np.float32)
+    orc.lib().orc_undistort_point(_p(k1), _p(dist), _p(corner), _p(und))
+    if und[0] < 0 or und[1] < 0:
+        assert np.array_equal(_res(orc, "orc_res_2d2d_dist", cur, k1, dist, corner, uv2), [0, 0])
+
+
+def test_undistort_inverts_opencv_model(orc):
+    """cv::undistortPoints with the reference's quirk: dist (k1,k2,k3,p1,p2) is read by OpenCV as (k1,k2,p1,p2,k3)."""
+    k = np.array([2000.0, 2000.0, 960.0, 540.0])
+    dist = np.array([-0.04, 0.01, 0.0, 0.0, 0.0])
+    x, y = 0.21, -0.13
+    r2 = x * x + y * y
+    rad = 1 + dist[0] * r2 + dist[1] * r2 * r2
+    uv = np.array([2000 * x * rad + 960, 2000 * y * rad + 540], dtype=np.float32)
+    out = np.zeros(2, dtype=np.float32)
+    orc.lib().orc_undistort_point(_p(k), _p(dist), _p(uv), _p(out))
+    assert abs(out[0] - (2000 * x + 960)) < 0.05 and abs(out[1] - (2000 * y + 540)) < 0.05  # 5 fixed-point iterations
+
+
+# ---------------------------------------------------------------- Jacobians: closed form vs Ceres-style central differences
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_analytic_vs_numeric_jacobian(pkg, orc, ftype):
+    sc = pkg.synth.make_scene(2, 20, 100, factor_type=ftype)
+    cam = sc.cam_init.copy()
+    if ftype:
+        cam[:, 10] = 0.02
+    a = orc.ba_linearize(sc, cam, sc.ray_init, jacobian_mode=orc.JAC_ANALYTIC)
+    n = orc.ba_linearize(sc, cam, sc.ray_init, jacobian_mode=orc.JAC_NUMERIC)
+    for k in ("U", "V", "W", "g_c", "g_r"):
+        assert np.abs(a[k] - n[k]).max() / np.abs(a[k]).max() < 1e-7, k
+    assert a["cost"] == n["cost"]
+    assert np.abs(n["W"][:, 1, :]).max() == 0.0  # dummy fy column is exactly zero in 2D-2D factors
+
+
+def test_f1_jacobian_against_sympy(orc):
+    """Independent symbolic derivative of PTZRayFactor w.r.t. (f, rvec, ray)."""
+    sp = pytest.importorskip("sympy")
+    f, r1, r2, r3, x1, x2, x3, u, v, cx, cy = sp.symbols("f r1 r2 r3 x1 x2 x3 u v cx cy", real=True)
+    th = sp.sqrt(r1 ** 2 + r2 ** 2 + r3 ** 2)
+    k = sp.Matrix([r1, r2, r3]) / th
+    K = sp.Matrix([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = sp.cos(th) * sp.eye(3) + (1 - sp.cos(th)) * k * k.T + sp.sin(th) * K
+    X = sp.Matrix([x1, x2, x3]); Xn = X / sp.sqrt(x1 ** 2 + x2 ** 2 + x3 ** 2)
+    P = R * Xn
+    res = sp.Matrix([u - (f * P[0] / P[2] + cx), v - (f * P[1] / P[2] + cy)])
+    J = res.jacobian([f, r1, r2, r3, x1, x2, x3])
+    fn = sp.lambdify([f, r1, r2, r3, x1, x2, x3, u, v, cx, cy], J, "numpy")
+    rng = np.random.default_rng(5)
+    lib = orc.lib()
+    for _ in range(5):
+        cam = _cam(f=rng.uniform(1500, 3500), rvec=rng.standard_normal(3) * 0.4)
+        X0 = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), 1.0]) * rng.uniform(0.5, 2)
+        uv = np.array([900.0, 500.0], dtype=np.float32)
+
+        class S:  # one-observation scene
+            n_cam, n_ray, factor_type = 1, 1, 0
+            obs_uv, obs_cam, obs_ray, ray_weight = uv[None], np.zeros(1, np.int32), np.zeros(1, np.int32), np.ones(1)
+        lin = orc.ba_linearize(S, cam[None], X0[None], jacobian_mode=orc.JAC_ANALYTIC)
+        Jsym = np.array(fn(cam[0], *cam[4:7], *X0, 900.0, 500.0, 960.0, 540.0), dtype=float)
+        Jc = Jsym[:, [0, 1, 2, 3]]; Jr = Jsym[:, 4:7]
+        # oracle free camera columns: [fx, fy(dummy), r1, r2, r3]
+        W_want = Jc.T @ Jr
+        assert np.allclose(lin["W"][0][[0, 2, 3, 4]], W_want, rtol=1e-9, atol=1e-9 * np.abs(W_want).max())
+        assert np.allclose(lin["V"][0], Jr.T @ Jr, rtol=1e-9, atol=1e-9 * np.abs(Jr.T @ Jr).max())
+
+
+# ---------------------------------------------------------------- LM: Ceres-1.14 policy
+def test_lm_recovers_ground_truth_c1(orc, scene_c1):
+    cam, ray, _, s, tr = orc.ba_solve(scene_c1, jacobian_mode=orc.JAC_NUMERIC, trace=True)
+    assert s["termination_type"] == orc.CONVERGENCE
+    assert s["num_residuals"] == 2 * scene_c1.n_obs
+    assert np.abs(cam[:, 0] - scene_c1.cam_gt[:, 0]).mean() < 5.0  # px, at noise level for ~100 obs/view
+    assert np.all(np.diff(tr.cost[tr.accepted == 1]) < 0)  # monotonic steps
+    # untouched: cx, cy, t, distortion, and the dummy fy (never read by PTZRayFactor -> zero step)
+    assert np.array_equal(cam[:, [1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14]], scene_c1.cam_init[:, [1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14]])
+    # reported error formula (ptzray_optimizer.cc:962-963)
+    err = math.sqrt(2) * math.sqrt(2 * s["final_cost"] / s["num_residuals"])
+    assert 0.5 < err < 5.0
+
+
+def test_lm_numeric_and_analytic_trajectories_agree(orc, scene_c1):
+    _, _, _, sn, tn = orc.ba_solve(scene_c1, jacobian_mode=orc.JAC_NUMERIC, trace=True)
+    _, _, _, sa, ta = orc.ba_solve(scene_c1, jacobian_mode=orc.JAC_ANALYTIC, trace=True)
+    assert sn["num_iterations"] == sa["num_iterations"] and np.array_equal(tn.accepted, ta.accepted)
+    assert np.allclose(tn.cost, ta.cost, rtol=1e-7)
+
+
+def test_lm_radius_policy(orc):
+    """LevenbergMarquardtStrategy: accepted -> radius / max(1/3, 1 - (2 rho - 1)^3), rejected -> radius / 2, / 4, ..."""
+    import __graft_entry__ as ge
+    sc = ge.load_package().synth.make_scene(5, 60, 300)
+    _, _, _, s, tr = orc.ba_solve(sc, jacobian_mode=orc.JAC_ANALYTIC, trace=True, num_threads=4)
+    assert tr.radius[0] == 1e4
+    dec = 2.0
+    for i in range(1, len(tr.cost)):
+        if tr.accepted[i] == 1:
+            want = min(1e16, tr.radius[i - 1] / max(1 / 3, 1 - (2 * tr.rho[i] - 1) ** 3)); dec = 2.0
+        elif tr.accepted[i] == 0:
+            want = tr.radius[i - 1] / dec; dec *= 2
+        else:
+            want = tr.radius[i - 1] * 0.5
+        assert math.isclose(tr.radius[i], want, rel_tol=1e-12)
+    assert (tr.accepted == 0).any()  # this seed exercises rejected steps
+
+
+def test_lm_max_iterations_and_counts(orc, scene_c1):
+    _, _, _, s, _ = orc.ba_solve(scene_c1, max_num_iterations=2)
+    assert s["termination_type"] == orc.NO_CONVERGENCE and s["num_iterations"] == 2
+    assert s["num_successful_steps"] + s["num_unsuccessful_steps"] == s["num_iterations"] + 1
+
+
+def test_lm_golden_trajectories(pkg, orc):
+    doc = json.load(open(os.path.join(GOLD, "lm_trajectories.json")))
+    for g in doc["ba"][:2]:  # the two C1-sized cases (the 60-view case is covered by the GPU suite)
+        sc = pkg.synth.make_scene(**g["scene"])
+        assert (sc.n_obs, sc.n_ray) == (g["n_obs"], g["n_ray"])  # generator is bit-reproducible
+        cam, _, _, s, tr = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, trace=True, num_threads=1)
+        assert s["termination_type"] == g["summary"]["termination_type"]
+        assert s["num_iterations"] == g["summary"]["num_iterations"]
+        assert tr.accepted.tolist() == g["accepted"]
+        assert np.allclose(tr.cost, g["cost"], rtol=1e-9)
+        assert np.allclose(cam[:, 0], g["focal"], rtol=1e-9)
+
+
+def test_krt_golden_and_gates(pkg, orc):
+    doc = json.load(open(os.path.join(GOLD, "lm_trajectories.json")))
+    rbs = {ft: pkg.synth.make_reloc_batch(8, 128, seed_id=ft, factor_type=ft) for ft in (0, 1)}
+    for g in doc["krt"]:
+        rb = rbs[g["factor_type"]]
+        q = g["query"]
+        sl = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, s, tr = orc.krt_solve(rb.uv_ref[sl], rb.uv_cur[sl], rb.cam_ref[q], loc0, factor_type=g["factor_type"],
+                                   jacobian_mode=orc.JAC_NUMERIC, trace=True)
+        assert s["num_iterations"] == g["summary"]["num_iterations"]
+        assert np.allclose(loc, g["cam_local"], rtol=1e-9, atol=1e-12)
+        assert orc.krt_check(s, loc, 100.0) == g["accepted_by_gates"]
+    # gates of KRTOptimizer::CheckResults (krt_optimizer.cc:504-533)
+    s_ok = dict(g["summary"])
+    cam = np.array(g["cam_local"])
+    assert orc.krt_check(s_ok, cam, 1e9)
+    assert not orc.krt_check(s_ok, cam, 1e-9)              # reprojection error gate
+    bad = cam.copy(); bad[0] = bad[1] = 10.0               # fov = 2 atan(960 / 10) > 170 deg
+    assert not orc.krt_check(s_ok, bad, 1e9)
+    s_nc = dict(s_ok); s_nc["termination_type"] = orc.NO_CONVERGENCE
+    assert not orc.krt_check(s_nc, cam, 1e9)
+
+
+def test_krt_frames_roundtrip(orc):
+    rng = np.random.default_rng(11)
+    ref = _cam(rvec=rng.standard_normal(3) * 0.5); ref[7:10] = [1, 2, 3]
+    cur = _cam(f=2600, rvec=rng.standard_normal(3) * 0.5); cur[7:10] = [-1, 0.5, 2]
+    loc = orc.krt_world_to_local(ref, cur)
+    back = orc.krt_local_to_world(ref, loc, 0)
+    assert np.allclose(orc.rodrigues(back[4:7]), orc.rodrigues(cur[4:7]), atol=1e-12)
+    assert np.allclose(back[7:10], cur[7:10], atol=1e-12)
+    same = orc.krt_world_to_local(ref, ref)  # reloc init: R_cur = R_ref -> local rotation I, rvec 0
+    assert np.allclose(same[4:7], 0, atol=1e-15)
