@@ -1,0 +1,207 @@
+#include "ptzray_optimizer.h"
+
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+namespace ptzcalib {
+
+PTZRayOptimizer::PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                                 const std::vector<Camera>& cameras, const std::vector<std::vector<Point2f>>& pixels,
+                                 const std::vector<std::vector<Point3d>>& pts3d, const std::unordered_set<long>& cam_ids,
+                                 int max_iter, FACTOR_TYPE type)
+    : cameras_(cameras), features_(features), matches_info_(matches_info), pixels_(pixels), pts3d_(pts3d),
+      num_cams_(cameras.size()), type_(type), max_iter_(max_iter)
+{
+  // empty cam_ids => every camera is a candidate (ptzray_optimizer.cc:418-425)
+  if (cam_ids.empty()) for (size_t i = 0; i < cameras_.size(); ++i) cam_ids_.insert(static_cast<long>(i));
+  else cam_ids_ = cam_ids;
+  shared_ic_ids_.resize(cameras_.size());
+  std::iota(shared_ic_ids_.begin(), shared_ic_ids_.end(), 0);  // intrinsics are NOT shared by default (:427-428)
+}
+
+PTZRayOptimizer::PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                                 const std::vector<Camera>& cameras, const std::unordered_set<long>& cam_ids, int max_iter,
+                                 FACTOR_TYPE type)
+    : PTZRayOptimizer(features, matches_info, cameras, {}, {}, cam_ids, max_iter, type)
+{
+}
+
+void PTZRayOptimizer::SetSharedIntrinsics(const std::vector<long>& shared_ic_ids)
+{
+  if (shared_ic_ids.size() != cameras_.size()) return;  // length mismatch: ignored with a warning in the reference (:499-502)
+  shared_ic_ids_ = shared_ic_ids;
+}
+
+void PTZRayOptimizer::T_l_w(const double* tlw, Mat33& R_l_w, Vec3& t_l_w)
+{
+  R_l_w = Rodrigues({tlw[0], tlw[1], tlw[2]});
+  t_l_w = {tlw[3], tlw[4], tlw[5]};
+}
+
+bool PTZRayOptimizer::CheckValid() const
+{  // ptzray_optimizer.cc:515-535
+  if (num_cams_ == 0) return false;
+  if (features_.size() != num_cams_) return false;
+  if (max_iter_ <= 0) return false;
+  if (!pixels_.empty()) {
+    if (pixels_.size() != num_cams_ || pts3d_.size() != num_cams_) return false;
+    for (size_t i = 0; i < num_cams_; ++i)
+      if (pixels_[i].size() != pts3d_[i].size()) return false;
+  }
+  return true;
+}
+
+void PTZRayOptimizer::FindTracks()
+{  // ptzray_optimizer.cc:537-552
+  TracksBuilder builder;
+  builder.Build(matches_info_);
+  builder.Filter(4);
+  builder.ExportToSTL(tracks_);
+  Length(tracks_, track_len_, max_track_len_, min_track_len_);
+}
+
+// SetUpInitialCameraParams (:635-670) + AddConstraints2d2d ordering (:799-850) + Pix2Ray (:768-797)
+void PTZRayOptimizer::Pack()
+{
+  PackedBA& p = packed_;
+  p = PackedBA();
+  std::vector<int> cam_of_image(num_cams_, -1);
+  for (size_t i = 0; i < num_cams_; ++i) {
+    if (!isCandidate(static_cast<long>(i))) continue;
+    cam_of_image[i] = static_cast<int>(p.cam_image.size());
+    p.cam_image.push_back(static_cast<long>(i));
+    const std::vector<double> v = cameras_[i].ToVector();
+    p.cam.insert(p.cam.end(), v.begin(), v.end());
+  }
+  std::vector<Mat33> Rinv(p.cam_image.size()), Kinv(p.cam_image.size());
+  for (size_t c = 0; c < p.cam_image.size(); ++c) {
+    Rinv[c] = Inverse(cameras_[p.cam_image[c]].R());
+    Kinv[c] = Inverse(cameras_[p.cam_image[c]].K());
+  }
+  for (const auto& te : tracks_) {  // std::map: ascending track id
+    const Track& track = te.second;
+    Vec3 acc = {0, 0, 0};
+    size_t n_cand = 0;
+    const int ray_id = static_cast<int>(p.ray_track.size());
+    for (const auto& kv : track) {  // ascending image id
+      if (!isCandidate(kv.first)) continue;
+      const int c = cam_of_image[kv.first];
+      const Point2f pt = features_[kv.first].keypoints[kv.second].pt;
+      p.obs_uv.push_back(pt.x);
+      p.obs_uv.push_back(pt.y);
+      p.obs_cam.push_back(c);
+      p.obs_ray.push_back(ray_id);
+      Vec3 t = Mul(Rinv[c], Mul(Kinv[c], Vec3{pt.x, pt.y, 1.0}));
+      const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+      acc[0] += t[0] / n; acc[1] += t[1] / n; acc[2] += t[2] / n;
+      ++n_cand;
+    }
+    if (n_cand == 0) continue;  // no residual block is ever added for this track: not a parameter of the problem
+    p.ray_track.push_back(te.first);
+    p.ray_weight.push_back(static_cast<double>(track.size()));  // FULL track length, also when only some views are candidates (:805)
+    acc[0] /= n_cand; acc[1] /= n_cand; acc[2] /= n_cand;
+    const double n = std::sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+    p.ray.push_back(acc[0] / n); p.ray.push_back(acc[1] / n); p.ray.push_back(acc[2] / n);
+  }
+}
+
+// host-side evaluation of the 2D-2D residual for the read-back statistics (CalReprojError2d2d, :970-1028)
+static void Residual2d2d(FACTOR_TYPE type, const double* c, const double* X, float u, float v, double* res)
+{
+  const Mat33 R = Rodrigues({c[4], c[5], c[6]});
+  Vec3 x = {X[0], X[1], X[2]};
+  if (type == PTZRay) {
+    const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x = {x[0] / n, x[1] / n, x[2] / n};
+  }
+  const Vec3 P = Mul(R, x);
+  if (type == PTZRay) {
+    res[0] = static_cast<double>(u) - (c[0] * P[0] + c[2] * P[2]) / P[2];
+    res[1] = static_cast<double>(v) - (c[0] * P[1] + c[3] * P[2]) / P[2];
+    return;
+  }
+  if (P[2] < 0) { res[0] = res[1] = 1000000.0; return; }
+  const double px = P[0] / P[2], py = P[1] / P[2];
+  const double r2 = px * px + py * py, r4 = r2 * r2, r6 = r2 * r2 * r2;
+  const double rad = 1.0 + c[10] * r2 + c[11] * r4 + c[12] * r6;
+  const double xd = px * rad + 2.0 * c[13] * px * py + c[14] * (r2 + 2.0 * px * px);
+  const double yd = py * rad + 2.0 * c[14] * px * py + c[13] * (r2 + 2.0 * py * py);
+  res[0] = static_cast<double>(u) - (c[0] * xd + c[2]);
+  res[1] = static_cast<double>(v) - (c[0] * yd + c[3]);
+}
+
+bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras)
+{
+  std::vector<std::vector<Ray>> rays;
+  return Solve(cameras, rays);
+}
+
+bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays)
+{
+  if (!CheckValid()) return false;
+  FindTracks();
+  // Device path limits (documented in DESIGN.md): 2D-3D annotation residuals (georeferencing), shared intrinsics and
+  // the Fxfy / Disp factor types are not implemented yet -> behave as a failed solve, never as a silent CPU solve.
+  for (size_t i = 0; i < num_cams_; ++i)
+    if (isCandidate(static_cast<long>(i)) && !pixels_.empty() && !pixels_[i].empty()) return false;
+  for (size_t i = 0; i < num_cams_; ++i)
+    if (shared_ic_ids_[i] != static_cast<long>(i)) return false;
+  if (type_ != PTZRay && type_ != PTZRayDist) return false;
+  Pack();
+  PackedBA& p = packed_;
+  if (p.obs_cam.empty() || p.ray_track.empty()) return false;
+
+  ptz_ba_problem prob{};
+  prob.n_cam = static_cast<int32_t>(p.cam_image.size());
+  prob.n_ray = static_cast<int32_t>(p.ray_track.size());
+  prob.n_obs = static_cast<int64_t>(p.obs_cam.size());
+  prob.obs_uv = p.obs_uv.data();
+  prob.obs_cam = p.obs_cam.data();
+  prob.obs_ray = p.obs_ray.data();
+  prob.ray_weight = p.ray_weight.data();
+  prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : PTZ_BA_PTZRayDist;
+  ptz_lm_options opt;
+  ptz_lm_options_default(&opt);
+  opt.max_num_iterations = max_iter_;  // ptzray_optimizer.cc:470
+  opt.device_id = device_id_;
+  std::vector<double> cam = p.cam, ray = p.ray;
+  double tlw[6] = {0, 0, 0, 0, 0, 0};
+  if (ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_) != PTZ_OK) return false;
+
+  // CalReprojError (:960-968)
+  init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);
+  final_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.final_cost) / summary_.num_residuals);
+  double sum0 = 0, sum1 = 0;
+  for (size_t a = 0; a < p.obs_cam.size(); ++a) {
+    double res[2];
+    Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
+                 p.obs_uv[2 * a + 1], res);
+    sum0 += res[0] * res[0];
+    sum1 += res[1] * res[1];
+  }
+  final_reproj_error_2d2d_ = std::sqrt((sum0 + sum1) / static_cast<double>(p.obs_cam.size()));
+  final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();  // sqrt(0 / 0) in the reference when there are no annotations
+
+  if (summary_.termination_type != PTZ_CONVERGENCE) return false;  // :482-488
+
+  // ObtainRefinedCameraParams (:672-766); tlw = 0 -> T_l_w is the identity
+  if (cameras.size() < num_cams_) cameras.resize(num_cams_);
+  for (size_t c = 0; c < p.cam_image.size(); ++c) {
+    std::vector<double> param(cam.begin() + 15 * c, cam.begin() + 15 * (c + 1));
+    param[1] = param[0];  // fy := fx for PTZRay / PTZRayDist (:705-706)
+    cameras[p.cam_image[c]].FromVector(param);
+  }
+  rays.clear();
+  rays.resize(num_cams_);
+  for (size_t j = 0; j < p.ray_track.size(); ++j) {
+    const Vec3 ray_w = {ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]};
+    for (const auto& kv : tracks_.at(p.ray_track[j]))
+      rays[kv.first].emplace_back(p.ray_track[j], ray_w, features_[kv.first].keypoints[kv.second].pt);
+  }
+  p.cam = cam;
+  p.ray = ray;
+  return true;
+}
+
+}  // namespace ptzcalib

@@ -1,0 +1,74 @@
+// ptzray_optimizer.h -- PTZRayOptimizer with the reference's public interface
+// (src/core/ptzray_optimizer.h:110-129): same constructors, Solve overloads, error accessors, FACTOR_TYPE.
+// Where the reference owns a ceres::Problem and calls ceres::Solve (ptzray_optimizer.cc:469-475), this class
+// packs the problem into flat arrays and calls the MI355X library through its C-ABI (ptz_ba_solve).
+#pragma once
+
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ptz_calib_amd.h"
+#include "tracks.h"
+#include "types.h"
+
+namespace ptzcalib {
+
+enum FACTOR_TYPE { PTZRay, PTZRayDist, PTZRayFxfyDist, PTZRayDistDisp };
+
+// Packed form of one global-BA problem (what crosses the C-ABI).
+struct PackedBA {
+  std::vector<long> cam_image;     // compact camera id -> image id (ascending)
+  std::vector<int> ray_track;      // compact ray id -> track id (ascending)
+  std::vector<float> obs_uv;       // [2*n_obs]
+  std::vector<int32_t> obs_cam, obs_ray;
+  std::vector<double> ray_weight;  // full track length (ptzray_optimizer.cc:805)
+  std::vector<double> cam;         // [15*n_cam]
+  std::vector<double> ray;         // [3*n_ray] Pix2Ray initialisation
+};
+
+class PTZRayOptimizer {
+ public:
+  PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                  const std::vector<Camera>& cameras, const std::vector<std::vector<Point2f>>& pixels,
+                  const std::vector<std::vector<Point3d>>& pts3d, const std::unordered_set<long>& cam_ids, int max_iter,
+                  FACTOR_TYPE type);
+  PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                  const std::vector<Camera>& cameras, const std::unordered_set<long>& cam_ids, int max_iter, FACTOR_TYPE type);
+  bool Solve(std::vector<Camera>& cameras);
+  bool Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays);
+  double final_reproj_error_all() const { return final_reproj_error_all_; }
+  double final_reproj_error_2d2d() const { return final_reproj_error_2d2d_; }
+  double final_reproj_error_2d3d() const { return final_reproj_error_2d3d_; }
+  void SetSharedIntrinsics(const std::vector<long>& shared_ic_ids);
+  static void T_l_w(const double* tlw, Mat33& R_l_w, Vec3& t_l_w);
+
+  // extras (not in the reference): the packed problem and the solver summary of the last Solve
+  const PackedBA& packed() const { return packed_; }
+  const ptz_lm_summary& summary() const { return summary_; }
+  void SetDevice(int device_id) { device_id_ = device_id; }
+
+ private:
+  bool CheckValid() const;
+  void FindTracks();
+  bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
+  void Pack();
+
+  std::vector<Camera> cameras_;
+  std::vector<ImageFeatures> features_;
+  std::vector<MatchesInfo> matches_info_;
+  std::vector<std::vector<Point2f>> pixels_;
+  std::vector<std::vector<Point3d>> pts3d_;
+  size_t num_cams_ = 0;
+  std::unordered_set<long> cam_ids_;
+  std::vector<long> shared_ic_ids_;
+  FACTOR_TYPE type_;
+  Tracks tracks_;
+  int track_len_ = 0, max_track_len_ = 0, min_track_len_ = 0;
+  int max_iter_ = 100;
+  int device_id_ = 0;
+  PackedBA packed_;
+  ptz_lm_summary summary_{};
+  double init_reproj_error_all_ = 0, final_reproj_error_all_ = 0, final_reproj_error_2d2d_ = 0, final_reproj_error_2d3d_ = 0;
+};
+
+}  // namespace ptzcalib

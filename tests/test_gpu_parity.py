@@ -233,3 +233,49 @@ def test_krt_ragged_and_degenerate(pkg, orc):
         if keep[q] >= 5:
             assert summ[q]["termination_type"] == osumm["termination_type"]
             assert summ[q]["num_iterations"] == osumm["num_iterations"]
+
+
+# ---------------------------------------------------------------------------------------- C++ host classes (drop-in seam)
+def test_cpp_ptzray_optimizer_matches_oracle(pkg, orc, scene_c1):
+    """PTZRayOptimizer (C++ mirror of ptzray_optimizer.h:110-129): features + matches in, refined Camera objects out,
+    through TracksBuilder -> packing -> ptz_ba_solve.  Compared with the oracle run on the same packed problem."""
+    import host_util as hu
+    from types import SimpleNamespace
+    sc = scene_c1
+    kps, plist = hu.scene_to_features_matches(sc)
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200)
+    assert ok and summ["termination_type"] == 0
+    ns = SimpleNamespace(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"],
+                         n_cam=sc.n_cam, n_ray=len(pk["ray_weight"]), factor_type=0, cam_init=sc.cam_init, ray_init=orc.pix2ray(
+                             SimpleNamespace(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"],
+                                             n_cam=sc.n_cam, n_ray=len(pk["ray_weight"]), factor_type=0), sc.cam_init))
+    ocam, oray, _, osumm, _ = orc.ba_solve(ns, jacobian_mode=orc.JAC_NUMERIC)
+    assert summ["num_iterations"] == osumm["num_iterations"]
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6
+    assert np.abs(_relative_rotations(orc, cam) - _relative_rotations(orc, ocam)).max() < 1e-6
+    assert np.array_equal(cam[:, 1], cam[:, 0])  # fy := fx on read-back (ptzray_optimizer.cc:705-706)
+    # reported errors (ptzray_optimizer.cc:962-963, 1027, 1071)
+    want_all = np.sqrt(2) * np.sqrt(2 * osumm["final_cost"] / osumm["num_residuals"])
+    assert abs(err[0] - want_all) / want_all < 1e-8
+    res = orc.ba_residuals(ns, ocam, oray)
+    assert abs(err[1] - np.sqrt((res ** 2).sum() / len(res))) < 1e-6
+    assert np.isnan(err[2])
+    # max_iter reached -> Solve returns false and the cameras are left untouched (ptzray_optimizer.cc:482-488)
+    ok2, cam2, _, s2, _ = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=2)
+    assert not ok2 and s2["termination_type"] == 1 and np.allclose(cam2, sc.cam_init, atol=1e-12)
+
+
+def test_cpp_krt_optimizer_matches_batch_api(pkg):
+    import host_util as hu
+    rb = pkg.synth.make_reloc_batch(6, 128, seed_id=4)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        ok, cur, nit, sm = hu.krt_solve(rb.cam_ref[q], rb.cam_init[q], rb.uv_ref[s], rb.uv_cur[s])
+        assert ok == bool(acc[q]) and nit == summ[q]["num_successful_steps"]  # num_iter_ (krt_optimizer.cc:396)
+        if ok:
+            # the class round-trips through Camera (rvec -> R -> rvec); compare rotations, not rvec bits
+            assert abs(cur[0] - cam_w[q, 0]) / cam_w[q, 0] < 1e-12
+            import __graft_entry__ as ge
+            o = ge.load_oracle()
+            assert np.abs(o.rodrigues(cur[4:7]) - o.rodrigues(cam_w[q, 4:7])).max() < 1e-12
