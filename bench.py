@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="scenes per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="scenes per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded scenes generated per GPU (cycled to fill the batch)")
     ap.add_argument("--views", type=int, default=200)
     ap.add_argument("--obs", type=int, default=500)
