@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptzcalib_hip.so")
+LIB_PATH = os.environ.get("PTZCALIB_LIB", os.path.join(_HERE, "libptzcalib_hip.so"))  # override: A/B probe builds only
 
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 BA_PTZRay, BA_PTZRayDist, BA_PTZRayFxfyDist, BA_PTZRayDistDisp = 0, 1, 2, 3

@@ -16,9 +16,9 @@
 //               S_ij = - sum_{tracks seen by i and j} T_a W_b^T for j < i          [workgroup / camera]
 //               (b is written as row n of the padded S)
 //   cholesky    S y_c = b  (ptz_chol.hip: panel + MFMA syrk per 64-wide block column, back-substitution)
-//   backsub     y_r = E (g_r - sum_a W_a^T y_c), candidate ray                     [thread / ray]
 //   cam_update  candidate camera, its rotation block                              [thread / camera]
-//   eval        model cost change -(J d)^T (r + J d / 2) and candidate cost        [thread / ray]
+//   eval        y_r = E (g_r - sum_a Jr_a^T Jc_a y_c), candidate ray, model cost change
+//               -(J d)^T (r + J d / 2) and candidate cost (Jacobians recomputed)   [thread / ray]
 //   lm_post     step validity, tolerances, rho, accept/reject, radius              [1 block / scene]
 //   (if accepted) cam_prep, lin_ray, lin_cam: re-linearise at the new point
 // Observation records are 16 B (2 x f32 pixel, i32 camera, i32 ray); a workgroup of lin_ray/eval/backsub
@@ -26,6 +26,8 @@
 // every thread then reads them by camera id.  All reductions are fixed-order (bitwise reproducible).
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,6 +39,8 @@ namespace ptz {
 namespace {
 
 constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
+constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (33 doubles: odd -> no same-field bank conflicts)
+constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
 constexpr int WS = 16;           // doubles per observation row of W (NC*3 used): one aligned 128-B line
 
 struct SceneDev {
@@ -46,6 +50,7 @@ struct SceneDev {
   int part_off;  // first partial-sum slot (one per ray chunk)
   int n_chunk;   // ceil(n_ray / RAY_BLOCK)
   int n;         // NC * n_cam: order of the reduced camera system
+  int idx;       // global scene index (the CSR pointer arrays carry one extra entry per preceding scene)
 };
 
 struct LmState {
@@ -76,6 +81,8 @@ struct Dev {
   const int* ray_ptr;   // [total_ray + n_scene] per scene n_ray + 1 entries, global obs index
   const int* cam_ptr;   // [total_cam + n_scene] per scene n_cam + 1 entries into cam_obs
   const int* cam_obs;   // global obs index, camera-major
+  const int* wpos;      // [total_obs] row of W that holds observation a (camera-major position)
+  const int* cam_ray;   // [total_obs] global ray id, camera-major (same order as cam_obs)
   const int* pair_ci;   // scene-local camera ids, ci >= cj
   const int* pair_cj;
   const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
@@ -103,7 +110,6 @@ struct Dev {
   double* diag_r;    // [total_ray][3]
   double* E;         // [total_ray][6]
   double* z;         // [total_ray][3]
-  double* dr;        // [total_ray][3] scaled-space ray step
   double* W;         // [total_obs][WS] (NC*3 used)
   double* partial;   // [total_chunk][2]
   // LM
@@ -168,6 +174,12 @@ __device__ __forceinline__ void stage_table(const double* __restrict__ src, doub
 {
   for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
 }
+// same, re-striding rows of SRC doubles to DST doubles in LDS
+template <int SRC, int DST>
+__device__ __forceinline__ void stage_rows(const double* __restrict__ src, double* dst, int rows)
+{
+  for (int i = threadIdx.x; i < rows * SRC; i += blockDim.x) dst[(i / SRC) * DST + (i % SRC)] = src[i];
+}
 
 // ---- lin_ray: per-ray linearisation ---------------------------------------------------------------------
 // thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  stage_table(d.camblk + (size_t)s.cam_off * CAMBLK, lds, s.n_cam * CAMBLK);
+  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, lds, s.n_cam);
   __syncthreads();
   const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
   if (j >= s.n_ray) return;
@@ -190,11 +202,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   const double Xr[3] = {X[0], X[1], X[2]};
   const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
   const double sw = sqrt(d.ray_w[gj]);
-  const int* rp = d.ray_ptr + s.ray_off + sc;
+  const int* rp = d.ray_ptr + s.ray_off + s.idx;
   double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int a = rp[j]; a < rp[j + 1]; ++a) {
     const float2 uv = d.obs_uv[a];
-    const double* cb = lds + d.obs_cam[a] * CAMBLK;
+    const double* cb = lds + d.obs_cam[a] * CBS;
     double res[2], Jc[2][NC], Jr[2][3];
     ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
     res[0] *= sw; res[1] *= sw;
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
-    double* Wa = d.W + (size_t)a * WS;
+    double* Wa = d.W + (size_t)d.wpos[a] * WS;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
   const double* rays = cur_ray(d, s, st);
-  const int* cp = d.cam_ptr + s.cam_off + sc;
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double U[NC * (NC + 1) / 2], g[NC], cost = 0;
 #pragma unroll
   for (int k = 0; k < NC * (NC + 1) / 2; ++k) U[k] = 0;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
     // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
     double c = 0, gm = 0, xn = 0;
     const double* cam = cur_cam(d, s, st);
-    const int* cp = d.cam_ptr + s.cam_off + sc;
+    const int* cp = d.cam_ptr + s.cam_off + s.idx;
     for (int i = tid; i < s.n_cam; i += 256) {
       const int gi = s.cam_off + i;
       c += d.costc[gi];
@@ -438,36 +450,46 @@ __global__ void k_cam_diag(Dev d)
 // Phase 2 (16-lane groups over ci's camera pairs (ci, cj < ci)): each lane takes entries e = lane, lane+16, ...
 //   of the pair (T_a from LDS, W_b = one aligned 128-B line from L2), accumulates the whole NC x NC product in
 //   registers, the group is reduced with a fixed butterfly and lane 0 stores S_ij = -sum.
+#ifndef PTZ_SCHUR_THREADS
+#define PTZ_SCHUR_THREADS 256
+#endif
+constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
 template <int TYPE>
-__global__ __launch_bounds__(256) void k_schur(Dev d)
+__global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(Dev d)
 {
   constexpr int NC = BaDims<TYPE>::NC;
   constexpr int NU = NC * (NC + 1) / 2;
   constexpr int NT = NC * 3;
-  const int sc = blockIdx.y;
+  int ci, sc;
+  xcd_remap(ci, sc);
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
-  const int ci = blockIdx.x;
   if (ci >= s.n_cam) return;
   const LmState& st = d.lm[sc];
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int* cp = d.cam_ptr + s.cam_off + sc;
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
-  double* T = lds;                 // [no][NT]
-  double* scratch = lds + (size_t)no * NT;  // [16]
+  const int* cpair = d.cam_pair + s.cam_off + s.idx;
+  const int* pp = d.pair_ptr + s.pair_off + s.idx;
+  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
+  const int eb = 0;                                        // entries are addressed by global index
+  double* T = lds;                                  // [no][NT]
+  double* strip = lds + (size_t)no * NT;            // [waves][NC + NU] reduction strip
+  const int2* ents = d.ent + eb;                    // (a slot, W row of b), this camera's contiguous range
+  const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
   double bsum[NC], D[NU];
 #pragma unroll
   for (int k = 0; k < NC; ++k) bsum[k] = 0;
 #pragma unroll
   for (int k = 0; k < NU; ++k) D[k] = 0;
-  for (int q = threadIdx.x; q < no; q += 256) {
-    const int a = d.cam_obs[o0 + q];
-    const int gj = s.ray_off + d.obs_ray[a];
+#ifndef PTZ_DIAG_SCHUR_SKIP_P1
+  for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
+    const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
     const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
     const double* E = d.E + (size_t)gj * 6;
     const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
     double w[NT];
-    const double* Wa = d.W + (size_t)a * WS;
+    const double* Wa = d.W + (size_t)(o0 + q) * WS;  // camera-major rows: sequential stream
 #pragma unroll
     for (int k = 0; k < NT; ++k) w[k] = Wa[k];
     int e = 0;
@@ -481,10 +503,32 @@ __global__ __launch_bounds__(256) void k_schur(Dev d)
       for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
     }
   }
+#endif
+  // one pass of the block tree for all NC + NU sums (fixed order: lanes by butterfly, waves in wave order)
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NV = NC + NU;
+    double v[NV];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) bsum[k] = block_sum(bsum[k], scratch);
+    for (int k = 0; k < NC; ++k) v[k] = wave_sum(bsum[k]);
 #pragma unroll
-  for (int k = 0; k < NU; ++k) D[k] = block_sum(D[k], scratch);   // (also orders the T stores before phase 2)
+    for (int k = 0; k < NU; ++k) v[NC + k] = wave_sum(D[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
+    }
+    __syncthreads();  // also orders the T / ents / pps stores before phase 2
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double t = 0;
+      for (int i = 0; i < SCHUR_THREADS / 64; ++i) t += strip[i * NV + k];
+      v[k] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) bsum[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) D[k] = v[NC + k];
+  }
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
   if (threadIdx.x == 0) {
@@ -506,28 +550,45 @@ __global__ __launch_bounds__(256) void k_schur(Dev d)
       }
     }
   }
-  // ---- phase 2: off-diagonal blocks of row-block ci
-  const int* cpair = d.cam_pair + s.cam_off + sc;
-  const int* pp = d.pair_ptr + s.pair_off + sc;
+#ifdef PTZ_DIAG_SCHUR_SKIP_P2
+  return;
+#endif
+  // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
   const int l = threadIdx.x & 15;
-  for (int pr = cpair[ci] + (threadIdx.x >> 4); pr < cpair[ci + 1]; pr += 16) {
+  for (int pl = (threadIdx.x >> 4); pl < npr; pl += SCHUR_THREADS / 16) {
     double acc[NC * NC];
 #pragma unroll
     for (int k = 0; k < NC * NC; ++k) acc[k] = 0;
-    for (int e = pp[pr] + l; e < pp[pr + 1]; e += 16) {
-      const int2 ab = d.ent[e];
-      const double* Ta = T + ab.x * NT;
-      const double* Wb = d.W + (size_t)ab.y * WS;
-      double wb[NT];
+    const int e1 = pps[pl + 1];
+    // two entries per trip: both 128-B W_b lines are in flight together
+    for (int e = pps[pl] + l; e < e1; e += 32) {
+      const bool two = (e + 16) < e1;
+      const int2 ab0 = ents[e];
+      const int2 ab1 = two ? ents[e + 16] : ab0;
+#ifdef PTZ_DIAG_NOGATHER
+      const double* Wb0 = d.W + (size_t)(o0 + (ab0.y & 7)) * WS;
+      const double* Wb1 = d.W + (size_t)(o0 + (ab1.y & 7)) * WS;
+#else
+      const double* Wb0 = d.W + (size_t)ab0.y * WS;
+      const double* Wb1 = d.W + (size_t)ab1.y * WS;
+#endif
+      double wb0[NT], wb1[NT];
 #pragma unroll
-      for (int k = 0; k < NT; ++k) wb[k] = Wb[k];
+      for (int k = 0; k < NT; ++k) { wb0[k] = Wb0[k]; wb1[k] = Wb1[k]; }
+      const double* Ta0 = T + ab0.x * NT;
+      const double* Ta1 = T + ab1.x * NT;
+      const double f1 = two ? 1.0 : 0.0;
 #pragma unroll
       for (int p = 0; p < NC; ++p) {
-        const double t0 = Ta[3 * p], t1 = Ta[3 * p + 1], t2 = Ta[3 * p + 2];
+        const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
+        const double u0 = f1 * Ta1[3 * p], u1 = f1 * Ta1[3 * p + 1], u2 = f1 * Ta1[3 * p + 2];
 #pragma unroll
-        for (int q = 0; q < NC; ++q) acc[p * NC + q] += t0 * wb[3 * q] + t1 * wb[3 * q + 1] + t2 * wb[3 * q + 2];
+        for (int q = 0; q < NC; ++q)
+          acc[p * NC + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
+                             (u0 * wb1[3 * q] + u1 * wb1[3 * q + 1] + u2 * wb1[3 * q + 2]);
       }
     }
+#ifndef PTZ_DIAG_NOSHFL
 #pragma unroll
     for (int k = 0; k < NC * NC; ++k) {
       double v = acc[k];
@@ -537,8 +598,9 @@ __global__ __launch_bounds__(256) void k_schur(Dev d)
       v += __shfl_xor(v, 1, 16);
       acc[k] = v;
     }
+#endif
     if (l == 0) {
-      const int cj = d.pair_cj[s.pair_off + pr];
+      const int cj = d.pair_cj[s.pair_off + pr0 + pl];
       double* S = A + (size_t)(ci * NC) * np + cj * NC;
 #pragma unroll
       for (int p = 0; p < NC; ++p)
@@ -546,43 +608,6 @@ __global__ __launch_bounds__(256) void k_schur(Dev d)
         for (int q = 0; q < NC; ++q) S[(size_t)p * np + q] = -acc[p * NC + q];
     }
   }
-}
-
-// ---- backsub: SchurEliminator::BackSubstitute + candidate ray --------------------------------------------
-template <int TYPE>
-__global__ __launch_bounds__(RAY_BLOCK) void k_backsub(Dev d)
-{
-  constexpr int NC = BaDims<TYPE>::NC;
-  const int sc = blockIdx.y;
-  if (!d.active[sc]) return;
-  const SceneDev s = d.scene[sc];
-  const LmState& st = d.lm[sc];
-  if (blockIdx.x >= s.n_chunk) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // y_c of the scene
-  stage_table(d.yc + (size_t)sc * d.chol.np, lds, s.n);
-  __syncthreads();
-  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
-  if (j >= s.n_ray) return;
-  const int gj = s.ray_off + j;
-  double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
-  const int* rp = d.ray_ptr + s.ray_off + sc;
-  for (int a = rp[j]; a < rp[j + 1]; ++a) {
-    const double* Wa = d.W + (size_t)a * WS;
-    const double* y = lds + d.obs_cam[a] * NC;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) { t0 -= Wa[3 * k] * y[k]; t1 -= Wa[3 * k + 1] * y[k]; t2 -= Wa[3 * k + 2] * y[k]; }
-  }
-  const double* E = d.E + (size_t)gj * 6;
-  // step = -y (Ceres solves J y = r and negates)
-  const double s0 = -(E[0] * t0 + E[1] * t1 + E[3] * t2);
-  const double s1 = -(E[1] * t0 + E[2] * t1 + E[4] * t2);
-  const double s2 = -(E[3] * t0 + E[4] * t1 + E[5] * t2);
-  d.dr[(size_t)gj * 3] = s0; d.dr[(size_t)gj * 3 + 1] = s1; d.dr[(size_t)gj * 3 + 2] = s2;
-  const double* x = cur_ray(d, s, st) + (size_t)j * 3;
-  double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
-  xc[0] = x[0] + s0 * d.scale_r[(size_t)gj * 3];
-  xc[1] = x[1] + s1 * d.scale_r[(size_t)gj * 3 + 1];
-  xc[2] = x[2] + s2 * d.scale_r[(size_t)gj * 3 + 2];
 }
 
 // ---- cam_update: candidate cameras and their residual-side blocks ----------------------------------------
@@ -617,9 +642,13 @@ __global__ void k_cam_update(Dev d)
   for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CANDBLK + k] = cb[k];
 }
 
-// ---- eval: model cost change and candidate cost -------------------------------------------------------------
-//   model_cost_change = -(J d)^T (r + J d / 2)   (TrustRegionMinimizer::ComputeTrustRegionStep)
+// ---- eval: ray back-substitution, model cost change and candidate cost in one ray-centric pass -----------------
+//   y_r = E (g_r - sum_a Jr_a^T (Jc_a y_c))            (SchurEliminator::BackSubstitute; W_a = Jc_a^T Jr_a is not
+//                                                        re-read: the Jacobian blocks are recomputed, flops are free)
+//   candidate ray = x + scale * (-y_r)
+//   model_cost_change = -(J d)^T (r + J d / 2)          (TrustRegionMinimizer::ComputeTrustRegionStep)
 //   candidate_cost    = 1/2 sum w |r(x + delta)|^2
+// The scaled camera step d_c = -y_c is staged in LDS next to the camera tables of x and of the candidate.
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
 {
@@ -630,40 +659,62 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
   const LmState& st = d.lm[sc];
   if (blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tab = lds;                         // [n_cam][CAMBLK]
-  double* ctab = tab + s.n_cam * CAMBLK;     // [n_cam][CANDBLK]
-  double* dct = ctab + s.n_cam * CANDBLK;    // [n_cam][NC] scaled camera step
-  double* scratch = dct + s.n_cam * NC;      // [16]
-  stage_table(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam * CAMBLK);
-  stage_table(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam * CANDBLK);
-  stage_table(d.dc + (size_t)s.cam_off * NC, dct, s.n_cam * NC);
+  constexpr int DCS = NC + 1;                // odd stride for the step table as well
+  double* tab = lds;                         // [n_cam][CBS]
+  double* ctab = tab + s.n_cam * CBS;        // [n_cam][CDS]
+  double* dct = ctab + s.n_cam * CDS;        // [n_cam][DCS] scaled camera step
+  double* scratch = dct + s.n_cam * DCS;     // [16]
+  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam);
+  stage_rows<CANDBLK, CDS>(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam);
+  stage_rows<NC, DCS>(d.dc + (size_t)s.cam_off * NC, dct, s.n_cam);
   __syncthreads();
   const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
   double mcc = 0, cost = 0;
   if (j < s.n_ray) {
     const int gj = s.ray_off + j;
     const double* X = cur_ray(d, s, st) + (size_t)j * 3;
-    const double* Xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
-    const double Xr[3] = {X[0], X[1], X[2]}, Xn[3] = {Xc[0], Xc[1], Xc[2]};
+    const double Xr[3] = {X[0], X[1], X[2]};
     const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
-    const double ds[3] = {d.dr[(size_t)gj * 3], d.dr[(size_t)gj * 3 + 1], d.dr[(size_t)gj * 3 + 2]};
     const double w = d.ray_w[gj];
     const double sw = sqrt(w);
-    const int* rp = d.ray_ptr + s.ray_off + sc;
-    for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const int* rp = d.ray_ptr + s.ray_off + s.idx;
+    const int a0 = rp[j], a1 = rp[j + 1];
+    // pass 1: t = g_r - sum_a Jr_a^T (Jc_a y_c) = g_r + sum_a Jr_a^T (Jc_a d_c)
+    double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
+    for (int a = a0; a < a1; ++a) {
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
-      const double* cb = tab + ci * CAMBLK;
+      const double* cb = tab + ci * CBS;
       double res[2], Jc[2][NC], Jr[2][3];
       ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
       double m0 = 0, m1 = 0;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * NC + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * DCS + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
+      t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
+      t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
+    }
+    const double* E = d.E + (size_t)gj * 6;
+    // step = -y_r (Ceres solves J y = r and negates)
+    const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
+    const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
+    double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
+    xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
+    // pass 2: model cost change and candidate cost
+    for (int a = a0; a < a1; ++a) {
+      const float2 uv = d.obs_uv[a];
+      const int ci = d.obs_cam[a];
+      const double* cb = tab + ci * CBS;
+      double res[2], Jc[2][NC], Jr[2][3];
+      ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      double m0 = 0, m1 = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * DCS + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
 #pragma unroll
       for (int k = 0; k < 3; ++k) { const double m = sw * sr[k] * ds[k]; m0 += Jr[0][k] * m; m1 += Jr[1][k] * m; }
       mcc += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       double rc[2];
-      ba_residual<TYPE>(ctab + ci * CANDBLK, Xn, uv.x, uv.y, rc);
+      ba_residual<TYPE>(ctab + ci * CDS, Xn, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
     }
   }
@@ -698,7 +749,7 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
   const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
   const double* ray = cur_ray(d, s, st);
   const double* rayc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)s.ray_off * 3;
-  const int* cp = d.cam_ptr + s.cam_off + sc;
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double dn = 0, cn = 0;
   for (int i = tid; i < s.n_cam; i += 256) {
     if (cp[i + 1] <= cp[i]) continue;
@@ -788,7 +839,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_pix2ray(Dev d, double* cam0, doub
   const SceneDev s = d.scene[sc];
   const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
   if (j >= s.n_ray) return;
-  const int* rp = d.ray_ptr + s.ray_off + sc;
+  const int* rp = d.ray_ptr + s.ray_off + s.idx;
   double acc[3] = {0, 0, 0};
   int cnt = 0;
   for (int a = rp[j]; a < rp[j + 1]; ++a) {
@@ -833,12 +884,19 @@ struct ptz_ba_batch {
   int n_scene = 0, type = 0, nc = 4, device = 0;
   std::vector<SceneDev> scenes;
   int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;
-  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0;
+  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0;
   ptz_lm_options opt;
   Dev d;
   std::vector<void*> allocs;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // stream of the group being enqueued (LAUNCH / prof_* use it)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // scenes are split into independent groups, one HIP stream each, so that the latency-bound kernels of one
+  // group (diagonal-tile factorisation, back-substitution, LM control) overlap the throughput kernels of another
+  int n_group = 1;
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> fork_ev, join_ev;
+  std::vector<int> group_first, group_count;
+  std::vector<Dev> dg;
   int* h_active = nullptr;  // pinned
   double *cam0 = nullptr, *ray0 = nullptr;  // device copies of the initial state
   bool has_state = false;
@@ -888,6 +946,13 @@ struct ptz_ba_batch {
 
 namespace {
 
+// dynamic LDS of k_schur: T table, scratch, staged entries, pair offsets, reduction strip
+inline size_t schur_lds_bytes(int max_obs, int max_ent, int max_pair, int NC)
+{
+  (void)max_ent; (void)max_pair;
+  return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2));
+}
+
 template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
 {
   T* p = nullptr;
@@ -905,9 +970,79 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
   const Dev& d = b->d;
   b->prof_begin(P_LIN);
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
-  LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CAMBLK, d);
+  LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   b->prof_end();
+}
+
+static void make_groups(ptz_ba_batch* b)
+{
+  const int B = b->n_scene;
+  const int G = std::max(1, std::min(b->n_group, B));
+  b->group_first.clear(); b->group_count.clear(); b->dg.clear();
+  for (int g = 0; g < G; ++g) {
+    const int lo = (int)((int64_t)B * g / G), hi = (int)((int64_t)B * (g + 1) / G);
+    b->group_first.push_back(lo);
+    b->group_count.push_back(hi - lo);
+    Dev d = b->d;  // per-scene arrays are re-based; everything else is addressed through SceneDev offsets
+    const size_t np = d.chol.np, nt = np / CHOL_NB;
+    d.n_scene = hi - lo;
+    d.scene += lo; d.lm += lo; d.active += lo; d.ray_fail += lo;
+    d.yc += (size_t)lo * np;
+    d.chol.count = hi - lo;
+    d.chol.A += (size_t)lo * np * np;
+    d.chol.Ldiag += (size_t)lo * nt * CHOL_NB * CHOL_NB;
+    d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
+    d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
+    b->dg.push_back(d);
+  }
+  while ((int)b->streams.size() < G) {
+    hipStream_t st; (void)hipStreamCreate(&st); b->streams.push_back(st);
+    hipEvent_t e1, e2; (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+    b->fork_ev.push_back(e1); b->join_ev.push_back(e2);
+  }
+}
+
+// one LM pass of one group, enqueued on b->stream; returns after enqueueing (no synchronisation)
+template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
+{
+  constexpr int NC = BaDims<TYPE>::NC;
+  const int B = d.n_scene;
+  hipStream_t st = b->stream;
+  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16);
+  const size_t schur_smem = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
+  b->prof_begin(P_LMCTL);
+  LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
+  b->prof_end();
+  if (last) return;
+  b->prof_begin(P_RAYPREP);
+  LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), 0, d);
+  LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+  b->prof_end();
+  b->prof_begin(P_CLEAR);
+  chol_clear(d.chol, st);
+  b->prof_end();
+  b->prof_begin(P_SCHUR);
+  LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  b->prof_end();
+  chol_factor_solve_profiled(d.chol, d.yc, st, b);
+  b->prof_begin(P_BACKSUB);
+  LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+  b->prof_end();
+  b->prof_begin(P_EVAL);
+  LAUNCH(k_eval<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), eval_smem, d);
+  b->prof_end();
+  b->prof_begin(P_LMCTL);
+  LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(256), 0, d);
+  b->prof_end();
+  {
+    const Dev& dd = d;
+    b->prof_begin(P_LIN);
+    LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, dd);
+    LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, dd);
+    LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
+    b->prof_end();
+  }
 }
 
 template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
@@ -915,11 +1050,18 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   constexpr int NC = BaDims<TYPE>::NC;
   const Dev& d = b->d;
   const int B = b->n_scene;
-  hipStream_t st = b->stream;
-  PTZ_HIP_TRY(hipEventRecord(b->ev0, st));
-  // x <- initial state, scales <- 1, LM state reset
-  PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, st));
-  PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, st));
+  const bool dbg = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  double t_enq = 0, t_sync = 0;
+  make_groups(b);
+  const int G = (int)b->dg.size();
+  hipStream_t s0 = b->streams[0];
+  b->stream = s0;
+  PTZ_HIP_TRY(hipEventRecord(b->ev0, s0));
+  // x <- initial state, scales <- 1, LM state reset (whole batch, stream 0)
+  PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, s0));
+  PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, s0));
   LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
   LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
@@ -929,51 +1071,51 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     LAUNCH(k_jacobi_scale<TYPE>, dim3((std::max(b->max_cam, b->max_ray) + 255) / 256, B), dim3(256), 0, d);
     enqueue_linearize<TYPE>(b);
   }
+  // fork: every group's stream continues after the common prologue
+  PTZ_HIP_TRY(hipEventRecord(b->fork_ev[0], s0));
+  for (int g = 1; g < G; ++g) PTZ_HIP_TRY(hipStreamWaitEvent(b->streams[g], b->fork_ev[0], 0));
   const int max_it = b->opt.max_num_iterations;
-  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16);
-  const size_t schur_smem = sizeof(double) * ((size_t)b->max_cam_obs * NC * 3 + 16);
+  std::vector<char> galive(G, 1);
   for (int pass = 0; pass <= max_it; ++pass) {
-    b->prof_begin(P_LMCTL);
-    LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
-    b->prof_end();
-    if (pass == max_it) break;
-    b->prof_begin(P_RAYPREP);
-    LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), 0, d);
-    LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
-    b->prof_end();
-    b->prof_begin(P_CLEAR);
-    chol_clear(d.chol, st);
-    b->prof_end();
-    b->prof_begin(P_SCHUR);
-    LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(256), schur_smem, d);
-    b->prof_end();
-    chol_factor_solve_profiled(d.chol, d.yc, st, b);
-    b->prof_begin(P_BACKSUB);
-    LAUNCH(k_backsub<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_n, d);
-    LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
-    b->prof_end();
-    b->prof_begin(P_EVAL);
-    LAUNCH(k_eval<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), eval_smem, d);
-    b->prof_end();
-    b->prof_begin(P_LMCTL);
-    LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(256), 0, d);
-    b->prof_end();
-    enqueue_linearize<TYPE>(b);
-    // any scene still running?
-    b->prof_begin(P_SYNC);
-    PTZ_HIP_TRY(hipMemcpyAsync(b->h_active, d.active, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    b->prof_end();
-    PTZ_HIP_TRY(hipStreamSynchronize(st));
-    bool any = false;
-    for (int i = 0; i < B; ++i) any |= (b->h_active[i] != 0);
-    if (!any) break;
+    bool any_group = false;
+    const double te0 = now();
+    for (int g = 0; g < G; ++g) {
+      if (!galive[g]) continue;
+      any_group = true;
+      b->stream = b->streams[g];
+      enqueue_pass<TYPE>(b, b->dg[g], pass == max_it);
+      if (pass < max_it) {
+        b->prof_begin(P_SYNC);
+        PTZ_HIP_TRY(hipMemcpyAsync(b->h_active + b->group_first[g], b->dg[g].active, sizeof(int) * b->group_count[g],
+                                   hipMemcpyDeviceToHost, b->streams[g]));
+        b->prof_end();
+      }
+    }
+    const double te1 = now();
+    t_enq += te1 - te0;
+    if (!any_group || pass == max_it) break;
+    for (int g = 0; g < G; ++g) {
+      if (!galive[g]) continue;
+      PTZ_HIP_TRY(hipStreamSynchronize(b->streams[g]));
+      bool any = false;
+      for (int i = 0; i < b->group_count[g]; ++i) any |= (b->h_active[b->group_first[g] + i] != 0);
+      galive[g] = any;
+    }
+    t_sync += now() - te1;
   }
-  PTZ_HIP_TRY(hipEventRecord(b->ev1, st));
-  PTZ_HIP_TRY(hipStreamSynchronize(st));
+  // join
+  for (int g = 1; g < G; ++g) {
+    PTZ_HIP_TRY(hipEventRecord(b->join_ev[g], b->streams[g]));
+    PTZ_HIP_TRY(hipStreamWaitEvent(s0, b->join_ev[g], 0));
+  }
+  b->stream = s0;
+  PTZ_HIP_TRY(hipEventRecord(b->ev1, s0));
+  PTZ_HIP_TRY(hipStreamSynchronize(s0));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
   b->last_ms = ms;
   b->prof_collect();
+  if (dbg) fprintf(stderr, "[ptz_ba] groups %d: total %.2f ms, enqueue %.2f ms, sync-wait %.2f ms, device %.2f ms\n", G, now() - t_start, t_enq, t_sync, ms);
   if (out) {
     std::vector<LmState> h(B);
     PTZ_HIP_TRY(hipMemcpy(h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
@@ -1071,7 +1213,9 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   if (b->h_active) (void)hipHostFree(b->h_active);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  for (auto st : b->streams) (void)hipStreamDestroy(st);
+  for (auto e : b->fork_ev) (void)hipEventDestroy(e);
+  for (auto e : b->join_ev) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -1104,7 +1248,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   ptz_ba_batch* b = new ptz_ba_batch();
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
   std::vector<float2> h_uv;
-  std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr;
+  std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr, h_wpos, h_camray;
   std::vector<int2> h_ent;
   std::vector<int> h_campair;
   std::vector<double> h_w;
@@ -1122,6 +1266,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     s.pair_off = b->total_pair; s.ent_off = b->total_ent; s.part_off = b->total_chunk;
     s.n_chunk = (p.n_ray + RAY_BLOCK - 1) / RAY_BLOCK;
     s.n = NC * p.n_cam;
+    s.idx = i;
     // observations, ray ranges
     const int obase = s.obs_off;
     std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
@@ -1144,7 +1289,12 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       std::vector<int> fill(cnt_cam.begin(), cnt_cam.end() - 1);
       const size_t base = h_camobs.size();
       h_camobs.resize(base + p.n_obs);
-      for (int64_t a = 0; a < p.n_obs; ++a) h_camobs[base + fill[p.obs_cam[a]]++] = obase + (int)a;
+      h_camray.resize(base + p.n_obs);
+      for (int64_t a = 0; a < p.n_obs; ++a) {
+        const int slot = fill[p.obs_cam[a]]++;
+        h_camobs[base + slot] = obase + (int)a;
+        h_camray[base + slot] = s.ray_off + p.obs_ray[a];
+      }
       for (int c = 0; c <= p.n_cam; ++c) h_camptr.push_back(obase + cnt_cam[c]);
     }
     // camera-pair entry lists (off-diagonal blocks): for every ray, every (a, b) with cam(a) > cam(b);
@@ -1155,6 +1305,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         std::vector<int> fill(p.n_cam, 0);
         for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
         for (int c = 0; c < p.n_cam; ++c) b->max_cam_obs = std::max(b->max_cam_obs, fill[c]);
+        for (int64_t a = 0; a < p.n_obs; ++a) h_wpos.push_back(obase + cnt_cam[p.obs_cam[a]] + pos[a]);
       }
       std::vector<int64_t> keys;  // (ci * n_cam + cj) << 32 | running index
       std::vector<int2> ents;
@@ -1165,7 +1316,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
             if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
             if (ci <= cj) continue;
             keys.push_back(((int64_t)ci * p.n_cam + cj) << 32 | (int64_t)ents.size());
-            ents.push_back(make_int2(pos[a], obase + bb));
+            ents.push_back(make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]));  // (LDS slot of T_a, W row of b)
           }
       }
       std::sort(keys.begin(), keys.end());
@@ -1189,8 +1340,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       h_pptr.push_back(b->total_ent + (int)keys.size());
       // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
       cam_first[p.n_cam] = npair;
+      {
+        std::vector<int> cnt(p.n_cam, 0);
+        for (size_t e = 0; e < keys.size(); ++e) ++cnt[(int)((keys[e] >> 32) / p.n_cam)];
+        for (int c = 0; c < p.n_cam; ++c) b->max_cam_ent = std::max(b->max_cam_ent, cnt[c]);
+      }
       for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
       for (int c = 0; c <= p.n_cam; ++c) h_campair.push_back(cam_first[c]);
+      for (int c = 0; c < p.n_cam; ++c) b->max_cam_pair = std::max(b->max_cam_pair, cam_first[c + 1] - cam_first[c]);
       s.n_pair = npair;
       b->total_ent += (int)keys.size();
       b->total_pair += npair;
@@ -1203,7 +1360,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   (void)tot_ent;
   // LDS budget of the eval kernel bounds the camera count of a scene (160 KiB per workgroup)
-  if (sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16) > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
+  if (sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16) > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
 
   Dev& d = b->d;
   memset(&d, 0, sizeof(d));
@@ -1217,6 +1374,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(upload(b, h_rayptr, &d.ray_ptr));
   TRY(upload(b, h_camptr, &d.cam_ptr));
   TRY(upload(b, h_camobs, &d.cam_obs));
+  TRY(upload(b, h_wpos, &d.wpos));
+  TRY(upload(b, h_camray, &d.cam_ray));
   TRY(upload(b, h_pci, &d.pair_ci));
   TRY(upload(b, h_pcj, &d.pair_cj));
   TRY(upload(b, h_pptr, &d.pair_ptr));
@@ -1243,7 +1402,6 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.dr, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.W, (size_t)b->total_obs * WS));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
@@ -1279,25 +1437,27 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   d.opt.function_tolerance = o.function_tolerance;
   d.opt.gradient_tolerance = o.gradient_tolerance;
   d.opt.parameter_tolerance = o.parameter_tolerance;
-  if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
+  b->n_group = 1;  // one group by default; more streams overlap little on MI355X (measured: <= 3 %)
+  if (const char* e = getenv("PTZ_BA_STREAMS")) b->n_group = std::max(1, atoi(e));
+  make_groups(b);
+  b->stream = b->streams.empty() ? nullptr : b->streams[0];
+  if (b->stream == nullptr || hipEventCreate(&b->ev0) != hipSuccess ||
       hipEventCreate(&b->ev1) != hipSuccess || hipHostMalloc((void**)&b->h_active, sizeof(int) * n) != hipSuccess) {
     ptz_ba_batch_destroy(b);
     return PTZ_ENODEVICE;
   }
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
-  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CAMBLK + CANDBLK + NC) + 16));
-  const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CAMBLK);
-  const int schur_smem = (int)(sizeof(double) * ((size_t)b->max_cam_obs * NC * 3 + 16));
+  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16));
+  const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CBS);
+  const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
   if (type == PTZ_BA_PTZRay) {
     (void)hipFuncSetAttribute((const void*)k_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
-    (void)hipFuncSetAttribute((const void*)k_backsub<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * b->max_n));
     (void)hipFuncSetAttribute((const void*)k_eval<0>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
     (void)hipFuncSetAttribute((const void*)k_lin_ray<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
   }
   else {
     (void)hipFuncSetAttribute((const void*)k_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
-    (void)hipFuncSetAttribute((const void*)k_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * b->max_n));
     (void)hipFuncSetAttribute((const void*)k_eval<1>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
     (void)hipFuncSetAttribute((const void*)k_lin_ray<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
   }
@@ -1410,7 +1570,13 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
       q[0] = p[0]; q[1] = p[1]; q[2] = p[3]; q[3] = p[1]; q[4] = p[2]; q[5] = p[4]; q[6] = p[3]; q[7] = p[4]; q[8] = p[5];
     }
   }
-  if (W) PTZ_HIP_TRY(hipMemcpy2D(W, sizeof(double) * NC * 3, d.W + (size_t)s.obs_off * WS, sizeof(double) * WS, sizeof(double) * NC * 3, s.n_obs, hipMemcpyDeviceToHost));
+  if (W) {  // rows are stored camera-major; return them in observation order
+    std::vector<double> rows((size_t)s.n_obs * WS);
+    std::vector<int> wp(s.n_obs);
+    PTZ_HIP_TRY(hipMemcpy(rows.data(), d.W + (size_t)s.obs_off * WS, sizeof(double) * WS * s.n_obs, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(hipMemcpy(wp.data(), d.wpos + s.obs_off, sizeof(int) * s.n_obs, hipMemcpyDeviceToHost));
+    for (int a = 0; a < s.n_obs; ++a) memcpy(W + (size_t)a * NC * 3, &rows[(size_t)(wp[a] - s.obs_off) * WS], sizeof(double) * NC * 3);
+  }
   return PTZ_OK;
 }
 

@@ -158,11 +158,12 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
 // wave-private LDS strip, so the four waves never synchronise after the initial load.
 __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const double* __restrict__ Dinv, int k)
 {
-  const int sys = blockIdx.y;
+  int bx, sys;
+  xcd_remap(bx, sys);
   if (cb.active && !cb.active[sys]) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const int ti = k + 1 + blockIdx.x;
+  const int ti = k + 1 + bx;
   if (k * NB > n || ti * NB > n) return;  // padding
   double* A = cb.A + (size_t)sys * np * np;
   __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
@@ -221,13 +222,14 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
 // ---- trailing update: A_ij -= L_ik L_jk^T on the matrix cores ---------------------------------------
 __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k)
 {
-  const int sys = blockIdx.y;
+  int bx, sys;
+  xcd_remap(bx, sys);
   if (cb.active && !cb.active[sys]) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   // linear index -> (i, j), k < j <= i < nt (row-major over the lower triangle of the trailing block)
   const int m = nt - k - 1;
-  int t = blockIdx.x;
+  int t = bx;
   int ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
   while (ii * (ii + 1) / 2 > t) --ii;

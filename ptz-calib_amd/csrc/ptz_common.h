@@ -21,6 +21,20 @@ namespace ptz {
 
 constexpr int WAVE = 64;
 
+// ---- XCD-aware block remap -------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs by linear block id.  For 2-D grids (x = item, y = scene) this
+// bijective remap gives each XCD a contiguous range of the logical (scene, item) space, so the workgroups that
+// share a scene's data share one XCD's L2.  Placement is a speed matter only; results never depend on it.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by)
+{
+  const unsigned gx = gridDim.x, total = gridDim.x * gridDim.y;
+  const unsigned L = blockIdx.x + gx * blockIdx.y;
+  const unsigned q = total / 8, r = total % 8, xcd = L % 8, idx = L / 8;
+  const unsigned Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bx = (int)(Lp % gx);
+  by = (int)(Lp / gx);
+}
+
 // ---- deterministic reductions ----------------------------------------------------------------------
 // Butterfly over the 64 lanes of a wave: every lane ends with the same, order-fixed sum.
 __device__ __forceinline__ double wave_sum(double v)
