@@ -22,7 +22,7 @@ _ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUP
 EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_batch_create", "ptz_ba_batch_destroy",
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
-           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_chol_solve_batch", "ptz_krt_solve_batch"]
+           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch"]
 
 
 class PtzError(RuntimeError):
@@ -106,7 +106,15 @@ def _pack_problem(sc, keep):
     p = BaProblem()
     p.n_cam, p.n_ray, p.n_obs = sc.n_cam, sc.n_ray, len(arrs["cam"])
     p.obs_uv, p.obs_cam, p.obs_ray, p.ray_weight = _p(arrs["uv"]), _p(arrs["cam"]), _p(arrs["ray"]), _p(arrs["w"])
-    p.n_obs3d = 0
+    o3 = getattr(sc, "obs3d", None)
+    if o3 is not None and len(o3["cam"]) > 0:
+        arrs["o3uv"] = np.ascontiguousarray(o3["uv"], dtype=np.float32)
+        arrs["o3xyz"] = np.ascontiguousarray(o3["xyz"], dtype=np.float64)
+        arrs["o3cam"] = np.ascontiguousarray(o3["cam"], dtype=np.int32)
+        p.n_obs3d = len(arrs["o3cam"])
+        p.obs3d_uv, p.obs3d_xyz, p.obs3d_cam = _p(arrs["o3uv"]), _p(arrs["o3xyz"]), _p(arrs["o3cam"])
+    else:
+        p.n_obs3d = 0
     p.factor_type = sc.factor_type
     return p
 
@@ -125,7 +133,8 @@ class BaBatch:
         self.cam_off = np.concatenate([[0], np.cumsum([s.n_cam for s in self.scenes])])
         self.ray_off = np.concatenate([[0], np.cumsum([s.n_ray for s in self.scenes])])
         self.obs_off = np.concatenate([[0], np.cumsum([s.n_obs for s in self.scenes])])
-        self.nc = int(lib().ptz_ba_cam_block_dim(self.scenes[0].factor_type))
+        self.nw = int(lib().ptz_ba_cam_block_dim(self.scenes[0].factor_type))
+        self.nc = int(lib().ptz_ba_batch_cam_block_dim(self.handle))
 
     def close(self):
         if self.handle:
@@ -138,10 +147,13 @@ class BaBatch:
         except Exception:
             pass
 
-    def set_state(self, cams=None, rays=None):
+    def set_state(self, cams=None, rays=None, tlws=None):
         cam = np.ascontiguousarray(np.concatenate([s.cam_init for s in self.scenes] if cams is None else cams), dtype=np.float64)
         ray = np.ascontiguousarray(np.concatenate([s.ray_init for s in self.scenes] if rays is None else rays), dtype=np.float64)
-        _check(lib().ptz_ba_batch_set_state(self.handle, _p(cam), _p(ray), None), "ptz_ba_batch_set_state")
+        if tlws is None and any(getattr(s, "tlw_init", None) is not None for s in self.scenes):
+            tlws = [getattr(s, "tlw_init", None) if getattr(s, "tlw_init", None) is not None else np.zeros(6) for s in self.scenes]
+        tlw = None if tlws is None else np.ascontiguousarray(np.stack(tlws), dtype=np.float64)
+        _check(lib().ptz_ba_batch_set_state(self.handle, _p(cam), _p(ray), _p(tlw)), "ptz_ba_batch_set_state")
 
     def pix2ray(self):
         _check(lib().ptz_ba_batch_pix2ray(self.handle), "ptz_ba_batch_pix2ray")
@@ -154,9 +166,11 @@ class BaBatch:
     def get_state(self):
         cam = np.zeros((int(self.cam_off[-1]), 15))
         ray = np.zeros((int(self.ray_off[-1]), 3))
-        _check(lib().ptz_ba_batch_get_state(self.handle, _p(cam), _p(ray), None), "ptz_ba_batch_get_state")
+        tlw = np.zeros((self.n, 6))
+        _check(lib().ptz_ba_batch_get_state(self.handle, _p(cam), _p(ray), _p(tlw)), "ptz_ba_batch_get_state")
         cams = [cam[self.cam_off[i]:self.cam_off[i + 1]] for i in range(self.n)]
         rays = [ray[self.ray_off[i]:self.ray_off[i + 1]] for i in range(self.n)]
+        self.last_tlw = tlw
         return cams, rays
 
     def last_solve_ms(self) -> float:
@@ -179,22 +193,25 @@ class BaBatch:
         nc = self.nc
         cost = C.c_double()
         g_c = np.zeros((s.n_cam, nc)); U = np.zeros((s.n_cam, nc, nc))
-        g_r = np.zeros((s.n_ray, 3)); V = np.zeros((s.n_ray, 3, 3)); W = np.zeros((s.n_obs, nc, 3))
+        g_r = np.zeros((s.n_ray, 3)); V = np.zeros((s.n_ray, 3, 3)); W = np.zeros((s.n_obs, self.nw, 3))
         _check(lib().ptz_ba_batch_linearize(self.handle, index, C.byref(cost), _p(g_c), _p(U), _p(g_r), _p(V), _p(W)),
                "ptz_ba_batch_linearize")
         return dict(cost=cost.value, g_c=g_c, U=U, g_r=g_r, V=V, W=W, nc=nc)
 
 
-def ba_solve(scene, cam0=None, ray0=None, **opt):
-    """One-shot ptz_ba_solve.  Returns (cam, ray, summary dict)."""
+def ba_solve(scene, cam0=None, ray0=None, tlw0=None, return_tlw=False, **opt):
+    """One-shot ptz_ba_solve.  Returns (cam, ray, summary dict) [+ tlw when return_tlw]."""
     keep = []
     p = _pack_problem(scene, keep)
     cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
     ray = np.array(scene.ray_init if ray0 is None else ray0, dtype=np.float64, order="C").copy()
+    if tlw0 is None:
+        tlw0 = getattr(scene, "tlw_init", None)
+    tlw = np.zeros(6) if tlw0 is None else np.array(tlw0, dtype=np.float64).copy()
     o = default_options(**opt)
     s = LmSummary()
-    _check(lib().ptz_ba_solve(C.byref(p), _p(cam), _p(ray), None, C.byref(o), C.byref(s)), "ptz_ba_solve")
-    return cam, ray, s.as_dict()
+    _check(lib().ptz_ba_solve(C.byref(p), _p(cam), _p(ray), _p(tlw), C.byref(o), C.byref(s)), "ptz_ba_solve")
+    return (cam, ray, s.as_dict(), tlw) if return_tlw else (cam, ray, s.as_dict())
 
 
 def chol_solve_batch(A, rhs, device_id=0):

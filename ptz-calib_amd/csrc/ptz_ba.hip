@@ -51,6 +51,7 @@ struct SceneDev {
   int n_chunk;   // ceil(n_ray / RAY_BLOCK)
   int n;         // NC * n_cam: order of the reduced camera system
   int idx;       // global scene index (the CSR pointer arrays carry one extra entry per preceding scene)
+  int o3_off, n_o3;  // 2D-3D annotation observations of the scene
 };
 
 struct LmState {
@@ -111,7 +112,23 @@ struct Dev {
   double* E;         // [total_ray][6]
   double* z;         // [total_ray][3]
   double* W;         // [total_obs][WS] (NC*3 used)
-  double* partial;   // [total_chunk][2]
+  double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
+  // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
+  const float2* o3_uv;  // [total_o3]
+  const double* o3_xyz; // [total_o3][3] world points
+  const int* o3_cam;    // [total_o3] scene-local camera id
+  double* tlw_x;     // [2][n_scene_total][6]
+  size_t tlw_stride;
+  double* tlwblk;    // [n_scene_total][TLWBLK] at x
+  double* tlwcand;   // [n_scene_total][TLWBLK] at the candidate (R_lw and t used)
+  double* scale_t;   // [n_scene_total][6]
+  double* diag_t;    // [n_scene_total][6]
+  double* Ut;        // [n_scene_total][36]
+  double* gt;        // [n_scene_total][6]
+  double* dt;        // [n_scene_total][6] scaled-space tlw step
+  double* Jc3;       // [total_o3][2][NC] (scaled)
+  double* Jt3;       // [total_o3][2][6]  (scaled)
+  double* r3;        // [total_o3][2]
   // LM
   LmState* lm;
   int* active;       // [n_scene]
@@ -131,9 +148,25 @@ __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s
   return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
 }
 
-template <int TYPE> struct FreeIdx;
-template <> struct FreeIdx<0> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : 3 + k; } };            // f, r1..r3
-template <> struct FreeIdx<1> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : (k == 1 ? 10 : 2 + k); } };  // f, k1, r1..r3
+// TYPE = factor (0 PTZRay, 1 PTZRayDist) | has3d << 1.
+//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]
+//   NC free camera parameters: without annotations the same set (the reference's always-zero fy column is not
+//   materialised); with 2D-3D annotation residuals fy becomes live (Reproj2d3dFactor reads it, ptzray_optimizer.cc:273):
+//   [f, fy, (k1), r1, r2, r3], and the 6-dof T_l_w block joins the reduced system.
+template <int TYPE> struct Dims {
+  static constexpr int FACTOR = TYPE & 1, HAS3D = (TYPE >> 1) & 1;
+  static constexpr int NW = 4 + FACTOR;
+  static constexpr int NC = NW + HAS3D;
+  static constexpr int NG = 6 * HAS3D;  // size of the global (tlw) block
+  // position of 2D-2D column k inside the NC block
+  static __host__ __device__ constexpr int pos(int k) { return HAS3D ? (k == 0 ? 0 : k + 1) : k; }
+  // index of free parameter k of the NC block in the Camera 15-vector
+  static __host__ __device__ constexpr int at(int k)
+  {
+    // PTZRay: f r1 r2 r3 | PTZRayDist: f k1 r.. | +3D: f fy r.. | f fy k1 r..
+    return k == 0 ? 0 : (HAS3D && k == 1) ? 1 : (FACTOR && k == 1 + HAS3D) ? 10 : 4 + (k - (NC - 3));
+  }
+};
 
 __device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl)
 {
@@ -156,7 +189,7 @@ __device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool 
 template <int TYPE>
 __global__ void k_cam_prep(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -167,6 +200,16 @@ __global__ void k_cam_prep(Dev d)
   fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
 #pragma unroll
   for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
+  if (Dims<TYPE>::HAS3D && i == 0) {
+    const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+    double R[9], Jl[9];
+    const double rv[3] = {t[0], t[1], t[2]};
+    rodrigues(rv, R);
+    so3_left_jacobian(rv, Jl);
+    for (int k = 0; k < 9; ++k) { tb[k] = R[k]; tb[9 + k] = Jl[k]; }
+    tb[18] = t[3]; tb[19] = t[4]; tb[20] = t[5];
+  }
 }
 
 // stage a scene's camera table into LDS (stride words per camera)
@@ -187,7 +230,7 @@ __device__ __forceinline__ void stage_rows(const double* __restrict__ src, doubl
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -207,11 +250,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   for (int a = rp[j]; a < rp[j + 1]; ++a) {
     const float2 uv = d.obs_uv[a];
     const double* cb = lds + d.obs_cam[a] * CBS;
-    double res[2], Jc[2][NC], Jr[2][3];
-    ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    double res[2], Jc[2][NW], Jr[2][3];
+    ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
     res[0] *= sw; res[1] *= sw;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k]; Jc[0][k] *= m; Jc[1][k] *= m; }
+    for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
     V[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
@@ -224,7 +267,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
     double* Wa = d.W + (size_t)d.wpos[a] * WS;
 #pragma unroll
-    for (int k = 0; k < NC; ++k)
+    for (int k = 0; k < NW; ++k)
 #pragma unroll
       for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
   }
@@ -240,7 +283,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -254,27 +297,27 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
   const double* rays = cur_ray(d, s, st);
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
-  double U[NC * (NC + 1) / 2], g[NC], cost = 0;
+  double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
-  for (int k = 0; k < NC * (NC + 1) / 2; ++k) U[k] = 0;
+  for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = 0;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) g[k] = 0;
+  for (int k = 0; k < NW; ++k) g[k] = 0;
   for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
     const int a = d.cam_obs[q];
     const float2 uv = d.obs_uv[a];
     const int j = d.obs_ray[a];
     const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
-    double res[2], Jc[2][NC], Jr[2][3];
-    ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    double res[2], Jc[2][NW], Jr[2][3];
+    ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
     const double w = d.ray_w[s.ray_off + j];
     const double sw = sqrt(w);
     cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
     res[0] *= sw; res[1] *= sw;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k]; Jc[0][k] *= m; Jc[1][k] *= m; }
+    for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
     int e = 0;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
+    for (int k = 0; k < NW; ++k) {
       g[k] += Jc[0][k] * res[0] + Jc[1][k] * res[1];
 #pragma unroll
       for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
@@ -282,30 +325,92 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   }
   cost = wave_sum(cost);
 #pragma unroll
-  for (int k = 0; k < NC; ++k) g[k] = wave_sum(g[k]);
+  for (int k = 0; k < NW; ++k) g[k] = wave_sum(g[k]);
 #pragma unroll
-  for (int k = 0; k < NC * (NC + 1) / 2; ++k) U[k] = wave_sum(U[k]);
+  for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
   if (lane == 0) {
     d.costc[gi] = cost;
+    if (Dims<TYPE>::HAS3D) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
+#pragma unroll
+      for (int k = 0; k < NC * NC; ++k) d.U[(size_t)gi * NC * NC + k] = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d.gc[(size_t)gi * NC + k] = 0;
+    }
     int e = 0;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      d.gc[(size_t)gi * NC + k] = g[k];
+    for (int k = 0; k < NW; ++k) {
+      const int pk = Dims<TYPE>::pos(k);
+      d.gc[(size_t)gi * NC + pk] = g[k];
 #pragma unroll
       for (int l = 0; l <= k; ++l) {
-        d.U[(size_t)gi * NC * NC + k * NC + l] = U[e];
-        d.U[(size_t)gi * NC * NC + l * NC + k] = U[e];
+        const int pl = Dims<TYPE>::pos(l);
+        d.U[(size_t)gi * NC * NC + pk * NC + pl] = U[e];
+        d.U[(size_t)gi * NC * NC + pl * NC + pk] = U[e];
         ++e;
       }
     }
   }
 }
 
+// ---- lin_3d: 2D-3D annotation residuals (AddConstraints2d3d, ptzray_optimizer.cc:887-923; weight 1) ----------
+// One workgroup per scene: thread = annotation point (closed-form Jacobians of Reproj2d3dFactor w.r.t. the camera
+// block [fx, fy, (k1), rvec] and the T_l_w block), then thread 0 adds the few blocks to U_i, g_i, cost_i and builds the
+// T_l_w diagonal block / gradient in observation order (fixed order, no atomics).
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lin_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, F = Dims<TYPE>::FACTOR;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+  const double* stl = d.scale_t + (size_t)s.idx * 6;
+  for (int o = threadIdx.x; o < s.n_o3; o += 256) {
+    const int go = s.o3_off + o;
+    const int ci = d.o3_cam[go];
+    const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CAMBLK;
+    const float2 uv = d.o3_uv[go];
+    const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
+    double res[2], Jc[2][5 + F], Jt[2][6];
+    reproj2d3d_eval<F, true>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
+    for (int k = 0; k < NC; ++k) { d.Jc3[(size_t)go * 2 * NC + k] = Jc[0][k] * cb[CB_S + k]; d.Jc3[(size_t)go * 2 * NC + NC + k] = Jc[1][k] * cb[CB_S + k]; }
+    for (int k = 0; k < 6; ++k) { d.Jt3[(size_t)go * 12 + k] = Jt[0][k] * stl[k]; d.Jt3[(size_t)go * 12 + 6 + k] = Jt[1][k] * stl[k]; }
+    d.r3[(size_t)go * 2] = res[0]; d.r3[(size_t)go * 2 + 1] = res[1];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double Ut[36], gt[6];
+  for (int k = 0; k < 36; ++k) Ut[k] = 0;
+  for (int k = 0; k < 6; ++k) gt[k] = 0;
+  for (int o = 0; o < s.n_o3; ++o) {
+    const int go = s.o3_off + o;
+    const int gi = s.cam_off + d.o3_cam[go];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    const double* j1 = j0 + NC;
+    const double* q0 = d.Jt3 + (size_t)go * 12;
+    const double* q1 = q0 + 6;
+    const double r0 = d.r3[(size_t)go * 2], r1 = d.r3[(size_t)go * 2 + 1];
+    d.costc[gi] += 0.5 * (r0 * r0 + r1 * r1);
+    for (int k = 0; k < NC; ++k) {
+      d.gc[(size_t)gi * NC + k] += j0[k] * r0 + j1[k] * r1;
+      for (int l = 0; l < NC; ++l) d.U[(size_t)gi * NC * NC + k * NC + l] += j0[k] * j0[l] + j1[k] * j1[l];
+    }
+    for (int k = 0; k < 6; ++k) {
+      gt[k] += q0[k] * r0 + q1[k] * r1;
+      for (int l = 0; l < 6; ++l) Ut[k * 6 + l] += q0[k] * q0[l] + q1[k] * q1[l];
+    }
+  }
+  for (int k = 0; k < 36; ++k) d.Ut[(size_t)s.idx * 36 + k] = Ut[k];
+  for (int k = 0; k < 6; ++k) d.gt[(size_t)s.idx * 6 + k] = gt[k];
+}
+
 // ---- Jacobi scaling (Ceres: s_j = 1 / (1 + |J_:j|), computed once at iteration 0) -----------------------
 template <int TYPE>
 __global__ void k_jacobi_scale(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,13 +425,14 @@ __global__ void k_jacobi_scale(Dev d)
     d.scale_r[(size_t)gj * 3 + 1] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 2]));
     d.scale_r[(size_t)gj * 3 + 2] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 5]));
   }
+  if (Dims<TYPE>::HAS3D && t < 6) d.scale_t[(size_t)s.idx * 6 + t] = 1.0 / (1.0 + sqrt(d.Ut[(size_t)s.idx * 36 + t * 7]));
 }
 
 // ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.x;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
@@ -354,6 +460,13 @@ __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
       }
     }
     // fixed-order cost: per-thread partial sums over a strided camera set, then the block tree
+    if (Dims<TYPE>::HAS3D && tid == 0) {
+      const double* tl = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+      for (int k = 0; k < 6; ++k) {
+        if (s.n_o3 > 0) xn += tl[k] * tl[k];  // the T_l_w block is in the problem only when annotation residuals exist
+        gm = fmax(gm, fabs(d.gt[(size_t)s.idx * 6 + k] / d.scale_t[(size_t)s.idx * 6 + k]));
+      }
+    }
     c = block_sum(c, scratch);
     gm = block_max(gm, scratch);
     xn = block_sum(xn, scratch);
@@ -430,7 +543,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
 template <int TYPE>
 __global__ void k_cam_diag(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
@@ -438,6 +551,9 @@ __global__ void k_cam_diag(Dev d)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n_cam || st.reuse_diagonal) return;
   const int gi = s.cam_off + i;
+  if (Dims<TYPE>::HAS3D && i == 0)
+    for (int k = 0; k < 6; ++k)
+      d.diag_t[(size_t)s.idx * 6 + k] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + k * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
@@ -457,9 +573,9 @@ constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
 template <int TYPE>
 __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
-  constexpr int NU = NC * (NC + 1) / 2;
-  constexpr int NT = NC * 3;
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
+  constexpr int NU = NW * (NW + 1) / 2;
+  constexpr int NT = NW * 3;
   int ci, sc;
   xcd_remap(ci, sc);
   if (!d.active[sc]) return;
@@ -477,9 +593,9 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
   double* strip = lds + (size_t)no * NT;            // [waves][NC + NU] reduction strip
   const int2* ents = d.ent + eb;                    // (a slot, W row of b), this camera's contiguous range
   const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
-  double bsum[NC], D[NU];
+  double bsum[NW], D[NU];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) bsum[k] = 0;
+  for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
   for (int k = 0; k < NU; ++k) D[k] = 0;
 #ifndef PTZ_DIAG_SCHUR_SKIP_P1
@@ -494,7 +610,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
     for (int k = 0; k < NT; ++k) w[k] = Wa[k];
     int e = 0;
 #pragma unroll
-    for (int p = 0; p < NC; ++p) {
+    for (int p = 0; p < NW; ++p) {
       const double w0 = w[3 * p], w1 = w[3 * p + 1], w2 = w[3 * p + 2];
       bsum[p] += w0 * z0 + w1 * z1 + w2 * z2;
       const double t0 = w0 * e0 + w1 * e1 + w2 * e3, t1 = w0 * e1 + w1 * e2 + w2 * e4, t2 = w0 * e3 + w1 * e4 + w2 * e5;
@@ -507,12 +623,12 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
   // one pass of the block tree for all NC + NU sums (fixed order: lanes by butterfly, waves in wave order)
   {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int NV = NC + NU;
+    constexpr int NV = NW + NU;
     double v[NV];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) v[k] = wave_sum(bsum[k]);
+    for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
 #pragma unroll
-    for (int k = 0; k < NU; ++k) v[NC + k] = wave_sum(D[k]);
+    for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
@@ -525,30 +641,42 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
       v[k] = t;
     }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) bsum[k] = v[k];
+    for (int k = 0; k < NW; ++k) bsum[k] = v[k];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) D[k] = v[NC + k];
+    for (int k = 0; k < NU; ++k) D[k] = v[NW + k];
   }
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
   if (threadIdx.x == 0) {
     const int gi = s.cam_off + ci;
     double* row = A + (size_t)s.n * np;
-    int e = 0;
+    // full NC x NC block: U (2D-2D + annotation terms) + D^2 - sum T W^T (the latter only on the NW x NW 2D-2D columns)
 #pragma unroll
     for (int p = 0; p < NC; ++p) {
-      row[ci * NC + p] = d.gc[(size_t)gi * NC + p] - bsum[p];
+      row[ci * NC + p] = d.gc[(size_t)gi * NC + p];
 #pragma unroll
       for (int qq = 0; qq <= p; ++qq) {
-        double v = d.U[(size_t)gi * NC * NC + p * NC + qq] - D[e++];
+        double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
         if (p == qq) {
           const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
           v += Dd * Dd;
         }
         A[(size_t)(ci * NC + p) * np + ci * NC + qq] = v;
-        A[(size_t)(ci * NC + qq) * np + ci * NC + p] = v;
       }
     }
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const int pp_ = Dims<TYPE>::pos(p);
+      row[ci * NC + pp_] -= bsum[p];
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) A[(size_t)(ci * NC + pp_) * np + ci * NC + Dims<TYPE>::pos(qq)] -= D[e++];
+    }
+    // mirror the lower triangle of the diagonal block (the factorisation reads the lower part only; kept symmetric)
+#pragma unroll
+    for (int p = 0; p < NC; ++p)
+#pragma unroll
+      for (int qq = 0; qq < p; ++qq) A[(size_t)(ci * NC + qq) * np + ci * NC + p] = A[(size_t)(ci * NC + p) * np + ci * NC + qq];
   }
 #ifdef PTZ_DIAG_SCHUR_SKIP_P2
   return;
@@ -556,9 +684,9 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
   // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
   const int l = threadIdx.x & 15;
   for (int pl = (threadIdx.x >> 4); pl < npr; pl += SCHUR_THREADS / 16) {
-    double acc[NC * NC];
+    double acc[NW * NW];
 #pragma unroll
-    for (int k = 0; k < NC * NC; ++k) acc[k] = 0;
+    for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
     const int e1 = pps[pl + 1];
     // two entries per trip: both 128-B W_b lines are in flight together
     for (int e = pps[pl] + l; e < e1; e += 32) {
@@ -579,18 +707,18 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
       const double* Ta1 = T + ab1.x * NT;
       const double f1 = two ? 1.0 : 0.0;
 #pragma unroll
-      for (int p = 0; p < NC; ++p) {
+      for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
         const double u0 = f1 * Ta1[3 * p], u1 = f1 * Ta1[3 * p + 1], u2 = f1 * Ta1[3 * p + 2];
 #pragma unroll
-        for (int q = 0; q < NC; ++q)
-          acc[p * NC + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
+        for (int q = 0; q < NW; ++q)
+          acc[p * NW + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
                              (u0 * wb1[3 * q] + u1 * wb1[3 * q + 1] + u2 * wb1[3 * q + 2]);
       }
     }
 #ifndef PTZ_DIAG_NOSHFL
 #pragma unroll
-    for (int k = 0; k < NC * NC; ++k) {
+    for (int k = 0; k < NW * NW; ++k) {
       double v = acc[k];
       v += __shfl_xor(v, 8, 16);
       v += __shfl_xor(v, 4, 16);
@@ -603,10 +731,44 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
       const int cj = d.pair_cj[s.pair_off + pr0 + pl];
       double* S = A + (size_t)(ci * NC) * np + cj * NC;
 #pragma unroll
-      for (int p = 0; p < NC; ++p)
+      for (int p = 0; p < NW; ++p)
 #pragma unroll
-        for (int q = 0; q < NC; ++q) S[(size_t)p * np + q] = -acc[p * NC + q];
+        for (int q = 0; q < NW; ++q) S[(size_t)Dims<TYPE>::pos(p) * np + Dims<TYPE>::pos(q)] = -acc[p * NW + q];
     }
+  }
+}
+
+// ---- schur_3d: rows of the T_l_w block in the reduced system (it is not coupled to the rays) ---------------------
+//   S_tt = U_t + D_t^2,  S_t,cam(i) = sum_{annotations of camera i} Jt^T Jc,  b_t = g_t
+template <int TYPE>
+__global__ __launch_bounds__(64) void k_schur_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  const int t0 = NC * s.n_cam;
+  const int k = threadIdx.x;  // one lane per T_l_w row
+  if (k >= 6) return;
+  for (int l = 0; l <= k; ++l) {
+    double v = d.Ut[(size_t)s.idx * 36 + k * 6 + l];
+    if (l == k) {
+      const double Dd = sqrt(d.diag_t[(size_t)s.idx * 6 + k] / st.radius);
+      v += Dd * Dd;
+    }
+    A[(size_t)(t0 + k) * np + t0 + l] = v;
+  }
+  A[(size_t)s.n * np + t0 + k] = d.gt[(size_t)s.idx * 6 + k];
+  for (int o = 0; o < s.n_o3; ++o) {  // observation order: deterministic accumulation into the (zeroed) coupling row
+    const int go = s.o3_off + o;
+    const int ci = d.o3_cam[go];
+    const double q0 = d.Jt3[(size_t)go * 12 + k], q1 = d.Jt3[(size_t)go * 12 + 6 + k];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    for (int l = 0; l < NC; ++l) A[(size_t)(t0 + k) * np + ci * NC + l] += q0 * j0[l] + q1 * j0[NC + l];
   }
 }
 
@@ -614,7 +776,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
 template <int TYPE>
 __global__ void k_cam_update(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
@@ -631,7 +793,7 @@ __global__ void k_cam_update(Dev d)
   for (int k = 0; k < NC; ++k) {
     const double step = -y[k];
     d.dc[(size_t)gi * NC + k] = step;
-    c15[FreeIdx<TYPE>::at(k)] += step * d.scale_c[(size_t)gi * NC + k];
+    c15[Dims<TYPE>::at(k)] += step * d.scale_c[(size_t)gi * NC + k];
   }
   double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
 #pragma unroll
@@ -640,6 +802,24 @@ __global__ void k_cam_update(Dev d)
   fill_camblk(c15, cb, false);
 #pragma unroll
   for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CANDBLK + k] = cb[k];
+  if (Dims<TYPE>::HAS3D && i == 0) {
+    const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
+    const double* yt = d.yc + (size_t)sc * d.chol.np + (size_t)NC * s.n_cam;
+    double tn[6];
+    for (int k = 0; k < 6; ++k) {
+      const double step = -yt[k];
+      d.dt[(size_t)s.idx * 6 + k] = step;
+      tn[k] = t[k] + step * d.scale_t[(size_t)s.idx * 6 + k];
+      tc[k] = tn[k];
+    }
+    double* tb = d.tlwcand + (size_t)s.idx * TLWBLK;
+    double R[9];
+    const double rv[3] = {tn[0], tn[1], tn[2]};
+    rodrigues(rv, R);
+    for (int k = 0; k < 9; ++k) tb[k] = R[k];
+    tb[18] = tn[3]; tb[19] = tn[4]; tb[20] = tn[5];
+  }
 }
 
 // ---- eval: ray back-substitution, model cost change and candidate cost in one ray-centric pass -----------------
@@ -652,14 +832,14 @@ __global__ void k_cam_update(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int DCS = NC + 1;                // odd stride for the step table as well
+  constexpr int DCS = NC | 1;                // odd stride for the step table as well
   double* tab = lds;                         // [n_cam][CBS]
   double* ctab = tab + s.n_cam * CBS;        // [n_cam][CDS]
   double* dct = ctab + s.n_cam * CDS;        // [n_cam][DCS] scaled camera step
@@ -685,11 +865,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
       const double* cb = tab + ci * CBS;
-      double res[2], Jc[2][NC], Jr[2][3];
-      ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      double res[2], Jc[2][NW], Jr[2][3];
+      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
       double m0 = 0, m1 = 0;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * DCS + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
       t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
@@ -705,16 +885,16 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
       const double* cb = tab + ci * CBS;
-      double res[2], Jc[2][NC], Jr[2][3];
-      ba_linearize<TYPE>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      double res[2], Jc[2][NW], Jr[2][3];
+      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
       double m0 = 0, m1 = 0;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) { const double m = sw * cb[CB_S + k] * dct[ci * DCS + k]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
 #pragma unroll
       for (int k = 0; k < 3; ++k) { const double m = sw * sr[k] * ds[k]; m0 += Jr[0][k] * m; m1 += Jr[1][k] * m; }
       mcc += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       double rc[2];
-      ba_residual<TYPE>(ctab + ci * CDS, Xn, uv.x, uv.y, rc);
+      ba_residual<F>(ctab + ci * CDS, Xn, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
     }
   }
@@ -723,6 +903,42 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
   if (threadIdx.x == 0) {
     d.partial[(size_t)(s.part_off + blockIdx.x) * 2] = mcc;
     d.partial[(size_t)(s.part_off + blockIdx.x) * 2 + 1] = cost;
+  }
+}
+
+// ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_eval_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, F = Dims<TYPE>::FACTOR;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  __shared__ double scratch[16];
+  double mcc = 0, cost = 0;
+  for (int o = threadIdx.x; o < s.n_o3; o += 256) {
+    const int go = s.o3_off + o;
+    const int gi = s.cam_off + d.o3_cam[go];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    const double* q0 = d.Jt3 + (size_t)go * 12;
+    double m0 = 0, m1 = 0;
+    for (int k = 0; k < NC; ++k) { const double st_ = d.dc[(size_t)gi * NC + k]; m0 += j0[k] * st_; m1 += j0[NC + k] * st_; }
+    for (int k = 0; k < 6; ++k) { const double st_ = d.dt[(size_t)s.idx * 6 + k]; m0 += q0[k] * st_; m1 += q0[6 + k] * st_; }
+    mcc += m0 * (d.r3[(size_t)go * 2] + m0 / 2.0) + m1 * (d.r3[(size_t)go * 2 + 1] + m1 / 2.0);
+    double cb[CAMBLK];
+    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CANDBLK + k];
+    const float2 uv = d.o3_uv[go];
+    const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
+    double rc[2], Jc[2][5 + F], Jt[2][6];
+    reproj2d3d_eval<F, false>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
+    cost += 0.5 * (rc[0] * rc[0] + rc[1] * rc[1]);
+  }
+  mcc = block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  if (threadIdx.x == 0) {
+    d.partial[(size_t)(s.part_off + s.n_chunk) * 2] = mcc;
+    d.partial[(size_t)(s.part_off + s.n_chunk) * 2 + 1] = cost;
   }
 }
 
@@ -738,7 +954,7 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
   const int tid = threadIdx.x;
   // chunk partials in chunk order (thread-strided, then the fixed block tree)
   double mcc = 0, cost = 0;
-  for (int c = tid; c < s.n_chunk; c += 256) {
+  for (int c = tid; c < s.n_chunk + Dims<TYPE>::HAS3D; c += 256) {
     mcc += d.partial[(size_t)(s.part_off + c) * 2];
     cost += d.partial[(size_t)(s.part_off + c) * 2 + 1];
   }
@@ -763,6 +979,11 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
     const double a = ray[j], b = rayc[j];
     dn += (a - b) * (a - b);
     cn += b * b;
+  }
+  if (Dims<TYPE>::HAS3D && tid == 0 && s.n_o3 > 0) {
+    const double* ta = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    const double* tb_ = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
+    for (int k = 0; k < 6; ++k) { dn += (ta[k] - tb_[k]) * (ta[k] - tb_[k]); cn += tb_[k] * tb_[k]; }
   }
   dn = block_sum(dn, scratch);
   cn = block_sum(cn, scratch);
@@ -898,7 +1119,8 @@ struct ptz_ba_batch {
   std::vector<int> group_first, group_count;
   std::vector<Dev> dg;
   int* h_active = nullptr;  // pinned
-  double *cam0 = nullptr, *ray0 = nullptr;  // device copies of the initial state
+  double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
+  int has3d = 0, total_o3 = 0;
   bool has_state = false;
   double last_ms = 0;
   // profiling
@@ -972,6 +1194,7 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
   LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
+  if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   b->prof_end();
 }
 
@@ -1006,10 +1229,10 @@ static void make_groups(ptz_ba_batch* b)
 // one LM pass of one group, enqueued on b->stream; returns after enqueueing (no synchronisation)
 template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const int B = d.n_scene;
   hipStream_t st = b->stream;
-  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16);
+  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16);
   const size_t schur_smem = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
@@ -1024,6 +1247,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_end();
   b->prof_begin(P_SCHUR);
   LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   b->prof_end();
   chol_factor_solve_profiled(d.chol, d.yc, st, b);
   b->prof_begin(P_BACKSUB);
@@ -1031,6 +1255,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_end();
   b->prof_begin(P_EVAL);
   LAUNCH(k_eval<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), eval_smem, d);
+  if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(256), 0, d);
@@ -1041,13 +1266,14 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
     LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, dd);
     LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
+    if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
     b->prof_end();
   }
 }
 
 template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
 {
-  constexpr int NC = BaDims<TYPE>::NC;
+  constexpr int NC = Dims<TYPE>::NC;
   const Dev& d = b->d;
   const int B = b->n_scene;
   const bool dbg = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
@@ -1065,6 +1291,8 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
   LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
+  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * B, hipMemcpyDeviceToDevice, s0));
+  LAUNCH(k_fill, dim3((6 * B + 255) / 256), dim3(256), 0, d.scale_t, (size_t)6 * B, 1.0);
   // IterationZero: evaluate, Jacobi scales from the column norms, re-evaluate scaled
   enqueue_linearize<TYPE>(b);
   if (b->opt.jacobi_scaling) {
@@ -1126,7 +1354,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       s.num_lm_steps = h[i].num_lm_steps;
       s.num_successful_steps = h[i].num_successful;
       s.num_unsuccessful_steps = h[i].num_unsuccessful;
-      s.num_residuals = 2 * b->scenes[i].n_obs;
+      s.num_residuals = 2 * b->scenes[i].n_obs + 2 * b->scenes[i].n_o3;
       s.num_linear_solves = h[i].num_linear_solves;
       s.num_jacobian_evals = h[i].num_jac_evals;
       s.initial_cost = h[i].initial_cost;
@@ -1204,6 +1432,8 @@ int32_t ptz_ba_cam_block_dim(int32_t factor_type)
   return PTZ_EUNSUPPORTED;
 }
 
+int32_t ptz_ba_batch_cam_block_dim(const ptz_ba_batch* b) { return b ? b->nc : PTZ_EINVAL; }
+
 void ptz_ba_batch_destroy(ptz_ba_batch* b)
 {
   if (!b) return;
@@ -1228,14 +1458,17 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
   const int type = problems[0].factor_type;
   if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist) return PTZ_EUNSUPPORTED;
-  const int NC = (type == PTZ_BA_PTZRay) ? 4 : 5;
+  int has3d = 0;
   // ---- validate + sizes (host only; no device touched before this passes)
   for (int i = 0; i < n; ++i) {
     const ptz_ba_problem& p = problems[i];
     if (p.factor_type != type) return PTZ_EINVAL;
     if (p.n_cam <= 0 || p.n_ray <= 0 || p.n_obs <= 0) return PTZ_EINVAL;  // num_cams_ == 0 -> false (:517)
     if (!p.obs_uv || !p.obs_cam || !p.obs_ray || !p.ray_weight) return PTZ_EINVAL;
-    if (p.n_obs3d != 0) return PTZ_EUNSUPPORTED;  // georeferencing residuals: not on the device path yet
+    if (p.n_obs3d < 0 || (p.n_obs3d > 0 && (!p.obs3d_uv || !p.obs3d_xyz || !p.obs3d_cam))) return PTZ_EINVAL;
+    for (int a = 0; a < p.n_obs3d; ++a)
+      if (p.obs3d_cam[a] < 0 || p.obs3d_cam[a] >= p.n_cam) return PTZ_EINVAL;
+    if (p.n_obs3d > 0) has3d = 1;
     for (int64_t a = 0; a < p.n_obs; ++a) {
       if (p.obs_cam[a] < 0 || p.obs_cam[a] >= p.n_cam || p.obs_ray[a] < 0 || p.obs_ray[a] >= p.n_ray) return PTZ_EINVAL;
       if (a > 0 && p.obs_ray[a] < p.obs_ray[a - 1]) return PTZ_EINVAL;
@@ -1245,13 +1478,17 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
   PTZ_HIP_TRY(hipSetDevice(o.device_id));
 
+  const int NC = ((type == PTZ_BA_PTZRay) ? 4 : 5) + has3d;  // fy becomes a live column with annotation residuals
   ptz_ba_batch* b = new ptz_ba_batch();
+  b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
   std::vector<float2> h_uv;
   std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr, h_wpos, h_camray;
   std::vector<int2> h_ent;
   std::vector<int> h_campair;
-  std::vector<double> h_w;
+  std::vector<double> h_w, h_o3xyz;
+  std::vector<float2> h_o3uv;
+  std::vector<int> h_o3cam;
   int64_t tot_obs = 0, tot_ent = 0;
   for (int i = 0; i < n; ++i) {
     tot_obs += problems[i].n_obs;
@@ -1265,8 +1502,15 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     s.cam_off = b->total_cam; s.ray_off = b->total_ray; s.obs_off = b->total_obs;
     s.pair_off = b->total_pair; s.ent_off = b->total_ent; s.part_off = b->total_chunk;
     s.n_chunk = (p.n_ray + RAY_BLOCK - 1) / RAY_BLOCK;
-    s.n = NC * p.n_cam;
+    s.n = NC * p.n_cam + 6 * has3d;
     s.idx = i;
+    s.o3_off = b->total_o3; s.n_o3 = p.n_obs3d;
+    for (int a = 0; a < p.n_obs3d; ++a) {
+      h_o3uv.push_back(make_float2(p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1]));
+      h_o3cam.push_back(p.obs3d_cam[a]);
+      for (int k = 0; k < 3; ++k) h_o3xyz.push_back(p.obs3d_xyz[3 * a + k]);
+    }
+    b->total_o3 += p.n_obs3d;
     // observations, ray ranges
     const int obase = s.obs_off;
     std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
@@ -1352,7 +1596,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       b->total_ent += (int)keys.size();
       b->total_pair += npair;
     }
-    b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk;
+    b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk + 1;
     b->max_cam = std::max(b->max_cam, p.n_cam); b->max_ray = std::max(b->max_ray, p.n_ray);
     b->max_chunk = std::max(b->max_chunk, s.n_chunk); b->max_pair = std::max(b->max_pair, s.n_pair);
     b->max_n = std::max(b->max_n, s.n);
@@ -1382,6 +1626,23 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(upload(b, h_campair, &d.cam_pair));
   TRY(upload(b, h_ent, &d.ent));
   TRY(upload(b, h_w, &d.ray_w));
+  TRY(upload(b, h_o3uv, &d.o3_uv));
+  TRY(upload(b, h_o3xyz, &d.o3_xyz));
+  TRY(upload(b, h_o3cam, &d.o3_cam));
+  d.tlw_stride = (size_t)n * 6;
+  TRY(b->alloc(&d.tlw_x, 2 * d.tlw_stride));
+  TRY(b->alloc(&b->tlw0, d.tlw_stride));
+  TRY(b->alloc(&d.tlwblk, (size_t)n * TLWBLK));
+  TRY(b->alloc(&d.tlwcand, (size_t)n * TLWBLK));
+  TRY(b->alloc(&d.scale_t, (size_t)n * 6));
+  TRY(b->alloc(&d.diag_t, (size_t)n * 6));
+  TRY(b->alloc(&d.Ut, (size_t)n * 36));
+  TRY(b->alloc(&d.gt, (size_t)n * 6));
+  TRY(b->alloc(&d.dt, (size_t)n * 6));
+  TRY(b->alloc(&d.Jc3, (size_t)b->total_o3 * 2 * NC));
+  TRY(b->alloc(&d.Jt3, (size_t)b->total_o3 * 12));
+  TRY(b->alloc(&d.r3, (size_t)b->total_o3 * 2));
+  if (hipMemset(b->tlw0, 0, sizeof(double) * d.tlw_stride) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   d.cam_stride = (size_t)b->total_cam * 15;
   d.ray_stride = (size_t)b->total_ray * 3;
   TRY(b->alloc(&d.cam_x, 2 * d.cam_stride));
@@ -1447,19 +1708,20 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     return PTZ_ENODEVICE;
   }
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
-  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16));
+  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16));
   const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CBS);
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
-  if (type == PTZ_BA_PTZRay) {
-    (void)hipFuncSetAttribute((const void*)k_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
-    (void)hipFuncSetAttribute((const void*)k_eval<0>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
-    (void)hipFuncSetAttribute((const void*)k_lin_ray<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
-  }
-  else {
-    (void)hipFuncSetAttribute((const void*)k_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);
-    (void)hipFuncSetAttribute((const void*)k_eval<1>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);
-    (void)hipFuncSetAttribute((const void*)k_lin_ray<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);
+  {
+    const int t = (type == PTZ_BA_PTZRay ? 0 : 1) + 2 * has3d;
+#define PTZ_SET_ATTR(T)                                                                                             \
+    if (t == T) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)k_schur<T>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);   \
+      (void)hipFuncSetAttribute((const void*)k_eval<T>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);     \
+      (void)hipFuncSetAttribute((const void*)k_lin_ray<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);   \
+    }
+    PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3)
+#undef PTZ_SET_ATTR
   }
   *out = b;
   return PTZ_OK;
@@ -1467,11 +1729,12 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
 
 int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double* ray, const double* tlw)
 {
-  (void)tlw;
   if (!b || !cam || !ray) return PTZ_EINVAL;
   PTZ_HIP_TRY(hipSetDevice(b->device));
   PTZ_HIP_TRY(hipMemcpy(b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
   PTZ_HIP_TRY(hipMemcpy(b->ray0, ray, sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
+  if (tlw) PTZ_HIP_TRY(hipMemcpy(b->tlw0, tlw, sizeof(double) * 6 * b->n_scene, hipMemcpyHostToDevice));
+  else PTZ_HIP_TRY(hipMemset(b->tlw0, 0, sizeof(double) * 6 * b->n_scene));
   b->has_state = true;
   return PTZ_OK;
 }
@@ -1480,7 +1743,12 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
   PTZ_HIP_TRY(hipSetDevice(b->device));
-  return b->type == PTZ_BA_PTZRay ? solve_impl<0>(b, summaries) : solve_impl<1>(b, summaries);
+  switch ((b->type == PTZ_BA_PTZRay ? 0 : 1) + 2 * b->has3d) {
+    case 0: return solve_impl<0>(b, summaries);
+    case 1: return solve_impl<1>(b, summaries);
+    case 2: return solve_impl<2>(b, summaries);
+    default: return solve_impl<3>(b, summaries);
+  }
 }
 
 int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw)
@@ -1497,7 +1765,9 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
     if (ray) PTZ_HIP_TRY(hipMemcpy(ray + (size_t)s.ray_off * 3, b->d.ray_x + cur * b->d.ray_stride + (size_t)s.ray_off * 3,
                                    sizeof(double) * 3 * s.n_ray, hipMemcpyDeviceToHost));
   }
-  if (tlw) memset(tlw, 0, sizeof(double) * 6 * b->n_scene);
+  if (tlw)
+    for (int i = 0; i < b->n_scene; ++i)
+      PTZ_HIP_TRY(hipMemcpy(tlw + 6 * (size_t)i, b->d.tlw_x + h[i].cur * b->d.tlw_stride + 6 * (size_t)i, sizeof(double) * 6, hipMemcpyDeviceToHost));
   return PTZ_OK;
 }
 
@@ -1548,7 +1818,14 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   hipLaunchKernelGGL(k_reset, dim3((b->n_scene + 63) / 64), dim3(64), 0, st, d);
   hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, st, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, st, d.scale_r, (size_t)b->total_ray * 3, 1.0);
-  if (b->type == PTZ_BA_PTZRay) enqueue_linearize<0>(b); else enqueue_linearize<1>(b);
+  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_fill, dim3((6 * b->n_scene + 255) / 256), dim3(256), 0, st, d.scale_t, (size_t)6 * b->n_scene, 1.0);
+  switch ((b->type == PTZ_BA_PTZRay ? 0 : 1) + 2 * b->has3d) {
+    case 0: enqueue_linearize<0>(b); break;
+    case 1: enqueue_linearize<1>(b); break;
+    case 2: enqueue_linearize<2>(b); break;
+    default: enqueue_linearize<3>(b); break;
+  }
   PTZ_HIP_TRY(hipStreamSynchronize(st));
   const SceneDev& s = b->scenes[index];
   if (cost) {
@@ -1575,7 +1852,8 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     std::vector<int> wp(s.n_obs);
     PTZ_HIP_TRY(hipMemcpy(rows.data(), d.W + (size_t)s.obs_off * WS, sizeof(double) * WS * s.n_obs, hipMemcpyDeviceToHost));
     PTZ_HIP_TRY(hipMemcpy(wp.data(), d.wpos + s.obs_off, sizeof(int) * s.n_obs, hipMemcpyDeviceToHost));
-    for (int a = 0; a < s.n_obs; ++a) memcpy(W + (size_t)a * NC * 3, &rows[(size_t)(wp[a] - s.obs_off) * WS], sizeof(double) * NC * 3);
+    const int NW = NC - b->has3d;  // W carries the 2D-2D columns only
+    for (int a = 0; a < s.n_obs; ++a) memcpy(W + (size_t)a * NW * 3, &rows[(size_t)(wp[a] - s.obs_off) * WS], sizeof(double) * NW * 3);
   }
   return PTZ_OK;
 }
@@ -1588,7 +1866,7 @@ int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* 
   if (rc) return rc;
   rc = ptz_ba_batch_set_state(b, cam, ray, tlw);
   if (!rc) rc = ptz_ba_batch_solve(b, summary);
-  if (!rc) rc = ptz_ba_batch_get_state(b, cam, ray, nullptr);
+  if (!rc) rc = ptz_ba_batch_get_state(b, cam, ray, tlw);
   ptz_ba_batch_destroy(b);
   return rc;
 }

@@ -32,8 +32,8 @@ namespace ptz {
 // [13..17] k1 k2 k3 p1 p2
 // ---- the first CANDBLK entries are all a residual-only evaluation needs ----
 // [18..26] Jl (row-major)        left Jacobian of SO(3) at rvec: d(R X)/d r_k = Jl[:,k] x (R X)
-// [27..31] Jacobi column scales of the free camera parameters (NC of them)
-constexpr int CAMBLK = 32;
+// [27..32] Jacobi column scales of the free camera parameters (NC <= 6 of them)
+constexpr int CAMBLK = 34;
 constexpr int CANDBLK = 18;
 constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13, CB_JL = 18, CB_S = 27;
 
@@ -142,7 +142,7 @@ PTZ_HD void brown_jac(double x, double y, const double* k, double B[4], double d
 // The reference also leaves intr[1] ("fy") free, but neither functor reads it (param[1] = intr[0],
 // ptzray_optimizer.cc:24-25, 69-70): its Jacobian column is identically zero, its LM step is exactly
 // zero, so the column is not materialised.
-template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : 5; static constexpr int ROT0 = NC - 3; };
+template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : 5; static constexpr int ROT0 = NC - 3; };  // TYPE = factor (0 / 1)
 
 // Residual only.  cb = camera block (R at [CB_R], intrinsics); X = ray parameter (3).
 template <int TYPE>
@@ -242,6 +242,62 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   for (int k = 0; k < 3; ++k) {
     Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
     Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
+  }
+}
+
+// ---- 2D-3D annotation factor (F3, Reproj2d3dFactor, ptzray_optimizer.cc:268-326) ---------------------------
+// X_l = R(tlw[0:3]) X_w + tlw[3:6];  P = R(rvec) X_l (the extrinsic translation is NOT applied, :300);
+// r = uv - (fx xd + cx, fy yd + cy) with Brown distortion; fy IS read here (:273).
+// Free camera columns (NC3 = 5 + FACTOR): [fx, fy, (k1), r1, r2, r3]; tlw columns: [rho1..3, t1..3].
+// tl = {R_lw (9), Jl_lw (9), t_lw (3)}.
+constexpr int TLWBLK = 21;
+template <int FACTOR, bool JAC>
+PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz[3], float u, float v, double res[2],
+                            double Jc[2][5 + FACTOR], double Jt[2][6])
+{
+  constexpr int ROT0 = 2 + FACTOR;
+  const double* R = cb + CB_R;
+  const double* Rl = tl;
+  const double fx = cb[CB_F], fy = cb[CB_FY], cx = cb[CB_CX], cy = cb[CB_CY];
+  const double Yx = Rl[0] * xyz[0] + Rl[1] * xyz[1] + Rl[2] * xyz[2];
+  const double Yy = Rl[3] * xyz[0] + Rl[4] * xyz[1] + Rl[5] * xyz[2];
+  const double Yz = Rl[6] * xyz[0] + Rl[7] * xyz[1] + Rl[8] * xyz[2];
+  const double Xx = Yx + tl[18], Xy = Yy + tl[19], Xz = Yz + tl[20];
+  const double Px = R[0] * Xx + R[1] * Xy + R[2] * Xz;
+  const double Py = R[3] * Xx + R[4] * Xy + R[5] * Xz;
+  const double Pz = R[6] * Xx + R[7] * Xy + R[8] * Xz;
+  const double iz = 1.0 / Pz, x = Px / Pz, y = Py / Pz;
+  double xd, yd;
+  brown(x, y, cb + CB_K, xd, yd);
+  res[0] = (double)u - (fx * xd + cx);
+  res[1] = (double)v - (fy * yd + cy);
+  if (!JAC) return;
+  double B[4], dk1[2];
+  brown_jac(x, y, cb + CB_K, B, dk1);
+  double M[2][3];
+  M[0][0] = fx * (B[0] * iz);  M[0][1] = fx * (B[1] * iz);  M[0][2] = fx * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  Jc[0][0] = -xd; Jc[1][0] = 0;
+  Jc[0][1] = 0;   Jc[1][1] = -yd;
+  if (FACTOR) { Jc[0][2] = -fx * dk1[0]; Jc[1][2] = -fy * dk1[1]; }
+  const double* Jl = cb + CB_JL;
+  const double* Jw = tl + 9;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // camera rotation: dP = Jl[:,k] x P
+    double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
+    double dx = ay * Pz - az * Py, dy = az * Px - ax * Pz, dz = ax * Py - ay * Px;
+    Jc[0][ROT0 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    Jc[1][ROT0 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+    // tlw rotation: dX_l = Jw[:,k] x (R_lw X_w), dP = R dX_l
+    ax = Jw[k]; ay = Jw[3 + k]; az = Jw[6 + k];
+    const double ex = ay * Yz - az * Yy, ey = az * Yx - ax * Yz, ez = ax * Yy - ay * Yx;
+    dx = R[0] * ex + R[1] * ey + R[2] * ez; dy = R[3] * ex + R[4] * ey + R[5] * ez; dz = R[6] * ex + R[7] * ey + R[8] * ez;
+    Jt[0][k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    Jt[1][k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+    // tlw translation: dP = R e_k
+    Jt[0][3 + k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]);
+    Jt[1][3 + k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]);
   }
 }
 

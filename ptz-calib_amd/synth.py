@@ -111,6 +111,9 @@ class Scene:
     ray_init: np.ndarray     # float64 [n_ray, 3] (Pix2Ray of cam_init)
     seed: int = 0
     meta: dict = field(default_factory=dict)
+    obs3d: dict | None = None        # 2D-3D annotations: {uv float32 [m,2], xyz float64 [m,3], cam int32 [m]}
+    tlw_gt: np.ndarray | None = None   # T_l_w as [rvec, t] (ptzray_optimizer.cc:507-513)
+    tlw_init: np.ndarray | None = None
 
     @property
     def n_obs(self) -> int:
@@ -321,3 +324,49 @@ def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_
     match_ptr = (np.arange(n_query + 1, dtype=np.int64) * n_match)
     return RelocBatch(n_query=n_query, match_ptr=match_ptr, uv_ref=uv_ref, uv_cur=uv_cur, cam_ref=cam_ref,
                       cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
+
+
+def add_annotations(scene: Scene, n_annotated: int = 6, pts_per_cam: int = 12, noise_px: float = 0.5,
+                    init_rot_sigma_deg: float = 1.0, init_trans_sigma: float = 0.5) -> Scene:
+    """Georeferencing stage input (run_ptz_ba.cc:131-155): 2D-3D annotations of world points on the ground plane
+    z_w = 0 seen by a few views, the ground-truth T_l_w and a perturbed initial T_l_w (the reference gets its initial
+    value from EPnP on the first annotated view, ptzray_optimizer.cc:562-633).  The rig sits 15 m above the ground."""
+    rng = SplitMix64(scene.seed ^ 0xA22074)
+    Rlw = _rot_x(math.radians(-65.0)) @ _rot_y(math.radians(8.0))   # world (z up) -> local (z forward at pan 0, y down)
+    C = np.array([3.0, -45.0, 15.0])                                  # rig centre in world coordinates
+    t_lw = -Rlw @ C
+    tlw_gt = np.concatenate([rodrigues_inv(Rlw), t_lw])
+    step = max(1, scene.n_cam // n_annotated)
+    cams = list(range(0, scene.n_cam, step))[:n_annotated]
+    uv, xyz, cam = [], [], []
+    for ci in cams:
+        c = scene.cam_gt[ci]
+        R = rodrigues(c[4:7])
+        got = 0
+        tries = 0
+        while got < pts_per_cam and tries < 50 * pts_per_cam:
+            tries += 1
+            u = float(rng.uniform(1, 40.0, scene.width - 40.0)[0])
+            v = float(rng.uniform(1, 40.0, scene.height - 40.0)[0])
+            d_l = R.T @ np.array([(u - c[2]) / c[0], (v - c[3]) / c[1], 1.0])
+            d_w = Rlw.T @ d_l
+            if d_w[2] > -1e-3:
+                continue  # does not hit the ground in front of the camera
+            lam = -C[2] / d_w[2]
+            Xw = C + lam * d_w
+            if lam > 400.0:
+                continue
+            Xl = Rlw @ Xw + t_lw
+            P = R @ Xl
+            x, y_ = P[0] / P[2], P[1] / P[2]
+            r2 = x * x + y_ * y_
+            rad = 1.0 + c[10] * r2
+            pu = c[0] * x * rad + c[2] + float(rng.normal(1, noise_px)[0])
+            pv = c[1] * y_ * rad + c[3] + float(rng.normal(1, noise_px)[0])
+            uv.append([pu, pv]); xyz.append(Xw); cam.append(ci)
+            got += 1
+    scene.obs3d = dict(uv=np.asarray(uv, dtype=np.float32), xyz=np.asarray(xyz, dtype=np.float64), cam=np.asarray(cam, dtype=np.int32))
+    scene.tlw_gt = tlw_gt
+    pert = rng.normal(3, math.radians(init_rot_sigma_deg))
+    scene.tlw_init = np.concatenate([rodrigues_inv(rodrigues(pert) @ Rlw), t_lw + rng.normal(3, init_trans_sigma)])
+    return scene

@@ -11,7 +11,7 @@ static void fill_camblk(const double* cam15, double* cb)
   so3_left_jacobian(cam15 + 4, cb + CB_JL);
   cb[CB_F] = cam15[0]; cb[CB_CX] = cam15[2]; cb[CB_CY] = cam15[3]; cb[CB_FY] = cam15[1];
   for (int k = 0; k < 5; ++k) cb[CB_K + k] = cam15[10 + k];
-  for (int k = 0; k < 5; ++k) cb[CB_S + k] = 1.0;
+  for (int k = 0; k < 6; ++k) cb[CB_S + k] = 1.0;
 }
 
 extern "C" {
@@ -70,6 +70,27 @@ void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* 
     krt_eval<1, true>(R, Jl, cam15[0], cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);
     for (int i = 0; i < 10; ++i) J[i] = (&j[0][0])[i];
   }
+}
+// F3: cam15, tlw6, xyz, uv -> res[2], Jc[2][5+factor], Jt[2][6]
+void h_reproj2d3d(int factor, const double* cam15, const double* tlw, const double* xyz, const float* uv, double* res, double* Jc, double* Jt)
+{
+  double cb[CAMBLK], tl[TLWBLK];
+  fill_camblk(cam15, cb);
+  rodrigues(tlw, tl);
+  so3_left_jacobian(tlw, tl + 9);
+  tl[18] = tlw[3]; tl[19] = tlw[4]; tl[20] = tlw[5];
+  double jt[2][6];
+  if (factor == 0) {
+    double jc[2][5];
+    reproj2d3d_eval<0, true>(cb, tl, xyz, uv[0], uv[1], res, jc, jt);
+    for (int i = 0; i < 10; ++i) Jc[i] = (&jc[0][0])[i];
+  }
+  else {
+    double jc[2][6];
+    reproj2d3d_eval<1, true>(cb, tl, xyz, uv[0], uv[1], res, jc, jt);
+    for (int i = 0; i < 12; ++i) Jc[i] = (&jc[0][0])[i];
+  }
+  for (int i = 0; i < 12; ++i) Jt[i] = (&jt[0][0])[i];
 }
 int h_inv3(const double* A6, double* Ai6) { return inv3_spd(A6, Ai6) ? 1 : 0; }
 }

@@ -295,3 +295,72 @@ def test_ba_stream_groups_do_not_change_results(pkg, monkeypatch):
         assert [s["final_cost"] for s in out[g][0]] == [s["final_cost"] for s in out["1"][0]]
         assert all(np.array_equal(a, c) for a, c in zip(out[g][1], out["1"][1]))
         assert all(np.array_equal(a, c) for a, c in zip(out[g][2], out["1"][2]))
+
+
+# ---------------------------------------------------------------------------------------- F3: 2D-3D annotation residuals
+def _georef_scene(pkg, ftype, seed=2):
+    sc = pkg.synth.make_scene(seed, 20, 100, factor_type=ftype)
+    return pkg.synth.add_annotations(sc)
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_linearize_with_annotations_vs_oracle(pkg, orc, ftype):
+    """Reproj2d3dFactor terms (ptzray_optimizer.cc:268-326): camera blocks with the live fy column, 1e-11 relative."""
+    sc = _georef_scene(pkg, ftype)
+    cam = sc.cam_init.copy()
+    if ftype:
+        cam[:, 10] = 0.01
+    b = pkg.api.BaBatch([sc]); b.set_state([cam], [sc.ray_init], [sc.tlw_init])
+    g = b.linearize(0)
+    o = orc.ba_linearize(sc, cam, sc.ray_init, tlw=sc.tlw_init, jacobian_mode=orc.JAC_ANALYTIC, obs3d=sc.obs3d)
+    assert b.nc == o["ncf"] == 5 + ftype  # [fx, fy, (k1), r1, r2, r3] -- same block as the oracle once fy is live
+    assert abs(g["cost"] - o["cost"]) / o["cost"] < 1e-12
+    assert _rel(g["U"], o["U"]) < 1e-11 and _rel(g["g_c"], o["g_c"]) < 1e-11
+    sel = [0, 2, 3, 4] if ftype == 0 else [0, 2, 3, 4, 5]
+    assert _rel(g["W"], o["W"][:, sel, :]) < 1e-11
+    ann = np.unique(sc.obs3d["cam"])
+    assert np.abs(g["U"][ann, 1, 1]).min() > 0 and np.abs(np.delete(g["U"], ann, axis=0)[:, 1, :]).max() == 0.0
+    b.close()
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_ba_georef_parity(pkg, orc, ftype):
+    """Georeferencing solve (RunGeoreferencing, run_ptz_ba.cc:131-155): 2D-2D + 2D-3D residuals, T_l_w block, fy fitted from
+    the annotations only.  Same LM bookkeeping as the oracle; gauge-invariant quantities within 1e-6."""
+    sc = _georef_scene(pkg, ftype)
+    cam, ray, summ, tlw = pkg.api.ba_solve(sc, return_tlw=True)
+    for mode in (orc.JAC_ANALYTIC, orc.JAC_NUMERIC):
+        ocam, oray, otlw, osumm, _ = orc.ba_solve(sc, obs3d=sc.obs3d, tlw0=sc.tlw_init, jacobian_mode=mode, num_threads=4)
+        assert summ["termination_type"] == osumm["termination_type"] == 0
+        assert summ["num_iterations"] == osumm["num_iterations"]
+        assert summ["num_residuals"] == osumm["num_residuals"] == 2 * sc.n_obs + 2 * len(sc.obs3d["cam"])
+        assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-8
+        assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6 and _rel(cam[:, 1], ocam[:, 1]) < 1e-6
+        if ftype:
+            assert np.abs(cam[:, 10] - ocam[:, 10]).max() < 1e-6
+        Rlw, oRlw = orc.rodrigues(tlw[:3]), orc.rodrigues(otlw[:3])
+        for i in range(sc.n_cam):  # world rotation of every camera R_i R_lw is gauge invariant
+            assert np.abs(orc.rodrigues(cam[i, 4:7]) @ Rlw - orc.rodrigues(ocam[i, 4:7]) @ oRlw).max() < 1e-6
+        assert np.abs(-Rlw.T @ tlw[3:] - (-oRlw.T @ otlw[3:])).max() < 1e-5  # rig centre in world coordinates (metres)
+    # fy moves only for annotated cameras (it is read by Reproj2d3dFactor alone); the rig centre is recovered
+    ann = np.unique(sc.obs3d["cam"])
+    assert np.all(cam[ann, 1] != sc.cam_init[ann, 1])
+    assert np.array_equal(np.delete(cam[:, 1], ann), np.delete(sc.cam_init[:, 1], ann))
+    Cw = -orc.rodrigues(tlw[:3]).T @ tlw[3:]
+    assert np.abs(Cw - np.array([3.0, -45.0, 15.0])).max() < 1.0
+
+
+def test_ba_mixed_batch_with_and_without_annotations(pkg):
+    """A batch where only some scenes carry annotations: every scene gets the same result as when solved alone."""
+    a = _georef_scene(pkg, 0, seed=2)
+    p = pkg.synth.make_scene(4, 24, 100)
+    b = pkg.api.BaBatch([a, p]); b.set_state(); summ = b.solve(); cams, rays = b.get_state()
+    ca, ra, sa, ta = pkg.api.ba_solve(a, return_tlw=True)
+    assert sa["num_iterations"] == summ[0]["num_iterations"] and np.array_equal(ca, cams[0])
+    assert np.array_equal(ta, b.last_tlw[0])
+    cp, rp, sp = pkg.api.ba_solve(p)  # plain solve of the annotation-free scene (NC = 4 path)
+    assert sp["num_iterations"] == summ[1]["num_iterations"]
+    assert abs(sp["final_cost"] - summ[1]["final_cost"]) / sp["final_cost"] < 1e-12
+    assert _rel(cams[1][:, 0], cp[:, 0]) < 1e-10
+    assert np.array_equal(b.last_tlw[1], np.zeros(6))
+    b.close()
