@@ -650,33 +650,33 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
   if (threadIdx.x == 0) {
     const int gi = s.cam_off + ci;
     double* row = A + (size_t)s.n * np;
-    // full NC x NC block: U (2D-2D + annotation terms) + D^2 - sum T W^T (the latter only on the NW x NW 2D-2D columns)
+    // full NC x NC block: U (2D-2D + annotation terms) + D^2 - sum T W^T (the latter only on the NW x NW 2D-2D columns);
+    // assembled in registers, stored once (both triangles: the block stays symmetric)
+    double blk[NC * NC], rhs[NC];
 #pragma unroll
     for (int p = 0; p < NC; ++p) {
-      row[ci * NC + p] = d.gc[(size_t)gi * NC + p];
+      rhs[p] = d.gc[(size_t)gi * NC + p];
 #pragma unroll
-      for (int qq = 0; qq <= p; ++qq) {
-        double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
-        if (p == qq) {
-          const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
-          v += Dd * Dd;
-        }
-        A[(size_t)(ci * NC + p) * np + ci * NC + qq] = v;
-      }
+      for (int qq = 0; qq <= p; ++qq) blk[p * NC + qq] = d.U[(size_t)gi * NC * NC + p * NC + qq];
+      const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+      blk[p * NC + p] += Dd * Dd;
     }
     int e = 0;
 #pragma unroll
     for (int p = 0; p < NW; ++p) {
-      const int pp_ = Dims<TYPE>::pos(p);
-      row[ci * NC + pp_] -= bsum[p];
+      rhs[Dims<TYPE>::pos(p)] -= bsum[p];
 #pragma unroll
-      for (int qq = 0; qq <= p; ++qq) A[(size_t)(ci * NC + pp_) * np + ci * NC + Dims<TYPE>::pos(qq)] -= D[e++];
+      for (int qq = 0; qq <= p; ++qq) blk[Dims<TYPE>::pos(p) * NC + Dims<TYPE>::pos(qq)] -= D[e++];
     }
-    // mirror the lower triangle of the diagonal block (the factorisation reads the lower part only; kept symmetric)
 #pragma unroll
-    for (int p = 0; p < NC; ++p)
+    for (int p = 0; p < NC; ++p) {
+      row[ci * NC + p] = rhs[p];
 #pragma unroll
-      for (int qq = 0; qq < p; ++qq) A[(size_t)(ci * NC + qq) * np + ci * NC + p] = A[(size_t)(ci * NC + p) * np + ci * NC + qq];
+      for (int qq = 0; qq <= p; ++qq) {
+        A[(size_t)(ci * NC + p) * np + ci * NC + qq] = blk[p * NC + qq];
+        A[(size_t)(ci * NC + qq) * np + ci * NC + p] = blk[p * NC + qq];
+      }
+    }
   }
 #ifdef PTZ_DIAG_SCHUR_SKIP_P2
   return;
