@@ -147,6 +147,16 @@ def main():
             achieved = per_launch * active_frac / (avg_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms, launches=launches)
+        # HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (same workload;
+        # PMC cannot be collected from inside the benchmark process): bytes per launch, gfx950-corrected.
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            kname = tj["slot_to_kernel"].get(dom)
+            if kname in tj["kernels"] and B == 256 and args.views == 200 and args.obs == 500:
+                roof["traffic"] = tj["kernels"][kname]["hbm_bytes_corrected"]
+                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per-dispatch mean)"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "LM iterations/sec (PTZ-IBA global BA, 200-view synthetic PTZ rig)",
             "value": total_steps / t_max,
