@@ -41,7 +41,7 @@ namespace {
 constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
 constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (33 doubles: odd -> no same-field bank conflicts)
 constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
-constexpr int WS = 16;           // doubles per observation row of W (NC*3 used): one aligned 128-B line
+// W row stride: see Dims<TYPE>::WS
 
 struct SceneDev {
   int n_cam, n_ray, n_obs, n_pair;
@@ -111,7 +111,7 @@ struct Dev {
   double* diag_r;    // [total_ray][3]
   double* E;         // [total_ray][6]
   double* z;         // [total_ray][3]
-  double* W;         // [total_obs][WS] (NC*3 used)
+  double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
   double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
   // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
   const float2* o3_uv;  // [total_o3]
@@ -158,6 +158,9 @@ template <int TYPE> struct Dims {
   static constexpr int NW = 4 + FACTOR;
   static constexpr int NC = NW + HAS3D;
   static constexpr int NG = 6 * HAS3D;  // size of the global (tlw) block
+  // doubles per observation row of W = Jc^T Jr (NW x 3), rounded up to a 16-byte multiple: 12 (96 B) / 16 (128 B).
+  // Measured on MI355X: unpadded 96-B rows beat 128-B-aligned rows (less write/stream traffic outweighs line straddling).
+  static constexpr int WS = (NW * 3 + 1) & ~1;
   // position of 2D-2D column k inside the NC block
   static __host__ __device__ constexpr int pos(int k) { return HAS3D ? (k == 0 ? 0 : k + 1) : k; }
   // index of free parameter k of the NC block in the Camera 15-vector
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
-    double* Wa = d.W + (size_t)d.wpos[a] * WS;
+    double* Wa = d.W + (size_t)d.wpos[a] * Dims<TYPE>::WS;
 #pragma unroll
     for (int k = 0; k < NW; ++k)
 #pragma unroll
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
     const double* E = d.E + (size_t)gj * 6;
     const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
     double w[NT];
-    const double* Wa = d.W + (size_t)(o0 + q) * WS;  // camera-major rows: sequential stream
+    const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
 #pragma unroll
     for (int k = 0; k < NT; ++k) w[k] = Wa[k];
     int e = 0;
@@ -694,11 +697,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
       const int2 ab0 = ents[e];
       const int2 ab1 = two ? ents[e + 16] : ab0;
 #ifdef PTZ_DIAG_NOGATHER
-      const double* Wb0 = d.W + (size_t)(o0 + (ab0.y & 7)) * WS;
-      const double* Wb1 = d.W + (size_t)(o0 + (ab1.y & 7)) * WS;
+      const double* Wb0 = d.W + (size_t)(o0 + (ab0.y & 7)) * Dims<TYPE>::WS;
+      const double* Wb1 = d.W + (size_t)(o0 + (ab1.y & 7)) * Dims<TYPE>::WS;
 #else
-      const double* Wb0 = d.W + (size_t)ab0.y * WS;
-      const double* Wb1 = d.W + (size_t)ab1.y * WS;
+      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
+      const double* Wb1 = d.W + (size_t)ab1.y * Dims<TYPE>::WS;
 #endif
       double wb0[NT], wb1[NT];
 #pragma unroll
@@ -859,8 +862,13 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
     const double sw = sqrt(w);
     const int* rp = d.ray_ptr + s.ray_off + s.idx;
     const int a0 = rp[j], a1 = rp[j + 1];
-    // pass 1: t = g_r - sum_a Jr_a^T (Jc_a y_c) = g_r + sum_a Jr_a^T (Jc_a d_c)
+    // pass 1 (one linearisation per observation): with p_a = Jc_a d_c (camera part of J d),
+    //   t  = g_r + sum_a Jr_a^T p_a                      -> y_r = E t, ray step d_r = -y_r
+    //   s1 = sum_a p_a . (r_a + p_a / 2)
+    // and, since J d = p_a + Jr_a d_r per observation, the ray's share of (J d)^T (r + J d / 2) is
+    //   s1 + d_r . t + 1/2 d_r^T V d_r      (V = sum_a Jr_a^T Jr_a is the stored, undamped ray block)
     double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
+    double s1 = 0;
     for (int a = a0; a < a1; ++a) {
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
@@ -870,6 +878,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       double m0 = 0, m1 = 0;
 #pragma unroll
       for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      s1 += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
@@ -880,21 +889,18 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
     const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
     double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
     xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
-    // pass 2: model cost change and candidate cost
+    {
+      const double* V = d.V + (size_t)gj * 6;  // [v00 v10 v11 v20 v21 v22]
+      const double q0 = V[0] * ds[0] + V[1] * ds[1] + V[3] * ds[2];
+      const double q1 = V[1] * ds[0] + V[2] * ds[1] + V[4] * ds[2];
+      const double q2 = V[3] * ds[0] + V[4] * ds[1] + V[5] * ds[2];
+      mcc = s1 + (ds[0] * t0 + ds[1] * t1 + ds[2] * t2) + 0.5 * (ds[0] * q0 + ds[1] * q1 + ds[2] * q2);
+    }
+    // pass 2: candidate cost (residuals only)
     for (int a = a0; a < a1; ++a) {
       const float2 uv = d.obs_uv[a];
-      const int ci = d.obs_cam[a];
-      const double* cb = tab + ci * CBS;
-      double res[2], Jc[2][NW], Jr[2][3];
-      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
-      double m0 = 0, m1 = 0;
-#pragma unroll
-      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k] * ds[k]; m0 += Jr[0][k] * m; m1 += Jr[1][k] * m; }
-      mcc += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       double rc[2];
-      ba_residual<F>(ctab + ci * CDS, Xn, uv.x, uv.y, rc);
+      ba_residual<F>(ctab + d.obs_cam[a] * CDS, Xn, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
     }
   }
@@ -1118,6 +1124,13 @@ struct ptz_ba_batch {
   std::vector<hipEvent_t> fork_ev, join_ev;
   std::vector<int> group_first, group_count;
   std::vector<Dev> dg;
+  // Cholesky look-ahead: one auxiliary stream and two events per group stream
+  std::vector<hipStream_t> aux;
+  std::vector<hipEvent_t> la_ev;
+  bool lookahead = true;
+  int group_of(hipStream_t st) const { for (size_t g = 0; g < streams.size(); ++g) if (streams[g] == st) return (int)g; return -1; }
+  hipStream_t aux_stream(hipStream_t st) const { const int g = group_of(st); return (lookahead && g >= 0 && g < (int)aux.size()) ? aux[g] : nullptr; }
+  void lookahead_events(hipStream_t st, hipEvent_t* t, hipEvent_t* r) const { const int g = group_of(st); *t = la_ev[2 * g]; *r = la_ev[2 * g + 1]; }
   int* h_active = nullptr;  // pinned
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
   int has3d = 0, total_o3 = 0;
@@ -1223,6 +1236,9 @@ static void make_groups(ptz_ba_batch* b)
     hipStream_t st; (void)hipStreamCreate(&st); b->streams.push_back(st);
     hipEvent_t e1, e2; (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
     b->fork_ev.push_back(e1); b->join_ev.push_back(e2);
+    hipStream_t ax; (void)hipStreamCreate(&ax); b->aux.push_back(ax);
+    hipEvent_t e3, e4; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e4, hipEventDisableTiming);
+    b->la_ev.push_back(e3); b->la_ev.push_back(e4);
   }
 }
 
@@ -1370,23 +1386,48 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
 
 namespace ptz {
 // defined here (needs ptz_ba_batch) but uses the kernels of ptz_chol.hip through chol_factor_solve pieces
-void chol_panel_launch(const CholBatch& cb, int k, hipStream_t s);
-void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t s);
-void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t s);
 void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof)
 {
+  // One-step look-ahead: after the triangular solve of block column k, the small update of block column k+1 stays on
+  // the main stream, so the (latency-bound) diagonal factorisation and triangular solve of step k+1 start at once,
+  // while the bulk of the trailing update (tile columns >= k+2) runs on the auxiliary stream.
   ptz_ba_batch* b = (ptz_ba_batch*)prof;
   const int nt = cb.np / CHOL_NB;
+  hipStream_t aux = b->aux_stream(stream);
+  const bool la = aux != nullptr && nt >= 3;
+  hipEvent_t evT = nullptr, evR = nullptr;
+  if (la) b->lookahead_events(stream, &evT, &evR);
+  bool rest_pending = false;
   for (int k = 0; k < nt; ++k) {
+    const int m = nt - k - 1;
     b->prof_begin(P_CHOL_PANEL);
     chol_panel_launch(cb, k, stream);
     b->prof_end();
-    if (nt - k - 1 > 0) {
+    if (m <= 0) continue;
+    if (!la) {
       b->prof_begin(P_CHOL_SYRK);
-      chol_syrk_launch(cb, k, stream);
+      chol_syrk_launch(cb, k, stream, 0);
       b->prof_end();
+      continue;
+    }
+    (void)hipEventRecord(evT, stream);              // panel k (L_ik tiles) is final
+    (void)hipStreamWaitEvent(aux, evT, 0);
+    if (rest_pending) (void)hipStreamWaitEvent(stream, evR, 0);  // column k+1 was last touched by rest(k-1)
+    b->prof_begin(P_CHOL_SYRK);
+    chol_syrk_launch(cb, k, stream, 1);
+    b->prof_end();
+    if (m >= 2) {
+      hipStream_t keep = b->stream;
+      b->stream = aux;
+      b->prof_begin(P_CHOL_SYRK);
+      chol_syrk_launch(cb, k, aux, 2);
+      b->prof_end();
+      b->stream = keep;
+      (void)hipEventRecord(evR, aux);
+      rest_pending = true;
     }
   }
+  if (la && rest_pending) (void)hipStreamWaitEvent(stream, evR, 0);
   b->prof_begin(P_CHOL_BACK);
   chol_backsolve_launch(cb, x, stream);
   b->prof_end();
@@ -1444,6 +1485,8 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   for (auto st : b->streams) (void)hipStreamDestroy(st);
+  for (auto st : b->aux) (void)hipStreamDestroy(st);
+  for (auto e : b->la_ev) (void)hipEventDestroy(e);
   for (auto e : b->fork_ev) (void)hipEventDestroy(e);
   for (auto e : b->join_ev) (void)hipEventDestroy(e);
   delete b;
@@ -1663,7 +1706,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.W, (size_t)b->total_obs * WS));
+  TRY(b->alloc(&d.W, (size_t)b->total_obs * 16));  // room for the widest row stride
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
@@ -1700,6 +1743,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   d.opt.parameter_tolerance = o.parameter_tolerance;
   b->n_group = 1;  // one group by default; more streams overlap little on MI355X (measured: <= 3 %)
   if (const char* e = getenv("PTZ_BA_STREAMS")) b->n_group = std::max(1, atoi(e));
+  b->lookahead = n >= 8;  // look-ahead pays for mid-size batches; a single scene is better off with fewer launches
+  if (const char* e = getenv("PTZ_BA_LOOKAHEAD")) b->lookahead = atoi(e) != 0;
   make_groups(b);
   b->stream = b->streams.empty() ? nullptr : b->streams[0];
   if (b->stream == nullptr || hipEventCreate(&b->ev0) != hipSuccess ||
@@ -1848,12 +1893,13 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     }
   }
   if (W) {  // rows are stored camera-major; return them in observation order
-    std::vector<double> rows((size_t)s.n_obs * WS);
+    const int NW = NC - b->has3d;           // W carries the 2D-2D columns only
+    const int ws = (NW * 3 + 1) & ~1;        // Dims<TYPE>::WS
+    std::vector<double> rows((size_t)s.n_obs * ws);
     std::vector<int> wp(s.n_obs);
-    PTZ_HIP_TRY(hipMemcpy(rows.data(), d.W + (size_t)s.obs_off * WS, sizeof(double) * WS * s.n_obs, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(hipMemcpy(rows.data(), d.W + (size_t)s.obs_off * ws, sizeof(double) * ws * s.n_obs, hipMemcpyDeviceToHost));
     PTZ_HIP_TRY(hipMemcpy(wp.data(), d.wpos + s.obs_off, sizeof(int) * s.n_obs, hipMemcpyDeviceToHost));
-    const int NW = NC - b->has3d;  // W carries the 2D-2D columns only
-    for (int a = 0; a < s.n_obs; ++a) memcpy(W + (size_t)a * NW * 3, &rows[(size_t)(wp[a] - s.obs_off) * WS], sizeof(double) * NW * 3);
+    for (int a = 0; a < s.n_obs; ++a) memcpy(W + (size_t)a * NW * 3, &rows[(size_t)(wp[a] - s.obs_off) * ws], sizeof(double) * NW * 3);
   }
   return PTZ_OK;
 }

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
 }
 
 // ---- trailing update: A_ij -= L_ik L_jk^T on the matrix cores ---------------------------------------
-__global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k)
+// mode 0: every trailing tile (i >= j > k); mode 1: only block column k+1 (tiles (i, k+1)), the part the next panel
+// depends on; mode 2: the rest (j >= k+2).  Modes 1 + 2 together equal mode 0 (one-step look-ahead split).
+__global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int mode)
 {
   int bx, sys;
   xcd_remap(bx, sys);
@@ -229,11 +231,18 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k)
   const int n = cb.n[sys];
   // linear index -> (i, j), k < j <= i < nt (row-major over the lower triangle of the trailing block)
   const int m = nt - k - 1;
-  int t = bx;
-  int ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-  while (ii * (ii + 1) / 2 > t) --ii;
-  const int jj = t - ii * (ii + 1) / 2;
+  int ii, jj;
+  if (mode == 1) {
+    ii = bx; jj = 0;
+  }
+  else {
+    const int t = bx;
+    ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    while (ii * (ii + 1) / 2 > t) --ii;
+    jj = t - ii * (ii + 1) / 2;
+    if (mode == 2) { ++ii; ++jj; }  // lower triangle of the (m-1) x (m-1) block that starts at tile column k+2
+  }
   if (ii >= m) return;
   const int ti = k + 1 + ii, tj = k + 1 + jj;
   if (ti * NB > n) return;  // rows of this tile are beyond the rhs row: nothing to update
@@ -346,10 +355,11 @@ void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream)
   const int m = cb.np / NB - k - 1;
   if (m > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, (const double*)cb.Dinv, k);
 }
-void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream)
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode)
 {
   const int m = cb.np / NB - k - 1;
-  if (m > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(m * (m + 1) / 2, cb.count), dim3(256), 0, stream, cb, k);
+  const int tiles = mode == 0 ? m * (m + 1) / 2 : (mode == 1 ? m : m * (m - 1) / 2);
+  if (tiles > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode);
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
@@ -362,7 +372,7 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
   const int nt = cb.np / NB;
   for (int k = 0; k < nt; ++k) {
     chol_panel_launch(cb, k, stream);
-    chol_syrk_launch(cb, k, stream);
+    chol_syrk_launch(cb, k, stream, 0);
   }
   chol_backsolve_launch(cb, x, stream);
 }

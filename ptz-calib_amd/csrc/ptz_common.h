@@ -98,7 +98,7 @@ inline int chol_padded_order(int n_max) { return ((n_max + 1 + CHOL_NB - 1) / CH
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
 // the three kernel families of chol_factor_solve, individually (for per-family timing)
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream);
-void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream);
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode);  // 0 all, 1 column k+1, 2 rest
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
 void chol_clear(const CholBatch& cb, hipStream_t stream);
