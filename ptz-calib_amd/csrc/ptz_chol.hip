@@ -86,15 +86,21 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
   const int n = cb.n[sys];
   if (k * NB > n) return;  // whole block column is padding (identity)
   const double* A = cb.A + (size_t)sys * np * np;
-  __shared__ __attribute__((aligned(16))) double Ls[NB * LD];
-  __shared__ double part[4][NB];
+  __shared__ __attribute__((aligned(16))) double As[NB * LD];   // the tile A_kk (read only)
+  __shared__ __attribute__((aligned(16))) double Ls[NB * LD];   // L_kk, written column by column by the owner waves
+  __shared__ double part[2][4][NB];                             // partial sums, double-buffered over the column parity
   __shared__ double rinv[NB];
   __shared__ int okflag;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, Ls);
+  tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, As);
+  for (int idx = threadIdx.x; idx < NB * LD; idx += 256) Ls[idx] = 0.0;
   if (threadIdx.x == 0) okflag = 1;
   __syncthreads();
+  // One barrier per column: every wave finishes column j redundantly (same arithmetic -> same bits), the owner wave
+  // publishes L[:, j] for ITS OWN later reads only (a wave reads just the columns it owns), the partial-sum buffer
+  // alternates so that a wave one column ahead never overwrites partials still being read.
   double aw[NB / 4];  // L[i][q] for this wave's columns q = 8 * (t >> 1) + 2 * w + (t & 1)
+  bool ok = true;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     double p0 = 0, p1 = 0;
@@ -110,27 +116,23 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
         p0 += aw[t] * Ls[j * LD + q];
       }
     }
-    part[w][lane] = p0 + p1;
+    double (*pb)[NB] = part[j & 1];
+    pb[w][lane] = p0 + p1;
     __syncthreads();
-    const double sres = Ls[lane * LD + j] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    const double d = __shfl(sres, j, WAVE);
-    if (!(d > 0.0) && (k * NB + j) < n && threadIdx.x == 0) okflag = 0;
+    const double sres = As[lane * LD + j] - ((pb[0][lane] + pb[1][lane]) + (pb[2][lane] + pb[3][lane]));
+    const double d = As[j * LD + j] - ((pb[0][j] + pb[1][j]) + (pb[2][j] + pb[3][j]));  // pivot: broadcast reads, same sum order
+    if (!(d > 0.0) && (k * NB + j) < n) ok = false;
     const double ird = rsqrt_nr(d);
     const double l = (lane == j) ? d * ird : ((lane > j) ? sres * ird : 0.0);
-    if (((j >> 1) & 3) == w) aw[2 * (j >> 3) + (j & 1)] = l;
-    __syncthreads();  // everyone has read column j of A and the partials
-    if (w == 0) {
+    if (((j >> 1) & 3) == w) {
+      aw[2 * (j >> 3) + (j & 1)] = l;
       Ls[lane * LD + j] = l;
       if (lane == j) rinv[j] = ird;
     }
-    __syncthreads();
   }
-  // zero the strict upper triangle (it still holds A) and publish L_kk
-  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    if (c > r) Ls[r * LD + c] = 0.0;
-  }
+  if (!ok && threadIdx.x == 0) okflag = 0;
   __syncthreads();
+  // publish L_kk (the strict upper triangle was zero-initialised)
   tile_s2g<256>(Ls, cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB);
   if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
   // inverses of the four 16x16 diagonal blocks: lane -> (block b, column c), forward substitution on e_c
