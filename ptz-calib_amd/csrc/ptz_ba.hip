@@ -572,9 +572,12 @@ __global__ void k_cam_diag(Dev d)
 #ifndef PTZ_SCHUR_THREADS
 #define PTZ_SCHUR_THREADS 256
 #endif
+#ifndef PTZ_SCHUR_WAVES
+#define PTZ_SCHUR_WAVES 3
+#endif
 constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
 template <int TYPE>
-__global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(Dev d)
+__global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
   constexpr int NU = NW * (NW + 1) / 2;
@@ -603,12 +606,20 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
   for (int k = 0; k < NU; ++k) D[k] = 0;
 #ifndef PTZ_DIAG_SCHUR_SKIP_P1
   for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
+#ifdef PTZ_DIAG_P1_NOEZ
+    const int gj = s.ray_off + (q & 63);
+#else
     const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
+#endif
     const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
     const double* E = d.E + (size_t)gj * 6;
     const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
     double w[NT];
+#ifdef PTZ_DIAG_P1_NOW
+    const double* Wa = d.W + (size_t)(o0 + (q & 7)) * Dims<TYPE>::WS;
+#else
     const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
+#endif
 #pragma unroll
     for (int k = 0; k < NT; ++k) w[k] = Wa[k];
     int e = 0;
@@ -628,10 +639,17 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NV = NW + NU;
     double v[NV];
+#ifdef PTZ_DIAG_P1_NORED
+#pragma unroll
+    for (int k = 0; k < NW; ++k) v[k] = bsum[k];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) v[NW + k] = D[k];
+#else
 #pragma unroll
     for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
 #pragma unroll
     for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
+#endif
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
@@ -691,11 +709,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
 #pragma unroll
     for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
     const int e1 = pps[pl + 1];
-    // two entries per trip: both 128-B W_b lines are in flight together
-    for (int e = pps[pl] + l; e < e1; e += 32) {
-      const bool two = (e + 16) < e1;
+    int e = pps[pl] + l;
+    // two entries per trip while both exist (both W_b rows in flight together), then at most one single entry
+    for (; e + 16 < e1; e += 32) {
       const int2 ab0 = ents[e];
-      const int2 ab1 = two ? ents[e + 16] : ab0;
+      const int2 ab1 = ents[e + 16];
 #ifdef PTZ_DIAG_NOGATHER
       const double* Wb0 = d.W + (size_t)(o0 + (ab0.y & 7)) * Dims<TYPE>::WS;
       const double* Wb1 = d.W + (size_t)(o0 + (ab1.y & 7)) * Dims<TYPE>::WS;
@@ -708,35 +726,52 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCHUR_THREADS / 128) void k_schur(De
       for (int k = 0; k < NT; ++k) { wb0[k] = Wb0[k]; wb1[k] = Wb1[k]; }
       const double* Ta0 = T + ab0.x * NT;
       const double* Ta1 = T + ab1.x * NT;
-      const double f1 = two ? 1.0 : 0.0;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
-        const double u0 = f1 * Ta1[3 * p], u1 = f1 * Ta1[3 * p + 1], u2 = f1 * Ta1[3 * p + 2];
+        const double u0 = Ta1[3 * p], u1 = Ta1[3 * p + 1], u2 = Ta1[3 * p + 2];
 #pragma unroll
         for (int q = 0; q < NW; ++q)
           acc[p * NW + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
                              (u0 * wb1[3 * q] + u1 * wb1[3 * q + 1] + u2 * wb1[3 * q + 2]);
       }
     }
-#ifndef PTZ_DIAG_NOSHFL
+    if (e < e1) {
+      const int2 ab0 = ents[e];
+      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
+      double wb0[NT];
 #pragma unroll
-    for (int k = 0; k < NW * NW; ++k) {
-      double v = acc[k];
-      v += __shfl_xor(v, 8, 16);
-      v += __shfl_xor(v, 4, 16);
-      v += __shfl_xor(v, 2, 16);
-      v += __shfl_xor(v, 1, 16);
-      acc[k] = v;
+      for (int k = 0; k < NT; ++k) wb0[k] = Wb0[k];
+      const double* Ta0 = T + ab0.x * NT;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) {
+        const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) acc[p * NW + q] += t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2];
+      }
     }
-#endif
-    if (l == 0) {
-      const int cj = d.pair_cj[s.pair_off + pr0 + pl];
-      double* S = A + (size_t)(ci * NC) * np + cj * NC;
+    // reduce-scatter over the 16 lanes of the group: after the steps with masks 8, 4, 2, 1 lane l holds the complete
+    // sum of block element l (fixed order); every lane then stores its own element.  Elements >= NW*NW (NW = 5 keeps
+    // 25 values) take a second pass with the lanes that are left.
+    const int cj = d.pair_cj[s.pair_off + pr0 + pl];
+    double* S = A + (size_t)(ci * NC) * np + cj * NC;
 #pragma unroll
-      for (int p = 0; p < NW; ++p)
+    for (int base = 0; base < NW * NW; base += 16) {
+      double v[16];
 #pragma unroll
-        for (int q = 0; q < NW; ++q) S[(size_t)Dims<TYPE>::pos(p) * np + Dims<TYPE>::pos(q)] = -acc[p * NW + q];
+      for (int k = 0; k < 16; ++k) v[k] = (base + k < NW * NW) ? acc[(base + k < NW * NW) ? base + k : 0] : 0.0;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) {
+        const bool up = (l & m) != 0;
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          const double keep = up ? v[k + m] : v[k];
+          const double send = up ? v[k] : v[k + m];
+          v[k] = keep + __shfl_xor(send, m, 16);
+        }
+      }
+      const int el = base + l;
+      if (el < NW * NW) S[(size_t)Dims<TYPE>::pos(el / NW) * np + Dims<TYPE>::pos(el % NW)] = -v[0];
     }
   }
 }
