@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "epnp.h"
 #include "krt_optimizer.h"
 #include "ptzray_optimizer.h"
 
@@ -75,13 +76,37 @@ int32_t ptzh_tracks_build(int32_t n_pairs, const int64_t* src, const int64_t* ds
   return static_cast<int32_t>(ids.size());
 }
 
+namespace {
+struct PackedOut {
+  int32_t *n_obs, *n_ray;
+  float** uv; int32_t** cam; int32_t** ray; double** w; double** cam15; double** ray3; int64_t** cam_image;
+};
+void ExportPacked(const PackedBA& p, const PackedOut& o)
+{
+  if (o.n_obs) *o.n_obs = static_cast<int32_t>(p.obs_cam.size());
+  if (o.n_ray) *o.n_ray = static_cast<int32_t>(p.ray_track.size());
+  if (o.uv) *o.uv = Dup(p.obs_uv);
+  if (o.cam) *o.cam = Dup(p.obs_cam);
+  if (o.ray) *o.ray = Dup(p.obs_ray);
+  if (o.w) *o.w = Dup(p.ray_weight);
+  if (o.cam15) *o.cam15 = Dup(p.cam);
+  if (o.ray3) *o.ray3 = Dup(p.ray);
+  if (o.cam_image) { std::vector<int64_t> ci(p.cam_image.begin(), p.cam_image.end()); *o.cam_image = Dup(ci); }
+}
+}  // namespace
+
 // Full PTZRayOptimizer::Solve through the C++ class.  cam15 [15*n_img] in/out (ToVector layout).
+// Annotations (may be NULL): ann_ptr [n_img+1] prefix offsets into ann_uv [2*] / ann_xyz [3*] (pixels_ / pts3d_ of the
+// reference's second constructor).  tlw_out [14]: initial T_l_w (6), refined T_l_w (6), 1.0 if the PnP initialisation passed, number of packed 2D-3D blocks.
 // packed_* outputs (malloc'ed, may be NULL): the packed problem the class handed to the C-ABI.
-int32_t ptzh_ptzray_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, int32_t n_pairs, const int64_t* src,
-                          const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t, double* cam15,
-                          const int64_t* cand_ids, int32_t n_cand, int32_t max_iter, int32_t type, int32_t solve_on_device,
-                          double* errors3, ptz_lm_summary* summary, int32_t* n_obs_out, int32_t* n_ray_out, float** p_uv,
-                          int32_t** p_cam, int32_t** p_ray, double** p_w, double** p_cam15, double** p_ray3, int64_t** p_cam_image)
+// solve_on_device == 0: packing only (CPU tests); without a device ptz_ba_solve returns PTZ_ENODEVICE, Solve returns
+// false and packed() holds the packed problem and the initial T_l_w.
+int32_t ptzh_ptzray_georef(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, int32_t n_pairs, const int64_t* src,
+                           const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t, double* cam15,
+                           const int64_t* ann_ptr, const float* ann_uv, const double* ann_xyz, const int64_t* cand_ids,
+                           int32_t n_cand, int32_t max_iter, int32_t type, int32_t solve_on_device, double* errors3,
+                           ptz_lm_summary* summary, double* tlw_out, int32_t* n_obs_out, int32_t* n_ray_out, float** p_uv,
+                           int32_t** p_cam, int32_t** p_ray, double** p_w, double** p_cam15, double** p_ray3, int64_t** p_cam_image)
 {
   std::vector<ImageFeatures> feats;
   std::vector<MatchesInfo> mis;
@@ -89,38 +114,40 @@ int32_t ptzh_ptzray_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_
   BuildInputs(n_img, kp_ptr, kp_xy, nullptr, n_pairs, src, dst, match_ptr, q, t, cam15, feats, mis, cams);
   std::unordered_set<long> ids;
   for (int i = 0; i < n_cand; ++i) ids.insert(static_cast<long>(cand_ids[i]));
-  PTZRayOptimizer opt(feats, mis, cams, ids, solve_on_device ? max_iter : 0, static_cast<FACTOR_TYPE>(type));
-  bool ok = false;
-  if (solve_on_device) {
-    ok = opt.Solve(cams);
+  std::vector<std::vector<Point2f>> pixels;
+  std::vector<std::vector<Point3d>> pts3d;
+  if (ann_ptr) {
+    pixels.resize(n_img);
+    pts3d.resize(n_img);
+    for (int i = 0; i < n_img; ++i)
+      for (int64_t k = ann_ptr[i]; k < ann_ptr[i + 1]; ++k) {
+        pixels[i].emplace_back(ann_uv[2 * k], ann_uv[2 * k + 1]);
+        pts3d[i].emplace_back(ann_xyz[3 * k], ann_xyz[3 * k + 1], ann_xyz[3 * k + 2]);
+      }
   }
-  else {
-    // packing only (CPU tests): run the pre-solve stages of Solve through a friend-free path: Solve() with max_iter 0 fails
-    // CheckValid before touching the device, so re-create with max_iter 1 and call the public pieces via packed().
-    PTZRayOptimizer opt2(feats, mis, cams, ids, 1, static_cast<FACTOR_TYPE>(type));
-    opt2.Solve(cams);  // without a device ptz_ba_solve returns PTZ_ENODEVICE -> Solve returns false, packed() is filled
-    const PackedBA& p = opt2.packed();
-    if (n_obs_out) *n_obs_out = static_cast<int32_t>(p.obs_cam.size());
-    if (n_ray_out) *n_ray_out = static_cast<int32_t>(p.ray_track.size());
-    if (p_uv) *p_uv = Dup(p.obs_uv);
-    if (p_cam) *p_cam = Dup(p.obs_cam);
-    if (p_ray) *p_ray = Dup(p.obs_ray);
-    if (p_w) *p_w = Dup(p.ray_weight);
-    if (p_cam15) *p_cam15 = Dup(p.cam);
-    if (p_ray3) *p_ray3 = Dup(p.ray);
-    if (p_cam_image) { std::vector<int64_t> ci(p.cam_image.begin(), p.cam_image.end()); *p_cam_image = Dup(ci); }
+  PTZRayOptimizer opt(feats, mis, cams, pixels, pts3d, ids, solve_on_device ? max_iter : 1, static_cast<FACTOR_TYPE>(type));
+  const std::array<double, 6> zero{{0, 0, 0, 0, 0, 0}};
+  const PackedOut po{n_obs_out, n_ray_out, p_uv, p_cam, p_ray, p_w, p_cam15, p_ray3, p_cam_image};
+  if (!solve_on_device) {
+    opt.Solve(cams);
+    const PackedBA& p = opt.packed();
+    ExportPacked(p, po);
+    if (tlw_out) {
+      for (int k = 0; k < 6; ++k) { tlw_out[k] = p.tlw[k]; tlw_out[6 + k] = zero[k]; }
+      tlw_out[12] = p.tlw_init_ok ? 1.0 : 0.0;
+    tlw_out[13] = static_cast<double>(p.obs3d_cam.size());
+      tlw_out[13] = static_cast<double>(p.obs3d_cam.size());
+    }
     return 0;
   }
+  const bool ok = opt.Solve(cams);
   const PackedBA& p = opt.packed();
-  if (n_obs_out) *n_obs_out = static_cast<int32_t>(p.obs_cam.size());
-  if (n_ray_out) *n_ray_out = static_cast<int32_t>(p.ray_track.size());
-  if (p_uv) *p_uv = Dup(p.obs_uv);
-  if (p_cam) *p_cam = Dup(p.obs_cam);
-  if (p_ray) *p_ray = Dup(p.obs_ray);
-  if (p_w) *p_w = Dup(p.ray_weight);
-  if (p_cam15) *p_cam15 = Dup(p.cam);
-  if (p_ray3) *p_ray3 = Dup(p.ray);
-  if (p_cam_image) { std::vector<int64_t> ci(p.cam_image.begin(), p.cam_image.end()); *p_cam_image = Dup(ci); }
+  if (tlw_out) {
+    for (int k = 0; k < 6; ++k) { tlw_out[k] = opt.initial_tlw()[k]; tlw_out[6 + k] = p.tlw[k]; }
+    tlw_out[12] = p.tlw_init_ok ? 1.0 : 0.0;
+    tlw_out[13] = static_cast<double>(p.obs3d_cam.size());
+  }
+  ExportPacked(p, po);
   if (errors3) { errors3[0] = opt.final_reproj_error_all(); errors3[1] = opt.final_reproj_error_2d2d(); errors3[2] = opt.final_reproj_error_2d3d(); }
   if (summary) *summary = opt.summary();
   if (ok)
@@ -129,6 +156,32 @@ int32_t ptzh_ptzray_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_
       memcpy(cam15 + 15 * i, v.data(), sizeof(double) * 15);
     }
   return ok ? 1 : 0;
+}
+
+int32_t ptzh_ptzray_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, int32_t n_pairs, const int64_t* src,
+                          const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t, double* cam15,
+                          const int64_t* cand_ids, int32_t n_cand, int32_t max_iter, int32_t type, int32_t solve_on_device,
+                          double* errors3, ptz_lm_summary* summary, int32_t* n_obs_out, int32_t* n_ray_out, float** p_uv,
+                          int32_t** p_cam, int32_t** p_ray, double** p_w, double** p_cam15, double** p_ray3, int64_t** p_cam_image)
+{
+  return ptzh_ptzray_georef(n_img, kp_ptr, kp_xy, n_pairs, src, dst, match_ptr, q, t, cam15, nullptr, nullptr, nullptr, cand_ids,
+                            n_cand, max_iter, type, solve_on_device, errors3, summary, nullptr, n_obs_out, n_ray_out, p_uv, p_cam,
+                            p_ray, p_w, p_cam15, p_ray3, p_cam_image);
+}
+
+// cv::solvePnP(..., SOLVEPNP_EPNP) replacement on its own: K9 row-major, dist5 (k1,k2,k3,p1,p2), out R9 row-major, t3.
+int32_t ptzh_epnp(int32_t n, const double* xyz, const float* uv, const double* K9, const double* dist5, double* R9, double* t3)
+{
+  std::vector<Point3d> pw;
+  std::vector<Point2f> px;
+  for (int i = 0; i < n; ++i) { pw.emplace_back(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); px.emplace_back(uv[2 * i], uv[2 * i + 1]); }
+  Mat33 K, R; Vec5 d; Vec3 tv;
+  for (int k = 0; k < 9; ++k) K[k] = K9[k];
+  for (int k = 0; k < 5; ++k) d[k] = dist5[k];
+  if (!SolvePnPEPnP(pw, px, K, d, R, tv)) return 0;
+  for (int k = 0; k < 9; ++k) R9[k] = R[k];
+  for (int k = 0; k < 3; ++k) t3[k] = tv[k];
+  return 1;
 }
 
 // KRTOptimizer through the C++ class: one query.  cam_cur15 in (initial, world) / out (refined, world).

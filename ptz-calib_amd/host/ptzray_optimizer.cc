@@ -4,6 +4,8 @@
 #include <limits>
 #include <numeric>
 
+#include "epnp.h"
+
 namespace ptzcalib {
 
 PTZRayOptimizer::PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
@@ -61,11 +63,58 @@ void PTZRayOptimizer::FindTracks()
   Length(tracks_, track_len_, max_track_len_, min_track_len_);
 }
 
+// T_l_w from the first candidate view whose annotations pass the PnP gates (ptzray_optimizer.cc:562-633).
+bool PTZRayOptimizer::SetInitTransLocalToWorld()
+{
+  packed_.tlw = {{0, 0, 0, 0, 0, 0}};
+  packed_.tlw_init_ok = false;
+  for (size_t i = 0; i < num_cams_; ++i) {
+    if (!isCandidate(static_cast<long>(i))) continue;
+    if (pixels_.empty() || pixels_[i].empty()) continue;
+    Mat33 R;
+    Vec3 tvec;
+    if (!SolvePnPEPnP(pts3d_[i], pixels_[i], cameras_[i].K(), cameras_[i].dist(), R, tvec)) continue;  // :572-576
+    // cv::solvePnP hands back rvec; the reference converts it back with cv::Rodrigues (:578-579)
+    R = Rodrigues(RodriguesInv(R));
+    const Vec3 p0 = Mul(R, Vec3{pts3d_[i][0].x, pts3d_[i][0].y, pts3d_[i][0].z});
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (p0[2] + tvec[2] < 0 || det < 0.0) continue;  // :581-586
+    // cv::projectPoints on float32 copies of the points, no distortion, float32 predictions (:588-596)
+    const Mat33& K = cameras_[i].K();
+    double err = 0;
+    for (size_t j = 0; j < pts3d_[i].size(); ++j) {
+      const Vec3 Xf = {static_cast<double>(static_cast<float>(pts3d_[i][j].x)), static_cast<double>(static_cast<float>(pts3d_[i][j].y)),
+                       static_cast<double>(static_cast<float>(pts3d_[i][j].z))};
+      const Vec3 X = Mul(R, Xf);
+      const double x = (X[0] + tvec[0]) / (X[2] + tvec[2]), y = (X[1] + tvec[1]) / (X[2] + tvec[2]);
+      const float pu = static_cast<float>(K[0] * x + K[2]), pv = static_cast<float>(K[4] * y + K[5]);
+      err += static_cast<double>((pu - pixels_[i][j].x) * (pu - pixels_[i][j].x) + (pv - pixels_[i][j].y) * (pv - pixels_[i][j].y));
+    }
+    err = std::sqrt(err / static_cast<double>(pts3d_[i].size()));
+    if (err > 300) continue;  // :602-605
+    // T_l_w = T_i_l^-1 T_i_w (:615-621)
+    const Mat33 Rt = Transpose(cameras_[i].R());
+    const Mat33 R_l_w = Mul(Rt, R);
+    const Vec3& ti = cameras_[i].t();
+    const Vec3 t_l_w = Mul(Rt, Vec3{tvec[0] - ti[0], tvec[1] - ti[1], tvec[2] - ti[2]});
+    const Vec3 rv = RodriguesInv(R_l_w);
+    packed_.tlw = {{rv[0], rv[1], rv[2], t_l_w[0], t_l_w[1], t_l_w[2]}};
+    packed_.tlw_init_ok = true;
+    return true;
+  }
+  return false;
+}
+
 // SetUpInitialCameraParams (:635-670) + AddConstraints2d2d ordering (:799-850) + Pix2Ray (:768-797)
 void PTZRayOptimizer::Pack()
 {
   PackedBA& p = packed_;
-  p = PackedBA();
+  {
+    PackedBA fresh;
+    fresh.tlw = p.tlw;
+    fresh.tlw_init_ok = p.tlw_init_ok;
+    p = fresh;
+  }
   std::vector<int> cam_of_image(num_cams_, -1);
   for (size_t i = 0; i < num_cams_; ++i) {
     if (!isCandidate(static_cast<long>(i))) continue;
@@ -104,6 +153,32 @@ void PTZRayOptimizer::Pack()
     const double n = std::sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
     p.ray.push_back(acc[0] / n); p.ray.push_back(acc[1] / n); p.ray.push_back(acc[2] / n);
   }
+  // AddConstraints2d3d (:887-923): candidate cameras ascending, annotation order within a camera
+  for (size_t i = 0; i < num_cams_; ++i) {
+    if (!isCandidate(static_cast<long>(i))) continue;
+    if (pixels_.empty() || pixels_[i].empty()) continue;
+    for (size_t j = 0; j < pixels_[i].size(); ++j) {
+      p.obs3d_uv.push_back(pixels_[i][j].x); p.obs3d_uv.push_back(pixels_[i][j].y);
+      p.obs3d_xyz.push_back(pts3d_[i][j].x); p.obs3d_xyz.push_back(pts3d_[i][j].y); p.obs3d_xyz.push_back(pts3d_[i][j].z);
+      p.obs3d_cam.push_back(cam_of_image[i]);
+    }
+  }
+}
+
+// host-side Reproj2d3dFactor residual for the read-back statistics (CalReprojError2d3d, :1030-1072; functor :268-326)
+static void Residual2d3d(const double* c, const double* tlw, const double* Xw, float u, float v, double* res)
+{
+  const Mat33 Rl = Rodrigues({tlw[0], tlw[1], tlw[2]});
+  Vec3 Xl = Mul(Rl, Vec3{Xw[0], Xw[1], Xw[2]});
+  Xl = {Xl[0] + tlw[3], Xl[1] + tlw[4], Xl[2] + tlw[5]};
+  const Vec3 P = Mul(Rodrigues({c[4], c[5], c[6]}), Xl);
+  const double px = P[0] / P[2], py = P[1] / P[2];
+  const double r2 = px * px + py * py, r4 = r2 * r2, r6 = r2 * r2 * r2;
+  const double rad = 1.0 + c[10] * r2 + c[11] * r4 + c[12] * r6;
+  const double xd = px * rad + 2.0 * c[13] * px * py + c[14] * (r2 + 2.0 * px * px);
+  const double yd = py * rad + 2.0 * c[14] * px * py + c[13] * (r2 + 2.0 * py * py);
+  res[0] = static_cast<double>(u) - (c[0] * xd + c[2]);
+  res[1] = static_cast<double>(v) - (c[1] * yd + c[3]);
 }
 
 // host-side evaluation of the 2D-2D residual for the read-back statistics (CalReprojError2d2d, :970-1028)
@@ -141,10 +216,9 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
 {
   if (!CheckValid()) return false;
   FindTracks();
-  // Device path limits (documented in DESIGN.md): 2D-3D annotation residuals (georeferencing), shared intrinsics and
-  // the Fxfy / Disp factor types are not implemented yet -> behave as a failed solve, never as a silent CPU solve.
-  for (size_t i = 0; i < num_cams_; ++i)
-    if (isCandidate(static_cast<long>(i)) && !pixels_.empty() && !pixels_[i].empty()) return false;
+  SetInitTransLocalToWorld();
+  // Device path limits (documented in DESIGN.md): shared intrinsics and the Fxfy / Disp factor types are not
+  // implemented yet -> behave as a failed solve, never as a silent CPU solve.
   for (size_t i = 0; i < num_cams_; ++i)
     if (shared_ic_ids_[i] != static_cast<long>(i)) return false;
   if (type_ != PTZRay && type_ != PTZRayDist) return false;
@@ -161,12 +235,20 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
   prob.obs_ray = p.obs_ray.data();
   prob.ray_weight = p.ray_weight.data();
   prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : PTZ_BA_PTZRayDist;
+  prob.n_obs3d = static_cast<int32_t>(p.obs3d_cam.size());
+  if (prob.n_obs3d > 0) {
+    prob.obs3d_uv = p.obs3d_uv.data();
+    prob.obs3d_xyz = p.obs3d_xyz.data();
+    prob.obs3d_cam = p.obs3d_cam.data();
+  }
   ptz_lm_options opt;
   ptz_lm_options_default(&opt);
   opt.max_num_iterations = max_iter_;  // ptzray_optimizer.cc:470
   opt.device_id = device_id_;
   std::vector<double> cam = p.cam, ray = p.ray;
-  double tlw[6] = {0, 0, 0, 0, 0, 0};
+  double tlw[6];
+  tlw_init_ = p.tlw;
+  for (int k = 0; k < 6; ++k) tlw[k] = p.tlw[k];
   if (ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_) != PTZ_OK) return false;
 
   // CalReprojError (:960-968)
@@ -181,26 +263,50 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
     sum1 += res[1] * res[1];
   }
   final_reproj_error_2d2d_ = std::sqrt((sum0 + sum1) / static_cast<double>(p.obs_cam.size()));
-  final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();  // sqrt(0 / 0) in the reference when there are no annotations
+  if (p.obs3d_cam.empty()) {
+    final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();  // sqrt(0 / 0) in the reference when there are no annotations
+  }
+  else {
+    double s0 = 0, s1 = 0;
+    for (size_t a = 0; a < p.obs3d_cam.size(); ++a) {
+      double res[2];
+      Residual2d3d(&cam[15 * static_cast<size_t>(p.obs3d_cam[a])], tlw, &p.obs3d_xyz[3 * a], p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1], res);
+      s0 += res[0] * res[0];
+      s1 += res[1] * res[1];
+    }
+    final_reproj_error_2d3d_ = std::sqrt((s0 + s1) / static_cast<double>(p.obs3d_cam.size()));
+  }
 
   if (summary_.termination_type != PTZ_CONVERGENCE) return false;  // :482-488
 
-  // ObtainRefinedCameraParams (:672-766); tlw = 0 -> T_l_w is the identity
+  // ObtainRefinedCameraParams (:672-766)
   if (cameras.size() < num_cams_) cameras.resize(num_cams_);
+  Mat33 R_l_w;
+  Vec3 t_l_w;
+  T_l_w(tlw, R_l_w, t_l_w);
   for (size_t c = 0; c < p.cam_image.size(); ++c) {
     std::vector<double> param(cam.begin() + 15 * c, cam.begin() + 15 * (c + 1));
-    param[1] = param[0];  // fy := fx for PTZRay / PTZRayDist (:705-706)
-    cameras[p.cam_image[c]].FromVector(param);
+    param[1] = param[0];  // fy := fx for PTZRay / PTZRayDist, also after fy was a free parameter of the annotations (:705-706)
+    Camera& out = cameras[p.cam_image[c]];
+    out.FromVector(param);
+    // local -> world: T_i_w = T_i_l T_l_w (:729-740)
+    const Vec3 Rt = Mul(out.R(), t_l_w);
+    out.t() = {Rt[0] + out.t()[0], Rt[1] + out.t()[1], Rt[2] + out.t()[2]};
+    out.R() = Mul(out.R(), R_l_w);
   }
   rays.clear();
   rays.resize(num_cams_);
+  const Mat33 R_w_l = Transpose(R_l_w);
+  const Vec3 Rtt = Mul(R_w_l, t_l_w);
   for (size_t j = 0; j < p.ray_track.size(); ++j) {
-    const Vec3 ray_w = {ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]};
+    const Vec3 rl = Mul(R_w_l, Vec3{ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]});
+    const Vec3 ray_w = {rl[0] - Rtt[0], rl[1] - Rtt[1], rl[2] - Rtt[2]};  // R_w_l ray_l + t_w_l (:746-754)
     for (const auto& kv : tracks_.at(p.ray_track[j]))
       rays[kv.first].emplace_back(p.ray_track[j], ray_w, features_[kv.first].keypoints[kv.second].pt);
   }
   p.cam = cam;
   p.ray = ray;
+  for (int k = 0; k < 6; ++k) p.tlw[k] = tlw[k];
   return true;
 }
 

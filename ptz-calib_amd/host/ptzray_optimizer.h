@@ -24,6 +24,11 @@ struct PackedBA {
   std::vector<double> ray_weight;  // full track length (ptzray_optimizer.cc:805)
   std::vector<double> cam;         // [15*n_cam]
   std::vector<double> ray;         // [3*n_ray] Pix2Ray initialisation
+  std::vector<float> obs3d_uv;     // [2*n_obs3d] annotation pixels, cameras ascending (ptzray_optimizer.cc:894-917)
+  std::vector<double> obs3d_xyz;   // [3*n_obs3d]
+  std::vector<int32_t> obs3d_cam;  // compact camera id
+  std::array<double, 6> tlw{{0, 0, 0, 0, 0, 0}};  // T_l_w: initial value before Solve, refined value after
+  bool tlw_init_ok = false;        // SetInitTransLocalToWorld() found a view that passed the PnP gates
 };
 
 class PTZRayOptimizer {
@@ -45,6 +50,7 @@ class PTZRayOptimizer {
   // extras (not in the reference): the packed problem and the solver summary of the last Solve
   const PackedBA& packed() const { return packed_; }
   const ptz_lm_summary& summary() const { return summary_; }
+  const std::array<double, 6>& initial_tlw() const { return tlw_init_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
 
  private:
@@ -52,6 +58,7 @@ class PTZRayOptimizer {
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
+  bool SetInitTransLocalToWorld();
 
   std::vector<Camera> cameras_;
   std::vector<ImageFeatures> features_;
@@ -67,6 +74,7 @@ class PTZRayOptimizer {
   int max_iter_ = 100;
   int device_id_ = 0;
   PackedBA packed_;
+  std::array<double, 6> tlw_init_{{0, 0, 0, 0, 0, 0}};
   ptz_lm_summary summary_{};
   double init_reproj_error_all_ = 0, final_reproj_error_all_ = 0, final_reproj_error_2d2d_ = 0, final_reproj_error_2d3d_ = 0;
 };

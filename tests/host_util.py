@@ -54,7 +54,18 @@ def scene_to_features_matches(sc, n_img=None):
     return kps, plist
 
 
-def ptzray_solve(kps, plist, cam15, cand_ids=(), max_iter=200, ftype=0, on_device=True):
+def epnp(xyz, uv, K, dist):
+    """cv::solvePnP(EPNP) replacement of the host library: returns (ok, R 3x3, t 3)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float32)
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9); dist = np.ascontiguousarray(dist, dtype=np.float64)
+    R = np.zeros(9); t = np.zeros(3)
+    ok = lib().ptzh_epnp(len(xyz), _p(xyz), _p(uv), _p(K), _p(dist), _p(R), _p(t))
+    return bool(ok), R.reshape(3, 3), t
+
+
+def ptzray_solve(kps, plist, cam15, cand_ids=(), max_iter=200, ftype=0, on_device=True, annotations=None):
+    """annotations: None or (cam index array, uv [n,2] f32, xyz [n,3] f64) sorted by camera.  With annotations the
+    returned dict `packed` also holds tlw_init / tlw / tlw_ok."""
     from ctypes import POINTER, byref, c_double, c_float, c_int32, c_int64
     import __graft_entry__ as ge
     api = ge.load_package().api
@@ -71,16 +82,26 @@ def ptzray_solve(kps, plist, cam15, cand_ids=(), max_iter=200, ftype=0, on_devic
     n_obs = c_int32(); n_ray = c_int32()
     puv = POINTER(c_float)(); pcam = POINTER(c_int32)(); pray = POINTER(c_int32)(); pw = POINTER(c_double)()
     pc15 = POINTER(c_double)(); pr3 = POINTER(c_double)(); pci = POINTER(c_int64)()
-    ok = lib().ptzh_ptzray_solve(n_img, _p(kp_ptr), _p(kp_xy), len(plist), _p(src), _p(dst), _p(mptr), _p(q), _p(t), _p(cam),
-                                 _p(cand) if len(cand) else None, len(cand), max_iter, ftype, int(on_device), _p(errors),
-                                 byref(summ), byref(n_obs), byref(n_ray), byref(puv), byref(pcam), byref(pray), byref(pw),
-                                 byref(pc15), byref(pr3), byref(pci))
+    ann_ptr = ann_uv = ann_xyz = None
+    if annotations is not None:
+        acam, auv, axyz = annotations
+        acam = np.asarray(acam)
+        assert np.all(np.diff(acam) >= 0)
+        ann_ptr = np.searchsorted(acam, np.arange(n_img + 1)).astype(np.int64)
+        ann_uv = np.ascontiguousarray(auv, dtype=np.float32); ann_xyz = np.ascontiguousarray(axyz, dtype=np.float64)
+    tlw_out = np.zeros(14)
+    ok = lib().ptzh_ptzray_georef(n_img, _p(kp_ptr), _p(kp_xy), len(plist), _p(src), _p(dst), _p(mptr), _p(q), _p(t), _p(cam),
+                                  _p(ann_ptr), _p(ann_uv), _p(ann_xyz),
+                                  _p(cand) if len(cand) else None, len(cand), max_iter, ftype, int(on_device), _p(errors),
+                                  byref(summ), _p(tlw_out), byref(n_obs), byref(n_ray), byref(puv), byref(pcam), byref(pray),
+                                  byref(pw), byref(pc15), byref(pr3), byref(pci))
     no, nr = n_obs.value, n_ray.value
     ncam = len(cand) if len(cand) else n_img
     packed = dict(obs_uv=np.ctypeslib.as_array(puv, (no, 2)).copy(), obs_cam=np.ctypeslib.as_array(pcam, (no,)).copy(),
                   obs_ray=np.ctypeslib.as_array(pray, (no,)).copy(), ray_weight=np.ctypeslib.as_array(pw, (nr,)).copy(),
                   cam=np.ctypeslib.as_array(pc15, (ncam, 15)).copy(), ray=np.ctypeslib.as_array(pr3, (nr, 3)).copy(),
-                  cam_image=np.ctypeslib.as_array(pci, (ncam,)).copy())
+                  cam_image=np.ctypeslib.as_array(pci, (ncam,)).copy(),
+                  tlw_init=tlw_out[:6].copy(), tlw=tlw_out[6:12].copy(), tlw_ok=bool(tlw_out[12]), n_obs3d=int(tlw_out[13]))
     for x in (puv, pcam, pray, pw, pc15, pr3, pci):
         lib().ptzh_free(x)
     return bool(ok), cam, errors, summ.as_dict(), packed

@@ -74,3 +74,92 @@ def test_packing_candidate_subset_keeps_full_track_weight(pkg, orc, scene_c1):
     assert set(np.unique(pk["obs_cam"])) <= set(range(len(cand)))
     n_expected = sum(sum(1 for i in tr if i in cand) for _, tr in kept)
     assert len(pk["obs_cam"]) == n_expected
+
+
+# ------------------------------------------------------------------------------------------------ EPnP initialisation
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    if th < 1e-12:
+        return np.eye(3)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def _pnp_case(rng, n, planar, noise, k1=0.0):
+    R = _rodrigues(rng.normal(size=3) * 0.8)
+    Xc = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(4, 12, n)]
+    if planar:
+        nrm = _rodrigues(rng.normal(size=3) * 0.5) @ np.array([0, 0, 1.0])
+        a = np.cross(nrm, [1, 0, 0]); a /= np.linalg.norm(a); b = np.cross(nrm, a)
+        ab = rng.uniform(-3, 3, (n, 2))
+        Xc = np.array([0, 0, 9.0]) + ab[:, :1] * a + ab[:, 1:] * b
+    t = rng.normal(size=3) * 3
+    Xw = (Xc - t) @ R
+    x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+    rad = 1 + k1 * (x * x + y * y)
+    uv = np.c_[2000 * x * rad + 960, 2000 * y * rad + 540] + rng.normal(size=(n, 2)) * noise
+    return R, t, Xw, uv
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_epnp_recovers_exact_pose(planar):
+    """SolvePnPEPnP (replacement for cv::solvePnP(..., SOLVEPNP_EPNP), ptzray_optimizer.cc:572): noise-free correspondences
+    give the pose back to round-off, for general and for coplanar (pitch) points, with and without k1."""
+    import host_util as hu
+    rng = np.random.default_rng(11)
+    K = np.array([[2000, 0, 960], [0, 2000, 540], [0, 0, 1.0]])
+    for trial in range(40):
+        n = int(rng.integers(4 if not planar else 5, 30))
+        k1 = 0.0 if trial % 2 == 0 else 0.05
+        R, t, Xw, uv = _pnp_case(rng, n, planar, 0.0, k1)
+        ok, Re, te = hu.epnp(Xw, uv.astype(np.float64), K, np.array([k1, 0, 0, 0, 0.0]))
+        assert ok
+        # float32 pixels are the only error source
+        assert np.abs(Re - R).max() < 2e-4 and np.abs(te - t).max() < 5e-3
+        assert abs(np.linalg.det(Re) - 1) < 1e-12
+
+
+def test_epnp_with_noise_and_degenerate_inputs():
+    import host_util as hu
+    rng = np.random.default_rng(12)
+    K = np.array([[2000, 0, 960], [0, 2000, 540], [0, 0, 1.0]])
+    for planar in (False, True):
+        worst = 0.0
+        for _ in range(40):
+            R, t, Xw, uv = _pnp_case(rng, 12, planar, 0.5)
+            ok, Re, te = hu.epnp(Xw, uv, K, np.zeros(5))
+            assert ok
+            worst = max(worst, np.degrees(np.arccos(np.clip((np.trace(Re @ R.T) - 1) / 2, -1, 1))))
+        assert worst < (1.0 if planar else 0.3)
+    R, t, Xw, uv = _pnp_case(rng, 3, False, 0.0)
+    assert not hu.epnp(Xw, uv, K, np.zeros(5))[0]                       # fewer than 4 points
+    line = np.outer(np.linspace(0, 1, 6), [1.0, 2.0, 0.5]) + [0, 0, 8]
+    assert not hu.epnp(line, np.zeros((6, 2)), K, np.zeros(5))[0]       # collinear points
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_georef_packing_and_tlw_initialisation(pkg, ftype):
+    """PTZRayOptimizer with annotations, stages before the device solve: SetInitTransLocalToWorld (ptzray_optimizer.cc:562-633)
+    from the first annotated candidate view, 2D-3D blocks in camera order (:894-917)."""
+    import host_util as hu
+    sc = pkg.synth.add_annotations(pkg.synth.make_scene(2, 20, 100, factor_type=ftype))
+    kps, plist = hu.scene_to_features_matches(sc)
+    ann = (sc.obs3d["cam"], sc.obs3d["uv"], sc.obs3d["xyz"])
+    # georeferencing runs on cameras already refined by the bundle adjustment (run_ptz_ba.cc:131-155): use the true ones here
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_gt, ftype=ftype, annotations=ann, on_device=False)
+    assert not ok and pk["tlw_ok"]
+    Rg, Ri = _rodrigues(sc.tlw_gt[:3]), _rodrigues(pk["tlw_init"][:3])
+    assert np.degrees(np.arccos(np.clip((np.trace(Ri @ Rg.T) - 1) / 2, -1, 1))) < 1.0
+    assert np.abs(-Ri.T @ pk["tlw_init"][3:] - np.array([3.0, -45.0, 15.0])).max() < 2.0
+    n3 = len(sc.obs3d["cam"])
+    assert pk["n_obs3d"] == n3
+    # annotations that project behind the camera fail the gates (:581-586): T_l_w stays zero, the solve still proceeds
+    # mismatched annotations (pixels shuffled against the points): the 300 px gate (:602-605) rejects every view
+    far = (sc.obs3d["cam"], sc.obs3d["uv"][::-1].copy(), sc.obs3d["xyz"])
+    ok2, _, _, _, pk2 = hu.ptzray_solve(kps, plist, sc.cam_gt, ftype=ftype, annotations=far, on_device=False)
+    assert not ok2 and not pk2["tlw_ok"] and np.array_equal(pk2["tlw_init"], np.zeros(6))
+    # candidate subset without any annotated view: no PnP, T_l_w = 0
+    cands = [i for i in range(sc.n_cam) if i not in set(sc.obs3d["cam"].tolist())]
+    ok3, _, _, _, pk3 = hu.ptzray_solve(kps, plist, sc.cam_gt, cand_ids=cands, ftype=ftype, annotations=ann, on_device=False)
+    assert not ok3 and not pk3["tlw_ok"] and np.array_equal(pk3["tlw_init"], np.zeros(6))

@@ -350,6 +350,42 @@ def test_ba_georef_parity(pkg, orc, ftype):
     assert np.abs(Cw - np.array([3.0, -45.0, 15.0])).max() < 1.0
 
 
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_cpp_ptzray_optimizer_georeferencing(pkg, orc, ftype):
+    """PTZRayOptimizer's annotation constructor (ptzray_optimizer.h:114-116): EPnP initialisation of T_l_w with its gates
+    (ptzray_optimizer.cc:562-633), 2D-3D residual blocks, read-back composed with T_l_w (:729-754).  The oracle is run on the
+    packed problem from the same initial T_l_w; cameras are compared in the world frame."""
+    import host_util as hu
+    from types import SimpleNamespace
+    sc = _georef_scene(pkg, ftype)
+    kps, plist = hu.scene_to_features_matches(sc)
+    ann = (sc.obs3d["cam"], sc.obs3d["uv"], sc.obs3d["xyz"])
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=ftype, annotations=ann)
+    assert ok and pk["tlw_ok"] and summ["termination_type"] == 0
+    # the PnP initial value is close to the truth (rig 15 m above the pitch, tens of metres away)
+    Rg, Ri = orc.rodrigues(sc.tlw_gt[:3]), orc.rodrigues(pk["tlw_init"][:3])
+    assert np.degrees(np.arccos(np.clip((np.trace(Ri @ Rg.T) - 1) / 2, -1, 1))) < 3.0
+    ns = SimpleNamespace(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"],
+                         n_cam=sc.n_cam, n_ray=len(pk["ray_weight"]), n_obs=len(pk["obs_cam"]), factor_type=ftype,
+                         cam_init=sc.cam_init, ray_init=pk["ray"])
+    ns.ray_init = orc.pix2ray(ns, sc.cam_init)
+    ocam, oray, otlw, osumm, _ = orc.ba_solve(ns, obs3d=sc.obs3d, tlw0=pk["tlw_init"], jacobian_mode=orc.JAC_NUMERIC, num_threads=4)
+    assert osumm["termination_type"] == 0 and summ["num_iterations"] == osumm["num_iterations"]
+    assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-8
+    oRlw = orc.rodrigues(otlw[:3])
+    for i in range(sc.n_cam):
+        Ro = orc.rodrigues(ocam[i, 4:7])
+        assert np.abs(orc.rodrigues(cam[i, 4:7]) - Ro @ oRlw).max() < 1e-6          # R_i_w = R_i_l R_l_w
+        assert np.abs(cam[i, 7:10] - (Ro @ otlw[3:] + ocam[i, 7:10])).max() < 1e-4    # t_i_w = R_i_l t_l_w + t_i_l (metres)
+        # every camera sits at the rig centre in world coordinates
+        assert np.abs(-orc.rodrigues(cam[i, 4:7]).T @ cam[i, 7:10] - np.array([3.0, -45.0, 15.0])).max() < 1.0
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6
+    assert np.array_equal(cam[:, 1], cam[:, 0])  # fy := fx on read-back although fy was fitted (:705-706)
+    # refined T_l_w and the reported 2D-3D error (CalReprojError2d3d, :1030-1072)
+    assert np.abs(-orc.rodrigues(pk["tlw"][:3]).T @ pk["tlw"][3:] - (-oRlw.T @ otlw[3:])).max() < 1e-5
+    assert 0.1 < err[2] < 2.0 and 0.1 < err[1] < 2.0
+
+
 def test_ba_mixed_batch_with_and_without_annotations(pkg):
     """A batch where only some scenes carry annotations: every scene gets the same result as when solved alone."""
     a = _georef_scene(pkg, 0, seed=2)
