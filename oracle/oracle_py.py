@@ -76,7 +76,8 @@ def build(force: bool = False) -> str:
     not using it."""
     so = os.path.join(_HERE, "libptz_oracle.so")
     src = os.path.join(_HERE, "ptz_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "std_sort_rank.cc")))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["make", "-C", _HERE, "libptz_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/src/core/union_find.h"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -289,6 +290,14 @@ def tracks_build(pairs, min_track_length=4):
     for ptr_ in (tid, tptr, eimg, efeat):
         lib().orc_free(ptr_)
     return out
+
+
+def rank_by_score(score):
+    """Image ids with a positive score, best first, ordered by the toolchain's std::sort (oracle/std_sort_rank.cc)."""
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    out = np.zeros(len(score), dtype=np.int64)
+    m = lib().orc_rank_by_score(len(score), _p(score), _p(out))
+    return [int(x) for x in out[:m]]
 
 
 def ref_tracks_available() -> bool:

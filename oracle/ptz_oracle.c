@@ -176,7 +176,7 @@ void orc_rodrigues_inv(const double Rin[9], double rv[3])
       t = (R[4] + 1) * 0.5;
       ry = sqrt(t > 0 ? t : 0.) * (R[1] < 0 ? -1. : 1.);
       t = (R[8] + 1) * 0.5;
-      rz = sqrt(t > 0 ? t : 0.) * ((R[2] < 0) != (R[5] < 0) ? -1. : 1.);
+      rz = sqrt(t > 0 ? t : 0.) * (R[2] < 0 ? -1. : 1.);
       if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
       double n = sqrt(rx * rx + ry * ry + rz * rz);
       theta /= n;

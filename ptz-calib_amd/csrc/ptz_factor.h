@@ -70,7 +70,7 @@ PTZ_HD void rodrigues_inv(const double R[9], double r[3])
       double t;
       t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0.);
       t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0.) * (R[1] < 0 ? -1. : 1.);
-      t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0.) * ((R[2] < 0) != (R[5] < 0) ? -1. : 1.);
+      t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0.) * (R[2] < 0 ? -1. : 1.);
       if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
       theta /= sqrt(rx * rx + ry * ry + rz * rz);
       rx *= theta; ry *= theta; rz *= theta;

@@ -5,6 +5,7 @@
 
 #include "epnp.h"
 #include "krt_optimizer.h"
+#include "ptz_incremental_optimizer.h"
 #include "ptzray_optimizer.h"
 
 using namespace ptzcalib;
@@ -49,6 +50,24 @@ template <typename T> T* Dup(const std::vector<T>& v)
 extern "C" {
 
 void ptzh_free(void* p) { free(p); }
+
+// Camera::FromVector -> Camera::ToVector round trip (cv::Rodrigues both ways) for the tests
+void ptzh_camera_roundtrip(const double* in15, double* out15, double* R9)
+{
+  Camera c;
+  c.FromVector(std::vector<double>(in15, in15 + 15));
+  const std::vector<double> v = c.ToVector();
+  memcpy(out15, v.data(), sizeof(double) * 15);
+  if (R9) memcpy(R9, c.R().data(), sizeof(double) * 9);
+}
+// rotation vector of an arbitrary (possibly scaled, noisy) 3x3 matrix, as cv::Rodrigues(matrix) gives it
+void ptzh_rodrigues_inv(const double* R9, double* rvec)
+{
+  Mat33 R;
+  for (int k = 0; k < 9; ++k) R[k] = R9[k];
+  const Vec3 r = RodriguesInv(R);
+  rvec[0] = r[0]; rvec[1] = r[1]; rvec[2] = r[2];
+}
 
 // TracksBuilder Build/Filter/ExportToSTL; same output convention as the oracle's orc_tracks_build
 int32_t ptzh_tracks_build(int32_t n_pairs, const int64_t* src, const int64_t* dst, const int64_t* match_ptr, const int32_t* q,
@@ -182,6 +201,45 @@ int32_t ptzh_epnp(int32_t n, const double* xyz, const float* uv, const double* K
   for (int k = 0; k < 9; ++k) R9[k] = R[k];
   for (int k = 0; k < 3; ++k) t3[k] = tv[k];
   return 1;
+}
+
+// PtzIncrementalOptimizer::Solve.  Pairs are the non-empty cells of the reference's N x N match table in table order;
+// H [9*n_pairs] row-major, h_valid [n_pairs] (0 = cv::Mat::empty()), confidence [n_pairs].  cam15 in/out.
+// registered [n_img] out (0/1).  events: up to max_events rows of (kind, a, b, success); returns the number of events;
+// *solved = Solve's return value.
+int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, const int32_t* img_wh, int32_t n_pairs,
+                               const int64_t* src, const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t,
+                               const double* H, const int32_t* h_valid, const double* confidence, double* cam15,
+                               const int64_t* seeds, int32_t n_seeds, int32_t max_iter, int32_t* registered, int64_t* events,
+                               int32_t max_events, int64_t* lm_iterations, int32_t* solved)
+{
+  std::vector<ImageFeatures> feats;
+  std::vector<MatchesInfo> mis;
+  std::vector<Camera> cams;
+  BuildInputs(n_img, kp_ptr, kp_xy, img_wh, n_pairs, src, dst, match_ptr, q, t, cam15, feats, mis, cams);
+  for (int p = 0; p < n_pairs; ++p) {
+    for (int k = 0; k < 9; ++k) mis[p].H[k] = H[9 * p + k];
+    mis[p].H_empty = h_valid[p] == 0;
+    mis[p].confidence = confidence[p];
+  }
+  PtzIncrementalOptimizer opt(feats, mis, cams, max_iter);
+  if (n_seeds > 0) opt.SetSeedImageId(std::vector<long>(seeds, seeds + n_seeds));
+  std::unordered_set<long> reg;
+  const bool ok = opt.Solve(cams, reg);
+  const auto& ev = opt.events();
+  const int32_t ne = static_cast<int32_t>(ev.size()) < max_events ? static_cast<int32_t>(ev.size()) : max_events;
+  for (int32_t e = 0; e < ne; ++e) {
+    events[4 * e] = ev[e].kind; events[4 * e + 1] = ev[e].a; events[4 * e + 2] = ev[e].b; events[4 * e + 3] = ev[e].success ? 1 : 0;
+  }
+  if (lm_iterations) *lm_iterations = opt.lm_iterations();
+  if (solved) *solved = ok ? 1 : 0;
+  if (!ok) return ne;
+  for (int i = 0; i < n_img; ++i) {
+    registered[i] = reg.count(i) ? 1 : 0;
+    const std::vector<double> v = cams[i].ToVector();
+    memcpy(cam15 + 15 * i, v.data(), sizeof(double) * 15);
+  }
+  return ne;
 }
 
 // KRTOptimizer through the C++ class: one query.  cam_cur15 in (initial, world) / out (refined, world).

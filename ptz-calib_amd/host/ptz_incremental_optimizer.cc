@@ -1,0 +1,299 @@
+#include "ptz_incremental_optimizer.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "../../include/ptz_calib_amd.h"
+#include "ptzray_optimizer.h"
+
+namespace ptzcalib {
+
+long PtzIncrementalOptimizer::kMaxNumImages = 100000;
+float PtzIncrementalOptimizer::kBaGlobalImagesRatio = 1.1f;
+
+namespace {
+// Images with a positive score, best first.  std::sort (not stable_sort) with the reference's comparator, so that ties
+// fall the way they do there under the same standard library (ptz_incremental_optimizer.cc:192-203).
+std::vector<long> RankByScore(const std::vector<float>& score)
+{
+  std::vector<long> order(score.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) -> bool { return score[a] > score[b]; });
+  std::vector<long> out;
+  for (long id : order) {
+    if (score[id] <= 0.0f) break;
+    out.push_back(id);
+  }
+  return out;
+}
+
+// initial guess of an uncalibrated view: f = 1.2 max(w, h), principal point at the image centre (:322-329)
+void SetDefaultIntrinsics(Camera& cam, const Size& size)
+{
+  constexpr double ratio = 1.2;
+  const double focal = ratio * std::max(size.width, size.height);
+  cam.K()[0] = cam.K()[4] = focal;
+  cam.K()[2] = 0.5 * size.width;
+  cam.K()[5] = 0.5 * size.height;
+}
+
+// rotation of view j predicted from registered view i through the pair homography: R_j = K_j^-1 H_ji K_i R_i (:391-394).
+// The product is a rotation only up to scale and noise; it is orthonormalised when it is converted to a rotation
+// vector (RodriguesInv), as cv::Rodrigues does in the reference.
+Mat33 RotationFromHomography(const Mat33& K_j, const Mat33& H_j_i, const Camera& cam_i)
+{
+  return Mul(Mul(Mul(Inverse(K_j), H_j_i), cam_i.K()), cam_i.R());
+}
+}  // namespace
+
+PtzIncrementalOptimizer::PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                                                 const std::vector<Camera>& cameras, int max_iter)
+    : cameras_(cameras), features_(features), matches_info_(matches_info), max_iter_(max_iter)
+{
+}
+
+PtzIncrementalOptimizer::PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                                                 const std::vector<Camera>& cameras, const std::vector<std::string>& names, int max_iter)
+    : cameras_(cameras), features_(features), matches_info_(matches_info), names_(names), max_iter_(max_iter)
+{
+}
+
+void PtzIncrementalOptimizer::SetSeedImageId(const std::vector<long>& image_ids) { seed_image_ids_ = image_ids; }
+
+bool PtzIncrementalOptimizer::CheckValid() const
+{  // :140-146
+  return !(features_.empty() || features_.size() != cameras_.size() || max_iter_ <= 0);
+}
+
+long PtzIncrementalOptimizer::ImagePairToPairId(long image_id1, long image_id2) const
+{
+  return image_id1 < image_id2 ? image_id1 * kMaxNumImages + image_id2 : image_id2 * kMaxNumImages + image_id1;
+}
+
+// Main loop (:39-131).
+bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered_set<long>& reg_image_ids)
+{
+  if (!CheckValid()) return false;
+  if (!tracks_) tracks_ = PTZRayOptimizer::BuildTracks(matches_info_);
+
+  const int kInitNumTrials = 50;
+  for (int num_trials = 0; num_trials < kInitNumTrials; ++num_trials) {
+    long image_id1, image_id2;
+    if (!FindInitialImagePair(image_id1, image_id2)) return false;
+    const bool seeded = RegisterInitialImagePair(image_id1, image_id2);
+    events_.push_back({Event::kInitPair, image_id1, image_id2, seeded});
+    if (!seeded) continue;
+
+    AdjustGlobalBundle();
+    size_t ba_prev_num_reg_images = NumRegImages();
+
+    bool reg_next_success = true;
+    while (reg_next_success) {
+      reg_next_success = false;
+      const std::vector<long> next_image_ids = FindNextImages();
+      if (next_image_ids.empty()) break;
+
+      for (size_t reg_trial = 0; reg_trial < next_image_ids.size(); ++reg_trial) {
+        const long image_id = next_image_ids[reg_trial];
+        reg_next_success = RegisterNextImage(image_id);
+        if (reg_next_success && static_cast<float>(NumRegImages()) >= kBaGlobalImagesRatio * static_cast<float>(ba_prev_num_reg_images)) {
+          if (AdjustGlobalBundle()) {
+            ba_prev_num_reg_images = NumRegImages();
+            break;  // re-rank the remaining images against the refined model
+          }
+          reg_image_ids_.erase(image_id);  // only the newest image is withdrawn, as in the reference (:99)
+          reg_next_success = false;
+        }
+        if (!reg_next_success) {
+          // a seed that cannot grow to three images within 30 attempts is abandoned (:105-113); the outer loop then
+          // runs the closing bundle adjustment and returns -- the reference does not go back for another seed either
+          const size_t kMinNumInitialRegTrials = 30;
+          const size_t kMinModelSize = 3;
+          if (reg_trial >= kMinNumInitialRegTrials && NumRegImages() < kMinModelSize) break;
+        }
+      }
+    }
+
+    AdjustGlobalBundle();
+    reg_image_ids = reg_image_ids_;
+    cameras = cameras_;
+    return true;
+  }
+  return false;  // 50 seeds failed (the reference falls off the end of the function here)
+}
+
+bool PtzIncrementalOptimizer::FindInitialImagePair(long& image_id1, long& image_id2)
+{  // :148-176
+  const std::vector<long> firsts = seed_image_ids_.empty() ? FindFirstInitialImage() : seed_image_ids_;
+  for (long first : firsts) {
+    image_id1 = first;
+    for (long second : FindSecondInitialImage(first)) {
+      image_id2 = second;
+      const long pair_id = ImagePairToPairId(first, second);
+      if (init_image_pairs_.count(pair_id) > 0) continue;
+      init_image_pairs_.insert(pair_id);
+      return true;
+    }
+  }
+  image_id1 = image_id2 = std::numeric_limits<long>::max();
+  return false;
+}
+
+std::vector<long> PtzIncrementalOptimizer::FindFirstInitialImage() const
+{  // :178-204: total matching confidence of every image (float accumulation)
+  std::vector<float> score(features_.size(), 0.0f);
+  for (const MatchesInfo& mi : matches_info_) {
+    const float confidence = static_cast<float>(mi.confidence);
+    score[mi.src_img_idx] += confidence;
+    score[mi.dst_img_idx] += confidence;
+  }
+  return RankByScore(score);
+}
+
+std::vector<long> PtzIncrementalOptimizer::FindSecondInitialImage(long image_id1) const
+{  // :206-244: partners of image_id1 with a mean match displacement of at least 50 px
+  std::vector<float> score(features_.size(), 0.0f);
+  const float kMinPixelDiff = 50;
+  for (const MatchesInfo& mi : matches_info_) {
+    const long src = mi.src_img_idx, dst = mi.dst_img_idx;
+    if (mi.matches.empty()) continue;
+    const bool is_src = image_id1 == src, is_dst = image_id1 == dst;
+    if (is_src == is_dst) continue;  // unrelated pair, or the image paired with itself
+    if (CalPixelDiff(src, dst, mi.matches) < kMinPixelDiff) continue;
+    score[is_src ? dst : src] += static_cast<float>(mi.confidence);
+  }
+  return RankByScore(score);
+}
+
+std::vector<long> PtzIncrementalOptimizer::FindNextImages() const
+{  // :246-296: unregistered images next to the model, by total confidence towards registered images
+  std::vector<float> score(features_.size(), 0.0f);
+  const size_t kMaxRegTrials = 4;
+  auto exhausted = [&](long id) {
+    const auto it = num_reg_trials_.find(id);
+    return it != num_reg_trials_.end() && it->second > kMaxRegTrials;
+  };
+  for (const MatchesInfo& mi : matches_info_) {
+    const long src = mi.src_img_idx, dst = mi.dst_img_idx;
+    if (src == dst || mi.H_empty) continue;
+    if (exhausted(src) || exhausted(dst)) continue;
+    const bool src_in = IsRegistered(src), dst_in = IsRegistered(dst);
+    if (src_in == dst_in) continue;  // both registered, or neither
+    score[src_in ? dst : src] += static_cast<float>(mi.confidence);
+  }
+  return RankByScore(score);
+}
+
+float PtzIncrementalOptimizer::CalPixelDiff(long image_id1, long image_id2, const std::vector<DMatch>& matches) const
+{  // :298-312: float accumulator, each distance taken in double (cv::norm of a Point2f)
+  float total = 0.0f;
+  for (const DMatch& m : matches) {
+    const Point2f a = features_[image_id1].keypoints[m.queryIdx].pt, b = features_[image_id2].keypoints[m.trainIdx].pt;
+    const float dx = a.x - b.x, dy = a.y - b.y;
+    total += std::sqrt(static_cast<double>(dx) * dx + static_cast<double>(dy) * dy);
+  }
+  return total * 1.0f / matches.size();
+}
+
+void PtzIncrementalOptimizer::SetInitialImagePairParameters(long image_id1, long image_id2)
+{  // :322-352
+  SetDefaultIntrinsics(cameras_[image_id1], features_[image_id1].img_size);
+  cameras_[image_id1].R() = Eye3();
+  SetDefaultIntrinsics(cameras_[image_id2], features_[image_id2].img_size);
+  for (const MatchesInfo& mi : matches_info_) {
+    // only the table entry stored in this direction is used (:344); a pair listed the other way round leaves R_2 as it was
+    if (mi.src_img_idx == image_id1 && mi.dst_img_idx == image_id2) {
+      cameras_[image_id2].R() = RotationFromHomography(cameras_[image_id2].K(), mi.H, cameras_[image_id1]);
+      break;
+    }
+  }
+}
+
+bool PtzIncrementalOptimizer::RunBundle(const std::unordered_set<long>& ids)
+{
+  PTZRayOptimizer optimizer(PTZRayOptimizer::Borrow{}, features_, matches_info_, cameras_, ids, max_iter_, PTZRay);
+  optimizer.UseTracks(tracks_);
+  optimizer.SetDevice(device_id_);
+  const bool ok = optimizer.Solve(cameras_);
+  lm_iterations_ += optimizer.summary().num_iterations;
+  events_.push_back({Event::kGlobalBA, static_cast<long>(ids.size()), optimizer.summary().num_iterations, ok});
+  return ok;
+}
+
+bool PtzIncrementalOptimizer::RegisterInitialImagePair(long image_id1, long image_id2)
+{  // :354-375
+  num_reg_trials_[image_id1] += 1;
+  num_reg_trials_[image_id2] += 1;
+  init_image_pairs_.insert(ImagePairToPairId(image_id1, image_id2));
+  SetInitialImagePairParameters(image_id1, image_id2);
+  const bool ok = RunBundle({image_id1, image_id2});
+  if (ok) {
+    reg_image_ids_.insert(image_id1);
+    reg_image_ids_.insert(image_id2);
+  }
+  return ok;
+}
+
+bool PtzIncrementalOptimizer::AdjustGlobalBundle() { return RunBundle(reg_image_ids_); }  // :420-440
+
+bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
+{  // :377-418
+  num_reg_trials_[image_id] += 1;
+  // every table entry (registered i -> image_id) with a homography is one attempt
+  std::vector<const MatchesInfo*> attempts;
+  for (const MatchesInfo& mi : matches_info_)
+    if (!mi.H_empty && IsRegistered(mi.src_img_idx) && mi.dst_img_idx == image_id) attempts.push_back(&mi);
+  if (attempts.empty()) {
+    events_.push_back({Event::kRegister, image_id, -1, false});
+    return false;
+  }
+  const size_t n = attempts.size();
+  std::vector<int64_t> match_ptr(n + 1, 0);
+  std::vector<float> uv_ref, uv_cur;
+  std::vector<double> cam_ref(15 * n), cam_cur(15 * n);
+  std::vector<Camera> init(n);
+  Camera& cam_j = cameras_[image_id];
+  for (size_t q = 0; q < n; ++q) {
+    const MatchesInfo& mi = *attempts[q];
+    const Camera& cam_i = cameras_[mi.src_img_idx];
+    init[q] = Camera(cam_i.K(), RotationFromHomography(cam_i.K(), mi.H, cam_i), cam_j.t(), cam_j.dist());  // K_j := K_i (:392)
+    const std::vector<double> vr = cam_i.ToVector(), vc = init[q].ToVector();
+    std::copy(vr.begin(), vr.end(), cam_ref.begin() + 15 * q);
+    std::copy(vc.begin(), vc.end(), cam_cur.begin() + 15 * q);
+    for (const DMatch& m : mi.matches) {
+      const Point2f a = features_[mi.src_img_idx].keypoints[m.queryIdx].pt, b = features_[image_id].keypoints[m.trainIdx].pt;
+      uv_ref.push_back(a.x); uv_ref.push_back(a.y);
+      uv_cur.push_back(b.x); uv_cur.push_back(b.y);
+    }
+    match_ptr[q + 1] = static_cast<int64_t>(uv_ref.size() / 2);
+  }
+  ptz_lm_options opt;
+  ptz_lm_options_default(&opt);
+  opt.max_num_iterations = 100;  // :396
+  opt.device_id = device_id_;
+  std::vector<ptz_lm_summary> summaries(n);
+  std::vector<int32_t> accepted(n, 0);
+  const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
+                                         cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
+                                         accepted.data(), nullptr);
+  if (rc == PTZ_OK)
+    for (size_t q = 0; q < n; ++q) {
+      if (!accepted[q]) continue;
+      Camera refined;
+      refined.FromVector(std::vector<double>(cam_cur.begin() + 15 * q, cam_cur.begin() + 15 * (q + 1)));
+      cam_j.K() = refined.K();  // t and dist are not taken over (:406-407)
+      cam_j.R() = refined.R();
+      reg_image_ids_.insert(image_id);
+      events_.push_back({Event::kRegister, image_id, attempts[q]->src_img_idx, true});
+      return true;
+    }
+  // all attempts failed: the camera keeps the initial guess of the last attempt (:392-394 run before every solve)
+  cam_j.K() = init[n - 1].K();
+  cam_j.R() = init[n - 1].R();
+  events_.push_back({Event::kRegister, image_id, -1, false});
+  return false;
+}
+
+}  // namespace ptzcalib

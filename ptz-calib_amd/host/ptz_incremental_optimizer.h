@@ -1,0 +1,80 @@
+// ptz_incremental_optimizer.h -- PTZ-IBA orchestration with the reference's public interface
+// (src/core/ptz_incremental_optimizer.h:21-44): seed pair, view-by-view registration, global bundle adjustment
+// whenever the model grew by kBaGlobalImagesRatio.  Every solve runs on the MI355X library:
+//  * RegisterNextImage gathers ALL (registered reference -> image) attempts of one image into a single
+//    ptz_krt_solve_batch launch and takes the first accepted one in table order, which is exactly what the
+//    reference's sequential loop with early exit returns (ptz_incremental_optimizer.cc:383-415) because the
+//    attempts do not depend on each other;
+//  * the feature tracks are built once per match table and shared by all bundle adjustments (the reference rebuilds
+//    them from the N^2 table inside every PTZRayOptimizer::Solve, ptzray_optimizer.cc:537-552), and the feature /
+//    match tables are borrowed instead of deep-copied.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "tracks.h"
+#include "types.h"
+
+namespace ptzcalib {
+
+class PtzIncrementalOptimizer {
+ public:
+  PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                          const std::vector<Camera>& cameras, int max_iter);
+  PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                          const std::vector<Camera>& cameras, const std::vector<std::string>& names, int max_iter);
+
+  bool Solve(std::vector<Camera>& cameras, std::unordered_set<long>& reg_image_ids);
+  void SetSeedImageId(const std::vector<long>& image_ids);
+
+  static long kMaxNumImages;
+  static float kBaGlobalImagesRatio;
+
+  // extras (not in the reference): the sequence of decisions, for tests and for throughput accounting
+  struct Event {
+    enum Kind { kInitPair = 0, kRegister = 1, kGlobalBA = 2 };
+    int kind;
+    long a, b;        // kInitPair: the two images; kRegister: image, reference it was registered against (-1 = none);
+                      // kGlobalBA: number of registered images, LM iterations
+    bool success;
+  };
+  const std::vector<Event>& events() const { return events_; }
+  long lm_iterations() const { return lm_iterations_; }  // summed over all bundle adjustments
+  void SetDevice(int device_id) { device_id_ = device_id; }
+
+ private:
+  bool CheckValid() const;
+  bool FindInitialImagePair(long& image_id1, long& image_id2);
+  std::vector<long> FindFirstInitialImage() const;
+  std::vector<long> FindSecondInitialImage(long image_id1) const;
+  std::vector<long> FindNextImages() const;
+  float CalPixelDiff(long image_id1, long image_id2, const std::vector<DMatch>& matches) const;
+  bool RegisterInitialImagePair(long image_id1, long image_id2);
+  bool RegisterNextImage(long image_id);
+  void SetInitialImagePairParameters(long image_id1, long image_id2);
+  bool AdjustGlobalBundle();
+  bool RunBundle(const std::unordered_set<long>& ids);
+  long ImagePairToPairId(long image_id1, long image_id2) const;
+  size_t NumRegImages() const { return reg_image_ids_.size(); }
+  bool IsRegistered(long id) const { return reg_image_ids_.count(id) != 0; }
+
+  std::vector<Camera> cameras_;
+  std::vector<ImageFeatures> features_;
+  std::vector<MatchesInfo> matches_info_;
+  std::vector<std::string> names_;
+  int max_iter_;
+  int device_id_ = 0;
+  std::unordered_set<long> init_image_pairs_;             // every pair is tried once as a seed
+  std::unordered_map<long, size_t> num_reg_trials_;       // registration attempts per image
+  std::unordered_set<long> reg_image_ids_;
+  std::vector<long> seed_image_ids_;
+  std::shared_ptr<const Tracks> tracks_;
+  std::vector<Event> events_;
+  long lm_iterations_ = 0;
+};
+
+}  // namespace ptzcalib

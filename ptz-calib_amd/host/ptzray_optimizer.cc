@@ -12,8 +12,8 @@ PTZRayOptimizer::PTZRayOptimizer(const std::vector<ImageFeatures>& features, con
                                  const std::vector<Camera>& cameras, const std::vector<std::vector<Point2f>>& pixels,
                                  const std::vector<std::vector<Point3d>>& pts3d, const std::unordered_set<long>& cam_ids,
                                  int max_iter, FACTOR_TYPE type)
-    : cameras_(cameras), features_(features), matches_info_(matches_info), pixels_(pixels), pts3d_(pts3d),
-      num_cams_(cameras.size()), type_(type), max_iter_(max_iter)
+    : cameras_(cameras), features_own_(features), matches_info_own_(matches_info), features_(features_own_),
+      matches_info_(matches_info_own_), pixels_(pixels), pts3d_(pts3d), num_cams_(cameras.size()), type_(type), max_iter_(max_iter)
 {
   // empty cam_ids => every camera is a candidate (ptzray_optimizer.cc:418-425)
   if (cam_ids.empty()) for (size_t i = 0; i < cameras_.size(); ++i) cam_ids_.insert(static_cast<long>(i));
@@ -27,6 +27,27 @@ PTZRayOptimizer::PTZRayOptimizer(const std::vector<ImageFeatures>& features, con
                                  FACTOR_TYPE type)
     : PTZRayOptimizer(features, matches_info, cameras, {}, {}, cam_ids, max_iter, type)
 {
+}
+
+PTZRayOptimizer::PTZRayOptimizer(Borrow, const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                                 const std::vector<Camera>& cameras, const std::unordered_set<long>& cam_ids, int max_iter,
+                                 FACTOR_TYPE type)
+    : cameras_(cameras), features_(features), matches_info_(matches_info), num_cams_(cameras.size()), type_(type), max_iter_(max_iter)
+{
+  if (cam_ids.empty()) for (size_t i = 0; i < cameras_.size(); ++i) cam_ids_.insert(static_cast<long>(i));
+  else cam_ids_ = cam_ids;
+  shared_ic_ids_.resize(cameras_.size());
+  std::iota(shared_ic_ids_.begin(), shared_ic_ids_.end(), 0);
+}
+
+std::shared_ptr<const Tracks> PTZRayOptimizer::BuildTracks(const std::vector<MatchesInfo>& matches_info)
+{
+  auto tracks = std::make_shared<Tracks>();
+  TracksBuilder builder;
+  builder.Build(matches_info);
+  builder.Filter(4);
+  builder.ExportToSTL(*tracks);
+  return tracks;
 }
 
 void PTZRayOptimizer::SetSharedIntrinsics(const std::vector<long>& shared_ic_ids)
@@ -56,6 +77,10 @@ bool PTZRayOptimizer::CheckValid() const
 
 void PTZRayOptimizer::FindTracks()
 {  // ptzray_optimizer.cc:537-552
+  if (shared_tracks_) {
+    Length(*shared_tracks_, track_len_, max_track_len_, min_track_len_);
+    return;
+  }
   TracksBuilder builder;
   builder.Build(matches_info_);
   builder.Filter(4);
@@ -128,7 +153,7 @@ void PTZRayOptimizer::Pack()
     Rinv[c] = Inverse(cameras_[p.cam_image[c]].R());
     Kinv[c] = Inverse(cameras_[p.cam_image[c]].K());
   }
-  for (const auto& te : tracks_) {  // std::map: ascending track id
+  for (const auto& te : tracks()) {  // std::map: ascending track id
     const Track& track = te.second;
     Vec3 acc = {0, 0, 0};
     size_t n_cand = 0;
@@ -301,7 +326,7 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
   for (size_t j = 0; j < p.ray_track.size(); ++j) {
     const Vec3 rl = Mul(R_w_l, Vec3{ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]});
     const Vec3 ray_w = {rl[0] - Rtt[0], rl[1] - Rtt[1], rl[2] - Rtt[2]};  // R_w_l ray_l + t_w_l (:746-754)
-    for (const auto& kv : tracks_.at(p.ray_track[j]))
+    for (const auto& kv : tracks().at(p.ray_track[j]))
       rays[kv.first].emplace_back(p.ray_track[j], ray_w, features_[kv.first].keypoints[kv.second].pt);
   }
   p.cam = cam;

@@ -4,6 +4,7 @@
 // packs the problem into flat arrays and calls the MI355X library through its C-ABI (ptz_ba_solve).
 #pragma once
 
+#include <memory>
 #include <unordered_set>
 #include <vector>
 
@@ -52,17 +53,30 @@ class PTZRayOptimizer {
   const ptz_lm_summary& summary() const { return summary_; }
   const std::array<double, 6>& initial_tlw() const { return tlw_init_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
+  // The tracks depend on the match table only, not on the candidate set: a caller that solves many candidate subsets of
+  // one match table (PtzIncrementalOptimizer) builds them once and shares them instead of repeating FindTracks().
+  void UseTracks(std::shared_ptr<const Tracks> tracks) { shared_tracks_ = std::move(tracks); }
+  static std::shared_ptr<const Tracks> BuildTracks(const std::vector<MatchesInfo>& matches_info);
+  // Same as the 2D-2D constructor but WITHOUT the deep copies of features / matches (ptzray_optimizer.h:145-149): the
+  // caller keeps both alive until Solve returns.
+  struct Borrow {};
+  PTZRayOptimizer(Borrow, const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
+                  const std::vector<Camera>& cameras, const std::unordered_set<long>& cam_ids, int max_iter, FACTOR_TYPE type);
 
  private:
   bool CheckValid() const;
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
+  const Tracks& tracks() const { return shared_tracks_ ? *shared_tracks_ : tracks_; }
   bool SetInitTransLocalToWorld();
 
   std::vector<Camera> cameras_;
-  std::vector<ImageFeatures> features_;
-  std::vector<MatchesInfo> matches_info_;
+  std::vector<ImageFeatures> features_own_;
+  std::vector<MatchesInfo> matches_info_own_;
+  const std::vector<ImageFeatures>& features_;
+  const std::vector<MatchesInfo>& matches_info_;
+  std::shared_ptr<const Tracks> shared_tracks_;
   std::vector<std::vector<Point2f>> pixels_;
   std::vector<std::vector<Point3d>> pts3d_;
   size_t num_cams_ = 0;

@@ -1,5 +1,7 @@
 #include "types.h"
 
+#include "small_linalg.h"
+
 #include <cfloat>
 #include <cmath>
 
@@ -37,8 +39,20 @@ Mat33 Rodrigues(const Vec3& r)
           c1 * x * z - s * y, c1 * y * z + s * x, c + c1 * z * z};
 }
 
-Vec3 RodriguesInv(const Mat33& R)
+Vec3 RodriguesInv(const Mat33& R_in)
 {
+  // cv::Rodrigues (matrix -> vector) first replaces R by U V^T of its SVD, which is what turns the scaled
+  // near-rotation K_j^-1 H K_i of the registration step (ptz_incremental_optimizer.cc:391-394) into a rotation.
+  Mat33 R = R_in;
+  {
+    std::vector<double> U, s, V;
+    JacobiSVD(3, 3, std::vector<double>(R_in.begin(), R_in.end()), U, s, V);
+    if (s[2] > 0) {
+      Mat33 Um, Vm;
+      for (int i = 0; i < 9; ++i) { Um[i] = U[i]; Vm[i] = V[i]; }
+      R = Mul(Um, Transpose(Vm));
+    }
+  }
   double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
   const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
   double c = (R[0] + R[4] + R[8] - 1) * 0.5;
@@ -49,7 +63,7 @@ Vec3 RodriguesInv(const Mat33& R)
     double t;
     t = (R[0] + 1) * 0.5; rx = std::sqrt(t > 0 ? t : 0.);
     t = (R[4] + 1) * 0.5; ry = std::sqrt(t > 0 ? t : 0.) * (R[1] < 0 ? -1. : 1.);
-    t = (R[8] + 1) * 0.5; rz = std::sqrt(t > 0 ? t : 0.) * ((R[2] < 0) != (R[5] < 0) ? -1. : 1.);
+    t = (R[8] + 1) * 0.5; rz = std::sqrt(t > 0 ? t : 0.) * (R[2] < 0 ? -1. : 1.);
     if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
     theta /= std::sqrt(rx * rx + ry * ry + rz * rz);
     return {rx * theta, ry * theta, rz * theta};

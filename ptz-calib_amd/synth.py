@@ -77,7 +77,9 @@ def rodrigues_inv(R: np.ndarray) -> np.ndarray:
             return np.zeros(3)
         t = np.sqrt(np.maximum((np.diag(R) + 1) * 0.5, 0.0))
         t[1] *= -1.0 if R[0, 1] < 0 else 1.0
-        t[2] *= -1.0 if (R[0, 2] < 0) != (R[1, 2] < 0) else 1.0
+        t[2] *= -1.0 if R[0, 2] < 0 else 1.0
+        if abs(t[0]) < abs(t[1]) and abs(t[0]) < abs(t[2]) and (R[1, 2] > 0) != (t[1] * t[2] > 0):
+            t[2] = -t[2]
         return t * (theta / np.linalg.norm(t))
     return v * (theta / (2.0 * s))
 
@@ -370,3 +372,91 @@ def add_annotations(scene: Scene, n_annotated: int = 6, pts_per_cam: int = 12, n
     pert = rng.normal(3, math.radians(init_rot_sigma_deg))
     scene.tlw_init = np.concatenate([rodrigues_inv(rodrigues(pert) @ Rlw), t_lw + rng.normal(3, init_trans_sigma)])
     return scene
+
+
+# ------------------------------------------------------------------------------------------------ match table (PTZ-IBA input)
+@dataclass
+class MatchTable:
+    """What LoadImages + LoadMatchesInfo hand to PtzIncrementalOptimizer (data_io.cc:294-400): key points per image and the
+    non-empty cells of the N x N MatchesInfo table in table order (row = source image, column = destination image)."""
+
+    n_img: int
+    img_wh: np.ndarray      # int32 [n_img, 2]
+    kp_ptr: np.ndarray      # int64 [n_img + 1]
+    kp_xy: np.ndarray       # float32 [n_kp, 2]
+    src: np.ndarray         # int64 [n_pairs]
+    dst: np.ndarray         # int64 [n_pairs]
+    match_ptr: np.ndarray   # int64 [n_pairs + 1]
+    q: np.ndarray           # int32 [n_match]  feature index in the source image
+    t: np.ndarray           # int32 [n_match]  feature index in the destination image
+    H: np.ndarray           # float64 [n_pairs, 9]  H_j_i (source pixel -> destination pixel), h33 = 1
+    h_valid: np.ndarray     # int32 [n_pairs]
+    confidence: np.ndarray  # float64 [n_pairs]  min(1, matches / 100) stored as float32 (CalMatchingScore, data_io.cc:358-366)
+
+    @property
+    def n_pairs(self) -> int:
+        return int(self.src.shape[0])
+
+    def pairs(self):
+        return [(int(self.src[p]), int(self.dst[p]),
+                 [(int(self.q[k]), int(self.t[k])) for k in range(self.match_ptr[p], self.match_ptr[p + 1])])
+                for p in range(self.n_pairs)]
+
+
+def homography_dlt(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Least-squares homography b ~ H a (normalised DLT) with h33 = 1: stands in for the inlier fit at the end of
+    cv::findHomography (data_io.cc:352) on outlier-free synthetic matches."""
+    def norm(p):
+        c = p.mean(0)
+        s = math.sqrt(2.0) / max(np.sqrt(((p - c) ** 2).sum(1)).mean(), 1e-12)
+        return np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    Ta, Tb = norm(a), norm(b)
+    an = a @ Ta[:2, :2].T + Ta[:2, 2]; bn = b @ Tb[:2, :2].T + Tb[:2, 2]
+    A = np.zeros((2 * len(a), 9))
+    A[0::2, 0:2] = an; A[0::2, 2] = 1; A[0::2, 6:8] = -bn[:, :1] * an; A[0::2, 8] = -bn[:, 0]
+    A[1::2, 3:5] = an; A[1::2, 5] = 1; A[1::2, 6:8] = -bn[:, 1:] * an; A[1::2, 8] = -bn[:, 1]
+    h = np.linalg.svd(A)[2][-1].reshape(3, 3)
+    Hm = np.linalg.inv(Tb) @ h @ Ta
+    return Hm / Hm[2, 2]
+
+
+def make_match_table(scene: Scene, min_pair_matches: int = 8, max_pair_gap: int | None = None,
+                     bidirectional: bool = True) -> MatchTable:
+    """Pairwise matches implied by the tracks of a synthetic scene: every two views of a track are matched, pairs with
+    fewer than `min_pair_matches` are dropped, one homography per pair.  bidirectional=False lists every pair once
+    (i < j); the reference then can only register images with a HIGHER index than an already registered one, because
+    RegisterNextImage reads the table in the (registered source -> new destination) direction only
+    (ptz_incremental_optimizer.cc:391).  bidirectional=True also lists (j, i) with the matches swapped and its own fit."""
+    n = scene.n_cam
+    counts = np.bincount(scene.obs_cam, minlength=n)
+    kp_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    order = np.argsort(scene.obs_cam, kind="stable")
+    kp_xy = np.ascontiguousarray(scene.obs_uv[order], dtype=np.float32)
+    feat_of_obs = np.empty(scene.n_obs, dtype=np.int64)
+    feat_of_obs[order] = np.arange(scene.n_obs) - kp_ptr[scene.obs_cam[order]]
+    pairs: dict = {}
+    bounds = np.flatnonzero(np.diff(scene.obs_ray)) + 1
+    for seg in np.split(np.arange(scene.n_obs), bounds):
+        for x in range(len(seg)):
+            for y in range(x + 1, len(seg)):
+                i, j = int(scene.obs_cam[seg[x]]), int(scene.obs_cam[seg[y]])
+                if max_pair_gap is not None and min(j - i, n - (j - i)) > max_pair_gap:
+                    continue
+                pairs.setdefault((i, j), []).append((int(feat_of_obs[seg[x]]), int(feat_of_obs[seg[y]])))
+    if bidirectional:
+        for (i, j), v in list(pairs.items()):
+            pairs[(j, i)] = [(b, a) for a, b in v]
+    keys = sorted(k for k, v in pairs.items() if len(v) >= min_pair_matches)
+    src = np.array([k[0] for k in keys], dtype=np.int64); dst = np.array([k[1] for k in keys], dtype=np.int64)
+    match_ptr = np.concatenate([[0], np.cumsum([len(pairs[k]) for k in keys])]).astype(np.int64)
+    q = np.array([m[0] for k in keys for m in pairs[k]], dtype=np.int32)
+    t = np.array([m[1] for k in keys for m in pairs[k]], dtype=np.int32)
+    H = np.zeros((len(keys), 9)); conf = np.zeros(len(keys))
+    for p, (i, j) in enumerate(keys):
+        ms = np.asarray(pairs[(i, j)])
+        a = kp_xy[kp_ptr[i] + ms[:, 0]]; b = kp_xy[kp_ptr[j] + ms[:, 1]]
+        H[p] = homography_dlt(a, b).reshape(9)
+        conf[p] = float(np.float32(1.0) if len(ms) >= 100 else np.float32(len(ms)) / np.float32(100))
+    img_wh = np.tile(np.array([scene.width, scene.height], dtype=np.int32), (n, 1))
+    return MatchTable(n, img_wh, kp_ptr, kp_xy, src, dst, match_ptr, q, t, H, np.ones(len(keys), dtype=np.int32), conf)

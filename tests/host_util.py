@@ -116,3 +116,24 @@ def krt_solve(cam_ref, cam_cur, uv_ref, uv_cur, max_iter=200, max_err=100.0, fty
     nit = C.c_int32(); summ = api.LmSummary()
     ok = lib().ptzh_krt_solve(_p(ref), _p(cur), len(ur), _p(ur), _p(uc), max_iter, C.c_double(max_err), ftype, C.byref(nit), C.byref(summ))
     return bool(ok), cur, nit.value, summ.as_dict()
+
+
+def incremental_solve(table, cam15, max_iter=200, seeds=()):
+    """PtzIncrementalOptimizer::Solve through the C++ class.  Returns (ok, cam15, registered ids, events, lm_iterations)."""
+    tb = table
+    cam = np.array(cam15, dtype=np.float64, order="C").copy()
+    reg = np.zeros(tb.n_img, dtype=np.int32)
+    max_events = 16 * tb.n_img + 256
+    ev = np.zeros((max_events, 4), dtype=np.int64)
+    seeds = np.array(list(seeds), dtype=np.int64)
+    nit = C.c_int64(0); solved = C.c_int32(0)
+    H = np.ascontiguousarray(tb.H, dtype=np.float64); hv = np.ascontiguousarray(tb.h_valid, dtype=np.int32)
+    conf = np.ascontiguousarray(tb.confidence, dtype=np.float64)
+    wh = np.ascontiguousarray(tb.img_wh, dtype=np.int32)
+    ne = lib().ptzh_incremental_solve(tb.n_img, _p(tb.kp_ptr), _p(tb.kp_xy), _p(wh), tb.n_pairs, _p(tb.src), _p(tb.dst),
+                                      _p(tb.match_ptr), _p(tb.q), _p(tb.t), _p(H), _p(hv), _p(conf), _p(cam),
+                                      _p(seeds) if len(seeds) else None, len(seeds), max_iter, _p(reg), _p(ev), max_events,
+                                      C.byref(nit), C.byref(solved))
+    ok = bool(solved.value)
+    events = [tuple(int(x) for x in row) for row in ev[:max(ne, 0)]]
+    return ok, cam, sorted(int(i) for i in np.flatnonzero(reg)), events, int(nit.value)

@@ -163,3 +163,79 @@ def test_georef_packing_and_tlw_initialisation(pkg, ftype):
     cands = [i for i in range(sc.n_cam) if i not in set(sc.obs3d["cam"].tolist())]
     ok3, _, _, _, pk3 = hu.ptzray_solve(kps, plist, sc.cam_gt, cand_ids=cands, ftype=ftype, annotations=ann, on_device=False)
     assert not ok3 and not pk3["tlw_ok"] and np.array_equal(pk3["tlw_init"], np.zeros(6))
+
+
+# ------------------------------------------------------------------------------------------- PTZ-IBA orchestration (CPU part)
+def _orchestration_oracle():
+    import __graft_entry__ as ge
+    ge.load_oracle()
+    import incremental_oracle
+    return incremental_oracle
+
+
+@pytest.mark.parametrize("bidirectional", [False, True])
+def test_incremental_seed_ranking_matches_restatement(pkg, bidirectional):
+    """Without a device every bundle adjustment fails, so PtzIncrementalOptimizer::Solve walks through 50 seed pairs and
+    returns false (ptz_incremental_optimizer.cc:44-63).  The SEQUENCE of seed pairs exercises FindFirstInitialImage,
+    FindSecondInitialImage, CalPixelDiff and the try-once bookkeeping (:148-244, :298-320), including the std::sort order of
+    tied scores, and must equal the restatement's."""
+    io = _orchestration_oracle()
+    sc = pkg.synth.make_scene(3, 24, 100)
+    tb = pkg.synth.make_match_table(sc, bidirectional=bidirectional)
+    cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
+    ok, cam, reg, events, nit = hu.incremental_solve(tb, cam0, max_iter=50)
+    assert not ok and nit == 0
+
+    class NoSolver(io.IncrementalOracle):
+        def _bundle(self, ids):
+            self.events.append((2, len(ids), 0, 0))
+            return False
+
+    o = NoSolver(tb, cam0, 50)
+    assert not o.solve()
+    assert [e for e in events if e[0] == 0] == [e for e in o.events if e[0] == 0]
+    assert len([e for e in events if e[0] == 0]) == 50 and events == o.events
+    # manual seeds (SetSeedImageId, :133-137) replace the first-image ranking
+    ok2, _, _, ev2, _ = hu.incremental_solve(tb, cam0, max_iter=50, seeds=[5])
+    o2 = NoSolver(tb, cam0, 50); o2.seeds = [5]
+    assert not o2.solve() and not ok2 and ev2 == o2.events and all(e[1] == 5 for e in ev2 if e[0] == 0)
+
+
+def test_incremental_invalid_inputs(pkg):
+    sc = pkg.synth.make_scene(3, 8, 60)
+    tb = pkg.synth.make_match_table(sc)
+    cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
+    assert not hu.incremental_solve(tb, cam0, max_iter=0)[0]  # CheckValid (:140-146)
+
+
+def test_rodrigues_roundtrip_near_pi_and_scaled_matrices(orc):
+    """cv::Rodrigues (matrix -> vector) as restated in the oracle and in the host Camera class: the theta ~ pi branch picks
+    the axis signs from R01, R02 (and R12 when x is the smallest component); a scaled, noisy near-rotation (K_j^-1 H K_i of
+    the registration step) is replaced by its polar factor first."""
+    rng = np.random.default_rng(5)
+    for th in [0.1, 1.0, 3.0, 3.1415, np.pi - 3e-6, np.pi - 1e-7, np.pi - 1e-9, np.pi, 3.3, 4.0]:
+        for _ in range(25):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            v = np.zeros(15); v[0] = v[1] = 1000.0; v[4:7] = ax * th
+            out = np.zeros(15)
+            hu.lib().ptzh_camera_roundtrip(hu._p(v), hu._p(out), None)
+            Ri = orc.rodrigues(v[4:7])
+            # the special branch is entered within 1e-5 of pi, where the axis sign is only known up to that angle (as in OpenCV)
+            tol = 3e-5 if abs(th - np.pi) < 1.1e-5 else 1e-9
+            assert np.abs(orc.rodrigues(out[4:7]) - Ri).max() < tol
+            assert np.abs(orc.rodrigues(orc.rodrigues_inv(Ri)) - Ri).max() < tol
+            assert np.abs(pkg_synth().rodrigues(pkg_synth().rodrigues_inv(Ri)) - Ri).max() < tol
+            M = Ri * rng.uniform(0.3, 3.0) + rng.normal(size=(3, 3)) * 1e-3
+            U, _, Vt = np.linalg.svd(M)
+            r1 = np.zeros(3)
+            hu.lib().ptzh_rodrigues_inv(hu._p(np.ascontiguousarray(M.reshape(9))), hu._p(r1))
+            P = U @ Vt
+            if abs(np.arccos(np.clip((np.trace(P) - 1) / 2, -1, 1)) - np.pi) < 2e-5:
+                continue
+            assert np.abs(orc.rodrigues(r1) - P).max() < 1e-9
+            assert np.abs(orc.rodrigues(orc.rodrigues_inv(M)) - P).max() < 1e-9
+
+
+def pkg_synth():
+    import __graft_entry__ as ge
+    return ge.load_package().synth

@@ -360,15 +360,19 @@ def test_cpp_ptzray_optimizer_georeferencing(pkg, orc, ftype):
     sc = _georef_scene(pkg, ftype)
     kps, plist = hu.scene_to_features_matches(sc)
     ann = (sc.obs3d["cam"], sc.obs3d["uv"], sc.obs3d["xyz"])
-    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=ftype, annotations=ann)
+    # stage 1, as run_ptz_ba.cc does: plain bundle adjustment; stage 2: georeferencing of the refined cameras (:131-155)
+    ok1, cam1, _, _, _ = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=ftype)
+    assert ok1
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, cam1, max_iter=200, ftype=ftype, annotations=ann)
     assert ok and pk["tlw_ok"] and summ["termination_type"] == 0
     # the PnP initial value is close to the truth (rig 15 m above the pitch, tens of metres away)
     Rg, Ri = orc.rodrigues(sc.tlw_gt[:3]), orc.rodrigues(pk["tlw_init"][:3])
-    assert np.degrees(np.arccos(np.clip((np.trace(Ri @ Rg.T) - 1) / 2, -1, 1))) < 3.0
+    gauge = orc.rodrigues(cam1[0, 4:7]).T @ orc.rodrigues(sc.cam_gt[0, 4:7])  # stage 1 leaves the global rotation free
+    assert np.degrees(np.arccos(np.clip((np.trace(Ri @ (gauge @ Rg).T) - 1) / 2, -1, 1))) < 1.0
     ns = SimpleNamespace(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"],
                          n_cam=sc.n_cam, n_ray=len(pk["ray_weight"]), n_obs=len(pk["obs_cam"]), factor_type=ftype,
-                         cam_init=sc.cam_init, ray_init=pk["ray"])
-    ns.ray_init = orc.pix2ray(ns, sc.cam_init)
+                         cam_init=cam1, ray_init=pk["ray"])
+    ns.ray_init = orc.pix2ray(ns, cam1)
     ocam, oray, otlw, osumm, _ = orc.ba_solve(ns, obs3d=sc.obs3d, tlw0=pk["tlw_init"], jacobian_mode=orc.JAC_NUMERIC, num_threads=4)
     assert osumm["termination_type"] == 0 and summ["num_iterations"] == osumm["num_iterations"]
     assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-8
@@ -400,3 +404,40 @@ def test_ba_mixed_batch_with_and_without_annotations(pkg):
     assert _rel(cams[1][:, 0], cp[:, 0]) < 1e-10
     assert np.array_equal(b.last_tlw[1], np.zeros(6))
     b.close()
+
+
+# ------------------------------------------------------------------------------------------- PTZ-IBA orchestration (next-1)
+@pytest.mark.parametrize("seed,n_views,bidirectional", [(1, 20, True), (3, 24, False), (6, 40, True)])
+def test_incremental_optimizer_matches_restatement(pkg, orc, seed, n_views, bidirectional):
+    """PtzIncrementalOptimizer (ptz_incremental_optimizer.cc:39-440) through the C++ class, every solve on the device, against
+    the Python restatement running the CPU oracle's solvers: identical sequence of decisions (seed pair, registration
+    order and reference view, bundle adjustments with their iteration counts), same registered set, cameras within 1e-6."""
+    import host_util as hu
+    import incremental_oracle as io
+    sc = pkg.synth.make_scene(seed, n_views, 100)
+    tb = pkg.synth.make_match_table(sc, bidirectional=bidirectional)
+    cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
+    ok, cam, reg, events, nit = hu.incremental_solve(tb, cam0, max_iter=200)
+    o = io.IncrementalOracle(tb, cam0, 200, jacobian_mode=orc.JAC_NUMERIC)
+    assert o.solve() and ok
+    assert events == o.events and nit == o.lm_iterations
+    assert reg == sorted(o.reg)
+    if bidirectional:
+        assert len(reg) == n_views
+    ocam = o.cam15()
+    # The panorama's global rotation is a null direction of the cost and a uniform focal-length scale is a weak one: with the
+    # trust region growing towards 1e16 the LM step amplifies round-off along both (in Ceres as well), so two correct
+    # solvers end a chain of ~20 bundle adjustments in different gauges.  Compare gauge-free quantities; the weak mode limits
+    # the agreement of a long chain to ~1e-5 (2.6e-6 measured on the 40-view case), single solves hold 1e-6 (tests above).
+    tol = 1e-6 if n_views <= 24 else 2e-5
+    assert _rel(cam[reg, 0], ocam[reg, 0]) < tol
+    R = [orc.rodrigues(c[4:7]) for c in cam]; Ro = [orc.rodrigues(c[4:7]) for c in ocam]
+    for i in reg:
+        assert np.abs(R[i] @ R[reg[0]].T - Ro[i] @ Ro[reg[0]].T).max() < tol
+    # and the model is right: focal lengths within 0.2 % of the truth, relative rotations within 0.1 degrees
+    assert np.abs(cam[reg, 0] / sc.cam_gt[reg, 0] - 1).max() < 2e-3
+    r0 = reg[0]
+    for i in reg:
+        Rg = orc.rodrigues(sc.cam_gt[i, 4:7]) @ orc.rodrigues(sc.cam_gt[r0, 4:7]).T
+        d = (R[i] @ R[r0].T) @ Rg.T
+        assert np.degrees(np.arccos(np.clip((np.trace(d) - 1) / 2, -1, 1))) < 0.1
