@@ -91,6 +91,10 @@ void ptz_lm_options_default(ptz_lm_options* o);
 /* Library / device probe.  ptz_device_count() never initialises a GPU context beyond counting. */
 const char* ptz_version(void);
 int32_t ptz_device_count(void);
+/* The reference builds a new optimizer object per solve; so do callers of this library.  Device blocks, pinned blocks,
+ * streams and events released by finished solves are parked in a process-wide cache (budget PTZ_CACHE_MAX_MB of device
+ * memory per GPU, default 4096) and reused by later ones.  ptz_trim_cache() hands everything parked back to the driver. */
+void ptz_trim_cache(void);
 
 /* ------------------------------------------------------------------------------------------------
  * PTZ-IBA global bundle adjustment

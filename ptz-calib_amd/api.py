@@ -22,7 +22,7 @@ _ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUP
 EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_batch_create", "ptz_ba_batch_destroy",
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
-           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch"]
+           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch", "ptz_trim_cache"]
 
 
 class PtzError(RuntimeError):
@@ -85,6 +85,11 @@ def _check(rc, where):
 
 def version() -> str:
     return lib().ptz_version().decode()
+
+
+def trim_cache() -> None:
+    """Give the library's parked device blocks / streams / events back to the driver (ptz_trim_cache)."""
+    lib().ptz_trim_cache()
 
 
 def device_count() -> int:

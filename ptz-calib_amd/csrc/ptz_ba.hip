@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "ptz_common.h"
+#include "ptz_pool.h"
 #include "ptz_factor.h"
 
 namespace ptz {
@@ -1181,7 +1182,7 @@ struct ptz_ba_batch {
   template <typename T> int alloc(T** p, size_t count)
   {
     void* q = nullptr;
-    if (hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1)) != hipSuccess) return PTZ_ENOMEM;
+    if (ptzpool::dev_acquire(device, sizeof(T) * std::max<size_t>(count, 1), &q) != hipSuccess) return PTZ_ENOMEM;
     allocs.push_back(q);
     *p = (T*)q;
     return PTZ_OK;
@@ -1190,7 +1191,7 @@ struct ptz_ba_batch {
   {
     if (!profiling) return;
     if (ev_used.size() * 2 + 2 > ev_pool.size()) {
-      for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+      for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)ptzpool::event_acquire(device, true, &e); ev_pool.push_back(e); }
     }
     const int idx = (int)ev_used.size() * 2;
     ev_used.push_back({slot, idx});
@@ -1268,11 +1269,11 @@ static void make_groups(ptz_ba_batch* b)
     b->dg.push_back(d);
   }
   while ((int)b->streams.size() < G) {
-    hipStream_t st; (void)hipStreamCreate(&st); b->streams.push_back(st);
-    hipEvent_t e1, e2; (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+    hipStream_t st; (void)ptzpool::stream_acquire(b->device, &st); b->streams.push_back(st);
+    hipEvent_t e1, e2; (void)ptzpool::event_acquire(b->device, false, &e1); (void)ptzpool::event_acquire(b->device, false, &e2);
     b->fork_ev.push_back(e1); b->join_ev.push_back(e2);
-    hipStream_t ax; (void)hipStreamCreate(&ax); b->aux.push_back(ax);
-    hipEvent_t e3, e4; (void)hipEventCreateWithFlags(&e3, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e4, hipEventDisableTiming);
+    hipStream_t ax; (void)ptzpool::stream_acquire(b->device, &ax); b->aux.push_back(ax);
+    hipEvent_t e3, e4; (void)ptzpool::event_acquire(b->device, false, &e3); (void)ptzpool::event_acquire(b->device, false, &e4);
     b->la_ev.push_back(e3); b->la_ev.push_back(e4);
   }
 }
@@ -1342,7 +1343,10 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
   LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
+  // both halves of the double buffer: without annotation residuals no kernel ever writes the candidate half, and the
+  // accepted-step parity decides which half is read back
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * B, hipMemcpyDeviceToDevice, s0));
+  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x + d.tlw_stride, b->tlw0, sizeof(double) * 6 * B, hipMemcpyDeviceToDevice, s0));
   LAUNCH(k_fill, dim3((6 * B + 255) / 256), dim3(256), 0, d.scale_t, (size_t)6 * B, 1.0);
   // IterationZero: evaluate, Jacobi scales from the column norms, re-evaluate scaled
   enqueue_linearize<TYPE>(b);
@@ -1514,16 +1518,20 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
 {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : b->allocs) (void)hipFree(p);
-  for (auto e : b->ev_pool) (void)hipEventDestroy(e);
-  if (b->h_active) (void)hipHostFree(b->h_active);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
-  for (auto st : b->streams) (void)hipStreamDestroy(st);
-  for (auto st : b->aux) (void)hipStreamDestroy(st);
-  for (auto e : b->la_ev) (void)hipEventDestroy(e);
-  for (auto e : b->fork_ev) (void)hipEventDestroy(e);
-  for (auto e : b->join_ev) (void)hipEventDestroy(e);
+  // nothing of this batch may still be running when its memory is handed to the next one
+  for (auto st : b->streams) (void)hipStreamSynchronize(st);
+  for (auto st : b->aux) (void)hipStreamSynchronize(st);
+  const int dv = b->device;
+  for (void* p : b->allocs) ptzpool::dev_release(dv, p);
+  for (auto e : b->ev_pool) ptzpool::event_release(dv, true, e);
+  if (b->h_active) ptzpool::pinned_release(b->h_active);
+  ptzpool::event_release(dv, true, b->ev0);
+  ptzpool::event_release(dv, true, b->ev1);
+  for (auto st : b->streams) ptzpool::stream_release(dv, st);
+  for (auto st : b->aux) ptzpool::stream_release(dv, st);
+  for (auto e : b->la_ev) ptzpool::event_release(dv, false, e);
+  for (auto e : b->fork_ev) ptzpool::event_release(dv, false, e);
+  for (auto e : b->join_ev) ptzpool::event_release(dv, false, e);
   delete b;
 }
 
@@ -1782,8 +1790,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (const char* e = getenv("PTZ_BA_LOOKAHEAD")) b->lookahead = atoi(e) != 0;
   make_groups(b);
   b->stream = b->streams.empty() ? nullptr : b->streams[0];
-  if (b->stream == nullptr || hipEventCreate(&b->ev0) != hipSuccess ||
-      hipEventCreate(&b->ev1) != hipSuccess || hipHostMalloc((void**)&b->h_active, sizeof(int) * n) != hipSuccess) {
+  if (b->stream == nullptr || ptzpool::event_acquire(b->device, true, &b->ev0) != hipSuccess ||
+      ptzpool::event_acquire(b->device, true, &b->ev1) != hipSuccess ||
+      ptzpool::pinned_acquire(sizeof(int) * n, (void**)&b->h_active) != hipSuccess) {
     ptz_ba_batch_destroy(b);
     return PTZ_ENODEVICE;
   }
@@ -1899,6 +1908,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, st, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   hipLaunchKernelGGL(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, st, d.scale_r, (size_t)b->total_ray * 3, 1.0);
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x + d.tlw_stride, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_fill, dim3((6 * b->n_scene + 255) / 256), dim3(256), 0, st, d.scale_t, (size_t)6 * b->n_scene, 1.0);
   switch ((b->type == PTZ_BA_PTZRay ? 0 : 1) + 2 * b->has3d) {
     case 0: enqueue_linearize<0>(b); break;
@@ -1938,6 +1948,8 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   }
   return PTZ_OK;
 }
+
+void ptz_trim_cache(void) { ptzpool::trim(); }
 
 int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary)
 {

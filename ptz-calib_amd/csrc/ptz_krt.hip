@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ptz_common.h"
+#include "ptz_pool.h"
 #include "ptz_factor.h"
 
 namespace ptz {
@@ -348,23 +349,38 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
   PTZ_HIP_TRY(hipSetDevice(o.device_id));
   const int64_t nm = match_ptr[n_query];
-  long long* d_ptr = nullptr;
-  float2 *d_ref = nullptr, *d_cur = nullptr;
-  double *d_cref = nullptr, *d_ccur = nullptr;
-  ptz_lm_summary* d_sum = nullptr;
-  int* d_acc = nullptr;
-  PTZ_HIP_TRY(hipMalloc(&d_ptr, sizeof(long long) * (n_query + 1)));
-  PTZ_HIP_TRY(hipMalloc(&d_ref, sizeof(float2) * (nm > 0 ? nm : 1)));
-  PTZ_HIP_TRY(hipMalloc(&d_cur, sizeof(float2) * (nm > 0 ? nm : 1)));
-  PTZ_HIP_TRY(hipMalloc(&d_cref, sizeof(double) * 15 * n_query));
-  PTZ_HIP_TRY(hipMalloc(&d_ccur, sizeof(double) * 15 * n_query));
-  PTZ_HIP_TRY(hipMalloc(&d_sum, sizeof(ptz_lm_summary) * n_query));
-  PTZ_HIP_TRY(hipMalloc(&d_acc, sizeof(int) * n_query));
-  PTZ_HIP_TRY(hipMemcpy(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice));
-  PTZ_HIP_TRY(hipMemcpy(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice));
-  PTZ_HIP_TRY(hipMemcpy(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice));
-  PTZ_HIP_TRY(hipMemcpy(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice));
-  PTZ_HIP_TRY(hipMemcpy(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice));
+  // one pooled device block for everything the launch touches
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_ptr = 0, o_ref = o_ptr + up(sizeof(long long) * (n_query + 1)), o_cur = o_ref + up(sizeof(float2) * (nm > 0 ? nm : 1)),
+               o_cref = o_cur + up(sizeof(float2) * (nm > 0 ? nm : 1)), o_ccur = o_cref + up(sizeof(double) * 15 * n_query),
+               o_sum = o_ccur + up(sizeof(double) * 15 * n_query), o_acc = o_sum + up(sizeof(ptz_lm_summary) * n_query),
+               total = o_acc + up(sizeof(int) * n_query);
+  struct Held {
+    int dev; char* base = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Held()
+    {
+      if (st) (void)hipStreamSynchronize(st);
+      ptzpool::dev_release(dev, base);
+      ptzpool::stream_release(dev, st);
+      ptzpool::event_release(dev, true, e0);
+      ptzpool::event_release(dev, true, e1);
+    }
+  } h;
+  h.dev = o.device_id;
+  if (ptzpool::dev_acquire(h.dev, total, (void**)&h.base) != hipSuccess) return PTZ_ENOMEM;
+  PTZ_HIP_TRY(ptzpool::stream_acquire(h.dev, &h.st));
+  PTZ_HIP_TRY(ptzpool::event_acquire(h.dev, true, &h.e0));
+  PTZ_HIP_TRY(ptzpool::event_acquire(h.dev, true, &h.e1));
+  long long* d_ptr = (long long*)(h.base + o_ptr);
+  float2 *d_ref = (float2*)(h.base + o_ref), *d_cur = (float2*)(h.base + o_cur);
+  double *d_cref = (double*)(h.base + o_cref), *d_ccur = (double*)(h.base + o_ccur);
+  ptz_lm_summary* d_sum = (ptz_lm_summary*)(h.base + o_sum);
+  int* d_acc = (int*)(h.base + o_acc);
+  PTZ_HIP_TRY(hipMemcpyAsync(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
   KrtOpt ko;
   ko.max_num_iterations = o.max_num_iterations;
   ko.max_consecutive_invalid = o.max_num_consecutive_invalid_steps;
@@ -379,23 +395,17 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   ko.gradient_tolerance = o.gradient_tolerance;
   ko.parameter_tolerance = o.parameter_tolerance;
   ko.max_reproj_error = max_reproj_error;
-  hipEvent_t e0, e1;
-  PTZ_HIP_TRY(hipEventCreate(&e0));
-  PTZ_HIP_TRY(hipEventCreate(&e1));
-  PTZ_HIP_TRY(hipEventRecord(e0, 0));
+  PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
   const dim3 grid((n_query + 3) / 4), block(256);
-  if (factor_type == PTZ_KRT_F) hipLaunchKernelGGL(k_krt<0>, grid, block, 0, 0, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
-  else hipLaunchKernelGGL(k_krt<1>, grid, block, 0, 0, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
-  PTZ_HIP_TRY(hipEventRecord(e1, 0));
-  PTZ_HIP_TRY(hipDeviceSynchronize());
+  if (factor_type == PTZ_KRT_F) hipLaunchKernelGGL(k_krt<0>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
+  else hipLaunchKernelGGL(k_krt<1>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
+  PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost, h.st));
+  PTZ_HIP_TRY(hipStreamSynchronize(h.st));
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventElapsedTime(&ms, h.e0, h.e1);
   if (device_ms) *device_ms = ms;
-  PTZ_HIP_TRY(hipMemcpy(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost));
-  PTZ_HIP_TRY(hipMemcpy(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost));
-  PTZ_HIP_TRY(hipMemcpy(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(d_ptr); (void)hipFree(d_ref); (void)hipFree(d_cur); (void)hipFree(d_cref); (void)hipFree(d_ccur);
-  (void)hipFree(d_sum); (void)hipFree(d_acc);
   return PTZ_OK;
 }

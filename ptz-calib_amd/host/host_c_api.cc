@@ -211,7 +211,7 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
                                const int64_t* src, const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t,
                                const double* H, const int32_t* h_valid, const double* confidence, double* cam15,
                                const int64_t* seeds, int32_t n_seeds, int32_t max_iter, int32_t* registered, int64_t* events,
-                               int32_t max_events, int64_t* lm_iterations, int32_t* solved)
+                               int32_t max_events, int64_t* lm_iterations, int32_t* solved, double* timing5)
 {
   std::vector<ImageFeatures> feats;
   std::vector<MatchesInfo> mis;
@@ -232,6 +232,7 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
     events[4 * e] = ev[e].kind; events[4 * e + 1] = ev[e].a; events[4 * e + 2] = ev[e].b; events[4 * e + 3] = ev[e].success ? 1 : 0;
   }
   if (lm_iterations) *lm_iterations = opt.lm_iterations();
+  if (timing5) memcpy(timing5, opt.timing_ms(), sizeof(double) * 5);
   if (solved) *solved = ok ? 1 : 0;
   if (!ok) return ne;
   for (int i = 0; i < n_img; ++i) {

@@ -1,9 +1,13 @@
 #include "ptz_incremental_optimizer.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <set>
 
 #include "../../include/ptz_calib_amd.h"
 #include "ptzray_optimizer.h"
@@ -14,6 +18,12 @@ long PtzIncrementalOptimizer::kMaxNumImages = 100000;
 float PtzIncrementalOptimizer::kBaGlobalImagesRatio = 1.1f;
 
 namespace {
+struct ScopedMs {
+  double& acc;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit ScopedMs(double& a) : acc(a) {}
+  ~ScopedMs() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 // Images with a positive score, best first.  std::sort (not stable_sort) with the reference's comparator, so that ties
 // fall the way they do there under the same standard library (ptz_incremental_optimizer.cc:192-203).
 std::vector<long> RankByScore(const std::vector<float>& score)
@@ -143,6 +153,7 @@ bool PtzIncrementalOptimizer::FindInitialImagePair(long& image_id1, long& image_
 
 std::vector<long> PtzIncrementalOptimizer::FindFirstInitialImage() const
 {  // :178-204: total matching confidence of every image (float accumulation)
+  ScopedMs tm(timing_ms_[0]);
   std::vector<float> score(features_.size(), 0.0f);
   for (const MatchesInfo& mi : matches_info_) {
     const float confidence = static_cast<float>(mi.confidence);
@@ -154,6 +165,7 @@ std::vector<long> PtzIncrementalOptimizer::FindFirstInitialImage() const
 
 std::vector<long> PtzIncrementalOptimizer::FindSecondInitialImage(long image_id1) const
 {  // :206-244: partners of image_id1 with a mean match displacement of at least 50 px
+  ScopedMs tm(timing_ms_[0]);
   std::vector<float> score(features_.size(), 0.0f);
   const float kMinPixelDiff = 50;
   for (const MatchesInfo& mi : matches_info_) {
@@ -169,6 +181,7 @@ std::vector<long> PtzIncrementalOptimizer::FindSecondInitialImage(long image_id1
 
 std::vector<long> PtzIncrementalOptimizer::FindNextImages() const
 {  // :246-296: unregistered images next to the model, by total confidence towards registered images
+  ScopedMs tm(timing_ms_[0]);
   std::vector<float> score(features_.size(), 0.0f);
   const size_t kMaxRegTrials = 4;
   auto exhausted = [&](long id) {
@@ -213,11 +226,29 @@ void PtzIncrementalOptimizer::SetInitialImagePairParameters(long image_id1, long
 
 bool PtzIncrementalOptimizer::RunBundle(const std::unordered_set<long>& ids)
 {
+  ScopedMs tm(timing_ms_[1]);
+  if (getenv("PTZ_INC_DEBUG") && atoi(getenv("PTZ_INC_DEBUG")) > 1)
+    for (long id : std::set<long>(ids.begin(), ids.end())) {
+      const std::vector<double> v = cameras_[id].ToVector();
+      fprintf(stderr, "[inc]   in  cam %ld: %.17g %.17g %.17g %.17g | %.17g %.17g %.17g\n", id, v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+    }
   PTZRayOptimizer optimizer(PTZRayOptimizer::Borrow{}, features_, matches_info_, cameras_, ids, max_iter_, PTZRay);
   optimizer.UseTracks(tracks_);
   optimizer.SetDevice(device_id_);
   const bool ok = optimizer.Solve(cameras_);
+  timing_ms_[2] += optimizer.device_ms();
   lm_iterations_ += optimizer.summary().num_iterations;
+  if (getenv("PTZ_INC_DEBUG") && atoi(getenv("PTZ_INC_DEBUG")) > 1)
+    for (long id : std::set<long>(ids.begin(), ids.end())) {
+      const std::vector<double> v = cameras_[id].ToVector();
+      fprintf(stderr, "[inc]   out cam %ld: %.17g %.17g %.17g %.17g | %.17g %.17g %.17g\n", id, v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+    }
+  if (getenv("PTZ_INC_DEBUG")) {
+    double cs = 0;
+    for (long id : ids) { const std::vector<double> v = cameras_[id].ToVector(); for (int k = 0; k < 7; ++k) cs += v[k] * (k + 1); }
+    fprintf(stderr, "[inc] BA n=%zu it=%d ok=%d init_cost=%.17g final_cost=%.17g cams=%.17g\n", ids.size(), optimizer.summary().num_iterations,
+            (int)ok, optimizer.summary().initial_cost, optimizer.summary().final_cost, cs);
+  }
   events_.push_back({Event::kGlobalBA, static_cast<long>(ids.size()), optimizer.summary().num_iterations, ok});
   return ok;
 }
@@ -240,6 +271,7 @@ bool PtzIncrementalOptimizer::AdjustGlobalBundle() { return RunBundle(reg_image_
 
 bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
 {  // :377-418
+  ScopedMs tm(timing_ms_[3]);
   num_reg_trials_[image_id] += 1;
   // every table entry (registered i -> image_id) with a homography is one attempt
   std::vector<const MatchesInfo*> attempts;
@@ -275,9 +307,11 @@ bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
   opt.device_id = device_id_;
   std::vector<ptz_lm_summary> summaries(n);
   std::vector<int32_t> accepted(n, 0);
+  const auto t_dev = std::chrono::steady_clock::now();
   const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
                                          cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
                                          accepted.data(), nullptr);
+  timing_ms_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
   if (rc == PTZ_OK)
     for (size_t q = 0; q < n; ++q) {
       if (!accepted[q]) continue;
@@ -286,6 +320,11 @@ bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
       cam_j.K() = refined.K();  // t and dist are not taken over (:406-407)
       cam_j.R() = refined.R();
       reg_image_ids_.insert(image_id);
+      if (getenv("PTZ_INC_DEBUG")) {
+        const std::vector<double> v = cam_j.ToVector();
+        fprintf(stderr, "[inc] REG %ld via %ld (attempt %zu of %zu) f=%.17g r=%.17g %.17g %.17g cost=%.17g\n", image_id, attempts[q]->src_img_idx, q, n,
+                v[0], v[4], v[5], v[6], summaries[q].final_cost);
+      }
       events_.push_back({Event::kRegister, image_id, attempts[q]->src_img_idx, true});
       return true;
     }

@@ -44,6 +44,9 @@ class PtzIncrementalOptimizer {
   };
   const std::vector<Event>& events() const { return events_; }
   long lm_iterations() const { return lm_iterations_; }  // summed over all bundle adjustments
+  // wall-clock split of Solve in milliseconds: [0] ranking, [1] bundle adjustments (pack + device), [2] device part of [1],
+  // [3] registrations (pack + device), [4] device part of [3]
+  const double* timing_ms() const { return timing_ms_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
 
  private:
@@ -75,6 +78,7 @@ class PtzIncrementalOptimizer {
   std::shared_ptr<const Tracks> tracks_;
   std::vector<Event> events_;
   long lm_iterations_ = 0;
+  mutable double timing_ms_[5] = {0, 0, 0, 0, 0};
 };
 
 }  // namespace ptzcalib

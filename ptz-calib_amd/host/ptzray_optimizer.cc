@@ -1,5 +1,6 @@
 #include "ptzray_optimizer.h"
 
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -274,7 +275,10 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
   double tlw[6];
   tlw_init_ = p.tlw;
   for (int k = 0; k < 6; ++k) tlw[k] = p.tlw[k];
-  if (ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_) != PTZ_OK) return false;
+  const auto t_dev = std::chrono::steady_clock::now();
+  const int32_t rc = ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);
+  device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
+  if (rc != PTZ_OK) return false;
 
   // CalReprojError (:960-968)
   init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);

@@ -53,6 +53,7 @@ class PTZRayOptimizer {
   const ptz_lm_summary& summary() const { return summary_; }
   const std::array<double, 6>& initial_tlw() const { return tlw_init_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
+  double device_ms() const { return device_ms_; }  // wall time of the ptz_ba_solve call of the last Solve
   // The tracks depend on the match table only, not on the candidate set: a caller that solves many candidate subsets of
   // one match table (PtzIncrementalOptimizer) builds them once and shares them instead of repeating FindTracks().
   void UseTracks(std::shared_ptr<const Tracks> tracks) { shared_tracks_ = std::move(tracks); }
@@ -87,6 +88,7 @@ class PTZRayOptimizer {
   int track_len_ = 0, max_track_len_ = 0, min_track_len_ = 0;
   int max_iter_ = 100;
   int device_id_ = 0;
+  double device_ms_ = 0;
   PackedBA packed_;
   std::array<double, 6> tlw_init_{{0, 0, 0, 0, 0, 0}};
   ptz_lm_summary summary_{};

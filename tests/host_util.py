@@ -119,6 +119,7 @@ def krt_solve(cam_ref, cam_cur, uv_ref, uv_cur, max_iter=200, max_err=100.0, fty
 
 
 def incremental_solve(table, cam15, max_iter=200, seeds=()):
+    incremental_solve.timing = np.zeros(5)
     """PtzIncrementalOptimizer::Solve through the C++ class.  Returns (ok, cam15, registered ids, events, lm_iterations)."""
     tb = table
     cam = np.array(cam15, dtype=np.float64, order="C").copy()
@@ -133,7 +134,7 @@ def incremental_solve(table, cam15, max_iter=200, seeds=()):
     ne = lib().ptzh_incremental_solve(tb.n_img, _p(tb.kp_ptr), _p(tb.kp_xy), _p(wh), tb.n_pairs, _p(tb.src), _p(tb.dst),
                                       _p(tb.match_ptr), _p(tb.q), _p(tb.t), _p(H), _p(hv), _p(conf), _p(cam),
                                       _p(seeds) if len(seeds) else None, len(seeds), max_iter, _p(reg), _p(ev), max_events,
-                                      C.byref(nit), C.byref(solved))
+                                      C.byref(nit), C.byref(solved), _p(incremental_solve.timing))
     ok = bool(solved.value)
     events = [tuple(int(x) for x in row) for row in ev[:max(ne, 0)]]
     return ok, cam, sorted(int(i) for i in np.flatnonzero(reg)), events, int(nit.value)

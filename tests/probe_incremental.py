@@ -18,4 +18,4 @@ for n_views, opv in ((20, 100), (60, 300), (200, 500)):
     nba = sum(1 for e in events if e[0] == 2); nreg = sum(1 for e in events if e[0] == 1)
     ferr = np.abs(cam[reg, 0] / sc.cam_gt[reg, 0] - 1).max() if reg else float("nan")
     print(f"views {n_views} pairs {tb.n_pairs} matches {len(tb.q)} (table gen {tg:.1f}s): ok={ok} registered={len(reg)} "
-          f"wall={dt*1e3:.1f} ms  BA calls={nba} (LM it {nit}) registrations={nreg}  views/s={len(reg)/dt:.1f} max f err={ferr:.2e}", flush=True)
+          f"wall={dt*1e3:.1f} ms  BA calls={nba} (LM it {nit}) registrations={nreg}  views/s={len(reg)/dt:.1f} max f err={ferr:.2e}\n    ms: rank/BA(total,device)/reg(total,device) = {np.round(hu.incremental_solve.timing, 1)}", flush=True)

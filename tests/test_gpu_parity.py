@@ -167,6 +167,24 @@ def test_ba_batch_matches_single(pkg, scene_c1):
     b.close()
 
 
+def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, monkeypatch):
+    """Resources are recycled between solves (ptz_pool.h); no result may depend on what an earlier solve left in them.
+    PTZ_POOL_FILL=255 hands out blocks filled with NaN bit patterns: a kernel that reads memory nobody initialised would
+    turn the result into NaNs.  Also: T_l_w comes back exactly as given when there are no annotations, whichever half of the
+    double buffer the accepted-step parity selects."""
+    ref = pkg.api.ba_solve(scene_c1, return_tlw=True)
+    other = pkg.synth.make_scene(9, 30, 120)
+    for fill in ("255", "1"):
+        monkeypatch.setenv("PTZ_POOL_FILL", fill)
+        for it in (1, 2, 3, 200):
+            cam, ray, summ, tlw = pkg.api.ba_solve(scene_c1, return_tlw=True, max_num_iterations=it)
+            assert np.array_equal(tlw, np.zeros(6)) and np.isfinite(cam).all() and np.isfinite(ray).all()
+        pkg.api.ba_solve(other)
+        cam, ray, summ, tlw = pkg.api.ba_solve(scene_c1, return_tlw=True)
+        assert np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1]) and summ == ref[2]
+    pkg.api.trim_cache()
+
+
 def test_ba_max_iterations_is_no_convergence(pkg, scene_c1):
     """Hitting max_num_iterations is NO_CONVERGENCE (the reference then returns false, ptzray_optimizer.cc:482)."""
     cam, ray, summ = pkg.api.ba_solve(scene_c1, max_num_iterations=2)
