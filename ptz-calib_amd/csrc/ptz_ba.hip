@@ -1266,6 +1266,7 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.Ldiag += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
+    if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
     b->dg.push_back(d);
   }
   while ((int)b->streams.size() < G) {
@@ -1770,6 +1771,40 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.chol.fail, (size_t)n));
   d.chol.active = d.active;
   TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));
+  // Tile-level structure of every reduced camera system: cameras that share a track couple their tiles, the T_l_w
+  // block and the rhs row couple to everything; closed under the fill of the right-looking factorisation.
+  if (!getenv("PTZ_BA_DENSE_CHOL")) {
+    const int nt = d.chol.np / CHOL_NB;
+    std::vector<unsigned char> hm((size_t)n * nt * nt, 0);
+    for (int i = 0; i < n; ++i) {
+      const SceneDev& sd = b->scenes[i];
+      unsigned char* m = hm.data() + (size_t)i * nt * nt;
+      auto tile_lo = [&](int cam) { return (cam * NC) / CHOL_NB; };
+      auto tile_hi = [&](int cam) { return (cam * NC + NC - 1) / CHOL_NB; };
+      for (int c = 0; c < sd.n_cam; ++c)
+        for (int a = tile_lo(c); a <= tile_hi(c); ++a)
+          for (int e = tile_lo(c); e <= a; ++e) m[a * nt + e] = 1;
+      for (int p = 0; p < sd.n_pair; ++p) {
+        const int ci = h_pci[sd.pair_off + p], cj = h_pcj[sd.pair_off + p];
+        for (int a = tile_lo(ci); a <= tile_hi(ci); ++a)
+          for (int e = tile_lo(cj); e <= tile_hi(cj); ++e) {
+            if (a >= e) m[a * nt + e] = 1; else m[e * nt + a] = 1;
+          }
+      }
+      // dense rows: the global block (if any) and the rhs row, index n_cam * NC .. n
+      for (int a = (sd.n_cam * NC) / CHOL_NB; a < nt; ++a)
+        for (int e = 0; e <= a; ++e) m[a * nt + e] = 1;
+      for (int k = 0; k < nt; ++k)
+        for (int x = k + 1; x < nt; ++x) {
+          if (!m[x * nt + k]) continue;
+          for (int y = k + 1; y <= x; ++y)
+            if (m[y * nt + k]) m[x * nt + y] = 1;
+        }
+    }
+    const unsigned char* dm = nullptr;
+    TRY(upload(b, hm, &dm));
+    d.chol.tmask = dm;
+  }
 #undef TRY
   d.cam_x0 = b->cam0; d.ray_x0 = b->ray0;
   d.opt.max_num_iterations = o.max_num_iterations;

@@ -72,12 +72,24 @@ __global__ void chol_pad_kernel(CholBatch cb)
 }
 
 // ---- diag: Cholesky of the diagonal tile by one 4-wave workgroup ----------------------------------------
-// lane = row i in every wave; wave w owns the columns q with (q >> 1) & 3 == w (pairs, so its LDS reads of
-// L[j][q] are 16-byte reads) and accumulates its share of  sum_{q<j} L[i][q] L[j][q];  the four partial sums
-// meet in LDS.  Then the four 16x16 diagonal blocks of L are inverted (64 lanes = 4 blocks x 16 columns) for the
-// MFMA triangular solve of chol_trsm.  Outputs: Ldiag[sys][k] = L_kk (upper part zero), Dinv[sys][k][4][16x16].
+// Blocked inside the tile, 16 columns at a time, so that the sequential part never crosses a barrier:
+//   1. the 16x16 diagonal block is factored IN REGISTERS by every wave redundantly (same arithmetic -> same bits):
+//      lane r holds row r, column steps exchange values with v_readlane, no LDS and no barrier;
+//   2. the inverse of that block follows the same way (lane c holds column c of L_bb^-1);
+//   3. the rows below are solved on the matrix cores, X = P L_bb^-T = P (L_bb^-1)^T, one 16-row block per wave;
+//   4. the trailing 16x16 blocks of the tile get  C -= X_i X_j^T  on the matrix cores.
+// Two barriers per 16 columns instead of one per column.  Outputs: Ldiag[sys][k] = L_kk (upper part zero) and
+// Dinv[sys][k][4][16x16], the inverses of its diagonal blocks for the MFMA triangular solve of chol_trsm.
 constexpr int DB = 16;              // diagonal sub-block order
 constexpr int LDD = DB + 2;         // LDS row stride of a 16x16 block
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __restrict__ Dinv, int k)
 {
   const int sys = blockIdx.y;
@@ -86,71 +98,108 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
   const int n = cb.n[sys];
   if (k * NB > n) return;  // whole block column is padding (identity)
   const double* A = cb.A + (size_t)sys * np * np;
-  __shared__ __attribute__((aligned(16))) double As[NB * LD];   // the tile A_kk (read only)
-  __shared__ __attribute__((aligned(16))) double Ls[NB * LD];   // L_kk, written column by column by the owner waves
-  __shared__ double part[2][4][NB];                             // partial sums, double-buffered over the column parity
-  __shared__ double rinv[NB];
+  __shared__ __attribute__((aligned(16))) double As[NB * LD];        // A_kk, overwritten by L_kk block column by block column
+  __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];    // L_bb^-1 of the current block, one private copy per wave
   __shared__ int okflag;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15;            // row (steps 1-2) / fragment row (steps 3-4)
+  const int fr = lane & 15, fq = lane >> 4;
   tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, As);
-  for (int idx = threadIdx.x; idx < NB * LD; idx += 256) Ls[idx] = 0.0;
   if (threadIdx.x == 0) okflag = 1;
   __syncthreads();
-  // One barrier per column: every wave finishes column j redundantly (same arithmetic -> same bits), the owner wave
-  // publishes L[:, j] for ITS OWN later reads only (a wave reads just the columns it owns), the partial-sum buffer
-  // alternates so that a wave one column ahead never overwrites partials still being read.
-  double aw[NB / 4];  // L[i][q] for this wave's columns q = 8 * (t >> 1) + 2 * w + (t & 1)
   bool ok = true;
+  double* dv = Dv[w];
+#pragma unroll 1
+  for (int b = 0; b < NB / DB; ++b) {
+    // ---- 1. factor the diagonal block in registers (right-looking; lanes 16..63 mirror lanes 0..15)
+    double a[DB], ird[DB];
+    {
+      const double* src = As + (DB * b + r) * LD + DB * b;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double p0 = 0, p1 = 0;
-#pragma unroll
-    for (int t = 0; t < NB / 4; t += 2) {
-      const int q = 8 * (t >> 1) + 2 * w;  // first column of the pair; w is wave-uniform
-      if (q + 1 < j) {
-        const double2 l2 = *reinterpret_cast<const double2*>(Ls + j * LD + q);
-        p0 += aw[t] * l2.x;
-        p1 += aw[t + 1] * l2.y;
-      }
-      else if (q < j) {
-        p0 += aw[t] * Ls[j * LD + q];
+      for (int q = 0; q < DB; q += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(src + q);
+        a[q] = v.x; a[q + 1] = v.y;
       }
     }
-    double (*pb)[NB] = part[j & 1];
-    pb[w][lane] = p0 + p1;
-    __syncthreads();
-    const double sres = As[lane * LD + j] - ((pb[0][lane] + pb[1][lane]) + (pb[2][lane] + pb[3][lane]));
-    const double d = As[j * LD + j] - ((pb[0][j] + pb[1][j]) + (pb[2][j] + pb[3][j]));  // pivot: broadcast reads, same sum order
-    if (!(d > 0.0) && (k * NB + j) < n) ok = false;
-    const double ird = rsqrt_nr(d);
-    const double l = (lane == j) ? d * ird : ((lane > j) ? sres * ird : 0.0);
-    if (((j >> 1) & 3) == w) {
-      aw[2 * (j >> 3) + (j & 1)] = l;
-      Ls[lane * LD + j] = l;
-      if (lane == j) rinv[j] = ird;
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+      const double d = readlane_f64(a[j], j);
+      if (!(d > 0.0) && (k * NB + DB * b + j) < n) ok = false;
+      ird[j] = rsqrt_nr(d);
+      const double l = (r == j) ? d * ird[j] : ((r > j) ? a[j] * ird[j] : 0.0);
+      a[j] = l;
+#pragma unroll
+      for (int q = j + 1; q < DB; ++q) a[q] -= l * readlane_f64(l, q);  // A[r][q] -= L[r][j] L[q][j]
     }
-  }
-  if (!ok && threadIdx.x == 0) okflag = 0;
-  __syncthreads();
-  // publish L_kk (the strict upper triangle was zero-initialised)
-  tile_s2g<256>(Ls, cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB);
-  if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
-  // inverses of the four 16x16 diagonal blocks: lane -> (block b, column c), forward substitution on e_c
-  if (w == 0) {
-    const int b = lane >> 4, c = lane & 15;
-    const double* Lb = Ls + (b * DB) * LD + b * DB;
+    // ---- 2. x = column c of L_bb^-1 by forward substitution; L[i][q] comes from lane i
     double x[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) {
-      double acc = (i == c) ? 1.0 : 0.0;
+      double acc0 = (i == r) ? 1.0 : 0.0, acc1 = 0.0;
 #pragma unroll
-      for (int q = 0; q < i; ++q) acc -= Lb[i * LD + q] * x[q];
-      x[i] = (i >= c) ? acc * rinv[b * DB + i] : 0.0;
+      for (int q = 0; q < i; ++q) {
+        const double lv = readlane_f64(a[q], i);
+        if (q & 1) acc1 -= lv * x[q]; else acc0 -= lv * x[q];
+      }
+      x[i] = (i >= r) ? (acc0 + acc1) * ird[i] : 0.0;
     }
-    double* out = Dinv + (((size_t)sys * nt + k) * 4 + b) * (DB * DB);
+    if (lane < DB) {
 #pragma unroll
-    for (int i = 0; i < DB; ++i) out[i * DB + c] = x[i];
+      for (int i = 0; i < DB; ++i) dv[i * LDD + r] = x[i];
+    }
+    if (w == 0 && lane < DB) {
+      double* out = Dinv + (((size_t)sys * nt + k) * 4 + b) * (DB * DB);
+#pragma unroll
+      for (int i = 0; i < DB; ++i) out[i * DB + r] = x[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): dv is private to this wave
+    // ---- 3. rows below: X = P (L_bb^-1)^T, wave w takes row block b + 1 + w
+    const int rb = b + 1 + w;
+    if (rb < NB / DB) {
+      double* P = As + (DB * rb) * LD + DB * b;
+      d4 xc = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[fr * LD + 4 * ks + fq], dv[fr * LDD + 4 * ks + fq], xc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P[(fq + 4 * i) * LD + fr] = xc[i];
+    }
+    __syncthreads();
+    if (w == 3 && lane < DB) {  // every wave has read the block by now: store L_bb with a clean upper triangle
+      double* dst = As + (DB * b + r) * LD + DB * b;
+#pragma unroll
+      for (int q = 0; q < DB; ++q) dst[q] = (q <= r) ? a[q] : 0.0;
+    }
+    // ---- 4. trailing blocks (ri >= rj > b): C -= X_ri X_rj^T, dealt round-robin to the waves
+    {
+      int t = 0;
+      for (int ri = b + 1; ri < NB / DB; ++ri)
+        for (int rj = b + 1; rj <= ri; ++rj, ++t) {
+          if ((t & 3) != w) continue;
+          double* C = As + (DB * ri) * LD + DB * rj;
+          const double* Xi = As + (DB * ri) * LD + DB * b;
+          const double* Xj = As + (DB * rj) * LD + DB * b;
+          d4 acc;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = C[(fq + 4 * i) * LD + fr];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[fr * LD + 4 * ks + fq], Xj[fr * LD + 4 * ks + fq], acc, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = acc[i];
+        }
+    }
+    __syncthreads();
   }
+  if (!ok && threadIdx.x == 0) okflag = 0;
+  // the strict upper triangle outside the diagonal blocks still holds A's entries: clear it before publishing
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    const int row = idx >> 6, col = idx & 63;
+    if ((col >> 4) > (row >> 4)) As[row * LD + col] = 0.0;
+  }
+  __syncthreads();
+  tile_s2g<256>(As, cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB);
+  if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
 }
 
 // ---- trsm: X L_kk^T = A_ik for one off-diagonal tile, blocked by 16 columns, on the matrix cores --------
@@ -167,6 +216,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
   const int n = cb.n[sys];
   const int ti = k + 1 + bx;
   if (k * NB > n || ti * NB > n) return;  // padding
+  if (cb.tmask && !cb.tmask[((size_t)sys * nt + ti) * nt + k]) return;  // structurally zero tile
   double* A = cb.A + (size_t)sys * np * np;
   __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
   __shared__ __attribute__((aligned(16))) double Di[4 * DB * LDD];
@@ -248,6 +298,10 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
   if (ii >= m) return;
   const int ti = k + 1 + ii, tj = k + 1 + jj;
   if (ti * NB > n) return;  // rows of this tile are beyond the rhs row: nothing to update
+  if (cb.tmask) {
+    const unsigned char* tm = cb.tmask + (size_t)sys * nt * nt;
+    if (!tm[ti * nt + k] || !tm[tj * nt + k]) return;  // L_ik or L_jk is structurally zero
+  }
   double* A = cb.A + (size_t)sys * np * np;
   __shared__ __attribute__((aligned(16))) double As[NB * LD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * LD];

@@ -92,6 +92,11 @@ struct CholBatch {
   const int* n = nullptr;   // device [count]
   int* fail = nullptr;      // device [count]: set to 1 if a pivot <= 0 is met in rows < n_i
   const int* active = nullptr;  // device [count] or nullptr; systems with active == 0 are skipped
+  // device [count][nt * nt] or nullptr (dense): tmask[i * nt + j] != 0  <=>  tile (i, j), i >= j, of L can be non-zero
+  // (structure of the reduced camera system closed under the fill of a tile-level symbolic factorisation; the tile row
+  // holding the rhs row is full).  Tiles outside the mask stay exactly zero and their panel / update work is skipped:
+  // the tile-granular counterpart of the sparse Cholesky behind the reference's SPARSE_SCHUR (ptzray_optimizer.cc:471).
+  const unsigned char* tmask = nullptr;
 };
 inline int chol_padded_order(int n_max) { return ((n_max + 1 + CHOL_NB - 1) / CHOL_NB) * CHOL_NB; }
 // enqueue factorisation + solve on `stream`; x: device [count][np]
