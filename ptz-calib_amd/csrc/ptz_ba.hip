@@ -433,8 +433,9 @@ __global__ void k_jacobi_scale(Dev d)
 }
 
 // ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
+constexpr int LM_THREADS = 1024;  // the LM bookkeeping kernels are one workgroup per scene: wide, to shorten their reductions
 template <int TYPE>
-__global__ __launch_bounds__(256) void k_lm_pre(Dev d)
+__global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.x;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
     double c = 0, gm = 0, xn = 0;
     const double* cam = cur_cam(d, s, st);
     const int* cp = d.cam_ptr + s.cam_off + s.idx;
-    for (int i = tid; i < s.n_cam; i += 256) {
+    for (int i = tid; i < s.n_cam; i += LM_THREADS) {
       const int gi = s.cam_off + i;
       c += d.costc[gi];
       for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(d.gc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void k_lm_pre(Dev d)
         for (int k = 0; k < 15; ++k) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
     }
     const double* ray = cur_ray(d, s, st);
-    for (int j = tid; j < s.n_ray; j += 256) {
+    for (int j = tid; j < s.n_ray; j += LM_THREADS) {
       const int gj = s.ray_off + j;
       for (int k = 0; k < 3; ++k) {
         gm = fmax(gm, fabs(d.gr[(size_t)gj * 3 + k] / d.scale_r[(size_t)gj * 3 + k]));
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 
 // ---- lm_post: the body of TrustRegionMinimizer::Minimize after the step has been computed --------------
 template <int TYPE>
-__global__ __launch_bounds__(256) void k_lm_post(Dev d)
+__global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
 {
   const int sc = blockIdx.x;
   if (!d.active[sc]) return;
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
   const int tid = threadIdx.x;
   // chunk partials in chunk order (thread-strided, then the fixed block tree)
   double mcc = 0, cost = 0;
-  for (int c = tid; c < s.n_chunk + Dims<TYPE>::HAS3D; c += 256) {
+  for (int c = tid; c < s.n_chunk + Dims<TYPE>::HAS3D; c += LM_THREADS) {
     mcc += d.partial[(size_t)(s.part_off + c) * 2];
     cost += d.partial[(size_t)(s.part_off + c) * 2 + 1];
   }
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
   const double* rayc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)s.ray_off * 3;
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double dn = 0, cn = 0;
-  for (int i = tid; i < s.n_cam; i += 256) {
+  for (int i = tid; i < s.n_cam; i += LM_THREADS) {
     if (cp[i + 1] <= cp[i]) continue;
     for (int k = 0; k < 15; ++k) {
       const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
@@ -1017,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_lm_post(Dev d)
       cn += b * b;
     }
   }
-  for (int j = tid; j < s.n_ray * 3; j += 256) {
+  for (int j = tid; j < s.n_ray * 3; j += LM_THREADS) {
     const double a = ray[j], b = rayc[j];
     dn += (a - b) * (a - b);
     cn += b * b;
@@ -1288,7 +1289,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16);
   const size_t schur_smem = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   b->prof_begin(P_LMCTL);
-  LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(256), 0, d);
+  LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   b->prof_end();
   if (last) return;
   b->prof_begin(P_RAYPREP);
@@ -1311,7 +1312,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
   b->prof_begin(P_LMCTL);
-  LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(256), 0, d);
+  LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   b->prof_end();
   {
     const Dev& dd = d;
@@ -1804,6 +1805,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     const unsigned char* dm = nullptr;
     TRY(upload(b, hm, &dm));
     d.chol.tmask = dm;
+    // tiles outside the structure are never written again: zero everything once (the block may be a recycled one)
+    if (hipMemset(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   }
 #undef TRY
   d.cam_x0 = b->cam0; d.ray_x0 = b->ray0;

@@ -59,6 +59,23 @@ __device__ __forceinline__ void tile_s2g(const double* s, double* __restrict__ g
   }
 }
 
+// ---- clear the tiles of the lower-triangular structure ------------------------------------------------
+__global__ __launch_bounds__(256) void chol_clear_tiles_kernel(CholBatch cb)
+{
+  const int sys = blockIdx.y;
+  if (cb.active && !cb.active[sys]) return;
+  const int np = cb.np, nt = np / NB;
+  const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+  if (tj > ti || !cb.tmask[((size_t)sys * nt + ti) * nt + tj]) return;
+  double* T = cb.A + (size_t)sys * np * np + (size_t)(ti * NB) * np + tj * NB;
+#pragma unroll
+  for (int p = 0; p < (NB * NB / 2) / 256; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    *reinterpret_cast<double2*>(T + (size_t)row * np + c2) = make_double2(0.0, 0.0);
+  }
+}
+
 // ---- padding: identity rows beyond n, CHOL_BIG at (n, n) --------------------------------------------
 __global__ void chol_pad_kernel(CholBatch cb)
 {
@@ -346,6 +363,9 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb
   double* xs = smem;              // [np]  y, overwritten by x
   double* Lt = xs + np;           // [NB * LD]
   double* xk = Lt + NB * LD;      // [NB]
+  double* red = xk + NB;          // [BS_THREADS] quarter sums of the update
+  double* xb = red + BS_THREADS;  // [NB]
+  double* Dvs = xb + NB;          // [4 * DB * DB] inverses of the diagonal blocks of L_kk
   const int tid = threadIdx.x;
   // y = row n of L: its entries in block columns left of the diagonal tile were updated in place, the
   // ones inside the diagonal tile of row n live in Ldiag (diagonal tiles are never written back to A)
@@ -363,35 +383,75 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb
       const int row = idx >> 5, c2 = (idx & 31) * 2;
       *reinterpret_cast<double2*>(Lt + row * LD + c2) = *reinterpret_cast<const double2*>(Ld + row * NB + c2);
     }
+    {
+      const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+      for (int idx = tid; idx < 4 * DB * DB; idx += BS_THREADS) Dvs[idx] = Dg[idx];
+    }
     __syncthreads();
     if (tid < 64) {
-      double rc = xs[c0 + tid];
-      const double inv = 1.0 / Lt[tid * LD + tid];
-      double xc = 0;
-      for (int i = NB - 1; i >= 0; --i) {
-        double xi = __shfl(rc * inv, i, WAVE);
-        if (c0 + i >= n) xi = 0.0;
-        if (tid == i) xc = xi;
-        if (tid < i) rc -= Lt[i * LD + tid] * xi;
+      // x_k = L_kk^-T y_k by 16-row blocks from the bottom: x_b = (L_bb^-1)^T v_b, then v_r -= sum_i L[16b+i][r] x_b[i] for
+      // the rows above.  One wave, values pass between lanes through the wave-private strips xk / xb.
+      double yv = (c0 + tid < n) ? xs[c0 + tid] : 0.0;
+#pragma unroll
+      for (int bb = NB / DB - 1; bb >= 0; --bb) {
+        xk[tid] = yv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double xc = 0;
+        if ((tid >> 4) == bb) {
+          const int c = tid & 15;
+          double q0 = 0, q1 = 0;
+#pragma unroll
+          for (int i = 0; i < DB; i += 2) {
+            q0 += Dvs[bb * DB * DB + i * DB + c] * xk[DB * bb + i];
+            q1 += Dvs[bb * DB * DB + (i + 1) * DB + c] * xk[DB * bb + i + 1];
+          }
+          xc = (c0 + tid < n) ? q0 + q1 : 0.0;
+          xb[tid] = xc;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (tid < DB * bb) {
+          double q0 = 0, q1 = 0;
+#pragma unroll
+          for (int i = 0; i < DB; i += 2) {
+            q0 += Lt[(DB * bb + i) * LD + tid] * xb[DB * bb + i];
+            q1 += Lt[(DB * bb + i + 1) * LD + tid] * xb[DB * bb + i + 1];
+          }
+          yv -= q0 + q1;
+        }
+        if ((tid >> 4) == bb) yv = xc;
       }
-      xs[c0 + tid] = xc;
-      xk[tid] = xc;
+      xs[c0 + tid] = yv;
+      xk[tid] = yv;
     }
     __syncthreads();
-    // y_j -= sum_r L[c0 + r][j] x_k[r], j < c0
-    for (int j = tid; j < c0; j += BS_THREADS) {
-      const double* col = A + (size_t)c0 * np + j;
-      double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll 4
-      for (int r = 0; r < NB; r += 4) {
-        p0 += col[(size_t)r * np] * xk[r];
-        p1 += col[(size_t)(r + 1) * np] * xk[r + 1];
-        p2 += col[(size_t)(r + 2) * np] * xk[r + 2];
-        p3 += col[(size_t)(r + 3) * np] * xk[r + 3];
+    // y_j -= sum_r L[c0 + r][j] x_k[r], j < c0.  Thread = (column j, quarter of the 64 rows): 16 independent loads in
+    // flight per thread, the four quarter sums of a column meet in LDS in a fixed order.
+    for (int j0 = 0; j0 < c0; j0 += BS_THREADS / 4) {
+      const int j = j0 + (tid & (BS_THREADS / 4 - 1)), qr = tid / (BS_THREADS / 4);
+      double part = 0;
+      if (j < c0) {
+        const double* col = A + (size_t)(c0 + 16 * qr) * np + j;
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = col[(size_t)r * np];
+        double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          p0 += v[r] * xk[16 * qr + r];
+          p1 += v[r + 1] * xk[16 * qr + r + 1];
+          p2 += v[r + 2] * xk[16 * qr + r + 2];
+          p3 += v[r + 3] * xk[16 * qr + r + 3];
+        }
+        part = (p0 + p1) + (p2 + p3);
       }
-      xs[j] -= (p0 + p1) + (p2 + p3);
+      red[tid] = part;
+      __syncthreads();
+      if (qr == 0 && j < c0) {
+        const int q = BS_THREADS / 4;
+        xs[j] -= (red[tid] + red[tid + q]) + (red[tid + 2 * q] + red[tid + 3 * q]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (int j = tid; j < np; j += BS_THREADS) xout[(size_t)sys * np + j] = (j < n) ? xs[j] : 0.0;
 }
@@ -400,7 +460,15 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb
 
 void chol_clear(const CholBatch& cb, hipStream_t stream)
 {
-  (void)hipMemsetAsync(cb.A, 0, sizeof(double) * (size_t)cb.count * cb.np * cb.np, stream);
+  if (cb.tmask) {
+    // only the tiles of the structure are ever written (by the assembly and by the fill of the factorisation); the rest
+    // of A was zeroed once when the batch was created and stays zero
+    const int nt = cb.np / NB;
+    hipLaunchKernelGGL(chol_clear_tiles_kernel, dim3(nt * nt, cb.count), dim3(256), 0, stream, cb);
+  }
+  else {
+    (void)hipMemsetAsync(cb.A, 0, sizeof(double) * (size_t)cb.count * cb.np * cb.np, stream);
+  }
   dim3 grid((cb.np + 255) / 256, cb.count);
   hipLaunchKernelGGL(chol_pad_kernel, grid, dim3(256), 0, stream, cb);
 }
@@ -419,7 +487,7 @@ void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode)
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
-  const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + NB);
+  const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + NB + BS_THREADS + NB + 4 * 16 * 16);
   hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1, cb.count), dim3(BS_THREADS), smem, stream, cb, x);
 }
 
