@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--obs", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-scene", action="store_true", help="also time one scene alone (latency-bound C2)")
+    ap.add_argument("--iba", action="store_true",
+                    help="also run the whole PTZ-IBA orchestration (seed pair, registrations, bundle adjustments) on one rig")
     args = ap.parse_args()
 
     import numpy as np
@@ -188,6 +190,19 @@ def main():
             out["single_scene"] = {"lm_iterations_per_s": s1[0]["num_lm_steps"] / d1, "ms_per_solve": 1e3 * d1,
                                    "lm_steps": s1[0]["num_lm_steps"]}
             b1.close()
+        if args.iba:
+            # views calibrated / s of the full incremental pipeline (PtzIncrementalOptimizer, C++ host class, every
+            # solve on the device): one rig of the same shape, starting from uncalibrated cameras
+            tb = pkg.synth.make_match_table(base[0])
+            cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
+            pkg.hostlib.incremental_solve(tb, cam0, max_iter=200)  # warm-up (resource pool, code objects)
+            t1 = time.perf_counter(); r = pkg.hostlib.incremental_solve(tb, cam0, max_iter=200); d1 = time.perf_counter() - t1
+            reg = r["registered"]
+            out["ptz_iba"] = {"views": tb.n_img, "registered": len(reg), "wall_ms": 1e3 * d1, "views_per_s": len(reg) / d1,
+                              "bundle_adjustments": sum(1 for e in r["events"] if e[0] == 2), "lm_iterations": r["lm_iterations"],
+                              "registrations": sum(1 for e in r["events"] if e[0] == 1),
+                              "max_focal_rel_error": float(np.abs(r["cameras"][reg, 0] / base[0].cam_gt[reg, 0] - 1).max()) if reg else None,
+                              "timing_ms": {k: round(float(v), 2) for k, v in r["timing_ms"].items()}}
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the reference-faithful oracle (central-difference Jacobians over all 18 block
             # parameters as ceres::NumericDiffCostFunction, Ceres-1.14 LM policy, dense Schur) on ONE scene of the

@@ -1,0 +1,52 @@
+"""ctypes access to libptzcalib_host.so, the C++ mirror of the reference's optimizer classes (ptz-calib_amd/host/):
+only what bench.py needs -- the PTZ-IBA orchestration (PtzIncrementalOptimizer).  Plumbing, not the product."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libptzcalib_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (or make -C ptz-calib_amd/host)")
+        _lib = C.CDLL(path)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def incremental_solve(table, cam15, max_iter: int = 200, seeds=()):
+    """PtzIncrementalOptimizer(features, matches_info, cameras, max_iter).Solve(cameras, reg_image_ids)
+    (src/core/ptz_incremental_optimizer.h:21-44).  `table` is a synth.MatchTable.  Returns a dict."""
+    tb = table
+    cam = np.array(cam15, dtype=np.float64, order="C").copy()
+    reg = np.zeros(tb.n_img, dtype=np.int32)
+    max_events = 16 * tb.n_img + 256
+    ev = np.zeros((max_events, 4), dtype=np.int64)
+    seeds = np.array(list(seeds), dtype=np.int64)
+    nit = C.c_int64(0)
+    solved = C.c_int32(0)
+    timing = np.zeros(5)
+    H = np.ascontiguousarray(tb.H, dtype=np.float64)
+    hv = np.ascontiguousarray(tb.h_valid, dtype=np.int32)
+    conf = np.ascontiguousarray(tb.confidence, dtype=np.float64)
+    wh = np.ascontiguousarray(tb.img_wh, dtype=np.int32)
+    ne = lib().ptzh_incremental_solve(tb.n_img, _p(tb.kp_ptr), _p(tb.kp_xy), _p(wh), tb.n_pairs, _p(tb.src), _p(tb.dst),
+                                      _p(tb.match_ptr), _p(tb.q), _p(tb.t), _p(H), _p(hv), _p(conf), _p(cam),
+                                      _p(seeds) if len(seeds) else None, len(seeds), max_iter, _p(reg), _p(ev), max_events,
+                                      C.byref(nit), C.byref(solved), _p(timing))
+    events = [tuple(int(x) for x in row) for row in ev[:max(ne, 0)]]
+    return dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)), events=events,
+                lm_iterations=int(nit.value),
+                timing_ms=dict(ranking=timing[0], bundle_total=timing[1], bundle_device=timing[2], registration_total=timing[3],
+                               registration_device=timing[4]))
