@@ -5,5 +5,5 @@ reference's PTZRayOptimizer / KRTOptimizer signatures).  This Python package is 
 the benchmark: a ctypes binding of the C-ABI (api.py) and the synthetic rig generator (synth.py).
 The directory name has a hyphen, so import it through __graft_entry__.load_package().
 """
-from . import evalmetrics, hostlib, sharding, synth  # noqa: F401
+from . import dataset_io, evalmetrics, hostlib, sharding, synth  # noqa: F401
 from .api import *  # noqa: F401,F403

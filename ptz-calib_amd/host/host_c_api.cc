@@ -3,7 +3,11 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "data_io.h"
 #include "epnp.h"
+#include "homography.h"
+#include "image_size.h"
+#include "json_mini.h"
 #include "krt_optimizer.h"
 #include "ptz_incremental_optimizer.h"
 #include "ptzray_optimizer.h"
@@ -241,6 +245,121 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
     memcpy(cam15 + 15 * i, v.data(), sizeof(double) * 15);
   }
   return ne;
+}
+
+// ---- file formats (data_io) for the tests: every probe answers with a JSON text (malloc'ed, free with ptzh_free) ------
+static char* DupText(const std::string& s)
+{
+  char* p = static_cast<char*>(malloc(s.size() + 1));
+  memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+// cmd = "load": a = image dir, b = feature dir  -> {ok, fnames, sizes, n_keypoints, first_keypoint, pairs:[{src,dst,n,H,H_empty,confidence}]}
+// cmd = "annotation": a = annotation json, b = image dir (for the file names) -> {ok, pixels, pts3d}
+// cmd = "rewrite": a = camera json in, b = camera json out (ReadFromJson -> SaveToJson)  -> {ok, names}
+// cmd = "image_size": a = file -> {ok, width, height}
+// cmd = "json": a = JSON text -> {ok, dump}
+char* ptzh_io_probe(const char* cmd_c, const char* a_c, const char* b_c)
+{
+  const std::string cmd = cmd_c ? cmd_c : "", a = a_c ? a_c : "", b = b_c ? b_c : "";
+  Json out = Json::Object();
+  if (cmd == "image_size") {
+    Size sz;
+    const bool ok = ReadImageSize(a, sz);
+    out["ok"] = Json::Bool(ok);
+    out["width"] = Json::Int(sz.width);
+    out["height"] = Json::Int(sz.height);
+  }
+  else if (cmd == "json") {
+    Json v;
+    std::string err;
+    const bool ok = Json::Parse(a, v, &err);
+    out["ok"] = Json::Bool(ok);
+    out["dump"] = Json::String(ok ? v.dump(4) : err);
+  }
+  else if (cmd == "load") {
+    std::vector<std::string> fnames;
+    std::vector<ImageFeatures> features;
+    std::vector<Size> sizes;
+    const bool ok = LoadImgsAndFeatures(a, b, fnames, features, sizes);
+    out["ok"] = Json::Bool(ok);
+    Json jn = Json::Array(), js = Json::Array(), jk = Json::Array(), jf = Json::Array();
+    for (size_t i = 0; i < fnames.size(); ++i) {
+      jn.push_back(Json::String(fnames[i]));
+      Json s = Json::Array(); s.push_back(Json::Int(sizes[i].width)); s.push_back(Json::Int(sizes[i].height)); js.push_back(s);
+      jk.push_back(Json::Int(static_cast<long long>(features[i].keypoints.size())));
+      Json f = Json::Array();
+      if (!features[i].keypoints.empty()) { f.push_back(Json::Float(features[i].keypoints[0].pt.x)); f.push_back(Json::Float(features[i].keypoints[0].pt.y)); }
+      jf.push_back(f);
+    }
+    out["fnames"] = jn; out["sizes"] = js; out["n_keypoints"] = jk; out["first_keypoint"] = jf;
+    Json jp = Json::Array();
+    if (ok) {
+      std::vector<MatchesInfo> mis;
+      LoadMatchesInfo(b + "/pairs_matches.txt", fnames, features, mis);
+      out["table_cells"] = Json::Int(static_cast<long long>(mis.size()));
+      for (const MatchesInfo& mi : mis) {
+        if (mi.matches.empty()) continue;
+        Json p = Json::Object();
+        p["src"] = Json::Int(mi.src_img_idx); p["dst"] = Json::Int(mi.dst_img_idx); p["n"] = Json::Int(static_cast<long long>(mi.matches.size()));
+        p["H"] = Json::FloatArray(std::vector<double>(mi.H.begin(), mi.H.end()));
+        p["H_empty"] = Json::Bool(mi.H_empty);
+        p["confidence"] = Json::Float(mi.confidence);
+        p["first_match"] = Json::FloatArray({static_cast<double>(mi.matches[0].queryIdx), static_cast<double>(mi.matches[0].trainIdx)});
+        jp.push_back(p);
+      }
+    }
+    out["pairs"] = jp;
+  }
+  else if (cmd == "annotation") {
+    std::vector<std::string> fnames;
+    std::vector<ImageFeatures> features;
+    std::vector<Size> sizes;
+    LoadImgsAndFeatures(b, b, fnames, features, sizes);
+    std::vector<std::vector<Point2f>> pixels;
+    std::vector<std::vector<Point3d>> pts3d;
+    const bool ok = LoadAnnotation(a, fnames, pixels, pts3d);
+    out["ok"] = Json::Bool(ok);
+    Json jp = Json::Array(), jq = Json::Array();
+    for (size_t i = 0; i < pixels.size(); ++i) {
+      Json pi = Json::Array(), qi = Json::Array();
+      for (size_t k = 0; k < pixels[i].size(); ++k) {
+        pi.push_back(Json::FloatArray({pixels[i][k].x, pixels[i][k].y}));
+        qi.push_back(Json::FloatArray({pts3d[i][k].x, pts3d[i][k].y, pts3d[i][k].z}));
+      }
+      jp.push_back(pi); jq.push_back(qi);
+    }
+    out["pixels"] = jp; out["pts3d"] = jq;
+  }
+  else if (cmd == "rewrite") {
+    std::vector<Camera> cams;
+    std::vector<std::string> names;
+    std::vector<std::vector<Point2f>> pixels;
+    std::vector<std::vector<Point3d>> pts3d;
+    std::vector<Size> sizes;
+    bool ok = ReadFromJson(a, cams, names, pixels, pts3d, sizes);
+    if (ok) ok = SaveToJson(cams, names, pixels, pts3d, b);
+    out["ok"] = Json::Bool(ok);
+    Json jn = Json::Array();
+    for (const std::string& n : names) jn.push_back(Json::String(n));
+    out["names"] = jn;
+  }
+  else out["ok"] = Json::Bool(false);
+  return DupText(out.dump(4));
+}
+
+// cv::findHomography(src, dst, RANSAC, thresh, mask) replacement: returns 1 and fills H9 / mask[n], or 0 (empty H)
+int32_t ptzh_find_homography(int32_t n, const float* src, const float* dst, double thresh, double* H9, unsigned char* mask)
+{
+  std::vector<Point2f> a, b;
+  for (int i = 0; i < n; ++i) { a.emplace_back(src[2 * i], src[2 * i + 1]); b.emplace_back(dst[2 * i], dst[2 * i + 1]); }
+  Mat33 H;
+  std::vector<unsigned char> m;
+  if (!FindHomographyRansac(a, b, thresh, H, &m)) return 0;
+  for (int k = 0; k < 9; ++k) H9[k] = H[k];
+  if (mask) memcpy(mask, m.data(), m.size());
+  return 1;
 }
 
 // KRTOptimizer through the C++ class: one query.  cam_cur15 in (initial, world) / out (refined, world).

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
 inputs.  Tolerances are stated per test.  BASELINE north_star: parameters within 1e-6 relative of the
 reference CPU solver, bit-exact track indexing."""
+import os
+
 import numpy as np
 import pytest
 
@@ -455,3 +457,74 @@ def test_incremental_optimizer_matches_restatement(pkg, orc, seed, n_views, bidi
         Rg = orc.rodrigues(sc.cam_gt[i, 4:7]) @ orc.rodrigues(sc.cam_gt[r0, 4:7]).T
         d = (R[i] @ R[r0].T) @ Rg.T
         assert np.degrees(np.arccos(np.clip((np.trace(d) - 1) / 2, -1, 1))) < 0.1
+
+
+# ------------------------------------------------------------------------------------------- the command-line tools (next-2)
+def _run_tool(name, *args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ptz-calib_amd", "bin", name)
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+
+
+def test_run_ptz_ba_tool_end_to_end(pkg, orc, tmp_path):
+    """run_ptz_ba (src/app/run_ptz_ba.cc:24-154) on a synthetic rig written in the reference's on-disk formats: images ->
+    PTZ-IBA -> georeferencing -> <output>/<images basename>.json with world-frame cameras.  Exit codes: 0 / 255 (-1) / 1."""
+    import json
+    sc = pkg.synth.add_annotations(pkg.synth.make_scene(1, 20, 100))
+    tb = pkg.synth.make_match_table(sc)
+    paths = pkg.dataset_io.write_rig(str(tmp_path), sc, tb, annotations=sc.obs3d)
+    out_dir = str(tmp_path / "out")
+    r = _run_tool("run_ptz_ba", "-i", paths["images"], "-f", paths["features"], "-a", paths["annotation"], "--output=" + out_dir)
+    assert r.returncode == 0, r.stderr
+    assert "Registered/Total: 20/20" in r.stderr and "Georeferencing End: success" in r.stderr
+    res = json.load(open(os.path.join(out_dir, "rig0.json")))["cameras"]
+    assert list(res.keys()) == [os.path.splitext(n)[0] for n in paths["names"]]
+    Rlw = orc.rodrigues(sc.tlw_gt[:3])
+    for i, n in enumerate(res):
+        c = res[n]
+        assert c["res"] == [1920, 1080] and c["version"] == "2.0" and c["distType"] == ""
+        K = np.array(c["K"]).reshape(3, 3); R = np.array(c["R"]).reshape(3, 3)
+        assert abs(K[0, 0] / sc.cam_gt[i, 0] - 1) < 2e-3 and K[0, 0] == K[1, 1]
+        Rg = orc.rodrigues(sc.cam_gt[i, 4:7]) @ Rlw
+        assert np.degrees(np.arccos(np.clip((np.trace(R @ Rg.T) - 1) / 2, -1, 1))) < 0.2
+        assert np.abs(np.array(c["pos"]) - np.array([3.0, -45.0, 15.0])).max() < 0.5  # rig centre (metres)
+        sel = np.flatnonzero(sc.obs3d["cam"] == i)
+        assert len(c["marker"]["pix"]) == len(sel)
+    # failures: missing annotation -> -1 after a successful PTZ-IBA; missing images -> -1; bad options -> 1
+    r2 = _run_tool("run_ptz_ba", "-i", paths["images"], "-f", paths["features"], "-o", out_dir)
+    assert r2.returncode == 255 and "PTZ-IBA End: success" in r2.stderr and "Error loading annotation" in r2.stderr
+    assert _run_tool("run_ptz_ba", "-i", str(tmp_path / "nope"), "-f", paths["features"], "-o", out_dir).returncode == 255
+    assert _run_tool("run_ptz_ba", "-i", paths["images"]).returncode == 1
+    assert _run_tool("run_ptz_ba", "--bogus", "x").returncode == 1
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_run_ptz_reloc_tool_matches_batch_api(pkg, orc, tmp_path, ftype):
+    """run_ptz_reloc (src/app/run_ptz_reloc.cc:23-148): per test image the reference with most matches, init from its camera with
+    the test image's principal point, one batched solve; output file holds the accepted test images only."""
+    import json
+    rb = pkg.synth.make_reloc_batch(12, 96, seed_id=6, factor_type=ftype)
+    rb.uv_cur[rb.match_ptr[3]:rb.match_ptr[4]] = rb.uv_cur[rb.match_ptr[3]:rb.match_ptr[4]][::-1]  # scrambled matches: query 3 fails
+    paths = pkg.dataset_io.write_reloc_set(str(tmp_path), rb)
+    out_dir = str(tmp_path / "out")
+    args = ["--ref_images", paths["ref_images"], "--ref_features", paths["ref_features"], "--ref_params", paths["ref_params"],
+            "--test_images", paths["test_images"], "--test_features", paths["test_features"], "--output", out_dir]
+    r = _run_tool("run_ptz_reloc", *(args + (["--dist"] if ftype else [])))
+    assert r.returncode == 0, r.stderr
+    res = json.load(open(os.path.join(out_dir, "tests.json")))["cameras"]
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    want = [os.path.splitext(paths["test_names"][q])[0] for q in range(rb.n_query) if acc[q]]
+    assert list(res.keys()) == want and 0 < len(want) < rb.n_query
+    for q in range(rb.n_query):
+        name = os.path.splitext(paths["test_names"][q])[0]
+        if not acc[q]:
+            assert ("failed: " + paths["test_names"][q]) in r.stderr
+            continue
+        c = res[name]
+        K = np.array(c["K"]).reshape(3, 3); R = np.array(c["R"]).reshape(3, 3)
+        # the files carry %.9g key points and shortest-round-trip camera numbers: same problem, same answer
+        assert abs(K[0, 0] / cam_w[q, 0] - 1) < 1e-9 and np.abs(R - orc.rodrigues(cam_w[q, 4:7])).max() < 1e-9
+        assert abs(K[0, 0] / rb.cam_gt[q, 0] - 1) < 5e-3
+        if ftype:
+            assert abs(c["dist"][0] - cam_w[q, 10]) < 1e-9
+    assert _run_tool("run_ptz_reloc", "--ref_images", paths["ref_images"]).returncode == 1
