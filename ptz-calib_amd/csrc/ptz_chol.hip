@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
   tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, As);
   if (threadIdx.x == 0) okflag = 1;
   __syncthreads();
-  bool ok = true;
+  double dmin = 1.0;
+  bool bad = false;
   double* dv = Dv[w];
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
@@ -138,27 +139,27 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
         a[q] = v.x; a[q + 1] = v.y;
       }
     }
+    // ---- 1 + 2 fused: lane r also carries column r of X = L_bb^-1 (x[i] = X[i][r]), built by the same column sweep
+    //      L X = I:  X[j][:] /= L[j][j];  X[i][:] -= L[i][j] X[j][:]  (i > j)  -- the scalar L[i][j] is the one the
+    //      factorisation step has just read from lane i, so the inverse costs no extra lane exchange.
+    double x[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) x[i] = (i == r) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < DB; ++j) {
       const double d = readlane_f64(a[j], j);
-      if (!(d > 0.0) && (k * NB + DB * b + j) < n) ok = false;
+      dmin = fmin(dmin, (k * NB + DB * b + j) < n ? d : 1.0);  // NaN pivots: fmin keeps the other operand, caught by l below
+      bad |= (d != d) && (k * NB + DB * b + j) < n;
       ird[j] = rsqrt_nr(d);
       const double l = (r == j) ? d * ird[j] : ((r > j) ? a[j] * ird[j] : 0.0);
       a[j] = l;
+      x[j] *= ird[j];
 #pragma unroll
-      for (int q = j + 1; q < DB; ++q) a[q] -= l * readlane_f64(l, q);  // A[r][q] -= L[r][j] L[q][j]
-    }
-    // ---- 2. x = column c of L_bb^-1 by forward substitution; L[i][q] comes from lane i
-    double x[DB];
-#pragma unroll
-    for (int i = 0; i < DB; ++i) {
-      double acc0 = (i == r) ? 1.0 : 0.0, acc1 = 0.0;
-#pragma unroll
-      for (int q = 0; q < i; ++q) {
-        const double lv = readlane_f64(a[q], i);
-        if (q & 1) acc1 -= lv * x[q]; else acc0 -= lv * x[q];
+      for (int q = j + 1; q < DB; ++q) {
+        const double lqj = readlane_f64(l, q);  // L[q][j]
+        a[q] -= l * lqj;                         // A[r][q] -= L[r][j] L[q][j]
+        x[q] -= lqj * x[j];                      // X[q][r] -= L[q][j] X[j][r]
       }
-      x[i] = (i >= r) ? (acc0 + acc1) * ird[i] : 0.0;
     }
     if (lane < DB) {
 #pragma unroll
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
     }
     __syncthreads();
   }
-  if (!ok && threadIdx.x == 0) okflag = 0;
+  if ((bad || !(dmin > 0.0)) && threadIdx.x == 0) okflag = 0;
   // the strict upper triangle outside the diagonal blocks still holds A's entries: clear it before publishing
   for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
     const int row = idx >> 6, col = idx & 63;
