@@ -349,6 +349,57 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// ---- left-looking column update: A_ij -= sum_{k < j} L_ik L_jk^T for the tiles (i, j), i >= j, of block column j -------
+// One workgroup per tile: the C tile stays in the accumulators while the loop walks the block columns k < j whose tiles
+// L_ik and L_jk are both in the structure, so C is read and written once per column step instead of once per k (the
+// right-looking update moves 128 KB per 64^3 update, this one 64 KB), and the whole factorisation needs no trailing
+// update launches.  Same arithmetic per (i, j, k) triple as chol_syrk_kernel; the k order is ascending.
+__global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int j)
+{
+  int bx, sys;
+  xcd_remap(bx, sys);
+  if (cb.active && !cb.active[sys]) return;
+  const int np = cb.np, nt = np / NB;
+  const int n = cb.n[sys];
+  const int ti = j + bx;
+  if (ti >= nt || ti * NB > n || j * NB > n) return;
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  if (tm && !tm[ti * nt + j]) return;
+  double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double As[NB * LD];
+  __shared__ __attribute__((aligned(16))) double Bs[NB * LD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  double* C = A + (size_t)(ti * NB + 16 * w) * np + j * NB;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
+  const double* ap = As + (16 * w + fr) * LD + fq;
+  const double* bp = Bs + fr * LD + fq;
+  bool any = false;
+  for (int k = 0; k < j; ++k) {
+    if (tm && (!tm[ti * nt + k] || !tm[j * nt + k])) continue;  // uniform over the workgroup
+    any = true;
+    __syncthreads();  // the previous step's fragment reads are done
+    tile_g2s<256, true>(A + (size_t)(ti * NB) * np + k * NB, np, As);   // -L_ik
+    tile_g2s<256, false>(A + (size_t)(j * NB) * np + k * NB, np, Bs);   //  L_jk
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double av = ap[4 * kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
+    }
+  }
+  if (!any) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+}
+
 // ---- back substitution L^T x = y (y = row n of the factored matrix) ---------------------------------
 // Column-oriented: for k = last..first  { x_k = L_kk^-T y_k ;  y_j -= L[k-tile rows][j] x_k for all j < k*NB }.
 // The update reads the row panel of tile k, one thread per column -> fully coalesced row reads.
@@ -485,6 +536,11 @@ void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode)
   const int m = cb.np / NB - k - 1;
   const int tiles = mode == 0 ? m * (m + 1) / 2 : (mode == 1 ? m : m * (m - 1) / 2);
   if (tiles > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode);
+}
+void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream)
+{
+  const int m = cb.np / NB - j;
+  if (j > 0 && m > 0) hipLaunchKernelGGL(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j);
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {

@@ -105,6 +105,7 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream);
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode);  // 0 all, 1 column k+1, 2 rest
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
+void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream);  // left-looking: column j -= all earlier columns
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
 void chol_clear(const CholBatch& cb, hipStream_t stream);
 
