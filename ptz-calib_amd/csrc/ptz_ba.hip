@@ -1656,49 +1656,61 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         for (int c = 0; c < p.n_cam; ++c) b->max_cam_obs = std::max(b->max_cam_obs, fill[c]);
         for (int64_t a = 0; a < p.n_obs; ++a) h_wpos.push_back(obase + cnt_cam[p.obs_cam[a]] + pos[a]);
       }
-      std::vector<int64_t> keys;  // (ci * n_cam + cj) << 32 | running index
-      std::vector<int2> ents;
-      for (int j = 0; j < p.n_ray; ++j) {
+      // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable)
+      const size_t ncc = (size_t)p.n_cam * p.n_cam;
+      std::vector<int> pair_cnt(ncc, 0);
+      int64_t n_ent = 0;
+      for (int j = 0; j < p.n_ray; ++j)
         for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
           for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
             const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
             if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
             if (ci <= cj) continue;
-            keys.push_back(((int64_t)ci * p.n_cam + cj) << 32 | (int64_t)ents.size());
-            ents.push_back(make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]));  // (LDS slot of T_a, W row of b)
+            ++pair_cnt[(size_t)ci * p.n_cam + cj];
+            ++n_ent;
           }
-      }
-      std::sort(keys.begin(), keys.end());
-      if ((int64_t)b->total_ent + (int64_t)ents.size() > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
-      int64_t prev = -1;
+      if ((int64_t)b->total_ent + n_ent > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
       int npair = 0;
-      std::vector<int> cam_first(p.n_cam + 1, -1);
-      for (size_t e = 0; e < keys.size(); ++e) {
-        const int64_t key = keys[e] >> 32;
-        if (key != prev) {
-          const int ci = (int)(key / p.n_cam);
-          h_pci.push_back(ci);
-          h_pcj.push_back((int)(key % p.n_cam));
-          h_pptr.push_back(b->total_ent + (int)e);
-          if (cam_first[ci] < 0) cam_first[ci] = npair;
-          prev = key;
-          ++npair;
-        }
-        h_ent.push_back(ents[keys[e] & 0xffffffff]);
+      std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
+      std::vector<int> pair_fill(ncc, -1);  // next free entry slot of a pair (scene-local)
+      {
+        int run = 0;
+        for (int ci = 0; ci < p.n_cam; ++ci)
+          for (int cj = 0; cj < ci; ++cj) {
+            const int c = pair_cnt[(size_t)ci * p.n_cam + cj];
+            if (c == 0) continue;
+            h_pci.push_back(ci);
+            h_pcj.push_back(cj);
+            h_pptr.push_back(b->total_ent + run);
+            if (cam_first[ci] < 0) cam_first[ci] = npair;
+            pair_fill[(size_t)ci * p.n_cam + cj] = run;
+            cam_ent[ci] += c;
+            run += c;
+            ++npair;
+          }
+        h_pptr.push_back(b->total_ent + run);
       }
-      h_pptr.push_back(b->total_ent + (int)keys.size());
+      {
+        const size_t ebase = h_ent.size();
+        h_ent.resize(ebase + (size_t)n_ent);
+        for (int j = 0; j < p.n_ray; ++j)
+          for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
+            for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
+              const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
+              if (ci <= cj) continue;
+              const int slot = pair_fill[(size_t)ci * p.n_cam + cj]++;
+              h_ent[ebase + slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
+            }
+      }
+      const int64_t n_keys = n_ent;
       // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
       cam_first[p.n_cam] = npair;
-      {
-        std::vector<int> cnt(p.n_cam, 0);
-        for (size_t e = 0; e < keys.size(); ++e) ++cnt[(int)((keys[e] >> 32) / p.n_cam)];
-        for (int c = 0; c < p.n_cam; ++c) b->max_cam_ent = std::max(b->max_cam_ent, cnt[c]);
-      }
+      for (int c = 0; c < p.n_cam; ++c) b->max_cam_ent = std::max(b->max_cam_ent, cam_ent[c]);
       for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
       for (int c = 0; c <= p.n_cam; ++c) h_campair.push_back(cam_first[c]);
       for (int c = 0; c < p.n_cam; ++c) b->max_cam_pair = std::max(b->max_cam_pair, cam_first[c + 1] - cam_first[c]);
       s.n_pair = npair;
-      b->total_ent += (int)keys.size();
+      b->total_ent += (int)n_keys;
       b->total_pair += npair;
     }
     b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk + 1;
@@ -2014,13 +2026,22 @@ void ptz_trim_cache(void) { ptzpool::trim(); }
 int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary)
 {
   if (!p || !cam || !ray) return PTZ_EINVAL;
+  const bool dbg = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   ptz_ba_batch* b = nullptr;
   int rc = ptz_ba_batch_create(1, p, opt, &b);
   if (rc) return rc;
+  const double t1 = now();
   rc = ptz_ba_batch_set_state(b, cam, ray, tlw);
+  const double t2 = now();
   if (!rc) rc = ptz_ba_batch_solve(b, summary);
+  const double t3 = now();
   if (!rc) rc = ptz_ba_batch_get_state(b, cam, ray, tlw);
+  const double t4 = now();
   ptz_ba_batch_destroy(b);
+  if (dbg) fprintf(stderr, "[ptz_ba_solve] n_cam %d n_obs %lld: create %.2f set_state %.2f solve %.2f get_state %.2f destroy %.2f ms\n", p->n_cam,
+                   (long long)p->n_obs, t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
   return rc;
 }
 

@@ -149,11 +149,10 @@ void PTZRayOptimizer::Pack()
     const std::vector<double> v = cameras_[i].ToVector();
     p.cam.insert(p.cam.end(), v.begin(), v.end());
   }
-  std::vector<Mat33> Rinv(p.cam_image.size()), Kinv(p.cam_image.size());
-  for (size_t c = 0; c < p.cam_image.size(); ++c) {
-    Rinv[c] = Inverse(cameras_[p.cam_image[c]].R());
-    Kinv[c] = Inverse(cameras_[p.cam_image[c]].K());
-  }
+  // R^-1 K^-1 once per camera: cv::Mat evaluates R.inv() * K.inv() * uv from the left (ptzray_optimizer.cc:786)
+  std::vector<Mat33> RKinv(p.cam_image.size());
+  for (size_t c = 0; c < p.cam_image.size(); ++c)
+    RKinv[c] = Mul(Inverse(cameras_[p.cam_image[c]].R()), Inverse(cameras_[p.cam_image[c]].K()));
   for (const auto& te : tracks()) {  // std::map: ascending track id
     const Track& track = te.second;
     Vec3 acc = {0, 0, 0};
@@ -167,7 +166,7 @@ void PTZRayOptimizer::Pack()
       p.obs_uv.push_back(pt.y);
       p.obs_cam.push_back(c);
       p.obs_ray.push_back(ray_id);
-      Vec3 t = Mul(Rinv[c], Mul(Kinv[c], Vec3{pt.x, pt.y, 1.0}));
+      const Vec3 t = Mul(RKinv[c], Vec3{pt.x, pt.y, 1.0});
       const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
       acc[0] += t[0] / n; acc[1] += t[1] / n; acc[2] += t[2] / n;
       ++n_cand;
@@ -208,9 +207,8 @@ static void Residual2d3d(const double* c, const double* tlw, const double* Xw, f
 }
 
 // host-side evaluation of the 2D-2D residual for the read-back statistics (CalReprojError2d2d, :970-1028)
-static void Residual2d2d(FACTOR_TYPE type, const double* c, const double* X, float u, float v, double* res)
+static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, const double* X, float u, float v, double* res)
 {
-  const Mat33 R = Rodrigues({c[4], c[5], c[6]});
   Vec3 x = {X[0], X[1], X[2]};
   if (type == PTZRay) {
     const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
@@ -234,11 +232,13 @@ static void Residual2d2d(FACTOR_TYPE type, const double* c, const double* X, flo
 
 bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras)
 {
-  std::vector<std::vector<Ray>> rays;
-  return Solve(cameras, rays);
+  // the reference builds the ray lists and throws them away here (ptzray_optimizer.cc:448-452); nothing reads them
+  return SolveImpl(cameras, nullptr);
 }
 
-bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays)
+bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays) { return SolveImpl(cameras, &rays); }
+
+bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>* rays_out)
 {
   if (!CheckValid()) return false;
   FindTracks();
@@ -284,9 +284,11 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
   init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);
   final_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.final_cost) / summary_.num_residuals);
   double sum0 = 0, sum1 = 0;
+  std::vector<Mat33> Rc(p.cam_image.size());  // one cv::Rodrigues per camera instead of one per residual
+  for (size_t c = 0; c < Rc.size(); ++c) Rc[c] = Rodrigues({cam[15 * c + 4], cam[15 * c + 5], cam[15 * c + 6]});
   for (size_t a = 0; a < p.obs_cam.size(); ++a) {
     double res[2];
-    Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
+    Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], Rc[p.obs_cam[a]], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
                  p.obs_uv[2 * a + 1], res);
     sum0 += res[0] * res[0];
     sum1 += res[1] * res[1];
@@ -323,11 +325,14 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vecto
     out.t() = {Rt[0] + out.t()[0], Rt[1] + out.t()[1], Rt[2] + out.t()[2]};
     out.R() = Mul(out.R(), R_l_w);
   }
-  rays.clear();
-  rays.resize(num_cams_);
   const Mat33 R_w_l = Transpose(R_l_w);
   const Vec3 Rtt = Mul(R_w_l, t_l_w);
-  for (size_t j = 0; j < p.ray_track.size(); ++j) {
+  if (rays_out) {
+    rays_out->clear();
+    rays_out->resize(num_cams_);
+  }
+  for (size_t j = 0; rays_out && j < p.ray_track.size(); ++j) {
+    std::vector<std::vector<Ray>>& rays = *rays_out;
     const Vec3 rl = Mul(R_w_l, Vec3{ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]});
     const Vec3 ray_w = {rl[0] - Rtt[0], rl[1] - Rtt[1], rl[2] - Rtt[2]};  // R_w_l ray_l + t_w_l (:746-754)
     for (const auto& kv : tracks().at(p.ray_track[j]))

@@ -66,6 +66,7 @@ class PTZRayOptimizer {
 
  private:
   bool CheckValid() const;
+  bool SolveImpl(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>* rays);
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
