@@ -528,3 +528,94 @@ def test_run_ptz_reloc_tool_matches_batch_api(pkg, orc, tmp_path, ftype):
         if ftype:
             assert abs(c["dist"][0] - cam_w[q, 10]) < 1e-9
     assert _run_tool("run_ptz_reloc", "--ref_images", paths["ref_images"]).returncode == 1
+
+
+# ------------------------------------------------------------------------------------------------------ edge cases
+def _drop_camera_observations(sc, cam_id):
+    import copy
+    keep = sc.obs_cam != cam_id
+    s = copy.copy(sc)
+    s.obs_uv = sc.obs_uv[keep]; s.obs_cam = sc.obs_cam[keep]
+    ray_old = sc.obs_ray[keep]
+    uniq, new_ray = np.unique(ray_old, return_inverse=True)  # rays that lost their only observation disappear
+    s.obs_ray = new_ray.astype(np.int32)
+    s.n_ray = len(uniq)
+    s.ray_weight = sc.ray_weight[uniq]
+    s.ray_init = sc.ray_init[uniq]; s.ray_gt = sc.ray_gt[uniq]
+    return s
+
+
+def test_ba_camera_without_observations(pkg, orc, scene_c1):
+    """A camera of the problem that no residual block touches (all its matches were filtered out): Ceres never sees its
+    parameter blocks, so it is not part of |x|, keeps its values, and its rows of the reduced system are identity."""
+    sc = _drop_camera_observations(scene_c1, 3)
+    assert sc.n_cam == scene_c1.n_cam and not np.any(sc.obs_cam == 3)
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC)
+    assert summ["termination_type"] == osumm["termination_type"] == 0 and summ["num_iterations"] == osumm["num_iterations"]
+    assert np.array_equal(cam[3], sc.cam_init[3]) and np.array_equal(ocam[3], sc.cam_init[3])
+    others = [i for i in range(sc.n_cam) if i != 3]
+    assert _rel(cam[others, 0], ocam[others, 0]) < 1e-6
+    assert np.abs(_relative_rotations(orc, cam[others]) - _relative_rotations(orc, ocam[others])).max() < 1e-6
+
+
+def test_ba_ragged_batch_is_bit_identical_to_solo_solves(pkg):
+    """Scenes of very different sizes in one batch (2, 20, 24 and 60 cameras; the padded reduced systems, LDS tables and grids
+    are sized by the largest): every scene's result has the bits of its solo solve."""
+    big = pkg.synth.make_scene(7, 60, 300)
+    mid = pkg.synth.make_scene(4, 24, 100)
+    c1 = pkg.synth.make_scene(0, 20, 100)
+    two = _two_camera_problem(pkg, c1)
+    scenes = [two, big, c1, mid]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    for k, sc in enumerate(scenes):
+        cam, ray, s = pkg.api.ba_solve(sc)
+        assert s == summ[k] and np.array_equal(cam, cams[k]) and np.array_equal(ray, rays[k])
+
+
+def _two_camera_problem(pkg, sc):
+    """Observations of cameras 0 and 1 only, re-indexed: rays seen by one or by both of them (track lengths 1 and 2), weights
+    kept at the full track length as a candidate-subset solve does (ptzray_optimizer.cc:805)."""
+    import copy
+    keep = sc.obs_cam < 2
+    s = copy.copy(sc)
+    s.n_cam = 2
+    s.obs_uv = sc.obs_uv[keep]; s.obs_cam = sc.obs_cam[keep]
+    uniq, new_ray = np.unique(sc.obs_ray[keep], return_inverse=True)
+    s.obs_ray = new_ray.astype(np.int32); s.n_ray = len(uniq)
+    s.ray_weight = sc.ray_weight[uniq]
+    s.cam_init = sc.cam_init[:2].copy(); s.cam_gt = sc.cam_gt[:2].copy()
+    s.ray_gt = sc.ray_gt[uniq]
+    s.ray_init = pkg.synth.pix2ray(s.obs_uv, s.obs_cam, s.obs_ray, s.n_ray, s.cam_init)
+    return s
+
+
+def test_ba_two_cameras_short_tracks_parity(pkg, orc, scene_c1):
+    """The seed-pair bundle adjustment of PTZ-IBA (ptz_incremental_optimizer.cc:366): two cameras, rays observed once or twice,
+    a reduced system of order 8 with a three-dimensional gauge null space held only by the LM diagonal."""
+    sc = _two_camera_problem(pkg, scene_c1)
+    lens = np.bincount(sc.obs_ray)
+    assert lens.min() == 1 and lens.max() == 2
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    for mode in (orc.JAC_ANALYTIC, orc.JAC_NUMERIC):
+        ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=mode)
+        assert summ["termination_type"] == osumm["termination_type"] and summ["num_iterations"] == osumm["num_iterations"]
+        assert abs(summ["final_cost"] - osumm["final_cost"]) <= 1e-9 * max(osumm["final_cost"], 1e-30)
+        assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6
+        assert np.abs(_relative_rotations(orc, cam) - _relative_rotations(orc, ocam)).max() < 1e-6
+
+
+def test_ba_size_limits_are_reported_not_worked_around(pkg):
+    """More cameras than the LDS-resident camera tables hold: PTZ_EUNSUPPORTED (-4), never a CPU fallback."""
+    n_cam = 600
+    rng = np.random.default_rng(0)
+    n_ray = 2 * n_cam
+    obs_cam = np.repeat(np.arange(n_cam, dtype=np.int32), 2)
+    obs_ray = np.arange(n_ray, dtype=np.int32)
+    from types import SimpleNamespace
+    sc = SimpleNamespace(n_cam=n_cam, n_ray=n_ray, n_obs=n_ray, factor_type=0, obs_uv=rng.uniform(100, 900, (n_ray, 2)).astype(np.float32),
+                         obs_cam=obs_cam, obs_ray=obs_ray, ray_weight=np.ones(n_ray), cam_init=np.tile(np.array([2000.0, 2000, 960, 540] + [0.0] * 11), (n_cam, 1)),
+                         ray_init=np.tile(np.array([0.0, 0, 1.0]), (n_ray, 1)), obs3d=None)
+    with pytest.raises(Exception) as ei:
+        pkg.api.BaBatch([sc])
+    assert "-4" in str(ei.value) or "UNSUPPORTED" in str(ei.value).upper()
