@@ -584,6 +584,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
   constexpr int NU = NW * (NW + 1) / 2;
   constexpr int NT = NW * 3;
+  constexpr int TS = NT;  // row stride of the T table in LDS (an odd stride was measured: 25 % slower, it breaks the 16-byte reads of phase 2)
   int ci, sc;
   xcd_remap(ci, sc);
   if (!d.active[sc]) return;
@@ -597,8 +598,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   const int* pp = d.pair_ptr + s.pair_off + s.idx;
   const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   const int eb = 0;                                        // entries are addressed by global index
-  double* T = lds;                                  // [no][NT]
-  double* strip = lds + (size_t)no * NT;            // [waves][NC + NU] reduction strip
+  double* T = lds;                                  // [no][TS]
+  double* strip = lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
   const int2* ents = d.ent + eb;                    // (a slot, W row of b), this camera's contiguous range
   const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
   double bsum[NW], D[NU];
@@ -606,22 +607,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
   for (int k = 0; k < NU; ++k) D[k] = 0;
-#ifndef PTZ_DIAG_SCHUR_SKIP_P1
   for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
-#ifdef PTZ_DIAG_P1_NOEZ
-    const int gj = s.ray_off + (q & 63);
-#else
     const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
-#endif
     const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
     const double* E = d.E + (size_t)gj * 6;
     const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
     double w[NT];
-#ifdef PTZ_DIAG_P1_NOW
-    const double* Wa = d.W + (size_t)(o0 + (q & 7)) * Dims<TYPE>::WS;
-#else
     const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
-#endif
 #pragma unroll
     for (int k = 0; k < NT; ++k) w[k] = Wa[k];
     int e = 0;
@@ -630,28 +622,20 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
       const double w0 = w[3 * p], w1 = w[3 * p + 1], w2 = w[3 * p + 2];
       bsum[p] += w0 * z0 + w1 * z1 + w2 * z2;
       const double t0 = w0 * e0 + w1 * e1 + w2 * e3, t1 = w0 * e1 + w1 * e2 + w2 * e4, t2 = w0 * e3 + w1 * e4 + w2 * e5;
-      T[q * NT + 3 * p] = t0; T[q * NT + 3 * p + 1] = t1; T[q * NT + 3 * p + 2] = t2;
+      T[q * TS + 3 * p] = t0; T[q * TS + 3 * p + 1] = t1; T[q * TS + 3 * p + 2] = t2;
 #pragma unroll
       for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
     }
   }
-#endif
   // one pass of the block tree for all NC + NU sums (fixed order: lanes by butterfly, waves in wave order)
   {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NV = NW + NU;
     double v[NV];
-#ifdef PTZ_DIAG_P1_NORED
-#pragma unroll
-    for (int k = 0; k < NW; ++k) v[k] = bsum[k];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) v[NW + k] = D[k];
-#else
 #pragma unroll
     for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
 #pragma unroll
     for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
-#endif
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
@@ -701,9 +685,6 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
       }
     }
   }
-#ifdef PTZ_DIAG_SCHUR_SKIP_P2
-  return;
-#endif
   // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
   const int l = threadIdx.x & 15;
   for (int pl = (threadIdx.x >> 4); pl < npr; pl += SCHUR_THREADS / 16) {
@@ -716,18 +697,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
     for (; e + 16 < e1; e += 32) {
       const int2 ab0 = ents[e];
       const int2 ab1 = ents[e + 16];
-#ifdef PTZ_DIAG_NOGATHER
-      const double* Wb0 = d.W + (size_t)(o0 + (ab0.y & 7)) * Dims<TYPE>::WS;
-      const double* Wb1 = d.W + (size_t)(o0 + (ab1.y & 7)) * Dims<TYPE>::WS;
-#else
       const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
       const double* Wb1 = d.W + (size_t)ab1.y * Dims<TYPE>::WS;
-#endif
       double wb0[NT], wb1[NT];
 #pragma unroll
       for (int k = 0; k < NT; ++k) { wb0[k] = Wb0[k]; wb1[k] = Wb1[k]; }
-      const double* Ta0 = T + ab0.x * NT;
-      const double* Ta1 = T + ab1.x * NT;
+      const double* Ta0 = T + ab0.x * TS;
+      const double* Ta1 = T + ab1.x * TS;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
@@ -744,7 +720,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
       double wb0[NT];
 #pragma unroll
       for (int k = 0; k < NT; ++k) wb0[k] = Wb0[k];
-      const double* Ta0 = T + ab0.x * NT;
+      const double* Ta0 = T + ab0.x * TS;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
