@@ -86,8 +86,9 @@ struct MatchEval {
   }
 };
 
+constexpr int KRT_CACHE = 256;  // matches per query whose constant part is cached (8 KiB of LDS per wave)
 template <int KTYPE>
-__global__ __launch_bounds__(256) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
+__global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
                                              const float2* __restrict__ uv_cur, const double* __restrict__ cam_ref,
                                              double* __restrict__ cam_cur, KrtOpt o, ptz_lm_summary* __restrict__ summ,
                                              int* __restrict__ accepted)
@@ -122,6 +123,23 @@ __global__ __launch_bounds__(256) void k_krt(int n_query, const long long* __res
   }
   const double kref[4] = {ref[0], ref[1], ref[2], ref[3]};
   const double dref[5] = {ref[10], ref[11], ref[12], ref[13], ref[14]};
+  // The unit ray of a reference pixel (and, with distortion, its iterative undistortion) does not depend on the parameters
+  // being optimised: computed once per match, kept in a wave-private LDS strip for the first KRT_CACHE matches of the query
+  // (the reference recomputes it in every functor call, krt_optimizer.cc:31-33, 89-104).
+  __shared__ double ray_cache[4][KRT_CACHE][4];
+  double (*rc)[4] = ray_cache[threadIdx.x >> 6];
+  for (int m = lane; m < M && m < KRT_CACHE; m += 64) {
+    const float2 a = uv_ref[m0 + m];
+    double r1[3];
+    bool skip;
+    MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
+    rc[m][0] = r1[0]; rc[m][1] = r1[1]; rc[m][2] = r1[2]; rc[m][3] = skip ? 1.0 : 0.0;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every lane reads back only what it wrote
+  auto match_ray = [&](int m, double r1[3], bool& skip) {
+    if (m < KRT_CACHE) { r1[0] = rc[m][0]; r1[1] = rc[m][1]; r1[2] = rc[m][2]; skip = rc[m][3] != 0.0; }
+    else { const float2 a = uv_ref[m0 + m]; MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip); }
+  };
 
   // residual-only pass at a camera vector
   auto eval_cost = [&](const double* c) -> double {
@@ -129,10 +147,10 @@ __global__ __launch_bounds__(256) void k_krt(int n_query, const long long* __res
     rodrigues(c + 4, R);
     double cost = 0;
     for (int m = lane; m < M; m += 64) {
-      const float2 a = uv_ref[m0 + m], bq = uv_cur[m0 + m];
+      const float2 bq = uv_cur[m0 + m];
       double r1[3], res[2], J[2][NF];
       bool skip;
-      MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
+      match_ray(m, r1, skip);
       krt_eval<KTYPE, false>(R, nullptr, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
     }
@@ -150,10 +168,10 @@ __global__ __launch_bounds__(256) void k_krt(int n_query, const long long* __res
 #pragma unroll
     for (int k = 0; k < NF; ++k) g[k] = 0;
     for (int m = lane; m < M; m += 64) {
-      const float2 a = uv_ref[m0 + m], bq = uv_cur[m0 + m];
+      const float2 bq = uv_cur[m0 + m];
       double r1[3], res[2], J[2][NF];
       bool skip;
-      MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
+      match_ray(m, r1, skip);
       krt_eval<KTYPE, true>(R, Jl, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
       int e = 0;

@@ -11,7 +11,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(os.path.join(ROOT, "ptz-calib_amd", "libptzcalib_host.so"))
+        _lib = C.CDLL(os.environ.get("PTZCALIB_HOST_LIB", os.path.join(ROOT, "ptz-calib_amd", "libptzcalib_host.so")))
     return _lib
 
 
