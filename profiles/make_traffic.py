@@ -8,7 +8,7 @@ s = json.load(open(sys.argv[1]))
 out = {"_note": "rocprofv3 --pmc passes on tests/probe_run.py 256 1 (256 C2 scenes, one solve); per-dispatch means. FETCH_SIZE/WRITE_SIZE "
                 "are KB; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports "
                 "half of wide 16-B/lane reads).",
-       "kernels": {}, "slot_to_kernel": {"schur": "k_schur", "chol_syrk": "chol_syrk", "eval": "k_eval", "linearize": "k_lin_ray"}}
+       "kernels": {}, "slot_to_kernel": {"schur": "k_schur", "chol_syrk": "chol_update_col", "eval": "k_eval", "linearize": "k_lin_ray"}}
 for k, v in s.items():
     if "FETCH_SIZE" not in v:
         continue

@@ -5,7 +5,7 @@ import csv, glob, os, sys, collections, json
 
 def short(name):
     for key in ("k_schur", "k_lin_ray", "k_lin_cam", "k_eval", "k_ray_prep", "k_cam_prep", "k_cam_update", "k_cam_diag", "k_lm_pre", "k_lm_post",
-                "chol_syrk", "chol_trsm", "chol_diag", "chol_backsolve", "chol_pad", "k_krt", "k_reset", "k_fill", "k_jacobi", "fillBuffer"):
+                "chol_update_col", "chol_clear_tiles", "chol_syrk", "chol_trsm", "chol_diag", "chol_backsolve", "chol_pad", "k_krt", "k_reset", "k_fill", "k_jacobi", "fillBuffer"):
         if key in name:
             return key
     return name[:40]
