@@ -111,3 +111,82 @@ def write_reloc_set(root: str, rb, width: int = 1920, height: int = 1080) -> dic
         json.dump({"cameras": entries}, f, indent=4)
     return dict(ref_images=ref_img, ref_features=ref_feat, ref_params=params, test_images=test_img, test_features=test_feat,
                 ref_names=ref_names, test_names=test_names)
+
+
+def write_synthetic_dataset(root: str, n_scenes: int = 10, n_views: int = 16, obs_per_view: int = 80, n_online: int = 6,
+                            n_match: int = 96, seed0: int = 40) -> dict:
+    """A data set in the directory layout the reference's run_ptzba_synthetic.sh / run_reloc_synthetic.sh expect:
+        <root>/offline/scene_XX/{img_*.png, scene_XX.json}   images + annotation (markers on the ground plane)
+        <root>/offline_matches/scene_XX/{img_*.png.txt, pairs_matches.txt}
+        <root>/online/scene_XX/q_*.png, <root>/online_matches/scene_XX/{q_*.png.txt, pairs_matches.txt}
+        <root>/gt/scene_XX.json                               ground-truth world-frame cameras of offline + online images
+    Online images look from the rig centre near one of the offline views (pan/tilt within a few degrees, other zoom); their
+    matches point into extra key points appended to that view's feature file."""
+    from . import synth
+    rng = np.random.default_rng(seed0)
+    out = {"scenes": []}
+    for s in range(1, n_scenes + 1):
+        tag = f"scene_{s:02d}"
+        sc = synth.add_annotations(synth.make_scene(seed0 + s, n_views, obs_per_view), n_annotated=8, pts_per_cam=14)
+        tb = synth.make_match_table(sc, min_pair_matches=6)
+        names = [image_name(i) for i in range(n_views)]
+        w, h = int(sc.width), int(sc.height)
+        Rlw = synth.rodrigues(sc.tlw_gt[:3]); tlw = sc.tlw_gt[3:]
+        img_dir = os.path.join(root, "offline", tag); feat_dir = os.path.join(root, "offline_matches", tag)
+        on_img = os.path.join(root, "online", tag); on_feat = os.path.join(root, "online_matches", tag)
+        for d in (img_dir, feat_dir, on_img, on_feat, os.path.join(root, "gt")):
+            os.makedirs(d, exist_ok=True)
+        # online queries
+        kps = [tb.kp_xy[tb.kp_ptr[i]:tb.kp_ptr[i + 1]].astype(np.float32) for i in range(n_views)]
+        gt_entries = {}
+        q_names, q_feats, q_pairs = [], [], []
+        for q in range(n_online):
+            v = int(rng.integers(0, n_views))
+            cv = sc.cam_gt[v]
+            Rv = synth.rodrigues(cv[4:7])
+            dR = synth.rodrigues(np.deg2rad(rng.uniform(-3, 3, 3)) * np.array([1.0, 1.0, 0.2]))
+            Rq = dR @ Rv
+            fq = cv[0] * rng.uniform(0.8, 1.25)
+            pu = rng.uniform(60, w - 60, 6 * n_match); pv = rng.uniform(60, h - 60, 6 * n_match)
+            ray = np.stack([(pu - cv[2]) / cv[0], (pv - cv[3]) / cv[1], np.ones_like(pu)], 1) @ Rv  # local frame
+            pc = ray @ Rq.T
+            qu = fq * pc[:, 0] / pc[:, 2] + 0.5 * w; qv = fq * pc[:, 1] / pc[:, 2] + 0.5 * h
+            ok = np.flatnonzero((pc[:, 2] > 0) & (qu > 10) & (qu < w - 10) & (qv > 10) & (qv < h - 10))[:n_match]
+            ref_pts = np.stack([pu[ok], pv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
+            cur_pts = np.stack([qu[ok], qv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
+            off = len(kps[v])
+            kps[v] = np.concatenate([kps[v], ref_pts.astype(np.float32)])
+            qn = f"q_{q:05d}.png"
+            q_names.append(qn); q_feats.append(cur_pts.astype(np.float32))
+            q_pairs.append((names[v], qn, [(off + k, k) for k in range(len(ok))]))
+            cq = np.zeros(15); cq[0] = cq[1] = fq; cq[2], cq[3] = 0.5 * w, 0.5 * h
+            Rw = Rq @ Rlw
+            cq[4:7] = synth.rodrigues_inv(Rw); cq[7:10] = Rq @ tlw
+            gt_entries[os.path.splitext(qn)[0]] = camera_json_entry(os.path.splitext(qn)[0], cq, w, h)
+        # offline files
+        for i, n in enumerate(names):
+            write_png(os.path.join(img_dir, n), w, h)
+        kp_ptr = np.concatenate([[0], np.cumsum([len(k) for k in kps])]).astype(np.int64)
+        write_features(feat_dir, names, kp_ptr, np.concatenate(kps))
+        write_matches(os.path.join(feat_dir, "pairs_matches.txt"), [(names[a], names[b], ms) for a, b, ms in tb.pairs()])
+        entries = {}
+        for i, n in enumerate(names):
+            sel = np.flatnonzero(sc.obs3d["cam"] == i)
+            root_n = os.path.splitext(n)[0]
+            cw = sc.cam_gt[i].copy()
+            Ri = synth.rodrigues(cw[4:7])
+            cw[4:7] = synth.rodrigues_inv(Ri @ Rlw); cw[7:10] = Ri @ tlw
+            entries[root_n] = camera_json_entry(root_n, cw, w, h, sc.obs3d["uv"][sel], sc.obs3d["xyz"][sel])
+            gt_entries[root_n] = camera_json_entry(root_n, cw, w, h)
+        with open(os.path.join(img_dir, tag + ".json"), "w") as f:
+            json.dump({"cameras": entries}, f, indent=4)
+        # online files
+        for n in q_names:
+            write_png(os.path.join(on_img, n), w, h)
+        q_ptr = np.concatenate([[0], np.cumsum([len(k) for k in q_feats])]).astype(np.int64)
+        write_features(on_feat, q_names, q_ptr, np.concatenate(q_feats))
+        write_matches(os.path.join(on_feat, "pairs_matches.txt"), q_pairs)
+        with open(os.path.join(root, "gt", tag + ".json"), "w") as f:
+            json.dump({"cameras": gt_entries}, f, indent=4)
+        out["scenes"].append(dict(tag=tag, n_views=n_views, n_online=n_online))
+    return out

@@ -619,3 +619,36 @@ def test_ba_size_limits_are_reported_not_worked_around(pkg):
     with pytest.raises(Exception) as ei:
         pkg.api.BaBatch([sc])
     assert "-4" in str(ei.value) or "UNSUPPORTED" in str(ei.value).upper()
+
+
+def test_dataset_scripts_offline_then_online(pkg, tmp_path):
+    """The reference's data-set level workflow (run_ptzba_synthetic.sh, run_reloc_synthetic.sh + scripts/eval_synthetic.py) on a
+    synthetic data set in the reference's directory layout: ten scenes calibrated and georeferenced, their online images
+    relocalised against the results, accuracy reported by the evaluation tool."""
+    import re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data" / "synthetic")
+    pkg.dataset_io.write_synthetic_dataset(data, n_scenes=10, n_views=16, obs_per_view=80, n_online=5)
+    env = dict(os.environ, DATA=data, NGPU="1")
+    off = str(tmp_path / "out-offline"); on = str(tmp_path / "out-online")
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "run_ptzba_synthetic.sh")], env=dict(env, OUT=off), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = r.stdout.strip().split("Total sample number: ")[1:]
+    assert len(blocks) == 10
+    for b in blocks:
+        assert int(b.split()[0]) == 16
+        f_mean = float(re.search(r"focal_error_abs \[mean, median\]: ([0-9.]+)", b).group(1))
+        rot = float(re.search(r"ape_rot \[mean, median\]:\s*([0-9.]+)", b).group(1))
+        trans = float(re.search(r"ape_trans \[mean, median\]:\s*([0-9.]+)", b).group(1))
+        assert f_mean < 8.0 and rot < 1.0 and trans < 2.0  # px, degrees, metres (markers 40-400 m away, 0.5 px noise)
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "run_reloc_synthetic.sh")], env=dict(env, REF=off, OUT=on), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = r.stdout.strip().split("Total sample number: ")[1:]
+    assert len(blocks) == 10
+    n_total = 0
+    for b in blocks:
+        n_total += int(b.split()[0])
+        f_mean = float(re.search(r"focal_error_abs \[mean, median\]: ([0-9.]+)", b).group(1))
+        rot = float(re.search(r"ape_rot \[mean, median\]:\s*([0-9.]+)", b).group(1))
+        assert f_mean < 15.0 and rot < 1.2
+    assert n_total >= 45  # of 50 online images
