@@ -8,6 +8,7 @@ namespace ptzcalib {
 
 int TracksBuilder::NodeIndex(const IndexedFeaturePair& node) const
 {
+  if (!dense_rank_.empty()) return dense_rank_[dense_offset_[node.first] + node.second];
   return static_cast<int>(std::lower_bound(nodes_.begin(), nodes_.end(), node) - nodes_.begin());
 }
 
@@ -25,14 +26,63 @@ int TracksBuilder::FindRoot(int i)
 
 void TracksBuilder::Build(const std::vector<MatchesInfo>& matches_info)
 {
+  // Node numbering = rank of (image, feature) in the sorted set of matched features (tracks.cc:24-41); the union-find
+  // roots, hence the track ids, depend on it.  Image and feature ids are small non-negative integers in practice: a dense
+  // presence table gives the ranks in one pass; anything else goes through sort + unique + binary search.
   nodes_.clear();
-  for (const auto& mi : matches_info)
-    for (const auto& m : mi.matches) {
-      nodes_.emplace_back(static_cast<int>(mi.src_img_idx), m.queryIdx);
-      nodes_.emplace_back(static_cast<int>(mi.dst_img_idx), m.trainIdx);
+  dense_offset_.clear();
+  dense_rank_.clear();
+  long max_img = -1;
+  bool dense = true;
+  for (const auto& mi : matches_info) {
+    if (mi.matches.empty()) continue;
+    if (mi.src_img_idx < 0 || mi.dst_img_idx < 0 || mi.src_img_idx > (1 << 24) || mi.dst_img_idx > (1 << 24)) { dense = false; break; }
+    max_img = std::max(max_img, std::max(mi.src_img_idx, mi.dst_img_idx));
+  }
+  if (dense && max_img >= 0) {
+    std::vector<int> max_feat(static_cast<size_t>(max_img) + 1, -1);
+    for (const auto& mi : matches_info)
+      for (const auto& m : mi.matches) {
+        if (m.queryIdx < 0 || m.trainIdx < 0) { dense = false; break; }
+        max_feat[mi.src_img_idx] = std::max(max_feat[mi.src_img_idx], m.queryIdx);
+        max_feat[mi.dst_img_idx] = std::max(max_feat[mi.dst_img_idx], m.trainIdx);
+      }
+    size_t total = 0;
+    if (dense) {
+      dense_offset_.assign(static_cast<size_t>(max_img) + 2, 0);
+      for (long i = 0; i <= max_img; ++i) { dense_offset_[i] = total; total += static_cast<size_t>(max_feat[i] + 1); }
+      dense_offset_[max_img + 1] = total;
+      if (total > (size_t(1) << 27)) dense = false;  // sparse, huge feature ids: not worth a table
     }
-  std::sort(nodes_.begin(), nodes_.end());
-  nodes_.erase(std::unique(nodes_.begin(), nodes_.end()), nodes_.end());
+    if (dense) {
+      dense_rank_.assign(total, -1);
+      for (const auto& mi : matches_info)
+        for (const auto& m : mi.matches) {
+          dense_rank_[dense_offset_[mi.src_img_idx] + m.queryIdx] = 0;
+          dense_rank_[dense_offset_[mi.dst_img_idx] + m.trainIdx] = 0;
+        }
+      int count = 0;
+      for (long i = 0; i <= max_img; ++i)
+        for (size_t s = dense_offset_[i]; s < dense_offset_[i + 1]; ++s)
+          if (dense_rank_[s] == 0) {
+            dense_rank_[s] = count++;
+            nodes_.emplace_back(static_cast<int>(i), static_cast<int>(s - dense_offset_[i]));
+          }
+    }
+  }
+  else dense = false;
+  if (!dense) {
+    dense_offset_.clear();
+    dense_rank_.clear();
+    nodes_.clear();
+    for (const auto& mi : matches_info)
+      for (const auto& m : mi.matches) {
+        nodes_.emplace_back(static_cast<int>(mi.src_img_idx), m.queryIdx);
+        nodes_.emplace_back(static_cast<int>(mi.dst_img_idx), m.trainIdx);
+      }
+    std::sort(nodes_.begin(), nodes_.end());
+    nodes_.erase(std::unique(nodes_.begin(), nodes_.end()), nodes_.end());
+  }
   const int n = static_cast<int>(nodes_.size());
   parent_.resize(n);
   for (int i = 0; i < n; ++i) parent_[i] = i;

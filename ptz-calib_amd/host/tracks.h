@@ -29,6 +29,8 @@ class TracksBuilder {
   int NodeIndex(const IndexedFeaturePair& node) const;
   std::vector<IndexedFeaturePair> nodes_;  // sorted unique (image, feature); position = node index
   std::vector<int> parent_, rank_, size_;
+  std::vector<size_t> dense_offset_;  // per image: first slot of its feature range in dense_rank_ (empty = sorted path)
+  std::vector<int> dense_rank_;       // node index of (image, feature), -1 = not a node
 };
 
 void Length(const Tracks& tracks, int& total_length, int& max_length, int& min_length);

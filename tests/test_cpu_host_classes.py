@@ -22,6 +22,21 @@ def test_host_tracks_match_reference_golden(name):
     assert got == want  # bit-exact track ids and membership
 
 
+def test_host_tracks_sparse_feature_ids_take_the_sorted_path(orc):
+    """Feature ids far apart (beyond the dense rank table of TracksBuilder::Build) go through sort + unique + binary search;
+    both paths number the nodes identically, so the track ids agree with the oracle either way."""
+    rng = np.random.default_rng(5)
+    feats = [int(x) for x in rng.choice(1 << 30, 40, replace=False)]
+    pairs = []
+    for i in range(6):
+        for j in range(i + 1, 6):
+            ms = [(feats[k], feats[k]) for k in rng.choice(40, 12, replace=False)]
+            pairs.append((i, j, ms))
+    assert hu.tracks_build(pairs, 3) == orc.tracks_build(pairs, 3)
+    small = [(i, j, [(a % 50, b % 50) for a, b in ms]) for i, j, ms in pairs]
+    assert hu.tracks_build(small, 3) == orc.tracks_build(small, 3)
+
+
 def test_host_tracks_equal_oracle_on_random_graphs(orc):
     rng = np.random.default_rng(21)
     for _ in range(20):
