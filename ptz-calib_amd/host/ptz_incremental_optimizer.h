@@ -16,6 +16,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "ptzray_optimizer.h"
 #include "tracks.h"
 #include "types.h"
 
@@ -75,7 +76,7 @@ class PtzIncrementalOptimizer {
   std::unordered_map<long, size_t> num_reg_trials_;       // registration attempts per image
   std::unordered_set<long> reg_image_ids_;
   std::vector<long> seed_image_ids_;
-  std::shared_ptr<const Tracks> tracks_;
+  std::shared_ptr<const SharedTracks> tracks_;
   std::vector<Event> events_;
   long lm_iterations_ = 0;
   mutable double timing_ms_[5] = {0, 0, 0, 0, 0};

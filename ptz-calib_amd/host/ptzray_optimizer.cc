@@ -41,14 +41,21 @@ PTZRayOptimizer::PTZRayOptimizer(Borrow, const std::vector<ImageFeatures>& featu
   std::iota(shared_ic_ids_.begin(), shared_ic_ids_.end(), 0);
 }
 
-std::shared_ptr<const Tracks> PTZRayOptimizer::BuildTracks(const std::vector<MatchesInfo>& matches_info)
+std::shared_ptr<const SharedTracks> PTZRayOptimizer::BuildTracks(const std::vector<MatchesInfo>& matches_info)
 {
-  auto tracks = std::make_shared<Tracks>();
+  auto st = std::make_shared<SharedTracks>();
   TracksBuilder builder;
   builder.Build(matches_info);
   builder.Filter(4);
-  builder.ExportToSTL(*tracks);
-  return tracks;
+  builder.ExportToSTL(st->tracks);
+  // the same tracks as flat arrays, in the map's iteration order (track id ascending, image id ascending)
+  st->ptr.push_back(0);
+  for (const auto& te : st->tracks) {
+    st->id.push_back(te.first);
+    for (const auto& kv : te.second) { st->img.push_back(kv.first); st->feat.push_back(kv.second); }
+    st->ptr.push_back(static_cast<int64_t>(st->img.size()));
+  }
+  return st;
 }
 
 void PTZRayOptimizer::SetSharedIntrinsics(const std::vector<long>& shared_ic_ids)
@@ -78,10 +85,7 @@ bool PTZRayOptimizer::CheckValid() const
 
 void PTZRayOptimizer::FindTracks()
 {  // ptzray_optimizer.cc:537-552
-  if (shared_tracks_) {
-    Length(*shared_tracks_, track_len_, max_track_len_, min_track_len_);
-    return;
-  }
+  if (shared_tracks_) return;  // built once by the caller (the statistics of Length() are only logged by the reference)
   TracksBuilder builder;
   builder.Build(matches_info_);
   builder.Filter(4);
@@ -153,15 +157,16 @@ void PTZRayOptimizer::Pack()
   std::vector<Mat33> RKinv(p.cam_image.size());
   for (size_t c = 0; c < p.cam_image.size(); ++c)
     RKinv[c] = Mul(Inverse(cameras_[p.cam_image[c]].R()), Inverse(cameras_[p.cam_image[c]].K()));
-  for (const auto& te : tracks()) {  // std::map: ascending track id
-    const Track& track = te.second;
+  std::vector<char> is_cand(num_cams_, 0);
+  for (size_t i = 0; i < num_cams_; ++i) is_cand[i] = isCandidate(static_cast<long>(i));
+  auto add_track = [&](int track_id, size_t track_len, auto&& for_each_view) {
     Vec3 acc = {0, 0, 0};
     size_t n_cand = 0;
     const int ray_id = static_cast<int>(p.ray_track.size());
-    for (const auto& kv : track) {  // ascending image id
-      if (!isCandidate(kv.first)) continue;
-      const int c = cam_of_image[kv.first];
-      const Point2f pt = features_[kv.first].keypoints[kv.second].pt;
+    for_each_view([&](int image, int feature) {
+      if (image < 0 || static_cast<size_t>(image) >= num_cams_ || !is_cand[image]) return;
+      const int c = cam_of_image[image];
+      const Point2f pt = features_[image].keypoints[feature].pt;
       p.obs_uv.push_back(pt.x);
       p.obs_uv.push_back(pt.y);
       p.obs_cam.push_back(c);
@@ -170,13 +175,31 @@ void PTZRayOptimizer::Pack()
       const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
       acc[0] += t[0] / n; acc[1] += t[1] / n; acc[2] += t[2] / n;
       ++n_cand;
-    }
-    if (n_cand == 0) continue;  // no residual block is ever added for this track: not a parameter of the problem
-    p.ray_track.push_back(te.first);
-    p.ray_weight.push_back(static_cast<double>(track.size()));  // FULL track length, also when only some views are candidates (:805)
+    });
+    if (n_cand == 0) return;  // no residual block is ever added for this track: not a parameter of the problem
+    p.ray_track.push_back(track_id);
+    p.ray_weight.push_back(static_cast<double>(track_len));  // FULL track length, also when only some views are candidates (:805)
     acc[0] /= n_cand; acc[1] /= n_cand; acc[2] /= n_cand;
     const double n = std::sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
     p.ray.push_back(acc[0] / n); p.ray.push_back(acc[1] / n); p.ray.push_back(acc[2] / n);
+  };
+  if (shared_tracks_) {
+    const SharedTracks& st = *shared_tracks_;
+    for (size_t k = 0; k < st.id.size(); ++k) {
+      // skip tracks without a candidate view before touching anything else (most tracks, early in an incremental run)
+      bool any = false;
+      for (int64_t e = st.ptr[k]; e < st.ptr[k + 1] && !any; ++e) any = st.img[e] >= 0 && static_cast<size_t>(st.img[e]) < num_cams_ && is_cand[st.img[e]] != 0;
+      if (!any) continue;
+      add_track(st.id[k], static_cast<size_t>(st.ptr[k + 1] - st.ptr[k]), [&](auto&& view) {
+        for (int64_t e = st.ptr[k]; e < st.ptr[k + 1]; ++e) view(st.img[e], st.feat[e]);
+      });
+    }
+  }
+  else {
+    for (const auto& te : tracks_)  // std::map: ascending track id, ascending image id inside
+      add_track(te.first, te.second.size(), [&](auto&& view) {
+        for (const auto& kv : te.second) view(kv.first, kv.second);
+      });
   }
   // AddConstraints2d3d (:887-923): candidate cameras ascending, annotation order within a camera
   for (size_t i = 0; i < num_cams_; ++i) {

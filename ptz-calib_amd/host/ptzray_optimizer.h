@@ -32,6 +32,15 @@ struct PackedBA {
   bool tlw_init_ok = false;        // SetInitTransLocalToWorld() found a view that passed the PnP gates
 };
 
+// Tracks of one match table, built once and shared by many solves: the reference's map plus the same content as flat
+// arrays in the map's iteration order.
+struct SharedTracks {
+  Tracks tracks;
+  std::vector<int> id;        // track ids, ascending
+  std::vector<int64_t> ptr;   // [n_tracks + 1]
+  std::vector<int> img, feat; // views of track k: ptr[k] .. ptr[k+1], image ids ascending
+};
+
 class PTZRayOptimizer {
  public:
   PTZRayOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
@@ -56,8 +65,8 @@ class PTZRayOptimizer {
   double device_ms() const { return device_ms_; }  // wall time of the ptz_ba_solve call of the last Solve
   // The tracks depend on the match table only, not on the candidate set: a caller that solves many candidate subsets of
   // one match table (PtzIncrementalOptimizer) builds them once and shares them instead of repeating FindTracks().
-  void UseTracks(std::shared_ptr<const Tracks> tracks) { shared_tracks_ = std::move(tracks); }
-  static std::shared_ptr<const Tracks> BuildTracks(const std::vector<MatchesInfo>& matches_info);
+  void UseTracks(std::shared_ptr<const SharedTracks> tracks) { shared_tracks_ = std::move(tracks); }
+  static std::shared_ptr<const SharedTracks> BuildTracks(const std::vector<MatchesInfo>& matches_info);
   // Same as the 2D-2D constructor but WITHOUT the deep copies of features / matches (ptzray_optimizer.h:145-149): the
   // caller keeps both alive until Solve returns.
   struct Borrow {};
@@ -70,7 +79,7 @@ class PTZRayOptimizer {
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
-  const Tracks& tracks() const { return shared_tracks_ ? *shared_tracks_ : tracks_; }
+  const Tracks& tracks() const { return shared_tracks_ ? shared_tracks_->tracks : tracks_; }
   bool SetInitTransLocalToWorld();
 
   std::vector<Camera> cameras_;
@@ -78,7 +87,7 @@ class PTZRayOptimizer {
   std::vector<MatchesInfo> matches_info_own_;
   const std::vector<ImageFeatures>& features_;
   const std::vector<MatchesInfo>& matches_info_;
-  std::shared_ptr<const Tracks> shared_tracks_;
+  std::shared_ptr<const SharedTracks> shared_tracks_;
   std::vector<std::vector<Point2f>> pixels_;
   std::vector<std::vector<Point3d>> pts3d_;
   size_t num_cams_ = 0;
