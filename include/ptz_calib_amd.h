@@ -43,6 +43,8 @@ extern "C" {
 /* KRTOptimizer::FACTOR_TYPE { F, FDist, Fxfy, FxfyDist }  (krt_optimizer.h:110) */
 #define PTZ_KRT_F 0
 #define PTZ_KRT_FDist 1
+#define PTZ_KRT_Fxfy 2      /* fy free as well: Factor2d2dFxfy (krt_optimizer.cc:52-71), dead from the reference's tools */
+#define PTZ_KRT_FxfyDist 3  /* Factor2d2dFxfyDist (krt_optimizer.cc:141-192) */
 #define PTZ_KRT_Fxfy 2
 #define PTZ_KRT_FxfyDist 3
 /* ceres::TerminationType as read by the reference (ptzray_optimizer.cc:482, krt_optimizer.cc:513) */

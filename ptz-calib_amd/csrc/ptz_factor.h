@@ -302,18 +302,23 @@ PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz
 }
 
 // ---- KRT single-view factors (F4 / F5) ------------------------------------------------------------
-// KTYPE 0 = F: free [f, r1, r2, r3]; 1 = FDist: free [f, r1, r2, r3, k1] (ascending 15-vector index,
-// krt_optimizer.cc:321-337).  ray1 = normalise(K1^-1 [u1, v1, 1]) is constant per match (R1 = I in the
-// local frame, krt_optimizer.cc:275) and is precomputed once per match by the caller.
-template <int KTYPE> struct KrtDims { static constexpr int NF = (KTYPE == 0) ? 4 : 5; };
+// KTYPE = KRTOptimizer::FACTOR_TYPE (krt_optimizer.h:110): 0 = F, 1 = FDist, 2 = Fxfy, 3 = FxfyDist; bit 0 = Brown
+// distortion with k1 free, bit 1 = fy free.  Free parameters in ascending 15-vector index (krt_optimizer.cc:321-340):
+// [fx, (fy), r1, r2, r3, (k1)].  ray1 = normalise(K1^-1 [u1, v1, 1]) is constant per match (R1 = I in the local frame,
+// krt_optimizer.cc:275) and is precomputed once per match by the caller.
+template <int KTYPE> struct KrtDims {
+  static constexpr int DIST = KTYPE & 1, FXFY = (KTYPE >> 1) & 1;
+  static constexpr int NF = 4 + DIST + FXFY;
+  static constexpr int ROT0 = 1 + FXFY;  // first rotation column
+};
 
 template <int KTYPE, bool JAC>
-PTZ_HD void krt_eval(const double* R, const double* Jl, double f, double cx, double cy, const double* kd,
+PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, double cx, double cy, const double* kd,
                      const double ray1[3], bool skip, float u2, float v2, double res[2],
                      double J[2][KrtDims<KTYPE>::NF])
 {
-  constexpr int NF = KrtDims<KTYPE>::NF;
-  if (skip) {  // undistorted reference pixel outside the frame: residual 0 (krt_optimizer.cc:97-101)
+  constexpr int NF = KrtDims<KTYPE>::NF, DIST = KrtDims<KTYPE>::DIST, FXFY = KrtDims<KTYPE>::FXFY, ROT0 = KrtDims<KTYPE>::ROT0;
+  if (skip) {  // undistorted reference pixel outside the frame: residual 0 (krt_optimizer.cc:97-101, 156-162)
     res[0] = 0; res[1] = 0;
     if (JAC) for (int k = 0; k < NF; ++k) { J[0][k] = 0; J[1][k] = 0; }
     return;
@@ -323,32 +328,38 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double f, double cx, dou
   const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
   const double iz = 1.0 / Pz, x = Px / Pz, y = Py / Pz;  // same arithmetic as the reference functor
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
-  if (KTYPE == 0) {
-    res[0] = (double)u2 - (f * Px + cx * Pz) / Pz;
-    res[1] = (double)v2 - (f * Py + cy * Pz) / Pz;
+  if (!DIST) {
+    res[0] = (double)u2 - (fx * Px + cx * Pz) / Pz;
+    res[1] = (double)v2 - (fy * Py + cy * Pz) / Pz;
   }
   else {
     brown(x, y, kd, xd, yd);
     if (JAC) brown_jac(x, y, kd, B, dk1);
-    res[0] = (double)u2 - (f * xd + cx);
-    res[1] = (double)v2 - (f * yd + cy);
+    res[0] = (double)u2 - (fx * xd + cx);
+    res[1] = (double)v2 - (fy * yd + cy);
   }
   if (!JAC) return;
   double M[2][3];
-  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
-  M[1][0] = f * (B[2] * iz);  M[1][1] = f * (B[3] * iz);  M[1][2] = f * (-(B[2] * x + B[3] * y) * iz);
-  J[0][0] = -xd;
-  J[1][0] = -yd;
+  M[0][0] = fx * (B[0] * iz);  M[0][1] = fx * (B[1] * iz);  M[0][2] = fx * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  if (FXFY) {
+    J[0][0] = -xd; J[1][0] = 0;
+    J[0][1] = 0;   J[1][1] = -yd;
+  }
+  else {
+    J[0][0] = -xd;
+    J[1][0] = -yd;
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
     const double dx = ay * Pz - az * Py, dy = az * Px - ax * Pz, dz = ax * Py - ay * Px;
-    J[0][1 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
-    J[1][1 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+    J[0][ROT0 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    J[1][ROT0 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
   }
-  if (KTYPE != 0) {
-    J[0][4] = -f * dk1[0];
-    J[1][4] = -f * dk1[1];
+  if (DIST) {
+    J[0][ROT0 + 3] = -fx * dk1[0];
+    J[1][ROT0 + 3] = -fy * dk1[1];
   }
 }
 

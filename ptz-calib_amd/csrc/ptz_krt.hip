@@ -25,9 +25,14 @@ struct KrtOpt {
   double function_tolerance, gradient_tolerance, parameter_tolerance, max_reproj_error;
 };
 
-template <int KTYPE> struct KFree;
-template <> struct KFree<0> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : 3 + k; } };                    // 0,4,5,6
-template <> struct KFree<1> { static __device__ __forceinline__ int at(int k) { return k == 0 ? 0 : (k == 4 ? 10 : 3 + k); } };     // 0,4,5,6,10
+// 15-vector index of free parameter k: F {0,4,5,6}, FDist {0,4,5,6,10}, Fxfy {0,1,4,5,6}, FxfyDist {0,1,4,5,6,10}
+template <int KTYPE> struct KFree {
+  static __device__ __forceinline__ int at(int k)
+  {
+    constexpr int ROT0 = KrtDims<KTYPE>::ROT0;
+    return k < ROT0 ? k : (k < ROT0 + 3 ? 4 + (k - ROT0) : 10);
+  }
+};
 
 // in-register Cholesky solve of an NF x NF SPD system (row-major full storage); false if not SPD
 template <int NF>
@@ -74,7 +79,7 @@ struct MatchEval {
   {
     double u = u1, v = v1;
     skip = false;
-    if (KTYPE == 1) {
+    if (KTYPE & 1) {
       float ou, ov;
       undistort_point(kref[0], kref[1], kref[2], kref[3], dref, u1, v1, ou, ov);
       skip = (ou < 0 || ou >= kref[2] * 2 || ov < 0 || ov >= kref[3] * 2);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       double r1[3], res[2], J[2][NF];
       bool skip;
       match_ray(m, r1, skip);
-      krt_eval<KTYPE, false>(R, nullptr, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
+      krt_eval<KTYPE, false>(R, nullptr, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
     }
     return wave_sum(cost);
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       double r1[3], res[2], J[2][NF];
       bool skip;
       match_ray(m, r1, skip);
-      krt_eval<KTYPE, true>(R, Jl, c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
+      krt_eval<KTYPE, true>(R, Jl, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
       int e = 0;
 #pragma unroll
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     summ[q] = s;
     accepted[q] = ok ? 1 : 0;
     if (ok) {
-      x[1] = x[0];  // fx = fy (krt_optimizer.cc:543)
+      if (!(KTYPE & 2)) x[1] = x[0];  // fx = fy for F / FDist (krt_optimizer.cc:540-551)
       double Rloc[9], Rw[9], rv[3];
       rodrigues(x + 4, Rloc);
       mat3_mul(Rloc, Rref, Rw);
@@ -358,7 +363,7 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
                                        const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
 {
   if (n_query <= 0 || !match_ptr || !uv_ref || !uv_cur || !cam_ref || !cam_cur || !summaries || !accepted) return PTZ_EINVAL;
-  if (factor_type != PTZ_KRT_F && factor_type != PTZ_KRT_FDist) return PTZ_EUNSUPPORTED;
+  if (factor_type < PTZ_KRT_F || factor_type > PTZ_KRT_FxfyDist) return PTZ_EUNSUPPORTED;
   ptz_lm_options o;
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   for (int q = 0; q < n_query; ++q)
@@ -415,8 +420,12 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   ko.max_reproj_error = max_reproj_error;
   PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
   const dim3 grid((n_query + 3) / 4), block(256);
-  if (factor_type == PTZ_KRT_F) hipLaunchKernelGGL(k_krt<0>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
-  else hipLaunchKernelGGL(k_krt<1>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc);
+  switch (factor_type) {
+    case PTZ_KRT_F: hipLaunchKernelGGL(k_krt<0>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
+    case PTZ_KRT_FDist: hipLaunchKernelGGL(k_krt<1>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
+    case PTZ_KRT_Fxfy: hipLaunchKernelGGL(k_krt<2>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
+    default: hipLaunchKernelGGL(k_krt<3>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
+  }
   PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));

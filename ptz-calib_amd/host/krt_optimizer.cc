@@ -34,7 +34,7 @@ void KRTOptimizer::Add2d3dConstraints(const std::vector<Point2f>& pts2d, const s
 
 bool KRTOptimizer::Solve(Mat33& K, Mat33& R, Vec3& t, Vec5& dist)
 {
-  if (has_2d3d_ || (factor_type_ != F && factor_type_ != FDist) || uv_ref_.empty()) return false;
+  if (has_2d3d_ || uv_ref_.empty()) return false;
   const int64_t match_ptr[2] = {0, static_cast<int64_t>(uv_ref_.size() / 2)};
   std::vector<double> ref = cam_ref_.ToVector(), cur = cam_curr_world_.ToVector();
   ptz_lm_options opt;
@@ -43,7 +43,7 @@ bool KRTOptimizer::Solve(Mat33& K, Mat33& R, Vec3& t, Vec5& dist)
   opt.device_id = device_id_;
   int32_t accepted = 0;
   if (ptz_krt_solve_batch(1, match_ptr, uv_ref_.data(), uv_cur_.data(), ref.data(), cur.data(),
-                          factor_type_ == F ? PTZ_KRT_F : PTZ_KRT_FDist, max_reproj_error_, &opt, &summary_, &accepted,
+                          static_cast<int32_t>(factor_type_), max_reproj_error_, &opt, &summary_, &accepted,
                           nullptr) != PTZ_OK)
     return false;
   num_iter_ = summary_.num_successful_steps;  // krt_optimizer.cc:396

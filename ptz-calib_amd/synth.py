@@ -283,7 +283,7 @@ def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_
     pan = rng.uniform(n_query, -math.pi, math.pi)
     tilt = np.deg2rad(rng.uniform(n_query, -10.0, 10.0))
     fq = rng.uniform(n_query, 1500.0, 4000.0)
-    k1q = rng.uniform(n_query, -0.05, 0.05) if factor_type == 1 else np.zeros(n_query)
+    k1q = rng.uniform(n_query, -0.05, 0.05) if (factor_type & 1) else np.zeros(n_query)
     over = 3  # oversampling factor for candidate pixels
     for q in range(n_query):
         Rq = _rot_x(tilt[q]) @ _rot_y(pan[q])

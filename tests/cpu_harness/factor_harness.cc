@@ -51,7 +51,7 @@ void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* 
   so3_left_jacobian(cam15 + 4, Jl);
   double u1 = uv1[0], v1 = uv1[1];
   bool skip = false;
-  if (ktype == 1) {
+  if (ktype & 1) {
     float ou, ov;
     undistort_point(k1[0], k1[1], k1[2], k1[3], dist1, uv1[0], uv1[1], ou, ov);
     skip = (ou < 0 || ou >= k1[2] * 2 || ov < 0 || ov >= k1[3] * 2);
@@ -60,16 +60,20 @@ void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* 
   double X[3] = {(u1 - k1[2]) / k1[0], (v1 - k1[3]) / k1[1], 1.0};
   double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
   double ray1[3] = {X[0] / n, X[1] / n, X[2] / n};
-  if (ktype == 0) {
-    double j[2][4];
-    krt_eval<0, true>(R, Jl, cam15[0], cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);
-    for (int i = 0; i < 8; ++i) J[i] = (&j[0][0])[i];
+  const double fy = (ktype & 2) ? cam15[1] : cam15[0];
+#define H_KRT(T)                                                                                                       \
+  {                                                                                                                    \
+    double j[2][KrtDims<T>::NF];                                                                                       \
+    krt_eval<T, true>(R, Jl, cam15[0], fy, cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);      \
+    for (int i = 0; i < 2 * KrtDims<T>::NF; ++i) J[i] = (&j[0][0])[i];                                               \
   }
-  else {
-    double j[2][5];
-    krt_eval<1, true>(R, Jl, cam15[0], cam15[2], cam15[3], cam15 + 10, ray1, skip, uv2[0], uv2[1], res, j);
-    for (int i = 0; i < 10; ++i) J[i] = (&j[0][0])[i];
+  switch (ktype) {
+    case 0: H_KRT(0) break;
+    case 1: H_KRT(1) break;
+    case 2: H_KRT(2) break;
+    default: H_KRT(3) break;
   }
+#undef H_KRT
 }
 // F3: cam15, tlw6, xyz, uv -> res[2], Jc[2][5+factor], Jt[2][6]
 void h_reproj2d3d(int factor, const double* cam15, const double* tlw, const double* xyz, const float* uv, double* res, double* Jc, double* Jt)

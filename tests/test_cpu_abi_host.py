@@ -124,36 +124,59 @@ def test_device_math_behind_camera_branch(harness):
     assert np.array_equal(res, [1e6, 1e6]) and not Jc.any() and not Jr.any()  # ptzray_optimizer.cc:97-102
 
 
-@pytest.mark.parametrize("ktype", [0, 1])
+def _krt_reference_residual(orc, ktype, x, k1, d1, uv1, uv2):
+    """F / FDist: the oracle's functors.  Fxfy / FxfyDist (krt_optimizer.cc:52-71, 141-192): written out here -- the same
+    projection with fy = x[1] instead of fx."""
+    out = np.zeros(2)
+    if ktype == 0:
+        orc.lib().orc_res_2d2d(_p(x), _p(k1), _p(uv1), _p(uv2), _p(out))
+        return out
+    if ktype == 1:
+        orc.lib().orc_res_2d2d_dist(_p(x), _p(k1), _p(d1), _p(uv1), _p(uv2), _p(out))
+        return out
+    u, v = float(uv1[0]), float(uv1[1])
+    if ktype == 3:
+        und = np.zeros(2, dtype=np.float32)
+        orc.lib().orc_undistort_point(_p(k1), _p(d1), _p(uv1), _p(und))
+        if und[0] < 0 or und[0] >= 2 * k1[2] or und[1] < 0 or und[1] >= 2 * k1[3]:
+            return out
+        u, v = float(und[0]), float(und[1])
+    X = np.array([(u - k1[2]) / k1[0], (v - k1[3]) / k1[1], 1.0])
+    P = orc.rodrigues(x[4:7]) @ (X / np.linalg.norm(X))
+    if ktype == 2:
+        return np.array([uv2[0] - (x[0] * P[0] + x[2] * P[2]) / P[2], uv2[1] - (x[1] * P[1] + x[3] * P[2]) / P[2]])
+    px, py = P[0] / P[2], P[1] / P[2]
+    r2 = px * px + py * py
+    rad = 1 + x[10] * r2 + x[11] * r2 ** 2 + x[12] * r2 ** 3
+    xd = px * rad + 2 * x[13] * px * py + x[14] * (r2 + 2 * px * px)
+    yd = py * rad + 2 * x[14] * px * py + x[13] * (r2 + 2 * py * py)
+    return np.array([uv2[0] - (x[0] * xd + x[2]), uv2[1] - (x[1] * yd + x[3])])
+
+
+@pytest.mark.parametrize("ktype", [0, 1, 2, 3])
 def test_device_krt_math_matches_oracle(pkg, orc, harness, ktype):
     rb = pkg.synth.make_reloc_batch(4, 32, seed_id=ktype, factor_type=ktype)
-    nf = 4 if ktype == 0 else 5
+    idx = {0: [0, 4, 5, 6], 1: [0, 4, 5, 6, 10], 2: [0, 1, 4, 5, 6], 3: [0, 1, 4, 5, 6, 10]}[ktype]  # krt_optimizer.cc:321-340
+    nf = len(idx)
     for q in range(rb.n_query):
         loc = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
         loc[4:7] += [0.01, -0.02, 0.005]
-        if ktype:
+        if ktype & 1:
             loc[10] = 0.01
+        if ktype & 2:
+            loc[1] = loc[0] * 1.03
         k1 = rb.cam_ref[q, :4].copy(); d1 = rb.cam_ref[q, 10:15].copy()
         for m in range(rb.match_ptr[q], rb.match_ptr[q + 1]):
-            res = np.zeros(2); J = np.zeros((2, nf)); want = np.zeros(2)
-            harness.h_krt_eval(ktype, _p(loc), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(res), _p(J))
-            if ktype == 0:
-                orc.lib().orc_res_2d2d(_p(loc), _p(k1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(want))
-            else:
-                orc.lib().orc_res_2d2d_dist(_p(loc), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(want))
-            assert np.allclose(res, want, rtol=0, atol=1e-9)
-            # Jacobian against central differences of the oracle functor
-            idx = [0, 4, 5, 6] + ([10] if ktype else [])
+            res = np.zeros(2); J = np.zeros((2, nf))
+            uv1 = rb.uv_ref[m].copy(); uv2 = rb.uv_cur[m].copy()
+            harness.h_krt_eval(ktype, _p(loc), _p(k1), _p(d1), _p(uv1), _p(uv2), _p(res), _p(J))
+            assert np.allclose(res, _krt_reference_residual(orc, ktype, loc, k1, d1, uv1, uv2), rtol=0, atol=1e-9)
+            # Jacobian against central differences of the reference functor
             for c, k in enumerate(idx):
                 h = max(1.5e-8, abs(loc[k]) * 1e-6)
-                fp = np.zeros(2); fm = np.zeros(2)
-                for sgn, out in ((1, fp), (-1, fm)):
-                    x = loc.copy(); x[k] += sgn * h
-                    if ktype == 0:
-                        orc.lib().orc_res_2d2d(_p(x), _p(k1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(out))
-                    else:
-                        orc.lib().orc_res_2d2d_dist(_p(x), _p(k1), _p(d1), _p(rb.uv_ref[m].copy()), _p(rb.uv_cur[m].copy()), _p(out))
-                num = (fp - fm) / (2 * h)
+                xp = loc.copy(); xp[k] += h
+                xm = loc.copy(); xm[k] -= h
+                num = (_krt_reference_residual(orc, ktype, xp, k1, d1, uv1, uv2) - _krt_reference_residual(orc, ktype, xm, k1, d1, uv1, uv2)) / (2 * h)
                 assert np.allclose(J[:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
 
 

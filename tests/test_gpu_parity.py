@@ -205,11 +205,12 @@ def test_ba_invalid_inputs(pkg, scene_c1):
         pkg.api.BaBatch([scene_c1], max_num_iterations=0)  # CheckValid: max_iter_ <= 0
 
 
-@pytest.mark.parametrize("ftype", [0, 1])
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3])
 def test_krt_batch_parity(pkg, orc, ftype):
     """Batched single-view LM (K6) vs the oracle's KRT solve (numeric-diff Jacobian + Householder QR, as the
     reference's NumericDiffCostFunction + DENSE_QR): same termination and iteration counts, refined f and
-    rotation within 1e-6 relative."""
+    rotation within 1e-6 relative.  ftype = KRTOptimizer::FACTOR_TYPE: F, FDist (the two the reference's tools use),
+    Fxfy, FxfyDist (fy free as well, krt_optimizer.cc:52-71, 141-192)."""
     rb = pkg.synth.make_reloc_batch(48, 128, seed_id=ftype, factor_type=ftype)
     cam_w, summ, acc, ms = pkg.api.krt_solve_batch(rb)
     n_acc = 0
@@ -227,8 +228,11 @@ def test_krt_batch_parity(pkg, orc, ftype):
             want = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
             assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
             assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
-            assert cam_w[q, 1] == cam_w[q, 0]
-            if ftype == 1:
+            if ftype < 2:
+                assert cam_w[q, 1] == cam_w[q, 0]  # fy := fx on read-back (krt_optimizer.cc:543)
+            else:
+                assert abs(cam_w[q, 1] - want[1]) / want[1] < 1e-6 and cam_w[q, 1] != cam_w[q, 0]
+            if ftype & 1:
                 assert abs(cam_w[q, 10] - want[10]) < 1e-6
             # ground truth recovered at noise level
             assert abs(cam_w[q, 0] - rb.cam_gt[q, 0]) / rb.cam_gt[q, 0] < 0.02
