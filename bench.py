@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--views", type=int, default=200)
     ap.add_argument("--obs", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-scene", action="store_true", help="also time one scene alone (latency-bound C2)")
+    ap.add_argument("--single-scene", action="store_true", help="(always on; kept for compatibility) time one scene alone")
     ap.add_argument("--iba", action="store_true",
                     help="also run the whole PTZ-IBA orchestration (seed pair, registrations, bundle adjustments) on one rig")
     args = ap.parse_args()
@@ -183,7 +183,7 @@ def main():
             "roofline": roof,
             "kernel_ms_per_solve": {k: round(v["ms"] / args.steps, 3) for k, v in per.items()},
         }
-        if args.single_scene:
+        if True:  # one rig alone (BASELINE configs[1]): latency-bound, reported beside the batch figure
             b1 = pkg.api.BaBatch([base[0]], device_id=local_rank)
             b1.set_state(); b1.solve()
             t1 = time.perf_counter(); s1 = b1.solve(); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
