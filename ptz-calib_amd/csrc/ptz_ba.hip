@@ -1420,11 +1420,11 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
     for (int k = 0; k < nt; ++k) {
       if (k > 0) {
         b->prof_begin(P_CHOL_SYRK);
-        chol_update_col_launch(cb, k, stream);
+        chol_update_col_launch(cb, k, stream, /*fuse_diag=*/true);  // also factors the diagonal tile of column k
         b->prof_end();
       }
       b->prof_begin(P_CHOL_PANEL);
-      chol_panel_launch(cb, k, stream);
+      chol_panel_launch(cb, k, stream, /*diag_done=*/k > 0);
       b->prof_end();
     }
     b->prof_begin(P_CHOL_BACK);
@@ -1435,12 +1435,12 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   for (int k = 0; k < nt; ++k) {
     const int m = nt - k - 1;
     b->prof_begin(P_CHOL_PANEL);
-    chol_panel_launch(cb, k, stream);
+    chol_panel_launch(cb, k, stream, /*diag_done=*/k > 0);  // the trailing update of step k - 1 factored this diagonal tile
     b->prof_end();
     if (m <= 0) continue;
     if (!la) {
       b->prof_begin(P_CHOL_SYRK);
-      chol_syrk_launch(cb, k, stream, 0);
+      chol_syrk_launch(cb, k, stream, 0, /*fuse_diag=*/true);
       b->prof_end();
       continue;
     }
@@ -1448,7 +1448,7 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
     (void)hipStreamWaitEvent(aux, evT, 0);
     if (rest_pending) (void)hipStreamWaitEvent(stream, evR, 0);  // column k+1 was last touched by rest(k-1)
     b->prof_begin(P_CHOL_SYRK);
-    chol_syrk_launch(cb, k, stream, 1);
+    chol_syrk_launch(cb, k, stream, 1, /*fuse_diag=*/true);
     b->prof_end();
     if (m >= 2) {
       hipStream_t keep = b->stream;

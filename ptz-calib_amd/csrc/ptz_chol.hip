@@ -107,21 +107,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __restrict__ Dinv, int k)
+// Factor the tile held in As (row-major, stride LD, fully loaded and synchronised by the caller; 256 threads).
+// Dv: LDS scratch [4][DB * LDD].  Writes Ldiag[sys][k], Dinv[sys][k][*] and raises cb.fail[sys] on a non-positive pivot.
+__device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n)
 {
-  const int sys = blockIdx.y;
-  if (cb.active && !cb.active[sys]) return;
   const int np = cb.np, nt = np / NB;
-  const int n = cb.n[sys];
-  if (k * NB > n) return;  // whole block column is padding (identity)
-  const double* A = cb.A + (size_t)sys * np * np;
-  __shared__ __attribute__((aligned(16))) double As[NB * LD];        // A_kk, overwritten by L_kk block column by block column
-  __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];    // L_bb^-1 of the current block, one private copy per wave
-  __shared__ int okflag;
+  double* __restrict__ Dinv = cb.Dinv;
+  int& okflag = *okflag_p;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15;            // row (steps 1-2) / fragment row (steps 3-4)
   const int fr = lane & 15, fq = lane >> 4;
-  tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, As);
   if (threadIdx.x == 0) okflag = 1;
   __syncthreads();
   double dmin = 1.0;
@@ -220,6 +215,22 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, double* __
   if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
 }
 
+__global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
+{
+  const int sys = blockIdx.y;
+  if (cb.active && !cb.active[sys]) return;
+  const int np = cb.np;
+  const int n = cb.n[sys];
+  if (k * NB > n) return;  // whole block column is padding (identity)
+  const double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double As[NB * LD];        // A_kk, overwritten by L_kk block column by block column
+  __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];    // L_bb^-1 of the current block, one private copy per wave
+  __shared__ int okflag;
+  tile_g2s<256, false>(A + (size_t)(k * NB) * np + k * NB, np, As);
+  __syncthreads();
+  diag_factor_tile(As, Dv, &okflag, cb, sys, k, n);
+}
+
 // ---- trsm: X L_kk^T = A_ik for one off-diagonal tile, blocked by 16 columns, on the matrix cores --------
 // wave w owns rows [16w, 16w+16) of the tile and walks the four column blocks:
 //   X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
 // ---- trailing update: A_ij -= L_ik L_jk^T on the matrix cores ---------------------------------------
 // mode 0: every trailing tile (i >= j > k); mode 1: only block column k+1 (tiles (i, k+1)), the part the next panel
 // depends on; mode 2: the rest (j >= k+2).  Modes 1 + 2 together equal mode 0 (one-step look-ahead split).
-__global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int mode)
+__global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int mode, int fuse_diag)
 {
   int bx, sys;
   xcd_remap(bx, sys);
@@ -316,15 +327,22 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
   if (ii >= m) return;
   const int ti = k + 1 + ii, tj = k + 1 + jj;
   if (ti * NB > n) return;  // rows of this tile are beyond the rhs row: nothing to update
+  const bool next_diag = fuse_diag && ti == tj && ti == k + 1;  // this workgroup also factors the tile afterwards
+  bool do_update = true;
   if (cb.tmask) {
     const unsigned char* tm = cb.tmask + (size_t)sys * nt * nt;
-    if (!tm[ti * nt + k] || !tm[tj * nt + k]) return;  // L_ik or L_jk is structurally zero
+    if (!tm[ti * nt + k] || !tm[tj * nt + k]) {  // L_ik or L_jk is structurally zero
+      if (!next_diag) return;
+      do_update = false;
+    }
   }
   double* A = cb.A + (size_t)sys * np * np;
   __shared__ __attribute__((aligned(16))) double As[NB * LD];
   __shared__ __attribute__((aligned(16))) double Bs[NB * LD];
-  tile_g2s<256, true>(A + (size_t)(ti * NB) * np + k * NB, np, As);   // -L_ik
-  tile_g2s<256, false>(A + (size_t)(tj * NB) * np + k * NB, np, Bs);  //  L_jk
+  if (do_update) {
+    tile_g2s<256, true>(A + (size_t)(ti * NB) * np + k * NB, np, As);   // -L_ik
+    tile_g2s<256, false>(A + (size_t)(tj * NB) * np + k * NB, np, Bs);  //  L_jk
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   // C fragment (f64 16x16x4): element (row = fq + 4 * i, col = fr) of the 16x16 block, i = 0..3
@@ -337,11 +355,27 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
   __syncthreads();
   const double* ap = As + (16 * w + fr) * LD + fq;
   const double* bp = Bs + fr * LD + fq;
+  if (do_update) {
 #pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    const double av = ap[4 * kk];
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double av = ap[4 * kk];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
+    }
+  }
+  if (next_diag) {
+    // This tile is final after this update and nobody else touches it: factor it right here instead of writing it out
+    // and launching the diagonal kernel for step k + 1 (saves a launch and a tile round trip per block column).
+    __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
+    __shared__ int okflag;
+    __syncthreads();  // all waves are done reading the operand tiles
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    diag_factor_tile(As, Dv, &okflag, cb, sys, ti, n);
+    return;
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
 // L_ik and L_jk are both in the structure, so C is read and written once per column step instead of once per k (the
 // right-looking update moves 128 KB per 64^3 update, this one 64 KB), and the whole factorisation needs no trailing
 // update launches.  Same arithmetic per (i, j, k) triple as chol_syrk_kernel; the k order is ascending.
-__global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int j)
+__global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int j, int fuse_diag)
 {
   int bx, sys;
   xcd_remap(bx, sys);
@@ -392,6 +426,19 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
     }
+  }
+  if (fuse_diag && ti == j) {
+    // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
+    __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
+    __shared__ int okflag;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    diag_factor_tile(As, Dv, &okflag, cb, sys, j, n);
+    return;
   }
   if (!any) return;
 #pragma unroll
@@ -525,22 +572,22 @@ void chol_clear(const CholBatch& cb, hipStream_t stream)
   hipLaunchKernelGGL(chol_pad_kernel, grid, dim3(256), 0, stream, cb);
 }
 
-void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream)
+void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag_done)
 {
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, cb.Dinv, k);
+  if (!diag_done) hipLaunchKernelGGL(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
   const int m = cb.np / NB - k - 1;
   if (m > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, (const double*)cb.Dinv, k);
 }
-void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode)
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag)
 {
   const int m = cb.np / NB - k - 1;
   const int tiles = mode == 0 ? m * (m + 1) / 2 : (mode == 1 ? m : m * (m - 1) / 2);
-  if (tiles > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode);
+  if (tiles > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode, fuse_diag ? 1 : 0);
 }
-void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream)
+void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag)
 {
   const int m = cb.np / NB - j;
-  if (j > 0 && m > 0) hipLaunchKernelGGL(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j);
+  if (j > 0 && m > 0) hipLaunchKernelGGL(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
@@ -551,9 +598,10 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
+  // every trailing update also factors the diagonal tile of the next block column (it is final by then)
   for (int k = 0; k < nt; ++k) {
-    chol_panel_launch(cb, k, stream);
-    chol_syrk_launch(cb, k, stream, 0);
+    chol_panel_launch(cb, k, stream, /*diag_done=*/k > 0);
+    chol_syrk_launch(cb, k, stream, 0, /*fuse_diag=*/true);
   }
   chol_backsolve_launch(cb, x, stream);
 }

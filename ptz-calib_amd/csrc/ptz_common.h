@@ -102,10 +102,10 @@ inline int chol_padded_order(int n_max) { return ((n_max + 1 + CHOL_NB - 1) / CH
 // enqueue factorisation + solve on `stream`; x: device [count][np]
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
 // the three kernel families of chol_factor_solve, individually (for per-family timing)
-void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream);
-void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode);  // 0 all, 1 column k+1, 2 rest
+void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag_done = false);  // diag (unless already done) + trsm
+void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag = false);  // mode 0 all, 1 column k+1, 2 rest; fuse_diag: also factor tile (k+1, k+1)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
-void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream);  // left-looking: column j -= all earlier columns
+void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
 void chol_clear(const CholBatch& cb, hipStream_t stream);
 
