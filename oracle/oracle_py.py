@@ -50,7 +50,7 @@ class BaProblem(C.Structure):
     _fields_ = [("n_cam", C.c_int32), ("n_ray", C.c_int32), ("n_obs", C.c_int64), ("obs_uv", C.c_void_p),
                 ("obs_cam", C.c_void_p), ("obs_ray", C.c_void_p), ("ray_weight", C.c_void_p),
                 ("n_obs3d", C.c_int32), ("obs3d_uv", C.c_void_p), ("obs3d_xyz", C.c_void_p),
-                ("obs3d_cam", C.c_void_p), ("factor_type", C.c_int32)]
+                ("obs3d_cam", C.c_void_p), ("factor_type", C.c_int32), ("ic_of_cam", C.c_void_p)]
 
 
 class KrtProblem(C.Structure):
@@ -130,7 +130,7 @@ def _mk_trace(cap):
     return t, arrs
 
 
-def _ba_problem(obs_uv, obs_cam, obs_ray, ray_weight, n_cam, n_ray, factor_type, obs3d=None):
+def _ba_problem(obs_uv, obs_cam, obs_ray, ray_weight, n_cam, n_ray, factor_type, obs3d=None, ic_of_cam=None):
     keep = dict(obs_uv=np.ascontiguousarray(obs_uv, dtype=np.float32),
                 obs_cam=np.ascontiguousarray(obs_cam, dtype=np.int32),
                 obs_ray=np.ascontiguousarray(obs_ray, dtype=np.int32),
@@ -145,13 +145,17 @@ def _ba_problem(obs_uv, obs_cam, obs_ray, ray_weight, n_cam, n_ray, factor_type,
         keep["o3cam"] = np.ascontiguousarray(obs3d["cam"], dtype=np.int32)
         p.n_obs3d = len(keep["o3cam"])
         p.obs3d_uv, p.obs3d_xyz, p.obs3d_cam = _p(keep["o3uv"]), _p(keep["o3xyz"]), _p(keep["o3cam"])
+    if ic_of_cam is not None:
+        keep["ic"] = np.ascontiguousarray(ic_of_cam, dtype=np.int32)
+        assert len(keep["ic"]) == n_cam
+        p.ic_of_cam = _p(keep["ic"])
     return p, keep
 
 
 def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, **opt):
     """Run the oracle's PTZ-IBA LM.  Returns (cam, ray, tlw, summary dict, Trace|None)."""
     p, keep = _ba_problem(scene.obs_uv, scene.obs_cam, scene.obs_ray, scene.ray_weight, scene.n_cam, scene.n_ray,
-                          scene.factor_type, obs3d)
+                          scene.factor_type, obs3d, getattr(scene, "ic_of_cam", None))
     cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
     ray = np.array(scene.ray_init if ray0 is None else ray0, dtype=np.float64, order="C").copy()
     tlw = np.zeros(6) if tlw0 is None else np.array(tlw0, dtype=np.float64).copy()

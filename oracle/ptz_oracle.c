@@ -833,6 +833,12 @@ typedef struct {
   int n_free;
   int n_amb;
   uint8_t* cam_active;   /* camera has >= 1 residual block (problem_.HasParameterBlock) */
+  /* shared intrinsics: tangent index of camera i's free slot k (its own slot, or the slot of the first camera of its
+   * intrinsics group for the intrinsic parameters); slots that nobody maps to stay in the vector as zero columns,
+   * exactly like the reference's never-read fy */
+  int* cmap;             /* [n_cam * ncf] */
+  uint8_t* counts_intr;  /* [n_cam] 1 = this camera's copy of the intrinsics block is the one counted in |x| */
+  int* first_of_group;   /* [n_cam] first camera (lowest index) with the same intrinsics id */
   /* stored linearisation (weighted; scaled in place by scale_cols) */
   double* Jc;   /* [n_obs][2][ncf] */
   double* Jr;   /* [n_obs][2][3]   */
@@ -1126,6 +1132,28 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
     if (p->obs3d_cam[a] < 0 || p->obs3d_cam[a] >= p->n_cam) return 1;
     c->cam_active[p->obs3d_cam[a]] = 1;
   }
+  c->cmap = (int*)malloc(sizeof(int) * ((size_t)p->n_cam * c->ncf + 1));
+  c->counts_intr = (uint8_t*)calloc((size_t)p->n_cam + 1, 1);
+  c->first_of_group = (int*)malloc(sizeof(int) * ((size_t)p->n_cam + 1));
+  for (int i = 0; i < p->n_cam; ++i) {
+    int first = i;
+    if (p->ic_of_cam)
+      for (int m = 0; m < i; ++m)
+        if (p->ic_of_cam[m] == p->ic_of_cam[i]) { first = m; break; }
+    c->first_of_group[i] = first;
+    for (int k = 0; k < c->ncf; ++k) {
+      int is_intr = c->cfree[k] < 4 || c->cfree[k] >= 10;
+      c->cmap[i * c->ncf + k] = (is_intr ? first : i) * c->ncf + k;
+    }
+  }
+  /* the shared block is in the problem if any member has residuals; it is counted once, at its first active member */
+  for (int i = 0; i < p->n_cam; ++i) {
+    if (!c->cam_active[i]) continue;
+    int seen = 0;
+    for (int m = 0; m < i; ++m)
+      if (c->cam_active[m] && c->first_of_group[m] == c->first_of_group[i]) { seen = 1; break; }
+    c->counts_intr[i] = !seen;
+  }
   c->Jc = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 2 * c->ncf + 1));
   c->Jr = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 6 + 1));
   c->r = (double*)malloc(sizeof(double) * (size_t)(p->n_obs * 2 + 1));
@@ -1144,7 +1172,7 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
 
 static void ba_ctx_free(ba_ctx* c)
 {
-  free(c->cterm); free(c->cam_active); free(c->Jc); free(c->Jr); free(c->r); free(c->Jc3); free(c->Jt3); free(c->r3);
+  free(c->cterm); free(c->cam_active); free(c->cmap); free(c->counts_intr); free(c->first_of_group); free(c->Jc); free(c->Jr); free(c->r); free(c->Jc3); free(c->Jt3); free(c->r3);
   free(c->S); free(c->E); free(c->yr); free(c->ray_ptr);
 }
 
@@ -1221,13 +1249,13 @@ static double ba_linearize(void* vc, const double* x, double* g)
     for (int64_t a = 0; a < p->n_obs; ++a) {
       int ci = p->obs_cam[a], rj = p->obs_ray[a];
       for (int k = 0; k < ncf; ++k)
-        gc[ci * ncf + k] += c->Jc[(2 * a) * ncf + k] * c->r[2 * a] + c->Jc[(2 * a + 1) * ncf + k] * c->r[2 * a + 1];
+        gc[c->cmap[ci * ncf + k]] += c->Jc[(2 * a) * ncf + k] * c->r[2 * a] + c->Jc[(2 * a + 1) * ncf + k] * c->r[2 * a + 1];
       for (int k = 0; k < 3; ++k) gr[3 * rj + k] += c->Jr[6 * a + k] * c->r[2 * a] + c->Jr[6 * a + 3 + k] * c->r[2 * a + 1];
     }
     for (int32_t a = 0; a < p->n_obs3d; ++a) {
       int ci = p->obs3d_cam[a];
       for (int k = 0; k < ncf; ++k)
-        gc[ci * ncf + k] += c->Jc3[(2 * a) * ncf + k] * c->r3[2 * a] + c->Jc3[(2 * a + 1) * ncf + k] * c->r3[2 * a + 1];
+        gc[c->cmap[ci * ncf + k]] += c->Jc3[(2 * a) * ncf + k] * c->r3[2 * a] + c->Jc3[(2 * a + 1) * ncf + k] * c->r3[2 * a + 1];
       for (int k = 0; k < 6; ++k) gt[k] += c->Jt3[12 * a + k] * c->r3[2 * a] + c->Jt3[12 * a + 6 + k] * c->r3[2 * a + 1];
     }
   }
@@ -1247,7 +1275,7 @@ static void ba_col_sqnorm(void* vc, double* out)
     int ci = p->obs_cam[a], rj = p->obs_ray[a];
     for (int k = 0; k < ncf; ++k) {
       double j0 = c->Jc[(2 * a) * ncf + k], j1 = c->Jc[(2 * a + 1) * ncf + k];
-      oc[ci * ncf + k] += j0 * j0 + j1 * j1;
+      oc[c->cmap[ci * ncf + k]] += j0 * j0 + j1 * j1;
     }
     for (int k = 0; k < 3; ++k) orr[3 * rj + k] += c->Jr[6 * a + k] * c->Jr[6 * a + k] + c->Jr[6 * a + 3 + k] * c->Jr[6 * a + 3 + k];
   }
@@ -1255,7 +1283,7 @@ static void ba_col_sqnorm(void* vc, double* out)
     int ci = p->obs3d_cam[a];
     for (int k = 0; k < ncf; ++k) {
       double j0 = c->Jc3[(2 * a) * ncf + k], j1 = c->Jc3[(2 * a + 1) * ncf + k];
-      oc[ci * ncf + k] += j0 * j0 + j1 * j1;
+      oc[c->cmap[ci * ncf + k]] += j0 * j0 + j1 * j1;
     }
     for (int k = 0; k < 6; ++k) ot[k] += c->Jt3[12 * a + k] * c->Jt3[12 * a + k] + c->Jt3[12 * a + 6 + k] * c->Jt3[12 * a + 6 + k];
   }
@@ -1272,8 +1300,8 @@ static void ba_scale_cols(void* vc, const double* s)
   for (int64_t a = 0; a < p->n_obs; ++a) {
     int ci = p->obs_cam[a], rj = p->obs_ray[a];
     for (int k = 0; k < ncf; ++k) {
-      c->Jc[(2 * a) * ncf + k] *= sc[ci * ncf + k];
-      c->Jc[(2 * a + 1) * ncf + k] *= sc[ci * ncf + k];
+      c->Jc[(2 * a) * ncf + k] *= sc[c->cmap[ci * ncf + k]];
+      c->Jc[(2 * a + 1) * ncf + k] *= sc[c->cmap[ci * ncf + k]];
     }
     for (int k = 0; k < 3; ++k) {
       c->Jr[6 * a + k] *= sr[3 * rj + k];
@@ -1283,8 +1311,8 @@ static void ba_scale_cols(void* vc, const double* s)
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     int ci = p->obs3d_cam[a];
     for (int k = 0; k < ncf; ++k) {
-      c->Jc3[(2 * a) * ncf + k] *= sc[ci * ncf + k];
-      c->Jc3[(2 * a + 1) * ncf + k] *= sc[ci * ncf + k];
+      c->Jc3[(2 * a) * ncf + k] *= sc[c->cmap[ci * ncf + k]];
+      c->Jc3[(2 * a + 1) * ncf + k] *= sc[c->cmap[ci * ncf + k]];
     }
     for (int k = 0; k < 6; ++k) {
       c->Jt3[12 * a + k] *= st[k];
@@ -1296,6 +1324,22 @@ static void ba_scale_cols(void* vc, const double* s)
 /* [Ceres-1.14] SchurComplementSolver / SchurEliminator (SPARSE_SCHUR, ptzray_optimizer.cc:471):
  * e-blocks = rays (3x3).  Solves (J^T J + D^2) y = J^T r; any exact elimination order gives the
  * same y up to round-off, so the reduced camera system is factored densely here. */
+/* Add v to entry (i, j) AND (j, i) of the symmetric camera system, of which only the lower triangle is stored.
+ * With shared intrinsics two different (camera, slot) pairs can map to one index: then both mirrored contributions land on
+ * the same diagonal entry. */
+static inline void S_add_pair(double* S, int n, int i, int j, double v)
+{
+  if (i == j) S[(size_t)i * n + i] += 2.0 * v;
+  else if (i > j) S[(size_t)i * n + j] += v;
+  else S[(size_t)j * n + i] += v;
+}
+/* Add v to entry (i, j) of a diagonal block (k >= l visited once): mirrored implicitly by the symmetric storage. */
+static inline void S_add_lower(double* S, int n, int i, int j, double v)
+{
+  if (i >= j) S[(size_t)i * n + j] += v;
+  else S[(size_t)j * n + i] += v;
+}
+
 static int ba_solve(void* vc, const double* D, double* y)
 {
   ba_ctx* c = (ba_ctx*)vc;
@@ -1314,8 +1358,8 @@ static int ba_solve(void* vc, const double* D, double* y)
     const double* j0 = c->Jc + (2 * a) * ncf;
     const double* j1 = j0 + ncf;
     for (int k = 0; k < ncf; ++k) {
-      b[ci * ncf + k] += j0[k] * c->r[2 * a] + j1[k] * c->r[2 * a + 1];
-      for (int l = 0; l <= k; ++l) S[(size_t)(ci * ncf + k) * n + ci * ncf + l] += j0[k] * j0[l] + j1[k] * j1[l];
+      b[c->cmap[ci * ncf + k]] += j0[k] * c->r[2 * a] + j1[k] * c->r[2 * a + 1];
+      for (int l = 0; l <= k; ++l) S_add_lower(S, n, c->cmap[ci * ncf + k], c->cmap[ci * ncf + l], j0[k] * j0[l] + j1[k] * j1[l]);
     }
   }
   /* 2D-3D observations: camera block, tlw block, camera-tlw coupling */
@@ -1327,13 +1371,13 @@ static int ba_solve(void* vc, const double* D, double* y)
     const double* q0 = c->Jt3 + 12 * (size_t)a;
     const double* q1 = q0 + 6;
     for (int k = 0; k < ncf; ++k) {
-      b[ci * ncf + k] += j0[k] * c->r3[2 * a] + j1[k] * c->r3[2 * a + 1];
-      for (int l = 0; l <= k; ++l) S[(size_t)(ci * ncf + k) * n + ci * ncf + l] += j0[k] * j0[l] + j1[k] * j1[l];
+      b[c->cmap[ci * ncf + k]] += j0[k] * c->r3[2 * a] + j1[k] * c->r3[2 * a + 1];
+      for (int l = 0; l <= k; ++l) S_add_lower(S, n, c->cmap[ci * ncf + k], c->cmap[ci * ncf + l], j0[k] * j0[l] + j1[k] * j1[l]);
     }
     for (int k = 0; k < 6; ++k) {
       b[t0 + k] += q0[k] * c->r3[2 * a] + q1[k] * c->r3[2 * a + 1];
       for (int l = 0; l <= k; ++l) S[(size_t)(t0 + k) * n + t0 + l] += q0[k] * q0[l] + q1[k] * q1[l];
-      for (int l = 0; l < ncf; ++l) S[(size_t)(t0 + k) * n + ci * ncf + l] += q0[k] * j0[l] + q1[k] * j1[l];
+      for (int l = 0; l < ncf; ++l) S[(size_t)(t0 + k) * n + c->cmap[ci * ncf + l]] += q0[k] * j0[l] + q1[k] * j1[l];
     }
   }
   /* eliminate rays */
@@ -1378,7 +1422,7 @@ static int ba_solve(void* vc, const double* D, double* y)
       for (int k = 0; k < ncf; ++k)
         for (int l = 0; l < 3; ++l) Ya[3 * k + l] = Wa[3 * k] * E[l] + Wa[3 * k + 1] * E[3 + l] + Wa[3 * k + 2] * E[6 + l];
       int ci = p->obs_cam[a];
-      for (int k = 0; k < ncf; ++k) b[ci * ncf + k] -= Wa[3 * k] * z[0] + Wa[3 * k + 1] * z[1] + Wa[3 * k + 2] * z[2];
+      for (int k = 0; k < ncf; ++k) b[c->cmap[ci * ncf + k]] -= Wa[3 * k] * z[0] + Wa[3 * k + 1] * z[1] + Wa[3 * k + 2] * z[2];
     }
     for (int64_t a = a0; a < a1; ++a)
       for (int64_t bb = a0; bb < a1; ++bb) {
@@ -1389,7 +1433,9 @@ static int ba_solve(void* vc, const double* D, double* y)
         for (int k = 0; k < ncf; ++k)
           for (int l = 0; l < ncf; ++l) {
             if (ci == cj && l > k) continue;
-            S[(size_t)(ci * ncf + k) * n + cj * ncf + l] -= Ya[3 * k] * Wb[3 * l] + Ya[3 * k + 1] * Wb[3 * l + 1] + Ya[3 * k + 2] * Wb[3 * l + 2];
+            const double v = -(Ya[3 * k] * Wb[3 * l] + Ya[3 * k + 1] * Wb[3 * l + 1] + Ya[3 * k + 2] * Wb[3 * l + 2]);
+            if (ci == cj) S_add_lower(S, n, c->cmap[ci * ncf + k], c->cmap[cj * ncf + l], v);
+            else S_add_pair(S, n, c->cmap[ci * ncf + k], c->cmap[cj * ncf + l], v);
           }
       }
     free(heap);
@@ -1407,7 +1453,7 @@ static int ba_solve(void* vc, const double* D, double* y)
       const double* q0 = c->Jr + 6 * a;
       const double* q1 = q0 + 3;
       double m0 = 0, m1 = 0; /* Jc_a y_c */
-      for (int k = 0; k < ncf; ++k) { m0 += j0[k] * b[ci * ncf + k]; m1 += j1[k] * b[ci * ncf + k]; }
+      for (int k = 0; k < ncf; ++k) { m0 += j0[k] * b[c->cmap[ci * ncf + k]]; m1 += j1[k] * b[c->cmap[ci * ncf + k]]; }
       for (int l = 0; l < 3; ++l) t[l] -= q0[l] * m0 + q1[l] * m1;
     }
     mat3_mul_vec(c->E + 9 * (size_t)j, t, y + c->n_cs + 3 * j);
@@ -1427,14 +1473,14 @@ static double ba_model_cost_change(void* vc, const double* step)
   for (int64_t a = 0; a < p->n_obs; ++a) {
     int ci = p->obs_cam[a], rj = p->obs_ray[a];
     double m0 = 0, m1 = 0;
-    for (int k = 0; k < ncf; ++k) { m0 += c->Jc[(2 * a) * ncf + k] * sc[ci * ncf + k]; m1 += c->Jc[(2 * a + 1) * ncf + k] * sc[ci * ncf + k]; }
+    for (int k = 0; k < ncf; ++k) { m0 += c->Jc[(2 * a) * ncf + k] * sc[c->cmap[ci * ncf + k]]; m1 += c->Jc[(2 * a + 1) * ncf + k] * sc[c->cmap[ci * ncf + k]]; }
     for (int k = 0; k < 3; ++k) { m0 += c->Jr[6 * a + k] * sr[3 * rj + k]; m1 += c->Jr[6 * a + 3 + k] * sr[3 * rj + k]; }
     acc += m0 * (c->r[2 * a] + m0 / 2.0) + m1 * (c->r[2 * a + 1] + m1 / 2.0);
   }
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     int ci = p->obs3d_cam[a];
     double m0 = 0, m1 = 0;
-    for (int k = 0; k < ncf; ++k) { m0 += c->Jc3[(2 * a) * ncf + k] * sc[ci * ncf + k]; m1 += c->Jc3[(2 * a + 1) * ncf + k] * sc[ci * ncf + k]; }
+    for (int k = 0; k < ncf; ++k) { m0 += c->Jc3[(2 * a) * ncf + k] * sc[c->cmap[ci * ncf + k]]; m1 += c->Jc3[(2 * a + 1) * ncf + k] * sc[c->cmap[ci * ncf + k]]; }
     for (int k = 0; k < 6; ++k) { m0 += c->Jt3[12 * a + k] * st[k]; m1 += c->Jt3[12 * a + 6 + k] * st[k]; }
     acc += m0 * (c->r3[2 * a] + m0 / 2.0) + m1 * (c->r3[2 * a + 1] + m1 / 2.0);
   }
@@ -1448,7 +1494,7 @@ static void ba_plus(void* vc, const double* x, const double* delta, double* xo)
   const int ncf = c->ncf;
   memcpy(xo, x, sizeof(double) * (size_t)c->n_amb);
   for (int i = 0; i < p->n_cam; ++i)
-    for (int k = 0; k < ncf; ++k) xo[15 * (size_t)i + c->cfree[k]] += delta[i * ncf + k];
+    for (int k = 0; k < ncf; ++k) xo[15 * (size_t)i + c->cfree[k]] += delta[c->cmap[i * ncf + k]];
   if (c->has_tlw)
     for (int k = 0; k < 6; ++k) xo[15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + k] += delta[ncf * p->n_cam + k];
   for (int j = 0; j < 3 * p->n_ray; ++j) xo[15 * (size_t)p->n_cam + j] += delta[c->n_cs + j];
@@ -1464,6 +1510,8 @@ static double ba_diff_norm(void* vc, const double* a, const double* b)
   for (int i = 0; i < p->n_cam; ++i) {
     if (!c->cam_active[i]) continue;
     for (int k = 0; k < 15; ++k) {
+      /* a shared intrinsics block (indices 0-3, 10-14) is one parameter block: counted at one member only */
+      if ((k < 4 || k >= 10) && !c->counts_intr[i]) continue;
       double d = a[15 * (size_t)i + k] - (b ? b[15 * (size_t)i + k] : 0.0);
       acc += d * d;
     }
@@ -1506,6 +1554,13 @@ int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* 
   set_threads(o->num_threads);
   double* x = (double*)malloc(sizeof(double) * (size_t)c.n_amb);
   memcpy(x, cam, sizeof(double) * 15 * (size_t)p->n_cam);
+  /* intrinsics_param_.insert({ic_id, ...}) keeps the FIRST camera's values for a shared block (ptzray_optimizer.cc:645-650) */
+  for (int i = 0; i < p->n_cam; ++i) {
+    const int f = c.first_of_group[i];
+    if (f == i) continue;
+    for (int k = 0; k < 15; ++k)
+      if (k < 4 || k >= 10) x[15 * (size_t)i + k] = x[15 * (size_t)f + k];
+  }
   memcpy(x + 15 * (size_t)p->n_cam, ray, sizeof(double) * 3 * (size_t)p->n_ray);
   memcpy(x + 15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray, tlw, sizeof(double) * 6);
   lm_problem P = {c.n_free, c.n_amb, &c, ba_cost, ba_linearize, ba_col_sqnorm, ba_scale_cols, ba_solve,

@@ -129,6 +129,9 @@ typedef struct {
   const double* obs3d_xyz;    /* [3*n_obs3d] world points */
   const int32_t* obs3d_cam;   /* [n_obs3d] */
   int32_t factor_type;        /* ORC_PTZRay... */
+  /* shared_ic_ids_ (ptzray_optimizer.cc:427-428, 497-505): cameras with equal ids share ONE intrinsics parameter block
+   * (intrinsics_param_ is keyed by the id, :645-650).  NULL = every camera its own block (the reference's default). */
+  const int32_t* ic_of_cam;   /* [n_cam] or NULL */
 } orc_ba_problem;
 
 /* cam[15*n_cam], ray[3*n_ray], tlw[6] are updated in place with the best point found

@@ -116,6 +116,7 @@ class Scene:
     obs3d: dict | None = None        # 2D-3D annotations: {uv float32 [m,2], xyz float64 [m,3], cam int32 [m]}
     tlw_gt: np.ndarray | None = None   # T_l_w as [rvec, t] (ptzray_optimizer.cc:507-513)
     tlw_init: np.ndarray | None = None
+    ic_of_cam: np.ndarray | None = None  # int32 [n_cam] intrinsics-block id per camera (SetSharedIntrinsics); None = own block
 
     @property
     def n_obs(self) -> int:
@@ -144,7 +145,7 @@ def pix2ray(obs_uv, obs_cam, obs_ray, n_ray, cam):
 def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, factor_type: int = 0,
                width: int = 1920, height: int = 1080, pan_range_deg: float | None = None,
                noise_px: float = 0.5, init_rot_sigma_deg: float = 0.5, init_focal: float | None = None,
-               min_track_len: int = 4) -> Scene:
+               min_track_len: int = 4, n_intrinsics_groups: int | None = None) -> Scene:
     """Synthetic PTZ rig.  C1: n_views=20, obs_per_view=100.  C2: 200 x 500.
 
     pan_range_deg=None picks min(360, 6 * n_views): a full 360-degree ring needs ~1.8-degree pan spacing for
@@ -162,6 +163,12 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
     tilt = np.deg2rad(np.array([-10.0, 0.0, 10.0])[np.arange(N) % 3] + rng.uniform(N, -0.2, 0.2))
     focal = rng.uniform(N, 1800.0, 3200.0) * (width / 1920.0)
     k1 = rng.uniform(N, -0.05, 0.05) if factor_type != 0 else np.zeros(N)
+    ic_of_cam = None
+    if n_intrinsics_groups is not None:
+        # fixed-zoom rigs: views i with the same (i mod G) share one intrinsics block (SetSharedIntrinsics)
+        ic_of_cam = (np.arange(N) % n_intrinsics_groups).astype(np.int32)
+        focal = focal[:n_intrinsics_groups][ic_of_cam]
+        k1 = k1[:n_intrinsics_groups][ic_of_cam]
     Rgt = np.stack([_rot_x(tilt[i]) @ _rot_y(pan[i]) for i in range(N)])
     cam_gt = np.zeros((N, 15))
     cam_gt[:, 0] = focal
@@ -245,7 +252,7 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
     ray_init = pix2ray(obs_uv, obs_cam, obs_ray, n_ray, cam_init)
     return Scene(n_cam=N, n_ray=n_ray, width=width, height=height, factor_type=factor_type, obs_uv=obs_uv,
                  obs_cam=obs_cam, obs_ray=obs_ray, ray_weight=ray_weight, cam_gt=cam_gt, cam_init=cam_init,
-                 ray_gt=ray_gt, ray_init=ray_init, seed=seed,
+                 ray_gt=ray_gt, ray_init=ray_init, seed=seed, ic_of_cam=ic_of_cam,
                  meta={"obs_per_view_mean": n_obs / N, "track_len_mean": n_obs / max(n_ray, 1)})
 
 
