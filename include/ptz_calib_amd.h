@@ -117,6 +117,10 @@ typedef struct ptz_ba_problem {
   const double* obs3d_xyz;   /* host [3*n_obs3d] */
   const int32_t* obs3d_cam;  /* host [n_obs3d] */
   int32_t factor_type;       /* PTZ_BA_* */
+  /* PTZRayOptimizer::SetSharedIntrinsics (ptzray_optimizer.cc:497-505): cameras with equal ids share ONE intrinsics block
+   * (fx, fy, cx, cy, k1..p2); its initial value is the first such camera's (:645-650).  NULL = every camera its own block,
+   * the reference's default (:427-428). */
+  const int32_t* ic_of_cam;  /* host [n_cam] or NULL */
 } ptz_ba_problem;
 
 typedef struct ptz_ba_batch ptz_ba_batch; /* opaque: device-resident problems + workspaces */

@@ -55,7 +55,7 @@ class BaProblem(C.Structure):
     _fields_ = [("n_cam", C.c_int32), ("n_ray", C.c_int32), ("n_obs", C.c_int64), ("obs_uv", C.c_void_p),
                 ("obs_cam", C.c_void_p), ("obs_ray", C.c_void_p), ("ray_weight", C.c_void_p),
                 ("n_obs3d", C.c_int32), ("obs3d_uv", C.c_void_p), ("obs3d_xyz", C.c_void_p),
-                ("obs3d_cam", C.c_void_p), ("factor_type", C.c_int32)]
+                ("obs3d_cam", C.c_void_p), ("factor_type", C.c_int32), ("ic_of_cam", C.c_void_p)]
 
 
 _lib = None
@@ -121,6 +121,12 @@ def _pack_problem(sc, keep):
     else:
         p.n_obs3d = 0
     p.factor_type = sc.factor_type
+    ic = getattr(sc, "ic_of_cam", None)
+    if ic is not None:
+        arrs["ic"] = np.ascontiguousarray(ic, dtype=np.int32)
+        if len(arrs["ic"]) != sc.n_cam:
+            raise ValueError("ic_of_cam must have one id per camera")
+        p.ic_of_cam = _p(arrs["ic"])
     return p
 
 

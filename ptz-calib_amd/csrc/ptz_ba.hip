@@ -53,6 +53,7 @@ struct SceneDev {
   int n;         // NC * n_cam: order of the reduced camera system
   int idx;       // global scene index (the CSR pointer arrays carry one extra entry per preceding scene)
   int o3_off, n_o3;  // 2D-3D annotation observations of the scene
+  int grp_off, n_grp;  // shared-intrinsics groups with >= 2 cameras (ranges into grp_ptr, which carries n_grp + 1 entries per scene)
 };
 
 struct LmState {
@@ -130,6 +131,12 @@ struct Dev {
   double* Jc3;       // [total_o3][2][NC] (scaled)
   double* Jt3;       // [total_o3][2][6]  (scaled)
   double* r3;        // [total_o3][2]
+  // shared intrinsics (SetSharedIntrinsics): groups of cameras whose intrinsic columns are one parameter
+  int shared;            // 0 = no group anywhere in the batch: none of the group kernels is launched
+  const int* grp_ptr;    // per scene n_grp + 1 offsets into grp_mem (global), at [scene.grp_off + scene.idx ...]
+  const int* grp_mem;    // scene-local camera ids of a group, ascending; the LAST one is the representative
+  const unsigned char* cam_flag;  // [total_cam] bit 0: this camera's intrinsics block is counted in |x| (one per group)
+  double* gfold;         // [total_cam][NC] gradient with the shared slots folded onto the representative
   // LM
   LmState* lm;
   int* active;       // [n_scene]
@@ -432,6 +439,164 @@ __global__ void k_jacobi_scale(Dev d)
   if (Dims<TYPE>::HAS3D && t < 6) d.scale_t[(size_t)s.idx * 6 + t] = 1.0 / (1.0 + sqrt(d.Ut[(size_t)s.idx * 36 + t * 7]));
 }
 
+// ---- shared intrinsics (PTZRayOptimizer::SetSharedIntrinsics, ptzray_optimizer.cc:497-505) ------------------------------
+// Cameras of a group share ONE intrinsics parameter block.  The per-camera pipeline above stays as it is (every camera
+// still carries its own copy of the intrinsic columns, with identical values and steps); what makes the copies one
+// parameter is a change of variables x_cam = P x_shared applied where it matters:
+//   * column norms, hence Jacobi scales and LM diagonals, are those of the stacked group column (k_group_scale, k_group_diag);
+//   * the reduced camera system is folded, S' = P^T S P, b' = P^T b, onto the group's representative (k_fold_system),
+//     solved, and the representative's step is copied back to the members (k_group_expand);
+//   * gradient norm and |x| count the block once (k_group_grad, cam_flag in k_lm_pre / k_lm_post).
+// The representative is the LAST camera of the group, so that the dense rows the fold creates sit at the bottom of the
+// system and cause no extra fill above them.
+template <int TYPE> __device__ __forceinline__ bool is_intr_slot(int k)
+{
+  const int a = Dims<TYPE>::at(k);
+  return a < 4 || a >= 10;
+}
+
+// thread = (group, slot): group-wide Jacobi scale from the summed squared column norms (members ascending)
+template <int TYPE>
+__global__ void k_group_scale(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t / NC, k = t % NC;
+  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double sum = 0;
+  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  const double sc_g = 1.0 / (1.0 + sqrt(sum));
+  for (int e = gp[g]; e < gp[g + 1]; ++e) d.scale_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = sc_g;
+}
+
+// LM diagonal of a shared slot: clamp(sum of the members' diagonal entries); each member carries an equal share so that
+// the fold of S adds them back up
+template <int TYPE>
+__global__ void k_group_diag(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (d.lm[sc].reuse_diagonal) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t / NC, k = t % NC;
+  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double sum = 0;
+  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  const double share = fmin(fmax(sum, d.opt.min_lm_diagonal), d.opt.max_lm_diagonal) / (double)(gp[g + 1] - gp[g]);
+  for (int e = gp[g]; e < gp[g + 1]; ++e) d.diag_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
+}
+
+// gradient with the shared slots folded onto the representative (others 0); every other slot copied.
+// One workgroup per scene: copy, barrier, fold.
+template <int TYPE>
+__global__ void k_group_grad(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  for (int t = threadIdx.x; t < s.n_cam * NC; t += blockDim.x) d.gfold[(size_t)s.cam_off * NC + t] = d.gc[(size_t)s.cam_off * NC + t];
+  __syncthreads();
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+    const int g = t / NC, k = t % NC;
+    if (!is_intr_slot<TYPE>(k)) continue;
+    double sum = 0;
+    for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
+    for (int e = gp[g]; e < gp[g + 1]; ++e)
+      d.gfold[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = (e == gp[g + 1] - 1) ? sum : 0.0;
+  }
+}
+
+// S' = P^T S P, b' = P^T b in place on the lower-triangular storage (row n = right-hand side), one workgroup per scene,
+// one (group, slot) after the other.  For slot index(m) = m * NC + k of the members m:
+//   v[c]  = sum_m Sfull[index(m)][c]            for every column c = 0 .. n (c = n is the right-hand side)
+//   S'[rep][c] = v[c]  (c not a member slot),   S'[rep][rep] = sum_m v[index(m)],
+//   rows / columns of the other members: 0, diagonal 1, right-hand side 0 (their step is copied from the representative).
+template <int TYPE>
+__global__ __launch_bounds__(1024) void k_fold_system(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (s.n_grp == 0) return;
+  const int np = d.chol.np, n = s.n;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  extern __shared__ double v[];  // [n + 1]
+  __shared__ double dsum;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  auto at = [&](int i, int c) -> double& { return i >= c ? A[(size_t)i * np + c] : A[(size_t)c * np + i]; };
+  for (int g = 0; g < s.n_grp; ++g) {
+    const int e0 = gp[g], e1 = gp[g + 1];
+    const int rep = d.grp_mem[e1 - 1];
+    for (int k = 0; k < NC; ++k) {
+      if (!is_intr_slot<TYPE>(k)) continue;
+      for (int c = threadIdx.x; c <= n; c += blockDim.x) {
+        double sum = 0;
+        for (int e = e0; e < e1; ++e) sum += at(d.grp_mem[e] * NC + k, c);
+        v[c] = sum;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double sum = 0;
+        for (int e = e0; e < e1; ++e) sum += v[d.grp_mem[e] * NC + k];
+        dsum = sum;
+      }
+      __syncthreads();
+      const int ri = rep * NC + k;
+      for (int c = threadIdx.x; c <= n; c += blockDim.x) {
+        // is c one of the member slots of this (group, slot)?
+        bool member = false;
+        if (c < n && c % NC == k) {
+          const int cam = c / NC;
+          for (int e = e0; e < e1 && !member; ++e) member = d.grp_mem[e] == cam;
+        }
+        if (!member) {
+          at(ri, c) = v[c];
+          for (int e = e0; e < e1 - 1; ++e) at(d.grp_mem[e] * NC + k, c) = 0.0;
+        }
+      }
+      __syncthreads();
+      // member x member block: representative diagonal = folded sum, other members identity, cross entries 0
+      for (int t = threadIdx.x; t < (e1 - e0) * (e1 - e0); t += blockDim.x) {
+        const int a = t / (e1 - e0), bq = t % (e1 - e0);
+        if (bq > a) continue;
+        const int ia = d.grp_mem[e0 + a] * NC + k, ib = d.grp_mem[e0 + bq] * NC + k;
+        double val = 0.0;
+        if (a == bq) val = (a == e1 - e0 - 1) ? dsum : 1.0;
+        at(ia, ib) = val;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// after the solve: the members of a group take the representative's step for the shared slots
+template <int TYPE>
+__global__ void k_group_expand(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double* y = d.yc + (size_t)sc * d.chol.np;
+  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+    const int g = t / NC, k = t % NC;
+    if (!is_intr_slot<TYPE>(k)) continue;
+    const double yr = y[d.grp_mem[gp[g + 1] - 1] * NC + k];
+    for (int e = gp[g]; e < gp[g + 1] - 1; ++e) y[d.grp_mem[e] * NC + k] = yr;
+  }
+}
+
 // ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
 constexpr int LM_THREADS = 1024;  // the LM bookkeeping kernels are one workgroup per scene: wide, to shorten their reductions
 template <int TYPE>
@@ -452,9 +617,13 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
     for (int i = tid; i < s.n_cam; i += LM_THREADS) {
       const int gi = s.cam_off + i;
       c += d.costc[gi];
-      for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(d.gc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
-      if (cp[i + 1] > cp[i])  // parameter blocks of cameras without residuals are not in the problem
-        for (int k = 0; k < 15; ++k) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
+      const double* gsrc = d.shared ? d.gfold : d.gc;  // shared intrinsics: the group's gradient sits at its representative
+      for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(gsrc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
+      if (cp[i + 1] > cp[i]) {  // parameter blocks of cameras without residuals are not in the problem
+        const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
+        for (int k = 0; k < 15; ++k)
+          if (intr || (k >= 4 && k < 10)) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
+      }
     }
     const double* ray = cur_ray(d, s, st);
     for (int j = tid; j < s.n_ray; j += LM_THREADS) {
@@ -988,7 +1157,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   double dn = 0, cn = 0;
   for (int i = tid; i < s.n_cam; i += LM_THREADS) {
     if (cp[i + 1] <= cp[i]) continue;
+    const bool intr = !d.shared || (d.cam_flag[s.cam_off + i] & 1);
     for (int k = 0; k < 15; ++k) {
+      if (!intr && (k < 4 || k >= 10)) continue;
       const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
       dn += (a - b) * (a - b);
       cn += b * b;
@@ -1148,6 +1319,9 @@ struct ptz_ba_batch {
   int* h_active = nullptr;  // pinned
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
   int has3d = 0, total_o3 = 0;
+  // shared intrinsics: per global camera, the global index of the first camera of its group (source of the initial values)
+  std::vector<int> first_of_group;
+  int max_grp = 0;
   bool has_state = false;
   double last_ms = 0;
   // profiling
@@ -1222,6 +1396,7 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
   LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
+  if (d.shared) LAUNCH(k_group_grad<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   b->prof_end();
 }
 
@@ -1272,6 +1447,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_begin(P_RAYPREP);
   LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), 0, d);
   LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+  if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_CLEAR);
   chol_clear(d.chol, st);
@@ -1279,8 +1455,10 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_begin(P_SCHUR);
   LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
+  if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 2), d);
   b->prof_end();
   chol_factor_solve_profiled(d.chol, d.yc, st, b);
+  if (d.shared) LAUNCH(k_group_expand<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_begin(P_BACKSUB);
   LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
@@ -1298,6 +1476,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
     LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
+    if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
     b->prof_end();
   }
 }
@@ -1331,6 +1510,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   enqueue_linearize<TYPE>(b);
   if (b->opt.jacobi_scaling) {
     LAUNCH(k_jacobi_scale<TYPE>, dim3((std::max(b->max_cam, b->max_ray) + 255) / 256, B), dim3(256), 0, d);
+    if (d.shared) LAUNCH(k_group_scale<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
     enqueue_linearize<TYPE>(b);
   }
   // fork: every group's stream continues after the common prologue
@@ -1570,6 +1750,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<double> h_w, h_o3xyz;
   std::vector<float2> h_o3uv;
   std::vector<int> h_o3cam;
+  std::vector<int> h_grpptr, h_grpmem;
+  std::vector<unsigned char> h_camflag;
+  int total_grp = 0;
+  bool any_shared = false;
   int64_t tot_obs = 0, tot_ent = 0;
   for (int i = 0; i < n; ++i) {
     tot_obs += problems[i].n_obs;
@@ -1689,6 +1873,40 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       b->total_ent += (int)n_keys;
       b->total_pair += npair;
     }
+    // shared intrinsics groups (ids are arbitrary integers; members in ascending camera order; groups in order of their
+    // first member); a camera alone in its group needs nothing
+    {
+      s.grp_off = total_grp;
+      s.n_grp = 0;
+      std::vector<int> first(p.n_cam);
+      for (int c = 0; c < p.n_cam; ++c) {
+        first[c] = c;
+        if (p.ic_of_cam)
+          for (int m = 0; m < c; ++m)
+            if (p.ic_of_cam[m] == p.ic_of_cam[c]) { first[c] = m; break; }
+      }
+      for (int c = 0; c < p.n_cam; ++c) b->first_of_group.push_back(b->total_cam + first[c]);
+      std::vector<char> counted(p.n_cam, 0);  // group (by first member) already has its counting camera
+      for (int c = 0; c < p.n_cam; ++c) {
+        const bool has_res = cnt_cam[c + 1] > cnt_cam[c];
+        unsigned char flag = 0;
+        if (has_res && !counted[first[c]]) { flag = 1; counted[first[c]] = 1; }
+        h_camflag.push_back(flag);
+      }
+      h_grpptr.push_back((int)h_grpmem.size());
+      for (int c = 0; c < p.n_cam; ++c) {
+        if (first[c] != c) continue;
+        int members = 0;
+        for (int m = c; m < p.n_cam; ++m) members += first[m] == c;
+        if (members < 2) continue;
+        for (int m = c; m < p.n_cam; ++m) if (first[m] == c) h_grpmem.push_back(m);
+        h_grpptr.push_back((int)h_grpmem.size());
+        ++s.n_grp;
+        any_shared = true;
+      }
+      total_grp += s.n_grp;
+      b->max_grp = std::max(b->max_grp, s.n_grp);
+    }
     b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk + 1;
     b->max_cam = std::max(b->max_cam, p.n_cam); b->max_ray = std::max(b->max_ray, p.n_ray);
     b->max_chunk = std::max(b->max_chunk, s.n_chunk); b->max_pair = std::max(b->max_pair, s.n_pair);
@@ -1756,6 +1974,13 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
+  d.shared = any_shared ? 1 : 0;
+  if (any_shared) {
+    TRY(upload(b, h_grpptr, &d.grp_ptr));
+    TRY(upload(b, h_grpmem, &d.grp_mem));
+    TRY(upload(b, h_camflag, &d.cam_flag));
+    TRY(b->alloc(&d.gfold, (size_t)b->total_cam * NC));
+  }
   TRY(b->alloc(&d.W, (size_t)b->total_obs * 16));  // room for the widest row stride
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
@@ -1796,6 +2021,17 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
           for (int e = tile_lo(cj); e <= tile_hi(cj); ++e) {
             if (a >= e) m[a * nt + e] = 1; else m[e * nt + a] = 1;
           }
+      }
+      // shared intrinsics: the fold puts a dense row / column at every group's representative (its last camera)
+      if (any_shared) {
+        const int* gp = h_grpptr.data() + sd.grp_off + i;
+        for (int g = 0; g < sd.n_grp; ++g) {
+          const int rep = h_grpmem[gp[g + 1] - 1];
+          for (int a = tile_lo(rep); a <= tile_hi(rep); ++a) {
+            for (int e = 0; e <= a; ++e) m[a * nt + e] = 1;
+            for (int r = a; r < nt; ++r) m[r * nt + a] = 1;
+          }
+        }
       }
       // dense rows: the global block (if any) and the rhs row, index n_cam * NC .. n
       for (int a = (sd.n_cam * NC) / CHOL_NB; a < nt; ++a)
@@ -1868,7 +2104,18 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
 {
   if (!b || !cam || !ray) return PTZ_EINVAL;
   PTZ_HIP_TRY(hipSetDevice(b->device));
-  PTZ_HIP_TRY(hipMemcpy(b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
+  if (b->d.shared) {
+    // a shared block starts from its first camera's values (intrinsics_param_.insert, ptzray_optimizer.cc:645-650)
+    std::vector<double> c(cam, cam + 15 * (size_t)b->total_cam);
+    for (int i = 0; i < b->total_cam; ++i) {
+      const int f = b->first_of_group[i];
+      if (f == i) continue;
+      for (int k = 0; k < 15; ++k)
+        if (k < 4 || k >= 10) c[15 * (size_t)i + k] = c[15 * (size_t)f + k];
+    }
+    PTZ_HIP_TRY(hipMemcpy(b->cam0, c.data(), sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
+  }
+  else PTZ_HIP_TRY(hipMemcpy(b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
   PTZ_HIP_TRY(hipMemcpy(b->ray0, ray, sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
   if (tlw) PTZ_HIP_TRY(hipMemcpy(b->tlw0, tlw, sizeof(double) * 6 * b->n_scene, hipMemcpyHostToDevice));
   else PTZ_HIP_TRY(hipMemset(b->tlw0, 0, sizeof(double) * 6 * b->n_scene));

@@ -181,6 +181,27 @@ int32_t ptzh_ptzray_georef(int32_t n_img, const int64_t* kp_ptr, const float* kp
   return ok ? 1 : 0;
 }
 
+// Same as ptzh_ptzray_georef without annotations, with PTZRayOptimizer::SetSharedIntrinsics(shared_ic_ids [n_img]) applied.
+int32_t ptzh_ptzray_solve_shared(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, int32_t n_pairs, const int64_t* src,
+                                 const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t, double* cam15,
+                                 const int64_t* shared_ic_ids, int32_t max_iter, int32_t type, ptz_lm_summary* summary)
+{
+  std::vector<ImageFeatures> feats;
+  std::vector<MatchesInfo> mis;
+  std::vector<Camera> cams;
+  BuildInputs(n_img, kp_ptr, kp_xy, nullptr, n_pairs, src, dst, match_ptr, q, t, cam15, feats, mis, cams);
+  PTZRayOptimizer opt(feats, mis, cams, {}, max_iter, static_cast<FACTOR_TYPE>(type));
+  opt.SetSharedIntrinsics(std::vector<long>(shared_ic_ids, shared_ic_ids + n_img));
+  const bool ok = opt.Solve(cams);
+  if (summary) *summary = opt.summary();
+  if (ok)
+    for (int i = 0; i < n_img; ++i) {
+      const std::vector<double> v = cams[i].ToVector();
+      memcpy(cam15 + 15 * i, v.data(), sizeof(double) * 15);
+    }
+  return ok ? 1 : 0;
+}
+
 int32_t ptzh_ptzray_solve(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, int32_t n_pairs, const int64_t* src,
                           const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t, double* cam15,
                           const int64_t* cand_ids, int32_t n_cand, int32_t max_iter, int32_t type, int32_t solve_on_device,

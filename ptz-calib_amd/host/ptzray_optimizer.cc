@@ -266,10 +266,8 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   if (!CheckValid()) return false;
   FindTracks();
   SetInitTransLocalToWorld();
-  // Device path limits (documented in DESIGN.md): shared intrinsics and the Fxfy / Disp factor types are not
-  // implemented yet -> behave as a failed solve, never as a silent CPU solve.
-  for (size_t i = 0; i < num_cams_; ++i)
-    if (shared_ic_ids_[i] != static_cast<long>(i)) return false;
+  // Device path limits (documented in DESIGN.md): the Fxfy / Disp factor types are not implemented -> behave as a failed
+  // solve, never as a silent CPU solve.
   if (type_ != PTZRay && type_ != PTZRayDist) return false;
   Pack();
   PackedBA& p = packed_;
@@ -284,6 +282,14 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   prob.obs_ray = p.obs_ray.data();
   prob.ray_weight = p.ray_weight.data();
   prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : PTZ_BA_PTZRayDist;
+  // SetSharedIntrinsics: the intrinsics block id of every candidate camera (ptzray_optimizer.cc:643-650)
+  p.ic_of_cam.clear();
+  bool shared = false;
+  for (long image : p.cam_image) {
+    p.ic_of_cam.push_back(static_cast<int32_t>(shared_ic_ids_[image]));
+    shared |= shared_ic_ids_[image] != image;
+  }
+  if (shared) prob.ic_of_cam = p.ic_of_cam.data();
   prob.n_obs3d = static_cast<int32_t>(p.obs3d_cam.size());
   if (prob.n_obs3d > 0) {
     prob.obs3d_uv = p.obs3d_uv.data();

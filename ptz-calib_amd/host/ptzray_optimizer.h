@@ -28,6 +28,7 @@ struct PackedBA {
   std::vector<float> obs3d_uv;     // [2*n_obs3d] annotation pixels, cameras ascending (ptzray_optimizer.cc:894-917)
   std::vector<double> obs3d_xyz;   // [3*n_obs3d]
   std::vector<int32_t> obs3d_cam;  // compact camera id
+  std::vector<int32_t> ic_of_cam;  // intrinsics block id per compact camera (SetSharedIntrinsics)
   std::array<double, 6> tlw{{0, 0, 0, 0, 0, 0}};  // T_l_w: initial value before Solve, refined value after
   bool tlw_init_ok = false;        // SetInitTransLocalToWorld() found a view that passed the PnP gates
 };

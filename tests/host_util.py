@@ -138,3 +138,21 @@ def incremental_solve(table, cam15, max_iter=200, seeds=()):
     ok = bool(solved.value)
     events = [tuple(int(x) for x in row) for row in ev[:max(ne, 0)]]
     return ok, cam, sorted(int(i) for i in np.flatnonzero(reg)), events, int(nit.value)
+
+
+def ptzray_solve_shared(kps, plist, cam15, shared_ic_ids, max_iter=200, ftype=0):
+    """PTZRayOptimizer with SetSharedIntrinsics(shared_ic_ids) through the C++ class.  Returns (ok, cam15, summary)."""
+    import __graft_entry__ as ge
+    api = ge.load_package().api
+    n_img = len(kps)
+    kp_ptr = np.concatenate([[0], np.cumsum([len(k) for k in kps])]).astype(np.int64)
+    kp_xy = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=np.float32).reshape(-1, 2) for k in kps]), dtype=np.float32)
+    src = np.array([p[0] for p in plist], dtype=np.int64); dst = np.array([p[1] for p in plist], dtype=np.int64)
+    mptr = np.concatenate([[0], np.cumsum([len(p[2]) for p in plist])]).astype(np.int64)
+    q = np.array([m[0] for p in plist for m in p[2]], dtype=np.int32); t = np.array([m[1] for p in plist for m in p[2]], dtype=np.int32)
+    cam = np.array(cam15, dtype=np.float64, order="C").copy()
+    ids = np.ascontiguousarray(shared_ic_ids, dtype=np.int64)
+    summ = api.LmSummary()
+    ok = lib().ptzh_ptzray_solve_shared(n_img, _p(kp_ptr), _p(kp_xy), len(plist), _p(src), _p(dst), _p(mptr), _p(q), _p(t), _p(cam),
+                                        _p(ids), max_iter, ftype, C.byref(summ))
+    return bool(ok), cam, summ.as_dict()

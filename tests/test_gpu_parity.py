@@ -656,3 +656,49 @@ def test_dataset_scripts_offline_then_online(pkg, tmp_path):
         rot = float(re.search(r"ape_rot \[mean, median\]:\s*([0-9.]+)", b).group(1))
         assert f_mean < 15.0 and rot < 1.2
     assert n_total >= 45  # of 50 online images
+
+
+# ---------------------------------------------------------------------------------------- shared intrinsics (next-4)
+@pytest.mark.parametrize("n_groups,ftype,seed", [(1, 0, 5), (3, 0, 5), (1, 1, 6), (4, 1, 7)])
+def test_ba_shared_intrinsics_parity(pkg, orc, n_groups, ftype, seed):
+    """SetSharedIntrinsics (ptzray_optimizer.cc:497-505): cameras with the same id share one intrinsics parameter block.  The
+    device keeps per-camera copies and folds the reduced system (S' = P^T S P); the oracle maps the shared slots onto one
+    index.  Same LM bookkeeping, shared focal lengths (and k1) equal within a group and within 1e-6 of the oracle's."""
+    sc = pkg.synth.make_scene(seed, 24, 100, factor_type=ftype, n_intrinsics_groups=n_groups)
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    for mode in (orc.JAC_ANALYTIC, orc.JAC_NUMERIC):
+        ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=mode, num_threads=4)
+        assert summ["termination_type"] == osumm["termination_type"] == 0
+        assert summ["num_iterations"] == osumm["num_iterations"]
+        assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-9
+        assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6
+        assert np.abs(_relative_rotations(orc, cam) - _relative_rotations(orc, ocam)).max() < 1e-6
+        if ftype:
+            assert np.abs(cam[:, 10] - ocam[:, 10]).max() < 1e-6
+    for g in range(n_groups):
+        members = np.flatnonzero(sc.ic_of_cam == g)
+        assert len(np.unique(cam[members, 0])) == 1 and len(np.unique(cam[members, 10])) == 1  # one parameter, bit-identical copies
+    assert len(np.unique(cam[:, 0])) == n_groups
+    assert np.abs(cam[:, 0] / sc.cam_gt[:, 0] - 1).max() < 5e-3
+
+
+def test_ba_shared_intrinsics_in_a_mixed_batch(pkg):
+    """Scenes with and without shared intrinsics in one batch; each equals its solo solve bit for bit."""
+    a = pkg.synth.make_scene(5, 24, 100, n_intrinsics_groups=2)
+    bsc = pkg.synth.make_scene(4, 20, 100)
+    b = pkg.api.BaBatch([a, bsc, a]); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    for k, sc in enumerate([a, bsc, a]):
+        cam, ray, s = pkg.api.ba_solve(sc)
+        assert s == summ[k] and np.array_equal(cam, cams[k]) and np.array_equal(ray, rays[k])
+
+
+def test_cpp_set_shared_intrinsics(pkg, orc):
+    """PTZRayOptimizer::SetSharedIntrinsics through the C++ class: same result as the packed problem with ic_of_cam; a vector of
+    the wrong length is ignored (ptzray_optimizer.cc:499-502)."""
+    import host_util as hu
+    sc = pkg.synth.make_scene(5, 24, 100, n_intrinsics_groups=2)
+    kps, plist = hu.scene_to_features_matches(sc)
+    ok, cam, summ = hu.ptzray_solve_shared(kps, plist, sc.cam_init, sc.ic_of_cam.astype(np.int64) + 100)  # ids are arbitrary labels
+    want, _, wsumm = pkg.api.ba_solve(sc)
+    assert ok and summ["num_iterations"] == wsumm["num_iterations"]
+    assert _rel(cam[:, 0], want[:, 0]) < 1e-9 and len(np.unique(cam[:, 0])) == 2
