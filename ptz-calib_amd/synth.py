@@ -423,7 +423,7 @@ def homography_dlt(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     A = np.zeros((2 * len(a), 9))
     A[0::2, 0:2] = an; A[0::2, 2] = 1; A[0::2, 6:8] = -bn[:, :1] * an; A[0::2, 8] = -bn[:, 0]
     A[1::2, 3:5] = an; A[1::2, 5] = 1; A[1::2, 6:8] = -bn[:, 1:] * an; A[1::2, 8] = -bn[:, 1]
-    h = np.linalg.svd(A)[2][-1].reshape(3, 3)
+    h = np.linalg.eigh(A.T @ A)[1][:, 0].reshape(3, 3)  # singular vector of the smallest singular value
     Hm = np.linalg.inv(Tb) @ h @ Ta
     return Hm / Hm[2, 2]
 
@@ -442,28 +442,43 @@ def make_match_table(scene: Scene, min_pair_matches: int = 8, max_pair_gap: int 
     kp_xy = np.ascontiguousarray(scene.obs_uv[order], dtype=np.float32)
     feat_of_obs = np.empty(scene.n_obs, dtype=np.int64)
     feat_of_obs[order] = np.arange(scene.n_obs) - kp_ptr[scene.obs_cam[order]]
-    pairs: dict = {}
-    bounds = np.flatnonzero(np.diff(scene.obs_ray)) + 1
-    for seg in np.split(np.arange(scene.n_obs), bounds):
-        for x in range(len(seg)):
-            for y in range(x + 1, len(seg)):
-                i, j = int(scene.obs_cam[seg[x]]), int(scene.obs_cam[seg[y]])
-                if max_pair_gap is not None and min(j - i, n - (j - i)) > max_pair_gap:
-                    continue
-                pairs.setdefault((i, j), []).append((int(feat_of_obs[seg[x]]), int(feat_of_obs[seg[y]])))
+    # every (x < y) pair of observations of a track, vectorised over the tracks of equal length
+    ray_start = np.concatenate([[0], np.flatnonzero(np.diff(scene.obs_ray)) + 1]).astype(np.int64)
+    ray_len = np.diff(np.concatenate([ray_start, [scene.n_obs]]))
+    ox_l, oy_l, tid_l = [], [], []
+    for L in np.unique(ray_len):
+        tr = np.flatnonzero(ray_len == L)
+        idx = ray_start[tr][:, None] + np.arange(L)[None, :]
+        xs, ys = np.triu_indices(int(L), k=1)
+        ox_l.append(idx[:, xs].ravel()); oy_l.append(idx[:, ys].ravel()); tid_l.append(np.repeat(tr, len(xs)))
+    ox = np.concatenate(ox_l); oy = np.concatenate(oy_l); tid = np.concatenate(tid_l)
+    ci = scene.obs_cam[ox].astype(np.int64); cj = scene.obs_cam[oy].astype(np.int64)
+    fi = feat_of_obs[ox]; fj = feat_of_obs[oy]
+    if max_pair_gap is not None:
+        gap = np.minimum(cj - ci, n - (cj - ci))
+        keep = gap <= max_pair_gap
+        ci, cj, fi, fj, tid, ox, oy = ci[keep], cj[keep], fi[keep], fj[keep], tid[keep], ox[keep], oy[keep]
     if bidirectional:
-        for (i, j), v in list(pairs.items()):
-            pairs[(j, i)] = [(b, a) for a, b in v]
-    keys = sorted(k for k, v in pairs.items() if len(v) >= min_pair_matches)
-    src = np.array([k[0] for k in keys], dtype=np.int64); dst = np.array([k[1] for k in keys], dtype=np.int64)
-    match_ptr = np.concatenate([[0], np.cumsum([len(pairs[k]) for k in keys])]).astype(np.int64)
-    q = np.array([m[0] for k in keys for m in pairs[k]], dtype=np.int32)
-    t = np.array([m[1] for k in keys for m in pairs[k]], dtype=np.int32)
-    H = np.zeros((len(keys), 9)); conf = np.zeros(len(keys))
-    for p, (i, j) in enumerate(keys):
-        ms = np.asarray(pairs[(i, j)])
-        a = kp_xy[kp_ptr[i] + ms[:, 0]]; b = kp_xy[kp_ptr[j] + ms[:, 1]]
-        H[p] = homography_dlt(a, b).reshape(9)
-        conf[p] = float(np.float32(1.0) if len(ms) >= 100 else np.float32(len(ms)) / np.float32(100))
+        ci, cj, fi, fj, tid = (np.concatenate(p) for p in ((ci, cj), (cj, ci), (fi, fj), (fj, fi), (tid, tid)))
+    key = ci * n + cj
+    # matches of a pair in track order (the order a per-track loop appends them), pairs in table order
+    srt = np.lexsort((fi, tid, key))
+    key, ci, cj, fi, fj = key[srt], ci[srt], cj[srt], fi[srt], fj[srt]
+    ukey, first, cnt = np.unique(key, return_index=True, return_counts=True)
+    good = cnt >= min_pair_matches
+    sel = np.repeat(good, cnt)
+    ci, cj, fi, fj = ci[sel], cj[sel], fi[sel], fj[sel]
+    cnt = cnt[good]
+    src = (ukey[good] // n).astype(np.int64); dst = (ukey[good] % n).astype(np.int64)
+    match_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    q = fi.astype(np.int32); t = fj.astype(np.int32)
+    H = np.zeros((len(src), 9)); conf = np.zeros(len(src))
+    pa = kp_xy[kp_ptr[ci] + fi].astype(np.float64); pb = kp_xy[kp_ptr[cj] + fj].astype(np.float64)
+    for p in range(len(src)):
+        sl = slice(match_ptr[p], match_ptr[p + 1])
+        H[p] = homography_dlt(pa[sl], pb[sl]).reshape(9)
+        m = int(cnt[p])
+        conf[p] = float(np.float32(1.0) if m >= 100 else np.float32(m) / np.float32(100))
+    keys = src
     img_wh = np.tile(np.array([scene.width, scene.height], dtype=np.int32), (n, 1))
     return MatchTable(n, img_wh, kp_ptr, kp_xy, src, dst, match_ptr, q, t, H, np.ones(len(keys), dtype=np.int32), conf)

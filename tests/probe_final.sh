@@ -3,7 +3,7 @@
 # usage: tests/probe_final.sh <tag>
 R=$GRAFT_REPO_ROOT; T=${1:-r01}
 mkdir -p $R/gpurun_out/$T
-cd $R && timeout 600 python bench.py --single-scene --iba > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
+cd $R && timeout 600 python bench.py > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/$T/bench_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/pmc1 -- python3 $R/tests/probe_run.py 256 1 > /dev/null 2>&1
