@@ -1714,6 +1714,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
 {
   if (n <= 0 || !problems || !out) return PTZ_EINVAL;
   *out = nullptr;
+  const bool dbg_t = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tc0 = now_ms();
+  double tc1 = 0, tc2 = 0, tc3 = 0;
   ptz_lm_options o;
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
@@ -1917,6 +1921,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // LDS budget of the eval kernel bounds the camera count of a scene (160 KiB per workgroup)
   if (sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16) > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
 
+  tc1 = now_ms();
   Dev& d = b->d;
   memset(&d, 0, sizeof(d));
   d.n_scene = n;
@@ -2002,6 +2007,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.chol.fail, (size_t)n));
   d.chol.active = d.active;
   TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));
+  tc2 = now_ms();
   // Tile-level structure of every reduced camera system: cameras that share a track couple their tiles, the T_l_w
   // block and the rhs row couple to everything; closed under the fill of the right-looking factorisation.
   if (!getenv("PTZ_BA_DENSE_CHOL")) {
@@ -2096,6 +2102,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3)
 #undef PTZ_SET_ATTR
   }
+  tc3 = now_ms();
+  if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms, uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, tc2 - tc1, tc3 - tc2);
   *out = b;
   return PTZ_OK;
 }

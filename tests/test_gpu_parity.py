@@ -702,3 +702,21 @@ def test_cpp_set_shared_intrinsics(pkg, orc):
     want, _, wsumm = pkg.api.ba_solve(sc)
     assert ok and summ["num_iterations"] == wsumm["num_iterations"]
     assert _rel(cam[:, 0], want[:, 0]) < 1e-9 and len(np.unique(cam[:, 0])) == 2
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_ba_shared_intrinsics_with_annotations(pkg, orc, ftype):
+    """Georeferencing of a rig whose views share intrinsics blocks: fy (read by the 2D-3D residuals only) and the T_l_w block
+    join the shared slots; same bookkeeping and parameters as the oracle."""
+    sc = pkg.synth.add_annotations(pkg.synth.make_scene(2, 20, 100, factor_type=ftype, n_intrinsics_groups=2))
+    cam, ray, summ, tlw = pkg.api.ba_solve(sc, return_tlw=True)
+    ocam, oray, otlw, osumm, _ = orc.ba_solve(sc, obs3d=sc.obs3d, tlw0=sc.tlw_init, jacobian_mode=orc.JAC_NUMERIC, num_threads=4)
+    assert summ["termination_type"] == osumm["termination_type"] == 0 and summ["num_iterations"] == osumm["num_iterations"]
+    assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-8
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6 and _rel(cam[:, 1], ocam[:, 1]) < 1e-6
+    for g in range(2):
+        m = np.flatnonzero(sc.ic_of_cam == g)
+        assert len(np.unique(cam[m, 0])) == 1 and len(np.unique(cam[m, 1])) == 1  # fx and fy are shared, bit-identical copies
+    Rlw, oRlw = orc.rodrigues(tlw[:3]), orc.rodrigues(otlw[:3])
+    for i in range(sc.n_cam):
+        assert np.abs(orc.rodrigues(cam[i, 4:7]) @ Rlw - orc.rodrigues(ocam[i, 4:7]) @ oRlw).max() < 1e-6
