@@ -169,6 +169,18 @@ def test_ba_batch_matches_single(pkg, scene_c1):
     b.close()
 
 
+def test_ba_large_batch_matches_single_across_cholesky_variants(pkg):
+    """Batches of >= 8 scenes factor the reduced systems left-looking (one column update per block column, the C tile kept in
+    the accumulators), smaller ones right-looking (one trailing update per block column).  Both apply the same MFMA
+    accumulations in the same order, so a scene's bits do not depend on the batch it is solved in -- including a rig large
+    enough for several 64-wide block columns."""
+    scenes = [pkg.synth.make_scene(20 + s, 40 + 4 * (s % 3), 120) for s in range(9)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    for i in (0, 4, 8):
+        cam1, ray1, s1 = pkg.api.ba_solve(scenes[i])
+        assert s1 == summ[i] and np.array_equal(cam1, cams[i]) and np.array_equal(ray1, rays[i])
+
+
 def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, monkeypatch):
     """Resources are recycled between solves (ptz_pool.h); no result may depend on what an earlier solve left in them.
     PTZ_POOL_FILL=255 hands out blocks filled with NaN bit patterns: a kernel that reads memory nobody initialised would
