@@ -26,6 +26,35 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; the in-repo guide lists no f64 figure
 
 
+def structural_update_flops(scene, nc, nb=64):
+    """Flops of the tile updates the factorisation actually executes: the library skips the 64 x 64 tiles that are zero by
+    structure (camera co-visibility closed under the fill of a symbolic factorisation, ptz_ba.hip / DESIGN.md section 4),
+    so the dense n^3/3 count would overstate the work.  Same construction as the host code, on the tile graph."""
+    import numpy as np
+    n = nc * scene.n_cam
+    nt = (n + 1 + nb - 1) // nb
+    tile = (np.arange(scene.n_cam) * nc) // nb  # a camera block can straddle two tiles: count both
+    tile_hi = (np.arange(scene.n_cam) * nc + nc - 1) // nb
+    m = np.zeros((nt, nt), dtype=bool)
+    bounds = np.flatnonzero(np.diff(scene.obs_ray)) + 1
+    starts = np.concatenate([[0], bounds]); ends = np.concatenate([bounds, [len(scene.obs_ray)]])
+    for a, b in zip(starts, ends):
+        cams = scene.obs_cam[a:b]
+        ts = np.unique(np.concatenate([tile[cams], tile_hi[cams]]))
+        m[np.ix_(ts, ts)] = True
+    m[(n // nb):, :] = True  # the tile row that holds the right-hand side is full
+    m = np.tril(m)
+    ops = 0
+    for k in range(nt):
+        rows = [i for i in range(k + 1, nt) if m[i, k]]
+        for x in rows:
+            for y in rows:
+                if y <= x:
+                    m[x, y] = True
+                    ops += 1
+    return ops * 2.0 * nb ** 3
+
+
 def kernel_models(scenes, nc):
     """Algorithmic bytes / flops per kernel family and per LM pass, summed over the scenes of one batch
     (SURVEY.md section 8(d) per-unit figures; DESIGN.md 'Roofline accounting')."""
@@ -36,15 +65,14 @@ def kernel_models(scenes, nc):
     syrk_flops = 0.0
     chol_flops = 0.0
     s_bytes = 0.0
+    cache = {}
     for s in scenes:
         n = nc * s.n_cam
         chol_flops += n ** 3 / 3.0 + 2.0 * n * n
         s_bytes += 8.0 * n * (n + 1) / 2
-        k = 0
-        while 64 * (k + 1) < n + 1:
-            r = n + 1 - 64 * (k + 1)
-            syrk_flops += float(r) * r * 64.0
-            k += 1
+        if id(s) not in cache:
+            cache[id(s)] = structural_update_flops(s, nc)
+        syrk_flops += cache[id(s)]
     m["linearize"] = dict(bound="hbm", bytes=16.0 * n_obs + 104.0 * n_ray)
     m["eval"] = dict(bound="hbm", bytes=16.0 * n_obs + 96.0 * n_ray)
     m["ray_prep"] = dict(bound="hbm", bytes=96.0 * n_ray)
@@ -79,11 +107,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    # Debug aid for boxes with ONE GPU: PTZ_BENCH_SHARED_GPU=1 lets several ranks share device 0 (gloo for the collectives),
+    # which exercises the multi-rank bookkeeping of this script; it is not a measurement mode.
+    shared_gpu = os.environ.get("PTZ_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank)
 
     pkg = ge.load_package()
     B = args.batch
