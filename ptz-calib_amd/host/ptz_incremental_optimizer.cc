@@ -87,6 +87,11 @@ bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered
 {
   if (!CheckValid()) return false;
   if (!tracks_) tracks_ = PTZRayOptimizer::BuildTracks(matches_info_);
+  by_dst_.assign(features_.size(), {});
+  for (size_t e = 0; e < matches_info_.size(); ++e) {
+    const MatchesInfo& mi = matches_info_[e];
+    if (!mi.H_empty && mi.dst_img_idx >= 0 && static_cast<size_t>(mi.dst_img_idx) < by_dst_.size()) by_dst_[mi.dst_img_idx].push_back(e);
+  }
 
   const int kInitNumTrials = 50;
   for (int num_trials = 0; num_trials < kInitNumTrials; ++num_trials) {
@@ -105,6 +110,14 @@ bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered
       const std::vector<long> next_image_ids = FindNextImages();
       if (next_image_ids.empty()) break;
 
+      // The walk below ends at the next successful bundle adjustment, i.e. after about 0.1 x (model size) registrations:
+      // solve the attempts of that many leading candidates (plus a little slack for failures) in one launch now.
+      attempt_cache_.clear();
+      {
+        const float need = kBaGlobalImagesRatio * static_cast<float>(ba_prev_num_reg_images) - static_cast<float>(NumRegImages());
+        const size_t ahead = static_cast<size_t>(std::max(1.0f, std::ceil(need))) + 2;
+        SpeculateRegistrations(next_image_ids, 0, ahead);
+      }
       for (size_t reg_trial = 0; reg_trial < next_image_ids.size(); ++reg_trial) {
         const long image_id = next_image_ids[reg_trial];
         reg_next_success = RegisterNextImage(image_id);
@@ -269,33 +282,33 @@ bool PtzIncrementalOptimizer::RegisterInitialImagePair(long image_id1, long imag
 
 bool PtzIncrementalOptimizer::AdjustGlobalBundle() { return RunBundle(reg_image_ids_); }  // :420-440
 
-bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
-{  // :377-418
-  ScopedMs tm(timing_ms_[3]);
-  num_reg_trials_[image_id] += 1;
-  // every table entry (registered i -> image_id) with a homography is one attempt
-  std::vector<const MatchesInfo*> attempts;
-  for (const MatchesInfo& mi : matches_info_)
-    if (!mi.H_empty && IsRegistered(mi.src_img_idx) && mi.dst_img_idx == image_id) attempts.push_back(&mi);
-  if (attempts.empty()) {
-    events_.push_back({Event::kRegister, image_id, -1, false});
-    return false;
-  }
-  const size_t n = attempts.size();
+// Batched KRT solves of the given table entries (each: registered reference mi.src -> image mi.dst); results go to the
+// cache.  One ptz_krt_solve_batch launch for all of them (queries are independent: one wave each).
+void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*>& todo)
+{
+  if (todo.empty()) return;
+  const size_t n = todo.size();
   std::vector<int64_t> match_ptr(n + 1, 0);
+  size_t total = 0;
+  for (const MatchesInfo* mi : todo) total += mi->matches.size();
   std::vector<float> uv_ref, uv_cur;
+  uv_ref.reserve(2 * total); uv_cur.reserve(2 * total);
   std::vector<double> cam_ref(15 * n), cam_cur(15 * n);
-  std::vector<Camera> init(n);
-  Camera& cam_j = cameras_[image_id];
+  std::vector<Attempt> res(n);
   for (size_t q = 0; q < n; ++q) {
-    const MatchesInfo& mi = *attempts[q];
+    const MatchesInfo& mi = *todo[q];
     const Camera& cam_i = cameras_[mi.src_img_idx];
-    init[q] = Camera(cam_i.K(), RotationFromHomography(cam_i.K(), mi.H, cam_i), cam_j.t(), cam_j.dist());  // K_j := K_i (:392)
-    const std::vector<double> vr = cam_i.ToVector(), vc = init[q].ToVector();
+    const Camera& cam_j = cameras_[mi.dst_img_idx];
+    const Camera init(cam_i.K(), RotationFromHomography(cam_i.K(), mi.H, cam_i), cam_j.t(), cam_j.dist());  // K_j := K_i (:392)
+    res[q].init_K = init.K();
+    res[q].init_R = init.R();
+    const std::vector<double> vr = cam_i.ToVector(), vc = init.ToVector();
     std::copy(vr.begin(), vr.end(), cam_ref.begin() + 15 * q);
     std::copy(vc.begin(), vc.end(), cam_cur.begin() + 15 * q);
+    const std::vector<KeyPoint>& kr = features_[mi.src_img_idx].keypoints;
+    const std::vector<KeyPoint>& kc = features_[mi.dst_img_idx].keypoints;
     for (const DMatch& m : mi.matches) {
-      const Point2f a = features_[mi.src_img_idx].keypoints[m.queryIdx].pt, b = features_[image_id].keypoints[m.trainIdx].pt;
+      const Point2f a = kr[m.queryIdx].pt, b = kc[m.trainIdx].pt;
       uv_ref.push_back(a.x); uv_ref.push_back(a.y);
       uv_cur.push_back(b.x); uv_cur.push_back(b.y);
     }
@@ -312,25 +325,62 @@ bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
                                          cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
                                          accepted.data(), nullptr);
   timing_ms_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
-  if (rc == PTZ_OK)
-    for (size_t q = 0; q < n; ++q) {
-      if (!accepted[q]) continue;
-      Camera refined;
-      refined.FromVector(std::vector<double>(cam_cur.begin() + 15 * q, cam_cur.begin() + 15 * (q + 1)));
-      cam_j.K() = refined.K();  // t and dist are not taken over (:406-407)
-      cam_j.R() = refined.R();
-      reg_image_ids_.insert(image_id);
-      if (getenv("PTZ_INC_DEBUG")) {
-        const std::vector<double> v = cam_j.ToVector();
-        fprintf(stderr, "[inc] REG %ld via %ld (attempt %zu of %zu) f=%.17g r=%.17g %.17g %.17g cost=%.17g\n", image_id, attempts[q]->src_img_idx, q, n,
-                v[0], v[4], v[5], v[6], summaries[q].final_cost);
-      }
-      events_.push_back({Event::kRegister, image_id, attempts[q]->src_img_idx, true});
-      return true;
+  for (size_t q = 0; q < n; ++q) {
+    res[q].accepted = rc == PTZ_OK && accepted[q] != 0;
+    if (res[q].accepted) std::copy(cam_cur.begin() + 15 * q, cam_cur.begin() + 15 * (q + 1), res[q].refined.begin());
+    attempt_cache_[todo[q]] = res[q];
+  }
+}
+
+void PtzIncrementalOptimizer::SpeculateRegistrations(const std::vector<long>& next_image_ids, size_t first, size_t count)
+{
+  ScopedMs tm(timing_ms_[3]);
+  std::vector<const MatchesInfo*> todo;
+  for (size_t r = first; r < next_image_ids.size() && r < first + count; ++r)
+    for (size_t e : by_dst_[next_image_ids[r]]) {
+      const MatchesInfo& mi = matches_info_[e];
+      if (IsRegistered(mi.src_img_idx) && !attempt_cache_.count(&mi)) todo.push_back(&mi);
     }
+  SolveAttempts(todo);
+}
+
+bool PtzIncrementalOptimizer::RegisterNextImage(long image_id)
+{  // :377-418
+  ScopedMs tm(timing_ms_[3]);
+  num_reg_trials_[image_id] += 1;
+  // every table entry (registered i -> image_id) with a homography is one attempt, tried in table order until one is accepted
+  std::vector<const MatchesInfo*> attempts;
+  for (size_t e : by_dst_[image_id])
+    if (IsRegistered(matches_info_[e].src_img_idx)) attempts.push_back(&matches_info_[e]);
+  if (attempts.empty()) {
+    events_.push_back({Event::kRegister, image_id, -1, false});
+    return false;
+  }
+  // attempts solved ahead of time are looked up; the ones that are not (their reference was registered after the
+  // speculation) and come before the first accepted one are solved now, together
+  std::vector<const MatchesInfo*> todo;
+  for (const MatchesInfo* mi : attempts) {
+    const auto it = attempt_cache_.find(mi);
+    if (it == attempt_cache_.end()) todo.push_back(mi);
+    else if (it->second.accepted) break;
+  }
+  SolveAttempts(todo);
+  Camera& cam_j = cameras_[image_id];
+  for (const MatchesInfo* mi : attempts) {
+    const Attempt& at = attempt_cache_.at(mi);
+    if (!at.accepted) continue;
+    Camera refined;
+    refined.FromVector(std::vector<double>(at.refined.begin(), at.refined.end()));
+    cam_j.K() = refined.K();  // t and dist are not taken over (:406-407)
+    cam_j.R() = refined.R();
+    reg_image_ids_.insert(image_id);
+    events_.push_back({Event::kRegister, image_id, mi->src_img_idx, true});
+    return true;
+  }
   // all attempts failed: the camera keeps the initial guess of the last attempt (:392-394 run before every solve)
-  cam_j.K() = init[n - 1].K();
-  cam_j.R() = init[n - 1].R();
+  const Attempt& last = attempt_cache_.at(attempts.back());
+  cam_j.K() = last.init_K;
+  cam_j.R() = last.init_R;
   events_.push_back({Event::kRegister, image_id, -1, false});
   return false;
 }

@@ -5,11 +5,15 @@
 //    ptz_krt_solve_batch launch and takes the first accepted one in table order, which is exactly what the
 //    reference's sequential loop with early exit returns (ptz_incremental_optimizer.cc:383-415) because the
 //    attempts do not depend on each other;
+//  * the attempts of the images that the current ranking will try next are solved ahead of time in one launch
+//    (SpeculateRegistrations): an attempt depends only on its reference camera, its match list and its homography, none
+//    of which changes before the next bundle adjustment, so looking its result up later is the same as solving it then;
 //  * the feature tracks are built once per match table and shared by all bundle adjustments (the reference rebuilds
 //    them from the N^2 table inside every PTZRayOptimizer::Solve, ptzray_optimizer.cc:537-552), and the feature /
 //    match tables are borrowed instead of deep-copied.
 #pragma once
 
+#include <array>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -59,6 +63,14 @@ class PtzIncrementalOptimizer {
   float CalPixelDiff(long image_id1, long image_id2, const std::vector<DMatch>& matches) const;
   bool RegisterInitialImagePair(long image_id1, long image_id2);
   bool RegisterNextImage(long image_id);
+  // one (registered reference -> image) attempt of RegisterNextImage and what came out of it
+  struct Attempt {
+    bool accepted = false;
+    std::array<double, 15> refined{};  // world-frame camera vector when accepted
+    Mat33 init_K = Eye3(), init_R = Eye3();  // what the reference leaves in cameras_[image] when the attempt fails (:392-394)
+  };
+  void SolveAttempts(const std::vector<const MatchesInfo*>& todo);  // results into attempt_cache_
+  void SpeculateRegistrations(const std::vector<long>& next_image_ids, size_t first, size_t count);
   void SetInitialImagePairParameters(long image_id1, long image_id2);
   bool AdjustGlobalBundle();
   bool RunBundle(const std::unordered_set<long>& ids);
@@ -77,6 +89,8 @@ class PtzIncrementalOptimizer {
   std::unordered_set<long> reg_image_ids_;
   std::vector<long> seed_image_ids_;
   std::shared_ptr<const SharedTracks> tracks_;
+  std::vector<std::vector<size_t>> by_dst_;  // table entries (indices into matches_info_, ascending) per destination image
+  std::unordered_map<const MatchesInfo*, Attempt> attempt_cache_;  // valid until the next successful bundle adjustment
   std::vector<Event> events_;
   long lm_iterations_ = 0;
   mutable double timing_ms_[5] = {0, 0, 0, 0, 0};
