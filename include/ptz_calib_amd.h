@@ -194,6 +194,18 @@ int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const flo
                             const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted,
                             double* device_ms);
 
+/* The same solve with 2D-3D constraints added to every query:
+ *   replaces KRTOptimizer::Add2d3dConstraints (krt_optimizer.cc:350-383; Factor2d3dDist / Factor2d3dFxfyDist,
+ *   :200-249) on top of Add2d2dConstraints -- never called by the reference's tools.
+ * Query q owns points [point_ptr[q], point_ptr[q+1]): pts2d = pixels (2 x f32), pts3d = WORLD points (3 x f64); the
+ * library moves them into the local frame of the query's reference camera as the reference does (:357-362) and
+ * projects them as cv::projectPoints does, including its (k1,k2,p1,p2,k3) reading of the stored distortion.
+ * num_residuals counts both kinds.  point_ptr = NULL is ptz_krt_solve_batch. */
+int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                                 const int64_t* point_ptr, const float* pts2d, const double* pts3d, const double* cam_ref,
+                                 double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                                 ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+
 #ifdef __cplusplus
 }
 #endif

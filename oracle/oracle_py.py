@@ -55,7 +55,7 @@ class BaProblem(C.Structure):
 
 class KrtProblem(C.Structure):
     _fields_ = [("n_match", C.c_int32), ("uv_ref", C.c_void_p), ("uv_cur", C.c_void_p), ("cam_ref", C.c_void_p),
-                ("factor_type", C.c_int32)]
+                ("factor_type", C.c_int32), ("n_pt", C.c_int32), ("pts2d", C.c_void_p), ("pts3d_local", C.c_void_p)]
 
 
 def usable_cores() -> int:
@@ -228,13 +228,38 @@ def krt_local_to_world(cam_ref, cam_loc, factor_type):
     return out
 
 
-def krt_solve(uv_ref, uv_cur, cam_ref, cam_cur_local, factor_type=0, trace=False, **opt):
-    """Single-view LM in the reference camera's local frame.  Returns (cam_local, summary, Trace|None)."""
+def krt_point_to_local(cam_ref, pts3d_world):
+    """R_local_world X_w + t_local_world (krt_optimizer.cc:357-362)."""
+    cam_ref = np.ascontiguousarray(cam_ref, dtype=np.float64)
+    X = np.ascontiguousarray(pts3d_world, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros_like(X)
+    for i in range(len(X)):
+        lib().orc_krt_point_to_local(_p(cam_ref), _p(X[i]), _p(out[i]))
+    return out
+
+
+def res_2d3d_krt(cam_local, fxfy, pt2d, pt3d_local):
+    cam = np.ascontiguousarray(cam_local, dtype=np.float64)
+    a = np.ascontiguousarray(pt2d, dtype=np.float32)
+    X = np.ascontiguousarray(pt3d_local, dtype=np.float64)
+    res = np.zeros(2)
+    lib().orc_res_2d3d_krt(_p(cam), C.c_int32(int(fxfy)), _p(a), _p(X), _p(res))
+    return res
+
+
+def krt_solve(uv_ref, uv_cur, cam_ref, cam_cur_local, factor_type=0, trace=False, pts2d=None, pts3d_local=None, **opt):
+    """Single-view LM in the reference camera's local frame.  Returns (cam_local, summary, Trace|None).
+    pts2d / pts3d_local: optional 2D-3D constraints (Add2d3dConstraints), points already in the local frame."""
     uv_ref = np.ascontiguousarray(uv_ref, dtype=np.float32)
     uv_cur = np.ascontiguousarray(uv_cur, dtype=np.float32)
     cam_ref = np.ascontiguousarray(cam_ref, dtype=np.float64)
     cam = np.array(cam_cur_local, dtype=np.float64).copy()
-    p = KrtProblem(len(uv_ref), _p(uv_ref), _p(uv_cur), _p(cam_ref), factor_type)
+    if pts2d is not None and len(pts2d):
+        pts2d = np.ascontiguousarray(pts2d, dtype=np.float32)
+        pts3d_local = np.ascontiguousarray(pts3d_local, dtype=np.float64)
+        p = KrtProblem(len(uv_ref), _p(uv_ref), _p(uv_cur), _p(cam_ref), factor_type, len(pts2d), _p(pts2d), _p(pts3d_local))
+    else:
+        p = KrtProblem(len(uv_ref), _p(uv_ref), _p(uv_cur), _p(cam_ref), factor_type, 0, None, None)
     o = default_options(**opt)
     s = LmSummary()
     t, arrs = _mk_trace(o.max_num_iterations + 2) if trace else (None, None)

@@ -1690,11 +1690,54 @@ typedef struct {
   double* rhs;
 } krt_ctx;
 
+/* cvProjectPoints2Internal (OpenCV 4.5.3 calibration.cpp) for one point, no tilt, 5 distortion coefficients */
+static void cv_project_point(const double* R, const double* t, double fx, double fy, double cx, double cy, const double* k,
+                             const double* X, double* uv)
+{
+  double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+  double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+  double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+  z = z ? 1. / z : 1;
+  x *= z; y *= z;
+  double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+  double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+  double xd = x * cdist + k[2] * a1 + k[3] * a2;
+  double yd = y * cdist + k[2] * a3 + k[3] * a1;
+  uv[0] = xd * fx + cx;
+  uv[1] = yd * fy + cy;
+}
+
+void orc_res_2d3d_krt(const double* cam, int32_t fxfy, const float* pt2d, const double* pt3d_local, double* res)
+{
+  /* krt_optimizer.cc:202-216 (param[1] = param[0]) / :228-241; cam.rvec() is Rodrigues(R(rvec)), the round trip is
+   * the identity to round-off and is not restated */
+  double R[9], uv[2];
+  orc_rodrigues(cam + 4, R);
+  cv_project_point(R, cam + 7, cam[0], fxfy ? cam[1] : cam[0], cam[2], cam[3], cam + 10, pt3d_local, uv);
+  res[0] = (double)pt2d[0] - uv[0];
+  res[1] = (double)pt2d[1] - uv[1];
+}
+
+void orc_krt_point_to_local(const double* ref, const double* Xw, double* Xl)
+{
+  double R[9];
+  orc_rodrigues(ref + 4, R);
+  mat3_mul_vec(R, Xw, Xl);
+  Xl[0] += ref[7]; Xl[1] += ref[8]; Xl[2] += ref[9];
+}
+
 static void krt_res(const krt_ctx* c, const double* cam, int m, double* res)
 {
   const orc_krt_problem* p = c->p;
   double cv[15];
   memcpy(cv, cam, sizeof(cv));
+  if (m >= p->n_match) { /* 2D-3D block (krt_optimizer.cc:364-381) */
+    int i = m - p->n_match;
+    orc_res_2d3d_krt(cv, p->factor_type == ORC_KRT_Fxfy || p->factor_type == ORC_KRT_FxfyDist, p->pts2d + 2 * i,
+                     p->pts3d_local + 3 * i, res);
+    return;
+  }
   switch (p->factor_type) {
     case ORC_KRT_F:
       orc_res_2d2d(cv, c->k1, p->uv_ref + 2 * m, p->uv_cur + 2 * m, res);
@@ -1734,6 +1777,36 @@ static void krt_block_analytic(const krt_ctx* c, const double* cam, int m, doubl
   int type = p->factor_type;
   int dist = (type == ORC_KRT_FDist || type == ORC_KRT_FxfyDist);
   int fxfy = (type == ORC_KRT_Fxfy || type == ORC_KRT_FxfyDist);
+  if (m >= p->n_match) { /* 2D-3D block: closed-form Jacobian of the projectPoints residual */
+    const double* X = p->pts3d_local + 3 * (m - p->n_match);
+    double R[9], dR[27], Q[3];
+    orc_rodrigues_jac(cam + 4, R, dR);
+    mat3_mul_vec(R, X, Q);
+    double P[3] = {Q[0] + cam[7], Q[1] + cam[8], Q[2] + cam[9]};
+    double iz = P[2] ? 1.0 / P[2] : 1.0, x = P[0] * iz, y = P[1] * iz;
+    double fx = cam[0], fy = fxfy ? cam[1] : cam[0];
+    double xd, yd, B[4], dk1[2];
+    /* stored (d0..d4) read by OpenCV as (k1,k2,p1,p2,k3) */
+    brown(x, y, cam[10], cam[11], cam[14], cam[12], cam[13], &xd, &yd);
+    brown_jac(x, y, cam[10], cam[11], cam[14], cam[12], cam[13], B, dk1);
+    res[0] = (double)p->pts2d[2 * (m - p->n_match)] - (xd * fx + cam[2]);
+    res[1] = (double)p->pts2d[2 * (m - p->n_match) + 1] - (yd * fy + cam[3]);
+    double dpi[6] = {iz, 0, -x * iz, 0, iz, -y * iz}, M[6];
+    for (int j = 0; j < 3; ++j) {
+      M[j] = fx * (B[0] * dpi[j] + B[1] * dpi[3 + j]);
+      M[3 + j] = fy * (B[2] * dpi[j] + B[3] * dpi[3 + j]);
+    }
+    if (fxfy) { J15[0] = -xd; J15[15 + 1] = -yd; }
+    else { J15[0] = -xd; J15[15] = -yd; }
+    if (dist) { J15[10] = -fx * dk1[0]; J15[15 + 10] = -fy * dk1[1]; }
+    for (int k = 0; k < 3; ++k) {
+      double dP[3];
+      mat3_mul_vec(dR + 9 * k, X, dP);
+      J15[4 + k] = -(M[0] * dP[0] + M[1] * dP[1] + M[2] * dP[2]);
+      J15[15 + 4 + k] = -(M[3] * dP[0] + M[4] * dP[1] + M[5] * dP[2]);
+    }
+    return;
+  }
   double u1 = p->uv_ref[2 * m], v1 = p->uv_ref[2 * m + 1];
   if (dist) {
     float und[2];
@@ -1775,11 +1848,13 @@ static void krt_block_analytic(const krt_ctx* c, const double* cam, int m, doubl
   }
 }
 
+static int krt_blocks(const krt_ctx* c) { return c->p->n_match + (c->p->pts2d ? c->p->n_pt : 0); }
+
 static double krt_cost(void* vc, const double* x)
 {
   krt_ctx* c = (krt_ctx*)vc;
   double cost = 0;
-  for (int m = 0; m < c->p->n_match; ++m) {
+  for (int m = 0; m < krt_blocks(c); ++m) {
     double res[2];
     krt_res(c, x, m, res);
     cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
@@ -1790,7 +1865,7 @@ static double krt_cost(void* vc, const double* x)
 static double krt_linearize(void* vc, const double* x, double* g)
 {
   krt_ctx* c = (krt_ctx*)vc;
-  const int nf = c->nf, M = c->p->n_match;
+  const int nf = c->nf, M = krt_blocks(c);
   double cost = 0;
   for (int m = 0; m < M; ++m) {
     double res[2], J15[30];
@@ -1835,14 +1910,14 @@ static void krt_col_sqnorm(void* vc, double* out)
   krt_ctx* c = (krt_ctx*)vc;
   for (int k = 0; k < c->nf; ++k) {
     double acc = 0;
-    for (int row = 0; row < 2 * c->p->n_match; ++row) acc += c->J[(size_t)row * c->nf + k] * c->J[(size_t)row * c->nf + k];
+    for (int row = 0; row < 2 * krt_blocks(c); ++row) acc += c->J[(size_t)row * c->nf + k] * c->J[(size_t)row * c->nf + k];
     out[k] = acc;
   }
 }
 static void krt_scale_cols(void* vc, const double* s)
 {
   krt_ctx* c = (krt_ctx*)vc;
-  for (int row = 0; row < 2 * c->p->n_match; ++row)
+  for (int row = 0; row < 2 * krt_blocks(c); ++row)
     for (int k = 0; k < c->nf; ++k) c->J[(size_t)row * c->nf + k] *= s[k];
 }
 
@@ -1850,7 +1925,7 @@ static void krt_scale_cols(void* vc, const double* s)
 static int krt_solve(void* vc, const double* D, double* y)
 {
   krt_ctx* c = (krt_ctx*)vc;
-  const int nf = c->nf, rows = 2 * c->p->n_match, R = rows + nf;
+  const int nf = c->nf, rows = 2 * krt_blocks(c), R = rows + nf;
   double* A = c->A; /* column-major R x nf */
   double* b = c->rhs;
   for (int k = 0; k < nf; ++k) {
@@ -1900,7 +1975,7 @@ static double krt_model_cost_change(void* vc, const double* step)
 {
   krt_ctx* c = (krt_ctx*)vc;
   double acc = 0;
-  for (int row = 0; row < 2 * c->p->n_match; ++row) {
+  for (int row = 0; row < 2 * krt_blocks(c); ++row) {
     double m = 0;
     for (int k = 0; k < c->nf; ++k) m += c->J[(size_t)row * c->nf + k] * step[k];
     acc += m * (c->r[row] + m / 2.0);
@@ -1948,7 +2023,7 @@ int32_t orc_krt_solve(const orc_krt_problem* p, double* cam, const orc_lm_option
   /* cam_ref_local: K and dist of the reference, R = I, t = 0 (krt_optimizer.cc:272-276) */
   c.k1[0] = p->cam_ref[0]; c.k1[1] = p->cam_ref[1]; c.k1[2] = p->cam_ref[2]; c.k1[3] = p->cam_ref[3];
   for (int k = 0; k < 5; ++k) c.dist1[k] = p->cam_ref[10 + k];
-  int rows = 2 * p->n_match;
+  int rows = 2 * krt_blocks(&c);
   c.J = (double*)malloc(sizeof(double) * ((size_t)rows * c.nf + 1));
   c.r = (double*)malloc(sizeof(double) * ((size_t)rows + 1));
   c.A = (double*)malloc(sizeof(double) * ((size_t)(rows + c.nf) * c.nf + 1));

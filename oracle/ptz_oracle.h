@@ -157,11 +157,21 @@ typedef struct {
   const double* cam_ref; /* [15] reference camera in world frame (only K, dist are used by the functors;
                             R, t define the local frame, krt_optimizer.cc:269-282) */
   int32_t factor_type;   /* ORC_KRT_* */
+  /* optional 2D-3D constraints, KRTOptimizer::Add2d3dConstraints (krt_optimizer.cc:350-383) */
+  int32_t n_pt;
+  const float* pts2d;        /* [2*n_pt] pixels */
+  const double* pts3d_local; /* [3*n_pt] points already in the local frame (orc_krt_point_to_local) */
 } orc_krt_problem;
 
 /* cam_cur[15]: in = initial camera in *local* frame vector form (krt_optimizer.cc:284), out = refined. */
 int32_t orc_krt_solve(const orc_krt_problem* p, double* cam_cur_local, const orc_lm_options* o, orc_lm_summary* s,
                       orc_lm_trace* trace);
+/* Factor2d3dDist / Factor2d3dFxfyDist functor (krt_optimizer.cc:200-249): cv::projectPoints of one local-frame point with
+ * the camera 15-vector (F / FDist: fy := fx).  OpenCV 4.5.3 cvProjectPoints2Internal arithmetic, 5 coefficients read as
+ * (k1,k2,p1,p2,k3). */
+void orc_res_2d3d_krt(const double* cam, int32_t fxfy, const float* pt2d, const double* pt3d_local, double* res);
+/* R_local_world X_w + t_local_world with the reference camera's pose (krt_optimizer.cc:357-362) */
+void orc_krt_point_to_local(const double* cam_ref_world, const double* pt3d_world, double* pt3d_local);
 /* world <-> local frame helpers (krt_optimizer.cc:269-284, 535-567); cams are 15-vectors */
 void orc_krt_world_to_local(const double* cam_ref_world, const double* cam_cur_world, double* cam_cur_local);
 void orc_krt_local_to_world(const double* cam_ref_world, const double* cam_cur_local, int32_t factor_type,

@@ -22,7 +22,8 @@ _ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUP
 EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_batch_create", "ptz_ba_batch_destroy",
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
-           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch", "ptz_trim_cache"]
+           "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
+           "ptz_krt_solve_batch_2d3d", "ptz_trim_cache"]
 
 
 class PtzError(RuntimeError):
@@ -249,7 +250,17 @@ def krt_solve_batch(batch, max_reproj_error=100.0, **opt):
     summ = (LmSummary * n)()
     acc = np.zeros(n, dtype=np.int32)
     ms = C.c_double()
-    _check(lib().ptz_krt_solve_batch(n, _p(ptr), _p(uvr), _p(uvc), _p(cref), _p(ccur), batch.factor_type,
-                                     C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.byref(ms)),
-           "ptz_krt_solve_batch")
+    point_ptr = getattr(batch, "point_ptr", None)
+    if point_ptr is not None:  # 2D-3D constraints per query (KRTOptimizer::Add2d3dConstraints), world points
+        pptr = np.ascontiguousarray(point_ptr, dtype=np.int64)
+        p2 = np.ascontiguousarray(batch.pts2d, dtype=np.float32)
+        p3 = np.ascontiguousarray(batch.pts3d, dtype=np.float64)
+        _check(lib().ptz_krt_solve_batch_2d3d(n, _p(ptr), _p(uvr), _p(uvc), _p(pptr), _p(p2), _p(p3), _p(cref), _p(ccur),
+                                              batch.factor_type, C.c_double(max_reproj_error), C.byref(o), summ, _p(acc),
+                                              C.byref(ms)),
+               "ptz_krt_solve_batch_2d3d")
+    else:
+        _check(lib().ptz_krt_solve_batch(n, _p(ptr), _p(uvr), _p(uvc), _p(cref), _p(ccur), batch.factor_type,
+                                         C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.byref(ms)),
+               "ptz_krt_solve_batch")
     return ccur, [s.as_dict() for s in summ], acc, ms.value

@@ -363,6 +363,55 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, do
   }
 }
 
+// Factor2d3dDist / Factor2d3dFxfyDist (krt_optimizer.cc:200-249): cv::projectPoints of a point given in the local frame,
+// P = R X_l + t with the (constant) local translation, z = P.z ? 1/P.z : 1, Brown distortion with OpenCV's reading of the
+// stored coefficients -- (k1,k2,p1,p2,k3) = kd[0,1,2,3,4] while the reference's own functors read (k1,k2,k3,p1,p2): the
+// permutation is the reference's behaviour and is kept.  F and FDist both use the Dist functor with fy := fx.
+// Same free columns as krt_eval.
+template <int KTYPE, bool JAC>
+PTZ_HD void krt_eval_2d3d(const double* R, const double* Jl, double fx, double fy, double cx, double cy, const double* kd,
+                          const double t[3], const double Xl[3], float u, float v, double res[2],
+                          double J[2][KrtDims<KTYPE>::NF])
+{
+  constexpr int DIST = KrtDims<KTYPE>::DIST, FXFY = KrtDims<KTYPE>::FXFY, ROT0 = KrtDims<KTYPE>::ROT0;
+  const double Qx = R[0] * Xl[0] + R[1] * Xl[1] + R[2] * Xl[2];
+  const double Qy = R[3] * Xl[0] + R[4] * Xl[1] + R[5] * Xl[2];
+  const double Qz = R[6] * Xl[0] + R[7] * Xl[1] + R[8] * Xl[2];
+  const double Px = Qx + t[0], Py = Qy + t[1], Pz = Qz + t[2];
+  const double iz = Pz != 0.0 ? 1.0 / Pz : 1.0;
+  const double x = Px * iz, y = Py * iz;
+  const double kcv[5] = {kd[0], kd[1], kd[4], kd[2], kd[3]};  // (k1,k2,k3,p1,p2) as cv::projectPoints reads the storage
+  double xd, yd;
+  brown(x, y, kcv, xd, yd);
+  res[0] = (double)u - (xd * fx + cx);
+  res[1] = (double)v - (yd * fy + cy);
+  if (!JAC) return;
+  double B[4], dk1[2];
+  brown_jac(x, y, kcv, B, dk1);
+  double M[2][3];
+  M[0][0] = fx * (B[0] * iz);  M[0][1] = fx * (B[1] * iz);  M[0][2] = fx * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  if (FXFY) {
+    J[0][0] = -xd; J[1][0] = 0;
+    J[0][1] = 0;   J[1][1] = -yd;
+  }
+  else {
+    J[0][0] = -xd;
+    J[1][0] = -yd;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // the rotation acts on R X_l only: dP = Jl[:,k] x (R X_l)
+    const double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
+    const double dx = ay * Qz - az * Qy, dy = az * Qx - ax * Qz, dz = ax * Qy - ay * Qx;
+    J[0][ROT0 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
+    J[1][ROT0 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
+  }
+  if (DIST) {
+    J[0][ROT0 + 3] = -fx * dk1[0];
+    J[1][ROT0 + 3] = -fy * dk1[1];
+  }
+}
+
 // cv::undistortPoints(src, dst, K, dist, noArray(), K) for one point, 5 fixed-point iterations
 // (OpenCV 4.5.3 default criteria), result rounded to float32 (cv::Point2f, krt_optimizer.cc:89-92).
 // OpenCV reads dist as (k1,k2,p1,p2,k3) while the reference stores (k1,k2,k3,p1,p2): the permutation

@@ -92,11 +92,14 @@ struct MatchEval {
 };
 
 constexpr int KRT_CACHE = 256;  // matches per query whose constant part is cached (8 KiB of LDS per wave)
-template <int KTYPE>
+// P3: the queries also carry 2D-3D constraints (KRTOptimizer::Add2d3dConstraints, krt_optimizer.cc:350-383): world points,
+// moved into the local frame of the reference camera as the reference does (:357-362), one residual block each.
+template <int KTYPE, bool P3>
 __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
-                                             const float2* __restrict__ uv_cur, const double* __restrict__ cam_ref,
-                                             double* __restrict__ cam_cur, KrtOpt o, ptz_lm_summary* __restrict__ summ,
-                                             int* __restrict__ accepted)
+                                             const float2* __restrict__ uv_cur, const long long* __restrict__ point_ptr,
+                                             const float2* __restrict__ pt_uv, const double* __restrict__ pt_xyz,
+                                             const double* __restrict__ cam_ref, double* __restrict__ cam_cur, KrtOpt o,
+                                             ptz_lm_summary* __restrict__ summ, int* __restrict__ accepted)
 {
   constexpr int NF = KrtDims<KTYPE>::NF;
   constexpr int NH = NF * (NF + 1) / 2;
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
   const int lane = threadIdx.x & 63;
   const long long m0 = match_ptr[q], m1 = match_ptr[q + 1];
   const int M = (int)(m1 - m0);
+  const long long p0 = P3 ? point_ptr[q] : 0;
+  const int NP = P3 ? (int)(point_ptr[q + 1] - p0) : 0;
   // ---- world -> local frame of the reference camera (krt_optimizer.cc:269-284)
   double ref[15], x[15];
 #pragma unroll
@@ -141,6 +146,12 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     rc[m][0] = r1[0]; rc[m][1] = r1[1]; rc[m][2] = r1[2]; rc[m][3] = skip ? 1.0 : 0.0;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every lane reads back only what it wrote
+  auto local_point = [&](int i, double Xl[3]) {  // R_local_world X_w + t_local_world (krt_optimizer.cc:357-362)
+    const double* X = pt_xyz + 3 * (p0 + i);
+    Xl[0] = Rref[0] * X[0] + Rref[1] * X[1] + Rref[2] * X[2] + ref[7];
+    Xl[1] = Rref[3] * X[0] + Rref[4] * X[1] + Rref[5] * X[2] + ref[8];
+    Xl[2] = Rref[6] * X[0] + Rref[7] * X[1] + Rref[8] * X[2] + ref[9];
+  };
   auto match_ray = [&](int m, double r1[3], bool& skip) {
     if (m < KRT_CACHE) { r1[0] = rc[m][0]; r1[1] = rc[m][1]; r1[2] = rc[m][2]; skip = rc[m][3] != 0.0; }
     else { const float2 a = uv_ref[m0 + m]; MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip); }
@@ -158,6 +169,15 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       match_ray(m, r1, skip);
       krt_eval<KTYPE, false>(R, nullptr, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+    }
+    if (P3) {
+      for (int i = lane; i < NP; i += 64) {
+        const float2 bq = pt_uv[p0 + i];
+        double Xl[3], res[2], J[2][NF];
+        local_point(i, Xl);
+        krt_eval_2d3d<KTYPE, false>(R, nullptr, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, c + 7, Xl, bq.x, bq.y, res, J);
+        cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+      }
     }
     return wave_sum(cost);
   };
@@ -185,6 +205,22 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
         g[k] += J[0][k] * res[0] + J[1][k] * res[1];
 #pragma unroll
         for (int l = 0; l <= k; ++l) H[e++] += J[0][k] * J[0][l] + J[1][k] * J[1][l];
+      }
+    }
+    if (P3) {
+      for (int i = lane; i < NP; i += 64) {
+        const float2 bq = pt_uv[p0 + i];
+        double Xl[3], res[2], J[2][NF];
+        local_point(i, Xl);
+        krt_eval_2d3d<KTYPE, true>(R, Jl, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, c + 7, Xl, bq.x, bq.y, res, J);
+        cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+        int e = 0;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          g[k] += J[0][k] * res[0] + J[1][k] * res[1];
+#pragma unroll
+          for (int l = 0; l <= k; ++l) H[e++] += J[0][k] * J[0][l] + J[1][k] * J[1][l];
+        }
       }
     }
 #pragma unroll
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     }
   }
   // ---- CheckResults (krt_optimizer.cc:504-533) + ObtainRefinedCameraParams (:535-567)
-  const int num_residuals = 2 * M;
+  const int num_residuals = 2 * (M + NP);
   const double final_reproj = sqrt(2.0) * sqrt((2 * final_cost) / num_residuals);
   bool ok = (termination == PTZ_CONVERGENCE) && !(final_reproj >= o.max_reproj_error);
   {
@@ -362,7 +398,23 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
                                        const double* cam_ref, double* cam_cur, int32_t factor_type, double max_reproj_error,
                                        const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
 {
+  return ptz_krt_solve_batch_2d3d(n_query, match_ptr, uv_ref, uv_cur, nullptr, nullptr, nullptr, cam_ref, cam_cur, factor_type,
+                                  max_reproj_error, opt, summaries, accepted, device_ms);
+}
+
+extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                                            const int64_t* point_ptr, const float* pts2d, const double* pts3d,
+                                            const double* cam_ref, double* cam_cur, int32_t factor_type,
+                                            double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries,
+                                            int32_t* accepted, double* device_ms)
+{
   if (n_query <= 0 || !match_ptr || !uv_ref || !uv_cur || !cam_ref || !cam_cur || !summaries || !accepted) return PTZ_EINVAL;
+  const bool p3 = point_ptr != nullptr;
+  if (p3 && (!pts2d || !pts3d)) return PTZ_EINVAL;
+  if (p3)
+    for (int q = 0; q < n_query; ++q)
+      if (point_ptr[q + 1] < point_ptr[q]) return PTZ_EINVAL;
+  const int64_t np = p3 ? point_ptr[n_query] : 0;
   if (factor_type < PTZ_KRT_F || factor_type > PTZ_KRT_FxfyDist) return PTZ_EUNSUPPORTED;
   ptz_lm_options o;
   if (opt) o = *opt; else ptz_lm_options_default(&o);
@@ -377,7 +429,8 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   const size_t o_ptr = 0, o_ref = o_ptr + up(sizeof(long long) * (n_query + 1)), o_cur = o_ref + up(sizeof(float2) * (nm > 0 ? nm : 1)),
                o_cref = o_cur + up(sizeof(float2) * (nm > 0 ? nm : 1)), o_ccur = o_cref + up(sizeof(double) * 15 * n_query),
                o_sum = o_ccur + up(sizeof(double) * 15 * n_query), o_acc = o_sum + up(sizeof(ptz_lm_summary) * n_query),
-               total = o_acc + up(sizeof(int) * n_query);
+               o_pptr = o_acc + up(sizeof(int) * n_query), o_puv = o_pptr + up(sizeof(long long) * (n_query + 1)),
+               o_pxyz = o_puv + up(sizeof(float2) * (np > 0 ? np : 1)), total = o_pxyz + up(sizeof(double) * 3 * (np > 0 ? np : 1));
   struct Held {
     int dev; char* base = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Held()
@@ -399,6 +452,16 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   double *d_cref = (double*)(h.base + o_cref), *d_ccur = (double*)(h.base + o_ccur);
   ptz_lm_summary* d_sum = (ptz_lm_summary*)(h.base + o_sum);
   int* d_acc = (int*)(h.base + o_acc);
+  long long* d_pptr = p3 ? (long long*)(h.base + o_pptr) : nullptr;
+  float2* d_puv = (float2*)(h.base + o_puv);
+  double* d_pxyz = (double*)(h.base + o_pxyz);
+  if (p3) {
+    PTZ_HIP_TRY(hipMemcpyAsync(d_pptr, point_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
+    if (np > 0) {
+      PTZ_HIP_TRY(hipMemcpyAsync(d_puv, pts2d, sizeof(float2) * np, hipMemcpyHostToDevice, h.st));
+      PTZ_HIP_TRY(hipMemcpyAsync(d_pxyz, pts3d, sizeof(double) * 3 * np, hipMemcpyHostToDevice, h.st));
+    }
+  }
   PTZ_HIP_TRY(hipMemcpyAsync(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
@@ -420,12 +483,20 @@ extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr
   ko.max_reproj_error = max_reproj_error;
   PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
   const dim3 grid((n_query + 3) / 4), block(256);
-  switch (factor_type) {
-    case PTZ_KRT_F: hipLaunchKernelGGL(k_krt<0>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
-    case PTZ_KRT_FDist: hipLaunchKernelGGL(k_krt<1>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
-    case PTZ_KRT_Fxfy: hipLaunchKernelGGL(k_krt<2>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
-    default: hipLaunchKernelGGL(k_krt<3>, grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_cref, d_ccur, ko, d_sum, d_acc); break;
+#define PTZ_KRT_LAUNCH(T, P)                                                                                            \
+  hipLaunchKernelGGL((k_krt<T, P>), grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
+                     d_ccur, ko, d_sum, d_acc)
+  switch (factor_type * 2 + (p3 ? 1 : 0)) {
+    case 0: PTZ_KRT_LAUNCH(0, false); break;
+    case 1: PTZ_KRT_LAUNCH(0, true); break;
+    case 2: PTZ_KRT_LAUNCH(1, false); break;
+    case 3: PTZ_KRT_LAUNCH(1, true); break;
+    case 4: PTZ_KRT_LAUNCH(2, false); break;
+    case 5: PTZ_KRT_LAUNCH(2, true); break;
+    case 6: PTZ_KRT_LAUNCH(3, false); break;
+    default: PTZ_KRT_LAUNCH(3, true); break;
   }
+#undef PTZ_KRT_LAUNCH
   PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));

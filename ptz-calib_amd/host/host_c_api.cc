@@ -9,6 +9,7 @@
 #include "image_size.h"
 #include "json_mini.h"
 #include "krt_optimizer.h"
+#include <stdexcept>
 #include "ptz_incremental_optimizer.h"
 #include "ptzray_optimizer.h"
 
@@ -404,6 +405,52 @@ int32_t ptzh_krt_solve(const double* cam_ref15, double* cam_cur15, int32_t n_mat
   const bool ok = opt.Solve(K, R, t, dist);
   if (num_iter) *num_iter = opt.num_iter_;
   if (summary) *summary = opt.summary();
+  if (ok) {
+    const std::vector<double> v = Camera(K, R, t, dist).ToVector();
+    memcpy(cam_cur15, v.data(), sizeof(double) * 15);
+  }
+  return ok ? 1 : 0;
+}
+
+// The same with KRTOptimizer::Add2d3dConstraints (world points) after Add2d2dConstraints; reproj2 = {Cal2d2dReprojError,
+// Cal2d3dReprojError} after the solve.  order_swapped != 0 calls Add2d3dConstraints first (expected to throw): returns -2.
+int32_t ptzh_krt_solve_2d3d(const double* cam_ref15, double* cam_cur15, int32_t n_match, const float* uv_ref, const float* uv_cur,
+                            int32_t n_pt, const float* pts2d, const double* pts3d, int32_t max_iter, double max_reproj_error,
+                            int32_t type, int32_t order_swapped, int32_t* num_iter, ptz_lm_summary* summary, double* reproj2)
+{
+  Camera ref, cur;
+  ref.FromVector(std::vector<double>(cam_ref15, cam_ref15 + 15));
+  cur.FromVector(std::vector<double>(cam_cur15, cam_cur15 + 15));
+  std::vector<KeyPoint> kr(n_match), kc(n_match);
+  std::vector<DMatch> ms(n_match);
+  for (int m = 0; m < n_match; ++m) {
+    kr[m].pt = Point2f(uv_ref[2 * m], uv_ref[2 * m + 1]);
+    kc[m].pt = Point2f(uv_cur[2 * m], uv_cur[2 * m + 1]);
+    ms[m].queryIdx = m; ms[m].trainIdx = m;
+  }
+  std::vector<Point2f> p2(n_pt);
+  std::vector<Point3d> p3(n_pt);
+  for (int i = 0; i < n_pt; ++i) {
+    p2[i] = Point2f(pts2d[2 * i], pts2d[2 * i + 1]);
+    p3[i] = Point3d(pts3d[3 * i], pts3d[3 * i + 1], pts3d[3 * i + 2]);
+  }
+  KRTOptimizer opt(max_iter, max_reproj_error, static_cast<KRTOptimizer::FACTOR_TYPE>(type));
+  opt.SetInitParams(cur.K(), cur.R(), cur.t(), cur.dist());
+  if (order_swapped) {
+    try { opt.Add2d3dConstraints(p2, p3); }
+    catch (const std::logic_error&) { return -2; }
+    return -1;
+  }
+  opt.Add2d2dConstraints(ref, kr, kc, ms);
+  opt.Add2d3dConstraints(p2, p3);
+  Mat33 K, R; Vec3 t; Vec5 dist;
+  const bool ok = opt.Solve(K, R, t, dist);
+  if (num_iter) *num_iter = opt.num_iter_;
+  if (summary) *summary = opt.summary();
+  if (reproj2) {
+    reproj2[0] = opt.Cal2d2dReprojError(ref, kr, kc, ms);
+    reproj2[1] = opt.Cal2d3dReprojError(p2, p3);
+  }
   if (ok) {
     const std::vector<double> v = Camera(K, R, t, dist).ToVector();
     memcpy(cam_cur15, v.data(), sizeof(double) * 15);

@@ -21,6 +21,7 @@ class KRTOptimizer {
   bool Solve(Mat33& K, Mat33& R, Vec3& t, Vec5& dist);
   double Cal2d2dReprojError(const Camera& cam_ref, const std::vector<KeyPoint>& kpts_ref, const std::vector<KeyPoint>& kpts_curr,
                             const std::vector<DMatch>& matches);
+  double Cal2d3dReprojError(const std::vector<Point2f>& pts2d, const std::vector<Point3d>& pts3d);
   void SetFixedFocal() { set_fixed_focal_ = true; }  // a flag nobody reads, as in the reference (krt_optimizer.cc:502)
   int num_iter_ = 0;
 
@@ -29,8 +30,9 @@ class KRTOptimizer {
 
  private:
   Camera cam_curr_world_, cam_ref_;
-  std::vector<float> uv_ref_, uv_cur_;
-  bool has_2d3d_ = false, set_fixed_focal_ = false;
+  std::vector<float> uv_ref_, uv_cur_, pts2d_;
+  std::vector<double> pts3d_;
+  bool has_2d2d_ = false, set_fixed_focal_ = false;
   FACTOR_TYPE factor_type_;
   int max_iter_;
   double max_reproj_error_;

@@ -268,6 +268,10 @@ class RelocBatch:
     cam_init: np.ndarray    # float64 [n_query, 15]  initial current camera, world frame (run_ptz_reloc.cc:96-104)
     cam_gt: np.ndarray      # float64 [n_query, 15]
     factor_type: int = 0
+    # optional 2D-3D constraints per query (KRTOptimizer::Add2d3dConstraints, krt_optimizer.cc:350-383)
+    point_ptr: np.ndarray | None = None   # int64 [n_query + 1]
+    pts2d: np.ndarray | None = None       # float32 [n_pt_total, 2]
+    pts3d: np.ndarray | None = None       # float64 [n_pt_total, 3]  world points
 
 
 def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_type: int = 0,
@@ -333,6 +337,41 @@ def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_
     match_ptr = (np.arange(n_query + 1, dtype=np.int64) * n_match)
     return RelocBatch(n_query=n_query, match_ptr=match_ptr, uv_ref=uv_ref, uv_cur=uv_cur, cam_ref=cam_ref,
                       cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
+
+
+def add_reloc_points(batch: RelocBatch, n_pt: int = 12, noise_px: float = 0.5, depth: float = 60.0) -> RelocBatch:
+    """Adds n_pt 2D-3D constraints to every query: world points in front of the ground-truth camera, projected the way
+    cv::projectPoints does with the ground-truth camera (its translation is the query's initial one, which the single-view
+    solve never changes) and its (k1,k2,p1,p2,k3) reading of the stored distortion."""
+    rng = SplitMix64(SEED_BASE + 0x2D3D00 + batch.n_query)
+    nq = batch.n_query
+    pts2d = np.zeros((nq * n_pt, 2), dtype=np.float32)
+    pts3d = np.zeros((nq * n_pt, 3))
+    for q in range(nq):
+        g = batch.cam_gt[q]
+        R = rodrigues(g[4:7])
+        t = batch.cam_init[q, 7:10]
+        u = rng.uniform(n_pt, 60.0, 2 * g[2] - 60.0)
+        v = rng.uniform(n_pt, 60.0, 2 * g[3] - 60.0)
+        z = rng.uniform(n_pt, 0.5 * depth, 1.5 * depth)
+        # a point at depth z along the (undistorted) pixel direction, then re-projected exactly with distortion
+        Pc = np.stack([(u - g[2]) / g[0] * z, (v - g[3]) / g[1] * z, z], axis=1)
+        Xw = (Pc - t) @ R          # R^T (P - t)
+        P = Xw @ R.T + t
+        x, y = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2]
+        k1, k2, p1, p2, k3 = g[10], g[11], g[12], g[13], g[14]
+        r2 = x * x + y * y
+        cd = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
+        xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        sl = slice(q * n_pt, (q + 1) * n_pt)
+        pts2d[sl, 0] = (xd * g[0] + g[2] + rng.normal(n_pt, noise_px)).astype(np.float32)
+        pts2d[sl, 1] = (yd * g[1] + g[3] + rng.normal(n_pt, noise_px)).astype(np.float32)
+        pts3d[sl] = Xw
+    batch.point_ptr = np.arange(nq + 1, dtype=np.int64) * n_pt
+    batch.pts2d = pts2d
+    batch.pts3d = pts3d
+    return batch
 
 
 def add_annotations(scene: Scene, n_annotated: int = 6, pts_per_cam: int = 12, noise_px: float = 0.5,

@@ -75,6 +75,27 @@ void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* 
   }
 #undef H_KRT
 }
+// KRT 2D-3D block: cam15 current (local frame), Xl local point
+void h_krt_eval_2d3d(int ktype, const double* cam15, const double* Xl, const float* uv, double* res, double* J)
+{
+  double R[9], Jl[9];
+  rodrigues(cam15 + 4, R);
+  so3_left_jacobian(cam15 + 4, Jl);
+  const double fy = (ktype & 2) ? cam15[1] : cam15[0];
+#define H_KRT3(T)                                                                                                      \
+  {                                                                                                                    \
+    double j[2][KrtDims<T>::NF];                                                                                       \
+    krt_eval_2d3d<T, true>(R, Jl, cam15[0], fy, cam15[2], cam15[3], cam15 + 10, cam15 + 7, Xl, uv[0], uv[1], res, j);  \
+    for (int i = 0; i < 2 * KrtDims<T>::NF; ++i) J[i] = (&j[0][0])[i];                                               \
+  }
+  switch (ktype) {
+    case 0: H_KRT3(0) break;
+    case 1: H_KRT3(1) break;
+    case 2: H_KRT3(2) break;
+    default: H_KRT3(3) break;
+  }
+#undef H_KRT3
+}
 // F3: cam15, tlw6, xyz, uv -> res[2], Jc[2][5+factor], Jt[2][6]
 void h_reproj2d3d(int factor, const double* cam15, const double* tlw, const double* xyz, const float* uv, double* res, double* Jc, double* Jt)
 {

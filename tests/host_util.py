@@ -118,6 +118,21 @@ def krt_solve(cam_ref, cam_cur, uv_ref, uv_cur, max_iter=200, max_err=100.0, fty
     return bool(ok), cur, nit.value, summ.as_dict()
 
 
+def krt_solve_2d3d(cam_ref, cam_cur, uv_ref, uv_cur, pts2d, pts3d, max_iter=200, max_err=100.0, ftype=0, swapped=False):
+    """KRTOptimizer with Add2d2dConstraints + Add2d3dConstraints.  Returns (code, cam, num_iter_, summary, [err2d2d, err2d3d]);
+    code 1 = solved, 0 = Solve returned false, -2 = Add2d3dConstraints before Add2d2dConstraints threw."""
+    import __graft_entry__ as ge
+    api = ge.load_package().api
+    cur = np.array(cam_cur, dtype=np.float64).copy()
+    ref = np.ascontiguousarray(cam_ref, dtype=np.float64)
+    ur = np.ascontiguousarray(uv_ref, dtype=np.float32); uc = np.ascontiguousarray(uv_cur, dtype=np.float32)
+    p2 = np.ascontiguousarray(pts2d, dtype=np.float32); p3 = np.ascontiguousarray(pts3d, dtype=np.float64)
+    nit = C.c_int32(); summ = api.LmSummary(); err = np.zeros(2)
+    code = lib().ptzh_krt_solve_2d3d(_p(ref), _p(cur), len(ur), _p(ur), _p(uc), len(p2), _p(p2), _p(p3), max_iter,
+                                     C.c_double(max_err), ftype, int(swapped), C.byref(nit), C.byref(summ), _p(err))
+    return int(code), cur, nit.value, summ.as_dict(), err
+
+
 def incremental_solve(table, cam15, max_iter=200, seeds=()):
     incremental_solve.timing = np.zeros(5)
     """PtzIncrementalOptimizer::Solve through the C++ class.  Returns (ok, cam15, registered ids, events, lm_iterations)."""

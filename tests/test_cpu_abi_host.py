@@ -180,6 +180,75 @@ def test_device_krt_math_matches_oracle(pkg, orc, harness, ktype):
                 assert np.allclose(J[:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
 
 
+@pytest.mark.parametrize("ktype", [0, 1, 2, 3])
+def test_device_krt_2d3d_math_matches_oracle(pkg, orc, harness, ktype):
+    """Factor2d3dDist / Factor2d3dFxfyDist (krt_optimizer.cc:200-249): device residual = the oracle's cv::projectPoints
+    restatement (all five distortion coefficients set, so the (k1,k2,p1,p2,k3) reading is exercised, and a non-zero
+    local translation), Jacobian = central differences of the oracle functor."""
+    rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(3, 16, seed_id=ktype, factor_type=ktype), n_pt=8)
+    idx = {0: [0, 4, 5, 6], 1: [0, 4, 5, 6, 10], 2: [0, 1, 4, 5, 6], 3: [0, 1, 4, 5, 6, 10]}[ktype]
+    nf = len(idx)
+    for q in range(rb.n_query):
+        ref = rb.cam_ref[q].copy(); ref[7:10] = [0.4, -0.2, 0.3]
+        cur = rb.cam_init[q].copy(); cur[7:10] = [0.1, 0.25, -0.3]
+        loc = orc.krt_world_to_local(ref, cur)
+        loc[4:7] += [0.01, -0.02, 0.005]
+        loc[10:15] = [0.02, -0.01, 0.003, -0.002, 0.004]
+        if ktype & 2:
+            loc[1] = loc[0] * 1.03
+        Xl = orc.krt_point_to_local(ref, rb.pts3d[rb.point_ptr[q]:rb.point_ptr[q + 1]])
+        for i in range(len(Xl)):
+            uv = rb.pts2d[rb.point_ptr[q] + i].copy()
+            res = np.zeros(2); J = np.zeros((2, nf))
+            harness.h_krt_eval_2d3d(ktype, _p(loc), _p(Xl[i]), _p(uv), _p(res), _p(J))
+            f = lambda x: orc.res_2d3d_krt(x, ktype & 2, uv, Xl[i])
+            assert np.allclose(res, f(loc), rtol=0, atol=1e-9)
+            for c, k in enumerate(idx):
+                h = max(1.5e-8, abs(loc[k]) * 1e-6)
+                xp = loc.copy(); xp[k] += h
+                xm = loc.copy(); xm[k] -= h
+                num = (f(xp) - f(xm)) / (2 * h)
+                assert np.allclose(J[:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+
+
+def test_oracle_krt_2d3d_known_answers(pkg, orc):
+    """Zero residual at the exact projection; the stored distortion (d0..d4) is read as (k1,k2,p1,p2,k3) by
+    cv::projectPoints, not as the (k1,k2,k3,p1,p2) of the reference's own functors; F/FDist use fy := fx; the solve
+    with both constraint kinds recovers the ground truth and counts both kinds of residuals."""
+    cam = np.zeros(15); cam[0] = 2100; cam[1] = 1900; cam[2], cam[3] = 960, 540
+    cam[4:7] = [0.02, -0.4, 0.01]; cam[7:10] = [0.3, -0.1, 0.2]; cam[10:15] = [0.03, -0.01, 0.002, -0.001, 0.005]
+    X = np.array([1.5, -0.7, 20.0])
+    R = orc.rodrigues(cam[4:7])
+    P = R @ X + cam[7:10]
+    x, y = P[0] / P[2], P[1] / P[2]
+    r2 = x * x + y * y
+    k1, k2, p1, p2, k3 = cam[10:15]
+    cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    uv = np.array([xd * cam[0] + cam[2], yd * cam[1] + cam[3]])
+    r_fxfy = orc.res_2d3d_krt(cam, 1, uv.astype(np.float32), X)
+    assert np.abs(r_fxfy - (uv.astype(np.float32) - uv)).max() < 1e-9
+    r_f = orc.res_2d3d_krt(cam, 0, uv.astype(np.float32), X)  # fy := fx
+    assert abs(r_f[1] - (float(np.float32(uv[1])) - (yd * cam[0] + cam[3]))) < 1e-9
+    # the solve
+    for ftype in (0, 3):
+        rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(2, 64, seed_id=11 + ftype, factor_type=ftype), n_pt=10)
+        for q in range(rb.n_query):
+            s = slice(rb.match_ptr[q], rb.match_ptr[q + 1]); ps = slice(rb.point_ptr[q], rb.point_ptr[q + 1])
+            loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+            Xl = orc.krt_point_to_local(rb.cam_ref[q], rb.pts3d[ps])
+            la, sa, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, pts2d=rb.pts2d[ps],
+                                      pts3d_local=Xl, jacobian_mode=orc.JAC_ANALYTIC)
+            ln, sn, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, pts2d=rb.pts2d[ps],
+                                      pts3d_local=Xl, jacobian_mode=orc.JAC_NUMERIC)
+            assert sa["num_residuals"] == sn["num_residuals"] == 2 * (64 + 10)
+            assert sa["termination_type"] == sn["termination_type"] == 0 and sa["num_iterations"] == sn["num_iterations"]
+            assert np.abs(la - ln).max() < 1e-6 * max(1.0, np.abs(ln).max())
+            w = orc.krt_local_to_world(rb.cam_ref[q], ln, ftype)
+            assert abs(w[0] - rb.cam_gt[q, 0]) / rb.cam_gt[q, 0] < 0.02
+
+
 def test_device_so3_and_inv3(orc, harness):
     rng = np.random.default_rng(9)
     for _ in range(20):

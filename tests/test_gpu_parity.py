@@ -253,6 +253,82 @@ def test_krt_batch_parity(pkg, orc, ftype):
     assert n_acc >= rb.n_query * 0.8
 
 
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3])
+def test_krt_2d3d_batch_parity(pkg, orc, ftype):
+    """Single-view LM with 2D-3D constraints on top of the matches (KRTOptimizer::Add2d3dConstraints,
+    krt_optimizer.cc:350-383; Factor2d3dDist / Factor2d3dFxfyDist :200-249) vs the oracle: same termination and
+    iteration counts, parameters within 1e-6.  Half of the queries use a reference camera with a translation and all
+    five distortion coefficients set, which exercises the local-frame move (:357-362), the constant local translation
+    inside cv::projectPoints and its (k1,k2,p1,p2,k3) reading of the stored distortion."""
+    rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(24, 96, seed_id=20 + ftype, factor_type=ftype), n_pt=12)
+    for q in range(0, rb.n_query, 2):
+        rb.cam_ref[q, 7:10] = [0.05, -0.02, 0.04]
+        rb.cam_init[q, 7:10] = [0.03, 0.01, -0.02]
+        rb.cam_init[q, 11:15] = [-0.004, 0.0015, -0.001, 0.002]
+    # ragged point counts, one query without points
+    keep = [(q * 5) % 13 for q in range(rb.n_query)]
+    idx = np.concatenate([np.arange(rb.point_ptr[q], rb.point_ptr[q] + min(k, 12)) for q, k in enumerate(keep)]).astype(np.int64)
+    rb.pts2d, rb.pts3d = rb.pts2d[idx], rb.pts3d[idx]
+    rb.point_ptr = np.concatenate([[0], np.cumsum([min(k, 12) for k in keep])]).astype(np.int64)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    n_acc = 0
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1]); ps = slice(rb.point_ptr[q], rb.point_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        Xl = orc.krt_point_to_local(rb.cam_ref[q], rb.pts3d[ps])
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, pts2d=rb.pts2d[ps],
+                                      pts3d_local=Xl, jacobian_mode=orc.JAC_NUMERIC)
+        ok = orc.krt_check(osumm, loc, 100.0)
+        assert summ[q]["num_residuals"] == osumm["num_residuals"] == 2 * (96 + (ps.stop - ps.start))
+        assert summ[q]["termination_type"] == osumm["termination_type"]
+        assert summ[q]["num_iterations"] == osumm["num_iterations"]
+        assert abs(summ[q]["initial_cost"] - osumm["initial_cost"]) <= 1e-9 * osumm["initial_cost"]
+        assert bool(acc[q]) == ok
+        if ok:
+            n_acc += 1
+            want = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
+            assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
+            assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
+            assert np.abs(cam_w[q, 7:10] - want[7:10]).max() < 1e-9
+            if ftype & 2:
+                assert abs(cam_w[q, 1] - want[1]) / want[1] < 1e-6
+            if ftype & 1:
+                assert abs(cam_w[q, 10] - want[10]) < 1e-6
+    assert n_acc >= rb.n_query * 0.7
+    # without points the 2D-3D entry point is the plain one
+    rb0 = pkg.synth.make_reloc_batch(4, 64, seed_id=3, factor_type=ftype)
+    a = pkg.api.krt_solve_batch(rb0)
+    rb0.point_ptr = np.zeros(5, dtype=np.int64); rb0.pts2d = np.zeros((1, 2), np.float32); rb0.pts3d = np.zeros((1, 3))
+    b = pkg.api.krt_solve_batch(rb0)
+    # (two instantiations of the kernel: the compiler may contract multiply-adds differently, hence not bit-equal)
+    assert np.allclose(a[0], b[0], rtol=1e-11, atol=1e-13) and [x["num_iterations"] for x in a[1]] == [x["num_iterations"] for x in b[1]]
+
+
+def test_cpp_krt_optimizer_2d3d(pkg, orc):
+    """KRTOptimizer::Add2d3dConstraints / Cal2d3dReprojError through the C++ class (krt_optimizer.h:122-135)."""
+    import host_util as hu
+    rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(4, 96, seed_id=31, factor_type=1), n_pt=10)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1]); ps = slice(rb.point_ptr[q], rb.point_ptr[q + 1])
+        code, cur, nit, sm, err = hu.krt_solve_2d3d(rb.cam_ref[q], rb.cam_init[q], rb.uv_ref[s], rb.uv_cur[s], rb.pts2d[ps],
+                                                     rb.pts3d[ps], ftype=1)
+        assert code == int(acc[q]) and nit == summ[q]["num_successful_steps"]
+        assert sm["num_residuals"] == 2 * (96 + 10)
+        if code == 1:
+            assert abs(cur[0] - cam_w[q, 0]) / cam_w[q, 0] < 1e-12
+            # Cal2d3dReprojError = RMS of the oracle's functor at the refined camera
+            loc = orc.krt_world_to_local(rb.cam_ref[q], cur)
+            Xl = orc.krt_point_to_local(rb.cam_ref[q], rb.pts3d[ps])
+            r = np.array([orc.res_2d3d_krt(loc, 0, rb.pts2d[ps][i], Xl[i]) for i in range(10)])
+            assert abs(err[1] - np.sqrt((r ** 2).sum() / 10)) < 1e-7
+            assert 0 < err[1] < 3.0
+    # Add2d3dConstraints needs the local frame set by Add2d2dConstraints (the reference fails inside OpenCV there)
+    code, *_ = hu.krt_solve_2d3d(rb.cam_ref[0], rb.cam_init[0], rb.uv_ref[:96], rb.uv_cur[:96], rb.pts2d[:10], rb.pts3d[:10],
+                                 ftype=1, swapped=True)
+    assert code == -2
+
+
 def test_krt_ragged_and_degenerate(pkg, orc):
     """Ragged match counts, including a query with too few matches to constrain 4 parameters."""
     rb = pkg.synth.make_reloc_batch(6, 64, seed_id=9)
