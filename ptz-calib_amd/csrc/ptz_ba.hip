@@ -156,26 +156,29 @@ __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s
   return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
 }
 
-// TYPE = factor (0 PTZRay, 1 PTZRayDist) | has3d << 1.
-//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]
-//   NC free camera parameters: without annotations the same set (the reference's always-zero fy column is not
-//   materialised); with 2D-3D annotation residuals fy becomes live (Reproj2d3dFactor reads it, ptzray_optimizer.cc:273):
-//   [f, fy, (k1), r1, r2, r3], and the 6-dof T_l_w block joins the reduced system.
+// TYPE = factor (0 PTZRay, 1 PTZRayDist, 2 PTZRayFxfyDist) + 3 * has3d.
+//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]; PTZRayFxfyDist [fx, fy, k1, r1, r2, r3]
+//   NC free camera parameters: without annotations the same set (the reference's always-zero fy column of PTZRay /
+//   PTZRayDist is not materialised); with 2D-3D annotation residuals fy becomes live (Reproj2d3dFactor reads it,
+//   ptzray_optimizer.cc:273): [f, fy, (k1), r1, r2, r3], and the 6-dof T_l_w block joins the reduced system.
 template <int TYPE> struct Dims {
-  static constexpr int FACTOR = TYPE & 1, HAS3D = (TYPE >> 1) & 1;
-  static constexpr int NW = 4 + FACTOR;
-  static constexpr int NC = NW + HAS3D;
+  static constexpr int FACTOR = TYPE % 3, HAS3D = TYPE / 3;
+  static constexpr int FXFY = FACTOR == 2;  // fy is a 2D-2D column
+  static constexpr int F3 = FACTOR ? 1 : 0;  // Reproj2d3dFactor variant: k1 free or not (same functor for Dist / FxfyDist)
+  static constexpr int NW = 4 + (FACTOR >= 1) + FXFY;
+  static constexpr int NC = NW + (HAS3D && !FXFY);
   static constexpr int NG = 6 * HAS3D;  // size of the global (tlw) block
   // doubles per observation row of W = Jc^T Jr (NW x 3), rounded up to a 16-byte multiple: 12 (96 B) / 16 (128 B).
   // Measured on MI355X: unpadded 96-B rows beat 128-B-aligned rows (less write/stream traffic outweighs line straddling).
   static constexpr int WS = (NW * 3 + 1) & ~1;
   // position of 2D-2D column k inside the NC block
-  static __host__ __device__ constexpr int pos(int k) { return HAS3D ? (k == 0 ? 0 : k + 1) : k; }
+  static __host__ __device__ constexpr int pos(int k) { return NC != NW ? (k == 0 ? 0 : k + 1) : k; }
   // index of free parameter k of the NC block in the Camera 15-vector
   static __host__ __device__ constexpr int at(int k)
   {
-    // PTZRay: f r1 r2 r3 | PTZRayDist: f k1 r.. | +3D: f fy r.. | f fy k1 r..
-    return k == 0 ? 0 : (HAS3D && k == 1) ? 1 : (FACTOR && k == 1 + HAS3D) ? 10 : 4 + (k - (NC - 3));
+    // PTZRay: f r1 r2 r3 | PTZRayDist: f k1 r.. | +3D: f fy r.. | f fy k1 r.. | PTZRayFxfyDist (with or without 3D): fx fy k1 r..
+    constexpr int FYL = (NC != NW) || FXFY;  // fy occupies slot 1
+    return k == 0 ? 0 : (FYL && k == 1) ? 1 : (FACTOR && k == 1 + FYL) ? 10 : 4 + (k - (NC - 3));
   }
 };
 
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
   if (lane == 0) {
     d.costc[gi] = cost;
-    if (Dims<TYPE>::HAS3D) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
+    if (NC != NW) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
 #pragma unroll
       for (int k = 0; k < NC * NC; ++k) d.U[(size_t)gi * NC * NC + k] = 0;
 #pragma unroll
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
 {
-  constexpr int NC = Dims<TYPE>::NC, F = Dims<TYPE>::FACTOR;
+  constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
   const int sc = blockIdx.x;
   const SceneDev s = d.scene[sc];
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
     const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CAMBLK;
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
-    double res[2], Jc[2][5 + F], Jt[2][6];
-    reproj2d3d_eval<F, true>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
+    double res[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, true>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
     for (int k = 0; k < NC; ++k) { d.Jc3[(size_t)go * 2 * NC + k] = Jc[0][k] * cb[CB_S + k]; d.Jc3[(size_t)go * 2 * NC + NC + k] = Jc[1][k] * cb[CB_S + k]; }
     for (int k = 0; k < 6; ++k) { d.Jt3[(size_t)go * 12 + k] = Jt[0][k] * stl[k]; d.Jt3[(size_t)go * 12 + 6 + k] = Jt[1][k] * stl[k]; }
     d.r3[(size_t)go * 2] = res[0]; d.r3[(size_t)go * 2 + 1] = res[1];
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 {
-  constexpr int NC = Dims<TYPE>::NC, F = Dims<TYPE>::FACTOR;
+  constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
   const int sc = blockIdx.x;
   if (!d.active[sc]) return;
@@ -1118,8 +1121,8 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
     for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CANDBLK + k];
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
-    double rc[2], Jc[2][5 + F], Jt[2][6];
-    reproj2d3d_eval<F, false>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
+    double rc[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, false>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
     cost += 0.5 * (rc[0] * rc[0] + rc[1] * rc[1]);
   }
   mcc = block_sum(mcc, scratch);
@@ -1684,6 +1687,7 @@ int32_t ptz_ba_cam_block_dim(int32_t factor_type)
 {
   if (factor_type == PTZ_BA_PTZRay) return 4;
   if (factor_type == PTZ_BA_PTZRayDist) return 5;
+  if (factor_type == PTZ_BA_PTZRayFxfyDist) return 6;
   return PTZ_EUNSUPPORTED;
 }
 
@@ -1722,7 +1726,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
   const int type = problems[0].factor_type;
-  if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist) return PTZ_EUNSUPPORTED;
+  if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist && type != PTZ_BA_PTZRayFxfyDist) return PTZ_EUNSUPPORTED;
   int has3d = 0;
   // ---- validate + sizes (host only; no device touched before this passes)
   for (int i = 0; i < n; ++i) {
@@ -1743,7 +1747,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
   PTZ_HIP_TRY(hipSetDevice(o.device_id));
 
-  const int NC = ((type == PTZ_BA_PTZRay) ? 4 : 5) + has3d;  // fy becomes a live column with annotation residuals
+  // fy becomes a live column with annotation residuals; PTZRayFxfyDist has it anyway
+  const int NC = type == PTZ_BA_PTZRayFxfyDist ? 6 : ((type == PTZ_BA_PTZRay) ? 4 : 5) + has3d;
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
@@ -1986,7 +1991,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     TRY(upload(b, h_camflag, &d.cam_flag));
     TRY(b->alloc(&d.gfold, (size_t)b->total_cam * NC));
   }
-  TRY(b->alloc(&d.W, (size_t)b->total_obs * 16));  // room for the widest row stride
+  TRY(b->alloc(&d.W, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
@@ -2092,14 +2097,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
   {
-    const int t = (type == PTZ_BA_PTZRay ? 0 : 1) + 2 * has3d;
+    const int t = type + 3 * has3d;  // Dims<TYPE>
 #define PTZ_SET_ATTR(T)                                                                                             \
     if (t == T) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)k_schur<T>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);   \
       (void)hipFuncSetAttribute((const void*)k_eval<T>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);     \
       (void)hipFuncSetAttribute((const void*)k_lin_ray<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);   \
     }
-    PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3)
+    PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
 #undef PTZ_SET_ATTR
   }
   tc3 = now_ms();
@@ -2135,11 +2140,13 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
   PTZ_HIP_TRY(hipSetDevice(b->device));
-  switch ((b->type == PTZ_BA_PTZRay ? 0 : 1) + 2 * b->has3d) {
+  switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
     case 0: return solve_impl<0>(b, summaries);
     case 1: return solve_impl<1>(b, summaries);
     case 2: return solve_impl<2>(b, summaries);
-    default: return solve_impl<3>(b, summaries);
+    case 3: return solve_impl<3>(b, summaries);
+    case 4: return solve_impl<4>(b, summaries);
+    default: return solve_impl<5>(b, summaries);
   }
 }
 
@@ -2213,11 +2220,13 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x + d.tlw_stride, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_fill, dim3((6 * b->n_scene + 255) / 256), dim3(256), 0, st, d.scale_t, (size_t)6 * b->n_scene, 1.0);
-  switch ((b->type == PTZ_BA_PTZRay ? 0 : 1) + 2 * b->has3d) {
+  switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
     case 0: enqueue_linearize<0>(b); break;
     case 1: enqueue_linearize<1>(b); break;
     case 2: enqueue_linearize<2>(b); break;
-    default: enqueue_linearize<3>(b); break;
+    case 3: enqueue_linearize<3>(b); break;
+    case 4: enqueue_linearize<4>(b); break;
+    default: enqueue_linearize<5>(b); break;
   }
   PTZ_HIP_TRY(hipStreamSynchronize(st));
   const SceneDev& s = b->scenes[index];
@@ -2241,7 +2250,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     }
   }
   if (W) {  // rows are stored camera-major; return them in observation order
-    const int NW = NC - b->has3d;           // W carries the 2D-2D columns only
+    const int NW = b->type == PTZ_BA_PTZRayFxfyDist ? 6 : NC - b->has3d;  // W carries the 2D-2D columns only
     const int ws = (NW * 3 + 1) & ~1;        // Dims<TYPE>::WS
     std::vector<double> rows((size_t)s.n_obs * ws);
     std::vector<int> wp(s.n_obs);

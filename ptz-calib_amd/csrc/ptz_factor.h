@@ -142,7 +142,9 @@ PTZ_HD void brown_jac(double x, double y, const double* k, double B[4], double d
 // The reference also leaves intr[1] ("fy") free, but neither functor reads it (param[1] = intr[0],
 // ptzray_optimizer.cc:24-25, 69-70): its Jacobian column is identically zero, its LM step is exactly
 // zero, so the column is not materialised.
-template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : 5; static constexpr int ROT0 = NC - 3; };  // TYPE = factor (0 / 1)
+// TYPE 2 = PTZRayFxfyDist (ptzray_optimizer.cc:136-191): free [fx, fy, k1, r1, r2, r3] (NC = 6); the ray IS normalised (:161),
+// there is no behind-the-camera branch, fy is read (:167,185).
+template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : (TYPE == 1 ? 5 : 6); static constexpr int ROT0 = NC - 3; };  // TYPE = factor (0 / 1 / 2)
 
 // Residual only.  cb = camera block (R at [CB_R], intrinsics); X = ray parameter (3).
 template <int TYPE>
@@ -151,7 +153,7 @@ PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, d
   const double* R = cb + CB_R;
   const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
   double Xn[3];
-  if (TYPE == 0) {
+  if (TYPE != 1) {
     const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
     Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
   }
@@ -167,12 +169,12 @@ PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, d
     res[1] = (double)v - (f * Py + cy * Pz) / Pz;
   }
   else {
-    if (Pz < 0) { res[0] = 1000000.0; res[1] = 1000000.0; return; }  // :97-102
+    if (TYPE == 1 && Pz < 0) { res[0] = 1000000.0; res[1] = 1000000.0; return; }  // :97-102
     const double x = Px / Pz, y = Py / Pz;
     double xd, yd;
     brown(x, y, cb + CB_K, xd, yd);
     res[0] = (double)u - (f * xd + cx);
-    res[1] = (double)v - (f * yd + cy);
+    res[1] = (double)v - ((TYPE == 2 ? cb[CB_FY] : f) * yd + cy);
   }
 }
 
@@ -186,8 +188,9 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   const double* R = cb + CB_R;
   const double* Jl = cb + CB_JL;
   const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
+  const double fy = TYPE == 2 ? cb[CB_FY] : f;
   double Xn[3], inv_n = 1.0;
-  if (TYPE == 0) {
+  if (TYPE != 1) {
     const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
     inv_n = 1.0 / n;
     Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
@@ -198,7 +201,7 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
   const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
   const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
-  if (TYPE != 0 && Pz < 0) {
+  if (TYPE == 1 && Pz < 0) {
     res[0] = 1000000.0; res[1] = 1000000.0;
     for (int k = 0; k < NC; ++k) { Jc[0][k] = 0; Jc[1][k] = 0; }
     for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
@@ -216,17 +219,25 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
     brown(x, y, cb + CB_K, xd, yd);
     brown_jac(x, y, cb + CB_K, B, dk1);
     res[0] = (double)u - (f * xd + cx);
-    res[1] = (double)v - (f * yd + cy);
+    res[1] = (double)v - (fy * yd + cy);
   }
-  // M = d pred / dP = f * B * dpi,  dpi = [[iz, 0, -x iz], [0, iz, -y iz]]
+  // M = d pred / dP = diag(f, fy) * B * dpi,  dpi = [[iz, 0, -x iz], [0, iz, -y iz]]
   double M[2][3];
   M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
-  M[1][0] = f * (B[2] * iz);  M[1][1] = f * (B[3] * iz);  M[1][2] = f * (-(B[2] * x + B[3] * y) * iz);
-  Jc[0][0] = -xd;
-  Jc[1][0] = -yd;
-  if (TYPE != 0) {
-    Jc[0][1] = -f * dk1[0];
-    Jc[1][1] = -f * dk1[1];
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  if (TYPE == 2) {
+    Jc[0][0] = -xd; Jc[1][0] = 0;
+    Jc[0][1] = 0;   Jc[1][1] = -yd;
+    Jc[0][2] = -f * dk1[0];
+    Jc[1][2] = -fy * dk1[1];
+  }
+  else {
+    Jc[0][0] = -xd;
+    Jc[1][0] = -yd;
+    if (TYPE != 0) {
+      Jc[0][1] = -f * dk1[0];
+      Jc[1][1] = -f * dk1[1];
+    }
   }
   // rotation: dP/dr_k = Jl[:,k] x P
 #pragma unroll
@@ -236,7 +247,7 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
     Jc[0][ROT0 + k] = -(M[0][0] * dx + M[0][1] * dy + M[0][2] * dz);
     Jc[1][ROT0 + k] = -(M[1][0] * dx + M[1][1] * dy + M[1][2] * dz);
   }
-  // ray: dP/dX = R (I - Xn Xn^T)/|X| for PTZRay; since M P = 0 (the projection is scale invariant)
+  // ray: dP/dX = R (I - Xn Xn^T)/|X| for PTZRay / PTZRayFxfyDist; since M P = 0 (the projection is scale invariant)
   // the projector term vanishes identically: d res/dX = -(M R)/|X|.  PTZRayDist: dP/dX = R.
 #pragma unroll
   for (int k = 0; k < 3; ++k) {

@@ -233,7 +233,7 @@ static void Residual2d3d(const double* c, const double* tlw, const double* Xw, f
 static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, const double* X, float u, float v, double* res)
 {
   Vec3 x = {X[0], X[1], X[2]};
-  if (type == PTZRay) {
+  if (type != PTZRayDist) {  // PTZRay and PTZRayFxfyDist normalise the ray (:42, :161)
     const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     x = {x[0] / n, x[1] / n, x[2] / n};
   }
@@ -243,14 +243,14 @@ static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, cons
     res[1] = static_cast<double>(v) - (c[0] * P[1] + c[3] * P[2]) / P[2];
     return;
   }
-  if (P[2] < 0) { res[0] = res[1] = 1000000.0; return; }
+  if (type == PTZRayDist && P[2] < 0) { res[0] = res[1] = 1000000.0; return; }  // :97-102, PTZRayDist only
   const double px = P[0] / P[2], py = P[1] / P[2];
   const double r2 = px * px + py * py, r4 = r2 * r2, r6 = r2 * r2 * r2;
   const double rad = 1.0 + c[10] * r2 + c[11] * r4 + c[12] * r6;
   const double xd = px * rad + 2.0 * c[13] * px * py + c[14] * (r2 + 2.0 * px * px);
   const double yd = py * rad + 2.0 * c[14] * px * py + c[13] * (r2 + 2.0 * py * py);
   res[0] = static_cast<double>(u) - (c[0] * xd + c[2]);
-  res[1] = static_cast<double>(v) - (c[0] * yd + c[3]);
+  res[1] = static_cast<double>(v) - ((type == PTZRayFxfyDist ? c[1] : c[0]) * yd + c[3]);  // fy read by PTZRayFxfyDist (:167)
 }
 
 bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras)
@@ -266,9 +266,9 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   if (!CheckValid()) return false;
   FindTracks();
   SetInitTransLocalToWorld();
-  // Device path limits (documented in DESIGN.md): the Fxfy / Disp factor types are not implemented -> behave as a failed
+  // Device path limit (documented in DESIGN.md): the displacement factor type is not implemented -> behaves as a failed
   // solve, never as a silent CPU solve.
-  if (type_ != PTZRay && type_ != PTZRayDist) return false;
+  if (type_ != PTZRay && type_ != PTZRayDist && type_ != PTZRayFxfyDist) return false;
   Pack();
   PackedBA& p = packed_;
   if (p.obs_cam.empty() || p.ray_track.empty()) return false;
@@ -281,7 +281,7 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   prob.obs_cam = p.obs_cam.data();
   prob.obs_ray = p.obs_ray.data();
   prob.ray_weight = p.ray_weight.data();
-  prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : PTZ_BA_PTZRayDist;
+  prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : (type_ == PTZRayDist ? PTZ_BA_PTZRayDist : PTZ_BA_PTZRayFxfyDist);
   // SetSharedIntrinsics: the intrinsics block id of every candidate camera (ptzray_optimizer.cc:643-650)
   p.ic_of_cam.clear();
   bool shared = false;
@@ -346,7 +346,9 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   T_l_w(tlw, R_l_w, t_l_w);
   for (size_t c = 0; c < p.cam_image.size(); ++c) {
     std::vector<double> param(cam.begin() + 15 * c, cam.begin() + 15 * (c + 1));
-    param[1] = param[0];  // fy := fx for PTZRay / PTZRayDist, also after fy was a free parameter of the annotations (:705-706)
+    // fy := fx for PTZRay / PTZRayDist, also after fy was a free parameter of the annotations (:705-706); PTZRayFxfyDist keeps
+    // its own fy (:683-685)
+    if (type_ != PTZRayFxfyDist) param[1] = param[0];
     Camera& out = cameras[p.cam_image[c]];
     out.FromVector(param);
     // local -> world: T_i_w = T_i_l T_l_w (:729-740)

@@ -86,6 +86,84 @@ def test_linearize_vs_oracle(pkg, orc, ftype):
     b.close()
 
 
+def _fxfy_scene(pkg, seed=3, annotated=False):
+    """PTZRayFxfyDist scene: the generator's cameras with fy pulled 1.5 % away from fx at the start."""
+    sc = pkg.synth.make_scene(seed, 20, 100, factor_type=2)
+    if annotated:
+        sc = pkg.synth.add_annotations(sc)
+    sc.cam_init = sc.cam_init.copy()
+    sc.cam_init[:, 1] = sc.cam_init[:, 0] * 1.015
+    return sc
+
+
+def test_linearize_fxfy_dist_vs_oracle(pkg, orc):
+    """PTZRayFxfyDistFactor (ptzray_optimizer.cc:136-191): normalised ray, no behind-the-camera branch, fy read;
+    camera block [fx, fy, k1, r1, r2, r3] -- the oracle's own block, so no column is dropped."""
+    sc = _fxfy_scene(pkg)
+    cam = sc.cam_init.copy(); cam[:, 10] = 0.012
+    ray = sc.ray_init * 1.3
+    b = pkg.api.BaBatch([sc]); b.set_state([cam], [ray])
+    assert b.nc == 6
+    g = b.linearize(0)
+    o = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_ANALYTIC)
+    assert abs(g["cost"] - o["cost"]) / o["cost"] < 1e-12
+    for k in ("U", "g_c", "V", "g_r", "W"):
+        assert _rel(g[k], o[k]) < 1e-11, k
+    on = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_NUMERIC)
+    assert _rel(g["W"], on["W"]) < 1e-6
+    b.close()
+
+
+@pytest.mark.parametrize("annotated", [False, True])
+def test_ba_fxfy_dist_parity(pkg, orc, annotated):
+    """PTZRayFxfyDist solve, without and with the georeferencing residuals (Reproj2d3dFactor is shared with PTZRayDist,
+    ptzray_optimizer.cc:905-911): LM bookkeeping identical to the oracle, fx, fy, k1 and relative rotations within 1e-6."""
+    sc = _fxfy_scene(pkg, seed=4, annotated=annotated)
+    if annotated:
+        cam, ray, summ, tlw = pkg.api.ba_solve(sc, return_tlw=True)
+    else:
+        cam, ray, summ = pkg.api.ba_solve(sc)
+    for mode in (orc.JAC_ANALYTIC, orc.JAC_NUMERIC):
+        if annotated:
+            ocam, oray, otlw, osumm, _ = orc.ba_solve(sc, obs3d=sc.obs3d, tlw0=sc.tlw_init, jacobian_mode=mode, num_threads=4)
+        else:
+            ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=mode, num_threads=4)
+        assert summ["termination_type"] == osumm["termination_type"] == 0
+        assert summ["num_iterations"] == osumm["num_iterations"]
+        assert summ["num_successful_steps"] == osumm["num_successful_steps"]
+        assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-8
+        assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6 and _rel(cam[:, 1], ocam[:, 1]) < 1e-6
+        assert np.abs(cam[:, 10] - ocam[:, 10]).max() < 1e-6
+        assert np.abs(_relative_rotations(orc, cam) - _relative_rotations(orc, ocam)).max() < 1e-6
+        if annotated:
+            Rlw, oRlw = orc.rodrigues(tlw[:3]), orc.rodrigues(otlw[:3])
+            for i in range(sc.n_cam):
+                assert np.abs(orc.rodrigues(cam[i, 4:7]) @ Rlw - orc.rodrigues(ocam[i, 4:7]) @ oRlw).max() < 1e-6
+    # fy is a live 2D-2D column: it moves for every camera, towards the ground truth (fy = fx in the generator)
+    assert np.all(cam[:, 1] != sc.cam_init[:, 1])
+    assert np.abs(cam[:, 1] - sc.cam_gt[:, 0]).mean() < np.abs(sc.cam_init[:, 1] - sc.cam_gt[:, 0]).mean()
+    assert np.array_equal(cam[:, [2, 3, 7, 8, 9, 11, 12, 13, 14]], sc.cam_init[:, [2, 3, 7, 8, 9, 11, 12, 13, 14]])
+
+
+def test_ba_fxfy_dist_batch_and_shared_intrinsics(pkg, orc):
+    """PTZRayFxfyDist in a batch of different scenes (bit-identical to single solves) and with SetSharedIntrinsics groups
+    (fx, fy, k1 shared inside a group)."""
+    scenes = [_fxfy_scene(pkg, seed=10 + i) for i in range(9)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, _ = b.get_state(); b.close()
+    for i in (0, 4, 8):
+        cam1, _, s1 = pkg.api.ba_solve(scenes[i])
+        assert s1["num_iterations"] == summ[i]["num_iterations"] and abs(s1["final_cost"] - summ[i]["final_cost"]) <= 1e-9 * s1["final_cost"]
+        assert _rel(cam1[:, :2], cams[i][:, :2]) < 1e-9
+    sc = pkg.synth.make_scene(6, 24, 100, factor_type=2, n_intrinsics_groups=3)
+    cam, _, summ1 = pkg.api.ba_solve(sc)
+    ocam, _, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, num_threads=4)
+    assert summ1["termination_type"] == osumm["termination_type"] and summ1["num_iterations"] == osumm["num_iterations"]
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6 and _rel(cam[:, 1], ocam[:, 1]) < 1e-6
+    for g in np.unique(sc.ic_of_cam):
+        m = np.flatnonzero(sc.ic_of_cam == g)
+        assert np.ptp(cam[m, 0]) == 0 and np.ptp(cam[m, 1]) == 0 and np.ptp(cam[m, 10]) == 0
+
+
 def test_pix2ray_vs_oracle(pkg, orc, scene_c1):
     b = pkg.api.BaBatch([scene_c1])
     b.set_state(None, [np.zeros_like(scene_c1.ray_init)])
@@ -375,6 +453,28 @@ def test_cpp_ptzray_optimizer_matches_oracle(pkg, orc, scene_c1):
     # max_iter reached -> Solve returns false and the cameras are left untouched (ptzray_optimizer.cc:482-488)
     ok2, cam2, _, s2, _ = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=2)
     assert not ok2 and s2["termination_type"] == 1 and np.allclose(cam2, sc.cam_init, atol=1e-12)
+
+
+def test_cpp_ptzray_optimizer_fxfy_dist(pkg, orc):
+    """PTZRayOptimizer with FACTOR_TYPE PTZRayFxfyDist (ptzray_optimizer.h:110): same answer as the packed C-ABI solve,
+    fy kept on read-back (ptzray_optimizer.cc:683-685) instead of being overwritten with fx; PTZRayDistDisp is refused."""
+    import host_util as hu
+    sc = _fxfy_scene(pkg, seed=5)
+    kps, plist = hu.scene_to_features_matches(sc)
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=2)
+    assert ok and summ["termination_type"] == 0
+    from types import SimpleNamespace
+    base = dict(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"], n_cam=sc.n_cam,
+                n_ray=len(pk["ray_weight"]), factor_type=2)
+    ns = SimpleNamespace(**base, cam_init=sc.cam_init, ray_init=orc.pix2ray(SimpleNamespace(**base), sc.cam_init))
+    ocam, oray, _, osumm, _ = orc.ba_solve(ns, jacobian_mode=orc.JAC_NUMERIC)
+    assert summ["num_iterations"] == osumm["num_iterations"]
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6 and _rel(cam[:, 1], ocam[:, 1]) < 1e-6
+    assert np.all(cam[:, 1] != cam[:, 0])
+    res = orc.ba_residuals(ns, ocam, oray)
+    assert abs(err[1] - np.sqrt((res ** 2).sum() / len(res))) < 1e-6
+    ok3, cam3, *_ = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=3)
+    assert not ok3 and np.allclose(cam3, sc.cam_init, atol=1e-12)
 
 
 def test_cpp_krt_optimizer_matches_batch_api(pkg):
