@@ -38,15 +38,13 @@ extern "C" {
 /* enum FACTOR_TYPE { PTZRay, PTZRayDist, PTZRayFxfyDist, PTZRayDistDisp }  (ptzray_optimizer.h:110) */
 #define PTZ_BA_PTZRay 0
 #define PTZ_BA_PTZRayDist 1
-#define PTZ_BA_PTZRayFxfyDist 2
-#define PTZ_BA_PTZRayDistDisp 3
+#define PTZ_BA_PTZRayFxfyDist 2 /* fx, fy, k1 free (ptzray_optimizer.cc:136-191); camera block of 6 columns */
+#define PTZ_BA_PTZRayDistDisp 3 /* displacement block: PTZ_EUNSUPPORTED (restated in oracle/ only) */
 /* KRTOptimizer::FACTOR_TYPE { F, FDist, Fxfy, FxfyDist }  (krt_optimizer.h:110) */
 #define PTZ_KRT_F 0
 #define PTZ_KRT_FDist 1
 #define PTZ_KRT_Fxfy 2      /* fy free as well: Factor2d2dFxfy (krt_optimizer.cc:52-71), dead from the reference's tools */
 #define PTZ_KRT_FxfyDist 3  /* Factor2d2dFxfyDist (krt_optimizer.cc:141-192) */
-#define PTZ_KRT_Fxfy 2
-#define PTZ_KRT_FxfyDist 3
 /* ceres::TerminationType as read by the reference (ptzray_optimizer.cc:482, krt_optimizer.cc:513) */
 #define PTZ_CONVERGENCE 0
 #define PTZ_NO_CONVERGENCE 1

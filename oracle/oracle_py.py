@@ -152,8 +152,10 @@ def _ba_problem(obs_uv, obs_cam, obs_ray, ray_weight, n_cam, n_ray, factor_type,
     return p, keep
 
 
-def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, **opt):
-    """Run the oracle's PTZ-IBA LM.  Returns (cam, ray, tlw, summary dict, Trace|None)."""
+def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, disp=None, **opt):
+    """Run the oracle's PTZ-IBA LM.  Returns (cam, ray, tlw, summary dict, Trace|None).
+    disp: optional float64[3] array, the displacement block of PTZRayDistDisp -- initial value in, refined value out
+    (updated in place); None starts it at zero as the reference does and drops the result."""
     p, keep = _ba_problem(scene.obs_uv, scene.obs_cam, scene.obs_ray, scene.ray_weight, scene.n_cam, scene.n_ray,
                           scene.factor_type, obs3d, getattr(scene, "ic_of_cam", None))
     cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
@@ -163,8 +165,10 @@ def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, **
     o.num_threads = max(1, min(o.num_threads, usable_cores()))
     s = LmSummary()
     t, arrs = _mk_trace(o.max_num_iterations + 2) if trace else (None, None)
-    rc = lib().orc_ba_solve(C.byref(p), _p(cam), _p(ray), _p(tlw), C.byref(o), C.byref(s),
-                            C.byref(t) if t is not None else None)
+    if disp is not None:
+        assert disp.dtype == np.float64 and disp.shape == (3,) and disp.flags.c_contiguous
+    rc = lib().orc_ba_solve_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(disp) if disp is not None else None, C.byref(o),
+                                 C.byref(s), C.byref(t) if t is not None else None)
     if rc != 0:
         raise RuntimeError("orc_ba_solve: invalid problem")
     tr = None
@@ -174,7 +178,7 @@ def ba_solve(scene, cam0=None, ray0=None, tlw0=None, obs3d=None, trace=False, **
     return cam, ray, tlw, s.as_dict(), tr
 
 
-def ba_linearize(scene, cam, ray, tlw=None, jacobian_mode=JAC_ANALYTIC, obs3d=None):
+def ba_linearize(scene, cam, ray, tlw=None, jacobian_mode=JAC_ANALYTIC, obs3d=None, disp=None):
     p, keep = _ba_problem(scene.obs_uv, scene.obs_cam, scene.obs_ray, scene.ray_weight, scene.n_cam, scene.n_ray,
                           scene.factor_type, obs3d)
     ncf = lib().orc_ba_cam_free_dim(scene.factor_type)
@@ -187,21 +191,23 @@ def ba_linearize(scene, cam, ray, tlw=None, jacobian_mode=JAC_ANALYTIC, obs3d=No
     g_r = np.zeros((scene.n_ray, 3))
     V = np.zeros((scene.n_ray, 3, 3))
     W = np.zeros((p.n_obs, ncf, 3))
-    rc = lib().orc_ba_linearize(C.byref(p), _p(cam), _p(ray), _p(tlw), jacobian_mode, C.byref(cost), _p(g_c), _p(U),
-                                _p(g_r), _p(V), _p(W))
+    dd = None if disp is None else np.ascontiguousarray(disp, dtype=np.float64)
+    rc = lib().orc_ba_linearize_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(dd) if dd is not None else None, jacobian_mode,
+                                     C.byref(cost), _p(g_c), _p(U), _p(g_r), _p(V), _p(W))
     if rc != 0:
         raise RuntimeError("orc_ba_linearize: invalid problem")
     return dict(cost=cost.value, g_c=g_c, U=U, g_r=g_r, V=V, W=W, ncf=ncf)
 
 
-def ba_residuals(scene, cam, ray, tlw=None, obs3d=None):
+def ba_residuals(scene, cam, ray, tlw=None, obs3d=None, disp=None):
     p, keep = _ba_problem(scene.obs_uv, scene.obs_cam, scene.obs_ray, scene.ray_weight, scene.n_cam, scene.n_ray,
                           scene.factor_type, obs3d)
     cam = np.ascontiguousarray(cam, dtype=np.float64)
     ray = np.ascontiguousarray(ray, dtype=np.float64)
     tlw = np.zeros(6) if tlw is None else np.ascontiguousarray(tlw, dtype=np.float64)
     res = np.zeros((p.n_obs + p.n_obs3d, 2))
-    lib().orc_ba_residuals(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(res))
+    dd = None if disp is None else np.ascontiguousarray(disp, dtype=np.float64)
+    lib().orc_ba_residuals_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(dd) if dd is not None else None, _p(res))
     return res
 
 

@@ -276,6 +276,47 @@ void orc_res_ptzray_fxfy_dist(const double* intr, const double* extr, const doub
   res[1] = (double)uv[1] - (fy * yd + cy);
 }
 
+/* PTZRayDistDispFactor::operator()  ptzray_optimizer.cc:195-259: unit ray, P = R X, P.z += d0 + d1 f + d2 f^2 (f = intr[0]),
+ * perspective divide, Brown distortion, fy := fx.  No behind-the-camera branch. */
+void orc_res_ptzray_dist_disp(const double* intr, const double* disp, const double* extr, const double* ray, const float* uv,
+                              double* res)
+{
+  double fx = intr[0], fy = intr[0], cx = intr[2], cy = intr[3];
+  double R[9], P[3];
+  orc_rodrigues(extr, R);
+  double n = vec3_norm(ray);
+  double X[3] = {ray[0] / n, ray[1] / n, ray[2] / n};
+  mat3_mul_vec(R, X, P);
+  double displacement = disp[0] + disp[1] * fx + disp[2] * fx * fx;
+  P[2] += displacement;
+  double x = P[0] / P[2], y = P[1] / P[2];
+  double xd, yd;
+  brown(x, y, intr[4], intr[5], intr[6], intr[7], intr[8], &xd, &yd);
+  res[0] = (double)uv[0] - (fx * xd + cx);
+  res[1] = (double)uv[1] - (fy * yd + cy);
+}
+
+/* Reproj2d3dDispFactor::operator()  ptzray_optimizer.cc:334-396: as Reproj2d3dFactor with the displacement added to the
+ * camera-frame z; fy = intr[1] IS read (:340). */
+void orc_res_reproj2d3d_disp(const double* intr, const double* disp, const double* extr, const double* tlw, const float* uv,
+                             const double* xyz, double* res)
+{
+  double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  double R[9], Rlw[9], Xl[3], P[3];
+  orc_rodrigues(extr, R);
+  orc_rodrigues(tlw, Rlw);
+  mat3_mul_vec(Rlw, xyz, Xl);
+  Xl[0] += tlw[3]; Xl[1] += tlw[4]; Xl[2] += tlw[5];
+  mat3_mul_vec(R, Xl, P);
+  double displacement = disp[0] + disp[1] * fx + disp[2] * fx * fx;
+  P[2] += displacement;
+  double x = P[0] / P[2], y = P[1] / P[2];
+  double xd, yd;
+  brown(x, y, intr[4], intr[5], intr[6], intr[7], intr[8], &xd, &yd);
+  res[0] = (double)uv[0] - (fx * xd + cx);
+  res[1] = (double)uv[1] - (fy * yd + cy);
+}
+
 /* F3  Reproj2d3dFactor::operator()  ptzray_optimizer.cc:268-326;  T_l_w :507-513 */
 void orc_res_reproj2d3d(const double* intr, const double* extr, const double* tlw, const float* uv, const double* xyz,
                         double* res)
@@ -821,7 +862,8 @@ static int inv3_llt(const double* A, double* Ainv)
 /* ------------------------------------------------------------------------------------------ */
 /* PTZ-IBA problem: evaluation with Ceres-style numeric or closed-form Jacobians               */
 /* ------------------------------------------------------------------------------------------ */
-#define MAX_NCF 6
+#define MAX_NCF 9
+#define CFREE_DISP 15 /* cfree values 15, 16, 17 denote the three displacement parameters (not part of the camera 15-vector) */
 
 typedef struct {
   const orc_ba_problem* p;
@@ -829,6 +871,9 @@ typedef struct {
   int ncf;               /* free camera parameters per camera */
   int cfree[MAX_NCF];    /* indices into the 15-vector */
   int has_tlw;
+  int has_disp;          /* PTZRayDistDisp: the global 3-parameter displacement block (disp_param_, ptzray_optimizer.cc:655).  It
+                          * is carried as three extra slots of every camera that all map (cmap) to the slots of camera 0 --
+                          * one parameter block shared by every residual, the same device as for shared intrinsics. */
   int n_cs;              /* camera-side system size = ncf * n_cam + 6 * has_tlw */
   int n_free;
   int n_amb;
@@ -854,7 +899,8 @@ typedef struct {
   int64_t* ray_ptr; /* [n_ray + 1] observation ranges */
 } ba_ctx;
 
-/* ambient x layout: [cam 15*n_cam | ray 3*n_ray | tlw 6] ; tangent: [cam ncf*n_cam | tlw 6*has | ray 3*n_ray] */
+/* ambient x layout: [cam 15*n_cam | ray 3*n_ray | tlw 6 | disp 3] ; tangent: [cam ncf*n_cam | tlw 6*has | ray 3*n_ray] */
+static inline const double* X_disp(const ba_ctx* c, const double* x) { return x + 15 * (size_t)c->p->n_cam + 3 * (size_t)c->p->n_ray + 6; }
 static inline const double* X_cam(const ba_ctx* c, const double* x, int i) { (void)c; return x + 15 * (size_t)i; }
 static inline const double* X_ray(const ba_ctx* c, const double* x, int j) { return x + 15 * (size_t)c->p->n_cam + 3 * (size_t)j; }
 static inline const double* X_tlw(const ba_ctx* c, const double* x) { return x + 15 * (size_t)c->p->n_cam + 3 * (size_t)c->p->n_ray; }
@@ -873,13 +919,21 @@ static int cam_idx_to_block18(int ci)
   return 9 + (ci - 4);
 }
 
-static void res2d2d(int type, const double* intr, const double* extr, const double* ray, const float* uv, double* res)
+static void res2d2d(int type, const double* intr, const double* disp, const double* extr, const double* ray, const float* uv,
+                    double* res)
 {
   switch (type) {
     case ORC_PTZRay: orc_res_ptzray(intr, extr, ray, uv, res); break;
     case ORC_PTZRayDist: orc_res_ptzray_dist(intr, extr, ray, uv, res); break;
+    case ORC_PTZRayDistDisp: orc_res_ptzray_dist_disp(intr, disp, extr, ray, uv, res); break;
     default: orc_res_ptzray_fxfy_dist(intr, extr, ray, uv, res); break;
   }
+}
+static void res2d3d(int type, const double* intr, const double* disp, const double* extr, const double* tlw, const float* uv,
+                    const double* xyz, double* res)
+{
+  if (type == ORC_PTZRayDistDisp) orc_res_reproj2d3d_disp(intr, disp, extr, tlw, uv, xyz, res);
+  else orc_res_reproj2d3d(intr, extr, tlw, uv, xyz, res);
 }
 
 /* [Ceres-1.14] numeric_diff.h NumericDiff<..., CENTRAL, ...>::EvaluateJacobianForParameterBlock:
@@ -894,18 +948,31 @@ static inline double nd_step(double xj)
 /* Evaluate one 2D-2D block: residual, Jacobian wrt the 18 block parameters [intr9 | extr6 | ... ] and ray3,
  * by central differences over ALL columns, exactly as NumericDiffCostFunction<F, CENTRAL, 2, 9, 6, 3>
  * (ptzray_optimizer.cc:60,133,197) does (37 functor calls). */
-static void block2d2d_numeric(int type, const double* cam, const double* ray, const float* uv, double* res, double* J15,
-                              double* Jray)
+static void block2d2d_numeric(int type, const double* cam, const double* disp, const double* ray, const float* uv, double* res,
+                              double* J15, double* Jray, double* Jd)
 {
-  double intr[9], extr[6], rr[3] = {ray[0], ray[1], ray[2]};
+  double intr[9], extr[6], rr[3] = {ray[0], ray[1], ray[2]}, dd[3] = {0, 0, 0};
+  if (disp) { dd[0] = disp[0]; dd[1] = disp[1]; dd[2] = disp[2]; }
   cam_to_blocks(cam, intr, extr);
-  res2d2d(type, intr, extr, rr, uv, res);
+  res2d2d(type, intr, dd, extr, rr, uv, res);
+  if (type == ORC_PTZRayDistDisp) { /* NumericDiffCostFunction<PTZRayDistDispFactor, CENTRAL, 2, 9, 3, 6, 3> (:263) */
+    double gp[2], gm[2];
+    for (int j = 0; j < 3; ++j) {
+      double x0 = dd[j], d = nd_step(x0);
+      dd[j] = x0 + d; res2d2d(type, intr, dd, extr, rr, uv, gp);
+      dd[j] = x0 - d; res2d2d(type, intr, dd, extr, rr, uv, gm);
+      dd[j] = x0;
+      double one_over = 1.0 / d; one_over /= 2;
+      Jd[j] = (gp[0] - gm[0]) * one_over;
+      Jd[3 + j] = (gp[1] - gm[1]) * one_over;
+    }
+  }
   double fp[2], fm[2];
   double J18[2][15];
   for (int j = 0; j < 9; ++j) {
     double x0 = intr[j], d = nd_step(x0);
-    intr[j] = x0 + d; res2d2d(type, intr, extr, rr, uv, fp);
-    intr[j] = x0 - d; res2d2d(type, intr, extr, rr, uv, fm);
+    intr[j] = x0 + d; res2d2d(type, intr, dd, extr, rr, uv, fp);
+    intr[j] = x0 - d; res2d2d(type, intr, dd, extr, rr, uv, fm);
     intr[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     J18[0][j] = (fp[0] - fm[0]) * one_over;
@@ -913,8 +980,8 @@ static void block2d2d_numeric(int type, const double* cam, const double* ray, co
   }
   for (int j = 0; j < 6; ++j) {
     double x0 = extr[j], d = nd_step(x0);
-    extr[j] = x0 + d; res2d2d(type, intr, extr, rr, uv, fp);
-    extr[j] = x0 - d; res2d2d(type, intr, extr, rr, uv, fm);
+    extr[j] = x0 + d; res2d2d(type, intr, dd, extr, rr, uv, fp);
+    extr[j] = x0 - d; res2d2d(type, intr, dd, extr, rr, uv, fm);
     extr[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     J18[0][9 + j] = (fp[0] - fm[0]) * one_over;
@@ -922,8 +989,8 @@ static void block2d2d_numeric(int type, const double* cam, const double* ray, co
   }
   for (int j = 0; j < 3; ++j) {
     double x0 = rr[j], d = nd_step(x0);
-    rr[j] = x0 + d; res2d2d(type, intr, extr, rr, uv, fp);
-    rr[j] = x0 - d; res2d2d(type, intr, extr, rr, uv, fm);
+    rr[j] = x0 + d; res2d2d(type, intr, dd, extr, rr, uv, fp);
+    rr[j] = x0 - d; res2d2d(type, intr, dd, extr, rr, uv, fm);
     rr[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     Jray[j] = (fp[0] - fm[0]) * one_over;
@@ -938,8 +1005,8 @@ static void block2d2d_numeric(int type, const double* cam, const double* ray, co
 
 /* closed-form version of the same block.  J15: d res / d cam15 (only columns that can be free are
  * filled: 0, 1, 4..6, 10), Jray: d res / d ray. */
-static void block2d2d_analytic(int type, const double* cam, const double* ray, const float* uv, double* res, double* J15,
-                               double* Jray)
+static void block2d2d_analytic(int type, const double* cam, const double* disp, const double* ray, const float* uv, double* res,
+                               double* J15, double* Jray, double* Jd)
 {
   memset(J15, 0, sizeof(double) * 30);
   double R[9], dR[27];
@@ -962,6 +1029,11 @@ static void block2d2d_analytic(int type, const double* cam, const double* ray, c
     res[0] = 1000000.0; res[1] = 1000000.0;
     memset(Jray, 0, sizeof(double) * 6);
     return;
+  }
+  double ddf = 0; /* d displacement / d fx */
+  if (type == ORC_PTZRayDistDisp) {
+    P[2] += disp[0] + disp[1] * fx + disp[2] * fx * fx;
+    ddf = disp[1] + 2.0 * disp[2] * fx;
   }
   double iz = 1.0 / P[2];
   double x = P[0] / P[2], y = P[1] / P[2]; /* same arithmetic as the functor */
@@ -998,6 +1070,12 @@ static void block2d2d_analytic(int type, const double* cam, const double* ray, c
     J15[10] = -fx * dk1[0];
     J15[15 + 10] = -fy * dk1[1];
   }
+  if (type == ORC_PTZRayDistDisp) { /* P.z also moves with fx; displacement block: dP.z/d(d0,d1,d2) = (1, fx, fx^2) */
+    J15[0] -= M[2] * ddf;
+    J15[15 + 0] -= M[5] * ddf;
+    const double pw[3] = {1.0, fx, fx * fx};
+    for (int k = 0; k < 3; ++k) { Jd[k] = -M[2] * pw[k]; Jd[3 + k] = -M[5] * pw[k]; }
+  }
   /* rotation: dP/dr_k = dR_k X */
   for (int k = 0; k < 3; ++k) {
     double dP[3];
@@ -1015,34 +1093,47 @@ static void block2d2d_analytic(int type, const double* cam, const double* ray, c
 }
 
 /* 2D-3D block (Reproj2d3dFactor, NumericDiffCostFunction<..., 2, 9, 6, 6>, ptzray_optimizer.cc:330) */
-static void block2d3d_numeric(const double* cam, const double* tlw, const float* uv, const double* xyz, double* res,
-                              double* J15, double* Jt)
+static void block2d3d_numeric(int type, const double* cam, const double* disp, const double* tlw, const float* uv,
+                              const double* xyz, double* res, double* J15, double* Jt, double* Jd)
 {
-  double intr[9], extr[6], tt[6];
+  double intr[9], extr[6], tt[6], dd[3] = {0, 0, 0};
+  if (disp) { dd[0] = disp[0]; dd[1] = disp[1]; dd[2] = disp[2]; }
   cam_to_blocks(cam, intr, extr);
   memcpy(tt, tlw, sizeof(tt));
-  orc_res_reproj2d3d(intr, extr, tt, uv, xyz, res);
+  res2d3d(type, intr, dd, extr, tt, uv, xyz, res);
+  if (type == ORC_PTZRayDistDisp) { /* NumericDiffCostFunction<Reproj2d3dDispFactor, CENTRAL, 2, 9, 3, 6, 6> (:400) */
+    double gp[2], gm[2];
+    for (int j = 0; j < 3; ++j) {
+      double x0 = dd[j], d = nd_step(x0);
+      dd[j] = x0 + d; res2d3d(type, intr, dd, extr, tt, uv, xyz, gp);
+      dd[j] = x0 - d; res2d3d(type, intr, dd, extr, tt, uv, xyz, gm);
+      dd[j] = x0;
+      double one_over = 1.0 / d; one_over /= 2;
+      Jd[j] = (gp[0] - gm[0]) * one_over;
+      Jd[3 + j] = (gp[1] - gm[1]) * one_over;
+    }
+  }
   double fp[2], fm[2], J18[2][15];
   for (int j = 0; j < 9; ++j) {
     double x0 = intr[j], d = nd_step(x0);
-    intr[j] = x0 + d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fp);
-    intr[j] = x0 - d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fm);
+    intr[j] = x0 + d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fp);
+    intr[j] = x0 - d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fm);
     intr[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     J18[0][j] = (fp[0] - fm[0]) * one_over; J18[1][j] = (fp[1] - fm[1]) * one_over;
   }
   for (int j = 0; j < 6; ++j) {
     double x0 = extr[j], d = nd_step(x0);
-    extr[j] = x0 + d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fp);
-    extr[j] = x0 - d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fm);
+    extr[j] = x0 + d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fp);
+    extr[j] = x0 - d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fm);
     extr[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     J18[0][9 + j] = (fp[0] - fm[0]) * one_over; J18[1][9 + j] = (fp[1] - fm[1]) * one_over;
   }
   for (int j = 0; j < 6; ++j) {
     double x0 = tt[j], d = nd_step(x0);
-    tt[j] = x0 + d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fp);
-    tt[j] = x0 - d; orc_res_reproj2d3d(intr, extr, tt, uv, xyz, fm);
+    tt[j] = x0 + d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fp);
+    tt[j] = x0 - d; res2d3d(type, intr, dd, extr, tt, uv, xyz, fm);
     tt[j] = x0;
     double one_over = 1.0 / d; one_over /= 2;
     Jt[j] = (fp[0] - fm[0]) * one_over; Jt[6 + j] = (fp[1] - fm[1]) * one_over;
@@ -1054,8 +1145,8 @@ static void block2d3d_numeric(const double* cam, const double* tlw, const float*
   }
 }
 
-static void block2d3d_analytic(const double* cam, const double* tlw, const float* uv, const double* xyz, double* res,
-                               double* J15, double* Jt)
+static void block2d3d_analytic(int type, const double* cam, const double* disp, const double* tlw, const float* uv,
+                               const double* xyz, double* res, double* J15, double* Jt, double* Jd)
 {
   memset(J15, 0, sizeof(double) * 30);
   double R[9], dR[27], Rlw[9], dRlw[27];
@@ -1066,6 +1157,11 @@ static void block2d3d_analytic(const double* cam, const double* tlw, const float
   mat3_mul_vec(Rlw, xyz, Xl);
   Xl[0] += tlw[3]; Xl[1] += tlw[4]; Xl[2] += tlw[5];
   mat3_mul_vec(R, Xl, P);
+  double ddf = 0;
+  if (type == ORC_PTZRayDistDisp) {
+    P[2] += disp[0] + disp[1] * fx + disp[2] * fx * fx;
+    ddf = disp[1] + 2.0 * disp[2] * fx;
+  }
   double iz = 1.0 / P[2], x = P[0] / P[2], y = P[1] / P[2]; /* same arithmetic as the functor */
   double dpi[6] = {iz, 0, -x * iz, 0, iz, -y * iz};
   double xd, yd, B[4], dk1[2];
@@ -1082,6 +1178,12 @@ static void block2d3d_analytic(const double* cam, const double* tlw, const float
   J15[15 + 1] = -yd;
   J15[10] = -fx * dk1[0];
   J15[15 + 10] = -fy * dk1[1];
+  if (type == ORC_PTZRayDistDisp) {
+    J15[0] -= M[2] * ddf;
+    J15[15 + 0] -= M[5] * ddf;
+    const double pw[3] = {1.0, fx, fx * fx};
+    for (int k = 0; k < 3; ++k) { Jd[k] = -M[2] * pw[k]; Jd[3 + k] = -M[5] * pw[k]; }
+  }
   for (int k = 0; k < 3; ++k) {
     double dP[3];
     mat3_mul_vec(dR + 9 * k, Xl, dP);
@@ -1099,18 +1201,24 @@ static void block2d3d_analytic(const double* cam, const double* tlw, const float
   }
 }
 
-int32_t orc_ba_cam_free_dim(int32_t factor_type) { return factor_type == ORC_PTZRay ? 5 : 6; }
+int32_t orc_ba_cam_free_dim(int32_t factor_type) { return factor_type == ORC_PTZRay ? 5 : (factor_type == ORC_PTZRayDistDisp ? 9 : 6); }
 
 static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
 {
   memset(c, 0, sizeof(*c));
-  if (p->factor_type == ORC_PTZRayDistDisp) return 1; /* displacement block: not restated (dead from the CLI) */
   c->p = p;
   c->jac_mode = jac_mode;
   /* SubsetParameterization (ptzray_optimizer.cc:863,870,881): free intr {fx,fy} (+k1 for *Dist*), free extr rvec */
   if (p->factor_type == ORC_PTZRay) {
     c->ncf = 5;
     int f[5] = {0, 1, 4, 5, 6};
+    memcpy(c->cfree, f, sizeof(f));
+  }
+  else if (p->factor_type == ORC_PTZRayDistDisp) {
+    /* intrinsics {fx, fy, k1} (:868-871), rvec, and the displacement block disp_param_ (no parameterization: all 3 free) */
+    c->ncf = 9;
+    c->has_disp = 1;
+    int f[9] = {0, 1, 10, 4, 5, 6, CFREE_DISP, CFREE_DISP + 1, CFREE_DISP + 2};
     memcpy(c->cfree, f, sizeof(f));
   }
   else {
@@ -1121,7 +1229,7 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
   c->has_tlw = p->n_obs3d > 0;
   c->n_cs = c->ncf * p->n_cam + 6 * c->has_tlw;
   c->n_free = c->n_cs + 3 * p->n_ray;
-  c->n_amb = 15 * p->n_cam + 3 * p->n_ray + 6;
+  c->n_amb = 15 * p->n_cam + 3 * p->n_ray + 6 + 3;
   c->cam_active = (uint8_t*)calloc((size_t)p->n_cam + 1, 1);
   for (int64_t a = 0; a < p->n_obs; ++a) {
     if (p->obs_cam[a] < 0 || p->obs_cam[a] >= p->n_cam || p->obs_ray[a] < 0 || p->obs_ray[a] >= p->n_ray) return 1;
@@ -1143,7 +1251,8 @@ static int ba_ctx_init(ba_ctx* c, const orc_ba_problem* p, int jac_mode)
     c->first_of_group[i] = first;
     for (int k = 0; k < c->ncf; ++k) {
       int is_intr = c->cfree[k] < 4 || c->cfree[k] >= 10;
-      c->cmap[i * c->ncf + k] = (is_intr ? first : i) * c->ncf + k;
+      if (c->cfree[k] >= CFREE_DISP) c->cmap[i * c->ncf + k] = k; /* the one displacement block: slots of camera 0 */
+      else c->cmap[i * c->ncf + k] = (is_intr ? first : i) * c->ncf + k;
     }
   }
   /* the shared block is in the problem if any member has residuals; it is counted once, at its first active member */
@@ -1186,7 +1295,7 @@ static double ba_cost(void* vc, const double* x)
   for (int64_t a = 0; a < p->n_obs; ++a) {
     double intr[9], extr[6], res[2];
     cam_to_blocks(X_cam(c, x, p->obs_cam[a]), intr, extr);
-    res2d2d(p->factor_type, intr, extr, X_ray(c, x, p->obs_ray[a]), p->obs_uv + 2 * a, res);
+    res2d2d(p->factor_type, intr, X_disp(c, x), extr, X_ray(c, x, p->obs_ray[a]), p->obs_uv + 2 * a, res);
     /* ScaledLoss(NULL, w): cost = 0.5 * w * |r|^2  (ptzray_optimizer.cc:805-806) */
     c->cterm[a] = 0.5 * (p->ray_weight[p->obs_ray[a]] * (res[0] * res[0] + res[1] * res[1]));
   }
@@ -1194,7 +1303,7 @@ static double ba_cost(void* vc, const double* x)
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     double intr[9], extr[6], res[2];
     cam_to_blocks(X_cam(c, x, p->obs3d_cam[a]), intr, extr);
-    orc_res_reproj2d3d(intr, extr, X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res);
+    res2d3d(p->factor_type, intr, X_disp(c, x), extr, X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res);
     cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
   }
   return cost;
@@ -1208,35 +1317,39 @@ static double ba_linearize(void* vc, const double* x, double* g)
   double cost = 0;
 #pragma omp parallel for schedule(static)
   for (int64_t a = 0; a < p->n_obs; ++a) {
-    double res[2], J15[30], Jray[6];
+    double res[2], J15[30], Jray[6], Jd[6] = {0, 0, 0, 0, 0, 0};
     const double* cam = X_cam(c, x, p->obs_cam[a]);
     const double* ray = X_ray(c, x, p->obs_ray[a]);
-    if (c->jac_mode == ORC_JAC_NUMERIC) block2d2d_numeric(p->factor_type, cam, ray, p->obs_uv + 2 * a, res, J15, Jray);
-    else block2d2d_analytic(p->factor_type, cam, ray, p->obs_uv + 2 * a, res, J15, Jray);
+    if (c->jac_mode == ORC_JAC_NUMERIC) block2d2d_numeric(p->factor_type, cam, X_disp(c, x), ray, p->obs_uv + 2 * a, res, J15, Jray, Jd);
+    else block2d2d_analytic(p->factor_type, cam, X_disp(c, x), ray, p->obs_uv + 2 * a, res, J15, Jray, Jd);
     double w = p->ray_weight[p->obs_ray[a]];
     double sw = sqrt(w); /* Corrector: residuals, jacobians *= sqrt(rho') */
     c->cterm[a] = 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
     c->r[2 * a] = res[0] * sw;
     c->r[2 * a + 1] = res[1] * sw;
     for (int k = 0; k < ncf; ++k) {
-      c->Jc[(2 * a) * ncf + k] = J15[c->cfree[k]] * sw;
-      c->Jc[(2 * a + 1) * ncf + k] = J15[15 + c->cfree[k]] * sw;
+      const int f = c->cfree[k];
+      c->Jc[(2 * a) * ncf + k] = (f >= CFREE_DISP ? Jd[f - CFREE_DISP] : J15[f]) * sw;
+      c->Jc[(2 * a + 1) * ncf + k] = (f >= CFREE_DISP ? Jd[3 + f - CFREE_DISP] : J15[15 + f]) * sw;
     }
     for (int k = 0; k < 6; ++k) c->Jr[6 * a + k] = Jray[k] * sw;
   }
   for (int64_t a = 0; a < p->n_obs; ++a) cost += c->cterm[a];
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
-    double res[2], J15[30], Jt[12];
+    double res[2], J15[30], Jt[12], Jd[6] = {0, 0, 0, 0, 0, 0};
     const double* cam = X_cam(c, x, p->obs3d_cam[a]);
-    if (c->jac_mode == ORC_JAC_NUMERIC) block2d3d_numeric(cam, X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res, J15, Jt);
-    else block2d3d_analytic(cam, X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res, J15, Jt);
+    if (c->jac_mode == ORC_JAC_NUMERIC)
+      block2d3d_numeric(p->factor_type, cam, X_disp(c, x), X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res, J15, Jt, Jd);
+    else
+      block2d3d_analytic(p->factor_type, cam, X_disp(c, x), X_tlw(c, x), p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res, J15, Jt, Jd);
     cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
     c->r3[2 * a] = res[0];
     c->r3[2 * a + 1] = res[1];
     for (int k = 0; k < ncf; ++k) {
       /* PTZRay keeps k1 constant; for *Dist* types k1 (cfree[2] = 10) is free */
-      c->Jc3[(2 * a) * ncf + k] = J15[c->cfree[k]];
-      c->Jc3[(2 * a + 1) * ncf + k] = J15[15 + c->cfree[k]];
+      const int f = c->cfree[k];
+      c->Jc3[(2 * a) * ncf + k] = f >= CFREE_DISP ? Jd[f - CFREE_DISP] : J15[f];
+      c->Jc3[(2 * a + 1) * ncf + k] = f >= CFREE_DISP ? Jd[3 + f - CFREE_DISP] : J15[15 + f];
     }
     memcpy(c->Jt3 + 12 * (size_t)a, Jt, sizeof(double) * 12);
   }
@@ -1494,7 +1607,12 @@ static void ba_plus(void* vc, const double* x, const double* delta, double* xo)
   const int ncf = c->ncf;
   memcpy(xo, x, sizeof(double) * (size_t)c->n_amb);
   for (int i = 0; i < p->n_cam; ++i)
-    for (int k = 0; k < ncf; ++k) xo[15 * (size_t)i + c->cfree[k]] += delta[c->cmap[i * ncf + k]];
+    for (int k = 0; k < ncf; ++k)
+      if (c->cfree[k] < CFREE_DISP) xo[15 * (size_t)i + c->cfree[k]] += delta[c->cmap[i * ncf + k]];
+  if (c->has_disp)
+    for (int k = 0; k < ncf; ++k)
+      if (c->cfree[k] >= CFREE_DISP)
+        xo[15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + 6 + (c->cfree[k] - CFREE_DISP)] += delta[c->cmap[k]];
   if (c->has_tlw)
     for (int k = 0; k < 6; ++k) xo[15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + k] += delta[ncf * p->n_cam + k];
   for (int j = 0; j < 3 * p->n_ray; ++j) xo[15 * (size_t)p->n_cam + j] += delta[c->n_cs + j];
@@ -1526,6 +1644,11 @@ static double ba_diff_norm(void* vc, const double* a, const double* b)
       double d = a[o + 3 * (size_t)p->n_ray + k] - (b ? b[o + 3 * (size_t)p->n_ray + k] : 0.0);
       acc += d * d;
     }
+  if (c->has_disp)
+    for (int k = 0; k < 3; ++k) {
+      double d = a[o + 3 * (size_t)p->n_ray + 6 + k] - (b ? b[o + 3 * (size_t)p->n_ray + 6 + k] : 0.0);
+      acc += d * d;
+    }
   return sqrt(acc);
 }
 static double ba_x_norm(void* vc, const double* x) { return ba_diff_norm(vc, x, NULL); }
@@ -1549,6 +1672,12 @@ static void set_threads(int n)
 int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* tlw, const orc_lm_options* o,
                      orc_lm_summary* s, orc_lm_trace* trace)
 {
+  return orc_ba_solve_disp(p, cam, ray, tlw, NULL, o, s, trace);
+}
+
+int32_t orc_ba_solve_disp(const orc_ba_problem* p, double* cam, double* ray, double* tlw, double* disp, const orc_lm_options* o,
+                          orc_lm_summary* s, orc_lm_trace* trace)
+{
   ba_ctx c;
   if (ba_ctx_init(&c, p, o->jacobian_mode)) { ba_ctx_free(&c); return 1; }
   set_threads(o->num_threads);
@@ -1563,6 +1692,7 @@ int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* 
   }
   memcpy(x + 15 * (size_t)p->n_cam, ray, sizeof(double) * 3 * (size_t)p->n_ray);
   memcpy(x + 15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray, tlw, sizeof(double) * 6);
+  for (int k = 0; k < 3; ++k) x[15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + 6 + k] = disp ? disp[k] : 0.0; /* :655 */
   lm_problem P = {c.n_free, c.n_amb, &c, ba_cost, ba_linearize, ba_col_sqnorm, ba_scale_cols, ba_solve,
                   ba_model_cost_change, ba_plus, ba_x_norm, ba_diff_norm, ba_grad_max};
   lm_minimize(&P, x, o, s, trace);
@@ -1570,6 +1700,7 @@ int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* 
   memcpy(cam, x, sizeof(double) * 15 * (size_t)p->n_cam);
   memcpy(ray, x + 15 * (size_t)p->n_cam, sizeof(double) * 3 * (size_t)p->n_ray);
   memcpy(tlw, x + 15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray, sizeof(double) * 6);
+  if (disp) memcpy(disp, x + 15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + 6, sizeof(double) * 3);
   free(x);
   ba_ctx_free(&c);
   return 0;
@@ -1577,21 +1708,36 @@ int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* 
 
 int32_t orc_ba_residuals(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw, double* res)
 {
+  return orc_ba_residuals_disp(p, cam, ray, tlw, NULL, res);
+}
+
+int32_t orc_ba_residuals_disp(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
+                              const double* disp, double* res)
+{
+  const double zero3[3] = {0, 0, 0};
+  if (!disp) disp = zero3;
   for (int64_t a = 0; a < p->n_obs; ++a) {
     double intr[9], extr[6];
     cam_to_blocks(cam + 15 * (size_t)p->obs_cam[a], intr, extr);
-    res2d2d(p->factor_type, intr, extr, ray + 3 * (size_t)p->obs_ray[a], p->obs_uv + 2 * a, res + 2 * a);
+    res2d2d(p->factor_type, intr, disp, extr, ray + 3 * (size_t)p->obs_ray[a], p->obs_uv + 2 * a, res + 2 * a);
   }
   for (int32_t a = 0; a < p->n_obs3d; ++a) {
     double intr[9], extr[6];
     cam_to_blocks(cam + 15 * (size_t)p->obs3d_cam[a], intr, extr);
-    orc_res_reproj2d3d(intr, extr, tlw, p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res + 2 * p->n_obs + 2 * a);
+    res2d3d(p->factor_type, intr, disp, extr, tlw, p->obs3d_uv + 2 * a, p->obs3d_xyz + 3 * a, res + 2 * p->n_obs + 2 * a);
   }
   return 0;
 }
 
 int32_t orc_ba_linearize(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
                          int32_t jacobian_mode, double* cost, double* g_c, double* U, double* g_r, double* V, double* W)
+{
+  return orc_ba_linearize_disp(p, cam, ray, tlw, NULL, jacobian_mode, cost, g_c, U, g_r, V, W);
+}
+
+int32_t orc_ba_linearize_disp(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
+                              const double* disp, int32_t jacobian_mode, double* cost, double* g_c, double* U, double* g_r,
+                              double* V, double* W)
 {
   ba_ctx c;
   if (ba_ctx_init(&c, p, jacobian_mode)) { ba_ctx_free(&c); return 1; }
@@ -1600,6 +1746,7 @@ int32_t orc_ba_linearize(const orc_ba_problem* p, const double* cam, const doubl
   memcpy(x, cam, sizeof(double) * 15 * (size_t)p->n_cam);
   memcpy(x + 15 * (size_t)p->n_cam, ray, sizeof(double) * 3 * (size_t)p->n_ray);
   memcpy(x + 15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray, tlw, sizeof(double) * 6);
+  for (int k = 0; k < 3; ++k) x[15 * (size_t)p->n_cam + 3 * (size_t)p->n_ray + 6 + k] = disp ? disp[k] : 0.0;
   double* g = (double*)malloc(sizeof(double) * (size_t)c.n_free);
   double cst = ba_linearize(&c, x, g);
   if (cost) *cost = cst;

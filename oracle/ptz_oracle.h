@@ -98,6 +98,9 @@ void orc_res_ptzray(const double* intr, const double* extr, const double* ray, c
 void orc_res_ptzray_dist(const double* intr, const double* extr, const double* ray, const float* uv, double* res);     /* :65-129 */
 void orc_res_ptzray_fxfy_dist(const double* intr, const double* extr, const double* ray, const float* uv, double* res);/* :138-193 */
 void orc_res_reproj2d3d(const double* intr, const double* extr, const double* tlw, const float* uv, const double* xyz, double* res); /* :268-326 */
+/* displacement variants: disp[3] = (d0, d1, d2), camera-frame z += d0 + d1 fx + d2 fx^2 */
+void orc_res_ptzray_dist_disp(const double* intr, const double* disp, const double* extr, const double* ray, const float* uv, double* res); /* :195-259 */
+void orc_res_reproj2d3d_disp(const double* intr, const double* disp, const double* extr, const double* tlw, const float* uv, const double* xyz, double* res); /* :334-396 */
 /* cam1 = reference camera in its own local frame (R = I, t = 0): k1[4] = {fx,fy,cx,cy}, dist1[5] in the
  * reference's Camera layout (k1,k2,k3,p1,p2).  cam[15] = current camera vector. */
 void orc_res_2d2d(const double* cam, const double* k1, const float* uv1, const float* uv2, double* res);               /* krt_optimizer.cc:22-43 */
@@ -139,6 +142,13 @@ typedef struct {
 int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* tlw, const orc_lm_options* o,
                      orc_lm_summary* s, orc_lm_trace* trace);
 
+/* The same with the displacement block of PTZRayDistDisp (disp_param_, ptzray_optimizer.cc:655: starts at zero when
+ * disp = NULL; in/out otherwise).  For the other factor types disp is carried along untouched. */
+int32_t orc_ba_solve_disp(const orc_ba_problem* p, double* cam, double* ray, double* tlw, double* disp, const orc_lm_options* o,
+                          orc_lm_summary* s, orc_lm_trace* trace);
+int32_t orc_ba_residuals_disp(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
+                              const double* disp, double* res);
+
 /* One linearisation at the given point, for kernel parity tests.  Outputs (any may be NULL):
  *  cost; per-camera free-parameter gradient g_c[ncf*n_cam] and diagonal blocks U[ncf*ncf*n_cam];
  *  per-ray g_r[3*n_ray], V[9*n_ray]; per-observation W[ncf*3*n_obs] (camera x ray coupling).
@@ -146,6 +156,11 @@ int32_t orc_ba_solve(const orc_ba_problem* p, double* cam, double* ray, double* 
 int32_t orc_ba_cam_free_dim(int32_t factor_type);
 int32_t orc_ba_linearize(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
                          int32_t jacobian_mode, double* cost, double* g_c, double* U, double* g_r, double* V, double* W);
+/* the same at a given displacement block (PTZRayDistDisp: ncf = 9, the last three camera columns are the block's columns
+ * d res / d (d0, d1, d2), identical parameter for every camera) */
+int32_t orc_ba_linearize_disp(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw,
+                              const double* disp, int32_t jacobian_mode, double* cost, double* g_c, double* U, double* g_r,
+                              double* V, double* W);
 /* residuals only: res[2*n_obs + 2*n_obs3d], unweighted */
 int32_t orc_ba_residuals(const orc_ba_problem* p, const double* cam, const double* ray, const double* tlw, double* res);
 
