@@ -231,6 +231,39 @@ def test_ba_c2_parity(pkg, orc):
     assert np.abs(cam[:, 0] - sc.cam_gt[:, 0]).mean() < 2.0
 
 
+@pytest.mark.parametrize("ftype", [0, 1, 2])
+def test_ba_varied_small_scenes_vs_oracle(pkg, orc, ftype):
+    """A spread of small problems in one ragged batch -- 6 to 17 views, 30 to 70 observations per view, pixel noise 0.3 to
+    2.5 px, initial rotations off by up to 6 degrees (sigma), initial focal 1000 to 6000 px, a few gross outliers -- so that
+    rejected steps, long and short runs and (for PTZRayDist) the behind-the-camera branch all occur.  Per scene: the LM
+    bookkeeping of the oracle (closed-form Jacobians, same arithmetic) step for step, final cost to 1e-8."""
+    rng = np.random.default_rng(100 + ftype)
+    scenes = []
+    for i in range(40):
+        sc = pkg.synth.make_scene(300 + 40 * ftype + i, int(rng.integers(6, 18)), int(rng.integers(30, 71)), factor_type=ftype,
+                                  noise_px=float(rng.uniform(0.3, 2.5)), init_rot_sigma_deg=float(rng.uniform(0.2, 6.0)),
+                                  init_focal=float(rng.uniform(1000, 6000)))
+        if i % 5 == 0:  # gross outliers
+            sc.obs_uv = sc.obs_uv.copy()
+            bad = rng.choice(sc.n_obs, size=max(1, sc.n_obs // 60), replace=False)
+            sc.obs_uv[bad] += rng.uniform(-60, 60, (len(bad), 2)).astype(np.float32)
+        if ftype == 2:
+            sc.cam_init = sc.cam_init.copy(); sc.cam_init[:, 1] *= 1.0 + float(rng.uniform(-0.03, 0.03))
+        scenes.append(sc)
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    n_rejected = 0
+    for i, sc in enumerate(scenes):
+        ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_ANALYTIC, num_threads=4)
+        tag = f"scene {i} ({sc.n_cam} views)"
+        assert summ[i]["termination_type"] == osumm["termination_type"], tag
+        assert summ[i]["num_iterations"] == osumm["num_iterations"], tag
+        assert summ[i]["num_successful_steps"] == osumm["num_successful_steps"], tag
+        assert abs(summ[i]["final_cost"] - osumm["final_cost"]) <= 1e-8 * osumm["final_cost"], tag
+        assert _rel(cams[i][:, 0], ocam[:, 0]) < 1e-6, tag
+        n_rejected += summ[i]["num_unsuccessful_steps"]
+    assert n_rejected > 0  # the batch does exercise StepRejected
+
+
 def test_ba_batch_matches_single(pkg, scene_c1):
     """A batch of different scenes gives, per scene, bit-identical results to solving it alone
     (fixed-order reductions; scenes never interact)."""
