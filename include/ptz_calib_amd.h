@@ -143,7 +143,8 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries);
 int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw);
 /* Device time of the last ptz_ba_batch_solve in milliseconds (HIP events on the batch's stream),
  * and, per kernel family, the accumulated device time and launch count when profiling was enabled
- * with ptz_ba_batch_set_profiling(b, 1) (serialises the stream between kernels). */
+ * with ptz_ba_batch_set_profiling(b, 1) (serialises the stream between kernels and runs the batch as ONE scene group,
+ * so that no other group's kernels share the device while a family is being timed). */
 int32_t ptz_ba_batch_last_solve_ms(const ptz_ba_batch* b, double* ms);
 int32_t ptz_ba_batch_set_profiling(ptz_ba_batch* b, int32_t enable);
 #define PTZ_PROF_SLOTS 16

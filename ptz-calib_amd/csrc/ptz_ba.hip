@@ -1406,7 +1406,8 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
 static void make_groups(ptz_ba_batch* b)
 {
   const int B = b->n_scene;
-  const int G = std::max(1, std::min(b->n_group, B));
+  // per-family timings are only meaningful when no other group's kernels share the device: profiling runs one group
+  const int G = b->profiling ? 1 : std::max(1, std::min(b->n_group, B));
   b->group_first.clear(); b->group_count.clear(); b->dg.clear();
   for (int g = 0; g < G; ++g) {
     const int lo = (int)((int64_t)B * g / G), hi = (int)((int64_t)B * (g + 1) / G);
