@@ -1733,7 +1733,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   const bool dbg_t = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tc0 = now_ms();
-  double tc1 = 0, tc2 = 0, tc3 = 0;
+  double tc1 = 0, tc2 = 0, tc3 = 0, ts_obs = 0, ts_ent = 0;
   ptz_lm_options o;
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
@@ -1772,6 +1772,13 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<float2> h_o3uv;
   std::vector<int> h_o3cam;
   std::vector<int> h_grpptr, h_grpmem;
+  {
+    size_t to = 0, tr = 0, tc = 0;
+    for (int i = 0; i < n; ++i) { to += (size_t)problems[i].n_obs; tr += (size_t)problems[i].n_ray; tc += (size_t)problems[i].n_cam; }
+    h_uv.reserve(to); h_cam.reserve(to); h_ray.reserve(to); h_camobs.reserve(to); h_wpos.reserve(to); h_camray.reserve(to);
+    h_rayptr.reserve(tr + n); h_w.reserve(tr); h_camptr.reserve(tc + n); h_campair.reserve(tc + n);
+    h_ent.reserve(to * 4);
+  }
   std::vector<unsigned char> h_camflag;
   int total_grp = 0;
   bool any_shared = false;
@@ -1798,6 +1805,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     }
     b->total_o3 += p.n_obs3d;
     // observations, ray ranges
+    const double tsa = now_ms();
     const int obase = s.obs_off;
     std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
     for (int64_t a = 0; a < p.n_obs; ++a) {
@@ -1827,6 +1835,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       }
       for (int c = 0; c <= p.n_cam; ++c) h_camptr.push_back(obase + cnt_cam[c]);
     }
+    const double tsb = now_ms();
+    ts_obs += tsb - tsa;
     // camera-pair entry lists (off-diagonal blocks): for every ray, every (a, b) with cam(a) > cam(b);
     // a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur)
     {
@@ -1837,19 +1847,43 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         for (int c = 0; c < p.n_cam; ++c) b->max_cam_obs = std::max(b->max_cam_obs, fill[c]);
         for (int64_t a = 0; a < p.n_obs; ++a) h_wpos.push_back(obase + cnt_cam[p.obs_cam[a]] + pos[a]);
       }
-      // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable)
+      // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
+      // One pass over the rays lists the (a, b) pairs with cam(a) > cam(b) in ray order and counts them per camera pair;
+      // the fill pass then runs over that flat list only.  Observations of a track come camera-ascending from the packing
+      // (track asc, image asc: ptzray_optimizer.cc:801-850), in which case the pairs are simply (a, b < a); any other order
+      // takes the general double loop.
       const size_t ncc = (size_t)p.n_cam * p.n_cam;
       std::vector<int> pair_cnt(ncc, 0);
-      int64_t n_ent = 0;
-      for (int j = 0; j < p.n_ray; ++j)
-        for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
-          for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
-            const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
-            if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
-            if (ci <= cj) continue;
-            ++pair_cnt[(size_t)ci * p.n_cam + cj];
-            ++n_ent;
+      std::vector<int> ea, ebq;
+      ea.reserve((size_t)p.n_obs * 4);
+      ebq.reserve((size_t)p.n_obs * 4);
+      for (int j = 0; j < p.n_ray; ++j) {
+        const int r0 = cnt_ray[j], r1 = cnt_ray[j + 1];
+        bool ascending = true;
+        for (int a = r0 + 1; a < r1; ++a) ascending &= p.obs_cam[a] > p.obs_cam[a - 1];
+        if (ascending) {
+          for (int a = r0 + 1; a < r1; ++a) {
+            const size_t row = (size_t)p.obs_cam[a] * p.n_cam;
+            for (int bb = r0; bb < a; ++bb) {
+              ++pair_cnt[row + p.obs_cam[bb]];
+              ea.push_back(a);
+              ebq.push_back(bb);
+            }
           }
+        }
+        else {
+          for (int a = r0; a < r1; ++a)
+            for (int bb = r0; bb < r1; ++bb) {
+              const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
+              if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
+              if (ci <= cj) continue;
+              ++pair_cnt[(size_t)ci * p.n_cam + cj];
+              ea.push_back(a);
+              ebq.push_back(bb);
+            }
+        }
+      }
+      const int64_t n_ent = (int64_t)ea.size();
       if ((int64_t)b->total_ent + n_ent > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
       int npair = 0;
       std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
@@ -1874,15 +1908,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       {
         const size_t ebase = h_ent.size();
         h_ent.resize(ebase + (size_t)n_ent);
-        for (int j = 0; j < p.n_ray; ++j)
-          for (int a = cnt_ray[j]; a < cnt_ray[j + 1]; ++a)
-            for (int bb = cnt_ray[j]; bb < cnt_ray[j + 1]; ++bb) {
-              const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
-              if (ci <= cj) continue;
-              const int slot = pair_fill[(size_t)ci * p.n_cam + cj]++;
-              h_ent[ebase + slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
-            }
+        for (int64_t e = 0; e < n_ent; ++e) {
+          const int a = ea[e], bb = ebq[e];
+          const int cj = p.obs_cam[bb];
+          const int slot = pair_fill[(size_t)p.obs_cam[a] * p.n_cam + cj]++;
+          h_ent[ebase + slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
+        }
       }
+      ts_ent += now_ms() - tsb;
       const int64_t n_keys = n_ent;
       // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
       cam_first[p.n_cam] = npair;
@@ -2123,7 +2156,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
 #undef PTZ_SET_ATTR
   }
   tc3 = now_ms();
-  if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms, uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, tc2 - tc1, tc3 - tc2);
+  if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms (observations %.2f, pair entries %.2f), uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, ts_obs, ts_ent, tc2 - tc1, tc3 - tc2);
   *out = b;
   return PTZ_OK;
 }
