@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ptz_common.h"
@@ -2144,16 +2145,32 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CBS);
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
+  if (eval_smem > 160 * 1024 || lin_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
   {
-    const int t = type + 3 * has3d;  // Dims<TYPE>
-#define PTZ_SET_ATTR(T)                                                                                             \
-    if (t == T) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)k_schur<T>, hipFuncAttributeMaxDynamicSharedMemorySize, schur_smem);   \
-      (void)hipFuncSetAttribute((const void*)k_eval<T>, hipFuncAttributeMaxDynamicSharedMemorySize, eval_smem);     \
-      (void)hipFuncSetAttribute((const void*)k_lin_ray<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lin_smem);   \
-    }
-    PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
+    // The cap on dynamic LDS is a property of the kernel, not of a batch: raise it to the hardware limit once per device
+    // and instantiation, so that batches of different sizes can live side by side (a per-batch value would let a small
+    // batch created later lower the cap under a large one).
+    static std::mutex attr_mu;
+    static std::vector<char> attr_done;
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if ((int)attr_done.size() <= o.device_id) attr_done.resize(o.device_id + 1, 0);
+    if (!attr_done[o.device_id]) {
+      bool attr_ok = true;
+      auto raise_cap = [&](const void* fn) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { attr_ok = false; return; }
+        const int cap = 160 * 1024 - (int)fa.sharedSizeBytes;  // the statically declared part counts against the same 160 KB
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) attr_ok = false;
+      };
+#define PTZ_SET_ATTR(T)                        \
+      raise_cap((const void*)k_schur<T>);      \
+      raise_cap((const void*)k_eval<T>);       \
+      raise_cap((const void*)k_lin_ray<T>);
+      PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
 #undef PTZ_SET_ATTR
+      if (!attr_ok) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+      attr_done[o.device_id] = 1;
+    }
   }
   tc3 = now_ms();
   if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms (observations %.2f, pair entries %.2f), uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, ts_obs, ts_ent, tc2 - tc1, tc3 - tc2);

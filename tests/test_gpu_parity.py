@@ -264,6 +264,21 @@ def test_ba_varied_small_scenes_vs_oracle(pkg, orc, ftype):
     assert n_rejected > 0  # the batch does exercise StepRejected
 
 
+def test_ba_batches_of_different_size_side_by_side(pkg):
+    """A large batch (camera tables above the default 64 KB of dynamic LDS) keeps working after a small one was created and
+    solved next to it: the dynamic-LDS cap belongs to the kernel, not to the batch created last."""
+    big = pkg.synth.make_scene(1, 200, 120)
+    small = pkg.synth.make_scene(2, 12, 60)
+    bb = pkg.api.BaBatch([big]); bb.set_state(); s1 = bb.solve(); c1, _ = bb.get_state()
+    bs = pkg.api.BaBatch([small]); bs.set_state(); t1 = bs.solve()
+    s2 = bb.solve(); c2, _ = bb.get_state()
+    t2 = bs.solve()
+    assert s1[0]["termination_type"] == 0 and s2[0]["num_iterations"] == s1[0]["num_iterations"] and s2[0]["final_cost"] == s1[0]["final_cost"]
+    assert np.array_equal(c1[0], c2[0])
+    assert t1[0]["final_cost"] == t2[0]["final_cost"]
+    bb.close(); bs.close()
+
+
 def test_ba_batch_matches_single(pkg, scene_c1):
     """A batch of different scenes gives, per scene, bit-identical results to solving it alone
     (fixed-order reductions; scenes never interact)."""
