@@ -1569,6 +1569,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   b->stream = s0;
   PTZ_HIP_TRY(hipEventRecord(b->ev1, s0));
   PTZ_HIP_TRY(hipStreamSynchronize(s0));
+  PTZ_HIP_TRY(hipGetLastError());  // a kernel launch that was refused (resources, arguments) must not pass for a solve
   float ms = 0;
   (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
   b->last_ms = ms;
@@ -2267,6 +2268,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
   PTZ_HIP_TRY(hipSetDevice(b->device));
   hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), 0, b->stream, b->d, b->cam0, b->ray0);
   PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
+  PTZ_HIP_TRY(hipGetLastError());
   return PTZ_OK;
 }
 
@@ -2294,6 +2296,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     default: enqueue_linearize<5>(b); break;
   }
   PTZ_HIP_TRY(hipStreamSynchronize(st));
+  PTZ_HIP_TRY(hipGetLastError());
   const SceneDev& s = b->scenes[index];
   if (cost) {
     std::vector<double> c(s.n_cam);

@@ -502,6 +502,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost, h.st));
   PTZ_HIP_TRY(hipStreamSynchronize(h.st));
+  PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
   float ms = 0;
   (void)hipEventElapsedTime(&ms, h.e0, h.e1);
   if (device_ms) *device_ms = ms;
