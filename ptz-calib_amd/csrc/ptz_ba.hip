@@ -241,7 +241,8 @@ __device__ __forceinline__ void stage_rows(const double* __restrict__ src, doubl
 
 // ---- lin_ray: per-ray linearisation ---------------------------------------------------------------------
 // thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
-// Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r, store W_a = Jc^T Jr.
+// Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r.  (The W_a = Jc^T Jr rows are written by k_lin_cam, whose
+// lanes walk a camera's observations in the order of its W rows: one sequential stream instead of a 96-byte scatter.)
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
 {
@@ -269,8 +270,6 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
     res[0] *= sw; res[1] *= sw;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
-#pragma unroll
     for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
     V[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
     V[1] += Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
@@ -280,11 +279,6 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
-    double* Wa = d.W + (size_t)d.wpos[a] * Dims<TYPE>::WS;
-#pragma unroll
-    for (int k = 0; k < NW; ++k)
-#pragma unroll
-      for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
@@ -294,7 +288,8 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
 
 // ---- lin_cam: per-camera blocks -------------------------------------------------------------------------
 // wave = camera: lanes stride over the camera's observation list, U = sum Jc^T Jc, g_c = sum Jc^T r,
-// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly.
+// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly; every lane also stores the row W_a = Jc^T Jr of its observation
+// (row index = position in the camera-major list, so a wave writes one contiguous stretch of W).
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
@@ -330,6 +325,16 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
     res[0] *= sw; res[1] *= sw;
 #pragma unroll
     for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
+    {
+      const double* sr = d.scale_r + (size_t)(s.ray_off + j) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+      double* Wa = d.W + (size_t)q * Dims<TYPE>::WS;
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+    }
     int e = 0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
