@@ -330,6 +330,41 @@ def test_lm_golden_trajectories(pkg, orc):
         assert np.allclose(cam[:, 0], g["focal"], rtol=1e-9)
 
 
+def _variant_scene(pkg, g):
+    sc = pkg.synth.make_scene(**g["scene"])
+    if g["annotated"]:
+        sc = pkg.synth.add_annotations(sc)
+    if g["fy_scale"] is not None:
+        sc.cam_init = sc.cam_init.copy(); sc.cam_init[:, 1] = sc.cam_init[:, 0] * g["fy_scale"]
+    return sc
+
+
+def test_lm_golden_trajectories_of_the_variants(pkg, orc):
+    """PTZRayFxfyDist, georeferencing, shared intrinsics, single-view LM with 2D-3D constraints: the oracle reproduces the
+    committed trajectories (tests/golden/lm_trajectories_variants.json, oracle/gen_golden_lm_variants.py)."""
+    doc = json.load(open(os.path.join(GOLD, "lm_trajectories_variants.json")))
+    for g in doc["ba"]:
+        sc = _variant_scene(pkg, g)
+        assert (sc.n_obs, sc.n_ray) == (g["n_obs"], g["n_ray"])
+        kw = dict(obs3d=sc.obs3d, tlw0=sc.tlw_init) if g["annotated"] else {}
+        cam, _, tlw, s, tr = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, trace=True, num_threads=1, **kw)
+        assert s["termination_type"] == g["summary"]["termination_type"] and s["num_iterations"] == g["summary"]["num_iterations"], g["name"]
+        assert tr.accepted.tolist() == g["accepted"]
+        assert np.allclose(tr.cost, g["cost"], rtol=1e-9)
+        assert np.allclose(cam[:, 0], g["focal"], rtol=1e-9) and np.allclose(cam[:, 1], g["fy"], rtol=1e-9)
+        assert np.allclose(tlw, g["tlw"], rtol=1e-7, atol=1e-9)
+    rbs = {ft: pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(6, 96, seed_id=40 + ft, factor_type=ft), n_pt=10) for ft in (0, 3)}
+    for g in doc["krt_2d3d"]:
+        rb = rbs[g["factor_type"]]; q = g["query"]
+        sl = slice(rb.match_ptr[q], rb.match_ptr[q + 1]); ps = slice(rb.point_ptr[q], rb.point_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, s, tr = orc.krt_solve(rb.uv_ref[sl], rb.uv_cur[sl], rb.cam_ref[q], loc0, factor_type=g["factor_type"], pts2d=rb.pts2d[ps],
+                                   pts3d_local=orc.krt_point_to_local(rb.cam_ref[q], rb.pts3d[ps]), jacobian_mode=orc.JAC_NUMERIC, trace=True)
+        assert s["num_iterations"] == g["summary"]["num_iterations"] and s["num_residuals"] == g["summary"]["num_residuals"]
+        assert np.allclose(tr.cost, g["cost"], rtol=1e-9) and np.allclose(loc, g["cam_local"], rtol=1e-9, atol=1e-12)
+        assert orc.krt_check(s, loc, 100.0) == g["accepted_by_gates"]
+
+
 def test_krt_golden_and_gates(pkg, orc):
     doc = json.load(open(os.path.join(GOLD, "lm_trajectories.json")))
     rbs = {ft: pkg.synth.make_reloc_batch(8, 128, seed_id=ft, factor_type=ft) for ft in (0, 1)}

@@ -279,6 +279,38 @@ def test_ba_batches_of_different_size_side_by_side(pkg):
     bb.close(); bs.close()
 
 
+def test_device_against_committed_trajectories_of_the_variants(pkg, orc):
+    """The device solves against the committed oracle trajectories (tests/golden/lm_trajectories_variants.json): iteration
+    counts, final cost, fx / fy / k1 within 1e-6 -- PTZRayFxfyDist, georeferencing (PTZRay and PTZRayFxfyDist), shared
+    intrinsics with distortion, and the single-view LM with 2D-3D constraints (F and FxfyDist)."""
+    import json, os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lm_trajectories_variants.json")))
+    for g in doc["ba"]:
+        sc = pkg.synth.make_scene(**g["scene"])
+        if g["annotated"]:
+            sc = pkg.synth.add_annotations(sc)
+        if g["fy_scale"] is not None:
+            sc.cam_init = sc.cam_init.copy(); sc.cam_init[:, 1] = sc.cam_init[:, 0] * g["fy_scale"]
+        out = pkg.api.ba_solve(sc, return_tlw=True) if g["annotated"] else pkg.api.ba_solve(sc)
+        cam, summ = out[0], out[2]
+        assert summ["termination_type"] == g["summary"]["termination_type"] and summ["num_iterations"] == g["summary"]["num_iterations"], g["name"]
+        assert abs(summ["final_cost"] - g["summary"]["final_cost"]) < 1e-7 * g["summary"]["final_cost"]
+        assert _rel(cam[:, 0], np.array(g["focal"])) < 1e-6 and np.abs(cam[:, 10] - np.array(g["k1"])).max() < 1e-6
+        live_fy = g["scene"].get("factor_type", 0) == 2 or g["annotated"]
+        if live_fy:
+            assert _rel(cam[:, 1], np.array(g["fy"])) < 1e-6
+    for ft in (0, 3):
+        rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(6, 96, seed_id=40 + ft, factor_type=ft), n_pt=10)
+        cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+        for g in (x for x in doc["krt_2d3d"] if x["factor_type"] == ft):
+            q = g["query"]
+            assert summ[q]["num_iterations"] == g["summary"]["num_iterations"] and bool(acc[q]) == g["accepted_by_gates"]
+            if acc[q]:
+                want = orc.krt_local_to_world(rb.cam_ref[q], np.array(g["cam_local"]), ft)
+                assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
+                assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
+
+
 def test_ba_batch_matches_single(pkg, scene_c1):
     """A batch of different scenes gives, per scene, bit-identical results to solving it alone
     (fixed-order reductions; scenes never interact)."""
