@@ -1,0 +1,1256 @@
+// ptz_ba_kernels.h -- device side of the PTZ-IBA bundle adjustment (gfx950): the structures the kernels read by value and
+// every kernel of one Levenberg-Marquardt pass (see the pass outline at the top of ptz_ba.hip, which is the only file that
+// includes this one; the host side -- batch creation, the pass loop, the C-ABI -- lives there).
+#ifndef PTZ_BA_KERNELS_H
+#define PTZ_BA_KERNELS_H
+#include "ptz_common.h"
+#include "ptz_factor.h"
+
+namespace ptz {
+
+namespace {
+
+constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
+constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (35 doubles: odd -> no same-field bank conflicts)
+constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
+// W row stride: see Dims<TYPE>::WS
+
+struct SceneDev {
+  int n_cam, n_ray, n_obs, n_pair;
+  int cam_off, ray_off, obs_off, pair_off;
+  int ent_off;   // first camera-pair entry
+  int part_off;  // first partial-sum slot (one per ray chunk)
+  int n_chunk;   // ceil(n_ray / RAY_BLOCK)
+  int n;         // NC * n_cam: order of the reduced camera system
+  int idx;       // global scene index (the CSR pointer arrays carry one extra entry per preceding scene)
+  int o3_off, n_o3;  // 2D-3D annotation observations of the scene
+  int grp_off, n_grp;  // shared-intrinsics groups with >= 2 cameras (ranges into grp_ptr, which carries n_grp + 1 entries per scene)
+};
+
+struct LmState {
+  double radius, decrease_factor;
+  double x_cost, x_norm, grad_max;
+  double candidate_cost, model_cost_change;
+  double initial_cost, final_cost, it_cost;
+  int reuse_diagonal, need_linearize, cur, iteration, n_summaries, step_is_successful;
+  int num_consecutive_invalid, termination;
+  int num_successful, num_unsuccessful, num_lm_steps, num_linear_solves, num_jac_evals;
+  int pad;
+};
+
+struct Opt {  // device copy of the solver options
+  int max_num_iterations, max_consecutive_invalid, jacobi_scaling;
+  double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+};
+
+// Everything the kernels read, by value.
+struct Dev {
+  int n_scene;
+  const SceneDev* scene;
+  // observations (sorted ray-major) and structure
+  const float2* obs_uv;
+  const int* obs_cam;   // scene-local camera id
+  const int* obs_ray;   // scene-local ray id
+  const int* ray_ptr;   // [total_ray + n_scene] per scene n_ray + 1 entries, global obs index
+  const int* cam_ptr;   // [total_cam + n_scene] per scene n_cam + 1 entries into cam_obs
+  const int* cam_obs;   // global obs index, camera-major
+  const int* wpos;      // [total_obs] row of W that holds observation a (camera-major position)
+  const int* cam_ray;   // [total_obs] global ray id, camera-major (same order as cam_obs)
+  const int* pair_ci;   // scene-local camera ids, ci >= cj
+  const int* pair_cj;
+  const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
+  const int* cam_pair;  // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local pair range of each camera ci
+  const int2* ent;      // (position of obs a in ci's observation list, global obs index b of cj); ci > cj only
+  const double* ray_w;
+  // state: two buffers, LmState.cur selects the current one
+  double* cam_x;  // [2][total_cam][15]
+  double* ray_x;  // [2][total_ray][3]
+  size_t cam_stride, ray_stride;
+  const double* cam_x0;
+  const double* ray_x0;
+  // per-camera blocks
+  double* camblk;    // [total_cam][CAMBLK]   at x
+  double* candblk;   // [total_cam][CANDBLK]  at the candidate
+  double* scale_c;   // [total_cam][NC]
+  double* scale_r;   // [total_ray][3]
+  double* U;         // [total_cam][NC*NC]
+  double* gc;        // [total_cam][NC]
+  double* costc;     // [total_cam]
+  double* diag_c;    // [total_cam][NC]
+  double* dc;        // [total_cam][NC] scaled-space camera step
+  double* V;         // [total_ray][6]
+  double* gr;        // [total_ray][3]
+  double* diag_r;    // [total_ray][3]
+  double* E;         // [total_ray][6]
+  double* z;         // [total_ray][3]
+  double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
+  double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
+  // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
+  const float2* o3_uv;  // [total_o3]
+  const double* o3_xyz; // [total_o3][3] world points
+  const int* o3_cam;    // [total_o3] scene-local camera id
+  double* tlw_x;     // [2][n_scene_total][6]
+  size_t tlw_stride;
+  double* tlwblk;    // [n_scene_total][TLWBLK] at x
+  double* tlwcand;   // [n_scene_total][TLWBLK] at the candidate (R_lw and t used)
+  double* scale_t;   // [n_scene_total][6]
+  double* diag_t;    // [n_scene_total][6]
+  double* Ut;        // [n_scene_total][36]
+  double* gt;        // [n_scene_total][6]
+  double* dt;        // [n_scene_total][6] scaled-space tlw step
+  double* Jc3;       // [total_o3][2][NC] (scaled)
+  double* Jt3;       // [total_o3][2][6]  (scaled)
+  double* r3;        // [total_o3][2]
+  // shared intrinsics (SetSharedIntrinsics): groups of cameras whose intrinsic columns are one parameter
+  int shared;            // 0 = no group anywhere in the batch: none of the group kernels is launched
+  const int* grp_ptr;    // per scene n_grp + 1 offsets into grp_mem (global), at [scene.grp_off + scene.idx ...]
+  const int* grp_mem;    // scene-local camera ids of a group, ascending; the LAST one is the representative
+  const unsigned char* cam_flag;  // [total_cam] bit 0: this camera's intrinsics block is counted in |x| (one per group)
+  double* gfold;         // [total_cam][NC] gradient with the shared slots folded onto the representative
+  // LM
+  LmState* lm;
+  int* active;       // [n_scene]
+  int* ray_fail;     // [n_scene]
+  Opt opt;
+  // reduced camera system
+  CholBatch chol;
+  double* yc;        // [n_scene][np]
+};
+
+__device__ __forceinline__ const double* cur_cam(const Dev& d, const SceneDev& s, const LmState& st)
+{
+  return d.cam_x + (size_t)st.cur * d.cam_stride + (size_t)s.cam_off * 15;
+}
+__device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s, const LmState& st)
+{
+  return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
+}
+
+// TYPE = factor (0 PTZRay, 1 PTZRayDist, 2 PTZRayFxfyDist) + 3 * has3d.
+//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]; PTZRayFxfyDist [fx, fy, k1, r1, r2, r3]
+//   NC free camera parameters: without annotations the same set (the reference's always-zero fy column of PTZRay /
+//   PTZRayDist is not materialised); with 2D-3D annotation residuals fy becomes live (Reproj2d3dFactor reads it,
+//   ptzray_optimizer.cc:273): [f, fy, (k1), r1, r2, r3], and the 6-dof T_l_w block joins the reduced system.
+template <int TYPE> struct Dims {
+  static constexpr int FACTOR = TYPE % 3, HAS3D = TYPE / 3;
+  static constexpr int FXFY = FACTOR == 2;  // fy is a 2D-2D column
+  static constexpr int F3 = FACTOR ? 1 : 0;  // Reproj2d3dFactor variant: k1 free or not (same functor for Dist / FxfyDist)
+  static constexpr int NW = 4 + (FACTOR >= 1) + FXFY;
+  static constexpr int NC = NW + (HAS3D && !FXFY);
+  static constexpr int NG = 6 * HAS3D;  // size of the global (tlw) block
+  // doubles per observation row of W = Jc^T Jr (NW x 3), rounded up to a 16-byte multiple: 12 (96 B) / 16 (128 B).
+  // Measured on MI355X: unpadded 96-B rows beat 128-B-aligned rows (less write/stream traffic outweighs line straddling).
+  static constexpr int WS = (NW * 3 + 1) & ~1;
+  // position of 2D-2D column k inside the NC block
+  static __host__ __device__ constexpr int pos(int k) { return NC != NW ? (k == 0 ? 0 : k + 1) : k; }
+  // index of free parameter k of the NC block in the Camera 15-vector
+  static __host__ __device__ constexpr int at(int k)
+  {
+    // PTZRay: f r1 r2 r3 | PTZRayDist: f k1 r.. | +3D: f fy r.. | f fy k1 r.. | PTZRayFxfyDist (with or without 3D): fx fy k1 r..
+    constexpr int FYL = (NC != NW) || FXFY;  // fy occupies slot 1
+    return k == 0 ? 0 : (FYL && k == 1) ? 1 : (FACTOR && k == 1 + FYL) ? 10 : 4 + (k - (NC - 3));
+  }
+};
+
+__device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl)
+{
+  double R[9];
+  rodrigues(c15 + 4, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cb[CB_R + i] = R[i];
+  cb[CB_F] = c15[0]; cb[CB_CX] = c15[2]; cb[CB_CY] = c15[3]; cb[CB_FY] = c15[1];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) cb[CB_K + i] = c15[10 + i];
+  if (with_jl) {
+    double Jl[9];
+    so3_left_jacobian(c15 + 4, Jl);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cb[CB_JL + i] = Jl[i];
+  }
+}
+
+// ---- cam_prep: rotation / SO(3) Jacobian / intrinsics / scales of every camera at x ------------------
+template <int TYPE>
+__global__ void k_cam_prep(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam) return;
+  double* cb = d.camblk + (size_t)(s.cam_off + i) * CAMBLK;
+  fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
+  if (Dims<TYPE>::HAS3D && i == 0) {
+    const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+    double R[9], Jl[9];
+    const double rv[3] = {t[0], t[1], t[2]};
+    rodrigues(rv, R);
+    so3_left_jacobian(rv, Jl);
+    for (int k = 0; k < 9; ++k) { tb[k] = R[k]; tb[9 + k] = Jl[k]; }
+    tb[18] = t[3]; tb[19] = t[4]; tb[20] = t[5];
+  }
+}
+
+// stage a scene's camera table into LDS (stride words per camera)
+__device__ __forceinline__ void stage_table(const double* __restrict__ src, double* dst, int count)
+{
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+// same, re-striding rows of SRC doubles to DST doubles in LDS
+template <int SRC, int DST>
+__device__ __forceinline__ void stage_rows(const double* __restrict__ src, double* dst, int rows)
+{
+  for (int i = threadIdx.x; i < rows * SRC; i += blockDim.x) dst[(i / SRC) * DST + (i % SRC)] = src[i];
+}
+
+// ---- lin_ray: per-ray linearisation ---------------------------------------------------------------------
+// thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
+// Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r.  (The W_a = Jc^T Jr rows are written by k_lin_cam, whose
+// lanes walk a camera's observations in the order of its W rows: one sequential stream instead of a 96-byte scatter.)
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
+{
+  constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, lds, s.n_cam);
+  __syncthreads();
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int gj = s.ray_off + j;
+  const double* X = cur_ray(d, s, st) + (size_t)j * 3;
+  const double Xr[3] = {X[0], X[1], X[2]};
+  const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
+  const double sw = sqrt(d.ray_w[gj]);
+  const int* rp = d.ray_ptr + s.ray_off + s.idx;
+  double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const float2 uv = d.obs_uv[a];
+    const double* cb = lds + d.obs_cam[a] * CBS;
+    double res[2], Jc[2][NW], Jr[2][3];
+    ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    res[0] *= sw; res[1] *= sw;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+    V[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
+    V[1] += Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
+    V[2] += Jr[0][1] * Jr[0][1] + Jr[1][1] * Jr[1][1];
+    V[3] += Jr[0][2] * Jr[0][0] + Jr[1][2] * Jr[1][0];
+    V[4] += Jr[0][2] * Jr[0][1] + Jr[1][2] * Jr[1][1];
+    V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d.gr[(size_t)gj * 3 + k] = g[k];
+}
+
+// ---- lin_cam: per-camera blocks -------------------------------------------------------------------------
+// wave = camera: lanes stride over the camera's observation list, U = sum Jc^T Jc, g_c = sum Jc^T r,
+// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly; every lane also stores the row W_a = Jc^T Jr of its observation
+// (row index = position in the camera-major list, so a wave writes one contiguous stretch of W).
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lin_cam(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= s.n_cam) return;
+  const int lane = threadIdx.x & 63;
+  const int gi = s.cam_off + i;
+  double cb[CAMBLK];
+#pragma unroll
+  for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
+  const double* rays = cur_ray(d, s, st);
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  double U[NW * (NW + 1) / 2], g[NW], cost = 0;
+#pragma unroll
+  for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) g[k] = 0;
+  for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
+    const int a = d.cam_obs[q];
+    const float2 uv = d.obs_uv[a];
+    const int j = d.obs_ray[a];
+    const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
+    double res[2], Jc[2][NW], Jr[2][3];
+    ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+    const double w = d.ray_w[s.ray_off + j];
+    const double sw = sqrt(w);
+    cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
+    res[0] *= sw; res[1] *= sw;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
+    {
+      const double* sr = d.scale_r + (size_t)(s.ray_off + j) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+      double* Wa = d.W + (size_t)q * Dims<TYPE>::WS;
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+    }
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      g[k] += Jc[0][k] * res[0] + Jc[1][k] * res[1];
+#pragma unroll
+      for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
+    }
+  }
+  cost = wave_sum(cost);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) g[k] = wave_sum(g[k]);
+#pragma unroll
+  for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
+  if (lane == 0) {
+    d.costc[gi] = cost;
+    if (NC != NW) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
+#pragma unroll
+      for (int k = 0; k < NC * NC; ++k) d.U[(size_t)gi * NC * NC + k] = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d.gc[(size_t)gi * NC + k] = 0;
+    }
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int pk = Dims<TYPE>::pos(k);
+      d.gc[(size_t)gi * NC + pk] = g[k];
+#pragma unroll
+      for (int l = 0; l <= k; ++l) {
+        const int pl = Dims<TYPE>::pos(l);
+        d.U[(size_t)gi * NC * NC + pk * NC + pl] = U[e];
+        d.U[(size_t)gi * NC * NC + pl * NC + pk] = U[e];
+        ++e;
+      }
+    }
+  }
+}
+
+// ---- lin_3d: 2D-3D annotation residuals (AddConstraints2d3d, ptzray_optimizer.cc:887-923; weight 1) ----------
+// One workgroup per scene: thread = annotation point (closed-form Jacobians of Reproj2d3dFactor w.r.t. the camera
+// block [fx, fy, (k1), rvec] and the T_l_w block), then thread 0 adds the few blocks to U_i, g_i, cost_i and builds the
+// T_l_w diagonal block / gradient in observation order (fixed order, no atomics).
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_lin_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  const double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+  const double* stl = d.scale_t + (size_t)s.idx * 6;
+  for (int o = threadIdx.x; o < s.n_o3; o += 256) {
+    const int go = s.o3_off + o;
+    const int ci = d.o3_cam[go];
+    const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CAMBLK;
+    const float2 uv = d.o3_uv[go];
+    const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
+    double res[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, true>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
+    for (int k = 0; k < NC; ++k) { d.Jc3[(size_t)go * 2 * NC + k] = Jc[0][k] * cb[CB_S + k]; d.Jc3[(size_t)go * 2 * NC + NC + k] = Jc[1][k] * cb[CB_S + k]; }
+    for (int k = 0; k < 6; ++k) { d.Jt3[(size_t)go * 12 + k] = Jt[0][k] * stl[k]; d.Jt3[(size_t)go * 12 + 6 + k] = Jt[1][k] * stl[k]; }
+    d.r3[(size_t)go * 2] = res[0]; d.r3[(size_t)go * 2 + 1] = res[1];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double Ut[36], gt[6];
+  for (int k = 0; k < 36; ++k) Ut[k] = 0;
+  for (int k = 0; k < 6; ++k) gt[k] = 0;
+  for (int o = 0; o < s.n_o3; ++o) {
+    const int go = s.o3_off + o;
+    const int gi = s.cam_off + d.o3_cam[go];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    const double* j1 = j0 + NC;
+    const double* q0 = d.Jt3 + (size_t)go * 12;
+    const double* q1 = q0 + 6;
+    const double r0 = d.r3[(size_t)go * 2], r1 = d.r3[(size_t)go * 2 + 1];
+    d.costc[gi] += 0.5 * (r0 * r0 + r1 * r1);
+    for (int k = 0; k < NC; ++k) {
+      d.gc[(size_t)gi * NC + k] += j0[k] * r0 + j1[k] * r1;
+      for (int l = 0; l < NC; ++l) d.U[(size_t)gi * NC * NC + k * NC + l] += j0[k] * j0[l] + j1[k] * j1[l];
+    }
+    for (int k = 0; k < 6; ++k) {
+      gt[k] += q0[k] * r0 + q1[k] * r1;
+      for (int l = 0; l < 6; ++l) Ut[k * 6 + l] += q0[k] * q0[l] + q1[k] * q1[l];
+    }
+  }
+  for (int k = 0; k < 36; ++k) d.Ut[(size_t)s.idx * 36 + k] = Ut[k];
+  for (int k = 0; k < 6; ++k) d.gt[(size_t)s.idx * 6 + k] = gt[k];
+}
+
+// ---- Jacobi scaling (Ceres: s_j = 1 / (1 + |J_:j|), computed once at iteration 0) -----------------------
+template <int TYPE>
+__global__ void k_jacobi_scale(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < s.n_cam) {
+    const int gi = s.cam_off + t;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) d.scale_c[(size_t)gi * NC + k] = 1.0 / (1.0 + sqrt(d.U[(size_t)gi * NC * NC + k * NC + k]));
+  }
+  if (t < s.n_ray) {
+    const int gj = s.ray_off + t;
+    d.scale_r[(size_t)gj * 3 + 0] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 0]));
+    d.scale_r[(size_t)gj * 3 + 1] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 2]));
+    d.scale_r[(size_t)gj * 3 + 2] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 5]));
+  }
+  if (Dims<TYPE>::HAS3D && t < 6) d.scale_t[(size_t)s.idx * 6 + t] = 1.0 / (1.0 + sqrt(d.Ut[(size_t)s.idx * 36 + t * 7]));
+}
+
+// ---- shared intrinsics (PTZRayOptimizer::SetSharedIntrinsics, ptzray_optimizer.cc:497-505) ------------------------------
+// Cameras of a group share ONE intrinsics parameter block.  The per-camera pipeline above stays as it is (every camera
+// still carries its own copy of the intrinsic columns, with identical values and steps); what makes the copies one
+// parameter is a change of variables x_cam = P x_shared applied where it matters:
+//   * column norms, hence Jacobi scales and LM diagonals, are those of the stacked group column (k_group_scale, k_group_diag);
+//   * the reduced camera system is folded, S' = P^T S P, b' = P^T b, onto the group's representative (k_fold_system),
+//     solved, and the representative's step is copied back to the members (k_group_expand);
+//   * gradient norm and |x| count the block once (k_group_grad, cam_flag in k_lm_pre / k_lm_post).
+// The representative is the LAST camera of the group, so that the dense rows the fold creates sit at the bottom of the
+// system and cause no extra fill above them.
+template <int TYPE> __device__ __forceinline__ bool is_intr_slot(int k)
+{
+  const int a = Dims<TYPE>::at(k);
+  return a < 4 || a >= 10;
+}
+
+// thread = (group, slot): group-wide Jacobi scale from the summed squared column norms (members ascending)
+template <int TYPE>
+__global__ void k_group_scale(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t / NC, k = t % NC;
+  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double sum = 0;
+  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  const double sc_g = 1.0 / (1.0 + sqrt(sum));
+  for (int e = gp[g]; e < gp[g + 1]; ++e) d.scale_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = sc_g;
+}
+
+// LM diagonal of a shared slot: clamp(sum of the members' diagonal entries); each member carries an equal share so that
+// the fold of S adds them back up
+template <int TYPE>
+__global__ void k_group_diag(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (d.lm[sc].reuse_diagonal) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t / NC, k = t % NC;
+  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double sum = 0;
+  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  const double share = fmin(fmax(sum, d.opt.min_lm_diagonal), d.opt.max_lm_diagonal) / (double)(gp[g + 1] - gp[g]);
+  for (int e = gp[g]; e < gp[g + 1]; ++e) d.diag_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
+}
+
+// gradient with the shared slots folded onto the representative (others 0); every other slot copied.
+// One workgroup per scene: copy, barrier, fold.
+template <int TYPE>
+__global__ void k_group_grad(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (!d.active[sc] || !st.need_linearize) return;
+  for (int t = threadIdx.x; t < s.n_cam * NC; t += blockDim.x) d.gfold[(size_t)s.cam_off * NC + t] = d.gc[(size_t)s.cam_off * NC + t];
+  __syncthreads();
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+    const int g = t / NC, k = t % NC;
+    if (!is_intr_slot<TYPE>(k)) continue;
+    double sum = 0;
+    for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
+    for (int e = gp[g]; e < gp[g + 1]; ++e)
+      d.gfold[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = (e == gp[g + 1] - 1) ? sum : 0.0;
+  }
+}
+
+// S' = P^T S P, b' = P^T b in place on the lower-triangular storage (row n = right-hand side), one workgroup per scene,
+// one (group, slot) after the other.  For slot index(m) = m * NC + k of the members m:
+//   v[c]  = sum_m Sfull[index(m)][c]            for every column c = 0 .. n (c = n is the right-hand side)
+//   S'[rep][c] = v[c]  (c not a member slot),   S'[rep][rep] = sum_m v[index(m)],
+//   rows / columns of the other members: 0, diagonal 1, right-hand side 0 (their step is copied from the representative).
+template <int TYPE>
+__global__ __launch_bounds__(1024) void k_fold_system(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (s.n_grp == 0) return;
+  const int np = d.chol.np, n = s.n;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  extern __shared__ double v[];  // [n + 1]
+  __shared__ double dsum;
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  auto at = [&](int i, int c) -> double& { return i >= c ? A[(size_t)i * np + c] : A[(size_t)c * np + i]; };
+  for (int g = 0; g < s.n_grp; ++g) {
+    const int e0 = gp[g], e1 = gp[g + 1];
+    const int rep = d.grp_mem[e1 - 1];
+    for (int k = 0; k < NC; ++k) {
+      if (!is_intr_slot<TYPE>(k)) continue;
+      for (int c = threadIdx.x; c <= n; c += blockDim.x) {
+        double sum = 0;
+        for (int e = e0; e < e1; ++e) sum += at(d.grp_mem[e] * NC + k, c);
+        v[c] = sum;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double sum = 0;
+        for (int e = e0; e < e1; ++e) sum += v[d.grp_mem[e] * NC + k];
+        dsum = sum;
+      }
+      __syncthreads();
+      const int ri = rep * NC + k;
+      for (int c = threadIdx.x; c <= n; c += blockDim.x) {
+        // is c one of the member slots of this (group, slot)?
+        bool member = false;
+        if (c < n && c % NC == k) {
+          const int cam = c / NC;
+          for (int e = e0; e < e1 && !member; ++e) member = d.grp_mem[e] == cam;
+        }
+        if (!member) {
+          at(ri, c) = v[c];
+          for (int e = e0; e < e1 - 1; ++e) at(d.grp_mem[e] * NC + k, c) = 0.0;
+        }
+      }
+      __syncthreads();
+      // member x member block: representative diagonal = folded sum, other members identity, cross entries 0
+      for (int t = threadIdx.x; t < (e1 - e0) * (e1 - e0); t += blockDim.x) {
+        const int a = t / (e1 - e0), bq = t % (e1 - e0);
+        if (bq > a) continue;
+        const int ia = d.grp_mem[e0 + a] * NC + k, ib = d.grp_mem[e0 + bq] * NC + k;
+        double val = 0.0;
+        if (a == bq) val = (a == e1 - e0 - 1) ? dsum : 1.0;
+        at(ia, ib) = val;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// after the solve: the members of a group take the representative's step for the shared slots
+template <int TYPE>
+__global__ void k_group_expand(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  double* y = d.yc + (size_t)sc * d.chol.np;
+  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+    const int g = t / NC, k = t % NC;
+    if (!is_intr_slot<TYPE>(k)) continue;
+    const double yr = y[d.grp_mem[gp[g + 1] - 1] * NC + k];
+    for (int e = gp[g]; e < gp[g + 1] - 1; ++e) y[d.grp_mem[e] * NC + k] = yr;
+  }
+}
+
+// ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
+constexpr int LM_THREADS = 1024;  // the LM bookkeeping kernels are one workgroup per scene: wide, to shorten their reductions
+template <int TYPE>
+__global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  LmState& st = d.lm[sc];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  if (st.step_is_successful) {
+    // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
+    double c = 0, gm = 0, xn = 0;
+    const double* cam = cur_cam(d, s, st);
+    const int* cp = d.cam_ptr + s.cam_off + s.idx;
+    for (int i = tid; i < s.n_cam; i += LM_THREADS) {
+      const int gi = s.cam_off + i;
+      c += d.costc[gi];
+      const double* gsrc = d.shared ? d.gfold : d.gc;  // shared intrinsics: the group's gradient sits at its representative
+      for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(gsrc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
+      if (cp[i + 1] > cp[i]) {  // parameter blocks of cameras without residuals are not in the problem
+        const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
+        for (int k = 0; k < 15; ++k)
+          if (intr || (k >= 4 && k < 10)) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
+      }
+    }
+    const double* ray = cur_ray(d, s, st);
+    for (int j = tid; j < s.n_ray; j += LM_THREADS) {
+      const int gj = s.ray_off + j;
+      for (int k = 0; k < 3; ++k) {
+        gm = fmax(gm, fabs(d.gr[(size_t)gj * 3 + k] / d.scale_r[(size_t)gj * 3 + k]));
+        xn += ray[(size_t)j * 3 + k] * ray[(size_t)j * 3 + k];
+      }
+    }
+    // fixed-order cost: per-thread partial sums over a strided camera set, then the block tree
+    if (Dims<TYPE>::HAS3D && tid == 0) {
+      const double* tl = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+      for (int k = 0; k < 6; ++k) {
+        if (s.n_o3 > 0) xn += tl[k] * tl[k];  // the T_l_w block is in the problem only when annotation residuals exist
+        gm = fmax(gm, fabs(d.gt[(size_t)s.idx * 6 + k] / d.scale_t[(size_t)s.idx * 6 + k]));
+      }
+    }
+    c = block_sum(c, scratch);
+    gm = block_max(gm, scratch);
+    xn = block_sum(xn, scratch);
+    if (tid == 0) {
+      st.x_cost = c;
+      st.it_cost = c;
+      st.grad_max = gm;
+      st.x_norm = sqrt(xn);
+      st.need_linearize = 0;
+      ++st.num_jac_evals;
+      if (st.n_summaries == 0) { st.initial_cost = c; st.final_cost = c; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (st.step_is_successful) ++st.num_successful; else ++st.num_unsuccessful;
+    if (st.it_cost < st.final_cost) st.final_cost = st.it_cost;
+    ++st.n_summaries;
+    if (st.iteration >= d.opt.max_num_iterations) { st.termination = PTZ_NO_CONVERGENCE; d.active[sc] = 0; }
+    else if (st.step_is_successful && st.grad_max <= d.opt.gradient_tolerance) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
+    else if (st.radius <= d.opt.min_radius) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
+    else {
+      ++st.iteration;
+      ++st.num_lm_steps;
+      st.step_is_successful = 0;
+      d.ray_fail[sc] = 0;
+    }
+  }
+}
+
+// ---- ray_prep: LevenbergMarquardtStrategy diagonal + SchurEliminator e-block inverse --------------------
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
+{
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int gj = s.ray_off + j;
+  double V[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) V[k] = d.V[(size_t)gj * 6 + k];
+  double dg[3];
+  if (!st.reuse_diagonal) {
+    dg[0] = fmin(fmax(V[0], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+    dg[1] = fmin(fmax(V[2], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+    dg[2] = fmin(fmax(V[5], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.diag_r[(size_t)gj * 3 + k] = dg[k];
+  }
+  else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dg[k] = d.diag_r[(size_t)gj * 3 + k];
+  }
+  // D = sqrt(diag / radius); V + D^2
+  const double D0 = sqrt(dg[0] / st.radius), D1 = sqrt(dg[1] / st.radius), D2 = sqrt(dg[2] / st.radius);
+  V[0] += D0 * D0; V[2] += D1 * D1; V[5] += D2 * D2;
+  double E[6];
+  if (!inv3_spd(V, E)) {
+    d.ray_fail[sc] = 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d.E[(size_t)gj * 6 + k] = E[k];
+  const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
+  d.z[(size_t)gj * 3 + 0] = E[0] * g0 + E[1] * g1 + E[3] * g2;
+  d.z[(size_t)gj * 3 + 1] = E[1] * g0 + E[2] * g1 + E[4] * g2;
+  d.z[(size_t)gj * 3 + 2] = E[3] * g0 + E[4] * g1 + E[5] * g2;
+}
+
+template <int TYPE>
+__global__ void k_cam_diag(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam || st.reuse_diagonal) return;
+  const int gi = s.cam_off + i;
+  if (Dims<TYPE>::HAS3D && i == 0)
+    for (int k = 0; k < 6; ++k)
+      d.diag_t[(size_t)s.idx * 6 + k] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + k * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+}
+
+// ---- schur: one workgroup per camera ci -------------------------------------------------------------------
+// Phase 1 (all threads, strided over ci's observations a): T_a = W_a E_ray(a) into LDS; at the same time the
+//   diagonal block S_ii = U_i + D_i^2 - sum_a T_a W_a^T and the right-hand side b_i = g_i - sum_a W_a z_ray(a)
+//   (z = E g_r) are reduced over the workgroup.  b is stored as row n of the padded system.
+// Phase 2 (16-lane groups over ci's camera pairs (ci, cj < ci)): each lane takes entries e = lane, lane+16, ...
+//   of the pair (T_a from LDS, W_b = one aligned 128-B line from L2), accumulates the whole NC x NC product in
+//   registers, the group is reduced with a fixed butterfly and lane 0 stores S_ij = -sum.
+#ifndef PTZ_SCHUR_THREADS
+#define PTZ_SCHUR_THREADS 256
+#endif
+#ifndef PTZ_SCHUR_WAVES
+#define PTZ_SCHUR_WAVES 3
+#endif
+constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
+template <int TYPE>
+__global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
+  constexpr int NU = NW * (NW + 1) / 2;
+  constexpr int NT = NW * 3;
+  constexpr int TS = NT;  // row stride of the T table in LDS (an odd stride was measured: 25 % slower, it breaks the 16-byte reads of phase 2)
+  int ci, sc;
+  xcd_remap(ci, sc);
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (ci >= s.n_cam) return;
+  const LmState& st = d.lm[sc];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  const int o0 = cp[ci], no = cp[ci + 1] - o0;
+  const int* cpair = d.cam_pair + s.cam_off + s.idx;
+  const int* pp = d.pair_ptr + s.pair_off + s.idx;
+  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
+  const int eb = 0;                                        // entries are addressed by global index
+  double* T = lds;                                  // [no][TS]
+  double* strip = lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
+  const int2* ents = d.ent + eb;                    // (a slot, W row of b), this camera's contiguous range
+  const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
+  double bsum[NW], D[NU];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) bsum[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) D[k] = 0;
+  for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
+    const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
+    const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
+    const double* E = d.E + (size_t)gj * 6;
+    const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
+    double w[NT];
+    const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
+#pragma unroll
+    for (int k = 0; k < NT; ++k) w[k] = Wa[k];
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const double w0 = w[3 * p], w1 = w[3 * p + 1], w2 = w[3 * p + 2];
+      bsum[p] += w0 * z0 + w1 * z1 + w2 * z2;
+      const double t0 = w0 * e0 + w1 * e1 + w2 * e3, t1 = w0 * e1 + w1 * e2 + w2 * e4, t2 = w0 * e3 + w1 * e4 + w2 * e5;
+      T[q * TS + 3 * p] = t0; T[q * TS + 3 * p + 1] = t1; T[q * TS + 3 * p + 2] = t2;
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
+    }
+  }
+  // one pass of the block tree for all NC + NU sums (fixed order: lanes by butterfly, waves in wave order)
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NV = NW + NU;
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
+    }
+    __syncthreads();  // also orders the T / ents / pps stores before phase 2
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double t = 0;
+      for (int i = 0; i < SCHUR_THREADS / 64; ++i) t += strip[i * NV + k];
+      v[k] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bsum[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) D[k] = v[NW + k];
+  }
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  if (threadIdx.x == 0) {
+    const int gi = s.cam_off + ci;
+    double* row = A + (size_t)s.n * np;
+    // full NC x NC block: U (2D-2D + annotation terms) + D^2 - sum T W^T (the latter only on the NW x NW 2D-2D columns);
+    // assembled in registers, stored once (both triangles: the block stays symmetric)
+    double blk[NC * NC], rhs[NC];
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+      rhs[p] = d.gc[(size_t)gi * NC + p];
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) blk[p * NC + qq] = d.U[(size_t)gi * NC * NC + p * NC + qq];
+      const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+      blk[p * NC + p] += Dd * Dd;
+    }
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      rhs[Dims<TYPE>::pos(p)] -= bsum[p];
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) blk[Dims<TYPE>::pos(p) * NC + Dims<TYPE>::pos(qq)] -= D[e++];
+    }
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+      row[ci * NC + p] = rhs[p];
+#pragma unroll
+      for (int qq = 0; qq <= p; ++qq) {
+        A[(size_t)(ci * NC + p) * np + ci * NC + qq] = blk[p * NC + qq];
+        A[(size_t)(ci * NC + qq) * np + ci * NC + p] = blk[p * NC + qq];
+      }
+    }
+  }
+  // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
+  const int l = threadIdx.x & 15;
+  for (int pl = (threadIdx.x >> 4); pl < npr; pl += SCHUR_THREADS / 16) {
+    double acc[NW * NW];
+#pragma unroll
+    for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
+    const int e1 = pps[pl + 1];
+    int e = pps[pl] + l;
+    // two entries per trip while both exist (both W_b rows in flight together), then at most one single entry
+    for (; e + 16 < e1; e += 32) {
+      const int2 ab0 = ents[e];
+      const int2 ab1 = ents[e + 16];
+      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
+      const double* Wb1 = d.W + (size_t)ab1.y * Dims<TYPE>::WS;
+      double wb0[NT], wb1[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) { wb0[k] = Wb0[k]; wb1[k] = Wb1[k]; }
+      const double* Ta0 = T + ab0.x * TS;
+      const double* Ta1 = T + ab1.x * TS;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) {
+        const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
+        const double u0 = Ta1[3 * p], u1 = Ta1[3 * p + 1], u2 = Ta1[3 * p + 2];
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+          acc[p * NW + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
+                             (u0 * wb1[3 * q] + u1 * wb1[3 * q + 1] + u2 * wb1[3 * q + 2]);
+      }
+    }
+    if (e < e1) {
+      const int2 ab0 = ents[e];
+      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
+      double wb0[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) wb0[k] = Wb0[k];
+      const double* Ta0 = T + ab0.x * TS;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) {
+        const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) acc[p * NW + q] += t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2];
+      }
+    }
+    // reduce-scatter over the 16 lanes of the group: after the steps with masks 8, 4, 2, 1 lane l holds the complete
+    // sum of block element l (fixed order); every lane then stores its own element.  Elements >= NW*NW (NW = 5 keeps
+    // 25 values) take a second pass with the lanes that are left.
+    const int cj = d.pair_cj[s.pair_off + pr0 + pl];
+    double* S = A + (size_t)(ci * NC) * np + cj * NC;
+#pragma unroll
+    for (int base = 0; base < NW * NW; base += 16) {
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = (base + k < NW * NW) ? acc[(base + k < NW * NW) ? base + k : 0] : 0.0;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) {
+        const bool up = (l & m) != 0;
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          const double keep = up ? v[k + m] : v[k];
+          const double send = up ? v[k] : v[k + m];
+          v[k] = keep + __shfl_xor(send, m, 16);
+        }
+      }
+      const int el = base + l;
+      if (el < NW * NW) S[(size_t)Dims<TYPE>::pos(el / NW) * np + Dims<TYPE>::pos(el % NW)] = -v[0];
+    }
+  }
+}
+
+// ---- schur_3d: rows of the T_l_w block in the reduced system (it is not coupled to the rays) ---------------------
+//   S_tt = U_t + D_t^2,  S_t,cam(i) = sum_{annotations of camera i} Jt^T Jc,  b_t = g_t
+template <int TYPE>
+__global__ __launch_bounds__(64) void k_schur_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  const int t0 = NC * s.n_cam;
+  const int k = threadIdx.x;  // one lane per T_l_w row
+  if (k >= 6) return;
+  for (int l = 0; l <= k; ++l) {
+    double v = d.Ut[(size_t)s.idx * 36 + k * 6 + l];
+    if (l == k) {
+      const double Dd = sqrt(d.diag_t[(size_t)s.idx * 6 + k] / st.radius);
+      v += Dd * Dd;
+    }
+    A[(size_t)(t0 + k) * np + t0 + l] = v;
+  }
+  A[(size_t)s.n * np + t0 + k] = d.gt[(size_t)s.idx * 6 + k];
+  for (int o = 0; o < s.n_o3; ++o) {  // observation order: deterministic accumulation into the (zeroed) coupling row
+    const int go = s.o3_off + o;
+    const int ci = d.o3_cam[go];
+    const double q0 = d.Jt3[(size_t)go * 12 + k], q1 = d.Jt3[(size_t)go * 12 + 6 + k];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    for (int l = 0; l < NC; ++l) A[(size_t)(t0 + k) * np + ci * NC + l] += q0 * j0[l] + q1 * j0[NC + l];
+  }
+}
+
+// ---- cam_update: candidate cameras and their residual-side blocks ----------------------------------------
+template <int TYPE>
+__global__ void k_cam_update(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam) return;
+  const int gi = s.cam_off + i;
+  const double* x = cur_cam(d, s, st) + (size_t)i * 15;
+  double c15[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) c15[k] = x[k];
+  const double* y = d.yc + (size_t)sc * d.chol.np + (size_t)i * NC;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double step = -y[k];
+    d.dc[(size_t)gi * NC + k] = step;
+    c15[Dims<TYPE>::at(k)] += step * d.scale_c[(size_t)gi * NC + k];
+  }
+  double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) xc[k] = c15[k];
+  double cb[CANDBLK];
+  fill_camblk(c15, cb, false);
+#pragma unroll
+  for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CANDBLK + k] = cb[k];
+  if (Dims<TYPE>::HAS3D && i == 0) {
+    const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
+    const double* yt = d.yc + (size_t)sc * d.chol.np + (size_t)NC * s.n_cam;
+    double tn[6];
+    for (int k = 0; k < 6; ++k) {
+      const double step = -yt[k];
+      d.dt[(size_t)s.idx * 6 + k] = step;
+      tn[k] = t[k] + step * d.scale_t[(size_t)s.idx * 6 + k];
+      tc[k] = tn[k];
+    }
+    double* tb = d.tlwcand + (size_t)s.idx * TLWBLK;
+    double R[9];
+    const double rv[3] = {tn[0], tn[1], tn[2]};
+    rodrigues(rv, R);
+    for (int k = 0; k < 9; ++k) tb[k] = R[k];
+    tb[18] = tn[3]; tb[19] = tn[4]; tb[20] = tn[5];
+  }
+}
+
+// ---- eval: ray back-substitution, model cost change and candidate cost in one ray-centric pass -----------------
+//   y_r = E (g_r - sum_a Jr_a^T (Jc_a y_c))            (SchurEliminator::BackSubstitute; W_a = Jc_a^T Jr_a is not
+//                                                        re-read: the Jacobian blocks are recomputed, flops are free)
+//   candidate ray = x + scale * (-y_r)
+//   model_cost_change = -(J d)^T (r + J d / 2)          (TrustRegionMinimizer::ComputeTrustRegionStep)
+//   candidate_cost    = 1/2 sum w |r(x + delta)|^2
+// The scaled camera step d_c = -y_c is staged in LDS next to the camera tables of x and of the candidate.
+template <int TYPE>
+__global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
+  const int sc = blockIdx.y;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  if (blockIdx.x >= s.n_chunk) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int DCS = NC | 1;                // odd stride for the step table as well
+  double* tab = lds;                         // [n_cam][CBS]
+  double* ctab = tab + s.n_cam * CBS;        // [n_cam][CDS]
+  double* dct = ctab + s.n_cam * CDS;        // [n_cam][DCS] scaled camera step
+  double* scratch = dct + s.n_cam * DCS;     // [16]
+  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam);
+  stage_rows<CANDBLK, CDS>(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam);
+  stage_rows<NC, DCS>(d.dc + (size_t)s.cam_off * NC, dct, s.n_cam);
+  __syncthreads();
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  double mcc = 0, cost = 0;
+  if (j < s.n_ray) {
+    const int gj = s.ray_off + j;
+    const double* X = cur_ray(d, s, st) + (size_t)j * 3;
+    const double Xr[3] = {X[0], X[1], X[2]};
+    const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
+    const double w = d.ray_w[gj];
+    const double sw = sqrt(w);
+    const int* rp = d.ray_ptr + s.ray_off + s.idx;
+    const int a0 = rp[j], a1 = rp[j + 1];
+    // pass 1 (one linearisation per observation): with p_a = Jc_a d_c (camera part of J d),
+    //   t  = g_r + sum_a Jr_a^T p_a                      -> y_r = E t, ray step d_r = -y_r
+    //   s1 = sum_a p_a . (r_a + p_a / 2)
+    // and, since J d = p_a + Jr_a d_r per observation, the ray's share of (J d)^T (r + J d / 2) is
+    //   s1 + d_r . t + 1/2 d_r^T V d_r      (V = sum_a Jr_a^T Jr_a is the stored, undamped ray block)
+    double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
+    double s1 = 0;
+    for (int a = a0; a < a1; ++a) {
+      const float2 uv = d.obs_uv[a];
+      const int ci = d.obs_cam[a];
+      const double* cb = tab + ci * CBS;
+      double res[2], Jc[2][NW], Jr[2][3];
+      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      double m0 = 0, m1 = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      s1 += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
+      t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
+      t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
+      t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
+    }
+    const double* E = d.E + (size_t)gj * 6;
+    // step = -y_r (Ceres solves J y = r and negates)
+    const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
+    const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
+    double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
+    xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
+    {
+      const double* V = d.V + (size_t)gj * 6;  // [v00 v10 v11 v20 v21 v22]
+      const double q0 = V[0] * ds[0] + V[1] * ds[1] + V[3] * ds[2];
+      const double q1 = V[1] * ds[0] + V[2] * ds[1] + V[4] * ds[2];
+      const double q2 = V[3] * ds[0] + V[4] * ds[1] + V[5] * ds[2];
+      mcc = s1 + (ds[0] * t0 + ds[1] * t1 + ds[2] * t2) + 0.5 * (ds[0] * q0 + ds[1] * q1 + ds[2] * q2);
+    }
+    // pass 2: candidate cost (residuals only)
+    for (int a = a0; a < a1; ++a) {
+      const float2 uv = d.obs_uv[a];
+      double rc[2];
+      ba_residual<F>(ctab + d.obs_cam[a] * CDS, Xn, uv.x, uv.y, rc);
+      cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
+    }
+  }
+  mcc = block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  if (threadIdx.x == 0) {
+    d.partial[(size_t)(s.part_off + blockIdx.x) * 2] = mcc;
+    d.partial[(size_t)(s.part_off + blockIdx.x) * 2 + 1] = cost;
+  }
+}
+
+// ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_eval_3d(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC;
+  if (!Dims<TYPE>::HAS3D) return;
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  __shared__ double scratch[16];
+  double mcc = 0, cost = 0;
+  for (int o = threadIdx.x; o < s.n_o3; o += 256) {
+    const int go = s.o3_off + o;
+    const int gi = s.cam_off + d.o3_cam[go];
+    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+    const double* q0 = d.Jt3 + (size_t)go * 12;
+    double m0 = 0, m1 = 0;
+    for (int k = 0; k < NC; ++k) { const double st_ = d.dc[(size_t)gi * NC + k]; m0 += j0[k] * st_; m1 += j0[NC + k] * st_; }
+    for (int k = 0; k < 6; ++k) { const double st_ = d.dt[(size_t)s.idx * 6 + k]; m0 += q0[k] * st_; m1 += q0[6 + k] * st_; }
+    mcc += m0 * (d.r3[(size_t)go * 2] + m0 / 2.0) + m1 * (d.r3[(size_t)go * 2 + 1] + m1 / 2.0);
+    double cb[CAMBLK];
+    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CANDBLK + k];
+    const float2 uv = d.o3_uv[go];
+    const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
+    double rc[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, false>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
+    cost += 0.5 * (rc[0] * rc[0] + rc[1] * rc[1]);
+  }
+  mcc = block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  if (threadIdx.x == 0) {
+    d.partial[(size_t)(s.part_off + s.n_chunk) * 2] = mcc;
+    d.partial[(size_t)(s.part_off + s.n_chunk) * 2 + 1] = cost;
+  }
+}
+
+// ---- lm_post: the body of TrustRegionMinimizer::Minimize after the step has been computed --------------
+template <int TYPE>
+__global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
+{
+  const int sc = blockIdx.x;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  LmState& st = d.lm[sc];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  // chunk partials in chunk order (thread-strided, then the fixed block tree)
+  double mcc = 0, cost = 0;
+  for (int c = tid; c < s.n_chunk + Dims<TYPE>::HAS3D; c += LM_THREADS) {
+    mcc += d.partial[(size_t)(s.part_off + c) * 2];
+    cost += d.partial[(size_t)(s.part_off + c) * 2 + 1];
+  }
+  mcc = -block_sum(mcc, scratch);
+  cost = block_sum(cost, scratch);
+  // |x - x_candidate| and |x_candidate| over the parameter blocks that are in the problem
+  const double* cam = cur_cam(d, s, st);
+  const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
+  const double* ray = cur_ray(d, s, st);
+  const double* rayc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)s.ray_off * 3;
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  double dn = 0, cn = 0;
+  for (int i = tid; i < s.n_cam; i += LM_THREADS) {
+    if (cp[i + 1] <= cp[i]) continue;
+    const bool intr = !d.shared || (d.cam_flag[s.cam_off + i] & 1);
+    for (int k = 0; k < 15; ++k) {
+      if (!intr && (k < 4 || k >= 10)) continue;
+      const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
+      dn += (a - b) * (a - b);
+      cn += b * b;
+    }
+  }
+  for (int j = tid; j < s.n_ray * 3; j += LM_THREADS) {
+    const double a = ray[j], b = rayc[j];
+    dn += (a - b) * (a - b);
+    cn += b * b;
+  }
+  if (Dims<TYPE>::HAS3D && tid == 0 && s.n_o3 > 0) {
+    const double* ta = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
+    const double* tb_ = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
+    for (int k = 0; k < 6; ++k) { dn += (ta[k] - tb_[k]) * (ta[k] - tb_[k]); cn += tb_[k] * tb_[k]; }
+  }
+  dn = block_sum(dn, scratch);
+  cn = block_sum(cn, scratch);
+  if (tid != 0) return;
+  const Opt& o = d.opt;
+  ++st.num_linear_solves;
+  st.reuse_diagonal = 1;  // LevenbergMarquardtStrategy::ComputeStep
+  const bool solve_fail = d.ray_fail[sc] || d.chol.fail[sc];
+  const bool valid = !solve_fail && isfinite(mcc) && isfinite(dn) && mcc > 0.0;
+  st.model_cost_change = mcc;
+  st.it_cost = st.x_cost;
+  if (!valid) {  // HandleInvalidStep
+    ++st.num_consecutive_invalid;
+    if (st.num_consecutive_invalid >= o.max_consecutive_invalid) { st.termination = PTZ_FAILURE; d.active[sc] = 0; return; }
+    st.radius *= 0.5;  // StepIsInvalid
+    st.reuse_diagonal = 0;
+    return;
+  }
+  st.num_consecutive_invalid = 0;
+  if (!isfinite(cost)) cost = 1.7976931348623157e308;
+  st.candidate_cost = cost;
+  // ParameterToleranceReached
+  if (sqrt(dn) <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  // FunctionToleranceReached
+  const double cost_change = st.x_cost - cost;
+  if (fabs(cost_change) <= o.function_tolerance * st.x_cost) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  const double rho = cost_change / mcc;  // TrustRegionStepEvaluator::StepQuality, monotonic steps
+  if (rho > o.min_relative_decrease) {
+    // HandleSuccessfulStep: x <- candidate; the Jacobian is re-evaluated by the kernels that follow
+    st.cur ^= 1;
+    st.need_linearize = 1;
+    st.step_is_successful = 1;
+    const double t = 2.0 * rho - 1.0;
+    st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);  // StepAccepted
+    st.radius = fmin(o.max_radius, st.radius);
+    st.decrease_factor = 2.0;
+    st.reuse_diagonal = 0;
+  }
+  else {
+    // HandleUnsuccessfulStep / StepRejected
+    st.it_cost = cost;
+    st.radius = st.radius / st.decrease_factor;
+    st.decrease_factor *= 2.0;
+    st.reuse_diagonal = 1;
+  }
+}
+
+// ---- reset / init -----------------------------------------------------------------------------------------
+__global__ void k_reset(Dev d)
+{
+  const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= d.n_scene) return;
+  LmState st;
+  memset(&st, 0, sizeof(st));
+  st.radius = d.opt.initial_radius;
+  st.decrease_factor = 2.0;
+  st.need_linearize = 1;
+  st.step_is_successful = 1;
+  st.termination = PTZ_NO_CONVERGENCE;
+  d.lm[sc] = st;
+  d.active[sc] = 1;
+  d.ray_fail[sc] = 0;
+}
+__global__ void k_fill(double* p, size_t n, double v)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Pix2Ray (ptzray_optimizer.cc:768-797): ray = normalise(mean_i normalise(R_i^-1 K_i^-1 [u, v, 1]))
+__global__ __launch_bounds__(RAY_BLOCK) void k_pix2ray(Dev d, double* cam0, double* ray0)
+{
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  if (j >= s.n_ray) return;
+  const int* rp = d.ray_ptr + s.ray_off + s.idx;
+  double acc[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int a = rp[j]; a < rp[j + 1]; ++a) {
+    const double* c = cam0 + (size_t)(s.cam_off + d.obs_cam[a]) * 15;
+    double R[9];
+    rodrigues(c + 4, R);
+    const float2 uv = d.obs_uv[a];
+    const double q0 = ((double)uv.x - c[2]) / c[0], q1 = ((double)uv.y - c[3]) / c[1];
+    // R^-1 = R^T for a rotation (the reference inverts numerically; identical to round-off)
+    double t0 = R[0] * q0 + R[3] * q1 + R[6], t1 = R[1] * q0 + R[4] * q1 + R[7], t2 = R[2] * q0 + R[5] * q1 + R[8];
+    const double n = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+    acc[0] += t0 / n; acc[1] += t1 / n; acc[2] += t2 / n;
+    ++cnt;
+  }
+  acc[0] /= cnt; acc[1] /= cnt; acc[2] /= cnt;
+  const double n = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+  double* out = ray0 + (size_t)(s.ray_off + j) * 3;
+  out[0] = acc[0] / n; out[1] = acc[1] / n; out[2] = acc[2] / n;
+}
+
+}  // namespace
+
+}  // namespace ptz
+#endif  // PTZ_BA_KERNELS_H
