@@ -205,6 +205,16 @@ int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* match_ptr, cons
                                  double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                                  ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
 
+/* The same launch on queries that are already resident in HBM (matches produced on the device, a serving loop that keeps its
+ * buffers): every d_* argument is a DEVICE pointer with the layout of its host counterpart above, d_point_ptr = NULL for no
+ * 2D-3D constraints.  The kernel is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream) of device
+ * opt->device_id and the call returns without synchronising: results (d_cam_cur, d_summaries, d_accepted) are valid once the
+ * stream has passed this point.  The CSR offsets are not validated (they live on the device). */
+int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_match_ptr, const float* d_uv_ref, const float* d_uv_cur,
+                                   const int64_t* d_point_ptr, const float* d_pts2d, const double* d_pts3d,
+                                   const double* d_cam_ref, double* d_cam_cur, int32_t factor_type, double max_reproj_error,
+                                   const ptz_lm_options* opt, ptz_lm_summary* d_summaries, int32_t* d_accepted, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

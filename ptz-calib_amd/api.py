@@ -23,7 +23,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
-           "ptz_krt_solve_batch_2d3d", "ptz_trim_cache"]
+           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache"]
 
 
 class PtzError(RuntimeError):
@@ -264,3 +264,21 @@ def krt_solve_batch(batch, max_reproj_error=100.0, **opt):
                                          C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.byref(ms)),
                "ptz_krt_solve_batch")
     return ccur, [s.as_dict() for s in summ], acc, ms.value
+
+
+def krt_solve_batch_device(n_query, d_match_ptr, d_uv_ref, d_uv_cur, d_cam_ref, d_cam_cur, d_summaries, d_accepted, factor_type=0,
+                           max_reproj_error=100.0, d_point_ptr=None, d_pts2d=None, d_pts3d=None, stream=None, **opt):
+    """ptz_krt_solve_batch_device: every d_* argument is a device buffer given as an object with .data_ptr() (a torch tensor)
+    or as an integer address; d_summaries needs n_query * sizeof(LmSummary) bytes.  Enqueues on `stream` (integer hipStream_t
+    handle, None = default stream) and returns without synchronising."""
+    o = default_options(**opt)
+
+    def ptr(x):
+        if x is None:
+            return None
+        return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+
+    _check(lib().ptz_krt_solve_batch_device(int(n_query), ptr(d_match_ptr), ptr(d_uv_ref), ptr(d_uv_cur), ptr(d_point_ptr), ptr(d_pts2d),
+                                            ptr(d_pts3d), ptr(d_cam_ref), ptr(d_cam_cur), int(factor_type), C.c_double(max_reproj_error),
+                                            C.byref(o), ptr(d_summaries), ptr(d_accepted), C.c_void_p(stream) if stream else None),
+           "ptz_krt_solve_batch_device")

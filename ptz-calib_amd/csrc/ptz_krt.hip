@@ -389,10 +389,73 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
   }
 }
 
+KrtOpt make_krt_opt(const ptz_lm_options& o, double max_reproj_error)
+{
+  KrtOpt ko;
+  ko.max_num_iterations = o.max_num_iterations;
+  ko.max_consecutive_invalid = o.max_num_consecutive_invalid_steps;
+  ko.jacobi_scaling = o.jacobi_scaling;
+  ko.initial_radius = o.initial_trust_region_radius;
+  ko.max_radius = o.max_trust_region_radius;
+  ko.min_radius = o.min_trust_region_radius;
+  ko.min_relative_decrease = o.min_relative_decrease;
+  ko.min_lm_diagonal = o.min_lm_diagonal;
+  ko.max_lm_diagonal = o.max_lm_diagonal;
+  ko.function_tolerance = o.function_tolerance;
+  ko.gradient_tolerance = o.gradient_tolerance;
+  ko.parameter_tolerance = o.parameter_tolerance;
+  ko.max_reproj_error = max_reproj_error;
+  return ko;
+}
+
+// one launch over device-resident queries (all pointers are device pointers; d_pptr = nullptr: no 2D-3D constraints)
+void launch_krt(int n_query, const long long* d_ptr, const float2* d_ref, const float2* d_cur, const long long* d_pptr,
+                const float2* d_puv, const double* d_pxyz, const double* d_cref, double* d_ccur, int factor_type, const KrtOpt& ko,
+                ptz_lm_summary* d_sum, int* d_acc, hipStream_t st)
+{
+  const dim3 grid((n_query + 3) / 4), block(256);
+  const bool p3 = d_pptr != nullptr;
+#define PTZ_KRT_LAUNCH(T, P)                                                                                         \
+  hipLaunchKernelGGL((k_krt<T, P>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
+                     d_ccur, ko, d_sum, d_acc)
+  switch (factor_type * 2 + (p3 ? 1 : 0)) {
+    case 0: PTZ_KRT_LAUNCH(0, false); break;
+    case 1: PTZ_KRT_LAUNCH(0, true); break;
+    case 2: PTZ_KRT_LAUNCH(1, false); break;
+    case 3: PTZ_KRT_LAUNCH(1, true); break;
+    case 4: PTZ_KRT_LAUNCH(2, false); break;
+    case 5: PTZ_KRT_LAUNCH(2, true); break;
+    case 6: PTZ_KRT_LAUNCH(3, false); break;
+    default: PTZ_KRT_LAUNCH(3, true); break;
+  }
+#undef PTZ_KRT_LAUNCH
+}
+
 }  // namespace
 }  // namespace ptz
 
 using namespace ptz;
+
+extern "C" int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_match_ptr, const float* d_uv_ref, const float* d_uv_cur,
+                                              const int64_t* d_point_ptr, const float* d_pts2d, const double* d_pts3d,
+                                              const double* d_cam_ref, double* d_cam_cur, int32_t factor_type,
+                                              double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* d_summaries,
+                                              int32_t* d_accepted, void* hip_stream)
+{
+  if (n_query <= 0 || !d_match_ptr || !d_uv_ref || !d_uv_cur || !d_cam_ref || !d_cam_cur || !d_summaries || !d_accepted) return PTZ_EINVAL;
+  if (d_point_ptr && (!d_pts2d || !d_pts3d)) return PTZ_EINVAL;
+  if (factor_type < PTZ_KRT_F || factor_type > PTZ_KRT_FxfyDist) return PTZ_EUNSUPPORTED;
+  ptz_lm_options o;
+  if (opt) o = *opt; else ptz_lm_options_default(&o);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
+  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+  launch_krt(n_query, (const long long*)d_match_ptr, (const float2*)d_uv_ref, (const float2*)d_uv_cur, (const long long*)d_point_ptr,
+             (const float2*)d_pts2d, d_pts3d, d_cam_ref, d_cam_cur, factor_type, make_krt_opt(o, max_reproj_error), d_summaries, d_accepted,
+             (hipStream_t)hip_stream);
+  PTZ_HIP_TRY(hipGetLastError());
+  return PTZ_OK;
+}
 
 extern "C" int32_t ptz_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
                                        const double* cam_ref, double* cam_cur, int32_t factor_type, double max_reproj_error,
@@ -467,36 +530,9 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   PTZ_HIP_TRY(hipMemcpyAsync(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
-  KrtOpt ko;
-  ko.max_num_iterations = o.max_num_iterations;
-  ko.max_consecutive_invalid = o.max_num_consecutive_invalid_steps;
-  ko.jacobi_scaling = o.jacobi_scaling;
-  ko.initial_radius = o.initial_trust_region_radius;
-  ko.max_radius = o.max_trust_region_radius;
-  ko.min_radius = o.min_trust_region_radius;
-  ko.min_relative_decrease = o.min_relative_decrease;
-  ko.min_lm_diagonal = o.min_lm_diagonal;
-  ko.max_lm_diagonal = o.max_lm_diagonal;
-  ko.function_tolerance = o.function_tolerance;
-  ko.gradient_tolerance = o.gradient_tolerance;
-  ko.parameter_tolerance = o.parameter_tolerance;
-  ko.max_reproj_error = max_reproj_error;
   PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
-  const dim3 grid((n_query + 3) / 4), block(256);
-#define PTZ_KRT_LAUNCH(T, P)                                                                                            \
-  hipLaunchKernelGGL((k_krt<T, P>), grid, block, 0, h.st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
-                     d_ccur, ko, d_sum, d_acc)
-  switch (factor_type * 2 + (p3 ? 1 : 0)) {
-    case 0: PTZ_KRT_LAUNCH(0, false); break;
-    case 1: PTZ_KRT_LAUNCH(0, true); break;
-    case 2: PTZ_KRT_LAUNCH(1, false); break;
-    case 3: PTZ_KRT_LAUNCH(1, true); break;
-    case 4: PTZ_KRT_LAUNCH(2, false); break;
-    case 5: PTZ_KRT_LAUNCH(2, true); break;
-    case 6: PTZ_KRT_LAUNCH(3, false); break;
-    default: PTZ_KRT_LAUNCH(3, true); break;
-  }
-#undef PTZ_KRT_LAUNCH
+  launch_krt(n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, d_ccur, factor_type, make_krt_opt(o, max_reproj_error), d_sum,
+             d_acc, h.st);
   PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
   PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));

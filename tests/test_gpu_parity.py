@@ -487,6 +487,18 @@ def test_cpp_krt_optimizer_2d3d(pkg, orc):
     assert code == -2
 
 
+@pytest.mark.parametrize("with_points", [0, 1])
+def test_krt_device_resident_entry_matches_host_entry(with_points):
+    """ptz_krt_solve_batch_device on buffers that already live in HBM (torch tensors as plumbing), enqueued on a caller's
+    stream without synchronisation: bit-identical to the host-pointer entry point, which runs the same kernel.  Runs in its own
+    process with torch initialised first -- the order bench.py uses; a process that starts the ROCm runtime through this
+    library and only then lets torch bring up its bundled runtime ends with torch seeing no GPU."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "run_krt_device_entry.py"), str(with_points)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device entry ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_krt_ragged_and_degenerate(pkg, orc):
     """Ragged match counts, including a query with too few matches to constrain 4 parameters."""
     rb = pkg.synth.make_reloc_batch(6, 64, seed_id=9)
