@@ -9,6 +9,7 @@
 #include "image_size.h"
 #include "json_mini.h"
 #include "krt_optimizer.h"
+#include <chrono>
 #include <stdexcept>
 #include "ptz_incremental_optimizer.h"
 #include "ptzray_optimizer.h"
@@ -237,8 +238,10 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
                                const int64_t* src, const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t,
                                const double* H, const int32_t* h_valid, const double* confidence, double* cam15,
                                const int64_t* seeds, int32_t n_seeds, int32_t max_iter, int32_t* registered, int64_t* events,
-                               int32_t max_events, int64_t* lm_iterations, int32_t* solved, double* timing5)
-{
+                               int32_t max_events, int64_t* lm_iterations, int32_t* solved, double* timing7)
+{  // timing7: the optimizer's five figures, then the wall time of its construction and of Solve() alone (milliseconds) -- the
+   // conversion of the flat arrays into ImageFeatures / MatchesInfo objects above them is this harness's, not the library's
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   std::vector<ImageFeatures> feats;
   std::vector<MatchesInfo> mis;
   std::vector<Camera> cams;
@@ -248,17 +251,24 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
     mis[p].H_empty = h_valid[p] == 0;
     mis[p].confidence = confidence[p];
   }
+  const double t_c0 = now_ms();
   PtzIncrementalOptimizer opt(feats, mis, cams, max_iter);
   if (n_seeds > 0) opt.SetSeedImageId(std::vector<long>(seeds, seeds + n_seeds));
   std::unordered_set<long> reg;
+  const double t_s0 = now_ms();
   const bool ok = opt.Solve(cams, reg);
+  const double t_s1 = now_ms();
   const auto& ev = opt.events();
   const int32_t ne = static_cast<int32_t>(ev.size()) < max_events ? static_cast<int32_t>(ev.size()) : max_events;
   for (int32_t e = 0; e < ne; ++e) {
     events[4 * e] = ev[e].kind; events[4 * e + 1] = ev[e].a; events[4 * e + 2] = ev[e].b; events[4 * e + 3] = ev[e].success ? 1 : 0;
   }
   if (lm_iterations) *lm_iterations = opt.lm_iterations();
-  if (timing5) memcpy(timing5, opt.timing_ms(), sizeof(double) * 5);
+  if (timing7) {
+    memcpy(timing7, opt.timing_ms(), sizeof(double) * 5);
+    timing7[5] = t_s0 - t_c0;
+    timing7[6] = t_s1 - t_s0;
+  }
   if (solved) *solved = ok ? 1 : 0;
   if (!ok) return ne;
   for (int i = 0; i < n_img; ++i) {

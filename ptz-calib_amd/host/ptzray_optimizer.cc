@@ -47,14 +47,9 @@ std::shared_ptr<const SharedTracks> PTZRayOptimizer::BuildTracks(const std::vect
   TracksBuilder builder;
   builder.Build(matches_info);
   builder.Filter(4);
-  builder.ExportToSTL(st->tracks);
-  // the same tracks as flat arrays, in the map's iteration order (track id ascending, image id ascending)
-  st->ptr.push_back(0);
-  for (const auto& te : st->tracks) {
-    st->id.push_back(te.first);
-    for (const auto& kv : te.second) { st->img.push_back(kv.first); st->feat.push_back(kv.second); }
-    st->ptr.push_back(static_cast<int64_t>(st->img.size()));
-  }
+  // flat arrays in the iteration order of the reference's map of maps (track id ascending, image id ascending); the maps
+  // themselves (a heap node per view) are not built for the shared form
+  builder.ExportFlat(st->id, st->ptr, st->img, st->feat);
   return st;
 }
 
@@ -159,6 +154,13 @@ void PTZRayOptimizer::Pack()
     RKinv[c] = Mul(Inverse(cameras_[p.cam_image[c]].R()), Inverse(cameras_[p.cam_image[c]].K()));
   std::vector<char> is_cand(num_cams_, 0);
   for (size_t i = 0; i < num_cams_; ++i) is_cand[i] = isCandidate(static_cast<long>(i));
+  {  // upper bounds (every view of every track a candidate): one allocation instead of the doubling sequence
+    size_t max_obs = 0, max_ray = 0;
+    if (shared_tracks_) { max_obs = shared_tracks_->img.size(); max_ray = shared_tracks_->id.size(); }
+    else { max_ray = tracks_.size(); for (const auto& te : tracks_) max_obs += te.second.size(); }
+    p.obs_uv.reserve(2 * max_obs); p.obs_cam.reserve(max_obs); p.obs_ray.reserve(max_obs);
+    p.ray_track.reserve(max_ray); p.ray_weight.reserve(max_ray); p.ray.reserve(3 * max_ray);
+  }
   auto add_track = [&](int track_id, size_t track_len, auto&& for_each_view) {
     Vec3 acc = {0, 0, 0};
     size_t n_cand = 0;
@@ -366,8 +368,16 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
     std::vector<std::vector<Ray>>& rays = *rays_out;
     const Vec3 rl = Mul(R_w_l, Vec3{ray[3 * j], ray[3 * j + 1], ray[3 * j + 2]});
     const Vec3 ray_w = {rl[0] - Rtt[0], rl[1] - Rtt[1], rl[2] - Rtt[2]};  // R_w_l ray_l + t_w_l (:746-754)
-    for (const auto& kv : tracks().at(p.ray_track[j]))
-      rays[kv.first].emplace_back(p.ray_track[j], ray_w, features_[kv.first].keypoints[kv.second].pt);
+    if (shared_tracks_) {
+      const SharedTracks& st = *shared_tracks_;
+      const size_t k = static_cast<size_t>(std::lower_bound(st.id.begin(), st.id.end(), p.ray_track[j]) - st.id.begin());
+      for (int64_t e = st.ptr[k]; e < st.ptr[k + 1]; ++e)
+        rays[st.img[e]].emplace_back(p.ray_track[j], ray_w, features_[st.img[e]].keypoints[st.feat[e]].pt);
+    }
+    else {
+      for (const auto& kv : tracks_.at(p.ray_track[j]))
+        rays[kv.first].emplace_back(p.ray_track[j], ray_w, features_[kv.first].keypoints[kv.second].pt);
+    }
   }
   p.cam = cam;
   p.ray = ray;

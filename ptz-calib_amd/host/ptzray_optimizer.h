@@ -36,7 +36,6 @@ struct PackedBA {
 // Tracks of one match table, built once and shared by many solves: the reference's map plus the same content as flat
 // arrays in the map's iteration order.
 struct SharedTracks {
-  Tracks tracks;
   std::vector<int> id;        // track ids, ascending
   std::vector<int64_t> ptr;   // [n_tracks + 1]
   std::vector<int> img, feat; // views of track k: ptr[k] .. ptr[k+1], image ids ascending
@@ -80,7 +79,7 @@ class PTZRayOptimizer {
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
-  const Tracks& tracks() const { return shared_tracks_ ? shared_tracks_->tracks : tracks_; }
+  const Tracks& tracks() const { return tracks_; }  // own tracks (FindTracks); empty when UseTracks() supplied the shared flat form
   bool SetInitTransLocalToWorld();
 
   std::vector<Camera> cameras_;

@@ -136,6 +136,39 @@ void TracksBuilder::ExportToSTL(Tracks& tracks)
   }
 }
 
+// The same content as ExportToSTL without the node-per-entry maps: tracks in ascending id order, the views of a track in
+// ascending image order (the nodes are image-sorted, and a filtered track holds an image once) -- the iteration order of the map.
+void TracksBuilder::ExportFlat(std::vector<int>& id, std::vector<int64_t>& ptr, std::vector<int>& img, std::vector<int>& feat) const
+{
+  const int n = static_cast<int>(nodes_.size());
+  const int none = std::numeric_limits<int>::max();
+  std::vector<int> count(static_cast<size_t>(n) + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    const int r = parent_[k];
+    if (r != none && size_[r] > 1) ++count[r];
+  }
+  id.clear(); ptr.clear();
+  std::vector<int64_t> start(static_cast<size_t>(n), -1);
+  int64_t run = 0;
+  ptr.push_back(0);
+  for (int r = 0; r < n; ++r)
+    if (count[r] > 0) {
+      id.push_back(r);
+      start[r] = run;
+      run += count[r];
+      ptr.push_back(run);
+    }
+  img.assign(static_cast<size_t>(run), 0);
+  feat.assign(static_cast<size_t>(run), 0);
+  for (int k = 0; k < n; ++k) {
+    const int r = parent_[k];
+    if (r == none || size_[r] <= 1) continue;
+    const int64_t slot = start[r]++;
+    img[slot] = nodes_[k].first;
+    feat[slot] = nodes_[k].second;
+  }
+}
+
 size_t TracksBuilder::NbTracks() const
 {
   std::set<int> ids(parent_.begin(), parent_.end());

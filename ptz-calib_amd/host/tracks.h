@@ -7,6 +7,7 @@
 #include <map>
 #include <set>
 #include <utility>
+#include <cstdint>
 #include <vector>
 
 #include "types.h"
@@ -22,6 +23,8 @@ class TracksBuilder {
   void Build(const std::vector<MatchesInfo>& matches_info);
   void Filter(int min_track_length = 2);  // drop tracks with < N images or with a repeated image
   void ExportToSTL(Tracks& tracks);
+  // flat form of the same export (ascending track id, ascending image id inside), without building the maps
+  void ExportFlat(std::vector<int>& id, std::vector<int64_t>& ptr, std::vector<int>& img, std::vector<int>& feat) const;
   size_t NbTracks() const;
 
  private:

@@ -36,7 +36,7 @@ def incremental_solve(table, cam15, max_iter: int = 200, seeds=()):
     seeds = np.array(list(seeds), dtype=np.int64)
     nit = C.c_int64(0)
     solved = C.c_int32(0)
-    timing = np.zeros(5)
+    timing = np.zeros(7)
     H = np.ascontiguousarray(tb.H, dtype=np.float64)
     hv = np.ascontiguousarray(tb.h_valid, dtype=np.int32)
     conf = np.ascontiguousarray(tb.confidence, dtype=np.float64)
@@ -49,4 +49,4 @@ def incremental_solve(table, cam15, max_iter: int = 200, seeds=()):
     return dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)), events=events,
                 lm_iterations=int(nit.value),
                 timing_ms=dict(ranking=timing[0], bundle_total=timing[1], bundle_device=timing[2], registration_total=timing[3],
-                               registration_device=timing[4]))
+                               registration_device=timing[4], construct=timing[5], solve=timing[6]))

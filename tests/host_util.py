@@ -134,7 +134,7 @@ def krt_solve_2d3d(cam_ref, cam_cur, uv_ref, uv_cur, pts2d, pts3d, max_iter=200,
 
 
 def incremental_solve(table, cam15, max_iter=200, seeds=()):
-    incremental_solve.timing = np.zeros(5)
+    incremental_solve.timing = np.zeros(7)
     """PtzIncrementalOptimizer::Solve through the C++ class.  Returns (ok, cam15, registered ids, events, lm_iterations)."""
     tb = table
     cam = np.array(cam15, dtype=np.float64, order="C").copy()
