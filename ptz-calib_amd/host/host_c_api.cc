@@ -9,6 +9,7 @@
 #include "image_size.h"
 #include "json_mini.h"
 #include "krt_optimizer.h"
+#include <algorithm>
 #include <chrono>
 #include <stdexcept>
 #include "ptz_incremental_optimizer.h"
@@ -96,6 +97,16 @@ int32_t ptzh_tracks_build(int32_t n_pairs, const int64_t* src, const int64_t* ds
     ids.push_back(te.first);
     for (const auto& kv : te.second) { ei.push_back(kv.first); ef.push_back(kv.second); }
     ptr.push_back(static_cast<int64_t>(ei.size()));
+  }
+  // the flat export (what the shared-track path of the optimizers uses) must be the map export, entry for entry
+  {
+    std::vector<int> fid, fimg, ffeat;
+    std::vector<int64_t> fptr;
+    b.ExportFlat(fid, fptr, fimg, ffeat);
+    const bool same = fid.size() == ids.size() && fptr == ptr && std::equal(fid.begin(), fid.end(), ids.begin()) &&
+                      fimg.size() == ei.size() && std::equal(fimg.begin(), fimg.end(), ei.begin()) &&
+                      std::equal(ffeat.begin(), ffeat.end(), ef.begin());
+    if (!same) return -2;
   }
   *track_id = Dup(ids); *track_ptr = Dup(ptr); *eimg = Dup(ei); *efeat = Dup(ef);
   return static_cast<int32_t>(ids.size());

@@ -26,6 +26,7 @@ def tracks_build(pairs, min_len=4):
     q = np.array([m[0] for p in pairs for m in p[2]], dtype=np.int32); t = np.array([m[1] for p in pairs for m in p[2]], dtype=np.int32)
     tid = C.POINTER(C.c_int32)(); tptr = C.POINTER(C.c_int64)(); ei = C.POINTER(C.c_int32)(); ef = C.POINTER(C.c_int32)()
     nt = lib().ptzh_tracks_build(n, _p(src), _p(dst), _p(ptr), _p(q), _p(t), min_len, C.byref(tid), C.byref(tptr), C.byref(ei), C.byref(ef))
+    assert nt != -2, "TracksBuilder::ExportFlat differs from ExportToSTL"
     out = {int(tid[k]): {int(ei[e]): int(ef[e]) for e in range(tptr[k], tptr[k + 1])} for k in range(nt)}
     for x in (tid, tptr, ei, ef):
         lib().ptzh_free(x)
