@@ -153,6 +153,48 @@ template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const
   return PTZ_OK;
 }
 
+// Many small host arrays -> ONE device block through ONE pinned staging buffer and one copy (a synchronous hipMemcpy from
+// pageable memory costs 10-15 us each whatever its size; a batch has about twenty of them).  Large batches, whose structure
+// would need a staging buffer of more than 64 MB, keep the per-array uploads.
+struct StagedUpload {
+  struct Item { const void* src; size_t bytes; const void** dst; };
+  std::vector<Item> items;
+  template <typename T> void add(const std::vector<T>& h, const T** dev)
+  {
+    items.push_back({h.data(), sizeof(T) * h.size(), reinterpret_cast<const void**>(dev)});
+  }
+  int commit(ptz_ba_batch* b)
+  {
+    auto up = [](size_t x) { return (std::max<size_t>(x, 1) + 255) & ~(size_t)255; };
+    size_t total = 0;
+    for (const Item& it : items) total += up(it.bytes);
+    void* pinned = nullptr;
+    if (total > ((size_t)64 << 20) || ptzpool::pinned_acquire(total, &pinned) != hipSuccess) {
+      (void)hipGetLastError();
+      for (const Item& it : items) {
+        char* p = nullptr;
+        int rc = b->alloc(&p, it.bytes);
+        if (rc) return rc;
+        if (it.bytes && hipMemcpy(p, it.src, it.bytes, hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
+        *it.dst = p;
+      }
+      return PTZ_OK;
+    }
+    char* dev = nullptr;
+    int rc = b->alloc(&dev, total);
+    if (rc) { ptzpool::pinned_release(pinned); return rc; }
+    size_t off = 0;
+    for (const Item& it : items) {
+      if (it.bytes) memcpy((char*)pinned + off, it.src, it.bytes);
+      *it.dst = dev + off;
+      off += up(it.bytes);
+    }
+    const hipError_t e = hipMemcpy(dev, pinned, total, hipMemcpyHostToDevice);
+    ptzpool::pinned_release(pinned);
+    return e == hipSuccess ? PTZ_OK : PTZ_ENODEVICE;
+  }
+};
+
 #define LAUNCH(kern, grid, block, smem, ...) hipLaunchKernelGGL(kern, grid, block, smem, b->stream, __VA_ARGS__)
 
 template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
@@ -742,24 +784,28 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   d.n_scene = n;
   int rc = PTZ_OK;
 #define TRY(x) do { rc = (x); if (rc) { ptz_ba_batch_destroy(b); return rc; } } while (0)
-  TRY(upload(b, b->scenes, &d.scene));
-  TRY(upload(b, h_uv, &d.obs_uv));
-  TRY(upload(b, h_cam, &d.obs_cam));
-  TRY(upload(b, h_ray, &d.obs_ray));
-  TRY(upload(b, h_rayptr, &d.ray_ptr));
-  TRY(upload(b, h_camptr, &d.cam_ptr));
-  TRY(upload(b, h_camobs, &d.cam_obs));
-  TRY(upload(b, h_wpos, &d.wpos));
-  TRY(upload(b, h_camray, &d.cam_ray));
-  TRY(upload(b, h_pci, &d.pair_ci));
-  TRY(upload(b, h_pcj, &d.pair_cj));
-  TRY(upload(b, h_pptr, &d.pair_ptr));
-  TRY(upload(b, h_campair, &d.cam_pair));
-  TRY(upload(b, h_ent, &d.ent));
-  TRY(upload(b, h_w, &d.ray_w));
-  TRY(upload(b, h_o3uv, &d.o3_uv));
-  TRY(upload(b, h_o3xyz, &d.o3_xyz));
-  TRY(upload(b, h_o3cam, &d.o3_cam));
+  {
+    StagedUpload up;
+    up.add(b->scenes, &d.scene);
+    up.add(h_uv, &d.obs_uv);
+    up.add(h_cam, &d.obs_cam);
+    up.add(h_ray, &d.obs_ray);
+    up.add(h_rayptr, &d.ray_ptr);
+    up.add(h_camptr, &d.cam_ptr);
+    up.add(h_camobs, &d.cam_obs);
+    up.add(h_wpos, &d.wpos);
+    up.add(h_camray, &d.cam_ray);
+    up.add(h_pci, &d.pair_ci);
+    up.add(h_pcj, &d.pair_cj);
+    up.add(h_pptr, &d.pair_ptr);
+    up.add(h_campair, &d.cam_pair);
+    up.add(h_ent, &d.ent);
+    up.add(h_w, &d.ray_w);
+    up.add(h_o3uv, &d.o3_uv);
+    up.add(h_o3xyz, &d.o3_xyz);
+    up.add(h_o3cam, &d.o3_cam);
+    TRY(up.commit(b));
+  }
   d.tlw_stride = (size_t)n * 6;
   TRY(b->alloc(&d.tlw_x, 2 * d.tlw_stride));
   TRY(b->alloc(&b->tlw0, d.tlw_stride));

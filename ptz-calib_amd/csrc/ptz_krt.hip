@@ -10,6 +10,7 @@
 //   J^T J (4x4 or 5x5), J^T r and the cost are reduced with a fixed butterfly, every lane then solves the
 //   damped normal equations redundantly in registers.  DENSE_QR on [J; D] and Cholesky on J^T J + D^2
 //   give the same step up to round-off (the Jacobi-scaled 4-/5-column Jacobian is well conditioned).
+#include <cstring>
 #include <vector>
 
 #include "ptz_common.h"
@@ -487,19 +488,20 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
   PTZ_HIP_TRY(hipSetDevice(o.device_id));
   const int64_t nm = match_ptr[n_query];
-  // one pooled device block for everything the launch touches
+  // one pooled device block for everything the launch touches: [inputs | cam_cur (in/out) | summaries | accepted]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_ptr = 0, o_ref = o_ptr + up(sizeof(long long) * (n_query + 1)), o_cur = o_ref + up(sizeof(float2) * (nm > 0 ? nm : 1)),
-               o_cref = o_cur + up(sizeof(float2) * (nm > 0 ? nm : 1)), o_ccur = o_cref + up(sizeof(double) * 15 * n_query),
-               o_sum = o_ccur + up(sizeof(double) * 15 * n_query), o_acc = o_sum + up(sizeof(ptz_lm_summary) * n_query),
-               o_pptr = o_acc + up(sizeof(int) * n_query), o_puv = o_pptr + up(sizeof(long long) * (n_query + 1)),
-               o_pxyz = o_puv + up(sizeof(float2) * (np > 0 ? np : 1)), total = o_pxyz + up(sizeof(double) * 3 * (np > 0 ? np : 1));
+               o_cref = o_cur + up(sizeof(float2) * (nm > 0 ? nm : 1)), o_pptr = o_cref + up(sizeof(double) * 15 * n_query),
+               o_puv = o_pptr + up(sizeof(long long) * (n_query + 1)), o_pxyz = o_puv + up(sizeof(float2) * (np > 0 ? np : 1)),
+               o_ccur = o_pxyz + up(sizeof(double) * 3 * (np > 0 ? np : 1)), o_sum = o_ccur + up(sizeof(double) * 15 * n_query),
+               o_acc = o_sum + up(sizeof(ptz_lm_summary) * n_query), total = o_acc + up(sizeof(int) * n_query);
   struct Held {
-    int dev; char* base = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    int dev; char* base = nullptr; void* pinned = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Held()
     {
       if (st) (void)hipStreamSynchronize(st);
       ptzpool::dev_release(dev, base);
+      ptzpool::pinned_release(pinned);
       ptzpool::stream_release(dev, st);
       ptzpool::event_release(dev, true, e0);
       ptzpool::event_release(dev, true, e1);
@@ -518,27 +520,56 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   long long* d_pptr = p3 ? (long long*)(h.base + o_pptr) : nullptr;
   float2* d_puv = (float2*)(h.base + o_puv);
   double* d_pxyz = (double*)(h.base + o_pxyz);
-  if (p3) {
-    PTZ_HIP_TRY(hipMemcpyAsync(d_pptr, point_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
-    if (np > 0) {
-      PTZ_HIP_TRY(hipMemcpyAsync(d_puv, pts2d, sizeof(float2) * np, hipMemcpyHostToDevice, h.st));
-      PTZ_HIP_TRY(hipMemcpyAsync(d_pxyz, pts3d, sizeof(double) * 3 * np, hipMemcpyHostToDevice, h.st));
+  // Small launches (a registration, a handful of queries) go through one pinned staging buffer: one copy in, one copy out,
+  // instead of eight synchronous-by-nature pageable copies of 10-15 us each.  Large ones keep the per-array copies.
+  const bool staged = total <= ((size_t)64 << 20) && ptzpool::pinned_acquire(total, &h.pinned) == hipSuccess;
+  if (!staged) (void)hipGetLastError();
+  if (staged) {
+    char* ps = (char*)h.pinned;
+    memcpy(ps + o_ptr, match_ptr, sizeof(long long) * (n_query + 1));
+    if (nm > 0) { memcpy(ps + o_ref, uv_ref, sizeof(float2) * nm); memcpy(ps + o_cur, uv_cur, sizeof(float2) * nm); }
+    memcpy(ps + o_cref, cam_ref, sizeof(double) * 15 * n_query);
+    memcpy(ps + o_ccur, cam_cur, sizeof(double) * 15 * n_query);
+    if (p3) {
+      memcpy(ps + o_pptr, point_ptr, sizeof(long long) * (n_query + 1));
+      if (np > 0) { memcpy(ps + o_puv, pts2d, sizeof(float2) * np); memcpy(ps + o_pxyz, pts3d, sizeof(double) * 3 * np); }
     }
+    PTZ_HIP_TRY(hipMemcpyAsync(h.base, ps, o_sum, hipMemcpyHostToDevice, h.st));
   }
-  PTZ_HIP_TRY(hipMemcpyAsync(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
+  else {
+    if (p3) {
+      PTZ_HIP_TRY(hipMemcpyAsync(d_pptr, point_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
+      if (np > 0) {
+        PTZ_HIP_TRY(hipMemcpyAsync(d_puv, pts2d, sizeof(float2) * np, hipMemcpyHostToDevice, h.st));
+        PTZ_HIP_TRY(hipMemcpyAsync(d_pxyz, pts3d, sizeof(double) * 3 * np, hipMemcpyHostToDevice, h.st));
+      }
+    }
+    PTZ_HIP_TRY(hipMemcpyAsync(d_ptr, match_ptr, sizeof(long long) * (n_query + 1), hipMemcpyHostToDevice, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(d_cref, cam_ref, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(d_ccur, cam_cur, sizeof(double) * 15 * n_query, hipMemcpyHostToDevice, h.st));
+  }
   PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
   launch_krt(n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, d_ccur, factor_type, make_krt_opt(o, max_reproj_error), d_sum,
              d_acc, h.st);
   PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));
-  PTZ_HIP_TRY(hipMemcpyAsync(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost, h.st));
-  PTZ_HIP_TRY(hipStreamSynchronize(h.st));
-  PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
+  if (staged) {
+    char* ps = (char*)h.pinned;
+    PTZ_HIP_TRY(hipMemcpyAsync(ps + o_ccur, h.base + o_ccur, total - o_ccur, hipMemcpyDeviceToHost, h.st));
+    PTZ_HIP_TRY(hipStreamSynchronize(h.st));
+    PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
+    memcpy(cam_cur, ps + o_ccur, sizeof(double) * 15 * n_query);
+    memcpy(summaries, ps + o_sum, sizeof(ptz_lm_summary) * n_query);
+    memcpy(accepted, ps + o_acc, sizeof(int) * n_query);
+  }
+  else {
+    PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));
+    PTZ_HIP_TRY(hipMemcpyAsync(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost, h.st));
+    PTZ_HIP_TRY(hipStreamSynchronize(h.st));
+    PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
+  }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, h.e0, h.e1);
   if (device_ms) *device_ms = ms;
