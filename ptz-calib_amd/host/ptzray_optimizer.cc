@@ -255,6 +255,40 @@ static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, cons
   res[1] = static_cast<double>(v) - ((type == PTZRayFxfyDist ? c[1] : c[0]) * yd + c[3]);  // fy read by PTZRayFxfyDist (:167)
 }
 
+void PTZRayOptimizer::ComputeErrors() const
+{
+  if (errors_ready_) return;
+  errors_ready_ = true;
+  const PackedBA& p = packed_;
+  if (p.obs_cam.empty()) return;
+  const std::vector<double>& cam = p.cam;
+  const std::vector<double>& ray = p.ray;
+  double sum0 = 0, sum1 = 0;
+  std::vector<Mat33> Rc(p.cam_image.size());  // one cv::Rodrigues per camera instead of one per residual
+  for (size_t c = 0; c < Rc.size(); ++c) Rc[c] = Rodrigues({cam[15 * c + 4], cam[15 * c + 5], cam[15 * c + 6]});
+  for (size_t a = 0; a < p.obs_cam.size(); ++a) {
+    double res[2];
+    Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], Rc[p.obs_cam[a]], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
+                 p.obs_uv[2 * a + 1], res);
+    sum0 += res[0] * res[0];
+    sum1 += res[1] * res[1];
+  }
+  final_reproj_error_2d2d_ = std::sqrt((sum0 + sum1) / static_cast<double>(p.obs_cam.size()));
+  if (p.obs3d_cam.empty()) {
+    final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();  // sqrt(0 / 0) in the reference when there are no annotations
+  }
+  else {
+    double s0 = 0, s1 = 0;
+    for (size_t a = 0; a < p.obs3d_cam.size(); ++a) {
+      double res[2];
+      Residual2d3d(&cam[15 * static_cast<size_t>(p.obs3d_cam[a])], p.tlw.data(), &p.obs3d_xyz[3 * a], p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1], res);
+      s0 += res[0] * res[0];
+      s1 += res[1] * res[1];
+    }
+    final_reproj_error_2d3d_ = std::sqrt((s0 + s1) / static_cast<double>(p.obs3d_cam.size()));
+  }
+}
+
 bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras)
 {
   // the reference builds the ray lists and throws them away here (ptzray_optimizer.cc:448-452); nothing reads them
@@ -314,30 +348,12 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   // CalReprojError (:960-968)
   init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);
   final_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.final_cost) / summary_.num_residuals);
-  double sum0 = 0, sum1 = 0;
-  std::vector<Mat33> Rc(p.cam_image.size());  // one cv::Rodrigues per camera instead of one per residual
-  for (size_t c = 0; c < Rc.size(); ++c) Rc[c] = Rodrigues({cam[15 * c + 4], cam[15 * c + 5], cam[15 * c + 6]});
-  for (size_t a = 0; a < p.obs_cam.size(); ++a) {
-    double res[2];
-    Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], Rc[p.obs_cam[a]], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
-                 p.obs_uv[2 * a + 1], res);
-    sum0 += res[0] * res[0];
-    sum1 += res[1] * res[1];
-  }
-  final_reproj_error_2d2d_ = std::sqrt((sum0 + sum1) / static_cast<double>(p.obs_cam.size()));
-  if (p.obs3d_cam.empty()) {
-    final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();  // sqrt(0 / 0) in the reference when there are no annotations
-  }
-  else {
-    double s0 = 0, s1 = 0;
-    for (size_t a = 0; a < p.obs3d_cam.size(); ++a) {
-      double res[2];
-      Residual2d3d(&cam[15 * static_cast<size_t>(p.obs3d_cam[a])], tlw, &p.obs3d_xyz[3 * a], p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1], res);
-      s0 += res[0] * res[0];
-      s1 += res[1] * res[1];
-    }
-    final_reproj_error_2d3d_ = std::sqrt((s0 + s1) / static_cast<double>(p.obs3d_cam.size()));
-  }
+  // CalReprojError2d2d / 2d3d (:970-1072) walk every residual on the host: evaluated on first use of the accessors (the
+  // incremental pipeline never reads them), from the solved state kept in packed_
+  p.cam = cam;
+  p.ray = ray;
+  for (int k = 0; k < 6; ++k) p.tlw[k] = tlw[k];
+  errors_ready_ = false;
 
   if (summary_.termination_type != PTZ_CONVERGENCE) return false;  // :482-488
 

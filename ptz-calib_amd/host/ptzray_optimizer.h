@@ -52,8 +52,8 @@ class PTZRayOptimizer {
   bool Solve(std::vector<Camera>& cameras);
   bool Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays);
   double final_reproj_error_all() const { return final_reproj_error_all_; }
-  double final_reproj_error_2d2d() const { return final_reproj_error_2d2d_; }
-  double final_reproj_error_2d3d() const { return final_reproj_error_2d3d_; }
+  double final_reproj_error_2d2d() const { ComputeErrors(); return final_reproj_error_2d2d_; }
+  double final_reproj_error_2d3d() const { ComputeErrors(); return final_reproj_error_2d3d_; }
   void SetSharedIntrinsics(const std::vector<long>& shared_ic_ids);
   static void T_l_w(const double* tlw, Mat33& R_l_w, Vec3& t_l_w);
 
@@ -102,7 +102,10 @@ class PTZRayOptimizer {
   PackedBA packed_;
   std::array<double, 6> tlw_init_{{0, 0, 0, 0, 0, 0}};
   ptz_lm_summary summary_{};
-  double init_reproj_error_all_ = 0, final_reproj_error_all_ = 0, final_reproj_error_2d2d_ = 0, final_reproj_error_2d3d_ = 0;
+  double init_reproj_error_all_ = 0, final_reproj_error_all_ = 0;
+  void ComputeErrors() const;  // unweighted 2D-2D / 2D-3D RMS of the solved state, on first use
+  mutable bool errors_ready_ = true;
+  mutable double final_reproj_error_2d2d_ = 0, final_reproj_error_2d3d_ = 0;
 };
 
 }  // namespace ptzcalib
