@@ -282,36 +282,59 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = 0;
 #pragma unroll
   for (int k = 0; k < NW; ++k) g[k] = 0;
-  for (int q = cp[i] + lane; q < cp[i + 1]; q += 64) {
-    const int a = d.cam_obs[q];
-    const float2 uv = d.obs_uv[a];
-    const int j = d.obs_ray[a];
-    const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
-    double res[2], Jc[2][NW], Jr[2][3];
-    ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
-    const double w = d.ray_w[s.ray_off + j];
-    const double sw = sqrt(w);
-    cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
-    res[0] *= sw; res[1] *= sw;
+  // The W rows of 64 consecutive observations are one contiguous stretch of 64 * WS doubles: every lane parks its row in a
+  // wave-private LDS strip, then the wave stores the stretch with unit-stride lanes -- whole 128-byte lines per store
+  // instruction.  (Lane-private 96-byte row stores fill the lines piecemeal and make the L2 fetch them first.)
+  constexpr int WS = Dims<TYPE>::WS, NT = NW * 3, WP = WS + 1;  // odd LDS pitch
+  __shared__ double wstrip[4][64 * WP];
+  double* ws = wstrip[threadIdx.x >> 6];
+  const int q_end = cp[i + 1];
+  for (int q0 = cp[i]; q0 < q_end; q0 += 64) {
+    const int q = q0 + lane;
+    if (q < q_end) {
+      const int a = d.cam_obs[q];
+      const float2 uv = d.obs_uv[a];
+      const int j = d.obs_ray[a];
+      const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
+      double res[2], Jc[2][NW], Jr[2][3];
+      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
+      const double w = d.ray_w[s.ray_off + j];
+      const double sw = sqrt(w);
+      cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
+      res[0] *= sw; res[1] *= sw;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
+      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
+      {
+        const double* sr = d.scale_r + (size_t)(s.ray_off + j) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+        double* Wl = ws + lane * WP;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+          for (int l = 0; l < 3; ++l) Wl[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+#pragma unroll
+        for (int k = NT; k < WS; ++k) Wl[k] = 0.0;  // row padding
+      }
+      int e = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        g[k] += Jc[0][k] * res[0] + Jc[1][k] * res[1];
+#pragma unroll
+        for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is private to this wave, its lanes run in lock step
     {
-      const double* sr = d.scale_r + (size_t)(s.ray_off + j) * 3;
+      const int n_el = min(64, q_end - q0) * WS;
+      double* Wg = d.W + (size_t)q0 * WS;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
-      double* Wa = d.W + (size_t)q * Dims<TYPE>::WS;
-#pragma unroll
-      for (int k = 0; k < NW; ++k)
-#pragma unroll
-        for (int l = 0; l < 3; ++l) Wa[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+      for (int t = 0; t < WS; ++t) {
+        const int idx = t * 64 + lane;
+        if (idx < n_el) Wg[idx] = ws[(idx / WS) * WP + (idx % WS)];
+      }
     }
-    int e = 0;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) {
-      g[k] += Jc[0][k] * res[0] + Jc[1][k] * res[1];
-#pragma unroll
-      for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
-    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is rewritten in the next trip
   }
   cost = wave_sum(cost);
 #pragma unroll
