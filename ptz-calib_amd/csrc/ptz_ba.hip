@@ -848,6 +848,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     TRY(b->alloc(&d.gfold, (size_t)b->total_cam * NC));
   }
   TRY(b->alloc(&d.W, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
+  TRY(b->alloc(&d.rayrec, (size_t)b->total_ray * 8));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));

@@ -85,6 +85,7 @@ struct Dev {
   double* E;         // [total_ray][6]
   double* z;         // [total_ray][3]
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
+  double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
   double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
   // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
   const float2* o3_uv;  // [total_o3]
@@ -254,6 +255,10 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) d.gr[(size_t)gj * 3 + k] = g[k];
+  {  // the camera pass (next launch) gathers this ray once per observation: one aligned 64-byte record instead of three arrays
+    double* rr = d.rayrec + (size_t)gj * 8;
+    rr[0] = Xr[0]; rr[1] = Xr[1]; rr[2] = Xr[2]; rr[3] = sr[0]; rr[4] = sr[1]; rr[5] = sr[2]; rr[6] = d.ray_w[gj]; rr[7] = 0.0;
+  }
 }
 
 // ---- lin_cam: per-camera blocks -------------------------------------------------------------------------
@@ -275,7 +280,6 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   double cb[CAMBLK];
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
-  const double* rays = cur_ray(d, s, st);
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
@@ -295,19 +299,19 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
       const int a = d.cam_obs[q];
       const float2 uv = d.obs_uv[a];
       const int j = d.obs_ray[a];
-      const double Xr[3] = {rays[(size_t)j * 3], rays[(size_t)j * 3 + 1], rays[(size_t)j * 3 + 2]};
+      const double* rr = d.rayrec + (size_t)(s.ray_off + j) * 8;  // written by k_lin_ray of the same linearisation
+      const double Xr[3] = {rr[0], rr[1], rr[2]};
       double res[2], Jc[2][NW], Jr[2][3];
       ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
-      const double w = d.ray_w[s.ray_off + j];
+      const double w = rr[6];
       const double sw = sqrt(w);
       cost += 0.5 * (w * (res[0] * res[0] + res[1] * res[1]));
       res[0] *= sw; res[1] *= sw;
 #pragma unroll
       for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
       {
-        const double* sr = d.scale_r + (size_t)(s.ray_off + j) * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+        for (int k = 0; k < 3; ++k) { const double m = sw * rr[3 + k]; Jr[0][k] *= m; Jr[1][k] *= m; }
         double* Wl = ws + lane * WP;
 #pragma unroll
         for (int k = 0; k < NW; ++k)
