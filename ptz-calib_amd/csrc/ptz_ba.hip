@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ptz_common.h"
@@ -156,10 +157,19 @@ template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const
 // Many small host arrays -> ONE device block through ONE pinned staging buffer and one copy (a synchronous hipMemcpy from
 // pageable memory costs 10-15 us each whatever its size; a batch has about twenty of them).  Large batches, whose structure
 // would need a staging buffer of more than 64 MB, keep the per-array uploads.
+// std::vector whose resize() leaves trivially-constructible elements uninitialised (the batch-wide observation arrays are
+// sized once and then filled in place by the builder threads; zero-filling 600 MB first costs more than building them)
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
 struct StagedUpload {
   struct Item { const void* src; size_t bytes; const void** dst; };
   std::vector<Item> items;
-  template <typename T> void add(const std::vector<T>& h, const T** dev)
+  template <typename T, typename A> void add(const std::vector<T, A>& h, const T** dev)
   {
     items.push_back({h.data(), sizeof(T) * h.size(), reinterpret_cast<const void**>(dev)});
   }
@@ -533,6 +543,133 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   delete b;
 }
 
+namespace {
+// Camera-pair entry lists of one scene (the off-diagonal blocks of the reduced system): for every ray, every (a, b) with
+// cam(a) > cam(b); a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur).  Independent of
+// every other scene apart from the base offset of its observations, so batches build these lists on several host threads.
+struct PairBuild {
+  std::vector<int> wpos, pci, pcj, pptr, campair;  // pptr: scene-local entry offsets (n_pair + 1)
+  std::vector<int2> ent;
+  int n_pair = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, err = PTZ_OK;
+};
+
+// Where a scene's observation-side arrays go in the batch-wide host arrays (all offsets are prefix sums of the scene sizes,
+// known before any scene is built, so the worker threads write them in place).
+struct ObsDest {
+  float2* uv; int* cam; int* ray; int* camobs; int* camray;  // + obs_off
+  int* rayptr; double* w;                                      // + ray_off (+ scene index for the pointer array)
+  int* camptr;                                                 // + cam_off + scene index
+};
+
+void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest& od, PairBuild& out)
+{
+  std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
+  for (int64_t a = 0; a < p.n_obs; ++a) {
+    od.uv[a] = make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]);
+    od.cam[a] = p.obs_cam[a];
+    od.ray[a] = p.obs_ray[a];
+    ++cnt_ray[p.obs_ray[a] + 1];
+    ++cnt_cam[p.obs_cam[a] + 1];
+  }
+  for (int j = 0; j < p.n_ray; ++j) {
+    if (cnt_ray[j + 1] == 0) { out.err = PTZ_EINVAL; return; }  // every ray has >= 1 observation
+    cnt_ray[j + 1] += cnt_ray[j];
+  }
+  for (int j = 0; j <= p.n_ray; ++j) od.rayptr[j] = obase + cnt_ray[j];
+  for (int j = 0; j < p.n_ray; ++j) od.w[j] = p.ray_weight[j];
+  for (int c = 0; c < p.n_cam; ++c) cnt_cam[c + 1] += cnt_cam[c];
+  {  // camera-major observation lists
+    std::vector<int> fill(cnt_cam.begin(), cnt_cam.end() - 1);
+    for (int64_t a = 0; a < p.n_obs; ++a) {
+      const int slot = fill[p.obs_cam[a]]++;
+      od.camobs[slot] = obase + (int)a;
+      od.camray[slot] = ray_off + p.obs_ray[a];
+    }
+    for (int c = 0; c <= p.n_cam; ++c) od.camptr[c] = obase + cnt_cam[c];
+  }
+  std::vector<int> pos(p.n_obs);
+  {
+    std::vector<int> fill(p.n_cam, 0);
+    for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
+    for (int c = 0; c < p.n_cam; ++c) out.max_cam_obs = std::max(out.max_cam_obs, fill[c]);
+    out.wpos.resize(p.n_obs);
+    for (int64_t a = 0; a < p.n_obs; ++a) out.wpos[a] = obase + cnt_cam[p.obs_cam[a]] + pos[a];
+  }
+  // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
+  // One pass over the rays lists the (a, b) pairs with cam(a) > cam(b) in ray order and counts them per camera pair;
+  // the fill pass then runs over that flat list only.  Observations of a track come camera-ascending from the packing
+  // (track asc, image asc: ptzray_optimizer.cc:801-850), in which case the pairs are simply (a, b < a); any other order
+  // takes the general double loop.
+  const size_t ncc = (size_t)p.n_cam * p.n_cam;
+  std::vector<int> pair_cnt(ncc, 0);
+  std::vector<int> ea, ebq;
+  ea.reserve((size_t)p.n_obs * 4);
+  ebq.reserve((size_t)p.n_obs * 4);
+  for (int j = 0; j < p.n_ray; ++j) {
+    const int r0 = cnt_ray[j], r1 = cnt_ray[j + 1];
+    bool ascending = true;
+    for (int a = r0 + 1; a < r1; ++a) ascending &= p.obs_cam[a] > p.obs_cam[a - 1];
+    if (ascending) {
+      for (int a = r0 + 1; a < r1; ++a) {
+        const size_t row = (size_t)p.obs_cam[a] * p.n_cam;
+        for (int bb = r0; bb < a; ++bb) {
+          ++pair_cnt[row + p.obs_cam[bb]];
+          ea.push_back(a);
+          ebq.push_back(bb);
+        }
+      }
+    }
+    else {
+      for (int a = r0; a < r1; ++a)
+        for (int bb = r0; bb < r1; ++bb) {
+          const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
+          if (ci == cj && a != bb) { out.err = PTZ_EINVAL; return; }  // an image appears once per track (tracks.cc:77)
+          if (ci <= cj) continue;
+          ++pair_cnt[(size_t)ci * p.n_cam + cj];
+          ea.push_back(a);
+          ebq.push_back(bb);
+        }
+    }
+  }
+  const int64_t n_ent = (int64_t)ea.size();
+  if (n_ent > 0x7fffffff) { out.err = PTZ_EINVAL; return; }
+  int npair = 0;
+  std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
+  std::vector<int> pair_fill(ncc, -1);  // next free entry slot of a pair (scene-local)
+  {
+    int run = 0;
+    for (int ci = 0; ci < p.n_cam; ++ci)
+      for (int cj = 0; cj < ci; ++cj) {
+        const int c = pair_cnt[(size_t)ci * p.n_cam + cj];
+        if (c == 0) continue;
+        out.pci.push_back(ci);
+        out.pcj.push_back(cj);
+        out.pptr.push_back(run);
+        if (cam_first[ci] < 0) cam_first[ci] = npair;
+        pair_fill[(size_t)ci * p.n_cam + cj] = run;
+        cam_ent[ci] += c;
+        run += c;
+        ++npair;
+      }
+    out.pptr.push_back(run);
+  }
+  out.ent.resize((size_t)n_ent);
+  for (int64_t e = 0; e < n_ent; ++e) {
+    const int a = ea[e], bb = ebq[e];
+    const int cj = p.obs_cam[bb];
+    const int slot = pair_fill[(size_t)p.obs_cam[a] * p.n_cam + cj]++;
+    out.ent[slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
+  }
+  // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
+  cam_first[p.n_cam] = npair;
+  for (int c = 0; c < p.n_cam; ++c) out.max_cam_ent = std::max(out.max_cam_ent, cam_ent[c]);
+  for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
+  out.campair.assign(cam_first.begin(), cam_first.end());
+  for (int c = 0; c < p.n_cam; ++c) out.max_cam_pair = std::max(out.max_cam_pair, cam_first[c + 1] - cam_first[c]);
+  out.n_pair = npair;
+}
+}  // namespace
+
 int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz_lm_options* opt, ptz_ba_batch** out)
 {
   if (n <= 0 || !problems || !out) return PTZ_EINVAL;
@@ -571,8 +708,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
-  std::vector<float2> h_uv;
-  std::vector<int> h_cam, h_ray, h_rayptr, h_camptr, h_camobs, h_pci, h_pcj, h_pptr, h_wpos, h_camray;
+  RawVec<float2> h_uv;
+  RawVec<int> h_cam, h_ray, h_camobs, h_camray;
+  std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr, h_wpos;
   std::vector<int2> h_ent;
   std::vector<int> h_campair;
   std::vector<double> h_w, h_o3xyz;
@@ -595,6 +733,23 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   if (tot_obs > 0x7fffffff) { delete b; return PTZ_EINVAL; }
   h_uv.reserve(tot_obs); h_cam.reserve(tot_obs); h_ray.reserve(tot_obs); h_camobs.reserve(tot_obs);
+  // the pair lists of the scenes are built a wave at a time on up to 8 host threads (PTZ_BA_HOST_THREADS)
+  std::vector<int> obs_base(n, 0), ray_base(n, 0), cam_base(n, 0);
+  for (int i = 1; i < n; ++i) {
+    obs_base[i] = obs_base[i - 1] + (int)problems[i - 1].n_obs;
+    ray_base[i] = ray_base[i - 1] + problems[i - 1].n_ray;
+    cam_base[i] = cam_base[i - 1] + problems[i - 1].n_cam;
+  }
+  {
+    const size_t tr = (size_t)ray_base[n - 1] + problems[n - 1].n_ray, tc = (size_t)cam_base[n - 1] + problems[n - 1].n_cam;
+    h_uv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
+    h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n);
+  }
+  int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("PTZ_BA_HOST_THREADS")) n_threads = std::max(1, atoi(e));
+  const int wave_scenes = 4 * n_threads;
+  std::vector<PairBuild> wave;
+  int wave_first = 0;
   for (int i = 0; i < n; ++i) {
     const ptz_ba_problem& p = problems[i];
     SceneDev s;
@@ -611,128 +766,49 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       for (int k = 0; k < 3; ++k) h_o3xyz.push_back(p.obs3d_xyz[3 * a + k]);
     }
     b->total_o3 += p.n_obs3d;
-    // observations, ray ranges
-    const double tsa = now_ms();
-    const int obase = s.obs_off;
-    std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
-    for (int64_t a = 0; a < p.n_obs; ++a) {
-      h_uv.push_back(make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]));
-      h_cam.push_back(p.obs_cam[a]);
-      h_ray.push_back(p.obs_ray[a]);
-      ++cnt_ray[p.obs_ray[a] + 1];
-      ++cnt_cam[p.obs_cam[a] + 1];
-    }
-    for (int j = 0; j < p.n_ray; ++j) {
-      if (cnt_ray[j + 1] == 0) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // every ray has >= 1 observation
-      cnt_ray[j + 1] += cnt_ray[j];
-    }
-    for (int j = 0; j <= p.n_ray; ++j) h_rayptr.push_back(obase + cnt_ray[j]);
-    for (int j = 0; j < p.n_ray; ++j) h_w.push_back(p.ray_weight[j]);
-    // camera-major observation lists
-    for (int c = 0; c < p.n_cam; ++c) cnt_cam[c + 1] += cnt_cam[c];
-    {
-      std::vector<int> fill(cnt_cam.begin(), cnt_cam.end() - 1);
-      const size_t base = h_camobs.size();
-      h_camobs.resize(base + p.n_obs);
-      h_camray.resize(base + p.n_obs);
-      for (int64_t a = 0; a < p.n_obs; ++a) {
-        const int slot = fill[p.obs_cam[a]]++;
-        h_camobs[base + slot] = obase + (int)a;
-        h_camray[base + slot] = s.ray_off + p.obs_ray[a];
-      }
-      for (int c = 0; c <= p.n_cam; ++c) h_camptr.push_back(obase + cnt_cam[c]);
-    }
+    // observations, ray ranges, camera-major lists, camera-pair entry lists: built ahead of this loop, a wave of scenes at a
+    // time on several threads (build_pairs); the observation-side arrays are written in place, the pair lists appended here
     const double tsb = now_ms();
-    ts_obs += tsb - tsa;
-    // camera-pair entry lists (off-diagonal blocks): for every ray, every (a, b) with cam(a) > cam(b);
-    // a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur)
     {
-      std::vector<int> pos(p.n_obs);
-      {
-        std::vector<int> fill(p.n_cam, 0);
-        for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
-        for (int c = 0; c < p.n_cam; ++c) b->max_cam_obs = std::max(b->max_cam_obs, fill[c]);
-        for (int64_t a = 0; a < p.n_obs; ++a) h_wpos.push_back(obase + cnt_cam[p.obs_cam[a]] + pos[a]);
-      }
-      // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
-      // One pass over the rays lists the (a, b) pairs with cam(a) > cam(b) in ray order and counts them per camera pair;
-      // the fill pass then runs over that flat list only.  Observations of a track come camera-ascending from the packing
-      // (track asc, image asc: ptzray_optimizer.cc:801-850), in which case the pairs are simply (a, b < a); any other order
-      // takes the general double loop.
-      const size_t ncc = (size_t)p.n_cam * p.n_cam;
-      std::vector<int> pair_cnt(ncc, 0);
-      std::vector<int> ea, ebq;
-      ea.reserve((size_t)p.n_obs * 4);
-      ebq.reserve((size_t)p.n_obs * 4);
-      for (int j = 0; j < p.n_ray; ++j) {
-        const int r0 = cnt_ray[j], r1 = cnt_ray[j + 1];
-        bool ascending = true;
-        for (int a = r0 + 1; a < r1; ++a) ascending &= p.obs_cam[a] > p.obs_cam[a - 1];
-        if (ascending) {
-          for (int a = r0 + 1; a < r1; ++a) {
-            const size_t row = (size_t)p.obs_cam[a] * p.n_cam;
-            for (int bb = r0; bb < a; ++bb) {
-              ++pair_cnt[row + p.obs_cam[bb]];
-              ea.push_back(a);
-              ebq.push_back(bb);
-            }
+      if (i >= wave_first + (int)wave.size()) {
+        wave_first = i;
+        const int wn = std::min(n - i, wave_scenes);
+        wave.assign(wn, PairBuild());
+        auto work = [&](int t0, int step) {
+          for (int k = t0; k < wn; k += step) {
+            const int sidx = wave_first + k;
+            const ObsDest od = {h_uv.data() + obs_base[sidx], h_cam.data() + obs_base[sidx], h_ray.data() + obs_base[sidx],
+                                h_camobs.data() + obs_base[sidx], h_camray.data() + obs_base[sidx],
+                                h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
+                                h_camptr.data() + cam_base[sidx] + sidx};
+            build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k]);
           }
-        }
+        };
+        const int nt = std::min(n_threads, wn);
+        if (nt <= 1) work(0, 1);
         else {
-          for (int a = r0; a < r1; ++a)
-            for (int bb = r0; bb < r1; ++bb) {
-              const int ci = p.obs_cam[a], cj = p.obs_cam[bb];
-              if (ci == cj && a != bb) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image appears once per track (tracks.cc:77)
-              if (ci <= cj) continue;
-              ++pair_cnt[(size_t)ci * p.n_cam + cj];
-              ea.push_back(a);
-              ebq.push_back(bb);
-            }
+          std::vector<std::thread> th;
+          for (int t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
+          work(0, nt);
+          for (auto& x : th) x.join();
         }
       }
-      const int64_t n_ent = (int64_t)ea.size();
-      if ((int64_t)b->total_ent + n_ent > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
-      int npair = 0;
-      std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
-      std::vector<int> pair_fill(ncc, -1);  // next free entry slot of a pair (scene-local)
-      {
-        int run = 0;
-        for (int ci = 0; ci < p.n_cam; ++ci)
-          for (int cj = 0; cj < ci; ++cj) {
-            const int c = pair_cnt[(size_t)ci * p.n_cam + cj];
-            if (c == 0) continue;
-            h_pci.push_back(ci);
-            h_pcj.push_back(cj);
-            h_pptr.push_back(b->total_ent + run);
-            if (cam_first[ci] < 0) cam_first[ci] = npair;
-            pair_fill[(size_t)ci * p.n_cam + cj] = run;
-            cam_ent[ci] += c;
-            run += c;
-            ++npair;
-          }
-        h_pptr.push_back(b->total_ent + run);
-      }
-      {
-        const size_t ebase = h_ent.size();
-        h_ent.resize(ebase + (size_t)n_ent);
-        for (int64_t e = 0; e < n_ent; ++e) {
-          const int a = ea[e], bb = ebq[e];
-          const int cj = p.obs_cam[bb];
-          const int slot = pair_fill[(size_t)p.obs_cam[a] * p.n_cam + cj]++;
-          h_ent[ebase + slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
-        }
-      }
+      PairBuild& pb = wave[i - wave_first];
+      if (pb.err != PTZ_OK || (int64_t)b->total_ent + (int64_t)pb.ent.size() > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+      h_wpos.insert(h_wpos.end(), pb.wpos.begin(), pb.wpos.end());
+      h_pci.insert(h_pci.end(), pb.pci.begin(), pb.pci.end());
+      h_pcj.insert(h_pcj.end(), pb.pcj.begin(), pb.pcj.end());
+      for (int v : pb.pptr) h_pptr.push_back(b->total_ent + v);
+      h_ent.insert(h_ent.end(), pb.ent.begin(), pb.ent.end());
+      h_campair.insert(h_campair.end(), pb.campair.begin(), pb.campair.end());
+      b->max_cam_obs = std::max(b->max_cam_obs, pb.max_cam_obs);
+      b->max_cam_ent = std::max(b->max_cam_ent, pb.max_cam_ent);
+      b->max_cam_pair = std::max(b->max_cam_pair, pb.max_cam_pair);
+      s.n_pair = pb.n_pair;
+      b->total_ent += (int)pb.ent.size();
+      b->total_pair += pb.n_pair;
       ts_ent += now_ms() - tsb;
-      const int64_t n_keys = n_ent;
-      // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
-      cam_first[p.n_cam] = npair;
-      for (int c = 0; c < p.n_cam; ++c) b->max_cam_ent = std::max(b->max_cam_ent, cam_ent[c]);
-      for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
-      for (int c = 0; c <= p.n_cam; ++c) h_campair.push_back(cam_first[c]);
-      for (int c = 0; c < p.n_cam; ++c) b->max_cam_pair = std::max(b->max_cam_pair, cam_first[c + 1] - cam_first[c]);
-      s.n_pair = npair;
-      b->total_ent += (int)n_keys;
-      b->total_pair += npair;
+      pb = PairBuild();  // release this scene's lists
     }
     // shared intrinsics groups (ids are arbitrary integers; members in ascending camera order; groups in order of their
     // first member); a camera alone in its group needs nothing
@@ -749,7 +825,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       for (int c = 0; c < p.n_cam; ++c) b->first_of_group.push_back(b->total_cam + first[c]);
       std::vector<char> counted(p.n_cam, 0);  // group (by first member) already has its counting camera
       for (int c = 0; c < p.n_cam; ++c) {
-        const bool has_res = cnt_cam[c + 1] > cnt_cam[c];
+        const int* camptr_s = h_camptr.data() + cam_base[i] + i;  // filled by build_pairs for this scene
+        const bool has_res = camptr_s[c + 1] > camptr_s[c];
         unsigned char flag = 0;
         if (has_res && !counted[first[c]]) { flag = 1; counted[first[c]] = 1; }
         h_camflag.push_back(flag);
