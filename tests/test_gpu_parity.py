@@ -585,6 +585,21 @@ def test_cpp_krt_optimizer_matches_batch_api(pkg):
             assert np.abs(o.rodrigues(cur[4:7]) - o.rodrigues(cam_w[q, 4:7])).max() < 1e-12
 
 
+def test_ba_host_threads_do_not_change_results(pkg, monkeypatch):
+    """ptz_ba_batch_create builds the per-scene structure on several host threads, a wave of scenes at a time: the batch, and
+    therefore every result, is the same for any thread count (40 ragged scenes = more than one wave at 8 threads)."""
+    scenes = [pkg.synth.make_scene(s % 7, 12 + 3 * (s % 7), 80) for s in range(40)]
+    out = {}
+    for t in ("1", "3", "8"):
+        monkeypatch.setenv("PTZ_BA_HOST_THREADS", t)
+        b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+        out[t] = (summ, cams, rays)
+    for t in ("3", "8"):
+        assert [s["final_cost"] for s in out[t][0]] == [s["final_cost"] for s in out["1"][0]]
+        assert all(np.array_equal(a, c) for a, c in zip(out[t][1], out["1"][1]))
+        assert all(np.array_equal(a, c) for a, c in zip(out[t][2], out["1"][2]))
+
+
 def test_ba_stream_groups_do_not_change_results(pkg, monkeypatch):
     """The batch is split into independent groups on separate HIP streams; results must be bit-identical to a
     single-stream solve (scenes never interact; all reductions are fixed-order)."""
