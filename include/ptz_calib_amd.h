@@ -75,7 +75,8 @@ typedef struct ptz_lm_summary {
   int32_t termination_type;     /* PTZ_CONVERGENCE / PTZ_NO_CONVERGENCE / PTZ_FAILURE */
   int32_t num_iterations;       /* summary.iterations.size() - 1 */
   int32_t num_lm_steps;         /* trust-region loop passes executed (includes the terminating pass) */
-  int32_t num_successful_steps; /* iteration 0 counts as successful, as in Ceres */
+  int32_t num_successful_steps; /* iteration 0 counts as successful (Ceres 2.x convention; whether 1.14 did is unverified here --
+                                   the reference only stores the value in KRTOptimizer::num_iter_, krt_optimizer.cc:396, and never reads it) */
   int32_t num_unsuccessful_steps;
   int32_t num_residuals;        /* scalar residuals */
   int32_t num_linear_solves;

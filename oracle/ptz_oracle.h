@@ -65,7 +65,7 @@ typedef struct {
   int32_t termination_type;      /* ORC_CONVERGENCE / NO_CONVERGENCE / FAILURE */
   int32_t num_iterations;        /* [Ceres] summary.iterations.size() - 1 */
   int32_t num_lm_steps;          /* trust-region loop passes executed (incl. the terminating one) */
-  int32_t num_successful_steps;  /* [Ceres] counts iteration 0 as successful */
+  int32_t num_successful_steps;  /* [Ceres] iteration 0 counted as successful (2.x convention; 1.14 unverified -- the value is never read by the reference) */
   int32_t num_unsuccessful_steps;
   int32_t num_residuals;         /* scalar residuals */
   int32_t num_linear_solves;
