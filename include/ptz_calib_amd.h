@@ -180,6 +180,10 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b);
 int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const double* rhs, double* x, int32_t* fail,
                              int32_t device_id, double* device_ms);
 
+/* Measured FP64 matrix-core rate of the device (v_mfma_f64_16x16x4_f64 from registers, every wave slot busy): the
+ * number the reduced-camera solve is priced against in the roofline reports. */
+int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops);
+
 /* ------------------------------------------------------------------------------------------------
  * Single-view LM, batched over queries
  *   replaces KRTOptimizer::Add2d2dConstraints + Solve (krt_optimizer.cc:265-348, 385-404), the loop

@@ -23,7 +23,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
-           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache"]
+           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak"]
 
 
 class PtzError(RuntimeError):
@@ -282,3 +282,10 @@ def krt_solve_batch_device(n_query, d_match_ptr, d_uv_ref, d_uv_cur, d_cam_ref, 
                                             ptr(d_pts3d), ptr(d_cam_ref), ptr(d_cam_cur), int(factor_type), C.c_double(max_reproj_error),
                                             C.byref(o), ptr(d_summaries), ptr(d_accepted), C.c_void_p(stream) if stream else None),
            "ptz_krt_solve_batch_device")
+
+
+def mfma_f64_peak(device_id=0):
+    """Measured FP64 MFMA rate of the device in TFLOP/s (register-resident v_mfma_f64_16x16x4_f64 loop)."""
+    t = C.c_double()
+    _check(lib().ptz_mfma_f64_peak(int(device_id), C.byref(t)), "ptz_mfma_f64_peak")
+    return t.value

@@ -608,6 +608,58 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 
 }  // namespace ptz
 
+// ---- FP64 MFMA peak micro-benchmark -----------------------------------------------------------------------
+// Every wave keeps eight independent 16x16 accumulators busy with v_mfma_f64_16x16x4_f64 (2048 flop each); nothing but
+// registers is touched inside the loop.  The result is the rate the reduced-camera solve is priced against.
+namespace ptz {
+namespace {
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters)
+{
+  d4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + 1e-9 * threadIdx.x, bq = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[k], 0, 0, 0);
+  }
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sum += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  if (sum == 123.456) out[0] = sum;  // keeps the loop alive; never true
+}
+}  // namespace
+}  // namespace ptz
+
+extern "C" int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops)
+{
+  using namespace ptz;
+  if (!tflops) return PTZ_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
+  PTZ_HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  PTZ_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  double* d_out = nullptr;
+  PTZ_HIP_TRY(hipMalloc(&d_out, sizeof(double)));
+  hipEvent_t e0, e1;
+  PTZ_HIP_TRY(hipEventCreate(&e0));
+  PTZ_HIP_TRY(hipEventCreate(&e1));
+  const int blocks = prop.multiProcessorCount * 8, iters = 20000;
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d_out, 100);  // warm-up
+  PTZ_HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d_out, iters);
+  PTZ_HIP_TRY(hipEventRecord(e1, nullptr));
+  PTZ_HIP_TRY(hipEventSynchronize(e1));
+  PTZ_HIP_TRY(hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)blocks * 4.0 /*waves*/ * iters * 8.0 * 2048.0;  // 16 x 16 x 4 x 2 per instruction
+  *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out);
+  return PTZ_OK;
+}
+
 // ---- C-ABI test / micro-benchmark entry ---------------------------------------------------------------
 extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const double* rhs, double* x,
                                         int32_t* fail, int32_t device_id, double* device_ms)
