@@ -52,6 +52,13 @@ def test_chol_solve_vs_numpy(pkg, n, count):
         assert _rel(x[s], ref) < 1e-9
 
 
+def test_mfma_f64_peak_microbenchmark(pkg):
+    """The FP64 matrix-core rate the factorisation is priced against: a register-resident v_mfma_f64_16x16x4_f64 loop must land
+    between a fifth of and the full datasheet figure (78.6 TFLOP/s) on an MI355X."""
+    t = pkg.api.mfma_f64_peak()
+    assert 15.0 < t < 90.0, t
+
+
 def test_chol_reports_indefinite(pkg):
     n = 100
     A = np.eye(n)[None].copy(); A[0, 50, 50] = -1.0
