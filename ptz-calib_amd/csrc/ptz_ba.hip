@@ -548,8 +548,9 @@ namespace {
 // cam(a) > cam(b); a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur).  Independent of
 // every other scene apart from the base offset of its observations, so batches build these lists on several host threads.
 struct PairBuild {
-  std::vector<int> wpos, pci, pcj, pptr, campair;  // pptr: scene-local entry offsets (n_pair + 1)
-  std::vector<int2> ent;
+  std::vector<int> pci, pcj, pptr;  // pptr: scene-local entry offsets (n_pair + 1)
+  std::vector<int2> ent;            // copied into the batch-wide array (in parallel, per wave) and released
+  int64_t n_ent = 0;
   int n_pair = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, err = PTZ_OK;
 };
 
@@ -558,7 +559,8 @@ struct PairBuild {
 struct ObsDest {
   float2* uv; int* cam; int* ray; int* camobs; int* camray;  // + obs_off
   int* rayptr; double* w;                                      // + ray_off (+ scene index for the pointer array)
-  int* camptr;                                                 // + cam_off + scene index
+  int* camptr; int* campair;                                   // + cam_off + scene index
+  int* wpos;                                                   // + obs_off
 };
 
 void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest& od, PairBuild& out)
@@ -592,8 +594,7 @@ void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest&
     std::vector<int> fill(p.n_cam, 0);
     for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
     for (int c = 0; c < p.n_cam; ++c) out.max_cam_obs = std::max(out.max_cam_obs, fill[c]);
-    out.wpos.resize(p.n_obs);
-    for (int64_t a = 0; a < p.n_obs; ++a) out.wpos[a] = obase + cnt_cam[p.obs_cam[a]] + pos[a];
+    for (int64_t a = 0; a < p.n_obs; ++a) od.wpos[a] = obase + cnt_cam[p.obs_cam[a]] + pos[a];
   }
   // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
   // One pass over the rays lists the (a, b) pairs with cam(a) > cam(b) in ray order and counts them per camera pair;
@@ -664,9 +665,10 @@ void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest&
   cam_first[p.n_cam] = npair;
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_ent = std::max(out.max_cam_ent, cam_ent[c]);
   for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
-  out.campair.assign(cam_first.begin(), cam_first.end());
+  for (int c = 0; c <= p.n_cam; ++c) od.campair[c] = cam_first[c];
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_pair = std::max(out.max_cam_pair, cam_first[c + 1] - cam_first[c]);
   out.n_pair = npair;
+  out.n_ent = n_ent;
 }
 }  // namespace
 
@@ -709,9 +711,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
   RawVec<float2> h_uv;
-  RawVec<int> h_cam, h_ray, h_camobs, h_camray;
-  std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr, h_wpos;
-  std::vector<int2> h_ent;
+  RawVec<int> h_cam, h_ray, h_camobs, h_camray, h_wpos;
+  std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr;
+  RawVec<int2> h_ent;
   std::vector<int> h_campair;
   std::vector<double> h_w, h_o3xyz;
   std::vector<float2> h_o3uv;
@@ -743,7 +745,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   {
     const size_t tr = (size_t)ray_base[n - 1] + problems[n - 1].n_ray, tc = (size_t)cam_base[n - 1] + problems[n - 1].n_cam;
     h_uv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
-    h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n);
+    h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n); h_campair.resize(tc + n); h_wpos.resize(tot_obs);
   }
   int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("PTZ_BA_HOST_THREADS")) n_threads = std::max(1, atoi(e));
@@ -780,32 +782,44 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
             const ObsDest od = {h_uv.data() + obs_base[sidx], h_cam.data() + obs_base[sidx], h_ray.data() + obs_base[sidx],
                                 h_camobs.data() + obs_base[sidx], h_camray.data() + obs_base[sidx],
                                 h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
-                                h_camptr.data() + cam_base[sidx] + sidx};
+                                h_camptr.data() + cam_base[sidx] + sidx, h_campair.data() + cam_base[sidx] + sidx,
+                                h_wpos.data() + obs_base[sidx]};
             build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k]);
           }
         };
         const int nt = std::min(n_threads, wn);
-        if (nt <= 1) work(0, 1);
-        else {
+        auto run = [&](auto&& fn) {
+          if (nt <= 1) { fn(0, 1); return; }
           std::vector<std::thread> th;
-          for (int t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
-          work(0, nt);
+          for (int t = 1; t < nt; ++t) th.emplace_back(fn, t, nt);
+          fn(0, nt);
           for (auto& x : th) x.join();
-        }
+        };
+        run(work);
+        // the entry lists of the wave go into the batch-wide array in one resize and a parallel copy
+        std::vector<size_t> ent_at(wn);
+        size_t at = h_ent.size();
+        bool wave_ok = true;
+        for (int k = 0; k < wn; ++k) { ent_at[k] = at; at += wave[k].ent.size(); wave_ok &= wave[k].err == PTZ_OK; }
+        if (!wave_ok || at > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+        h_ent.resize(at);
+        run([&](int t0, int step) {
+          for (int k = t0; k < wn; k += step) {
+            if (!wave[k].ent.empty()) memcpy(h_ent.data() + ent_at[k], wave[k].ent.data(), sizeof(int2) * wave[k].ent.size());
+            std::vector<int2>().swap(wave[k].ent);
+          }
+        });
       }
       PairBuild& pb = wave[i - wave_first];
-      if (pb.err != PTZ_OK || (int64_t)b->total_ent + (int64_t)pb.ent.size() > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
-      h_wpos.insert(h_wpos.end(), pb.wpos.begin(), pb.wpos.end());
+      if (pb.err != PTZ_OK || (int64_t)b->total_ent + pb.n_ent > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
       h_pci.insert(h_pci.end(), pb.pci.begin(), pb.pci.end());
       h_pcj.insert(h_pcj.end(), pb.pcj.begin(), pb.pcj.end());
       for (int v : pb.pptr) h_pptr.push_back(b->total_ent + v);
-      h_ent.insert(h_ent.end(), pb.ent.begin(), pb.ent.end());
-      h_campair.insert(h_campair.end(), pb.campair.begin(), pb.campair.end());
       b->max_cam_obs = std::max(b->max_cam_obs, pb.max_cam_obs);
       b->max_cam_ent = std::max(b->max_cam_ent, pb.max_cam_ent);
       b->max_cam_pair = std::max(b->max_cam_pair, pb.max_cam_pair);
       s.n_pair = pb.n_pair;
-      b->total_ent += (int)pb.ent.size();
+      b->total_ent += (int)pb.n_ent;
       b->total_pair += pb.n_pair;
       ts_ent += now_ms() - tsb;
       pb = PairBuild();  // release this scene's lists
