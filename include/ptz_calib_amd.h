@@ -174,6 +174,14 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
  * overwrites the ray part of the stored initial state from the stored cameras. */
 int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b);
 
+/* n independent problems over the devices device_ids[0 .. n_devices) of one node, from one process: scenes are dealt
+ * longest-first to the least loaded device, one host thread per device creates / solves / reads back its own batch
+ * (replaces the sequential scene loops of the reference's scripts, run_ptzba_synthetic.sh:4-13, run_ptzba_worldcup14.sh).
+ * cam [15 * sum n_cam], ray [3 * sum n_ray], tlw [6 * n] or NULL: in = initial values, out = solutions, all in problem
+ * order; summaries [n] or NULL.  opt->device_id is ignored.  No collective is involved: the scenes never interact. */
+int32_t ptz_ba_solve_sharded(int32_t n, const ptz_ba_problem* problems, double* cam, double* ray, double* tlw,
+                             const int32_t* device_ids, int32_t n_devices, const ptz_lm_options* opt, ptz_lm_summary* summaries);
+
 /* Dense SPD solve used for the reduced camera system, exposed for parity tests and micro-benchmarks:
  * solves A x = rhs for `count` independent n x n systems (host, row-major, lower triangle read).
  * Returns per-system status in fail[count] (1 = not positive definite). */

@@ -23,7 +23,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
-           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak"]
+           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded"]
 
 
 class PtzError(RuntimeError):
@@ -289,3 +289,25 @@ def mfma_f64_peak(device_id=0):
     t = C.c_double()
     _check(lib().ptz_mfma_f64_peak(int(device_id), C.byref(t)), "ptz_mfma_f64_peak")
     return t.value
+
+
+def ba_solve_sharded(scenes, device_ids, **opt):
+    """ptz_ba_solve_sharded: many scenes over several devices from this one process.  Returns (cams, rays, summaries)."""
+    keep = []
+    n = len(scenes)
+    probs = (BaProblem * n)(*[_pack_problem(s, keep) for s in scenes])
+    o = default_options(**opt)
+    cam = np.ascontiguousarray(np.concatenate([s.cam_init for s in scenes]), dtype=np.float64)
+    ray = np.ascontiguousarray(np.concatenate([s.ray_init for s in scenes]), dtype=np.float64)
+    has_tlw = any(getattr(s, "tlw_init", None) is not None for s in scenes)
+    tlw = np.ascontiguousarray(np.stack([getattr(s, "tlw_init", None) if getattr(s, "tlw_init", None) is not None else np.zeros(6)
+                                         for s in scenes]), dtype=np.float64) if has_tlw else None
+    dev = np.ascontiguousarray(device_ids, dtype=np.int32)
+    summ = (LmSummary * n)()
+    _check(lib().ptz_ba_solve_sharded(n, probs, _p(cam), _p(ray), _p(tlw) if tlw is not None else None, _p(dev), len(dev), C.byref(o), summ),
+           "ptz_ba_solve_sharded")
+    co = np.concatenate([[0], np.cumsum([s.n_cam for s in scenes])])
+    ro = np.concatenate([[0], np.cumsum([s.n_ray for s in scenes])])
+    cams = [cam[co[i]:co[i + 1]] for i in range(n)]
+    rays = [ray[ro[i]:ro[i + 1]] for i in range(n)]
+    return cams, rays, [s.as_dict() for s in summ]

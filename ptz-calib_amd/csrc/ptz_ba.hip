@@ -1254,4 +1254,75 @@ int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* 
   return rc;
 }
 
+// Many scenes over several devices of one node, from one process: scenes are dealt longest-first to the least loaded device
+// (they never interact -- run_ptzba_synthetic.sh:4-13 runs them as separate processes), every device gets one host thread
+// that creates, solves and reads back its own batch, and the results are scattered back into the caller's arrays.  No
+// collective: there is nothing to exchange.
+int32_t ptz_ba_solve_sharded(int32_t n, const ptz_ba_problem* problems, double* cam, double* ray, double* tlw,
+                             const int32_t* device_ids, int32_t n_devices, const ptz_lm_options* opt, ptz_lm_summary* summaries)
+{
+  if (n <= 0 || !problems || !cam || !ray || !device_ids || n_devices <= 0) return PTZ_EINVAL;
+  ptz_lm_options base;
+  if (opt) base = *opt; else ptz_lm_options_default(&base);
+  std::vector<size_t> cam_off(n + 1, 0), ray_off(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    if (problems[i].n_cam <= 0 || problems[i].n_ray <= 0) return PTZ_EINVAL;
+    cam_off[i + 1] = cam_off[i] + (size_t)problems[i].n_cam;
+    ray_off[i + 1] = ray_off[i] + (size_t)problems[i].n_ray;
+  }
+  // longest-first greedy assignment by observation count
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int bq) { return problems[a].n_obs > problems[bq].n_obs; });
+  std::vector<std::vector<int>> shard(n_devices);
+  std::vector<int64_t> load(n_devices, 0);
+  for (int i : order) {
+    int best = 0;
+    for (int dv = 1; dv < n_devices; ++dv) if (load[dv] < load[best]) best = dv;
+    shard[best].push_back(i);
+    load[best] += problems[i].n_obs;
+  }
+  std::vector<int> rcs(n_devices, PTZ_OK);
+  auto run = [&](int dv) {
+    std::vector<int>& ids = shard[dv];
+    if (ids.empty()) return;
+    std::sort(ids.begin(), ids.end());  // problem order inside the shard
+    std::vector<ptz_ba_problem> probs;
+    std::vector<double> c, r, t;
+    for (int i : ids) {
+      probs.push_back(problems[i]);
+      c.insert(c.end(), cam + 15 * cam_off[i], cam + 15 * cam_off[i + 1]);
+      r.insert(r.end(), ray + 3 * ray_off[i], ray + 3 * ray_off[i + 1]);
+      if (tlw) t.insert(t.end(), tlw + 6 * (size_t)i, tlw + 6 * (size_t)(i + 1));
+    }
+    ptz_lm_options o = base;
+    o.device_id = device_ids[dv];
+    ptz_ba_batch* b = nullptr;
+    int rc = ptz_ba_batch_create((int32_t)ids.size(), probs.data(), &o, &b);
+    std::vector<ptz_lm_summary> summ(ids.size());
+    if (!rc) rc = ptz_ba_batch_set_state(b, c.data(), r.data(), tlw ? t.data() : nullptr);
+    if (!rc) rc = ptz_ba_batch_solve(b, summ.data());
+    if (!rc) rc = ptz_ba_batch_get_state(b, c.data(), r.data(), tlw ? t.data() : nullptr);
+    if (b) ptz_ba_batch_destroy(b);
+    rcs[dv] = rc;
+    if (rc) return;
+    size_t co = 0, ro = 0;
+    for (size_t k = 0; k < ids.size(); ++k) {
+      const int i = ids[k];
+      const size_t nc = (size_t)problems[i].n_cam, nr = (size_t)problems[i].n_ray;
+      memcpy(cam + 15 * cam_off[i], c.data() + 15 * co, sizeof(double) * 15 * nc);
+      memcpy(ray + 3 * ray_off[i], r.data() + 3 * ro, sizeof(double) * 3 * nr);
+      if (tlw) memcpy(tlw + 6 * (size_t)i, t.data() + 6 * k, sizeof(double) * 6);
+      if (summaries) summaries[i] = summ[k];
+      co += nc; ro += nr;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int dv = 1; dv < n_devices; ++dv) th.emplace_back(run, dv);
+  run(0);
+  for (auto& x : th) x.join();
+  for (int rc : rcs) if (rc) return rc;
+  return PTZ_OK;
+}
+
 }  // extern "C"

@@ -71,6 +71,12 @@ def test_validation_precedes_device_and_no_cpu_fallback(pkg, scene_c1):
         with pytest.raises(api.PtzError) as e:
             api.krt_solve_batch(rb)
         assert e.value.code == -2
+        with pytest.raises(api.PtzError) as e:
+            api.ba_solve_sharded([scene_c1, scene_c1], [0, 1])
+        assert e.value.code == -2
+        with pytest.raises(api.PtzError) as e:
+            api.mfma_f64_peak()
+        assert e.value.code == -2
 
 
 def test_product_package_never_imports_oracle():

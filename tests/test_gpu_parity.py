@@ -592,6 +592,21 @@ def test_cpp_krt_optimizer_matches_batch_api(pkg):
             assert np.abs(o.rodrigues(cur[4:7]) - o.rodrigues(cam_w[q, 4:7])).max() < 1e-12
 
 
+def test_ba_solve_sharded_matches_one_batch(pkg):
+    """ptz_ba_solve_sharded: scenes dealt over a device list, one host thread and one batch per entry.  With the one GPU of
+    this box listed three times the three shards run concurrently on it; every scene must come back bit-identical to the
+    single-batch solve, in problem order."""
+    scenes = [pkg.synth.make_scene(s, 10 + 3 * (s % 5), 60 + 10 * (s % 3)) for s in range(11)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); want_s = b.solve(); want_c, want_r = b.get_state(); b.close()
+    for devs in ([0], [0, 0, 0]):
+        cams, rays, summ = pkg.api.ba_solve_sharded(scenes, devs)
+        for i in range(len(scenes)):
+            assert summ[i]["num_iterations"] == want_s[i]["num_iterations"] and summ[i]["final_cost"] == want_s[i]["final_cost"]
+            assert np.array_equal(cams[i], want_c[i]) and np.array_equal(rays[i], want_r[i])
+    with pytest.raises(pkg.api.PtzError):
+        pkg.api.ba_solve_sharded(scenes, [0, 97])  # no such device
+
+
 def test_ba_host_threads_do_not_change_results(pkg, monkeypatch):
     """ptz_ba_batch_create builds the per-scene structure on several host threads, a wave of scenes at a time: the batch, and
     therefore every result, is the same for any thread count (40 ragged scenes = more than one wave at 8 threads)."""
