@@ -228,6 +228,14 @@ int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_match_ptr, 
                                    const double* d_cam_ref, double* d_cam_cur, int32_t factor_type, double max_reproj_error,
                                    const ptz_lm_options* opt, ptz_lm_summary* d_summaries, int32_t* d_accepted, void* hip_stream);
 
+/* The queries over the devices device_ids[0 .. n_devices) of one node, from one process: contiguous chunks of about equal
+ * total match count, one host thread per device, results written into the caller's arrays in query order.  Host pointers
+ * as in ptz_krt_solve_batch_2d3d (point_ptr = NULL: no 2D-3D constraints); opt->device_id is ignored. */
+int32_t ptz_krt_solve_batch_sharded(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                                    const int64_t* point_ptr, const float* pts2d, const double* pts3d, const double* cam_ref,
+                                    double* cam_cur, int32_t factor_type, double max_reproj_error, const int32_t* device_ids,
+                                    int32_t n_devices, const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted);
+
 #ifdef __cplusplus
 }
 #endif

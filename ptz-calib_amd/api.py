@@ -23,7 +23,8 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
-           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded"]
+           "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
+           "ptz_krt_solve_batch_sharded"]
 
 
 class PtzError(RuntimeError):
@@ -311,3 +312,27 @@ def ba_solve_sharded(scenes, device_ids, **opt):
     cams = [cam[co[i]:co[i + 1]] for i in range(n)]
     rays = [ray[ro[i]:ro[i + 1]] for i in range(n)]
     return cams, rays, [s.as_dict() for s in summ]
+
+
+def krt_solve_batch_sharded(batch, device_ids, max_reproj_error=100.0, **opt):
+    """ptz_krt_solve_batch_sharded: the queries of `batch` over several devices from this one process."""
+    o = default_options(**opt)
+    n = batch.n_query
+    ptr = np.ascontiguousarray(batch.match_ptr, dtype=np.int64)
+    uvr = np.ascontiguousarray(batch.uv_ref, dtype=np.float32)
+    uvc = np.ascontiguousarray(batch.uv_cur, dtype=np.float32)
+    cref = np.ascontiguousarray(batch.cam_ref, dtype=np.float64)
+    ccur = np.array(batch.cam_init, dtype=np.float64, order="C").copy()
+    pp = p2 = p3 = None
+    if getattr(batch, "point_ptr", None) is not None:
+        pp = np.ascontiguousarray(batch.point_ptr, dtype=np.int64)
+        p2 = np.ascontiguousarray(batch.pts2d, dtype=np.float32)
+        p3 = np.ascontiguousarray(batch.pts3d, dtype=np.float64)
+    dev = np.ascontiguousarray(device_ids, dtype=np.int32)
+    summ = (LmSummary * n)()
+    acc = np.zeros(n, dtype=np.int32)
+    _check(lib().ptz_krt_solve_batch_sharded(n, _p(ptr), _p(uvr), _p(uvc), _p(pp) if pp is not None else None,
+                                             _p(p2) if p2 is not None else None, _p(p3) if p3 is not None else None, _p(cref), _p(ccur),
+                                             batch.factor_type, C.c_double(max_reproj_error), _p(dev), len(dev), C.byref(o), summ, _p(acc)),
+           "ptz_krt_solve_batch_sharded")
+    return ccur, [s.as_dict() for s in summ], acc

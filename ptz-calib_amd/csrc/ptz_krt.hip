@@ -11,6 +11,8 @@
 //   damped normal equations redundantly in registers.  DENSE_QR on [J; D] and Cholesky on J^T J + D^2
 //   give the same step up to round-off (the Jacobi-scaled 4-/5-column Jacobian is well conditioned).
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "ptz_common.h"
@@ -575,3 +577,49 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   if (device_ms) *device_ms = ms;
   return PTZ_OK;
 }
+
+// Queries over several devices of one node, from one process: contiguous chunks of (nearly) equal total match count, one host
+// thread per device, results written straight into the caller's arrays (the queries are independent, run_ptz_reloc.cc:68).
+extern "C" int32_t ptz_krt_solve_batch_sharded(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                                               const int64_t* point_ptr, const float* pts2d, const double* pts3d,
+                                               const double* cam_ref, double* cam_cur, int32_t factor_type, double max_reproj_error,
+                                               const int32_t* device_ids, int32_t n_devices, const ptz_lm_options* opt,
+                                               ptz_lm_summary* summaries, int32_t* accepted)
+{
+  if (n_query <= 0 || !match_ptr || !device_ids || n_devices <= 0 || !summaries || !accepted) return PTZ_EINVAL;
+  ptz_lm_options base;
+  if (opt) base = *opt; else ptz_lm_options_default(&base);
+  const int nd = std::min(n_devices, n_query);
+  // chunk boundaries: query index at which the running match count passes k / nd of the total
+  std::vector<int> cut(nd + 1, 0);
+  cut[nd] = n_query;
+  const int64_t total = match_ptr[n_query] - match_ptr[0];
+  for (int k = 1; k < nd; ++k) {
+    const int64_t want = match_ptr[0] + total * k / nd;
+    int q = (int)(std::lower_bound(match_ptr, match_ptr + n_query + 1, want) - match_ptr);
+    cut[k] = std::min(std::max(q, cut[k - 1] + 1), n_query - (nd - k));
+  }
+  std::vector<int> rcs(nd, PTZ_OK);
+  auto run = [&](int k) {
+    const int q0 = cut[k], nq = cut[k + 1] - cut[k];
+    std::vector<int64_t> mp(nq + 1), pp;
+    for (int q = 0; q <= nq; ++q) mp[q] = match_ptr[q0 + q] - match_ptr[q0];
+    if (point_ptr) {
+      pp.resize(nq + 1);
+      for (int q = 0; q <= nq; ++q) pp[q] = point_ptr[q0 + q] - point_ptr[q0];
+    }
+    ptz_lm_options o = base;
+    o.device_id = device_ids[k];
+    rcs[k] = ptz_krt_solve_batch_2d3d(nq, mp.data(), uv_ref + 2 * match_ptr[q0], uv_cur + 2 * match_ptr[q0],
+                                      point_ptr ? pp.data() : nullptr, point_ptr ? pts2d + 2 * point_ptr[q0] : nullptr,
+                                      point_ptr ? pts3d + 3 * point_ptr[q0] : nullptr, cam_ref + 15 * (size_t)q0, cam_cur + 15 * (size_t)q0,
+                                      factor_type, max_reproj_error, &o, summaries + q0, accepted + q0, nullptr);
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < nd; ++k) th.emplace_back(run, k);
+  run(0);
+  for (auto& x : th) x.join();
+  for (int rc : rcs) if (rc) return rc;
+  return PTZ_OK;
+}
+

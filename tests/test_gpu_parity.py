@@ -506,6 +506,22 @@ def test_krt_device_resident_entry_matches_host_entry(with_points):
     assert r.returncode == 0 and "device entry ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_krt_solve_sharded_matches_one_launch(pkg):
+    """ptz_krt_solve_batch_sharded: ragged queries (with 2D-3D constraints) cut into chunks of about equal match count, one
+    host thread per listed device -- here the same GPU four times; bit-identical to the single launch, in query order."""
+    rb = pkg.synth.add_reloc_points(pkg.synth.make_reloc_batch(37, 64, seed_id=12, factor_type=1), n_pt=6)
+    keep = [(7 * q) % 60 + 5 for q in range(rb.n_query)]
+    idx = np.concatenate([np.arange(rb.match_ptr[q], rb.match_ptr[q] + k) for q, k in enumerate(keep)])
+    rb.uv_ref, rb.uv_cur = rb.uv_ref[idx], rb.uv_cur[idx]
+    rb.match_ptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    want_cam, want_summ, want_acc, _ = pkg.api.krt_solve_batch(rb)
+    for devs in ([0], [0, 0, 0, 0]):
+        cam, summ, acc = pkg.api.krt_solve_batch_sharded(rb, devs)
+        assert np.array_equal(acc, want_acc) and np.array_equal(cam, want_cam)
+        assert [s["num_iterations"] for s in summ] == [s["num_iterations"] for s in want_summ]
+        assert [s["num_residuals"] for s in summ] == [s["num_residuals"] for s in want_summ]
+
+
 def test_krt_ragged_and_degenerate(pkg, orc):
     """Ragged match counts, including a query with too few matches to constrain 4 parameters."""
     rb = pkg.synth.make_reloc_batch(6, 64, seed_id=9)
