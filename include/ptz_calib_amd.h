@@ -192,6 +192,9 @@ int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const do
  * number the reduced-camera solve is priced against in the roofline reports. */
 int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops);
 
+/* Measured HBM rates of the device in GB/s: streaming read of 4 GB, and copy of 4 GB counted as read + write. */
+int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps);
+
 /* ------------------------------------------------------------------------------------------------
  * Single-view LM, batched over queries
  *   replaces KRTOptimizer::Add2d2dConstraints + Solve (krt_optimizer.cc:265-348, 385-404), the loop

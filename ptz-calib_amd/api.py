@@ -24,7 +24,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
-           "ptz_krt_solve_batch_sharded"]
+           "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth"]
 
 
 class PtzError(RuntimeError):
@@ -336,3 +336,10 @@ def krt_solve_batch_sharded(batch, device_ids, max_reproj_error=100.0, **opt):
                                              batch.factor_type, C.c_double(max_reproj_error), _p(dev), len(dev), C.byref(o), summ, _p(acc)),
            "ptz_krt_solve_batch_sharded")
     return ccur, [s.as_dict() for s in summ], acc
+
+
+def hbm_bandwidth(device_id=0):
+    """Measured HBM rates in GB/s: (streaming read, copy counted as read + write)."""
+    r, c = C.c_double(), C.c_double()
+    _check(lib().ptz_hbm_bandwidth(int(device_id), C.byref(r), C.byref(c)), "ptz_hbm_bandwidth")
+    return r.value, c.value

@@ -660,6 +660,69 @@ extern "C" int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops)
   return PTZ_OK;
 }
 
+// ---- HBM bandwidth micro-benchmark ------------------------------------------------------------------------
+// Streaming read (16 bytes per lane per load, sum kept in registers) and streaming copy over a buffer far larger than the
+// 256 MB memory-side cache: the rates the HBM-bound kernels are held against.
+namespace ptz {
+namespace {
+__global__ __launch_bounds__(256) void hbm_read_kernel(const double2* __restrict__ src, size_t n, double* out)
+{
+  double acc = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const double2 v = src[i]; acc += v.x + v.y; }
+  if (acc == 123.456) out[0] = acc;  // never true: keeps the loads alive
+}
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+}  // namespace ptz
+
+extern "C" int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps)
+{
+  using namespace ptz;
+  if (!read_gbps || !copy_gbps) return PTZ_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
+  PTZ_HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  PTZ_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  const size_t bytes = (size_t)4 << 30, n = bytes / sizeof(double2);
+  double2 *a = nullptr, *bq = nullptr;
+  double* d_out = nullptr;
+  PTZ_HIP_TRY(hipMalloc(&a, bytes));
+  if (hipMalloc(&bq, bytes) != hipSuccess) { (void)hipFree(a); return PTZ_ENOMEM; }
+  PTZ_HIP_TRY(hipMalloc(&d_out, sizeof(double)));
+  PTZ_HIP_TRY(hipMemset(a, 0, bytes));
+  PTZ_HIP_TRY(hipMemset(bq, 0, bytes));
+  hipEvent_t e0, e1;
+  PTZ_HIP_TRY(hipEventCreate(&e0));
+  PTZ_HIP_TRY(hipEventCreate(&e1));
+  const int blocks = prop.multiProcessorCount * 16;
+  float ms = 0, best_r = 1e30f, best_c = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    PTZ_HIP_TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(hbm_read_kernel, dim3(blocks), dim3(256), 0, nullptr, a, n, d_out);
+    PTZ_HIP_TRY(hipEventRecord(e1, nullptr));
+    PTZ_HIP_TRY(hipEventSynchronize(e1));
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best_r) best_r = ms;
+    PTZ_HIP_TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, a, bq, n);
+    PTZ_HIP_TRY(hipEventRecord(e1, nullptr));
+    PTZ_HIP_TRY(hipEventSynchronize(e1));
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best_c) best_c = ms;
+  }
+  PTZ_HIP_TRY(hipGetLastError());
+  *read_gbps = (double)bytes / (best_r * 1e-3) / 1e9;
+  *copy_gbps = 2.0 * (double)bytes / (best_c * 1e-3) / 1e9;  // read + write
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(bq); (void)hipFree(d_out);
+  return PTZ_OK;
+}
+
 // ---- C-ABI test / micro-benchmark entry ---------------------------------------------------------------
 extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const double* rhs, double* x,
                                         int32_t* fail, int32_t device_id, double* device_ms)

@@ -77,6 +77,9 @@ def test_validation_precedes_device_and_no_cpu_fallback(pkg, scene_c1):
         with pytest.raises(api.PtzError) as e:
             api.mfma_f64_peak()
         assert e.value.code == -2
+        with pytest.raises(api.PtzError) as e:
+            api.hbm_bandwidth()
+        assert e.value.code == -2
 
 
 def test_product_package_never_imports_oracle():

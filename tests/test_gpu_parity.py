@@ -59,6 +59,12 @@ def test_mfma_f64_peak_microbenchmark(pkg):
     assert 15.0 < t < 90.0, t
 
 
+def test_hbm_bandwidth_microbenchmark(pkg):
+    """Streaming read / copy rates the HBM-bound kernels are held against: between 2 and 8.5 TB/s on an MI355X."""
+    r, c = pkg.api.hbm_bandwidth()
+    assert 2000.0 < r < 8500.0 and 2000.0 < c < 8500.0, (r, c)
+
+
 def test_chol_reports_indefinite(pkg):
     n = 100
     A = np.eye(n)[None].copy(); A[0, 50, 50] = -1.0
