@@ -234,6 +234,13 @@ def main():
                     else f"PTZ_BA_STREAMS={os.environ['PTZ_BA_STREAMS']} from the environment, rank 0 only, profiling off")
             out["default_two_groups"] = {"lm_iterations_per_s": sum(s["num_lm_steps"] for s in s2) / d2, "ms_per_solve": 1e3 * d2,
                                          "note": note}
+        if extras:  # what this device sustains in the two units the roofline uses (micro-benchmarks of the library, ~1 s)
+            try:
+                rd, cp = pkg.api.hbm_bandwidth(local_rank)
+                out["measured_peaks"] = {"hbm_read_GBps": rd, "hbm_copy_GBps": cp, "mfma_f64_TFLOPs": pkg.api.mfma_f64_peak(local_rank),
+                                         "note": "streaming read / copy of 4 GB; register-resident v_mfma_f64_16x16x4_f64 loop"}
+            except pkg.api.PtzError:
+                pass
         if extras:  # one rig alone (BASELINE configs[1]): latency-bound, reported beside the batch figure
             b1 = pkg.api.BaBatch([base[0]], device_id=local_rank)
             b1.set_state(); b1.solve()
