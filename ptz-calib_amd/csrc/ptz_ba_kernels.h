@@ -1037,7 +1037,20 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
   double* scratch = dct + s.n_cam * DCS;     // [16]
   stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam);
   stage_rows<CANDBLK, CDS>(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam);
-  stage_rows<NC, DCS>(d.dc + (size_t)s.cam_off * NC, dct, s.n_cam);
+  __syncthreads();
+  // per camera: the scaled step of its 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir)
+  for (int c = threadIdx.x; c < s.n_cam; c += RAY_BLOCK) {
+    const double* cbc = tab + c * CBS;
+    const double* dcg = d.dc + (size_t)(s.cam_off + c) * NC;
+    double sv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * dcg[Dims<TYPE>::pos(k)];
+#pragma unroll
+    for (int k = 0; k < NW - 3; ++k) dct[c * DCS + k] = sv[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      dct[c * DCS + NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
+  }
   __syncthreads();
   const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
   double mcc = 0, cost = 0;
@@ -1061,11 +1074,9 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
       const double* cb = tab + ci * CBS;
-      double res[2], Jc[2][NW], Jr[2][3];
-      ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
-      double m0 = 0, m1 = 0;
-#pragma unroll
-      for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)] * dct[ci * DCS + Dims<TYPE>::pos(k)]; m0 += Jc[0][k] * m; m1 += Jc[1][k] * m; }
+      double res[2], pd[2], Jr[2][3];
+      ba_step_dir<F>(cb, Xr, uv.x, uv.y, dct + ci * DCS, dct + ci * DCS + (NW - 3), res, pd, Jr);
+      const double m0 = sw * pd[0], m1 = sw * pd[1];
       s1 += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);

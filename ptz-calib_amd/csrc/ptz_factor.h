@@ -256,6 +256,70 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   }
 }
 
+// Residual, ray Jacobian and the camera-side DIRECTIONAL derivative p = Jc v of one observation, for a camera step v given as
+// its intrinsic components sv[NC - 3] (in the column order of ba_linearize) and om = Jl v_rot: the three rotation columns
+// -M (Jl[:,k] x P) collapse into -M (om x P), one cross product instead of three.  Same projection arithmetic as ba_linearize.
+template <int TYPE>
+PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, const double* sv, const double om[3], double res[2],
+                        double p[2], double Jr[2][3])
+{
+  const double* R = cb + CB_R;
+  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
+  const double fy = TYPE == 2 ? cb[CB_FY] : f;
+  double Xn[3], inv_n = 1.0;
+  if (TYPE != 1) {
+    const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+    inv_n = 1.0 / n;
+    Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
+  }
+  else {
+    Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2];
+  }
+  const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
+  const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
+  const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
+  if (TYPE == 1 && Pz < 0) {
+    res[0] = 1000000.0; res[1] = 1000000.0;
+    p[0] = 0; p[1] = 0;
+    for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
+    return;
+  }
+  const double iz = 1.0 / Pz;
+  const double x = Px / Pz, y = Py / Pz;
+  double xd = x, yd = y;
+  double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
+  if (TYPE == 0) {
+    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
+    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+  }
+  else {
+    brown(x, y, cb + CB_K, xd, yd);
+    brown_jac(x, y, cb + CB_K, B, dk1);
+    res[0] = (double)u - (f * xd + cx);
+    res[1] = (double)v - (fy * yd + cy);
+  }
+  double M[2][3];
+  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  if (TYPE == 2) {
+    p[0] = -xd * sv[0] - f * dk1[0] * sv[2];
+    p[1] = -yd * sv[1] - fy * dk1[1] * sv[2];
+  }
+  else {
+    p[0] = -xd * sv[0];
+    p[1] = -yd * sv[0];
+    if (TYPE != 0) { p[0] -= f * dk1[0] * sv[1]; p[1] -= f * dk1[1] * sv[1]; }
+  }
+  const double dx = om[1] * Pz - om[2] * Py, dy = om[2] * Px - om[0] * Pz, dz = om[0] * Py - om[1] * Px;
+  p[0] -= M[0][0] * dx + M[0][1] * dy + M[0][2] * dz;
+  p[1] -= M[1][0] * dx + M[1][1] * dy + M[1][2] * dz;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
+    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
+  }
+}
+
 // ---- 2D-3D annotation factor (F3, Reproj2d3dFactor, ptzray_optimizer.cc:268-326) ---------------------------
 // X_l = R(tlw[0:3]) X_w + tlw[3:6];  P = R(rvec) X_l (the extrinsic translation is NOT applied, :300);
 // r = uv - (fx xd + cx, fy yd + cy) with Brown distortion; fy IS read here (:273).

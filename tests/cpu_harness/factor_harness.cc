@@ -28,10 +28,15 @@ void h_ba_linearize(int type, const double* cam15, const double* ray, const floa
     ba_linearize<0>(cb, ray, uv[0], uv[1], res, jc, jr);
     for (int i = 0; i < 8; ++i) Jc[i] = (&jc[0][0])[i];
   }
-  else {
+  else if (type == 1) {
     double jc[2][5];
     ba_linearize<1>(cb, ray, uv[0], uv[1], res, jc, jr);
     for (int i = 0; i < 10; ++i) Jc[i] = (&jc[0][0])[i];
+  }
+  else {
+    double jc[2][6];
+    ba_linearize<2>(cb, ray, uv[0], uv[1], res, jc, jr);
+    for (int i = 0; i < 12; ++i) Jc[i] = (&jc[0][0])[i];
   }
   for (int i = 0; i < 6; ++i) Jr[i] = (&jr[0][0])[i];
 }
@@ -41,6 +46,21 @@ void h_ba_residual(int type, const double* cam15, const double* ray, const float
   fill_camblk(cam15, cb);
   if (type == 0) ba_residual<0>(cb, ray, uv[0], uv[1], res);
   else ba_residual<1>(cb, ray, uv[0], uv[1], res);
+}
+// directional variant used by the evaluation kernel: v = camera step in ba_linearize's column order (NC entries)
+void h_ba_step_dir(int type, const double* cam15, const double* ray, const float* uv, const double* v, double* res, double* p, double* Jr)
+{
+  double cb[CAMBLK];
+  fill_camblk(cam15, cb);
+  const int nc = type == 0 ? 4 : (type == 1 ? 5 : 6);
+  const double* Jl = cb + CB_JL;
+  double om[3];
+  for (int r = 0; r < 3; ++r) om[r] = Jl[3 * r] * v[nc - 3] + Jl[3 * r + 1] * v[nc - 2] + Jl[3 * r + 2] * v[nc - 1];
+  double jr[2][3];
+  if (type == 0) ba_step_dir<0>(cb, ray, uv[0], uv[1], v, om, res, p, jr);
+  else if (type == 1) ba_step_dir<1>(cb, ray, uv[0], uv[1], v, om, res, p, jr);
+  else ba_step_dir<2>(cb, ray, uv[0], uv[1], v, om, res, p, jr);
+  for (int i = 0; i < 6; ++i) Jr[i] = (&jr[0][0])[i];
 }
 // KRT: cam15 current (local frame), k1[4], dist1[5] reference intrinsics/distortion
 void h_krt_eval(int ktype, const double* cam15, const double* k1, const double* dist1, const float* uv1, const float* uv2,

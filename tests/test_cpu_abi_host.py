@@ -126,6 +126,31 @@ def test_device_math_matches_oracle(pkg, orc, harness, ftype):
     assert np.abs(W - lin["W"][:, sel, :]).max() / np.abs(W).max() < 1e-13
 
 
+@pytest.mark.parametrize("ftype", [0, 1, 2])
+def test_device_step_direction_equals_jacobian_times_step(harness, ftype):
+    """ba_step_dir (the evaluation kernel's one-cross-product form): residual and ray Jacobian identical to ba_linearize,
+    camera-side directional derivative equal to Jc v."""
+    rng = np.random.default_rng(5 + ftype)
+    nc = [4, 5, 6][ftype]
+    for _ in range(50):
+        cam = np.zeros(15); cam[0] = rng.uniform(1500, 3500); cam[1] = cam[0] * (1.03 if ftype == 2 else 1.0)
+        cam[2], cam[3] = 960, 540
+        cam[4:7] = rng.normal(0, 0.4, 3)
+        if ftype:
+            cam[10] = rng.uniform(-0.05, 0.05)
+        R = np.zeros(9); Jl = np.zeros(9)
+        harness.h_rodrigues(_p(cam[4:7].copy()), _p(R), _p(Jl))
+        ray = R.reshape(3, 3).T @ np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), 1.0]) * rng.uniform(0.7, 1.4)
+        uv = np.array([rng.uniform(100, 1800), rng.uniform(100, 1000)], dtype=np.float32)
+        v = rng.normal(0, 1, nc) * np.array([10.0] * (nc - 3) + [1e-3] * 3)
+        res = np.zeros(2); Jc = np.zeros((2, nc)); Jr = np.zeros((2, 3))
+        harness.h_ba_linearize(ftype, _p(cam), _p(ray), _p(uv), _p(res), _p(Jc), _p(Jr))
+        res2 = np.zeros(2); pd = np.zeros(2); Jr2 = np.zeros((2, 3))
+        harness.h_ba_step_dir(ftype, _p(cam), _p(ray), _p(uv), _p(v), _p(res2), _p(pd), _p(Jr2))
+        assert np.array_equal(res, res2) and np.array_equal(Jr, Jr2)
+        assert np.allclose(pd, Jc @ v, rtol=1e-12, atol=1e-12 * np.abs(Jc @ v).max())
+
+
 def test_device_math_behind_camera_branch(harness):
     cam = np.zeros(15); cam[0] = cam[1] = 2000; cam[2], cam[3] = 960, 540
     res = np.zeros(2); Jc = np.ones((2, 5)); Jr = np.ones((2, 3))
