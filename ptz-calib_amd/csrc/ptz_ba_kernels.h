@@ -1070,12 +1070,14 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
     //   s1 + d_r . t + 1/2 d_r^T V d_r      (V = sum_a Jr_a^T Jr_a is the stored, undamped ray block)
     double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
     double s1 = 0;
+    double Xu[3], inv_n;  // the functor's point for this ray, once for all of its observations
+    ba_ray_point<F>(Xr, Xu, inv_n);
     for (int a = a0; a < a1; ++a) {
       const float2 uv = d.obs_uv[a];
       const int ci = d.obs_cam[a];
       const double* cb = tab + ci * CBS;
       double res[2], pd[2], Jr[2][3];
-      ba_step_dir<F>(cb, Xr, uv.x, uv.y, dct + ci * DCS, dct + ci * DCS + (NW - 3), res, pd, Jr);
+      ba_step_dir_unit<F>(cb, Xu, inv_n, uv.x, uv.y, dct + ci * DCS, dct + ci * DCS + (NW - 3), res, pd, Jr);
       const double m0 = sw * pd[0], m1 = sw * pd[1];
       s1 += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
       t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
@@ -1096,10 +1098,12 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       mcc = s1 + (ds[0] * t0 + ds[1] * t1 + ds[2] * t2) + 0.5 * (ds[0] * q0 + ds[1] * q1 + ds[2] * q2);
     }
     // pass 2: candidate cost (residuals only)
+    double Xcu[3], inv_nc;
+    ba_ray_point<F>(Xn, Xcu, inv_nc);
     for (int a = a0; a < a1; ++a) {
       const float2 uv = d.obs_uv[a];
       double rc[2];
-      ba_residual<F>(ctab + d.obs_cam[a] * CDS, Xn, uv.x, uv.y, rc);
+      ba_residual_unit<F>(ctab + d.obs_cam[a] * CDS, Xcu, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
     }
   }

@@ -146,20 +146,28 @@ PTZ_HD void brown_jac(double x, double y, const double* k, double B[4], double d
 // there is no behind-the-camera branch, fy is read (:167,185).
 template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : (TYPE == 1 ? 5 : 6); static constexpr int ROT0 = NC - 3; };  // TYPE = factor (0 / 1 / 2)
 
-// Residual only.  cb = camera block (R at [CB_R], intrinsics); X = ray parameter (3).
+// the point the functor feeds to the rotation: X / |X| for PTZRay / PTZRayFxfyDist, X itself for PTZRayDist; inv_n = 1 / |X| (or 1).
+// A ray-centric kernel computes it once per ray instead of once per observation (same operations, same bits).
 template <int TYPE>
-PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, double res[2])
+PTZ_HD void ba_ray_point(const double X[3], double Xn[3], double& inv_n)
 {
-  const double* R = cb + CB_R;
-  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
-  double Xn[3];
   if (TYPE != 1) {
     const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+    inv_n = 1.0 / n;
     Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
   }
   else {
+    inv_n = 1.0;
     Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2];
   }
+}
+
+// Residual only.  cb = camera block (R at [CB_R], intrinsics); X = ray parameter (3).
+template <int TYPE>
+PTZ_HD void ba_residual_unit(const double* cb, const double Xn[3], float u, float v, double res[2])
+{
+  const double* R = cb + CB_R;
+  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
   const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
   const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
   const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
@@ -176,6 +184,14 @@ PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, d
     res[0] = (double)u - (f * xd + cx);
     res[1] = (double)v - ((TYPE == 2 ? cb[CB_FY] : f) * yd + cy);
   }
+}
+
+template <int TYPE>
+PTZ_HD void ba_residual(const double* cb, const double X[3], float u, float v, double res[2])
+{
+  double Xn[3], inv_n;
+  ba_ray_point<TYPE>(X, Xn, inv_n);
+  ba_residual_unit<TYPE>(cb, Xn, u, v, res);
 }
 
 // Residual + Jacobians.  Jc[2][NC] wrt the free camera parameters, Jr[2][3] wrt the ray.  Unweighted,
@@ -260,21 +276,12 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
 // its intrinsic components sv[NC - 3] (in the column order of ba_linearize) and om = Jl v_rot: the three rotation columns
 // -M (Jl[:,k] x P) collapse into -M (om x P), one cross product instead of three.  Same projection arithmetic as ba_linearize.
 template <int TYPE>
-PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, const double* sv, const double om[3], double res[2],
-                        double p[2], double Jr[2][3])
+PTZ_HD void ba_step_dir_unit(const double* cb, const double Xn[3], double inv_n, float u, float v, const double* sv, const double om[3],
+                             double res[2], double p[2], double Jr[2][3])
 {
   const double* R = cb + CB_R;
   const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
   const double fy = TYPE == 2 ? cb[CB_FY] : f;
-  double Xn[3], inv_n = 1.0;
-  if (TYPE != 1) {
-    const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
-    inv_n = 1.0 / n;
-    Xn[0] = X[0] / n; Xn[1] = X[1] / n; Xn[2] = X[2] / n;
-  }
-  else {
-    Xn[0] = X[0]; Xn[1] = X[1]; Xn[2] = X[2];
-  }
   const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
   const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
   const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
@@ -318,6 +325,15 @@ PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, c
     Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
     Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
   }
+}
+
+template <int TYPE>
+PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, const double* sv, const double om[3], double res[2],
+                        double p[2], double Jr[2][3])
+{
+  double Xn[3], inv_n;
+  ba_ray_point<TYPE>(X, Xn, inv_n);
+  ba_step_dir_unit<TYPE>(cb, Xn, inv_n, u, v, sv, om, res, p, Jr);
 }
 
 // ---- 2D-3D annotation factor (F3, Reproj2d3dFactor, ptzray_optimizer.cc:268-326) ---------------------------
