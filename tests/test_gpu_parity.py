@@ -528,6 +528,25 @@ def test_krt_solve_sharded_matches_one_launch(pkg):
         assert [s["num_residuals"] for s in summ] == [s["num_residuals"] for s in want_summ]
 
 
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_krt_more_matches_than_the_lds_cache(pkg, orc, ftype):
+    """Queries with 700 matches: the kernel caches the constant part of the first 256 matches of a query in LDS and recomputes
+    the rest on the fly (with the iterative undistortion for FDist); both paths must give the oracle's answer."""
+    rb = pkg.synth.make_reloc_batch(5, 700, seed_id=50 + ftype, factor_type=ftype)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, jacobian_mode=orc.JAC_NUMERIC)
+        assert summ[q]["num_residuals"] == 1400 and summ[q]["num_iterations"] == osumm["num_iterations"]
+        assert abs(summ[q]["final_cost"] - osumm["final_cost"]) <= 1e-9 * osumm["final_cost"]
+        assert bool(acc[q]) == orc.krt_check(osumm, loc, 100.0)
+        if acc[q]:
+            want = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
+            assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
+            assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
+
+
 def test_krt_ragged_and_degenerate(pkg, orc):
     """Ragged match counts, including a query with too few matches to constrain 4 parameters."""
     rb = pkg.synth.make_reloc_batch(6, 64, seed_id=9)
