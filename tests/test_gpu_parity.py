@@ -324,6 +324,14 @@ def test_device_against_committed_trajectories_of_the_variants(pkg, orc):
                 assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
 
 
+def test_ba_dense_overlap_long_tracks(pkg, orc):
+    """140 views inside a 5-degree pan range: every camera pair shares rays (a dense reduced system, no empty tiles), tracks of
+    up to 72 views (2556 entries per ray in the pair lists).  LM bookkeeping of the oracle, parameters within 1e-6."""
+    sc = pkg.synth.make_scene(80, 140, 250, pan_range_deg=5.0)
+    assert np.bincount(sc.obs_ray).max() > 64
+    _check_ba_parity(pkg, orc, sc)
+
+
 def test_ba_batch_matches_single(pkg, scene_c1):
     """A batch of different scenes gives, per scene, bit-identical results to solving it alone
     (fixed-order reductions; scenes never interact)."""
