@@ -548,8 +548,8 @@ namespace {
 // cam(a) > cam(b); a is stored as its position in cam(a)'s observation list (the LDS slot of T_a in k_schur).  Independent of
 // every other scene apart from the base offset of its observations, so batches build these lists on several host threads.
 struct PairBuild {
-  std::vector<int> pci, pcj, pptr;  // pptr: scene-local entry offsets (n_pair + 1)
-  std::vector<int2> ent;            // copied into the batch-wide array (in parallel, per wave) and released
+  std::vector<int> pci, pcj, pptr, pbrow;  // pptr: scene-local entry offsets (n_pair + 1); pbrow: first W row of camera cj
+  std::vector<unsigned> ent;        // copied into the batch-wide array (in parallel, per wave) and released
   int64_t n_ent = 0;
   int n_pair = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, err = PTZ_OK;
 };
@@ -645,6 +645,7 @@ void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest&
         if (c == 0) continue;
         out.pci.push_back(ci);
         out.pcj.push_back(cj);
+        out.pbrow.push_back(obase + cnt_cam[cj]);
         out.pptr.push_back(run);
         if (cam_first[ci] < 0) cam_first[ci] = npair;
         pair_fill[(size_t)ci * p.n_cam + cj] = run;
@@ -659,7 +660,7 @@ void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest&
     const int a = ea[e], bb = ebq[e];
     const int cj = p.obs_cam[bb];
     const int slot = pair_fill[(size_t)p.obs_cam[a] * p.n_cam + cj]++;
-    out.ent[slot] = make_int2(pos[a], obase + cnt_cam[cj] + pos[bb]);  // (LDS slot of T_a, W row of b)
+    out.ent[slot] = (unsigned)pos[a] | ((unsigned)pos[bb] << 16);  // (LDS slot of T_a, W row of b relative to camera cj's first row)
   }
   // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
   cam_first[p.n_cam] = npair;
@@ -713,7 +714,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   RawVec<float2> h_uv;
   RawVec<int> h_cam, h_ray, h_camobs, h_camray, h_wpos;
   std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr;
-  RawVec<int2> h_ent;
+  RawVec<unsigned> h_ent;
+  std::vector<int> h_pbrow;
   std::vector<int> h_campair;
   std::vector<double> h_w, h_o3xyz;
   std::vector<float2> h_o3uv;
@@ -805,8 +807,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         h_ent.resize(at);
         run([&](int t0, int step) {
           for (int k = t0; k < wn; k += step) {
-            if (!wave[k].ent.empty()) memcpy(h_ent.data() + ent_at[k], wave[k].ent.data(), sizeof(int2) * wave[k].ent.size());
-            std::vector<int2>().swap(wave[k].ent);
+            if (!wave[k].ent.empty()) memcpy(h_ent.data() + ent_at[k], wave[k].ent.data(), sizeof(unsigned) * wave[k].ent.size());
+            std::vector<unsigned>().swap(wave[k].ent);
           }
         });
       }
@@ -814,6 +816,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       if (pb.err != PTZ_OK || (int64_t)b->total_ent + pb.n_ent > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
       h_pci.insert(h_pci.end(), pb.pci.begin(), pb.pci.end());
       h_pcj.insert(h_pcj.end(), pb.pcj.begin(), pb.pcj.end());
+      h_pbrow.insert(h_pbrow.end(), pb.pbrow.begin(), pb.pbrow.end());
       for (int v : pb.pptr) h_pptr.push_back(b->total_ent + v);
       b->max_cam_obs = std::max(b->max_cam_obs, pb.max_cam_obs);
       b->max_cam_ent = std::max(b->max_cam_ent, pb.max_cam_ent);
@@ -888,6 +891,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     up.add(h_camray, &d.cam_ray);
     up.add(h_pci, &d.pair_ci);
     up.add(h_pcj, &d.pair_cj);
+    up.add(h_pbrow, &d.pair_brow);
     up.add(h_pptr, &d.pair_ptr);
     up.add(h_campair, &d.cam_pair);
     up.add(h_ent, &d.ent);
@@ -1046,7 +1050,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16));
   const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CBS);
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
-  if (schur_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
+  if (schur_smem > 160 * 1024 || b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }  // (entry records hold 16-bit positions)
   if (eval_smem > 160 * 1024 || lin_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
   {
     // The cap on dynamic LDS is a property of the kernel, not of a batch: raise it to the hardware limit once per device

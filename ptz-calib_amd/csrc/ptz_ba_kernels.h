@@ -61,7 +61,8 @@ struct Dev {
   const int* pair_cj;
   const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
   const int* cam_pair;  // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local pair range of each camera ci
-  const int2* ent;      // (position of obs a in ci's observation list, global obs index b of cj); ci > cj only
+  const unsigned* ent;  // low 16 bits: position of obs a in ci's observation list; high 16: position of obs b in cj's; ci > cj only
+  const int* pair_brow; // first W row of camera cj of every pair
   const double* ray_w;
   // state: two buffers, LmState.cur selects the current one
   double* cam_x;  // [2][total_cam][15]
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   const int eb = 0;                                        // entries are addressed by global index
   double* T = lds;                                  // [no][TS]
   double* strip = lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
-  const int2* ents = d.ent + eb;                    // (a slot, W row of b), this camera's contiguous range
+  const unsigned* ents = d.ent + eb;                // (a slot | b slot << 16), this camera's contiguous range
   const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
   double bsum[NW], D[NU];
 #pragma unroll
@@ -868,17 +869,18 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
     for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
     const int e1 = pps[pl + 1];
     int e = pps[pl] + l;
+    const int brow = d.pair_brow[s.pair_off + pr0 + pl];
     // two entries per trip while both exist (both W_b rows in flight together), then at most one single entry
     for (; e + 16 < e1; e += 32) {
-      const int2 ab0 = ents[e];
-      const int2 ab1 = ents[e + 16];
-      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
-      const double* Wb1 = d.W + (size_t)ab1.y * Dims<TYPE>::WS;
+      const unsigned ab0 = ents[e];
+      const unsigned ab1 = ents[e + 16];
+      const double* Wb0 = d.W + (size_t)(brow + (int)(ab0 >> 16)) * Dims<TYPE>::WS;
+      const double* Wb1 = d.W + (size_t)(brow + (int)(ab1 >> 16)) * Dims<TYPE>::WS;
       double wb0[NT], wb1[NT];
 #pragma unroll
       for (int k = 0; k < NT; ++k) { wb0[k] = Wb0[k]; wb1[k] = Wb1[k]; }
-      const double* Ta0 = T + ab0.x * TS;
-      const double* Ta1 = T + ab1.x * TS;
+      const double* Ta0 = T + (ab0 & 0xffffu) * TS;
+      const double* Ta1 = T + (ab1 & 0xffffu) * TS;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
@@ -890,12 +892,12 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
       }
     }
     if (e < e1) {
-      const int2 ab0 = ents[e];
-      const double* Wb0 = d.W + (size_t)ab0.y * Dims<TYPE>::WS;
+      const unsigned ab0 = ents[e];
+      const double* Wb0 = d.W + (size_t)(brow + (int)(ab0 >> 16)) * Dims<TYPE>::WS;
       double wb0[NT];
 #pragma unroll
       for (int k = 0; k < NT; ++k) wb0[k] = Wb0[k];
-      const double* Ta0 = T + ab0.x * TS;
+      const double* Ta0 = T + (ab0 & 0xffffu) * TS;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
         const double t0 = Ta0[3 * p], t1 = Ta0[3 * p + 1], t2 = Ta0[3 * p + 2];
