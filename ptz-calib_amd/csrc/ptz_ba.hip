@@ -557,7 +557,7 @@ struct PairBuild {
 // Where a scene's observation-side arrays go in the batch-wide host arrays (all offsets are prefix sums of the scene sizes,
 // known before any scene is built, so the worker threads write them in place).
 struct ObsDest {
-  float2* uv; int* cam; int* ray; int* camobs; int* camray;  // + obs_off
+  float2* uv; int* cam; int* ray; int* camobs; int* camray; float2* camuv;  // + obs_off
   int* rayptr; double* w;                                      // + ray_off (+ scene index for the pointer array)
   int* camptr; int* campair;                                   // + cam_off + scene index
   int* wpos;                                                   // + obs_off
@@ -586,6 +586,7 @@ void build_pairs(const ptz_ba_problem& p, int obase, int ray_off, const ObsDest&
       const int slot = fill[p.obs_cam[a]]++;
       od.camobs[slot] = obase + (int)a;
       od.camray[slot] = ray_off + p.obs_ray[a];
+      od.camuv[slot] = make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]);
     }
     for (int c = 0; c <= p.n_cam; ++c) od.camptr[c] = obase + cnt_cam[c];
   }
@@ -711,7 +712,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
-  RawVec<float2> h_uv;
+  RawVec<float2> h_uv, h_camuv;
   RawVec<int> h_cam, h_ray, h_camobs, h_camray, h_wpos;
   std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr;
   RawVec<unsigned> h_ent;
@@ -746,7 +747,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   {
     const size_t tr = (size_t)ray_base[n - 1] + problems[n - 1].n_ray, tc = (size_t)cam_base[n - 1] + problems[n - 1].n_cam;
-    h_uv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
+    h_uv.resize(tot_obs); h_camuv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
     h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n); h_campair.resize(tc + n); h_wpos.resize(tot_obs);
   }
   int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -782,7 +783,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
           for (int k = t0; k < wn; k += step) {
             const int sidx = wave_first + k;
             const ObsDest od = {h_uv.data() + obs_base[sidx], h_cam.data() + obs_base[sidx], h_ray.data() + obs_base[sidx],
-                                h_camobs.data() + obs_base[sidx], h_camray.data() + obs_base[sidx],
+                                h_camobs.data() + obs_base[sidx], h_camray.data() + obs_base[sidx], h_camuv.data() + obs_base[sidx],
                                 h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
                                 h_camptr.data() + cam_base[sidx] + sidx, h_campair.data() + cam_base[sidx] + sidx,
                                 h_wpos.data() + obs_base[sidx]};
@@ -889,6 +890,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     up.add(h_camobs, &d.cam_obs);
     up.add(h_wpos, &d.wpos);
     up.add(h_camray, &d.cam_ray);
+    up.add(h_camuv, &d.cam_uv);
     up.add(h_pci, &d.pair_ci);
     up.add(h_pcj, &d.pair_cj);
     up.add(h_pbrow, &d.pair_brow);

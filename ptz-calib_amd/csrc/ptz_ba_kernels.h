@@ -57,6 +57,7 @@ struct Dev {
   const int* cam_obs;   // global obs index, camera-major
   const int* wpos;      // [total_obs] row of W that holds observation a (camera-major position)
   const int* cam_ray;   // [total_obs] global ray id, camera-major (same order as cam_obs)
+  const float2* cam_uv; // [total_obs] the pixel, camera-major: the camera pass streams (pixel, ray id) instead of gathering them
   const int* pair_ci;   // scene-local camera ids, ci >= cj
   const int* pair_cj;
   const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
@@ -297,10 +298,8 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   for (int q0 = cp[i]; q0 < q_end; q0 += 64) {
     const int q = q0 + lane;
     if (q < q_end) {
-      const int a = d.cam_obs[q];
-      const float2 uv = d.obs_uv[a];
-      const int j = d.obs_ray[a];
-      const double* rr = d.rayrec + (size_t)(s.ray_off + j) * 8;  // written by k_lin_ray of the same linearisation
+      const float2 uv = d.cam_uv[q];
+      const double* rr = d.rayrec + (size_t)d.cam_ray[q] * 8;  // written by k_lin_ray of the same linearisation
       const double Xr[3] = {rr[0], rr[1], rr[2]};
       double res[2], Jc[2][NW], Jr[2][3];
       ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
