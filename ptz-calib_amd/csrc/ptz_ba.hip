@@ -935,8 +935,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.V, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.gr, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.E, (size_t)b->total_ray * 6));
-  TRY(b->alloc(&d.z, (size_t)b->total_ray * 3));
+  TRY(b->alloc(&d.E, (size_t)b->total_ray * EZS));  // (E, z) records
   d.shared = any_shared ? 1 : 0;
   if (any_shared) {
     TRY(upload(b, h_grpptr, &d.grp_ptr));

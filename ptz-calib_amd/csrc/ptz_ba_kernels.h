@@ -11,6 +11,7 @@ namespace ptz {
 namespace {
 
 constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
+constexpr int EZS = 10;           // doubles per ray in the (E, z) record: 6 + 3, padded to a 16-byte multiple
 constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (35 doubles: odd -> no same-field bank conflicts)
 constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
 // W row stride: see Dims<TYPE>::WS
@@ -84,8 +85,8 @@ struct Dev {
   double* V;         // [total_ray][6]
   double* gr;        // [total_ray][3]
   double* diag_r;    // [total_ray][3]
-  double* E;         // [total_ray][6]
-  double* z;         // [total_ray][3]
+  double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), padding -- one record,
+                     // because the Schur kernel gathers both for every observation
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
   double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
@@ -713,11 +714,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
     for (int k = 0; k < 6; ++k) E[k] = 0;
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) d.E[(size_t)gj * 6 + k] = E[k];
+  for (int k = 0; k < 6; ++k) d.E[(size_t)gj * EZS + k] = E[k];
   const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
-  d.z[(size_t)gj * 3 + 0] = E[0] * g0 + E[1] * g1 + E[3] * g2;
-  d.z[(size_t)gj * 3 + 1] = E[1] * g0 + E[2] * g1 + E[4] * g2;
-  d.z[(size_t)gj * 3 + 2] = E[3] * g0 + E[4] * g1 + E[5] * g2;
+  d.E[(size_t)gj * EZS + 6] = E[0] * g0 + E[1] * g1 + E[3] * g2;  // z = E g_r rides in the same record
+  d.E[(size_t)gj * EZS + 7] = E[1] * g0 + E[2] * g1 + E[4] * g2;
+  d.E[(size_t)gj * EZS + 8] = E[3] * g0 + E[4] * g1 + E[5] * g2;
 }
 
 template <int TYPE>
@@ -784,8 +785,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   for (int k = 0; k < NU; ++k) D[k] = 0;
   for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
     const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
-    const double z0 = d.z[(size_t)gj * 3], z1 = d.z[(size_t)gj * 3 + 1], z2 = d.z[(size_t)gj * 3 + 2];
-    const double* E = d.E + (size_t)gj * 6;
+    const double* E = d.E + (size_t)gj * EZS;  // one 80-byte record per ray: E (6), z (3)
+    const double z0 = E[6], z1 = E[7], z2 = E[8];
     const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
     double w[NT];
     const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
     }
-    const double* E = d.E + (size_t)gj * 6;
+    const double* E = d.E + (size_t)gj * EZS;
     // step = -y_r (Ceres solves J y = r and negates)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
     const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
