@@ -713,12 +713,13 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
 #pragma unroll
     for (int k = 0; k < 6; ++k) E[k] = 0;
   }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) d.E[(size_t)gj * EZS + k] = E[k];
   const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
-  d.E[(size_t)gj * EZS + 6] = E[0] * g0 + E[1] * g1 + E[3] * g2;  // z = E g_r rides in the same record
-  d.E[(size_t)gj * EZS + 7] = E[1] * g0 + E[2] * g1 + E[4] * g2;
-  d.E[(size_t)gj * EZS + 8] = E[3] * g0 + E[4] * g1 + E[5] * g2;
+  // the record goes out whole (E, z = E g_r, padding) in five 16-byte stores
+  const double rec[EZS] = {E[0], E[1], E[2], E[3], E[4], E[5],
+                           E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2, 0.0};
+  double2* out = reinterpret_cast<double2*>(d.E + (size_t)gj * EZS);
+#pragma unroll
+  for (int k = 0; k < EZS / 2; ++k) out[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
 }
 
 template <int TYPE>
