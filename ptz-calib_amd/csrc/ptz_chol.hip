@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 extern "C" int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops)
 {
   using namespace ptz;
+  (void)hipGetLastError();
   if (!tflops) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const double2* __restrict
 extern "C" int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps)
 {
   using namespace ptz;
+  (void)hipGetLastError();
   if (!read_gbps || !copy_gbps) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
