@@ -223,9 +223,12 @@ int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* match_ptr, cons
 
 /* The same launch on queries that are already resident in HBM (matches produced on the device, a serving loop that keeps its
  * buffers): every d_* argument is a DEVICE pointer with the layout of its host counterpart above, d_point_ptr = NULL for no
- * 2D-3D constraints.  The kernel is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream) of device
- * opt->device_id and the call returns without synchronising: results (d_cam_cur, d_summaries, d_accepted) are valid once the
- * stream has passed this point.  The CSR offsets are not validated (they live on the device). */
+ * 2D-3D constraints.  The kernel is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream) of the device that
+ * OWNS d_cam_cur (hipPointerGetAttributes) and the call returns without synchronising: results (d_cam_cur, d_summaries,
+ * d_accepted) are valid once the stream has passed this point.  PTZ_EINVAL if the stream belongs to another device than the
+ * buffers, or if opt->device_id names a different device explicitly (a non-zero value; 0 is the untouched default and is
+ * not taken as a request for device 0).  The CSR offsets are not validated (they live on the device).
+ * Like every entry point of this library the call leaves the calling thread's current HIP device as it found it. */
 int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_match_ptr, const float* d_uv_ref, const float* d_uv_cur,
                                    const int64_t* d_point_ptr, const float* d_pts2d, const double* d_pts3d,
                                    const double* d_cam_ref, double* d_cam_cur, int32_t factor_type, double max_reproj_error,

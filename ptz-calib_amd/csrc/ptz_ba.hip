@@ -84,7 +84,15 @@ struct ptz_ba_batch {
   int group_of(hipStream_t st) const { for (size_t g = 0; g < streams.size(); ++g) if (streams[g] == st) return (int)g; return -1; }
   hipStream_t aux_stream(hipStream_t st) const { const int g = group_of(st); return (lookahead && g >= 0 && g < (int)aux.size()) ? aux[g] : nullptr; }
   void lookahead_events(hipStream_t st, hipEvent_t* t, hipEvent_t* r) const { const int g = group_of(st); *t = la_ev[2 * g]; *r = la_ev[2 * g + 1]; }
-  int* h_active = nullptr;  // pinned
+  // pass pipeline control (Dev::grp_ctl / host_ctl): 4 ints per scene group, device block + pinned host mirror
+  int* d_ctl = nullptr;
+  int* h_ctl = nullptr;      // pinned; read by the host while the device writes (fine-grained host memory)
+  int* h_ctl_dev = nullptr;  // the device's address of h_ctl
+  int ctl_groups = 0;        // groups the control blocks were sized for
+  int ahead = 3;             // LM passes the host may have enqueued beyond the last one known to have reached its step evaluation
+  // one captured LM pass per scene group (kernel arguments never change during a batch's life), replayed per pass
+  bool use_graph = true;
+  std::vector<hipGraphExec_t> pass_graph;
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
   int has3d = 0, total_o3 = 0;
   // shared intrinsics: per global camera, the global index of the first camera of its group (source of the initial values)
@@ -223,7 +231,7 @@ static void make_groups(ptz_ba_batch* b)
 {
   const int B = b->n_scene;
   // per-family timings are only meaningful when no other group's kernels share the device: profiling runs one group
-  const int G = b->profiling ? 1 : std::max(1, std::min(b->n_group, B));
+  const int G = b->profiling ? 1 : std::max(1, std::min(std::min(b->n_group, B), b->ctl_groups));
   b->group_first.clear(); b->group_count.clear(); b->dg.clear();
   for (int g = 0; g < G; ++g) {
     const int lo = (int)((int64_t)B * g / G), hi = (int)((int64_t)B * (g + 1) / G);
@@ -240,7 +248,13 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
     if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
+    d.grp_ctl = b->d_ctl + 4 * g;
+    d.host_ctl = b->h_ctl_dev + 4 * g;
     b->dg.push_back(d);
+  }
+  if ((int)b->pass_graph.size() != G) {  // the grouping changed (profiling on / off): captured passes are stale
+    for (auto ge : b->pass_graph) if (ge) (void)hipGraphExecDestroy(ge);
+    b->pass_graph.assign(G, nullptr);
   }
   while ((int)b->streams.size() < G) {
     hipStream_t st; (void)ptzpool::stream_acquire(b->device, &st); b->streams.push_back(st);
@@ -314,6 +328,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   const int G = (int)b->dg.size();
   hipStream_t s0 = b->streams[0];
   b->stream = s0;
+  for (int i = 0; i < 4 * b->ctl_groups; ++i) __atomic_store_n(&b->h_ctl[i], 0, __ATOMIC_RELEASE);  // nothing of this batch is in flight
   PTZ_HIP_TRY(hipEventRecord(b->ev0, s0));
   // x <- initial state, scales <- 1, LM state reset (whole batch, stream 0)
   PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, s0));
@@ -333,49 +348,60 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     if (d.shared) LAUNCH(k_group_scale<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
     enqueue_linearize<TYPE>(b);
   }
+  for (int g = 0; g < G; ++g) hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(64), 0, s0, b->dg[g]);
   // fork: every group's stream continues after the common prologue
   PTZ_HIP_TRY(hipEventRecord(b->fork_ev[0], s0));
   for (int g = 1; g < G; ++g) PTZ_HIP_TRY(hipStreamWaitEvent(b->streams[g], b->fork_ev[0], 0));
   const int max_it = b->opt.max_num_iterations;
-  // Every group runs its own pass pipeline: the host waits for a group's active flags, enqueues that group's next pass at once
-  // and only then turns to the next group.  The groups therefore drift out of phase, and the latency-bound part of one
+  // Every group runs its own pass pipeline and the host is not part of it: LM control lives on the device (k_lm_pre /
+  // k_lm_post), every kernel of a pass returns at once for a scene that has terminated, so the host simply keeps `ahead`
+  // passes enqueued beyond the last one the device is known to have reached, and stops when the device reports that the
+  // group's last scene has retired (two words in pinned memory per group, polled; no stream synchronisation, no copy).
+  // Passes enqueued past that point are empty launches.  Groups drift out of phase, so the latency-bound part of one
   // group's pass (block-column chain of the factorisation, LM control) overlaps the throughput kernels of another.
-  std::vector<char> galive(G, 1);
-  std::vector<int> gpass(G, 0);
-  auto enqueue_group = [&](int g) -> int {
-    const double te0 = now();
-    b->stream = b->streams[g];
-    enqueue_pass<TYPE>(b, b->dg[g], gpass[g] == max_it);
-    if (gpass[g] < max_it) {
-      b->prof_begin(P_SYNC);
-      PTZ_HIP_TRY(hipMemcpyAsync(b->h_active + b->group_first[g], b->dg[g].active, sizeof(int) * b->group_count[g],
-                                 hipMemcpyDeviceToHost, b->streams[g]));
-      b->prof_end();
+  const bool graph = b->use_graph && !b->profiling;
+  if (graph) {
+    for (int g = 0; g < G; ++g) {
+      if (b->pass_graph[g]) continue;
+      hipStream_t st = b->streams[g];
+      hipGraph_t gr = nullptr;
+      b->stream = st;
+      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        enqueue_pass<TYPE>(b, b->dg[g], false);
+        ok = hipStreamEndCapture(st, &gr) == hipSuccess && gr != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&b->pass_graph[g], gr, nullptr, nullptr, 0) == hipSuccess;
+      if (gr) (void)hipGraphDestroy(gr);
+      if (!ok) { (void)hipGetLastError(); b->pass_graph[g] = nullptr; b->use_graph = false; break; }
     }
-    t_enq += now() - te0;
-    return PTZ_OK;
-  };
-  int alive = G;
-  for (int g = 0; g < G; ++g) {
-    if (enqueue_group(g) != PTZ_OK) return PTZ_ENODEVICE;
-    if (max_it == 0) { galive[g] = 0; --alive; }
   }
+  std::vector<char> galive(G, 1);
+  std::vector<int> enq(G, 0);
+  int alive = G;
   while (alive > 0) {
+    bool progressed = false;
     for (int g = 0; g < G; ++g) {
       if (!galive[g]) continue;
+      if (__atomic_load_n(&b->h_ctl[4 * g + 1], __ATOMIC_ACQUIRE)) { galive[g] = 0; --alive; progressed = true; continue; }
+      if (enq[g] - __atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE) >= b->ahead) continue;
+      const double te0 = now();
+      b->stream = b->streams[g];
+      const bool last = enq[g] == max_it;  // the last pass only closes the books (k_lm_pre)
+      if (!last && b->use_graph && !b->profiling && b->pass_graph[g]) PTZ_HIP_TRY(hipGraphLaunch(b->pass_graph[g], b->streams[g]));
+      else enqueue_pass<TYPE>(b, b->dg[g], last);
+      ++enq[g];
+      progressed = true;
+      t_enq += now() - te0;
+      if (last) { galive[g] = 0; --alive; }
+    }
+    if (!progressed) {
       const double ts0 = now();
-      PTZ_HIP_TRY(hipStreamSynchronize(b->streams[g]));
-      bool any = false;
-      int na = 0;
-      for (int i = 0; i < b->group_count[g]; ++i) { const bool a = b->h_active[b->group_first[g] + i] != 0; any |= a; na += a; }
+      __builtin_ia32_pause();
       t_sync += now() - ts0;
-      if (dbg) fprintf(stderr, "[ptz_ba] group %d pass %d: %d scenes active afterwards (t = %.3f ms)\n", g, gpass[g], na, now() - t_start);
-      if (!any) { galive[g] = 0; --alive; continue; }
-      ++gpass[g];
-      if (enqueue_group(g) != PTZ_OK) return PTZ_ENODEVICE;
-      if (gpass[g] == max_it) { galive[g] = 0; --alive; }  // the last pass only closes the books (k_lm_pre)
     }
   }
+  if (dbg) for (int g = 0; g < G; ++g) fprintf(stderr, "[ptz_ba] group %d: %d passes enqueued, %d reached by the device when the host stopped\n", g, enq[g], b->h_ctl[4 * g]);
   // join
   for (int g = 1; g < G; ++g) {
     PTZ_HIP_TRY(hipEventRecord(b->join_ev[g], b->streams[g]));
@@ -525,14 +551,15 @@ int32_t ptz_ba_batch_cam_block_dim(const ptz_ba_batch* b) { return b ? b->nc : P
 void ptz_ba_batch_destroy(ptz_ba_batch* b)
 {
   if (!b) return;
-  (void)hipSetDevice(b->device);
+  DeviceGuard guard(b->device);
   // nothing of this batch may still be running when its memory is handed to the next one
   for (auto st : b->streams) (void)hipStreamSynchronize(st);
   for (auto st : b->aux) (void)hipStreamSynchronize(st);
   const int dv = b->device;
   for (void* p : b->allocs) ptzpool::dev_release(dv, p);
   for (auto e : b->ev_pool) ptzpool::event_release(dv, true, e);
-  if (b->h_active) ptzpool::pinned_release(b->h_active);
+  if (b->h_ctl) ptzpool::pinned_release(b->h_ctl);
+  for (auto ge : b->pass_graph) if (ge) (void)hipGraphExecDestroy(ge);
   ptzpool::event_release(dv, true, b->ev0);
   ptzpool::event_release(dv, true, b->ev1);
   for (auto st : b->streams) ptzpool::stream_release(dv, st);
@@ -705,7 +732,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+  PTZ_DEVICE_GUARD(o.device_id);
 
   // fy becomes a live column with annotation residuals; PTZRayFxfyDist has it anyway
   const int NC = type == PTZ_BA_PTZRayFxfyDist ? 6 : ((type == PTZ_BA_PTZRay) ? 4 : 5) + has3d;
@@ -1039,11 +1066,19 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // 141.9 -> 137.8 ms, single scene 16.4 -> 19.4 ms with the left-looking form)
   b->left_looking = n >= 8;
   if (const char* e = getenv("PTZ_BA_CHOL_LEFT")) b->left_looking = atoi(e) != 0;
+  if (const char* e = getenv("PTZ_BA_AHEAD")) b->ahead = std::max(1, atoi(e));
+  if (const char* e = getenv("PTZ_BA_GRAPH")) b->use_graph = atoi(e) != 0;
+  b->ctl_groups = std::max(1, std::min(b->n_group, n));
+  if (b->alloc(&b->d_ctl, (size_t)4 * b->ctl_groups) != PTZ_OK ||
+      ptzpool::pinned_acquire(sizeof(int) * 4 * b->ctl_groups, (void**)&b->h_ctl) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&b->h_ctl_dev, b->h_ctl, 0) != hipSuccess) {
+    ptz_ba_batch_destroy(b);
+    return PTZ_ENODEVICE;
+  }
   make_groups(b);
   b->stream = b->streams.empty() ? nullptr : b->streams[0];
   if (b->stream == nullptr || ptzpool::event_acquire(b->device, true, &b->ev0) != hipSuccess ||
-      ptzpool::event_acquire(b->device, true, &b->ev1) != hipSuccess ||
-      ptzpool::pinned_acquire(sizeof(int) * n, (void**)&b->h_active) != hipSuccess) {
+      ptzpool::event_acquire(b->device, true, &b->ev1) != hipSuccess) {
     ptz_ba_batch_destroy(b);
     return PTZ_ENODEVICE;
   }
@@ -1088,7 +1123,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
 int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double* ray, const double* tlw)
 {
   if (!b || !cam || !ray) return PTZ_EINVAL;
-  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_DEVICE_GUARD(b->device);
   if (b->d.shared) {
     // a shared block starts from its first camera's values (intrinsics_param_.insert, ptzray_optimizer.cc:645-650)
     std::vector<double> c(cam, cam + 15 * (size_t)b->total_cam);
@@ -1112,7 +1147,7 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
   (void)hipGetLastError();  // an error left behind by somebody else's earlier call on this thread is not this solve's
-  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_DEVICE_GUARD(b->device);
   switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
     case 0: return solve_impl<0>(b, summaries);
     case 1: return solve_impl<1>(b, summaries);
@@ -1126,7 +1161,7 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
 int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw)
 {
   if (!b) return PTZ_EINVAL;
-  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_DEVICE_GUARD(b->device);
   std::vector<LmState> h(b->n_scene);
   PTZ_HIP_TRY(hipMemcpy(h.data(), b->d.lm, sizeof(LmState) * b->n_scene, hipMemcpyDeviceToHost));
   for (int i = 0; i < b->n_scene; ++i) {
@@ -1173,7 +1208,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
   (void)hipGetLastError();
-  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_DEVICE_GUARD(b->device);
   hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), 0, b->stream, b->d, b->cam0, b->ray0);
   PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
   PTZ_HIP_TRY(hipGetLastError());
@@ -1184,7 +1219,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
 {
   (void)hipGetLastError();
   if (!b || !b->has_state || index < 0 || index >= b->n_scene) return PTZ_EINVAL;
-  PTZ_HIP_TRY(hipSetDevice(b->device));
+  PTZ_DEVICE_GUARD(b->device);
   const Dev& d = b->d;
   const int NC = b->nc;
   hipStream_t st = b->stream;

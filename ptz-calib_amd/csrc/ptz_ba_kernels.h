@@ -116,6 +116,13 @@ struct Dev {
   LmState* lm;
   int* active;       // [n_scene]
   int* ray_fail;     // [n_scene]
+  // Pass pipeline control of this scene group.  The host enqueues LM passes ahead of the device and never waits for one:
+  //   grp_ctl[0]  scenes of the group still active (device memory; atomically decremented by the block that retires a scene)
+  //   grp_ctl[1]  LM passes whose step-evaluation kernel has started (device memory)
+  //   host_ctl[0] copy of grp_ctl[1] in pinned host memory (the host throttles its run-ahead on it)
+  //   host_ctl[1] set to 1 by whoever retires the group's last scene (the host stops enqueuing passes when it sees it)
+  int* grp_ctl;
+  int* host_ctl;
   Opt opt;
   // reduced camera system
   CholBatch chol;
@@ -129,6 +136,14 @@ __device__ __forceinline__ const double* cur_cam(const Dev& d, const SceneDev& s
 __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s, const LmState& st)
 {
   return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
+}
+
+// A scene leaves the pass pipeline (one thread of the scene's LM block calls this, once per scene and solve).
+__device__ __forceinline__ void retire_scene(const Dev& d, int sc)
+{
+  d.active[sc] = 0;
+  if (atomicSub(&d.grp_ctl[0], 1) == 1)
+    __hip_atomic_store(&d.host_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // TYPE = factor (0 PTZRay, 1 PTZRayDist, 2 PTZRayFxfyDist) + 3 * has3d.
@@ -666,9 +681,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
     if (st.step_is_successful) ++st.num_successful; else ++st.num_unsuccessful;
     if (st.it_cost < st.final_cost) st.final_cost = st.it_cost;
     ++st.n_summaries;
-    if (st.iteration >= d.opt.max_num_iterations) { st.termination = PTZ_NO_CONVERGENCE; d.active[sc] = 0; }
-    else if (st.step_is_successful && st.grad_max <= d.opt.gradient_tolerance) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
-    else if (st.radius <= d.opt.min_radius) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; }
+    if (st.iteration >= d.opt.max_num_iterations) { st.termination = PTZ_NO_CONVERGENCE; retire_scene(d, sc); }
+    else if (st.step_is_successful && st.grad_max <= d.opt.gradient_tolerance) { st.termination = PTZ_CONVERGENCE; retire_scene(d, sc); }
+    else if (st.radius <= d.opt.min_radius) { st.termination = PTZ_CONVERGENCE; retire_scene(d, sc); }
     else {
       ++st.iteration;
       ++st.num_lm_steps;
@@ -1159,6 +1174,8 @@ template <int TYPE>
 __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
 {
   const int sc = blockIdx.x;
+  if (sc == 0 && threadIdx.x == 0)  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
+    __hip_atomic_store(&d.host_ctl[0], ++d.grp_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
@@ -1211,7 +1228,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   st.it_cost = st.x_cost;
   if (!valid) {  // HandleInvalidStep
     ++st.num_consecutive_invalid;
-    if (st.num_consecutive_invalid >= o.max_consecutive_invalid) { st.termination = PTZ_FAILURE; d.active[sc] = 0; return; }
+    if (st.num_consecutive_invalid >= o.max_consecutive_invalid) { st.termination = PTZ_FAILURE; retire_scene(d, sc); return; }
     st.radius *= 0.5;  // StepIsInvalid
     st.reuse_diagonal = 0;
     return;
@@ -1220,10 +1237,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   if (!isfinite(cost)) cost = 1.7976931348623157e308;
   st.candidate_cost = cost;
   // ParameterToleranceReached
-  if (sqrt(dn) <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  if (sqrt(dn) <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { st.termination = PTZ_CONVERGENCE; retire_scene(d, sc); return; }
   // FunctionToleranceReached
   const double cost_change = st.x_cost - cost;
-  if (fabs(cost_change) <= o.function_tolerance * st.x_cost) { st.termination = PTZ_CONVERGENCE; d.active[sc] = 0; return; }
+  if (fabs(cost_change) <= o.function_tolerance * st.x_cost) { st.termination = PTZ_CONVERGENCE; retire_scene(d, sc); return; }
   const double rho = cost_change / mcc;  // TrustRegionStepEvaluator::StepQuality, monotonic steps
   if (rho > o.min_relative_decrease) {
     // HandleSuccessfulStep: x <- candidate; the Jacobian is re-evaluated by the kernels that follow
@@ -1260,6 +1277,11 @@ __global__ void k_reset(Dev d)
   d.lm[sc] = st;
   d.active[sc] = 1;
   d.ray_fail[sc] = 0;
+}
+// control words of one scene group (see Dev::grp_ctl); the host zeroes its pinned mirror itself before it enqueues anything
+__global__ void k_ctl_reset(Dev d)
+{
+  if (threadIdx.x == 0) { d.grp_ctl[0] = d.n_scene; d.grp_ctl[1] = 0; }
 }
 __global__ void k_fill(double* p, size_t n, double v)
 {

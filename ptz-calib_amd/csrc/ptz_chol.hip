@@ -638,7 +638,7 @@ extern "C" int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops)
   if (!tflops) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(device_id));
+  PTZ_DEVICE_GUARD(device_id);
   hipDeviceProp_t prop;
   PTZ_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   double* d_out = nullptr;
@@ -688,7 +688,7 @@ extern "C" int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, doubl
   if (!read_gbps || !copy_gbps) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(device_id));
+  PTZ_DEVICE_GUARD(device_id);
   hipDeviceProp_t prop;
   PTZ_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   const size_t bytes = (size_t)4 << 30, n = bytes / sizeof(double2);
@@ -733,7 +733,7 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   if (count <= 0 || n <= 0 || !A || !rhs || !x) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(device_id));
+  PTZ_DEVICE_GUARD(device_id);
   CholBatch cb;
   cb.count = count;
   cb.np = chol_padded_order(n);

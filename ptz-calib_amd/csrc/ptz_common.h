@@ -21,6 +21,24 @@ namespace ptz {
 
 constexpr int WAVE = 64;
 
+// Every C-ABI entry point runs on the device it was given and leaves the calling thread's current device as it found it
+// (a PyTorch caller's later launches must not land on another GPU because a batch was destroyed at GC time).
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false, ok = true;
+  explicit DeviceGuard(int dev)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; changed = ok; }
+  }
+  ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define PTZ_DEVICE_GUARD(dev)              \
+  ptz::DeviceGuard _ptz_guard(dev);        \
+  if (!_ptz_guard.ok) return PTZ_ENODEVICE
+
 // ---- XCD-aware block remap -------------------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs by linear block id.  For 2-D grids (x = item, y = scene) this
 // bijective remap gives each XCD a contiguous range of the logical (scene, item) space, so the workgroups that

@@ -452,8 +452,23 @@ extern "C" int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   (void)hipGetLastError();  // not this call's: an error left behind earlier on this thread
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PTZ_ENODEVICE;
+  // The launch goes to the device that owns the caller's buffers, on the caller's stream: a caller holding tensors and a
+  // stream on GPU 1 must not need to repeat that in opt->device_id.  An explicit, different device_id is a contradiction.
+  int device = -1;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_cam_cur) != hipSuccess) { (void)hipGetLastError(); return PTZ_EINVAL; }
+    device = attr.device;
+    if (hip_stream) {
+      hipDevice_t sdev = -1;
+      if (hipStreamGetDevice((hipStream_t)hip_stream, &sdev) != hipSuccess) { (void)hipGetLastError(); return PTZ_EINVAL; }
+      if ((int)sdev != device) return PTZ_EINVAL;  // stream and buffers live on different devices
+    }
+    if (device < 0 || device >= ndev) return PTZ_EINVAL;
+    if (opt && opt->device_id != 0 && opt->device_id != device) return PTZ_EINVAL;
+  }
+  PTZ_DEVICE_GUARD(device);
   launch_krt(n_query, (const long long*)d_match_ptr, (const float2*)d_uv_ref, (const float2*)d_uv_cur, (const long long*)d_point_ptr,
              (const float2*)d_pts2d, d_pts3d, d_cam_ref, d_cam_cur, factor_type, make_krt_opt(o, max_reproj_error), d_summaries, d_accepted,
              (hipStream_t)hip_stream);
@@ -490,7 +505,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   (void)hipGetLastError();  // not this call's: an error left behind earlier on this thread
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
-  PTZ_HIP_TRY(hipSetDevice(o.device_id));
+  PTZ_DEVICE_GUARD(o.device_id);
   const int64_t nm = match_ptr[n_query];
   // one pooled device block for everything the launch touches: [inputs | cam_cur (in/out) | summaries | accepted]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
