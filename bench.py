@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- PTZ-IBA LM throughput on MI355X (BASELINE.json metric: LM iterations/sec + views calibrated/sec,
-200-view synthetic PTZ rig).
+"""bench.py -- PTZ-IBA / PTZ-Reloc throughput on MI355X, on BASELINE.json's own configurations.
 
-A "step" is one pass of the hot path over one batch: every scene of the per-GPU shard is solved from its
-initial guess to Ceres-style termination (ptz_ba_batch_solve).  Inputs (observations, structure, initial
-state) are resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, backend
-nccl = RCCL), each rank owns its own scenes (weak scaling, no data-path collective); the timed region is
-bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
+BASELINE metric: "LM iterations/sec + views calibrated/sec, 200-view synthetic PTZ rig, 1/2/4/8 GPU".
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--views 200] [--obs 500]
+  --config C4 (default)  configs[3]: synthetic 1000-scene batch, 200 views x 500 obs/view each, every scene its own seed.
+                         One batch of 1000 scenes PER GPU (weak scaling: rank r solves seeds r*1000 .. r*1000+999); a "step" is
+                         one pass of the hot path over that batch: every scene solved from its initial guess to Ceres-style
+                         termination (ptz_ba_batch_solve).  The line also carries configs[1] (ONE 200 x 500 rig alone, `c2_single_rig`,
+                         the configuration the 10 k it/s target is quoted on) with its per-pass critical path, configs[4]
+                         (`c5_reloc`, a bounded sample of the relocalization queries) and the PTZ-IBA orchestration on one rig.
+  --config C2            configs[1] as the headline: one rig per GPU, a step = one solve of it.
+  --config C5            configs[4] as the headline: 100 000 relocalization queries x 128 matches per GPU, a step = one
+                         ptz_krt_solve_batch_device launch over all of them (metric: LM iterations/s; queries/s beside it).
+
+Inputs (observations, structure, initial state) are resident in HBM before the timed region.  N > 1: one process per GPU
+(torch.distributed, backend nccl = RCCL), every rank owns its own scenes, no data-path collective; the timed region is
+bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported; the result gather (15 doubles per view)
+is timed separately (`gather_ms`).
+
+The roofline block prices every kernel family with SURVEY.md section 8(d)'s ALGORITHMIC bytes / flops per unit of work
+(DESIGN.md section 5): the implementation's own intermediates (the W = Jc^T Jr rows) are not algorithmic traffic.
 """
 from __future__ import annotations
 
@@ -22,18 +33,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; the in-repo guide lists no f64 figure
+F64_VALU_PEAK_TFLOPS = 78.6  # datasheet FP64 vector (same rate as the matrix path on MI355X)
 
 
-def structural_update_flops(scene, nc, nb=64):
-    """Flops of the tile updates the factorisation actually executes: the library skips the 64 x 64 tiles that are zero by
-    structure (camera co-visibility closed under the fill of a symbolic factorisation, ptz_ba.hip / DESIGN.md section 4),
-    so the dense n^3/3 count would overstate the work.  Same construction as the host code, on the tile graph."""
+# ----------------------------------------------------------------------------------------------------------------- models
+def structural_tile_ops(scene, nc, nb=64):
+    """Tile operations the factorisation executes on a scene's reduced camera system: the library skips the 64 x 64 tiles that
+    are zero by structure (camera co-visibility closed under the fill of a symbolic factorisation, ptz_ba.hip / DESIGN.md
+    section 4).  Returns (tile updates, tile triangular solves, diagonal tiles).  Same construction as the host code."""
     import numpy as np
     n = nc * scene.n_cam
     nt = (n + 1 + nb - 1) // nb
-    tile = (np.arange(scene.n_cam) * nc) // nb  # a camera block can straddle two tiles: count both
+    tile = (np.arange(scene.n_cam) * nc) // nb
     tile_hi = (np.arange(scene.n_cam) * nc + nc - 1) // nb
     m = np.zeros((nt, nt), dtype=bool)
     bounds = np.flatnonzero(np.diff(scene.obs_ray)) + 1
@@ -44,79 +57,301 @@ def structural_update_flops(scene, nc, nb=64):
         m[np.ix_(ts, ts)] = True
     m[(n // nb):, :] = True  # the tile row that holds the right-hand side is full
     m = np.tril(m)
-    ops = 0
+    upd = 0
     for k in range(nt):
         rows = [i for i in range(k + 1, nt) if m[i, k]]
         for x in rows:
             for y in rows:
                 if y <= x:
                     m[x, y] = True
-                    ops += 1
-    return ops * 2.0 * nb ** 3
+                    upd += 1
+    trsm = int(np.tril(m, -1).sum())
+    return upd, trsm, nt
 
 
-def kernel_models(scenes, nc):
-    """Algorithmic bytes / flops per kernel family and per LM pass, summed over the scenes of one batch
-    (SURVEY.md section 8(d) per-unit figures; DESIGN.md 'Roofline accounting')."""
-    m = {}
-    n_obs = sum(s.n_obs for s in scenes)
-    n_ray = sum(s.n_ray for s in scenes)
-    ent = sum(int((s.ray_weight_local * (s.ray_weight_local + 1) // 2).sum()) for s in scenes)
-    syrk_flops = 0.0
-    chol_flops = 0.0
-    s_bytes = 0.0
-    cache = {}
-    for s in scenes:
-        n = nc * s.n_cam
-        chol_flops += n ** 3 / 3.0 + 2.0 * n * n
-        s_bytes += 8.0 * n * (n + 1) / 2
-        if id(s) not in cache:
-            cache[id(s)] = structural_update_flops(s, nc)
-        syrk_flops += cache[id(s)]
-    m["linearize"] = dict(bound="hbm", bytes=16.0 * n_obs + 104.0 * n_ray)
-    m["eval"] = dict(bound="hbm", bytes=16.0 * n_obs + 96.0 * n_ray)
-    m["ray_prep"] = dict(bound="hbm", bytes=96.0 * n_ray)
-    m["backsub"] = dict(bound="hbm", bytes=96.0 * n_ray)
-    m["schur"] = dict(bound="hbm", bytes=s_bytes + 2.0 * 8.0 * nc * 3 * n_obs, flops=ent * 2.0 * nc * 3 * nc)
-    m["chol_syrk"] = dict(bound="mfma", flops=syrk_flops)
-    m["chol_panel"] = dict(bound="mfma", flops=max(chol_flops - syrk_flops, 0.0))
-    m["chol_total_flops"] = chol_flops
-    return m
+def family_models(scene, nc):
+    """SURVEY.md section 8(d) per-unit figures for one scene and one LM pass, per kernel family of the library's profile:
+    bytes are ALGORITHMIC HBM bytes (what any implementation must move), flops the factorisation's arithmetic."""
+    n = nc * scene.n_cam
+    n_obs, n_ray = scene.n_obs, scene.n_ray
+    s_bytes = 8.0 * n * (n + 1) / 2            # reduced camera system, written once (K2) and read once (K3)
+    upd, trsm, nt = structural_tile_ops(scene, nc)
+    nb = 64
+    return {
+        "linearize": dict(bound="hbm", bytes=16.0 * n_obs + 104.0 * n_ray, unit="relinearisation"),     # K1
+        "eval": dict(bound="hbm", bytes=16.0 * n_obs + 96.0 * n_ray, unit="lm_step"),                     # K4
+        "ray_prep": dict(bound="hbm", bytes=96.0 * n_ray, unit="lm_step"),
+        "schur": dict(bound="hbm", bytes=s_bytes, unit="lm_step"),                                        # K2: S written once
+        "chol_syrk": dict(bound="mfma", flops=upd * 2.0 * nb ** 3 + nt * nb ** 3 / 3.0, unit="lm_step",   # tile updates + diagonal tiles
+                          flops_dense=n ** 3 / 3.0 + 2.0 * n * n),
+        "chol_panel": dict(bound="mfma", flops=trsm * 1.0 * nb ** 3, unit="lm_step"),                     # tile triangular solves
+        "chol_backsolve": dict(bound="hbm", bytes=s_bytes, unit="lm_step"),                               # L read once
+    }
 
 
+def roofline_table(prof, models, units, steps, traffic=None):
+    """Per family: device ms per solve, launches, algorithmic work, achieved rate and fraction of the bounding peak.
+    units[name] = executions of that family's unit of work by ALL scenes during the timed region."""
+    out = {}
+    for name, p in prof.items():
+        if p["launches"] <= 0:
+            continue
+        row = {"ms_per_solve": round(p["ms"] / steps, 4), "launches_per_solve": p["launches"] / steps,
+               "avg_launch_us": round(1e3 * p["ms"] / p["launches"], 2)}
+        mdl = models.get(name)
+        if mdl is not None:
+            u = units[mdl["unit"]]
+            if mdl["bound"] == "hbm":
+                work = mdl["bytes"] * u
+                ach = work / (p["ms"] * 1e-3) / 1e9
+                row.update(bound="hbm", algorithmic_bytes_per_unit=mdl["bytes"], unit=mdl["unit"], achieved_GBps=round(ach, 2),
+                           frac=round(ach / HBM_PEAK_GBS, 5))
+            else:
+                work = mdl["flops"] * u
+                ach = work / (p["ms"] * 1e-3) / 1e12
+                row.update(bound="mfma", flops_per_unit=mdl["flops"], unit=mdl["unit"], achieved_TFLOPs=round(ach, 3),
+                           frac=round(ach / F64_MFMA_PEAK_TFLOPS, 5))
+            if traffic and name in traffic:
+                t = traffic[name]
+                row["traffic_bytes_per_launch"] = t["hbm_bytes"]
+                row["traffic_note"] = t.get("note", "")
+                if mdl["bound"] == "hbm":
+                    alg_per_launch = work / p["launches"]
+                    row["traffic_ratio"] = round(t["hbm_bytes"] / max(alg_per_launch, 1.0), 2)
+        out[name] = row
+    return out
+
+
+def dominant_roofline(table, prof, models, units, traffic=None):
+    cand = [k for k in table if k in models]
+    dom = max(cand, key=lambda k: prof[k]["ms"])
+    row, mdl, p = table[dom], models[dom], prof[dom]
+    u = units[mdl["unit"]]
+    if mdl["bound"] == "hbm":
+        per_launch = mdl["bytes"] * u / p["launches"]
+        ach = per_launch / (p["ms"] / p["launches"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    algorithmic_bytes_per_launch=per_launch)
+    else:
+        per_launch = mdl["flops"] * u / p["launches"]
+        ach = per_launch / (p["ms"] / p["launches"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=ach / F64_MFMA_PEAK_TFLOPS, algorithmic_flops_per_launch=per_launch)
+    roof.update(traffic=row.get("traffic_bytes_per_launch"), avg_launch_ms=p["ms"] / p["launches"], launches=p["launches"])
+    if "traffic_ratio" in row:
+        roof["traffic_ratio"] = row["traffic_ratio"]
+        roof["traffic_source"] = row.get("traffic_note", "")
+    return roof
+
+
+def load_traffic(tag):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (same workload shape; PMC cannot be
+    collected from inside the benchmark process)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    except (OSError, ValueError):
+        return None
+    if tj.get("workload_tag") != tag:
+        return None
+    return tj.get("families")
+
+
+# ------------------------------------------------------------------------------------------------------------------ legs
+def single_rig_leg(pkg, scene, device_id):
+    """BASELINE configs[1]: ONE 200 x 500 rig alone on the GPU.  Wall time of a whole solve (graph-replayed passes, nothing
+    profiled), then the same solve with HIP events around every kernel family: the per-pass critical path in microseconds."""
+    import torch
+    b1 = pkg.api.BaBatch([scene], device_id=device_id)
+    b1.set_state(); b1.solve()
+    best = None
+    for _ in range(5):
+        t1 = time.perf_counter(); s1 = b1.solve(); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+        best = d1 if best is None else min(best, d1)
+    steps = s1[0]["num_lm_steps"]
+    b1.set_profiling(True); b1.solve(); prof = b1.get_profile(); b1.set_profiling(False)
+    dev_ms = b1.last_solve_ms()
+    b1.close()
+    per_pass = {k: round(1e3 * v["ms"] / steps, 2) for k, v in prof.items() if v["launches"] > 0}
+    return {"workload": f"C2: one rig, {scene.n_cam} views x {scene.n_obs // scene.n_cam} obs/view ({scene.n_obs} observations, "
+                        f"{scene.n_ray} rays), solved alone",
+            "lm_iterations_per_s": steps / best, "views_per_s": scene.n_cam / best, "ms_per_solve": 1e3 * best, "lm_steps": steps,
+            "us_per_lm_iteration": 1e6 * best / steps,
+            "per_pass_critical_path_us": per_pass,
+            "per_pass_critical_path_note": "HIP events around every kernel family of an eagerly enqueued solve (event pairs add "
+                                           f"a few us per family); that profiled solve took {dev_ms:.2f} ms on the device",
+            "termination_type": s1[0]["termination_type"]}
+
+
+class RelocRun:
+    """BASELINE configs[4]: relocalization queries x 128 matches, queries resident in HBM, one launch for all of them."""
+
+    def __init__(self, pkg, rb, device_id):
+        import numpy as np
+        import torch
+        self.pkg, self.rb, self.device_id = pkg, rb, device_id
+        self.dev = torch.device("cuda", device_id)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
+        self.d_ptr, self.d_ref, self.d_cur, self.d_cref = t(rb.match_ptr), t(rb.uv_ref), t(rb.uv_cur), t(rb.cam_ref)
+        self.init = t(rb.cam_init)
+        self.d_ccur = self.init.clone()
+        self.d_sum = torch.zeros((rb.n_query, 64), dtype=torch.uint8, device=self.dev)  # sizeof(ptz_lm_summary) = 64
+        self.d_acc = torch.zeros(rb.n_query, dtype=torch.int32, device=self.dev)
+        self.launch()
+        torch.cuda.synchronize()
+
+    def launch(self):
+        import torch
+        st = torch.cuda.current_stream(self.dev)
+        self.pkg.api.krt_solve_batch_device(self.rb.n_query, self.d_ptr, self.d_ref, self.d_cur, self.d_cref, self.d_ccur, self.d_sum,
+                                            self.d_acc, factor_type=self.rb.factor_type, stream=st.cuda_stream)
+
+    def run(self, steps):
+        """`steps` launches, each from the initial cameras.  Returns (wall seconds for all of them, leg dict)."""
+        import numpy as np
+        import torch
+        st = torch.cuda.current_stream(self.dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.d_ccur.copy_(self.init)
+            ev[2 * k].record(st)
+            self.launch()
+            ev[2 * k + 1].record(st)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kern_ms = sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(steps)) / steps
+        n_query = self.rb.n_query
+        summ = np.frombuffer(self.d_sum.cpu().numpy().tobytes(), dtype=np.int32).reshape(n_query, 16)
+        lm_steps = int(summ[:, 2].sum())
+        acc = int(self.d_acc.sum().item())
+        # SURVEY 8(d): 2 x 16 B x M per LM iteration (linearise + candidate) + 240 B of state; ~300 flop per match and iteration
+        alg_bytes = 2.0 * 16.0 * 128 * lm_steps + 240.0 * lm_steps
+        alg_flops = 300.0 * 128 * lm_steps
+        gbps = alg_bytes / (kern_ms * 1e-3) / 1e9
+        tfl = alg_flops / (kern_ms * 1e-3) / 1e12
+        leg = {"workload": f"C5: {n_query} relocalization queries x 128 matches ({'FDist' if self.rb.factor_type else 'F'} factor), resident in "
+                           "HBM, one ptz_krt_solve_batch_device launch", "queries": n_query, "matches": int(self.rb.match_ptr[-1]),
+               "queries_per_s": n_query / (kern_ms * 1e-3), "lm_iterations_per_s": lm_steps / (kern_ms * 1e-3),
+               "kernel_ms": kern_ms, "wall_ms_per_launch": 1e3 * wall / steps, "lm_iterations": lm_steps, "accepted": acc,
+               "roofline": {"kernel": "k_krt", "bound": "hbm" if gbps / HBM_PEAK_GBS > tfl / F64_VALU_PEAK_TFLOPS else "f64_valu",
+                            "achieved_GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS, "achieved_TFLOPs_f64_valu": tfl,
+                            "frac_f64_valu": tfl / F64_VALU_PEAK_TFLOPS, "algorithmic_bytes_per_launch": alg_bytes,
+                            "algorithmic_flops_per_launch": alg_flops,
+                            "note": "bytes: 2 x 16 B x M + 240 B per LM iteration, flops: ~300 per match and iteration (SURVEY 8(d)); "
+                                    "`bound` names the peak the kernel sits closer to"}}
+        return wall, leg, lm_steps
+
+
+def iba_leg(pkg, scene):
+    """Second half of BASELINE's metric: views calibrated / s of the full incremental pipeline (PtzIncrementalOptimizer, C++
+    host class, every solve on the device): one rig of the same shape, starting from uncalibrated cameras."""
+    import numpy as np
+    tb = pkg.synth.make_match_table(scene)
+    cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
+    pkg.hostlib.incremental_solve(tb, cam0, max_iter=200)  # warm-up (resource pool, code objects)
+    t1 = time.perf_counter(); r = pkg.hostlib.incremental_solve(tb, cam0, max_iter=200); d1 = time.perf_counter() - t1
+    reg = r["registered"]
+    solve_ms = float(r["timing_ms"]["construct"] + r["timing_ms"]["solve"])
+    return {"views": tb.n_img, "registered": len(reg), "wall_ms": 1e3 * d1, "views_per_s": len(reg) / d1,
+            "solve_ms": solve_ms, "views_per_s_solve_only": len(reg) / (solve_ms * 1e-3),
+            "bundle_adjustments": sum(1 for e in r["events"] if e[0] == 2), "lm_iterations": r["lm_iterations"],
+            "registrations": sum(1 for e in r["events"] if e[0] == 1),
+            "max_focal_rel_error": float(np.abs(r["cameras"][reg, 0] / scene.cam_gt[reg, 0] - 1).max()) if reg else None,
+            "timing_ms": {k: round(float(v), 2) for k, v in r["timing_ms"].items()}}
+
+
+def cpu_baseline_leg(scenes, budget_s=12.0):
+    """The reference-faithful CPU oracle ("port": central-difference Jacobians over all 18 block parameters as
+    ceres::NumericDiffCostFunction, Ceres-1.14 LM policy, dense Schur) on scenes of the same workload: all usable host
+    cores (the figure of record), then one scene in closed-form-Jacobian mode and a few iterations on ONE thread, to
+    separate the algorithmic from the hardware speed-up.  A restatement, not the Ceres/OpenCV binary."""
+    orc = ge.load_oracle()
+    orc.build()
+    cores = orc.usable_cores()
+    n_done, steps_done, t_cpu = 0, 0, 0.0
+    for sc in scenes:
+        t1 = time.perf_counter()
+        _, _, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, num_threads=cores)
+        t_cpu += time.perf_counter() - t1
+        n_done += 1
+        steps_done += osumm["num_lm_steps"]
+        if t_cpu > budget_s:
+            break
+    t1 = time.perf_counter()
+    _, _, _, asumm, _ = orc.ba_solve(scenes[0], jacobian_mode=orc.JAC_ANALYTIC, num_threads=cores)
+    t_an = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    _, _, _, ssumm, _ = orc.ba_solve(scenes[0], jacobian_mode=orc.JAC_NUMERIC, num_threads=1, max_num_iterations=6)
+    t_1 = time.perf_counter() - t1
+    return {"value": steps_done / t_cpu, "unit": "LM iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} scenes of the same workload (seeds {scenes[0].seed:#x}..), solved one after the other to termination: "
+                      f"{steps_done} LM iterations in {t_cpu:.2f} s, numeric-diff oracle with OpenMP on {cores} cores",
+            "analytic_jacobians_all_cores": {"value": asumm["num_lm_steps"] / t_an, "sample": f"1 scene, {asumm['num_lm_steps']} LM iterations in {t_an:.2f} s"},
+            "numeric_one_thread": {"value": ssumm["num_lm_steps"] / t_1, "cores": 1,
+                                   "sample": f"1 scene, first {ssumm['num_lm_steps']} LM iterations in {t_1:.2f} s"}}
+
+
+# ------------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="scenes per GPU")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct seeded scenes generated per GPU (cycled to fill the batch)")
+    ap.add_argument("--config", choices=["C4", "C2", "C5"], default="C4")
+    ap.add_argument("--scenes", type=int, default=None, help="scenes per GPU (C4: 1000, C2: 1)")
+    ap.add_argument("--batch", type=int, default=None, help="alias of --scenes")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct seeded scenes per GPU (default: all of them)")
+    ap.add_argument("--queries", type=int, default=100000, help="C5: queries per GPU")
     ap.add_argument("--views", type=int, default=200)
     ap.add_argument("--obs", type=int, default=500)
+    ap.add_argument("--workers", type=int, default=None, help="host processes that generate the synthetic scenes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the timed batch solves: no single-rig / orchestration / two-group / CPU extras, so that a "
-                         "rocprofv3 --stats summary of this command averages over the timed launch shape alone")
-    ap.add_argument("--single-scene", action="store_true", help="(always on; kept for compatibility) time one scene alone")
-    ap.add_argument("--iba", action="store_true", help="(always on; kept for compatibility) run the whole PTZ-IBA orchestration on one rig")
+                    help="only the timed steps: no single-rig / reloc / orchestration / CPU legs, so that a rocprofv3 --stats "
+                         "summary of this command averages over the timed launch shape alone")
     args = ap.parse_args()
 
     import numpy as np
-    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    pkg = ge.load_package()
+
+    # ---- synthetic inputs first: the generator forks worker processes, which must happen before this process touches the GPU
+    n_scenes = args.scenes or args.batch or (1000 if args.config == "C4" else 1)
+    t_gen = time.perf_counter()
+    scenes, base = [], []
+    if args.config in ("C4", "C2"):
+        distinct = max(1, min(n_scenes, args.distinct or n_scenes))
+        workers = args.workers
+        if workers is None and world > 1:
+            workers = max(1, min(16, (os.cpu_count() or 8) // world))
+        base = pkg.synth.make_scenes([rank * n_scenes + i for i in range(distinct)], args.views, args.obs, workers=workers)
+        scenes = [base[i % distinct] for i in range(n_scenes)]
+    rb_c5 = pkg.synth.make_reloc_queries(args.queries, 128, seed_id=1 + rank, factor_type=0) if args.config == "C5" else None
+    extras = not args.headline_only
+    c2_scene = None
+    if extras and rank == 0:
+        c2_scene = base[0] if base else pkg.synth.make_scene(0, args.views, args.obs)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
     dist = None
     # Debug aid for boxes with ONE GPU: PTZ_BENCH_SHARED_GPU=1 lets several ranks share device 0 (gloo for the collectives),
     # which exercises the multi-rank bookkeeping of this script; it is not a measurement mode.
     shared_gpu = os.environ.get("PTZ_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
-    if world > 1:
+    backend = None
+    # under torch.distributed.run (RANK / MASTER_ADDR in the environment) the collectives are set up even for one rank, so that
+    # `--gpus 1` launched the way the driver launches N > 1 exercises the same RCCL code path
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
+        backend = "gloo" if shared_gpu else "nccl"
         if shared_gpu:
             dist.init_process_group(backend="gloo")
         else:
@@ -124,81 +359,74 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank)
 
-    pkg = ge.load_package()
-    B = args.batch
-    distinct = max(1, min(B, args.distinct))
-    base = [pkg.synth.make_scene(rank * distinct + i, args.views, args.obs) for i in range(distinct)]
-    scenes = [base[i % distinct] for i in range(B)]
-    for s in base:
-        s.ray_weight_local = np.bincount(s.obs_ray, minlength=s.n_ray).astype(np.int64)
-    batch = pkg.api.BaBatch(scenes, device_id=local_rank)
-    batch.set_state()  # observations, structure and the initial state are now resident in HBM
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        summ = batch.solve()
-    batch.set_profiling(True)  # HIP events around every kernel family on the solver's own stream
-    barrier()
-    t0 = time.perf_counter()
-    lm_steps = 0
-    for _ in range(args.steps):
-        summ = batch.solve()
-        lm_steps += sum(s["num_lm_steps"] for s in summ)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = batch.get_profile()
-    batch.set_profiling(False)
+    out = {}
+    gather_ms = None
+    if args.config == "C5":
+        rr = RelocRun(pkg, rb_c5, local_rank)
+        rr.run(max(args.warmup, 1))
+        barrier()
+        t0 = time.perf_counter()
+        _, leg, lm_steps_launch = rr.run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        lm_steps = lm_steps_launch * args.steps
+        units_done = float(args.queries * args.steps)
+        summ = []
+    else:
+        batch = pkg.api.BaBatch(scenes, device_id=local_rank)
+        batch.set_state()  # observations, structure and the initial state are now resident in HBM
+        for _ in range(args.warmup):
+            summ = batch.solve()
+        batch.set_profiling(True)  # HIP events around every kernel family on the solver's own stream
+        barrier()
+        t0 = time.perf_counter()
+        lm_steps = 0
+        jac_evals = 0
+        for _ in range(args.steps):
+            summ = batch.solve()
+            lm_steps += sum(s["num_lm_steps"] for s in summ)
+            jac_evals += sum(s["num_jacobian_evals"] + 1 for s in summ)  # + the re-evaluation after the Jacobi scales are fixed
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = batch.get_profile()
+        batch.set_profiling(False)
+        units_done = float(n_scenes * args.views * args.steps)
+        # results to rank 0: 15 doubles per view and a summary triple per scene (the only collective of the path)
+        if dist is not None:
+            cams, _ = batch.get_state()
+            payload = np.stack([np.concatenate([c.reshape(-1), [s["termination_type"], s["num_iterations"], s["final_cost"]]])
+                                for c, s in zip(cams, summ)])
+            barrier()
+            tg = time.perf_counter()
+            gathered = pkg.sharding.gather_results(list(range(rank * n_scenes, (rank + 1) * n_scenes)), payload, n_scenes * world, dist,
+                                                   None if shared_gpu else dev)
+            barrier()
+            gather_ms = 1e3 * (time.perf_counter() - tg)
+            assert gathered.shape[0] == n_scenes * world
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ws = torch.tensor([float(lm_steps), float(B * args.views * args.steps),
-                       float(sum(1 for s in summ if s["termination_type"] == 0))], dtype=torch.float64, device=dev)
+    ws = torch.tensor([float(lm_steps), units_done, float(sum(1 for s in summ if s["termination_type"] == 0))], dtype=torch.float64, device=dev)
+    per_rank = None
     if dist is not None:
+        parts = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        per_rank = [1e3 * float(p.item()) / args.steps for p in parts]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ws, op=dist.ReduceOp.SUM)
     t_max = float(tt.item())
-    total_steps, total_views, n_conv = (float(v) for v in ws.tolist())
+    total_steps, total_units, n_conv = (float(v) for v in ws.tolist())
 
-    out = None
     if rank == 0:
-        models = kernel_models(scenes, batch.nc)
-        per = {k: v for k, v in prof.items() if v["launches"] > 0}
-        # dominant kernel family = largest device time among the families whose work scales with the batch
-        cand = [k for k in per if k in models and k != "chol_total_flops"]
-        dom = max(cand, key=lambda k: per[k]["ms"])
-        passes = lm_steps / max(len(scenes), 1) / args.steps  # mean LM passes per scene
-        launches = per[dom]["launches"]
-        avg_ms = per[dom]["ms"] / launches
-        mdl = models[dom]
-        n_pass_launches = per["ray_prep"]["launches"]  # one ray_prep launch per LM pass
-        if mdl["bound"] == "mfma":
-            per_launch = mdl["flops"] * (n_pass_launches / launches)  # family flops per pass spread over its launches
-            # only scenes still active do work: scale by the mean active fraction
-            active_frac = (lm_steps / args.steps) / (len(scenes) * (n_pass_launches / args.steps))
-            achieved = per_launch * active_frac / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, avg_launch_ms=avg_ms, launches=launches)
-        else:
-            per_launch = mdl["bytes"] * (n_pass_launches / launches)
-            active_frac = (lm_steps / args.steps) / (len(scenes) * (n_pass_launches / args.steps))
-            achieved = per_launch * active_frac / (avg_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms, launches=launches)
-        # HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (same workload;
-        # PMC cannot be collected from inside the benchmark process): bytes per launch, gfx950-corrected.
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            kname = tj["slot_to_kernel"].get(dom)
-            if kname in tj["kernels"] and B == 256 and args.views == 200 and args.obs == 500:
-                roof["traffic"] = tj["kernels"][kname]["hbm_bytes_corrected"]
-                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per-dispatch mean)"
-        except (OSError, KeyError, ValueError):
-            pass
+        par = {"world_size": world, "backend": backend or "none", "ranks_ms_per_step": per_rank, "gather_ms": gather_ms,
+               "world_size_seen_by_collective": (dist.get_world_size() if dist is not None else 1)}
         out = {
-            "metric": "LM iterations/sec (PTZ-IBA global BA, 200-view synthetic PTZ rig)",
+            "metric": "LM iterations/sec (PTZ-IBA global BA, 200-view synthetic PTZ rig)" if args.config != "C5"
+                      else "LM iterations/sec (PTZ-Reloc single-view LM, 128 matches per query)",
             "value": total_steps / t_max,
             "unit": "LM iterations/s",
             "n_gpus": world,
@@ -210,83 +438,68 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"C2-shaped PTZ-IBA scenes ({args.views} views x {args.obs} obs/view, PTZRay factor), "
-                                   f"{B} scenes per GPU solved concurrently ({distinct} distinct seeds per GPU)",
-                       "scenes_per_gpu": B, "views": args.views, "obs_per_view": args.obs,
-                       "n_obs_per_scene": base[0].n_obs, "n_ray_per_scene": base[0].n_ray,
-                       "parallelism": f"scene-sharded x{world}"},
-            "views_per_s": total_views / t_max,
-            "lm_steps_per_solve": total_steps / args.steps / world,
-            "converged_scenes": int(n_conv), "scenes_total": B * world,
-            "roofline": roof,
-            "kernel_ms_per_solve": {k: round(v["ms"] / args.steps, 3) for k, v in per.items()},
         }
-        # The timed region above runs with per-family profiling, which makes the library solve the batch as one scene group
-        # (exclusive kernel timings for the roofline).  Its default for batches is two independently pipelined groups whose
-        # kernels overlap; that throughput on the same resident batch, same solve, is reported beside the headline value.
-        extras = not args.headline_only
-        if extras:
+        if args.config == "C5":
+            out["config"] = {"workload": f"C5 (BASELINE configs[4]): {args.queries} relocalization queries x 128 matches per GPU, F factor, "
+                                         "queries resident in HBM", "queries_per_gpu": args.queries, "parallelism": f"query-sharded x{world}"}
+            out["queries_per_s"] = total_units / t_max
+            out["roofline"] = {"bound": "hbm", "kernel": "k_krt", "achieved": leg["roofline"]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": leg["roofline"]["frac_hbm"], "traffic": None,
+                               "avg_launch_ms": leg["kernel_ms"], "detail": leg["roofline"]}
+            out["c5_reloc"] = leg
+        else:
+            name = "C4 (BASELINE configs[3])" if args.config == "C4" and n_scenes == 1000 else ("C2 (BASELINE configs[1])" if n_scenes == 1 else "C4-shaped")
+            out["config"] = {"workload": f"{name}: {n_scenes} synthetic scenes per GPU in one batch, each {args.views} views x {args.obs} obs/view "
+                                         f"(PTZRay factor), {len(base)} distinct seeds per GPU (seed ids rank*{n_scenes} + i), every scene "
+                                         "solved from its initial guess to termination",
+                             "scenes_per_gpu": n_scenes, "distinct_seeds_per_gpu": len(base), "views": args.views, "obs_per_view": args.obs,
+                             "n_obs_per_scene_mean": float(np.mean([s.n_obs for s in base])),
+                             "n_ray_per_scene_mean": float(np.mean([s.n_ray for s in base])),
+                             "parallelism": f"scene-sharded x{world}", "scene_generation_s": round(t_gen, 1)}
+            out["views_per_s"] = total_units / t_max
+            out["lm_steps_per_solve"] = total_steps / args.steps / world
+            out["converged_scenes"] = int(n_conv)
+            out["scenes_total"] = n_scenes * world
+            models = family_models(base[0], batch.nc)
+            units = {"lm_step": float(lm_steps), "relinearisation": float(jac_evals)}
+            traffic = load_traffic(f"{args.config}:{n_scenes}x{args.views}x{args.obs}")
+            table = roofline_table(prof, models, units, args.steps, traffic)
+            out["roofline"] = dominant_roofline(table, prof, models, units, traffic)
+            out["kernel_families"] = table
+            out["roofline_note"] = ("achieved = SURVEY 8(d) algorithmic bytes (flops) of the family x units executed by all scenes in the "
+                                    "timed region / family device time (HIP events on the solver's stream); W = Jc^T Jr rows are an "
+                                    "intermediate, not algorithmic traffic; traffic = rocprofv3 PMC bytes per launch (profiles/)")
+        out["parallel"] = par
+        if extras and args.config != "C5":
+            # The timed region above runs with per-family profiling, which makes the library enqueue eagerly and solve the batch as
+            # one scene group (exclusive kernel timings for the roofline).  The library's default on the same resident batch:
             t2 = time.perf_counter()
             s2 = batch.solve()
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t2
-            note = ("library default (two pipelined scene groups), rank 0 only, profiling off" if "PTZ_BA_STREAMS" not in os.environ
-                    else f"PTZ_BA_STREAMS={os.environ['PTZ_BA_STREAMS']} from the environment, rank 0 only, profiling off")
-            out["default_two_groups"] = {"lm_iterations_per_s": sum(s["num_lm_steps"] for s in s2) / d2, "ms_per_solve": 1e3 * d2,
-                                         "note": note}
-        if extras:  # what this device sustains in the two units the roofline uses (micro-benchmarks of the library, ~1 s)
+            out["default_pipeline"] = {"lm_iterations_per_s": sum(s["num_lm_steps"] for s in s2) / d2, "ms_per_solve": 1e3 * d2,
+                                       "note": "library defaults (graph-replayed passes, scene groups as the library chooses), rank 0, profiling off"}
+        if extras:
             try:
                 rd, cp = pkg.api.hbm_bandwidth(local_rank)
                 out["measured_peaks"] = {"hbm_read_GBps": rd, "hbm_copy_GBps": cp, "mfma_f64_TFLOPs": pkg.api.mfma_f64_peak(local_rank),
                                          "note": "streaming read / copy of 4 GB; register-resident v_mfma_f64_16x16x4_f64 loop"}
             except pkg.api.PtzError:
                 pass
-        if extras:  # one rig alone (BASELINE configs[1]): latency-bound, reported beside the batch figure
-            b1 = pkg.api.BaBatch([base[0]], device_id=local_rank)
-            b1.set_state(); b1.solve()
-            t1 = time.perf_counter(); s1 = b1.solve(); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
-            out["single_scene"] = {"lm_iterations_per_s": s1[0]["num_lm_steps"] / d1, "ms_per_solve": 1e3 * d1,
-                                   "lm_steps": s1[0]["num_lm_steps"]}
-            b1.close()
-        if extras:  # second half of BASELINE's metric: views calibrated / s of the full incremental pipeline
-            # views calibrated / s of the full incremental pipeline (PtzIncrementalOptimizer, C++ host class, every
-            # solve on the device): one rig of the same shape, starting from uncalibrated cameras
-            tb = pkg.synth.make_match_table(base[0])
-            cam0 = np.zeros((tb.n_img, 15)); cam0[:, 0] = cam0[:, 1] = 1.0
-            pkg.hostlib.incremental_solve(tb, cam0, max_iter=200)  # warm-up (resource pool, code objects)
-            t1 = time.perf_counter(); r = pkg.hostlib.incremental_solve(tb, cam0, max_iter=200); d1 = time.perf_counter() - t1
-            reg = r["registered"]
-            solve_ms = float(r["timing_ms"]["construct"] + r["timing_ms"]["solve"])  # PtzIncrementalOptimizer ctor + Solve()
-            out["ptz_iba"] = {"views": tb.n_img, "registered": len(reg), "wall_ms": 1e3 * d1, "views_per_s": len(reg) / d1,
-                              "solve_ms": solve_ms, "views_per_s_solve_only": len(reg) / (solve_ms * 1e-3),
-                              "bundle_adjustments": sum(1 for e in r["events"] if e[0] == 2), "lm_iterations": r["lm_iterations"],
-                              "registrations": sum(1 for e in r["events"] if e[0] == 1),
-                              "max_focal_rel_error": float(np.abs(r["cameras"][reg, 0] / base[0].cam_gt[reg, 0] - 1).max()) if reg else None,
-                              "timing_ms": {k: round(float(v), 2) for k, v in r["timing_ms"].items()}}
+    if args.config != "C5":
+        batch.close()
+    if rank == 0:
+        if extras:
+            pkg.api.trim_cache()
+            out["c2_single_rig"] = single_rig_leg(pkg, c2_scene, local_rank)
+            if args.config != "C5":
+                out["c5_reloc"] = RelocRun(pkg, pkg.synth.make_reloc_queries(min(args.queries, 20000), 128, seed_id=1, factor_type=0), local_rank).run(5)[1]
+                out["c5_reloc"]["note"] = "bounded sample of configs[4]; `bench.py --config C5` runs all 100 000 queries"
+            out["ptz_iba"] = iba_leg(pkg, c2_scene)
         if world == 1 and extras and not args.no_cpu_baseline:
-            # CPU baseline: the reference-faithful oracle (central-difference Jacobians over all 18 block
-            # parameters as ceres::NumericDiffCostFunction, Ceres-1.14 LM policy, dense Schur) on scenes of the
-            # same workload, all host cores.  A restatement ("port"), not the Ceres/OpenCV binary.
-            orc = ge.load_oracle()
-            orc.build()
-            cores = orc.usable_cores()
-            # bounded sample: the distinct scenes of the workload one after the other until about 12 s of CPU work are spent
-            n_done, steps_done, t_cpu = 0, 0, 0.0
-            for sc in base:
-                t1 = time.perf_counter()
-                _, _, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, num_threads=cores)
-                t_cpu += time.perf_counter() - t1
-                n_done += 1
-                steps_done += osumm["num_lm_steps"]
-                if t_cpu > 12.0:
-                    break
-            out["cpu_baseline"] = {"value": steps_done / t_cpu, "unit": "LM iterations/s", "cores": cores,
-                                   "kind": "port",
-                                   "sample": f"{n_done} scenes of the same workload (seeds {base[0].seed:#x}..), solved one after the other "
-                                             f"to termination: {steps_done} LM iterations in {t_cpu:.2f} s, numeric-diff oracle with "
-                                             f"OpenMP on {cores} cores"}
+            cb_scenes = base if base else [c2_scene]
+            out["cpu_baseline"] = cpu_baseline_leg(cb_scenes)
         print(json.dumps(out), flush=True)
-    batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -41,7 +41,7 @@ def gather_results(local_ids, local_payload: np.ndarray, n_items: int, dist=None
     Returns [n_items, width] on every rank.  With dist=None (single process) it is a local scatter."""
     width = local_payload.shape[1] if local_payload.ndim == 2 else 0
     out = np.zeros((n_items, width))
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():  # (a one-rank group still goes through the collective)
         out[list(local_ids)] = local_payload
         return out
     import torch
@@ -50,18 +50,18 @@ def gather_results(local_ids, local_payload: np.ndarray, n_items: int, dist=None
     cap = (n_items + world - 1) // world + 1
     blk = torch.zeros((cap, width + 1), dtype=torch.float64)
     blk[:, 0] = -1
-    for k, i in enumerate(local_ids):
-        blk[k, 0] = i
-        blk[k, 1:] = torch.from_numpy(np.asarray(local_payload[k], dtype=np.float64))
+    ids = np.asarray(list(local_ids), dtype=np.float64)
+    if len(ids):
+        blk[: len(ids), 0] = torch.from_numpy(ids)
+        blk[: len(ids), 1:] = torch.from_numpy(np.ascontiguousarray(local_payload, dtype=np.float64).reshape(len(ids), width))
     if device is not None:
         blk = blk.to(device)
     parts = [torch.empty_like(blk) for _ in range(world)]
     dist.all_gather(parts, blk)
     for p in parts:
         p = p.cpu().numpy()
-        for row in p:
-            if row[0] >= 0:
-                out[int(row[0])] = row[1:]
+        rows = p[:, 0] >= 0
+        out[p[rows, 0].astype(np.int64)] = p[rows, 1:]
     return out
 
 

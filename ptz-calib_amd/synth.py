@@ -339,6 +339,125 @@ def make_reloc_batch(n_query: int, n_match: int = 128, seed_id: int = 0, factor_
                       cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
 
 
+def _mix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _grid_uniform(seed: int, q: np.ndarray, first: int, count: int) -> np.ndarray:
+    """Uniform [0, 1) numbers u[q, i], i = first .. first + count - 1, of a counter-based generator addressed by
+    (query, index): a query's numbers do not depend on how many queries are generated or in which chunks."""
+    with np.errstate(over="ignore"):
+        ctr = q.astype(np.uint64)[:, None] * np.uint64(1 << 16) + np.arange(first + 1, first + count + 1, dtype=np.uint64)[None, :]
+        z = _mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + ctr * _GOLDEN)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def make_reloc_queries(n_query: int, n_match: int = 128, seed_id: int = 0, factor_type: int = 0,
+                       rig: np.ndarray | None = None, width: int = 1920, height: int = 1080,
+                       noise_px: float = 0.5, chunk: int = 2048) -> RelocBatch:
+    """BASELINE C5 at full size (100 000 queries): the workload of make_reloc_batch -- pan / tilt over the covered band,
+    f ~ U(1500, 4000), n_match matches against the best-overlap reference view, 0.5 px noise, init = (f_ref, R_ref)
+    (run_ptz_reloc.cc:96-104) -- generated a chunk of queries at a time with a counter-based generator, because the
+    per-query Python loop of make_reloc_batch takes minutes at this size.  (A different random stream: the two functions do
+    not produce the same queries for the same seed.)"""
+    seed = SEED_BASE + 0x300000 + seed_id
+    cx, cy = 0.5 * width, 0.5 * height
+    if rig is None:
+        rig = make_scene(0, 200, 20).cam_gt
+    Rref = np.stack([rodrigues(c[4:7]) for c in rig])
+    fwd = Rref[:, 2, :]
+    cand = n_match * 4
+    assert 4 + 2 * cand + 8 * n_match < (1 << 16)
+    cam_ref = np.zeros((n_query, 15)); cam_gt = np.zeros((n_query, 15)); cam_init = np.zeros((n_query, 15))
+    uv_ref = np.zeros((n_query, n_match, 2), dtype=np.float32); uv_cur = np.zeros((n_query, n_match, 2), dtype=np.float32)
+    for q0 in range(0, n_query, chunk):
+        q = np.arange(q0, min(n_query, q0 + chunk))
+        nq = len(q)
+        head = _grid_uniform(seed, q, 0, 4)
+        pan = -math.pi + 2.0 * math.pi * head[:, 0]
+        tilt = np.deg2rad(-10.0 + 20.0 * head[:, 1])
+        fq = 1500.0 + 2500.0 * head[:, 2]
+        k1q = (-0.05 + 0.1 * head[:, 3]) if (factor_type & 1) else np.zeros(nq)
+        ct, st_, cp, sp = np.cos(tilt), np.sin(tilt), np.cos(pan), np.sin(pan)
+        # Rq = rot_x(tilt) @ rot_y(pan)
+        Rq = np.zeros((nq, 3, 3))
+        Rq[:, 0, 0] = cp; Rq[:, 0, 2] = sp
+        Rq[:, 1, 0] = st_ * sp; Rq[:, 1, 1] = ct; Rq[:, 1, 2] = -st_ * cp
+        Rq[:, 2, 0] = -ct * sp; Rq[:, 2, 1] = st_; Rq[:, 2, 2] = ct * cp
+        ref = np.argmax(Rq[:, 2, :] @ fwd.T, axis=1)
+        cr = rig[ref]                                   # [nq, 15]
+        u = _grid_uniform(seed, q, 4, 2 * cand)
+        pu = 8.0 + (width - 16.0) * u[:, :cand]
+        pv = 8.0 + (height - 16.0) * u[:, cand:]
+        ray_c = np.stack([(pu - cr[:, 2:3]) / cr[:, 0:1], (pv - cr[:, 3:4]) / cr[:, 1:2], np.ones_like(pu)], axis=2)  # [nq, cand, 3]
+        pc = ray_c @ (Rref[ref] @ np.transpose(Rq, (0, 2, 1)))  # R_ref^T applied to the pixel direction, then R_q
+        zz = pc[:, :, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = pc[:, :, 0] / zz
+            y = pc[:, :, 1] / zz
+            rad = 1.0 + k1q[:, None] * (x * x + y * y)
+            qu = fq[:, None] * x * rad + cx
+            qv = fq[:, None] * y * rad + cy
+        ok = (zz > 0.1) & (qu >= 8) & (qu <= width - 8) & (qv >= 8) & (qv <= height - 8)
+        first = np.argsort(~ok, axis=1, kind="stable")[:, :n_match]   # the first n_match candidates that land in the query frame
+        short = np.flatnonzero(ok.sum(axis=1) < n_match)
+        for r in short:  # degenerate overlap: pixels nearest the reference centre, as make_reloc_batch does
+            first[r] = np.argsort((pu[r] - cx) ** 2 + (pv[r] - cy) ** 2)[:n_match]
+        rows = np.arange(nq)[:, None]
+        un = _grid_uniform(seed, q, 4 + 2 * cand, 8 * n_match)
+        def gauss(k):  # Box-Muller on columns [2k, 2k + 1) blocks of n_match
+            u1 = 1.0 - un[:, (2 * k) * n_match:(2 * k + 1) * n_match]
+            u2 = un[:, (2 * k + 1) * n_match:(2 * k + 2) * n_match]
+            return noise_px * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+        uv_ref[q, :, 0] = (pu[rows, first] + gauss(0)).astype(np.float32)
+        uv_ref[q, :, 1] = (pv[rows, first] + gauss(1)).astype(np.float32)
+        uv_cur[q, :, 0] = (qu[rows, first] + gauss(2)).astype(np.float32)
+        uv_cur[q, :, 1] = (qv[rows, first] + gauss(3)).astype(np.float32)
+        cam_ref[q] = cr
+        g = cr.copy()
+        g[:, 0] = g[:, 1] = fq
+        g[:, 2], g[:, 3] = cx, cy
+        # rotation vector of Rq = rot_x(tilt) rot_y(pan), per query
+        for i in range(nq):
+            g[i, 4:7] = rodrigues_inv(Rq[i])
+        g[:, 10] = k1q
+        cam_gt[q] = g
+        ini = cr.copy()
+        ini[:, 1] = cr[:, 0]
+        ini[:, 2], ini[:, 3] = cx, cy
+        cam_init[q] = ini
+    match_ptr = np.arange(n_query + 1, dtype=np.int64) * n_match
+    return RelocBatch(n_query=n_query, match_ptr=match_ptr, uv_ref=uv_ref.reshape(-1, 2), uv_cur=uv_cur.reshape(-1, 2),
+                      cam_ref=cam_ref, cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
+
+
+def _make_scene_job(args):
+    return make_scene(*args[0], **args[1])
+
+
+def make_scenes(scene_ids, n_views: int = 200, obs_per_view: int = 500, workers: int | None = None, **kw) -> list:
+    """make_scene for many ids on several host processes (a C2 scene takes 0.2-0.5 s of numpy; BASELINE C4 wants 1000).
+    Call BEFORE the process touches the GPU: the workers are forked."""
+    import multiprocessing as mp
+    import os
+    ids = list(scene_ids)
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        workers = min(workers, 16)
+    workers = max(1, min(workers, len(ids)))
+    jobs = [((i, n_views, obs_per_view), kw) for i in ids]
+    if workers == 1:
+        return [_make_scene_job(j) for j in jobs]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_scene_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+
+
 def add_reloc_points(batch: RelocBatch, n_pt: int = 12, noise_px: float = 0.5, depth: float = 60.0) -> RelocBatch:
     """Adds n_pt 2D-3D constraints to every query: world points in front of the ground-truth camera, projected the way
     cv::projectPoints does with the ground-truth camera (its translation is the query's initial one, which the single-view
