@@ -81,6 +81,7 @@ struct ptz_ba_batch {
   std::vector<hipEvent_t> la_ev;
   bool lookahead = true;
   bool left_looking = true;  // left-looking column updates instead of right-looking trailing updates
+  bool fused_steps = false;  // a few scenes: one launch per block column, triangular solves folded into the trailing update
   int group_of(hipStream_t st) const { for (size_t g = 0; g < streams.size(); ++g) if (streams[g] == st) return (int)g; return -1; }
   hipStream_t aux_stream(hipStream_t st) const { const int g = group_of(st); return (lookahead && g >= 0 && g < (int)aux.size()) ? aux[g] : nullptr; }
   void lookahead_events(hipStream_t st, hipEvent_t* t, hipEvent_t* r) const { const int g = group_of(st); *t = la_ev[2 * g]; *r = la_ev[2 * g + 1]; }
@@ -213,7 +214,7 @@ struct StagedUpload {
   }
 };
 
-#define LAUNCH(kern, grid, block, smem, ...) hipLaunchKernelGGL(kern, grid, block, smem, b->stream, __VA_ARGS__)
+#define LAUNCH(kern, grid, block, smem, ...) ptz::launch(kern, grid, block, smem, b->stream, __VA_ARGS__)
 
 template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
 {
@@ -244,6 +245,7 @@ static void make_groups(ptz_ba_batch* b)
     d.yc += (size_t)lo * np;
     d.chol.count = hi - lo;
     d.chol.A += (size_t)lo * np * np;
+    if (d.chol.L) d.chol.L += (size_t)lo * np * np;
     d.chol.Ldiag += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
@@ -359,20 +361,20 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   // group's last scene has retired (two words in pinned memory per group, polled; no stream synchronisation, no copy).
   // Passes enqueued past that point are empty launches.  Groups drift out of phase, so the latency-bound part of one
   // group's pass (block-column chain of the factorisation, LM control) overlaps the throughput kernels of another.
-  const bool graph = b->use_graph && !b->profiling;
+  const bool graph = b->use_graph && !b->profiling && !b->lookahead && b->d.chol.tmask != nullptr;
   if (graph) {
     for (int g = 0; g < G; ++g) {
       if (b->pass_graph[g]) continue;
-      hipStream_t st = b->streams[g];
-      hipGraph_t gr = nullptr;
-      b->stream = st;
-      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      GraphRecorder rec;
+      bool ok = hipGraphCreate(&rec.graph, 0) == hipSuccess;
       if (ok) {
+        b->stream = b->streams[g];
+        g_recorder = &rec;
         enqueue_pass<TYPE>(b, b->dg[g], false);
-        ok = hipStreamEndCapture(st, &gr) == hipSuccess && gr != nullptr;
+        g_recorder = nullptr;
+        ok = rec.ok && hipGraphInstantiate(&b->pass_graph[g], rec.graph, nullptr, nullptr, 0) == hipSuccess;
       }
-      if (ok) ok = hipGraphInstantiate(&b->pass_graph[g], gr, nullptr, nullptr, 0) == hipSuccess;
-      if (gr) (void)hipGraphDestroy(gr);
+      if (rec.graph) (void)hipGraphDestroy(rec.graph);
       if (!ok) { (void)hipGetLastError(); b->pass_graph[g] = nullptr; b->use_graph = false; break; }
     }
   }
@@ -388,7 +390,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       const double te0 = now();
       b->stream = b->streams[g];
       const bool last = enq[g] == max_it;  // the last pass only closes the books (k_lm_pre)
-      if (!last && b->use_graph && !b->profiling && b->pass_graph[g]) PTZ_HIP_TRY(hipGraphLaunch(b->pass_graph[g], b->streams[g]));
+      if (!last && graph && b->use_graph && b->pass_graph[g]) PTZ_HIP_TRY(hipGraphLaunch(b->pass_graph[g], b->streams[g]));
       else enqueue_pass<TYPE>(b, b->dg[g], last);
       ++enq[g];
       progressed = true;
@@ -454,6 +456,20 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   hipEvent_t evT = nullptr, evR = nullptr;
   if (la) b->lookahead_events(stream, &evT, &evR);
   bool rest_pending = false;
+  if (b->fused_steps) {  // a few scenes: one launch per block column (chol_col_step_kernel)
+    b->prof_begin(P_CHOL_PANEL);
+    chol_diag_launch(cb, 0, stream);
+    b->prof_end();
+    for (int k = 0; k + 1 < nt; ++k) {
+      b->prof_begin(P_CHOL_SYRK);
+      chol_col_step_launch(cb, k, stream);
+      b->prof_end();
+    }
+    b->prof_begin(P_CHOL_BACK);
+    chol_backsolve_launch(cb, x, stream);
+    b->prof_end();
+    return;
+  }
   if (b->left_looking) {
     for (int k = 0; k < nt; ++k) {
       if (k > 0) {
@@ -987,6 +1003,13 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     d.chol.n = dn;
   }
   TRY(b->alloc(&d.chol.A, (size_t)n * d.chol.np * d.chol.np));
+  b->fused_steps = n < 8;  // a few scenes: one launch per block column (needs a second matrix for the finished L tiles)
+  if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) b->fused_steps = atoi(e) != 0;
+  if (b->fused_steps) {
+    TRY(b->alloc(&d.chol.L, (size_t)n * d.chol.np * d.chol.np));
+    // tiles outside the structure are read as zeros by the back-substitution and never written
+    if (hipMemset(d.chol.L, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+  }
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
   TRY(b->alloc(&d.chol.Dinv, (size_t)n * (d.chol.np / CHOL_NB) * 4 * 16 * 16));
   TRY(b->alloc(&d.chol.fail, (size_t)n));

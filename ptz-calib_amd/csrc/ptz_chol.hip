@@ -15,6 +15,9 @@
 //                          A_ij -= L_ik L_jk^T with v_mfma_f64_16x16x4_f64, operands staged through LDS.
 //   The right-hand side rides along as row n of the padded matrix (diagonal = CHOL_BIG), so the forward
 //   substitution is done by the same kernels; chol_backsolve finishes with L^T x = y.
+#include <atomic>
+#include <cstdlib>
+
 #include "ptz_common.h"
 
 namespace ptz {
@@ -108,111 +111,147 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 }
 
 // Factor the tile held in As (row-major, stride LD, fully loaded and synchronised by the caller; 256 threads).
-// Dv: LDS scratch [4][DB * LDD].  Writes Ldiag[sys][k], Dinv[sys][k][*] and raises cb.fail[sys] on a non-positive pivot.
+// Writes Ldiag[sys][k], Dinv[sys][k][*] and raises cb.fail[sys] on a non-positive pivot.
+//
+// The factorisation of a 64 x 64 tile is a chain of 64 pivots; what bounds it is the instruction stream of one pivot step,
+// not arithmetic.  So ONE wave runs the chain and keeps it in registers: lane r holds row 16 b + r of the current 16-column
+// block -- the rows of the diagonal block AND every row below it -- and one column sweep
+//     d = A[j][j];  L[r][j] = A[r][j] / sqrt(d);  A[r][q] -= L[r][j] L[q][j]   (q = j + 1 .. 15, all lanes at once)
+// factors the block and solves the rows below in the same instructions (the scalars L[q][j] come from lane q by
+// v_readlane; no LDS, no separate triangular solve).  Measured: 185 cycles per pivot, issue-bound (two v_readlane and one
+// FP64 FMA per updated column).  Everything else happens beside the chain: before a sweep the four waves bring its 16
+// columns up to date on the matrix cores (one 16-row block each, C -= X X^T over the finished column blocks); during a
+// sweep wave 1 inverts the previous 16 x 16 diagonal block (for the MFMA triangular solves of chol_trsm and the
+// back-substitution) and wave 2 stores the previous column block of L.
+__device__ __forceinline__ void diag_sweep_block(double* As, double* rdiag, int b, int kbase, int n, double& dmin, bool& bad)
+{
+  const int lane = threadIdx.x & 63;
+  const int rows = NB - DB * b;  // rows 16 b .. 63 of the tile live in lanes 0 .. rows - 1
+  // The rows of the diagonal block start with a zero upper triangle, so that L[r][j] = A[r][j] / sqrt(d) needs no case
+  // distinction (0 for r < j).
+  double a[DB], ird[DB];
+  {
+    const double* src = As + (DB * b + (lane < rows ? lane : 0)) * LD + DB * b;
+#pragma unroll
+    for (int q = 0; q < DB; q += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(src + q);
+      a[q] = (lane < DB && q > lane) ? 0.0 : v.x;
+      a[q + 1] = (lane < DB && q + 1 > lane) ? 0.0 : v.y;
+    }
+  }
+  // Software-pipelined by hand: the chain d_j -> 1/sqrt(d_j) -> L[:, j] -> A[:, j+1] -> d_{j+1} is issued first in every
+  // step, the updates of the columns further right fill its latency.  The scheduling fences keep the compiler from
+  // deferring those updates (it otherwise turns the sweep left-looking: a dependent chain of j products in front of
+  // every pivot).
+  double d = readlane_f64(a[0], 0);
+  ird[0] = rsqrt_nr(d);
+#pragma unroll
+  for (int j = 0; j < DB; ++j) {
+    const bool live = (kbase + DB * b + j) < n;
+    dmin = fmin(dmin, live ? d : 1.0);  // NaN pivots: fmin keeps the other operand, caught by `bad`
+    bad |= (d != d) && live;
+    const double l = a[j] * ird[j];   // lane j: d / sqrt(d); lanes below: L[r][j]; lanes above (diagonal block): 0
+    a[j] = l;
+    if (j + 1 < DB) {
+      a[j + 1] -= l * readlane_f64(l, j + 1);
+      d = readlane_f64(a[j + 1], j + 1);
+      ird[j + 1] = rsqrt_nr(d);
+    }
+#pragma unroll
+    for (int q = j + 2; q < DB; ++q) a[q] -= l * readlane_f64(l, q);  // A[r][q] -= L[r][j] L[q][j]
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < DB; ++j) rdiag[DB * b + j] = ird[j];  // 1 / L[j][j], for the block inverses
+  }
+  if (lane < rows) {
+    double* dst = As + (DB * b + lane) * LD + DB * b;
+#pragma unroll
+    for (int q = 0; q < DB; q += 2) *reinterpret_cast<double2*>(dst + q) = make_double2(a[q], a[q + 1]);
+  }
+}
+
+// inverse of the 16 x 16 diagonal block b of the factored tile by forward substitution, one wave, lane c = column c of
+// X = L_bb^-1:  X[i][c] = (delta_ic - sum_{m < i} L[i][m] X[m][c]) / L[i][i]   (the L entries are LDS broadcasts)
+__device__ __forceinline__ void diag_block_inverse(const double* As, const double* rdiag, int b, double* out)
+{
+  const int lane = threadIdx.x & 63, fr = lane & 15;
+  const double* Lb = As + (DB * b) * LD + DB * b;
+  double x[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) {
+    double s0 = (i == fr) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m + 1 < i; m += 2) {
+      const double2 lv = *reinterpret_cast<const double2*>(Lb + i * LD + m);
+      s0 -= lv.x * x[m]; s1 -= lv.y * x[m + 1];
+    }
+    if (i & 1) s0 -= Lb[i * LD + i - 1] * x[i - 1];
+    x[i] = (s0 + s1) * rdiag[DB * b + i];
+  }
+  if (lane < DB) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i) out[i * DB + fr] = x[i];
+  }
+}
+
+// column block b of the factored tile (16 columns, all 64 rows; the rows above the diagonal block are zero) to global, one wave
+__device__ __forceinline__ void diag_store_block(const double* As, int b, double* __restrict__ Lg)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = p * 64 + lane;           // 64 rows x 8 double2
+    const int row = idx >> 3, c2 = (idx & 7) * 2;
+    double2 v = make_double2(0.0, 0.0);
+    if (row >= DB * b) v = *reinterpret_cast<const double2*>(As + row * LD + DB * b + c2);
+    *reinterpret_cast<double2*>(Lg + (size_t)row * NB + DB * b + c2) = v;
+  }
+}
+
 __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n)
 {
   const int np = cb.np, nt = np / NB;
-  double* __restrict__ Dinv = cb.Dinv;
   int& okflag = *okflag_p;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15;            // row (steps 1-2) / fragment row (steps 3-4)
   const int fr = lane & 15, fq = lane >> 4;
-  if (threadIdx.x == 0) okflag = 1;
-  __syncthreads();
+  double* rdiag = &Dv[0][0];  // [64] reciprocals of the diagonal of L
+  double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
+  double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
   double dmin = 1.0;
   bool bad = false;
-  double* dv = Dv[w];
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
-    // ---- 1. factor the diagonal block in registers (right-looking; lanes 16..63 mirror lanes 0..15)
-    double a[DB], ird[DB];
-    {
-      const double* src = As + (DB * b + r) * LD + DB * b;
+    if (b > 0) {
+      // bring column block b up to date: wave w takes the 16-row block ri = b + w:  C(ri, b) -= sum_{m < b} X(ri, m) X(b, m)^T
+      const int ri = b + w;
+      if (ri < NB / DB) {
+        double* C = As + (DB * ri) * LD + DB * b;
+        d4 acc;
 #pragma unroll
-      for (int q = 0; q < DB; q += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(src + q);
-        a[q] = v.x; a[q + 1] = v.y;
-      }
-    }
-    // ---- 1 + 2 fused: lane r also carries column r of X = L_bb^-1 (x[i] = X[i][r]), built by the same column sweep
-    //      L X = I:  X[j][:] /= L[j][j];  X[i][:] -= L[i][j] X[j][:]  (i > j)  -- the scalar L[i][j] is the one the
-    //      factorisation step has just read from lane i, so the inverse costs no extra lane exchange.
-    double x[DB];
-#pragma unroll
-    for (int i = 0; i < DB; ++i) x[i] = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < DB; ++j) {
-      const double d = readlane_f64(a[j], j);
-      dmin = fmin(dmin, (k * NB + DB * b + j) < n ? d : 1.0);  // NaN pivots: fmin keeps the other operand, caught by l below
-      bad |= (d != d) && (k * NB + DB * b + j) < n;
-      ird[j] = rsqrt_nr(d);
-      const double l = (r == j) ? d * ird[j] : ((r > j) ? a[j] * ird[j] : 0.0);
-      a[j] = l;
-      x[j] *= ird[j];
-#pragma unroll
-      for (int q = j + 1; q < DB; ++q) {
-        const double lqj = readlane_f64(l, q);  // L[q][j]
-        a[q] -= l * lqj;                         // A[r][q] -= L[r][j] L[q][j]
-        x[q] -= lqj * x[j];                      // X[q][r] -= L[q][j] X[j][r]
-      }
-    }
-    if (lane < DB) {
-#pragma unroll
-      for (int i = 0; i < DB; ++i) dv[i * LDD + r] = x[i];
-    }
-    if (w == 0 && lane < DB) {
-      double* out = Dinv + (((size_t)sys * nt + k) * 4 + b) * (DB * DB);
-#pragma unroll
-      for (int i = 0; i < DB; ++i) out[i * DB + r] = x[i];
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): dv is private to this wave
-    // ---- 3. rows below: X = P (L_bb^-1)^T, wave w takes row block b + 1 + w
-    const int rb = b + 1 + w;
-    if (rb < NB / DB) {
-      double* P = As + (DB * rb) * LD + DB * b;
-      d4 xc = {0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[fr * LD + 4 * ks + fq], dv[fr * LDD + 4 * ks + fq], xc, 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) P[(fq + 4 * i) * LD + fr] = xc[i];
-    }
-    __syncthreads();
-    if (w == 3 && lane < DB) {  // every wave has read the block by now: store L_bb with a clean upper triangle
-      double* dst = As + (DB * b + r) * LD + DB * b;
-#pragma unroll
-      for (int q = 0; q < DB; ++q) dst[q] = (q <= r) ? a[q] : 0.0;
-    }
-    // ---- 4. trailing blocks (ri >= rj > b): C -= X_ri X_rj^T, dealt round-robin to the waves
-    {
-      int t = 0;
-      for (int ri = b + 1; ri < NB / DB; ++ri)
-        for (int rj = b + 1; rj <= ri; ++rj, ++t) {
-          if ((t & 3) != w) continue;
-          double* C = As + (DB * ri) * LD + DB * rj;
-          const double* Xi = As + (DB * ri) * LD + DB * b;
-          const double* Xj = As + (DB * rj) * LD + DB * b;
-          d4 acc;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = C[(fq + 4 * i) * LD + fr];
+        for (int i = 0; i < 4; ++i) acc[i] = C[(fq + 4 * i) * LD + fr];
+        for (int m = 0; m < b; ++m) {
+          const double* Xi = As + (DB * ri) * LD + DB * m;
+          const double* Xj = As + (DB * b) * LD + DB * m;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[fr * LD + 4 * ks + fq], Xj[fr * LD + 4 * ks + fq], acc, 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = acc[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = acc[i];
+      }
+      __syncthreads();
     }
+    if (w == 0) diag_sweep_block(As, rdiag, b, k * NB, n, dmin, bad);
+    else if (w == 1 && b > 0) diag_block_inverse(As, rdiag, b - 1, Dg + (b - 1) * (DB * DB));
+    else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
     __syncthreads();
   }
-  if ((bad || !(dmin > 0.0)) && threadIdx.x == 0) okflag = 0;
-  // the strict upper triangle outside the diagonal blocks still holds A's entries: clear it before publishing
-  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-    const int row = idx >> 6, col = idx & 63;
-    if ((col >> 4) > (row >> 4)) As[row * LD + col] = 0.0;
-  }
-  __syncthreads();
-  tile_s2g<256>(As, cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB);
-  if (threadIdx.x == 0 && !okflag) cb.fail[sys] = 1;
+  if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) cb.fail[sys] = 1;
+  if (w == 1) diag_block_inverse(As, rdiag, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB));
+  else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
+  (void)okflag;
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
@@ -383,6 +422,133 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// ---- one launch per block column for a FEW systems: triangular solves folded into the trailing update --------------------
+// Right-looking step k as ONE kernel: the workgroup of trailing tile (i, j), i >= j > k, first turns A_ik and A_jk into
+// L_ik = A_ik L_kk^-T and L_jk itself (the same blocked MFMA solve as chol_trsm_kernel, into LDS), then A_ij -= L_ik L_jk^T,
+// and the workgroup of tile (k+1, k+1) factors it on the spot.  Every L_ik is solved for by each tile of row / column i --
+// redundant arithmetic on compute units that would otherwise idle -- which removes the separate triangular-solve launch
+// from the 13-deep dependency chain of a single 800 x 800 system (26 launches -> 13).  The workgroup of the diagonal tile
+// (i, i) is the one that writes L_ik back (the back-substitution reads it).  For batches the left-looking kernels are used.
+__device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, int ldg, const double* Lk, const double* Di, double* xs,
+                                                 double* __restrict__ store_to)
+{
+  // this wave's 16 rows of the tile: X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T, c = 0..3; xs = those rows of the LDS image
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int q = 0; q < c; ++q)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double av = -xs[fr * LD + 16 * q + 4 * ks + fq];
+        const double bv = Lk[(16 * c + fr) * LD + 16 * q + 4 * ks + fq];
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[(fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): these rows are private to this wave
+    d4 xc = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double av = xs[fr * LD + 16 * c + 4 * ks + fq];
+      const double bv = Di[c * DB * LDD + fr * LDD + 4 * ks + fq];
+      xc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xc, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xs[(fq + 4 * i) * LD + 16 * c + fr] = xc[i];
+      if (store_to) store_to[(size_t)(fq + 4 * i) * ldg + 16 * c + fr] = xc[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
+{
+  int bx, sys;
+  xcd_remap(bx, sys);
+  if (cb.active && !cb.active[sys]) return;
+  const int np = cb.np, nt = np / NB;
+  const int n = cb.n[sys];
+  const int m = nt - k - 1;
+  int ii = (int)((sqrt(8.0 * bx + 1.0) - 1.0) * 0.5);
+  while ((ii + 1) * (ii + 2) / 2 <= bx) ++ii;
+  while (ii * (ii + 1) / 2 > bx) --ii;
+  const int jj = bx - ii * (ii + 1) / 2;
+  if (ii >= m) return;
+  const int ti = k + 1 + ii, tj = k + 1 + jj;
+  if (k * NB > n || ti * NB > n) return;  // padding
+  const bool next_diag = ti == tj && ti == k + 1;
+  bool do_update = true;
+  if (cb.tmask) {
+    const unsigned char* tm = cb.tmask + (size_t)sys * nt * nt;
+    if (!tm[ti * nt + k] || !tm[tj * nt + k]) do_update = false;  // L_ik or L_jk is structurally zero
+    else if (!tm[ti * nt + tj]) return;                            // (cannot happen: the mask is closed under fill)
+  }
+  if (!do_update && !next_diag) return;
+  double* A = cb.A + (size_t)sys * np * np;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Lk = smem;                    // [NB * LD]   L_kk
+  double* As = Lk + NB * LD;            // [NB * LD]   L_ik
+  double* Bs = As + NB * LD;            // [NB * LD]   L_jk (i != j)
+  double* Di = Bs + NB * LD;            // [4 * DB * LDD] inverses of the diagonal blocks of L_kk
+  double (*Dv)[DB * LDD] = reinterpret_cast<double (*)[DB * LDD]>(Di + 4 * DB * LDD);  // scratch of the diagonal factorisation
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const double* Bop = As;
+  if (do_update) {
+    tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+    const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+    for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
+    __syncthreads();
+    double* Tik = A + (size_t)(ti * NB + 16 * w) * np + k * NB;
+    double* Lik = cb.L + (size_t)sys * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
+    trsm_rows_to_lds(Tik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
+    if (ti != tj) {
+      trsm_rows_to_lds(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np, Lk, Di, Bs + 16 * w * LD, nullptr);
+      Bop = Bs;
+    }
+  }
+  double* C = A + (size_t)(ti * NB + 16 * w) * np + tj * NB;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
+  __syncthreads();
+  if (do_update) {
+    const double* ap = As + (16 * w + fr) * LD + fq;
+    const double* bp = Bop + fr * LD + fq;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double av = -ap[4 * kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
+    }
+  }
+  if (next_diag) {
+    __syncthreads();  // all waves are done reading the operand tiles
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+}
+
 // ---- left-looking column update: A_ij -= sum_{k < j} L_ik L_jk^T for the tiles (i, j), i >= j, of block column j -------
 // One workgroup per tile: the C tile stays in the accumulators while the loop walks the block columns k < j whose tiles
 // L_ik and L_jk are both in the structure, so C is read and written once per column step instead of once per k (the
@@ -457,7 +623,7 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb
   if (cb.active && !cb.active[sys]) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const double* A = cb.A + (size_t)sys * np * np;
+  const double* A = (cb.L ? cb.L : cb.A) + (size_t)sys * np * np;  // off-diagonal tiles of L
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* xs = smem;              // [np]  y, overwritten by x
   double* Lt = xs + np;           // [NB * LD]
@@ -563,41 +729,67 @@ void chol_clear(const CholBatch& cb, hipStream_t stream)
     // only the tiles of the structure are ever written (by the assembly and by the fill of the factorisation); the rest
     // of A was zeroed once when the batch was created and stays zero
     const int nt = cb.np / NB;
-    hipLaunchKernelGGL(chol_clear_tiles_kernel, dim3(nt * nt, cb.count), dim3(256), 0, stream, cb);
+    launch(chol_clear_tiles_kernel, dim3(nt * nt, cb.count), dim3(256), 0, stream, cb);
   }
   else {
     (void)hipMemsetAsync(cb.A, 0, sizeof(double) * (size_t)cb.count * cb.np * cb.np, stream);
   }
   dim3 grid((cb.np + 255) / 256, cb.count);
-  hipLaunchKernelGGL(chol_pad_kernel, grid, dim3(256), 0, stream, cb);
+  launch(chol_pad_kernel, grid, dim3(256), 0, stream, cb);
 }
 
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag_done)
 {
-  if (!diag_done) hipLaunchKernelGGL(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
+  if (!diag_done) launch(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
   const int m = cb.np / NB - k - 1;
-  if (m > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, (const double*)cb.Dinv, k);
+  if (m > 0) launch(chol_trsm_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, (const double*)cb.Dinv, k);
 }
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag)
 {
   const int m = cb.np / NB - k - 1;
   const int tiles = mode == 0 ? m * (m + 1) / 2 : (mode == 1 ? m : m * (m - 1) / 2);
-  if (tiles > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode, fuse_diag ? 1 : 0);
+  if (tiles > 0) launch(chol_syrk_kernel, dim3(tiles, cb.count), dim3(256), 0, stream, cb, k, mode, fuse_diag ? 1 : 0);
 }
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag)
 {
   const int m = cb.np / NB - j;
-  if (j > 0 && m > 0) hipLaunchKernelGGL(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
+  if (j > 0 && m > 0) launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
+}
+void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream)
+{
+  const int m = cb.np / NB - k - 1;
+  const size_t smem = sizeof(double) * (3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2);
+  {  // > 64 KiB of dynamic LDS: the cap is raised once per device
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)chol_col_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2, cb.count), dim3(256), smem, stream, cb, k);
+}
+void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
+{
+  launch(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
 }
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + NB + BS_THREADS + NB + 4 * 16 * 16);
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1, cb.count), dim3(BS_THREADS), smem, stream, cb, x);
+  launch(chol_backsolve_kernel, dim3(1, cb.count), dim3(BS_THREADS), smem, stream, cb, x);
 }
 
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
+  if (cb.L) {  // a few systems: one launch per block column
+    chol_diag_launch(cb, 0, stream);
+    for (int k = 0; k + 1 < nt; ++k) chol_col_step_launch(cb, k, stream);
+    chol_backsolve_launch(cb, x, stream);
+    return;
+  }
   // every trailing update also factors the diagonal tile of the next block column (it is final by then)
   for (int k = 0; k < nt; ++k) {
     chol_panel_launch(cb, k, stream, /*diag_done=*/k > 0);
@@ -747,6 +939,12 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   PTZ_HIP_TRY(hipMalloc(&dn, sizeof(int) * count));
   PTZ_HIP_TRY(hipMalloc(&dfail, sizeof(int) * count));
   cb.A = dA; cb.Ldiag = dL; cb.Dinv = dD; cb.n = dn; cb.fail = dfail;
+  double* dL2 = nullptr;
+  if (count < 8 && !getenv("PTZ_CHOL_MULTI_LAUNCH")) {  // the path a few bundle-adjustment scenes take
+    PTZ_HIP_TRY(hipMalloc(&dL2, sizeof(double) * (size_t)count * np * np));
+    PTZ_HIP_TRY(hipMemset(dL2, 0, sizeof(double) * (size_t)count * np * np));
+    cb.L = dL2;
+  }
   {
     int* hn = new int[count];
     for (int i = 0; i < count; ++i) hn[i] = n;
@@ -777,5 +975,6 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   if (fail) PTZ_HIP_TRY(hipMemcpy(fail, dfail, sizeof(int) * count, hipMemcpyDeviceToHost));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
+  if (dL2) (void)hipFree(dL2);
   return PTZ_OK;
 }

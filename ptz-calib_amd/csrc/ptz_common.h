@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <tuple>
+#include <utility>
 
 #include "../../include/ptz_calib_amd.h"
 
@@ -38,6 +42,46 @@ struct DeviceGuard {
 #define PTZ_DEVICE_GUARD(dev)              \
   ptz::DeviceGuard _ptz_guard(dev);        \
   if (!_ptz_guard.ok) return PTZ_ENODEVICE
+
+// ---- kernel launches that can be recorded into a hipGraph instead of being issued -----------------------------------------
+// One LM pass is the same ~25 launches with the same arguments every time, so it is built ONCE as a graph of kernel nodes
+// (a linear chain) and replayed per pass: one host call instead of 25.  The graph is built explicitly, node by node, not by
+// stream capture: capture puts a stream into a state that other host threads' synchronous runtime calls (another shard's
+// batch creation on the same device) can stall on, which deadlocked ptz_ba_solve_sharded.
+struct GraphRecorder {
+  hipGraph_t graph = nullptr;
+  hipGraphNode_t last = nullptr;
+  bool ok = true;
+};
+inline thread_local GraphRecorder* g_recorder = nullptr;  // set while a pass is being recorded on this thread
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t st, Args&&... args)
+{
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
+  if (!g_recorder) {
+    hipLaunchKernelGGL(kern, grid, block, smem, st, std::forward<Args>(args)...);
+    return;
+  }
+  std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);  // the kernel's own parameter types; copied by the runtime at node creation
+  void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+  {
+    size_t i = 0;
+    std::apply([&](auto&... v) { ((ptrs[i++] = (void*)&v), ...); }, vals);
+  }
+  hipKernelNodeParams p;
+  memset(&p, 0, sizeof(p));
+  p.func = (void*)kern;
+  p.gridDim = grid;
+  p.blockDim = block;
+  p.sharedMemBytes = (unsigned)smem;
+  p.kernelParams = ptrs;
+  p.extra = nullptr;
+  hipGraphNode_t node = nullptr;
+  GraphRecorder& r = *g_recorder;
+  if (hipGraphAddKernelNode(&node, r.graph, r.last ? &r.last : nullptr, r.last ? 1 : 0, &p) != hipSuccess) { r.ok = false; (void)hipGetLastError(); }
+  else r.last = node;
+}
 
 // ---- XCD-aware block remap -------------------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs by linear block id.  For 2-D grids (x = item, y = scene) this
@@ -105,6 +149,10 @@ struct CholBatch {
   int count = 0;
   int np = 0;             // padded order, multiple of CHOL_NB, >= max(n_i) + 1
   double* A = nullptr;    // device
+  // Where the off-diagonal tiles of L live once they are final.  nullptr: in place in A (the multi-launch paths).  The
+  // one-launch-per-column path (chol_col_step_kernel) cannot publish L_ik in place -- other workgroups of the same launch
+  // still read A_ik -- and writes a second matrix [count][np][np]; the back-substitution reads L from there.
+  double* L = nullptr;
   double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
   double* Dinv = nullptr;   // device [count][np/NB][4][16*16]: inverses of the 16x16 diagonal blocks of L_kk
   const int* n = nullptr;   // device [count]
@@ -123,6 +171,8 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag_done = false);  // diag (unless already done) + trsm
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag = false);  // mode 0 all, 1 column k+1, 2 rest; fuse_diag: also factor tile (k+1, k+1)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
+void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);       // factor the diagonal tile of block column k
+void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream);   // few systems: trsm + trailing update + next diagonal tile, one launch
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
 void chol_clear(const CholBatch& cb, hipStream_t stream);
