@@ -246,6 +246,7 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.count = hi - lo;
     d.chol.A += (size_t)lo * np * np;
     if (d.chol.L) d.chol.L += (size_t)lo * np * np;
+    if (d.chol.Linv) d.chol.Linv += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Ldiag += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
@@ -482,6 +483,7 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
       b->prof_end();
     }
     b->prof_begin(P_CHOL_BACK);
+    chol_tile_inverse_launch(cb, stream);
     chol_backsolve_launch(cb, x, stream);
     b->prof_end();
     return;
@@ -517,6 +519,7 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   }
   if (la && rest_pending) (void)hipStreamWaitEvent(stream, evR, 0);
   b->prof_begin(P_CHOL_BACK);
+  chol_tile_inverse_launch(cb, stream);
   chol_backsolve_launch(cb, x, stream);
   b->prof_end();
 }
@@ -1009,9 +1012,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     TRY(b->alloc(&d.chol.L, (size_t)n * d.chol.np * d.chol.np));
     // tiles outside the structure are read as zeros by the back-substitution and never written
     if (hipMemset(d.chol.L, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+
   }
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
   TRY(b->alloc(&d.chol.Dinv, (size_t)n * (d.chol.np / CHOL_NB) * 4 * 16 * 16));
+  TRY(b->alloc(&d.chol.Linv, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
   TRY(b->alloc(&d.chol.fail, (size_t)n));
   d.chol.active = d.active;
   TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));

@@ -123,7 +123,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // columns up to date on the matrix cores (one 16-row block each, C -= X X^T over the finished column blocks); during a
 // sweep wave 1 inverts the previous 16 x 16 diagonal block (for the MFMA triangular solves of chol_trsm and the
 // back-substitution) and wave 2 stores the previous column block of L.
-__device__ __forceinline__ void diag_sweep_block(double* As, double* rdiag, int b, int kbase, int n, double& dmin, bool& bad)
+__device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, int n, double& dmin, bool& bad)
 {
   const int lane = threadIdx.x & 63;
   const int rows = NB - DB * b;  // rows 16 b .. 63 of the tile live in lanes 0 .. rows - 1
@@ -163,7 +163,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, double* rdiag, int 
   }
   if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < DB; ++j) rdiag[DB * b + j] = ird[j];  // 1 / L[j][j], for the block inverses
+    for (int j = 0; j < DB; ++j) As[(DB * b + j) * LD + NB] = ird[j];  // 1 / L[j][j] in the padding column of the tile image, for the block inverses
   }
   if (lane < rows) {
     double* dst = As + (DB * b + lane) * LD + DB * b;
@@ -174,7 +174,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, double* rdiag, int 
 
 // inverse of the 16 x 16 diagonal block b of the factored tile by forward substitution, one wave, lane c = column c of
 // X = L_bb^-1:  X[i][c] = (delta_ic - sum_{m < i} L[i][m] X[m][c]) / L[i][i]   (the L entries are LDS broadcasts)
-__device__ __forceinline__ void diag_block_inverse(const double* As, const double* rdiag, int b, double* out)
+__device__ __forceinline__ void diag_block_inverse(const double* As, int b, double* out, double* out_lds)
 {
   const int lane = threadIdx.x & 63, fr = lane & 15;
   const double* Lb = As + (DB * b) * LD + DB * b;
@@ -188,11 +188,11 @@ __device__ __forceinline__ void diag_block_inverse(const double* As, const doubl
       s0 -= lv.x * x[m]; s1 -= lv.y * x[m + 1];
     }
     if (i & 1) s0 -= Lb[i * LD + i - 1] * x[i - 1];
-    x[i] = (s0 + s1) * rdiag[DB * b + i];
+    x[i] = (s0 + s1) * As[(DB * b + i) * LD + NB];
   }
   if (lane < DB) {
 #pragma unroll
-    for (int i = 0; i < DB; ++i) out[i * DB + fr] = x[i];
+    for (int i = 0; i < DB; ++i) { out[i * DB + fr] = x[i]; out_lds[i * LDD + fr] = x[i]; }
   }
 }
 
@@ -210,13 +210,51 @@ __device__ __forceinline__ void diag_store_block(const double* As, int b, double
   }
 }
 
+// X = L^-1 of a factored 64 x 64 tile from its 16 x 16 block inverses D_i = L_ii^-1:  X_ii = D_i,
+//   X_ij = -D_i sum_{m = j}^{i-1} L_im X_mj   (i > j),
+// one wave per block column j, everything on the matrix cores and in registers: with v_mfma_f64_16x16x4_f64 the accumulator
+// of a product (lane = column, register ks = row 4 ks + lane / 16) already IS the B operand of the next product.
+// Ls: tile image in LDS (stride LD); Dis: [4][16][LDD] block inverses in LDS; out: row-major 64 x 64 in global memory.
+__device__ __forceinline__ void tile_inverse(const double* Ls, const double* Dis, double* __restrict__ out)
+{
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  d4 X[NB / DB];  // X_mj, m = j .. 3, as B operands / accumulators
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) X[0][ks] = Dis[j * DB * LDD + (4 * ks + fq) * LDD + fr];
+  // block column j of X: zero above the diagonal block, D_j on it, X_ij below
+#pragma unroll
+  for (int bi = 0; bi < NB / DB; ++bi)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      if (bi <= j) out[(size_t)(DB * bi + 4 * ks + fq) * NB + DB * j + fr] = (bi == j) ? X[0][ks] : 0.0;
+#pragma unroll
+  for (int i = 1; i < NB / DB; ++i) {
+    const int bi = j + i;  // block row
+    if (bi < NB / DB) {    // (uniform per wave)
+      d4 S = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < i; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          S = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(DB * bi + fr) * LD + DB * (j + m) + 4 * ks + fq], X[m][ks], S, 0, 0, 0);
+      d4 R = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(-Dis[bi * DB * LDD + fr * LDD + 4 * ks + fq], S[ks], R, 0, 0, 0);
+      X[i] = R;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) out[(size_t)(DB * bi + 4 * ks + fq) * NB + DB * j + fr] = R[ks];
+    }
+  }
+}
+
 __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n)
 {
   const int np = cb.np, nt = np / NB;
   int& okflag = *okflag_p;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  double* rdiag = &Dv[0][0];  // [64] reciprocals of the diagonal of L
   double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
   double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
   double dmin = 1.0;
@@ -243,15 +281,20 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
       }
       __syncthreads();
     }
-    if (w == 0) diag_sweep_block(As, rdiag, b, k * NB, n, dmin, bad);
-    else if (w == 1 && b > 0) diag_block_inverse(As, rdiag, b - 1, Dg + (b - 1) * (DB * DB));
+    if (w == 0) diag_sweep_block(As, b, k * NB, n, dmin, bad);
+    else if (w == 1 && b > 0) diag_block_inverse(As, b - 1, Dg + (b - 1) * (DB * DB), Dv[b - 1]);
     else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
     __syncthreads();
   }
   if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) cb.fail[sys] = 1;
-  if (w == 1) diag_block_inverse(As, rdiag, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB));
+  if (w == 1) diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
   else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
   (void)okflag;
+  if (cb.L && cb.Linv && k == nt - 1) {
+    // the last diagonal tile has no later launch whose spare workgroup could invert it
+    __syncthreads();
+    tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + k) * (NB * NB));
+  }
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
@@ -478,6 +521,20 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   const int m = nt - k - 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (bx == m * (m + 1) / 2) {
+    // the spare workgroup of the launch: full inverse of the diagonal tile k (factored by the previous launch), off the
+    // critical chain; the back-substitution multiplies by it instead of solving with it
+    if (!cb.Linv || k * NB > n) return;
+    double* Lk = smem;
+    double* Di = smem + 3 * NB * LD;
+    tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+    const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+    for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
+    __syncthreads();
+    tile_inverse(Lk, Di, cb.Linv + ((size_t)sys * nt + k) * (NB * NB));
+    return;
+  }
   int ii = (int)((sqrt(8.0 * bx + 1.0) - 1.0) * 0.5);
   while ((ii + 1) * (ii + 2) / 2 <= bx) ++ii;
   while (ii * (ii + 1) / 2 > bx) --ii;
@@ -494,7 +551,6 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
   }
   if (!do_update && !next_diag) return;
   double* A = cb.A + (size_t)sys * np * np;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Lk = smem;                    // [NB * LD]   L_kk
   double* As = Lk + NB * LD;            // [NB * LD]   L_ik
   double* Bs = As + NB * LD;            // [NB * LD]   L_jk (i != j)
@@ -613,112 +669,124 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
-// ---- back substitution L^T x = y (y = row n of the factored matrix) ---------------------------------
-// Column-oriented: for k = last..first  { x_k = L_kk^-T y_k ;  y_j -= L[k-tile rows][j] x_k for all j < k*NB }.
-// The update reads the row panel of tile k, one thread per column -> fully coalesced row reads.
-constexpr int BS_THREADS = 1024;
-__global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(CholBatch cb, double* xout)
+// ---- full inverses of the factored diagonal tiles, all at once (the multi-launch paths; the one-launch-per-column path
+//      computes them in a spare workgroup of every launch) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
+{
+  const int sys = blockIdx.y, k = blockIdx.x;
+  if (cb.active && !cb.active[sys]) return;
+  const int nt = cb.np / NB;
+  if (k * NB > cb.n[sys]) return;
+  __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
+  __shared__ __attribute__((aligned(16))) double Di[4 * DB * LDD];
+  tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+  const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+  for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
+  __syncthreads();
+  tile_inverse(Lk, Di, cb.Linv + ((size_t)sys * nt + k) * (NB * NB));
+}
+
+// ---- back substitution with the inverted diagonal tiles ----------------------------------------------------------------
+// L^T x = y by block columns from the last:  x_k = (L_kk^-1)^T t_k;  t_j -= L_kj^T x_k for the tiles (k, j), j < k, of the
+// structure.  Both are the same operation -- out[c] (-)= sum_r M[r][c] v[r] over a 64 x 64 tile -- so the kernel runs ONE
+// list of work groups (the inverse of tile k alone, then the tiles of row k four at a time): thread = (slot, quarter of the
+// rows, column), coalesced 512-byte row reads straight from global memory (each tile is read exactly once), the four
+// quarter sums of a column meet in LDS in a fixed order.  The tile data does not depend on the vectors, so the loads of
+// the next TWO groups are always in flight while a group is reduced: the kernel streams L at the rate one compute unit
+// can pull, instead of paying a cold-miss latency per dependent step.  One workgroup per system: the steps depend on each
+// other, and a hand-off between workgroups costs more than a step.
+constexpr int BI_THREADS = 1024;
+struct BsItem { long long off; int ld, in_off, out_off, kind; };  // kind: 0 empty slot, 1 x = M^T t (diagonal inverse), 2 t -= M^T x
+
+__device__ __forceinline__ void bs_load(const BsItem* grp, const double* Lm, const double* Li, int sl, int q, int c, double (&v)[16])
+{
+  const BsItem it = grp[sl];
+  if (it.kind == 0) return;
+  const double* col = (it.kind == 1 ? Li : Lm) + it.off + (size_t)(16 * q) * it.ld + c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = col[(size_t)r * it.ld];
+}
+__device__ __forceinline__ void bs_apply(const BsItem* grp, double* t, double* red, int n, int sl, int q, int c, const double (&v)[16])
+{
+  const BsItem it = grp[sl];
+  double p = 0;
+  if (it.kind != 0) {
+    const double* xin = t + it.in_off + 16 * q;
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+      p0 += v[r] * xin[r];
+      p1 += v[r + 1] * xin[r + 1];
+      p2 += v[r + 2] * xin[r + 2];
+      p3 += v[r + 3] * xin[r + 3];
+    }
+    p = (p0 + p1) + (p2 + p3);
+  }
+  const int tid = threadIdx.x;
+  red[tid] = p;
+  __syncthreads();
+  if (q == 0 && it.kind != 0) {
+    const double sum = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    if (it.kind == 1) t[it.out_off + c] = (it.out_off + c < n) ? sum : 0.0;
+    else t[it.out_off + c] -= sum;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb, double* xout, int max_groups)
 {
   const int sys = blockIdx.y;
   if (cb.active && !cb.active[sys]) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const double* A = (cb.L ? cb.L : cb.A) + (size_t)sys * np * np;  // off-diagonal tiles of L
+  const double* Lm = (cb.L ? cb.L : cb.A) + (size_t)sys * np * np;
+  const double* Li = cb.Linv + (size_t)sys * nt * (NB * NB);
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* xs = smem;              // [np]  y, overwritten by x
-  double* Lt = xs + np;           // [NB * LD]
-  double* xk = Lt + NB * LD;      // [NB]
-  double* red = xk + NB;          // [BS_THREADS] quarter sums of the update
-  double* xb = red + BS_THREADS;  // [NB]
-  double* Dvs = xb + NB;          // [4 * DB * DB] inverses of the diagonal blocks of L_kk
+  double* t = smem;          // [np] y, overwritten by x
+  double* red = t + np;      // [BI_THREADS]
+  BsItem* items = reinterpret_cast<BsItem*>(red + BI_THREADS);  // [max_groups][4]
+  __shared__ int n_groups;
   const int tid = threadIdx.x;
-  // y = row n of L: its entries in block columns left of the diagonal tile were updated in place, the
-  // ones inside the diagonal tile of row n live in Ldiag (diagonal tiles are never written back to A)
+  const int c = tid & 63, q = (tid >> 6) & 3, sl = tid >> 8;
+  if (tid == 0) {  // the work list, in execution order
+    int g = 0;
+    for (int k = nt - 1; k >= 0; --k) {
+      const int c0 = k * NB;
+      if (c0 >= n) continue;
+      BsItem* grp = items + 4 * g++;
+      grp[0] = BsItem{(long long)k * (NB * NB), NB, c0, c0, 1};
+      grp[1].kind = grp[2].kind = grp[3].kind = 0;
+      int ns = 4;
+      for (int tj = 0; tj < k; ++tj) {
+        if (tm && !tm[k * nt + tj]) continue;
+        if (ns == 4) { grp = items + 4 * g++; grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0; ns = 0; }
+        grp[ns++] = BsItem{(long long)c0 * np + (long long)tj * NB, np, c0, tj * NB, 2};
+      }
+    }
+    n_groups = g;
+  }
   {
     const int kt = n / NB;
     const double* Ldn = cb.Ldiag + ((size_t)sys * nt + kt) * (NB * NB) + (size_t)(n - kt * NB) * NB;
-    for (int j = tid; j < np; j += BS_THREADS) xs[j] = (j < n) ? ((j >= kt * NB) ? Ldn[j - kt * NB] : A[(size_t)n * np + j]) : 0.0;
+    for (int j = tid; j < np; j += BI_THREADS) t[j] = (j < n) ? ((j >= kt * NB) ? Ldn[j - kt * NB] : Lm[(size_t)n * np + j]) : 0.0;
   }
   __syncthreads();
-  for (int k = nt - 1; k >= 0; --k) {
-    const int c0 = k * NB;
-    if (c0 >= n) continue;
-    const double* Ld = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
-    for (int idx = tid; idx < NB * NB / 2; idx += BS_THREADS) {
-      const int row = idx >> 5, c2 = (idx & 31) * 2;
-      *reinterpret_cast<double2*>(Lt + row * LD + c2) = *reinterpret_cast<const double2*>(Ld + row * NB + c2);
-    }
-    {
-      const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
-      for (int idx = tid; idx < 4 * DB * DB; idx += BS_THREADS) Dvs[idx] = Dg[idx];
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // x_k = L_kk^-T y_k by 16-row blocks from the bottom: x_b = (L_bb^-1)^T v_b, then v_r -= sum_i L[16b+i][r] x_b[i] for
-      // the rows above.  One wave, values pass between lanes through the wave-private strips xk / xb.
-      double yv = (c0 + tid < n) ? xs[c0 + tid] : 0.0;
-#pragma unroll
-      for (int bb = NB / DB - 1; bb >= 0; --bb) {
-        xk[tid] = yv;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        double xc = 0;
-        if ((tid >> 4) == bb) {
-          const int c = tid & 15;
-          double q0 = 0, q1 = 0;
-#pragma unroll
-          for (int i = 0; i < DB; i += 2) {
-            q0 += Dvs[bb * DB * DB + i * DB + c] * xk[DB * bb + i];
-            q1 += Dvs[bb * DB * DB + (i + 1) * DB + c] * xk[DB * bb + i + 1];
-          }
-          xc = (c0 + tid < n) ? q0 + q1 : 0.0;
-          xb[tid] = xc;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (tid < DB * bb) {
-          double q0 = 0, q1 = 0;
-#pragma unroll
-          for (int i = 0; i < DB; i += 2) {
-            q0 += Lt[(DB * bb + i) * LD + tid] * xb[DB * bb + i];
-            q1 += Lt[(DB * bb + i + 1) * LD + tid] * xb[DB * bb + i + 1];
-          }
-          yv -= q0 + q1;
-        }
-        if ((tid >> 4) == bb) yv = xc;
-      }
-      xs[c0 + tid] = yv;
-      xk[tid] = yv;
-    }
-    __syncthreads();
-    // y_j -= sum_r L[c0 + r][j] x_k[r], j < c0.  Thread = (column j, quarter of the 64 rows): 16 independent loads in
-    // flight per thread, the four quarter sums of a column meet in LDS in a fixed order.
-    for (int j0 = 0; j0 < c0; j0 += BS_THREADS / 4) {
-      const int j = j0 + (tid & (BS_THREADS / 4 - 1)), qr = tid / (BS_THREADS / 4);
-      double part = 0;
-      if (j < c0) {
-        const double* col = A + (size_t)(c0 + 16 * qr) * np + j;
-        double v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = col[(size_t)r * np];
-        double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-          p0 += v[r] * xk[16 * qr + r];
-          p1 += v[r + 1] * xk[16 * qr + r + 1];
-          p2 += v[r + 2] * xk[16 * qr + r + 2];
-          p3 += v[r + 3] * xk[16 * qr + r + 3];
-        }
-        part = (p0 + p1) + (p2 + p3);
-      }
-      red[tid] = part;
-      __syncthreads();
-      if (qr == 0 && j < c0) {
-        const int q = BS_THREADS / 4;
-        xs[j] -= (red[tid] + red[tid + q]) + (red[tid + 2 * q] + red[tid + 3 * q]);
-      }
-      __syncthreads();
-    }
+  const int G = n_groups;
+  double r0[16], r1[16], r2[16];
+  if (0 < G) bs_load(items + 0, Lm, Li, sl, q, c, r0);
+  if (1 < G) bs_load(items + 4, Lm, Li, sl, q, c, r1);
+  for (int g = 0; g < G; g += 3) {
+    if (g + 2 < G) bs_load(items + 4 * (g + 2), Lm, Li, sl, q, c, r2);
+    bs_apply(items + 4 * g, t, red, n, sl, q, c, r0);
+    if (g + 1 >= G) break;
+    if (g + 3 < G) bs_load(items + 4 * (g + 3), Lm, Li, sl, q, c, r0);
+    bs_apply(items + 4 * (g + 1), t, red, n, sl, q, c, r1);
+    if (g + 2 >= G) break;
+    if (g + 4 < G) bs_load(items + 4 * (g + 4), Lm, Li, sl, q, c, r1);
+    bs_apply(items + 4 * (g + 2), t, red, n, sl, q, c, r2);
   }
-  for (int j = tid; j < np; j += BS_THREADS) xout[(size_t)sys * np + j] = (j < n) ? xs[j] : 0.0;
+  for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[j] : 0.0;
 }
 
 }  // namespace
@@ -769,16 +837,33 @@ void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream)
       done.fetch_or(bit, std::memory_order_release);
     }
   }
-  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2, cb.count), dim3(256), smem, stream, cb, k);
+  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? 1 : 0), cb.count), dim3(256), smem, stream, cb, k);
 }
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
   launch(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
 }
+void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream)
+{
+  launch(chol_tile_inverse_kernel, dim3(cb.np / NB, cb.count), dim3(256), 0, stream, cb);
+}
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
-  const size_t smem = sizeof(double) * ((size_t)cb.np + NB * LD + NB + BS_THREADS + NB + 4 * 16 * 16);
-  launch(chol_backsolve_kernel, dim3(1, cb.count), dim3(BS_THREADS), smem, stream, cb, x);
+  const int nt = cb.np / NB;
+  int max_groups = nt;  // one group per diagonal inverse + the tiles of row k four at a time
+  for (int k = 0; k < nt; ++k) max_groups += (k + 3) / 4;
+  const size_t smem = sizeof(double) * ((size_t)cb.np + BI_THREADS) + sizeof(BsItem) * 4 * (size_t)max_groups;
+  {  // large systems: the work list can take the dynamic LDS beyond 64 KiB
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  launch(chol_backsolve_kernel, dim3(1, cb.count), dim3(BI_THREADS), smem, stream, cb, x, max_groups);
 }
 
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
@@ -795,6 +880,7 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
     chol_panel_launch(cb, k, stream, /*diag_done=*/k > 0);
     chol_syrk_launch(cb, k, stream, 0, /*fuse_diag=*/true);
   }
+  chol_tile_inverse_launch(cb, stream);
   chol_backsolve_launch(cb, x, stream);
 }
 
@@ -939,12 +1025,14 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   PTZ_HIP_TRY(hipMalloc(&dn, sizeof(int) * count));
   PTZ_HIP_TRY(hipMalloc(&dfail, sizeof(int) * count));
   cb.A = dA; cb.Ldiag = dL; cb.Dinv = dD; cb.n = dn; cb.fail = dfail;
-  double* dL2 = nullptr;
+  double *dL2 = nullptr, *dLi = nullptr;
   if (count < 8 && !getenv("PTZ_CHOL_MULTI_LAUNCH")) {  // the path a few bundle-adjustment scenes take
     PTZ_HIP_TRY(hipMalloc(&dL2, sizeof(double) * (size_t)count * np * np));
     PTZ_HIP_TRY(hipMemset(dL2, 0, sizeof(double) * (size_t)count * np * np));
     cb.L = dL2;
   }
+  PTZ_HIP_TRY(hipMalloc(&dLi, sizeof(double) * (size_t)count * nt * CHOL_NB * CHOL_NB));
+  cb.Linv = dLi;
   {
     int* hn = new int[count];
     for (int i = 0; i < count; ++i) hn[i] = n;
@@ -976,5 +1064,6 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
   if (dL2) (void)hipFree(dL2);
+  if (dLi) (void)hipFree(dLi);
   return PTZ_OK;
 }

@@ -153,6 +153,10 @@ struct CholBatch {
   // one-launch-per-column path (chol_col_step_kernel) cannot publish L_ik in place -- other workgroups of the same launch
   // still read A_ik -- and writes a second matrix [count][np][np]; the back-substitution reads L from there.
   double* L = nullptr;
+  // device [count][np/NB][NB*NB] or nullptr: full inverses of the factored diagonal tiles (lower triangular, row-major).  Written
+  // by the one-launch-per-column path beside the critical chain (a spare workgroup of the next launch); with them the
+  // back-substitution is two matrix-vector products per block column instead of a blocked triangular solve.
+  double* Linv = nullptr;
   double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
   double* Dinv = nullptr;   // device [count][np/NB][4][16*16]: inverses of the 16x16 diagonal blocks of L_kk
   const int* n = nullptr;   // device [count]
@@ -171,6 +175,7 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
 void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag_done = false);  // diag (unless already done) + trsm
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag = false);  // mode 0 all, 1 column k+1, 2 rest; fuse_diag: also factor tile (k+1, k+1)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
+void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream);  // Linv of every diagonal tile (multi-launch paths, before the back-substitution)
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);       // factor the diagonal tile of block column k
 void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream);   // few systems: trsm + trailing update + next diagonal tile, one launch
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)
