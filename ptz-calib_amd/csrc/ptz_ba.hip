@@ -62,7 +62,10 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
 struct ptz_ba_batch {
   int n_scene = 0, type = 0, nc = 4, device = 0;
   std::vector<SceneDev> scenes;
-  int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;
+  int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;  // total_chunk: partial-sum slots (waves of 64 rays + 1 per scene)
+  int ray_block = RAY_BLOCK;
+  bool small_blocks = false;     // ray_block <= 256: the SMALL instantiations of k_lin_ray / k_eval (observation prefetch through LDS)
+  size_t lin_smem = 0, eval_smem = 0;
   int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0;
   ptz_lm_options opt;
   Dev d;
@@ -221,7 +224,8 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
   const Dev& d = b->d;
   b->prof_begin(P_LIN);
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
-  LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, d);
+  if (b->small_blocks) LAUNCH((k_lin_ray<TYPE, true>), dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), b->lin_smem, d);
+  else LAUNCH((k_lin_ray<TYPE, false>), dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), b->lin_smem, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   if (d.shared) LAUNCH(k_group_grad<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
@@ -275,14 +279,13 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   constexpr int NC = Dims<TYPE>::NC;
   const int B = d.n_scene;
   hipStream_t st = b->stream;
-  const size_t eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16);
   const size_t schur_smem = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   b->prof_end();
   if (last) return;
   b->prof_begin(P_RAYPREP);
-  LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), 0, d);
+  LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(b->d.ray_block), 0, d);
   LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
@@ -300,7 +303,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_EVAL);
-  LAUNCH(k_eval<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), eval_smem, d);
+  if (b->small_blocks) LAUNCH((k_eval<TYPE, true>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->eval_smem, d);
+  else LAUNCH((k_eval<TYPE, false>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->eval_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
   b->prof_begin(P_LMCTL);
@@ -310,7 +314,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
     const Dev& dd = d;
     b->prof_begin(P_LIN);
     LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, dd);
-    LAUNCH(k_lin_ray<TYPE>, dim3(b->max_chunk, B), dim3(RAY_BLOCK), sizeof(double) * b->max_cam * CBS, dd);
+    if (b->small_blocks) LAUNCH((k_lin_ray<TYPE, true>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
+    else LAUNCH((k_lin_ray<TYPE, false>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
     if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
@@ -758,6 +763,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
+  // rays per workgroup of the ray-centric kernels: one rig's ~13 k rays on 1024-ray workgroups keep 14 compute units busy,
+  // so a few scenes use small workgroups; large batches amortise the LDS camera tables over many rays (results do not
+  // depend on it: per-ray sums are reduced per wave of 64 rays)
+  b->ray_block = n <= 4 ? 128 : (n <= 32 ? 256 : RAY_BLOCK);
+  if (const char* e = getenv("PTZ_BA_RAY_BLOCK")) b->ray_block = std::min(RAY_BLOCK, std::max(64, (atoi(e) / 64) * 64));
   RawVec<float2> h_uv, h_camuv;
   RawVec<int> h_cam, h_ray, h_camobs, h_camray, h_wpos;
   std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr;
@@ -807,7 +817,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     s.n_cam = p.n_cam; s.n_ray = p.n_ray; s.n_obs = (int)p.n_obs;
     s.cam_off = b->total_cam; s.ray_off = b->total_ray; s.obs_off = b->total_obs;
     s.pair_off = b->total_pair; s.ent_off = b->total_ent; s.part_off = b->total_chunk;
-    s.n_chunk = (p.n_ray + RAY_BLOCK - 1) / RAY_BLOCK;
+    s.n_chunk = (p.n_ray + b->ray_block - 1) / b->ray_block;
+    s.n_wave = (p.n_ray + 63) / 64;
     s.n = NC * p.n_cam + 6 * has3d;
     s.idx = i;
     s.o3_off = b->total_o3; s.n_o3 = p.n_obs3d;
@@ -909,7 +920,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       total_grp += s.n_grp;
       b->max_grp = std::max(b->max_grp, s.n_grp);
     }
-    b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_chunk + 1;
+    b->total_cam += p.n_cam; b->total_ray += p.n_ray; b->total_obs += (int)p.n_obs; b->total_chunk += s.n_wave + 1;
     b->max_cam = std::max(b->max_cam, p.n_cam); b->max_ray = std::max(b->max_ray, p.n_ray);
     b->max_chunk = std::max(b->max_chunk, s.n_chunk); b->max_pair = std::max(b->max_pair, s.n_pair);
     b->max_n = std::max(b->max_n, s.n);
@@ -969,8 +980,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.ray_x, 2 * d.ray_stride));
   TRY(b->alloc(&b->cam0, d.cam_stride));
   TRY(b->alloc(&b->ray0, d.ray_stride));
-  TRY(b->alloc(&d.camblk, (size_t)b->total_cam * CAMBLK));
-  TRY(b->alloc(&d.candblk, (size_t)b->total_cam * CANDBLK));
+  TRY(b->alloc(&d.camblk, (size_t)b->total_cam * CBS + 2));
+  TRY(b->alloc(&d.candblk, (size_t)b->total_cam * CDS + 2));
   TRY(b->alloc(&d.scale_c, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.scale_r, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.U, (size_t)b->total_cam * NC * NC));
@@ -991,7 +1002,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   }
   TRY(b->alloc(&d.W, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
   TRY(b->alloc(&d.rayrec, (size_t)b->total_ray * 8));
-  TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 2));
+  TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 4));
+  TRY(b->alloc(&d.partial_lin, (size_t)b->total_chunk * 2));
+  d.ray_block = b->ray_block;
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
   TRY(b->alloc(&d.ray_fail, (size_t)n));
@@ -1111,8 +1124,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     return PTZ_ENODEVICE;
   }
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
-  const int eval_smem = (int)(sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16));
-  const int lin_smem = (int)(sizeof(double) * (size_t)b->max_cam * CBS);
+  b->small_blocks = b->ray_block <= 256;
+  const size_t obs_lds = b->small_blocks ? (size_t)OBS_PREFETCH_BYTES * b->ray_block : 0;
+  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 8) + obs_lds;
+  b->lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 4) + obs_lds;
+  const int eval_smem = (int)b->eval_smem, lin_smem = (int)b->lin_smem;
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024 || b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }  // (entry records hold 16-bit positions)
   if (eval_smem > 160 * 1024 || lin_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
@@ -1134,8 +1150,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       };
 #define PTZ_SET_ATTR(T)                        \
       raise_cap((const void*)k_schur<T>);      \
-      raise_cap((const void*)k_eval<T>);       \
-      raise_cap((const void*)k_lin_ray<T>);
+      raise_cap((const void*)k_eval<T, true>);       \
+      raise_cap((const void*)k_eval<T, false>);      \
+      raise_cap((const void*)k_lin_ray<T, true>);    \
+      raise_cap((const void*)k_lin_ray<T, false>);
       PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
 #undef PTZ_SET_ATTR
       if (!attr_ok) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
@@ -1237,7 +1255,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
   if (!b || !b->has_state) return PTZ_EINVAL;
   (void)hipGetLastError();
   PTZ_DEVICE_GUARD(b->device);
-  hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(RAY_BLOCK), 0, b->stream, b->d, b->cam0, b->ray0);
+  hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), 0, b->stream, b->d, b->cam0, b->ray0);
   PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
   PTZ_HIP_TRY(hipGetLastError());
   return PTZ_OK;

@@ -10,7 +10,8 @@ namespace ptz {
 
 namespace {
 
-constexpr int RAY_BLOCK = 1024;  // rays per workgroup in the ray-centric kernels
+constexpr int RAY_BLOCK = 1024;  // most rays per workgroup in the ray-centric kernels (Dev::ray_block is the batch's actual value:
+                                 // a few scenes use small workgroups so that one rig's 13 k rays spread over a hundred compute units)
 constexpr int EZS = 10;           // doubles per ray in the (E, z) record: 6 + 3, padded to a 16-byte multiple
 constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (35 doubles: odd -> no same-field bank conflicts)
 constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
@@ -20,8 +21,10 @@ struct SceneDev {
   int n_cam, n_ray, n_obs, n_pair;
   int cam_off, ray_off, obs_off, pair_off;
   int ent_off;   // first camera-pair entry
-  int part_off;  // first partial-sum slot (one per ray chunk)
-  int n_chunk;   // ceil(n_ray / RAY_BLOCK)
+  int part_off;  // first partial-sum slot (one per WAVE of 64 rays, plus one for the 2D-3D terms: the reduction tree of the
+                 // per-ray sums does not depend on the workgroup size, so a scene's bits do not depend on the batch it is in)
+  int n_chunk;   // ceil(n_ray / Dev::ray_block)
+  int n_wave;    // ceil(n_ray / 64)
   int n;         // NC * n_cam: order of the reduced camera system
   int idx;       // global scene index (the CSR pointer arrays carry one extra entry per preceding scene)
   int o3_off, n_o3;  // 2D-3D annotation observations of the scene
@@ -73,8 +76,8 @@ struct Dev {
   const double* cam_x0;
   const double* ray_x0;
   // per-camera blocks
-  double* camblk;    // [total_cam][CAMBLK]   at x
-  double* candblk;   // [total_cam][CANDBLK]  at the candidate
+  double* camblk;    // [total_cam][CBS]   at x          (rows already carry the odd LDS pitch: a workgroup stages its scene's
+  double* candblk;   // [total_cam][CDS]   at the candidate   table with a flat, 16-byte-per-lane copy)
   double* scale_c;   // [total_cam][NC]
   double* scale_r;   // [total_ray][3]
   double* U;         // [total_cam][NC*NC]
@@ -89,7 +92,10 @@ struct Dev {
                      // because the Schur kernel gathers both for every observation
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
-  double* partial;   // [total_chunk + n_scene][2] (one extra slot per scene for the 2D-3D terms)
+  double* partial;   // [total_wave + n_scene][4] per wave of rays {model cost change, candidate cost, |x - x_c|^2, |x_c|^2} of k_eval
+                     // (one extra slot per scene for the 2D-3D terms)
+  double* partial_lin;  // [total_wave][2] per wave of rays {max |g_r / scale|, |x|^2} of k_lin_ray
+  int ray_block;     // rays per workgroup of k_lin_ray / k_ray_prep / k_eval in this batch (multiple of 64, <= RAY_BLOCK)
   // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
   const float2* o3_uv;  // [total_o3]
   const double* o3_xyz; // [total_o3][3] world points
@@ -200,7 +206,7 @@ __global__ void k_cam_prep(Dev d)
   if (!d.active[sc] || !st.need_linearize) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n_cam) return;
-  double* cb = d.camblk + (size_t)(s.cam_off + i) * CAMBLK;
+  double* cb = d.camblk + (size_t)(s.cam_off + i) * CBS;
   fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
 #pragma unroll
   for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
@@ -216,24 +222,62 @@ __global__ void k_cam_prep(Dev d)
   }
 }
 
-// stage a scene's camera table into LDS (stride words per camera)
-__device__ __forceinline__ void stage_table(const double* __restrict__ src, double* dst, int count)
+// Stage `count` doubles of a scene's camera table (global rows already at the LDS pitch) into LDS with 16-byte loads, eight
+// in flight per thread.  The source starts at an 8-byte boundary, so the copy starts at the 16-byte boundary at or below it:
+// the table then sits `return value` (0 or 1) doubles into `dst`, which needs room for count + 2 doubles.
+__device__ __forceinline__ int stage_flat(const double* __restrict__ src, double* dst, int count)
 {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+  const int shift = (int)((reinterpret_cast<uintptr_t>(src) >> 3) & 1);
+  const double2* s2 = reinterpret_cast<const double2*>(src - shift);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  const int n2 = (count + shift + 1) >> 1;
+  constexpr int U = 8;
+  for (int i0 = threadIdx.x; i0 < n2; i0 += blockDim.x * U) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int idx = i0 + u * blockDim.x; if (idx < n2) v[u] = s2[idx]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int idx = i0 + u * blockDim.x; if (idx < n2) d2[idx] = v[u]; }
+  }
+  return shift;
 }
-// same, re-striding rows of SRC doubles to DST doubles in LDS
-template <int SRC, int DST>
-__device__ __forceinline__ void stage_rows(const double* __restrict__ src, double* dst, int rows)
+
+// Walk the observations [a0, a1) of one ray.  Large workgroups (batches: 16 waves per compute unit hide the latency) read
+// the 16-byte records where they are needed.  SMALL workgroups (a few scenes, two to four waves per compute unit) would pay
+// one exposed memory round trip per observation, so they fetch eight records at a time -- all loads in flight together --
+// park them in a thread-private LDS slot and run the same body over them: same arithmetic, same order, same bits.
+template <bool SMALL, typename Body>
+__device__ __forceinline__ void for_each_obs(const Dev& d, int a0, int a1, float4* obsbuf, Body&& body)
 {
-  for (int i = threadIdx.x; i < rows * SRC; i += blockDim.x) dst[(i / SRC) * DST + (i % SRC)] = src[i];
+  if (!SMALL) {
+    for (int a = a0; a < a1; ++a) body(d.obs_uv[a], d.obs_cam[a]);
+    return;
+  }
+  constexpr int P = 8;
+  for (int ab = a0; ab < a1; ab += P) {
+    float2 uvr[P];
+    int cr[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+      if (ab + u < a1) { uvr[u] = d.obs_uv[ab + u]; cr[u] = d.obs_cam[ab + u]; }
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+      if (ab + u < a1) obsbuf[u * blockDim.x + threadIdx.x] = make_float4(uvr[u].x, uvr[u].y, __int_as_float(cr[u]), 0.f);
+    const int ne = min(P, a1 - ab);
+    for (int u = 0; u < ne; ++u) {
+      const float4 r = obsbuf[u * blockDim.x + threadIdx.x];
+      body(make_float2(r.x, r.y), __float_as_int(r.z));
+    }
+  }
 }
+constexpr int OBS_PREFETCH_BYTES = 8 * 16;  // per thread of a SMALL workgroup
 
 // ---- lin_ray: per-ray linearisation ---------------------------------------------------------------------
 // thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
 // Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r.  (The W_a = Jc^T Jr rows are written by k_lin_cam, whose
 // lanes walk a camera's observations in the order of its W rows: one sequential stream instead of a 96-byte scatter.)
-template <int TYPE>
-__global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
+template <int TYPE, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 {
   constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = blockIdx.y;
@@ -241,10 +285,12 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, lds, s.n_cam);
+  const double* tab = lds + stage_flat(d.camblk + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
+  float4* obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 3) & ~1));  // SMALL only
   __syncthreads();
-  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
-  if (j >= s.n_ray) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double gm = 0, xn = 0;  // this ray's share of the gradient max-norm and of |x|^2 (k_lm_pre)
+  if (j < s.n_ray) {
   const int gj = s.ray_off + j;
   const double* X = cur_ray(d, s, st) + (size_t)j * 3;
   const double Xr[3] = {X[0], X[1], X[2]};
@@ -252,9 +298,8 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   const double sw = sqrt(d.ray_w[gj]);
   const int* rp = d.ray_ptr + s.ray_off + s.idx;
   double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-  for (int a = rp[j]; a < rp[j + 1]; ++a) {
-    const float2 uv = d.obs_uv[a];
-    const double* cb = lds + d.obs_cam[a] * CBS;
+  for_each_obs<SMALL>(d, rp[j], rp[j + 1], obsbuf, [&](float2 uv, int ci) {
+    const double* cb = tab + ci * CBS;
     double res[2], Jc[2][NW], Jr[2][3];
     ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
     res[0] *= sw; res[1] *= sw;
@@ -268,7 +313,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
     V[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
-  }
+  });
 #pragma unroll
   for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
 #pragma unroll
@@ -276,6 +321,15 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_lin_ray(Dev d)
   {  // the camera pass (next launch) gathers this ray once per observation: one aligned 64-byte record instead of three arrays
     double* rr = d.rayrec + (size_t)gj * 8;
     rr[0] = Xr[0]; rr[1] = Xr[1]; rr[2] = Xr[2]; rr[3] = sr[0]; rr[4] = sr[1]; rr[5] = sr[2]; rr[6] = d.ray_w[gj]; rr[7] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { gm = fmax(gm, fabs(g[k] / sr[k])); xn += Xr[k] * Xr[k]; }
+  }
+  gm = wave_max(gm);
+  xn = wave_sum(xn);
+  if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
+    double* pl = d.partial_lin + (size_t)(s.part_off - s.idx + (j >> 6)) * 2;  // (part_off counts one extra slot per preceding scene)
+    pl[0] = gm; pl[1] = xn;
   }
 }
 
@@ -297,7 +351,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   const int gi = s.cam_off + i;
   double cb[CAMBLK];
 #pragma unroll
-  for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CAMBLK + k];
+  for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CBS + k];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
@@ -403,7 +457,7 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
   for (int o = threadIdx.x; o < s.n_o3; o += 256) {
     const int go = s.o3_off + o;
     const int ci = d.o3_cam[go];
-    const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CAMBLK;
+    const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CBS;
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
     double res[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
@@ -647,13 +701,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
           if (intr || (k >= 4 && k < 10)) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
       }
     }
-    const double* ray = cur_ray(d, s, st);
-    for (int j = tid; j < s.n_ray; j += LM_THREADS) {
-      const int gj = s.ray_off + j;
-      for (int k = 0; k < 3; ++k) {
-        gm = fmax(gm, fabs(d.gr[(size_t)gj * 3 + k] / d.scale_r[(size_t)gj * 3 + k]));
-        xn += ray[(size_t)j * 3 + k] * ray[(size_t)j * 3 + k];
-      }
+    for (int wv = tid; wv < s.n_wave; wv += LM_THREADS) {  // the rays' share, one entry per wave of k_lin_ray
+      const double* pl = d.partial_lin + (size_t)(s.part_off - s.idx + wv) * 2;
+      gm = fmax(gm, pl[0]);
+      xn += pl[1];
     }
     // fixed-order cost: per-thread partial sums over a strided camera set, then the block tree
     if (Dims<TYPE>::HAS3D && tid == 0) {
@@ -701,7 +752,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s.n_ray) return;
   const int gj = s.ray_off + j;
   double V[6];
@@ -1010,7 +1061,7 @@ __global__ void k_cam_update(Dev d)
   double cb[CANDBLK];
   fill_camblk(c15, cb, false);
 #pragma unroll
-  for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CANDBLK + k] = cb[k];
+  for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CDS + k] = cb[k];
   if (Dims<TYPE>::HAS3D && i == 0) {
     const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
     double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
@@ -1038,8 +1089,8 @@ __global__ void k_cam_update(Dev d)
 //   model_cost_change = -(J d)^T (r + J d / 2)          (TrustRegionMinimizer::ComputeTrustRegionStep)
 //   candidate_cost    = 1/2 sum w |r(x + delta)|^2
 // The scaled camera step d_c = -y_c is staged in LDS next to the camera tables of x and of the candidate.
-template <int TYPE>
-__global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
+template <int TYPE, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = blockIdx.y;
@@ -1049,15 +1100,16 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
   if (blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int DCS = NC | 1;                // odd stride for the step table as well
-  double* tab = lds;                         // [n_cam][CBS]
-  double* ctab = tab + s.n_cam * CBS;        // [n_cam][CDS]
-  double* dct = ctab + s.n_cam * CDS;        // [n_cam][DCS] scaled camera step
-  double* scratch = dct + s.n_cam * DCS;     // [16]
-  stage_rows<CAMBLK, CBS>(d.camblk + (size_t)s.cam_off * CAMBLK, tab, s.n_cam);
-  stage_rows<CANDBLK, CDS>(d.candblk + (size_t)s.cam_off * CANDBLK, ctab, s.n_cam);
+  double* tab0 = lds;                                    // [n_cam][CBS] (+ 2: alignment slack of the flat copy)
+  double* ctab0 = tab0 + ((s.n_cam * CBS + 3) & ~1);     // [n_cam][CDS] (+ 2)
+  double* dct = ctab0 + ((s.n_cam * CDS + 3) & ~1);      // [n_cam][DCS] scaled camera step
+  double* scratch = dct + s.n_cam * DCS;                 // [16]
+  float4* obsbuf = reinterpret_cast<float4*>(scratch + 16);  // SMALL only: [8][blockDim.x]
+  const double* tab = tab0 + stage_flat(d.camblk + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+  const double* ctab = ctab0 + stage_flat(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
   __syncthreads();
   // per camera: the scaled step of its 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir)
-  for (int c = threadIdx.x; c < s.n_cam; c += RAY_BLOCK) {
+  for (int c = threadIdx.x; c < s.n_cam; c += blockDim.x) {
     const double* cbc = tab + c * CBS;
     const double* dcg = d.dc + (size_t)(s.cam_off + c) * NC;
     double sv[NW];
@@ -1070,8 +1122,8 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       dct[c * DCS + NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
   }
   __syncthreads();
-  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
-  double mcc = 0, cost = 0;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double mcc = 0, cost = 0, dn = 0, cn = 0;
   if (j < s.n_ray) {
     const int gj = s.ray_off + j;
     const double* X = cur_ray(d, s, st) + (size_t)j * 3;
@@ -1090,9 +1142,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
     double s1 = 0;
     double Xu[3], inv_n;  // the functor's point for this ray, once for all of its observations
     ba_ray_point<F>(Xr, Xu, inv_n);
-    for (int a = a0; a < a1; ++a) {
-      const float2 uv = d.obs_uv[a];
-      const int ci = d.obs_cam[a];
+    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
       const double* cb = tab + ci * CBS;
       double res[2], pd[2], Jr[2][3];
       ba_step_dir_unit<F>(cb, Xu, inv_n, uv.x, uv.y, dct + ci * DCS, dct + ci * DCS + (NW - 3), res, pd, Jr);
@@ -1101,13 +1151,15 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
       t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
-    }
+    });
     const double* E = d.E + (size_t)gj * EZS;
     // step = -y_r (Ceres solves J y = r and negates)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
     const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
     double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
     xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dn += (Xr[k] - Xn[k]) * (Xr[k] - Xn[k]); cn += Xn[k] * Xn[k]; }  // |x - x_c|^2, |x_c|^2 (k_lm_post)
     {
       const double* V = d.V + (size_t)gj * 6;  // [v00 v10 v11 v20 v21 v22]
       const double q0 = V[0] * ds[0] + V[1] * ds[1] + V[3] * ds[2];
@@ -1118,19 +1170,22 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_eval(Dev d)
     // pass 2: candidate cost (residuals only)
     double Xcu[3], inv_nc;
     ba_ray_point<F>(Xn, Xcu, inv_nc);
-    for (int a = a0; a < a1; ++a) {
-      const float2 uv = d.obs_uv[a];
+    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
       double rc[2];
-      ba_residual_unit<F>(ctab + d.obs_cam[a] * CDS, Xcu, uv.x, uv.y, rc);
+      ba_residual_unit<F>(ctab + ci * CDS, Xcu, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
-    }
+    });
   }
-  mcc = block_sum(mcc, scratch);
-  cost = block_sum(cost, scratch);
-  if (threadIdx.x == 0) {
-    d.partial[(size_t)(s.part_off + blockIdx.x) * 2] = mcc;
-    d.partial[(size_t)(s.part_off + blockIdx.x) * 2 + 1] = cost;
+  // one partial per wave of 64 rays (fixed butterfly), whatever the workgroup size
+  mcc = wave_sum(mcc);
+  cost = wave_sum(cost);
+  dn = wave_sum(dn);
+  cn = wave_sum(cn);
+  if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
+    double* pp = d.partial + (size_t)(s.part_off + (j >> 6)) * 4;
+    pp[0] = mcc; pp[1] = cost; pp[2] = dn; pp[3] = cn;
   }
+  (void)scratch;
 }
 
 // ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
@@ -1154,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
     for (int k = 0; k < 6; ++k) { const double st_ = d.dt[(size_t)s.idx * 6 + k]; m0 += q0[k] * st_; m1 += q0[6 + k] * st_; }
     mcc += m0 * (d.r3[(size_t)go * 2] + m0 / 2.0) + m1 * (d.r3[(size_t)go * 2 + 1] + m1 / 2.0);
     double cb[CAMBLK];
-    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CANDBLK + k];
+    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CDS + k];
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
     double rc[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
@@ -1164,8 +1219,8 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
   mcc = block_sum(mcc, scratch);
   cost = block_sum(cost, scratch);
   if (threadIdx.x == 0) {
-    d.partial[(size_t)(s.part_off + s.n_chunk) * 2] = mcc;
-    d.partial[(size_t)(s.part_off + s.n_chunk) * 2 + 1] = cost;
+    double* pp = d.partial + (size_t)(s.part_off + s.n_wave) * 4;
+    pp[0] = mcc; pp[1] = cost; pp[2] = 0.0; pp[3] = 0.0;
   }
 }
 
@@ -1182,20 +1237,17 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   __shared__ double scratch[16];
   const int tid = threadIdx.x;
   // chunk partials in chunk order (thread-strided, then the fixed block tree)
-  double mcc = 0, cost = 0;
-  for (int c = tid; c < s.n_chunk + Dims<TYPE>::HAS3D; c += LM_THREADS) {
-    mcc += d.partial[(size_t)(s.part_off + c) * 2];
-    cost += d.partial[(size_t)(s.part_off + c) * 2 + 1];
+  double mcc = 0, cost = 0, dn = 0, cn = 0;
+  for (int c = tid; c < s.n_wave + Dims<TYPE>::HAS3D; c += LM_THREADS) {
+    const double* pp = d.partial + (size_t)(s.part_off + c) * 4;
+    mcc += pp[0]; cost += pp[1]; dn += pp[2]; cn += pp[3];  // the rays' |x - x_c|^2 and |x_c|^2 come from k_eval as well
   }
   mcc = -block_sum(mcc, scratch);
   cost = block_sum(cost, scratch);
   // |x - x_candidate| and |x_candidate| over the parameter blocks that are in the problem
   const double* cam = cur_cam(d, s, st);
   const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
-  const double* ray = cur_ray(d, s, st);
-  const double* rayc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)s.ray_off * 3;
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
-  double dn = 0, cn = 0;
   for (int i = tid; i < s.n_cam; i += LM_THREADS) {
     if (cp[i + 1] <= cp[i]) continue;
     const bool intr = !d.shared || (d.cam_flag[s.cam_off + i] & 1);
@@ -1205,11 +1257,6 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
       dn += (a - b) * (a - b);
       cn += b * b;
     }
-  }
-  for (int j = tid; j < s.n_ray * 3; j += LM_THREADS) {
-    const double a = ray[j], b = rayc[j];
-    dn += (a - b) * (a - b);
-    cn += b * b;
   }
   if (Dims<TYPE>::HAS3D && tid == 0 && s.n_o3 > 0) {
     const double* ta = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
@@ -1294,7 +1341,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_pix2ray(Dev d, double* cam0, doub
 {
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
-  const int j = blockIdx.x * RAY_BLOCK + threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s.n_ray) return;
   const int* rp = d.ray_ptr + s.ray_off + s.idx;
   double acc[3] = {0, 0, 0};
