@@ -285,12 +285,15 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_end();
   if (last) return;
   b->prof_begin(P_RAYPREP);
-  LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(b->d.ray_block), 0, d);
-  LAUNCH(k_cam_diag<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+  {
+    const int nt = d.chol.np / CHOL_NB;
+    if (d.chol.tmask) LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk + nt * nt, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
+    else {  // dense debugging path (PTZ_BA_DENSE_CHOL): whole matrices zeroed by a memset
+      LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
+      chol_clear(d.chol, st);
+    }
+  }
   if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
-  b->prof_end();
-  b->prof_begin(P_CLEAR);
-  chol_clear(d.chol, st);
   b->prof_end();
   b->prof_begin(P_SCHUR);
   LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
@@ -313,7 +316,6 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   {
     const Dev& dd = d;
     b->prof_begin(P_LIN);
-    LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, dd);
     if (b->small_blocks) LAUNCH((k_lin_ray<TYPE, true>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
     else LAUNCH((k_lin_ray<TYPE, false>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
@@ -963,7 +965,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   d.tlw_stride = (size_t)n * 6;
   TRY(b->alloc(&d.tlw_x, 2 * d.tlw_stride));
   TRY(b->alloc(&b->tlw0, d.tlw_stride));
-  TRY(b->alloc(&d.tlwblk, (size_t)n * TLWBLK));
+  d.tlwblk_stride = (size_t)n * TLWBLK;
+  TRY(b->alloc(&d.tlwblk, 2 * d.tlwblk_stride));
   TRY(b->alloc(&d.tlwcand, (size_t)n * TLWBLK));
   TRY(b->alloc(&d.scale_t, (size_t)n * 6));
   TRY(b->alloc(&d.diag_t, (size_t)n * 6));
@@ -980,7 +983,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.ray_x, 2 * d.ray_stride));
   TRY(b->alloc(&b->cam0, d.cam_stride));
   TRY(b->alloc(&b->ray0, d.ray_stride));
-  TRY(b->alloc(&d.camblk, (size_t)b->total_cam * CBS + 2));
+  d.camblk_stride = ((size_t)b->total_cam * CBS + 2 + 1) & ~(size_t)1;
+  TRY(b->alloc(&d.camblk, 2 * d.camblk_stride));
   TRY(b->alloc(&d.candblk, (size_t)b->total_cam * CDS + 2));
   TRY(b->alloc(&d.scale_c, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.scale_r, (size_t)b->total_ray * 3));

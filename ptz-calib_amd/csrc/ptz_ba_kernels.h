@@ -78,6 +78,8 @@ struct Dev {
   // per-camera blocks
   double* camblk;    // [total_cam][CBS]   at x          (rows already carry the odd LDS pitch: a workgroup stages its scene's
   double* candblk;   // [total_cam][CDS]   at the candidate   table with a flat, 16-byte-per-lane copy)
+  size_t camblk_stride;  // camblk is double-buffered like the state: [2][camblk_stride]; k_cam_update fills the candidate's half,
+                         // so an accepted step needs no camera pass before it is re-linearised
   double* scale_c;   // [total_cam][NC]
   double* scale_r;   // [total_ray][3]
   double* U;         // [total_cam][NC*NC]
@@ -102,7 +104,8 @@ struct Dev {
   const int* o3_cam;    // [total_o3] scene-local camera id
   double* tlw_x;     // [2][n_scene_total][6]
   size_t tlw_stride;
-  double* tlwblk;    // [n_scene_total][TLWBLK] at x
+  double* tlwblk;    // [2][n_scene_total][TLWBLK] at x / at the candidate, selected by LmState.cur like camblk
+  size_t tlwblk_stride;
   double* tlwcand;   // [n_scene_total][TLWBLK] at the candidate (R_lw and t used)
   double* scale_t;   // [n_scene_total][6]
   double* diag_t;    // [n_scene_total][6]
@@ -143,6 +146,9 @@ __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s
 {
   return d.ray_x + (size_t)st.cur * d.ray_stride + (size_t)s.ray_off * 3;
 }
+
+__device__ __forceinline__ double* cur_camblk(const Dev& d, const LmState& st) { return d.camblk + (size_t)st.cur * d.camblk_stride; }
+__device__ __forceinline__ double* cur_tlwblk(const Dev& d, const LmState& st) { return d.tlwblk + (size_t)st.cur * d.tlwblk_stride; }
 
 // A scene leaves the pass pipeline (one thread of the scene's LM block calls this, once per scene and solve).
 __device__ __forceinline__ void retire_scene(const Dev& d, int sc)
@@ -206,13 +212,13 @@ __global__ void k_cam_prep(Dev d)
   if (!d.active[sc] || !st.need_linearize) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n_cam) return;
-  double* cb = d.camblk + (size_t)(s.cam_off + i) * CBS;
+  double* cb = cur_camblk(d, st) + (size_t)(s.cam_off + i) * CBS;
   fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
 #pragma unroll
   for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
   if (Dims<TYPE>::HAS3D && i == 0) {
     const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
-    double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+    double* tb = cur_tlwblk(d, st) + (size_t)s.idx * TLWBLK;
     double R[9], Jl[9];
     const double rv[3] = {t[0], t[1], t[2]};
     rodrigues(rv, R);
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const double* tab = lds + stage_flat(d.camblk + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
+  const double* tab = lds + stage_flat(cur_camblk(d, st) + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
   float4* obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 3) & ~1));  // SMALL only
   __syncthreads();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   const int gi = s.cam_off + i;
   double cb[CAMBLK];
 #pragma unroll
-  for (int k = 0; k < CAMBLK; ++k) cb[k] = d.camblk[(size_t)gi * CBS + k];
+  for (int k = 0; k < CAMBLK; ++k) cb[k] = cur_camblk(d, st)[(size_t)gi * CBS + k];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
@@ -452,12 +458,12 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
-  const double* tb = d.tlwblk + (size_t)s.idx * TLWBLK;
+  const double* tb = cur_tlwblk(d, st) + (size_t)s.idx * TLWBLK;
   const double* stl = d.scale_t + (size_t)s.idx * 6;
   for (int o = threadIdx.x; o < s.n_o3; o += 256) {
     const int go = s.o3_off + o;
     const int ci = d.o3_cam[go];
-    const double* cb = d.camblk + (size_t)(s.cam_off + ci) * CBS;
+    const double* cb = cur_camblk(d, st) + (size_t)(s.cam_off + ci) * CBS;
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
     double res[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
@@ -742,16 +748,51 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
       d.ray_fail[sc] = 0;
     }
   }
+  // LevenbergMarquardtStrategy: the camera blocks' LM diagonal, clamp(diag(J^T J)), refreshed unless the last step was rejected
+  // (was a kernel of its own; the scene's LM block has the threads to spare)
+  __syncthreads();
+  if (!d.active[sc] || st.reuse_diagonal) return;
+  for (int i = tid; i < s.n_cam; i += LM_THREADS) {
+    const int gi = s.cam_off + i;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+  }
+  if (Dims<TYPE>::HAS3D && tid < 6)
+    d.diag_t[(size_t)s.idx * 6 + tid] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + tid * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
 }
 
 // ---- ray_prep: LevenbergMarquardtStrategy diagonal + SchurEliminator e-block inverse --------------------
+// The launch also readies the reduced camera system for k_schur (blocks past the ray chunks: one per tile of the lower
+// triangle): structural tiles zeroed, identity on the padding rows, CHOL_BIG under the right-hand-side row.
 template <int TYPE>
-__global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d)
+__global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
 {
   const int sc = blockIdx.y;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
+  if ((int)blockIdx.x >= n_ray_blocks) {
+    const int np = d.chol.np, nt = np / CHOL_NB;
+    const int t = blockIdx.x - n_ray_blocks;
+    const int ti = t / nt, tj = t % nt;
+    if (tj > ti || !d.chol.tmask[((size_t)sc * nt + ti) * nt + tj]) return;
+    double* T = d.chol.A + (size_t)sc * np * np + (size_t)(ti * CHOL_NB) * np + tj * CHOL_NB;
+    for (int idx = threadIdx.x; idx < CHOL_NB * CHOL_NB / 2; idx += blockDim.x) {
+      const int row = idx >> 5, c2 = (idx & 31) * 2;
+      double2 v = make_double2(0.0, 0.0);
+      if (ti == tj) {  // padding rows of the diagonal tile: identity, CHOL_BIG at (n, n)
+        const int gr = ti * CHOL_NB + row;
+        if (gr >= s.n) {
+          if (c2 == row) v.x = (gr == s.n) ? CHOL_BIG : 1.0;
+          if (c2 + 1 == row) v.y = (gr == s.n) ? CHOL_BIG : 1.0;
+        }
+      }
+      *reinterpret_cast<double2*>(T + (size_t)row * np + c2) = v;
+    }
+    if (ti == tj && threadIdx.x == 0 && s.n >= ti * CHOL_NB && s.n < (ti + 1) * CHOL_NB) d.chol.fail[sc] = 0;
+    return;
+  }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s.n_ray) return;
   const int gj = s.ray_off + j;
@@ -1058,8 +1099,17 @@ __global__ void k_cam_update(Dev d)
   double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
 #pragma unroll
   for (int k = 0; k < 15; ++k) xc[k] = c15[k];
-  double cb[CANDBLK];
-  fill_camblk(c15, cb, false);
+  // the candidate's full camera block (rotation, SO(3) Jacobian, intrinsics, scales) goes to the other half of camblk: if the
+  // step is accepted the linearisation kernels find it there; its first CANDBLK entries are what k_eval needs of it
+  double cb[CAMBLK];
+#pragma unroll
+  for (int k = CB_S; k < CAMBLK; ++k) cb[k] = 0.0;
+  fill_camblk(c15, cb, true);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)gi * NC + k];
+  double* cfull = d.camblk + (size_t)(st.cur ^ 1) * d.camblk_stride + (size_t)gi * CBS;
+#pragma unroll
+  for (int k = 0; k < CAMBLK; ++k) cfull[k] = cb[k];
 #pragma unroll
   for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CDS + k] = cb[k];
   if (Dims<TYPE>::HAS3D && i == 0) {
@@ -1074,11 +1124,14 @@ __global__ void k_cam_update(Dev d)
       tc[k] = tn[k];
     }
     double* tb = d.tlwcand + (size_t)s.idx * TLWBLK;
-    double R[9];
+    double* tf = d.tlwblk + (size_t)(st.cur ^ 1) * d.tlwblk_stride + (size_t)s.idx * TLWBLK;  // full block, used if the step is accepted
+    double R[9], Jl[9];
     const double rv[3] = {tn[0], tn[1], tn[2]};
     rodrigues(rv, R);
-    for (int k = 0; k < 9; ++k) tb[k] = R[k];
+    so3_left_jacobian(rv, Jl);
+    for (int k = 0; k < 9; ++k) { tb[k] = R[k]; tf[k] = R[k]; tf[9 + k] = Jl[k]; }
     tb[18] = tn[3]; tb[19] = tn[4]; tb[20] = tn[5];
+    tf[18] = tn[3]; tf[19] = tn[4]; tf[20] = tn[5];
   }
 }
 
@@ -1105,7 +1158,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   double* dct = ctab0 + ((s.n_cam * CDS + 3) & ~1);      // [n_cam][DCS] scaled camera step
   double* scratch = dct + s.n_cam * DCS;                 // [16]
   float4* obsbuf = reinterpret_cast<float4*>(scratch + 16);  // SMALL only: [8][blockDim.x]
-  const double* tab = tab0 + stage_flat(d.camblk + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+  const double* tab = tab0 + stage_flat(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
   const double* ctab = ctab0 + stage_flat(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
   __syncthreads();
   // per camera: the scaled step of its 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir)
