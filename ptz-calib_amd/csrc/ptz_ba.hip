@@ -1167,8 +1167,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
   b->small_blocks = b->ray_block <= 256;
   const size_t obs_lds = b->small_blocks ? (size_t)OBS_PREFETCH_BYTES * b->ray_block : 0;
-  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 8) + obs_lds;
-  b->lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 4) + obs_lds;
+  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 12) + obs_lds;
+  b->lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 6) + obs_lds;
   const int eval_smem = (int)b->eval_smem, lin_smem = (int)b->lin_smem;
   const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   if (schur_smem > 160 * 1024 || b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }  // (entry records hold 16-bit positions)

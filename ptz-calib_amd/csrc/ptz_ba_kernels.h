@@ -230,20 +230,30 @@ __global__ void k_cam_prep(Dev d)
 
 // Stage `count` doubles of a scene's camera table (global rows already at the LDS pitch) into LDS with 16-byte loads, eight
 // in flight per thread.  The source starts at an 8-byte boundary, so the copy starts at the 16-byte boundary at or below it:
-// the table then sits `return value` (0 or 1) doubles into `dst`, which needs room for count + 2 doubles.
+// the table then sits `return value` (0 or 1) doubles into `dst`, which needs room for count + 4 doubles.
+template <int U>
 __device__ __forceinline__ int stage_flat(const double* __restrict__ src, double* dst, int count)
 {
   const int shift = (int)((reinterpret_cast<uintptr_t>(src) >> 3) & 1);
   const double2* s2 = reinterpret_cast<const double2*>(src - shift);
   double2* d2 = reinterpret_cast<double2*>(dst);
   const int n2 = (count + shift + 1) >> 1;
-  constexpr int U = 8;
-  for (int i0 = threadIdx.x; i0 < n2; i0 += blockDim.x * U) {
+  const int bd = blockDim.x;
+  for (int base = 0; base < n2; base += bd * U) {
+    // Unconditional loads, all in flight together (hipcc sinks a conditional load next to its store and parks the buffer in
+    // scratch: one exposed round trip per 16 bytes).  Lanes past the end of the table re-read its tail instead, each its own
+    // element, so that no single line is hammered.
     double2 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int idx = i0 + u * blockDim.x; if (idx < n2) v[u] = s2[idx]; }
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * bd + (int)threadIdx.x;
+      v[u] = s2[idx < n2 ? idx : max(n2 - 1 - (int)threadIdx.x, 0)];
+    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int idx = i0 + u * blockDim.x; if (idx < n2) d2[idx] = v[u]; }
+    for (int u = 0; u < U; ++u) {  // unconditional as well (a conditional store sends v[] through scratch memory): lanes past the
+      const int idx = base + u * bd + (int)threadIdx.x;  // end write the spare 16 bytes behind the table
+      d2[min(idx, n2)] = v[u];
+    }
   }
   return shift;
 }
@@ -264,11 +274,13 @@ __device__ __forceinline__ void for_each_obs(const Dev& d, int a0, int a1, float
     float2 uvr[P];
     int cr[P];
 #pragma unroll
-    for (int u = 0; u < P; ++u)
-      if (ab + u < a1) { uvr[u] = d.obs_uv[ab + u]; cr[u] = d.obs_cam[ab + u]; }
+    for (int u = 0; u < P; ++u) {  // unconditional (clamped) so that the loads are issued back to back
+      const int aa = min(ab + u, a1 - 1);
+      uvr[u] = d.obs_uv[aa]; cr[u] = d.obs_cam[aa];
+    }
 #pragma unroll
-    for (int u = 0; u < P; ++u)
-      if (ab + u < a1) obsbuf[u * blockDim.x + threadIdx.x] = make_float4(uvr[u].x, uvr[u].y, __int_as_float(cr[u]), 0.f);
+    for (int u = 0; u < P; ++u)  // (slots past the end of the track hold a copy of its last record and are not read)
+      obsbuf[u * blockDim.x + threadIdx.x] = make_float4(uvr[u].x, uvr[u].y, __int_as_float(cr[u]), 0.f);
     const int ne = min(P, a1 - ab);
     for (int u = 0; u < ne; ++u) {
       const float4 r = obsbuf[u * blockDim.x + threadIdx.x];
@@ -291,8 +303,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const double* tab = lds + stage_flat(cur_camblk(d, st) + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
-  float4* obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 3) & ~1));  // SMALL only
+  const double* tab = lds + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
+  float4* obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 5) & ~1));  // SMALL only
   __syncthreads();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double gm = 0, xn = 0;  // this ray's share of the gradient max-norm and of |x|^2 (k_lm_pre)
@@ -1142,6 +1154,15 @@ __global__ void k_cam_update(Dev d)
 //   model_cost_change = -(J d)^T (r + J d / 2)          (TrustRegionMinimizer::ComputeTrustRegionStep)
 //   candidate_cost    = 1/2 sum w |r(x + delta)|^2
 // The scaled camera step d_c = -y_c is staged in LDS next to the camera tables of x and of the candidate.
+#ifdef PTZ_EVAL_STAMPS  // probe builds only: where k_eval's time goes (block 0, thread 0; 100 MHz wall clock)
+#define EV_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ev_t[i] = wall_clock64(); } while (0)
+#define EV_STAMP_DECL long long ev_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define EV_STAMP_PRINT do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) printf("k_eval stamps (x10 ns): stage %lld, step table %lld, ray prologue %lld, pass1 %lld, mid %lld, pass2 %lld, reduce %lld\n", ev_t[1] - ev_t[0], ev_t[2] - ev_t[1], ev_t[3] - ev_t[2], ev_t[4] - ev_t[3], ev_t[5] - ev_t[4], ev_t[6] - ev_t[5], ev_t[7] - ev_t[6]); } while (0)
+#else
+#define EV_STAMP(i) do { } while (0)
+#define EV_STAMP_DECL do { } while (0)
+#define EV_STAMP_PRINT do { } while (0)
+#endif
 template <int TYPE, bool SMALL>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
@@ -1151,16 +1172,19 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (blockIdx.x >= s.n_chunk) return;
+  EV_STAMP_DECL;
+  EV_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int DCS = NC | 1;                // odd stride for the step table as well
-  double* tab0 = lds;                                    // [n_cam][CBS] (+ 2: alignment slack of the flat copy)
-  double* ctab0 = tab0 + ((s.n_cam * CBS + 3) & ~1);     // [n_cam][CDS] (+ 2)
-  double* dct = ctab0 + ((s.n_cam * CDS + 3) & ~1);      // [n_cam][DCS] scaled camera step
+  double* tab0 = lds;                                    // [n_cam][CBS] (+ 4: alignment slack and spare slot of the flat copy)
+  double* ctab0 = tab0 + ((s.n_cam * CBS + 5) & ~1);     // [n_cam][CDS] (+ 4)
+  double* dct = ctab0 + ((s.n_cam * CDS + 5) & ~1);      // [n_cam][DCS] scaled camera step
   double* scratch = dct + s.n_cam * DCS;                 // [16]
   float4* obsbuf = reinterpret_cast<float4*>(scratch + 16);  // SMALL only: [8][blockDim.x]
-  const double* tab = tab0 + stage_flat(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
-  const double* ctab = ctab0 + stage_flat(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
+  const double* tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+  const double* ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
   __syncthreads();
+  EV_STAMP(1);
   // per camera: the scaled step of its 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir)
   for (int c = threadIdx.x; c < s.n_cam; c += blockDim.x) {
     const double* cbc = tab + c * CBS;
@@ -1175,6 +1199,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
       dct[c * DCS + NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
   }
   __syncthreads();
+  EV_STAMP(2);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double mcc = 0, cost = 0, dn = 0, cn = 0;
   if (j < s.n_ray) {
@@ -1195,6 +1220,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     double s1 = 0;
     double Xu[3], inv_n;  // the functor's point for this ray, once for all of its observations
     ba_ray_point<F>(Xr, Xu, inv_n);
+    EV_STAMP(3);
     for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
       const double* cb = tab + ci * CBS;
       double res[2], pd[2], Jr[2][3];
@@ -1205,6 +1231,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
       t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
     });
+    EV_STAMP(4);
     const double* E = d.E + (size_t)gj * EZS;
     // step = -y_r (Ceres solves J y = r and negates)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
@@ -1223,12 +1250,14 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     // pass 2: candidate cost (residuals only)
     double Xcu[3], inv_nc;
     ba_ray_point<F>(Xn, Xcu, inv_nc);
+    EV_STAMP(5);
     for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
       double rc[2];
       ba_residual_unit<F>(ctab + ci * CDS, Xcu, uv.x, uv.y, rc);
       cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
     });
   }
+  EV_STAMP(6);
   // one partial per wave of 64 rays (fixed butterfly), whatever the workgroup size
   mcc = wave_sum(mcc);
   cost = wave_sum(cost);
@@ -1239,6 +1268,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     pp[0] = mcc; pp[1] = cost; pp[2] = dn; pp[3] = cn;
   }
   (void)scratch;
+  EV_STAMP(7);
+  EV_STAMP_PRINT;
 }
 
 // ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
