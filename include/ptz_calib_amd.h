@@ -34,6 +34,11 @@ extern "C" {
 #define PTZ_ENODEVICE (-2)  /* no usable HIP device / HIP runtime error */
 #define PTZ_ENOMEM (-3)
 #define PTZ_EUNSUPPORTED (-4) /* factor type not implemented on the device path */
+#define PTZ_ELIMIT (-5)     /* a problem dimension beyond what the device path handles: more than 65535 observations in ONE view
+                               (16-bit positions in the camera-pair records), more than 2^31 - 1 observations or pair entries in
+                               one batch.  The number of views and tracks is bounded by device memory only (the reduced camera
+                               system is stored as dense tiles: 8 (NC n_views + 64)^2 bytes per scene).  Never a silent failure:
+                               the C++ classes report it on stderr and return false. */
 
 /* enum FACTOR_TYPE { PTZRay, PTZRayDist, PTZRayFxfyDist, PTZRayDistDisp }  (ptzray_optimizer.h:110) */
 #define PTZ_BA_PTZRay 0

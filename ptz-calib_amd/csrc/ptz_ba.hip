@@ -64,6 +64,8 @@ struct ptz_ba_batch {
   std::vector<SceneDev> scenes;
   int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;  // total_chunk: partial-sum slots (waves of 64 rays + 1 per scene)
   int ray_block = RAY_BLOCK;
+  bool schur_tg = false;         // a camera with more observations than k_schur's LDS table holds: table in global memory
+  bool gtab = false;             // camera tables too large for LDS: the GTAB instantiations read them from global memory
   bool small_blocks = false;     // ray_block <= 256: the SMALL instantiations of k_lin_ray / k_eval (observation prefetch through LDS)
   size_t lin_smem = 0, eval_smem = 0;
   int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0;
@@ -221,14 +223,25 @@ struct StagedUpload {
 };
 
 #define LAUNCH(kern, grid, block, smem, ...) ptz::launch(kern, grid, block, smem, b->stream, __VA_ARGS__)
+// the ray-centric kernels come in four shapes: small / large workgroups x camera tables staged in LDS / read from global memory
+#define PTZ_LAUNCH_RAY(kern, grid, smem, dev)                                                                       \
+  do {                                                                                                              \
+    if (b->small_blocks) {                                                                                          \
+      if (b->gtab) LAUNCH((kern<TYPE, true, true>), grid, dim3(b->d.ray_block), smem, dev);                         \
+      else LAUNCH((kern<TYPE, true, false>), grid, dim3(b->d.ray_block), smem, dev);                                \
+    }                                                                                                               \
+    else {                                                                                                          \
+      if (b->gtab) LAUNCH((kern<TYPE, false, true>), grid, dim3(b->d.ray_block), smem, dev);                        \
+      else LAUNCH((kern<TYPE, false, false>), grid, dim3(b->d.ray_block), smem, dev);                               \
+    }                                                                                                               \
+  } while (0)
 
 template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
 {
   const Dev& d = b->d;
   b->prof_begin(P_LIN);
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
-  if (b->small_blocks) LAUNCH((k_lin_ray<TYPE, true>), dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), b->lin_smem, d);
-  else LAUNCH((k_lin_ray<TYPE, false>), dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), b->lin_smem, d);
+  PTZ_LAUNCH_RAY(k_lin_ray, dim3(b->max_chunk, b->n_scene), b->lin_smem, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   if (d.shared) LAUNCH(k_group_grad<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
@@ -282,7 +295,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   constexpr int NC = Dims<TYPE>::NC;
   const int B = d.n_scene;
   hipStream_t st = b->stream;
-  const size_t schur_smem = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
+  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   b->prof_end();
@@ -290,7 +303,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   b->prof_begin(P_RAYPREP);
   {
     const int nt = d.chol.np / CHOL_NB;
-    if (d.chol.tmask) LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk + nt * nt, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
+    const int per = std::max(1, b->d.ray_block / 256);  // tiles of the lower triangle a workgroup clears
+    if (d.chol.tmask) LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk + (nt * (nt + 1) / 2 + per - 1) / per, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
     else {  // dense debugging path (PTZ_BA_DENSE_CHOL): whole matrices zeroed by a memset
       LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
       chol_clear(d.chol, st);
@@ -299,7 +313,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_SCHUR);
-  LAUNCH(k_schur<TYPE>, dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 2), d);
   b->prof_end();
@@ -309,8 +324,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_EVAL);
-  if (b->small_blocks) LAUNCH((k_eval<TYPE, true>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->eval_smem, d);
-  else LAUNCH((k_eval<TYPE, false>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->eval_smem, d);
+  PTZ_LAUNCH_RAY(k_eval, dim3(b->max_chunk, B), b->eval_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
   b->prof_begin(P_LMCTL);
@@ -319,8 +333,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   {
     const Dev& dd = d;
     b->prof_begin(P_LIN);
-    if (b->small_blocks) LAUNCH((k_lin_ray<TYPE, true>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
-    else LAUNCH((k_lin_ray<TYPE, false>), dim3(b->max_chunk, B), dim3(b->d.ray_block), b->lin_smem, dd);
+    PTZ_LAUNCH_RAY(k_lin_ray, dim3(b->max_chunk, B), b->lin_smem, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
     if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
@@ -966,8 +979,6 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     b->scenes.push_back(s);
   }
   (void)tot_ent;
-  // LDS budget of the eval kernel bounds the camera count of a scene (160 KiB per workgroup)
-  if (sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + NC + 1) + 16) > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
 
   tc1 = now_ms();
   Dev& d = b->d;
@@ -1030,6 +1041,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.costc, (size_t)b->total_cam));
   TRY(b->alloc(&d.diag_c, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.dc, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.dct, (size_t)b->total_cam * (NC | 1) + 4));
   TRY(b->alloc(&d.V, (size_t)b->total_ray * 6));
   TRY(b->alloc(&d.gr, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
@@ -1167,12 +1179,25 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
   b->small_blocks = b->ray_block <= 256;
   const size_t obs_lds = b->small_blocks ? (size_t)OBS_PREFETCH_BYTES * b->ray_block : 0;
-  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 12) + obs_lds;
+  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 18) + obs_lds;
   b->lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 6) + obs_lds;
+  // Rigs whose camera tables do not fit in LDS (the 160 KiB hold ~340 cameras) read them from global memory instead: the
+  // reference has no cap on the number of views (ptzray_optimizer.cc:799-885)
+  b->gtab = b->eval_smem > 160 * 1024;
+  if (const char* e = getenv("PTZ_BA_GLOBAL_TABLES")) b->gtab = atoi(e) != 0;
+  if (b->gtab) { b->eval_smem = sizeof(double) * 16 + obs_lds + 16; b->lin_smem = obs_lds + 16; }
   const int eval_smem = (int)b->eval_smem, lin_smem = (int)b->lin_smem;
-  const int schur_smem = (int)schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
-  if (schur_smem > 160 * 1024 || b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }  // (entry records hold 16-bit positions)
-  if (eval_smem > 160 * 1024 || lin_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_EUNSUPPORTED; }
+  // k_schur keeps a camera's T_a rows in LDS (up to ~1700 observations of one view); beyond that the table goes to global
+  // memory.  What remains is the 16-bit position inside the camera-pair entry records: 65535 observations per view.
+  if (b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+  b->schur_tg = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC) > 160 * 1024;
+  if (const char* e = getenv("PTZ_BA_SCHUR_GLOBAL_T")) b->schur_tg = atoi(e) != 0;
+  if (b->schur_tg) {
+    const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 15));
+    if (rc2) { ptz_ba_batch_destroy(b); return rc2; }
+    for (auto& dgp : b->dg) dgp.Tbuf = b->d.Tbuf;
+  }
+  if (eval_smem > 160 * 1024 || lin_smem > 160 * 1024) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
   {
     // The cap on dynamic LDS is a property of the kernel, not of a batch: raise it to the hardware limit once per device
     // and instantiation, so that batches of different sizes can live side by side (a per-batch value would let a small
@@ -1190,11 +1215,12 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) attr_ok = false;
       };
 #define PTZ_SET_ATTR(T)                        \
-      raise_cap((const void*)k_schur<T>);      \
-      raise_cap((const void*)k_eval<T, true>);       \
-      raise_cap((const void*)k_eval<T, false>);      \
-      raise_cap((const void*)k_lin_ray<T, true>);    \
-      raise_cap((const void*)k_lin_ray<T, false>);
+      raise_cap((const void*)k_schur<T, false>);      \
+      raise_cap((const void*)k_schur<T, true>);       \
+      raise_cap((const void*)k_eval<T, true, false>);       \
+      raise_cap((const void*)k_eval<T, false, false>);      \
+      raise_cap((const void*)k_lin_ray<T, true, false>);    \
+      raise_cap((const void*)k_lin_ray<T, false, false>);
       PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
 #undef PTZ_SET_ATTR
       if (!attr_ok) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }

@@ -87,12 +87,14 @@ struct Dev {
   double* costc;     // [total_cam]
   double* diag_c;    // [total_cam][NC]
   double* dc;        // [total_cam][NC] scaled-space camera step
+  double* dct;       // [total_cam][NC | 1] the same step as k_eval applies it per observation: [intrinsic components | Jl v_rot]
   double* V;         // [total_ray][6]
   double* gr;        // [total_ray][3]
   double* diag_r;    // [total_ray][3]
   double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), padding -- one record,
                      // because the Schur kernel gathers both for every observation
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
+  double* Tbuf;      // [total_obs][NW * 3] or nullptr: T_a = W_a E rows of k_schur when a camera's do not fit in LDS
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
   double* partial;   // [total_wave + n_scene][4] per wave of rays {model cost change, candidate cost, |x - x_c|^2, |x_c|^2} of k_eval
                      // (one extra slot per scene for the 2D-3D terms)
@@ -294,7 +296,9 @@ constexpr int OBS_PREFETCH_BYTES = 8 * 16;  // per thread of a SMALL workgroup
 // thread = ray: for every observation of the ray evaluate residual + Jacobians, apply sqrt(w) and the
 // Jacobi scales, accumulate V = sum Jr^T Jr and g_r = sum Jr^T r.  (The W_a = Jc^T Jr rows are written by k_lin_cam, whose
 // lanes walk a camera's observations in the order of its W rows: one sequential stream instead of a 96-byte scatter.)
-template <int TYPE, bool SMALL>
+// GTAB: the scene's camera table does not fit in LDS (more than ~340 cameras): the blocks are read where they lie, through the
+// caches (the reference has no cap on the number of cameras, ptzray_optimizer.cc:799-885).
+template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 {
   constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
@@ -303,9 +307,17 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const double* tab = lds + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
-  float4* obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 5) & ~1));  // SMALL only
-  __syncthreads();
+  const double* tab;
+  float4* obsbuf;  // SMALL only
+  if constexpr (GTAB) {
+    tab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
+    obsbuf = reinterpret_cast<float4*>(lds);
+  }
+  else {
+    tab = lds + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, lds, s.n_cam * CBS);
+    obsbuf = reinterpret_cast<float4*>(lds + ((s.n_cam * CBS + 5) & ~1));
+    __syncthreads();
+  }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double gm = 0, xn = 0;  // this ray's share of the gradient max-norm and of |x|^2 (k_lm_pre)
   if (j < s.n_ray) {
@@ -785,12 +797,19 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if ((int)blockIdx.x >= n_ray_blocks) {
+    // 256 threads per tile of the lower triangle (a 1024-thread workgroup takes four tiles, a 128-thread one half the rate)
     const int np = d.chol.np, nt = np / CHOL_NB;
-    const int t = blockIdx.x - n_ray_blocks;
-    const int ti = t / nt, tj = t % nt;
-    if (tj > ti || !d.chol.tmask[((size_t)sc * nt + ti) * nt + tj]) return;
+    const int per = max(1, (int)blockDim.x / 256), tpt = blockDim.x / per;
+    const int t = ((int)blockIdx.x - n_ray_blocks) * per + (int)threadIdx.x / tpt;
+    if (t >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    if (!d.chol.tmask[((size_t)sc * nt + ti) * nt + tj]) return;
     double* T = d.chol.A + (size_t)sc * np * np + (size_t)(ti * CHOL_NB) * np + tj * CHOL_NB;
-    for (int idx = threadIdx.x; idx < CHOL_NB * CHOL_NB / 2; idx += blockDim.x) {
+    const int lt = threadIdx.x % tpt;
+    for (int idx = lt; idx < CHOL_NB * CHOL_NB / 2; idx += tpt) {
       const int row = idx >> 5, c2 = (idx & 31) * 2;
       double2 v = make_double2(0.0, 0.0);
       if (ti == tj) {  // padding rows of the diagonal tile: identity, CHOL_BIG at (n, n)
@@ -802,7 +821,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
       }
       *reinterpret_cast<double2*>(T + (size_t)row * np + c2) = v;
     }
-    if (ti == tj && threadIdx.x == 0 && s.n >= ti * CHOL_NB && s.n < (ti + 1) * CHOL_NB) d.chol.fail[sc] = 0;
+    if (ti == tj && lt == 0 && s.n >= ti * CHOL_NB && s.n < (ti + 1) * CHOL_NB) d.chol.fail[sc] = 0;
     return;
   }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,7 +893,9 @@ __global__ void k_cam_diag(Dev d)
 #define PTZ_SCHUR_WAVES 3
 #endif
 constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
-template <int TYPE>
+// TG: a camera has more observations than the LDS table of T_a rows holds (~1700): the table lives in global memory instead
+// (d.Tbuf, camera-major like W; written and re-read by the same workgroup, so it stays in that compute unit's caches).
+template <int TYPE, bool TG>
 __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
@@ -894,8 +915,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   const int* pp = d.pair_ptr + s.pair_off + s.idx;
   const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   const int eb = 0;                                        // entries are addressed by global index
-  double* T = lds;                                  // [no][TS]
-  double* strip = lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
+  double* T = TG ? d.Tbuf + (size_t)o0 * TS : lds;             // [no][TS]
+  double* strip = TG ? lds : lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
   const unsigned* ents = d.ent + eb;                // (a slot | b slot << 16), this camera's contiguous range
   const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
   double bsum[NW], D[NU];
@@ -1111,6 +1132,19 @@ __global__ void k_cam_update(Dev d)
   double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
 #pragma unroll
   for (int k = 0; k < 15; ++k) xc[k] = c15[k];
+  {  // the scaled step of the camera's 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir), for k_eval
+    constexpr int NW = Dims<TYPE>::NW, DCS = NC | 1;
+    const double* cbc = cur_camblk(d, st) + (size_t)gi * CBS;
+    double sv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * (-y[Dims<TYPE>::pos(k)]);
+    double* dr = d.dct + (size_t)gi * DCS;
+#pragma unroll
+    for (int k = 0; k < NW - 3; ++k) dr[k] = sv[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      dr[NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
+  }
   // the candidate's full camera block (rotation, SO(3) Jacobian, intrinsics, scales) goes to the other half of camblk: if the
   // step is accepted the linearisation kernels find it there; its first CANDBLK entries are what k_eval needs of it
   double cb[CAMBLK];
@@ -1163,7 +1197,7 @@ __global__ void k_cam_update(Dev d)
 #define EV_STAMP_DECL do { } while (0)
 #define EV_STAMP_PRINT do { } while (0)
 #endif
-template <int TYPE, bool SMALL>
+template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
@@ -1176,29 +1210,28 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   EV_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int DCS = NC | 1;                // odd stride for the step table as well
-  double* tab0 = lds;                                    // [n_cam][CBS] (+ 4: alignment slack and spare slot of the flat copy)
-  double* ctab0 = tab0 + ((s.n_cam * CBS + 5) & ~1);     // [n_cam][CDS] (+ 4)
-  double* dct = ctab0 + ((s.n_cam * CDS + 5) & ~1);      // [n_cam][DCS] scaled camera step
-  double* scratch = dct + s.n_cam * DCS;                 // [16]
-  float4* obsbuf = reinterpret_cast<float4*>(scratch + 16);  // SMALL only: [8][blockDim.x]
-  const double* tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
-  const double* ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
-  __syncthreads();
-  EV_STAMP(1);
-  // per camera: the scaled step of its 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir)
-  for (int c = threadIdx.x; c < s.n_cam; c += blockDim.x) {
-    const double* cbc = tab + c * CBS;
-    const double* dcg = d.dc + (size_t)(s.cam_off + c) * NC;
-    double sv[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * dcg[Dims<TYPE>::pos(k)];
-#pragma unroll
-    for (int k = 0; k < NW - 3; ++k) dct[c * DCS + k] = sv[k];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      dct[c * DCS + NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
+  const double *tab, *ctab, *dct;
+  double* scratch;
+  float4* obsbuf;  // SMALL only: [8][blockDim.x]
+  if constexpr (GTAB) {  // tables read where they lie (see k_lin_ray)
+    tab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
+    ctab = d.candblk + (size_t)s.cam_off * CDS;
+    dct = d.dct + (size_t)s.cam_off * DCS;
+    scratch = lds;
+    obsbuf = reinterpret_cast<float4*>(scratch + 16);
   }
-  __syncthreads();
+  else {
+    double* tab0 = lds;                                    // [n_cam][CBS] (+ 4: alignment slack and spare slot of the flat copy)
+    double* ctab0 = tab0 + ((s.n_cam * CBS + 5) & ~1);     // [n_cam][CDS] (+ 4)
+    double* dct0 = ctab0 + ((s.n_cam * CDS + 5) & ~1);     // [n_cam][DCS] (+ 4) scaled camera step (k_cam_update)
+    scratch = dct0 + ((s.n_cam * DCS + 5) & ~1);           // [16]
+    obsbuf = reinterpret_cast<float4*>(scratch + 16);
+    tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+    ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
+    dct = dct0 + stage_flat<SMALL ? 16 : 8>(d.dct + (size_t)s.cam_off * DCS, dct0, s.n_cam * DCS);
+    __syncthreads();
+  }
+  EV_STAMP(1);
   EV_STAMP(2);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double mcc = 0, cost = 0, dn = 0, cn = 0;

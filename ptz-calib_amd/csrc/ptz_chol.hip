@@ -698,17 +698,15 @@ __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
 constexpr int BI_THREADS = 1024;
 struct BsItem { long long off; int ld, in_off, out_off, kind; };  // kind: 0 empty slot, 1 x = M^T t (diagonal inverse), 2 t -= M^T x
 
-__device__ __forceinline__ void bs_load(const BsItem* grp, const double* Lm, const double* Li, int sl, int q, int c, double (&v)[16])
+__device__ __forceinline__ void bs_load(const BsItem it, const double* Lm, const double* Li, int q, int c, double (&v)[16])
 {
-  const BsItem it = grp[sl];
   if (it.kind == 0) return;
   const double* col = (it.kind == 1 ? Li : Lm) + it.off + (size_t)(16 * q) * it.ld + c;
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = col[(size_t)r * it.ld];
 }
-__device__ __forceinline__ void bs_apply(const BsItem* grp, double* t, double* red, int n, int sl, int q, int c, const double (&v)[16])
+__device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red, int n, int q, int c, const double (&v)[16])
 {
-  const BsItem it = grp[sl];
   double p = 0;
   if (it.kind != 0) {
     const double* xin = t + it.in_off + 16 * q;
@@ -733,6 +731,9 @@ __device__ __forceinline__ void bs_apply(const BsItem* grp, double* t, double* r
   __syncthreads();
 }
 
+// LIST: the work list is built once in LDS and the loads run two groups ahead.  Systems with so many block columns that the
+// list does not fit (more than ~60, i.e. ~1000 views) walk the structure on the fly instead, one group at a time.
+template <bool LIST>
 __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb, double* xout, int max_groups)
 {
   const int sys = blockIdx.y;
@@ -745,11 +746,11 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* t = smem;          // [np] y, overwritten by x
   double* red = t + np;      // [BI_THREADS]
-  BsItem* items = reinterpret_cast<BsItem*>(red + BI_THREADS);  // [max_groups][4]
+  BsItem* items = reinterpret_cast<BsItem*>(red + BI_THREADS);  // LIST: [max_groups][4]
   __shared__ int n_groups;
   const int tid = threadIdx.x;
   const int c = tid & 63, q = (tid >> 6) & 3, sl = tid >> 8;
-  if (tid == 0) {  // the work list, in execution order
+  if (LIST && tid == 0) {  // the work list, in execution order
     int g = 0;
     for (int k = nt - 1; k >= 0; --k) {
       const int c0 = k * NB;
@@ -772,19 +773,42 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     for (int j = tid; j < np; j += BI_THREADS) t[j] = (j < n) ? ((j >= kt * NB) ? Ldn[j - kt * NB] : Lm[(size_t)n * np + j]) : 0.0;
   }
   __syncthreads();
-  const int G = n_groups;
-  double r0[16], r1[16], r2[16];
-  if (0 < G) bs_load(items + 0, Lm, Li, sl, q, c, r0);
-  if (1 < G) bs_load(items + 4, Lm, Li, sl, q, c, r1);
-  for (int g = 0; g < G; g += 3) {
-    if (g + 2 < G) bs_load(items + 4 * (g + 2), Lm, Li, sl, q, c, r2);
-    bs_apply(items + 4 * g, t, red, n, sl, q, c, r0);
-    if (g + 1 >= G) break;
-    if (g + 3 < G) bs_load(items + 4 * (g + 3), Lm, Li, sl, q, c, r0);
-    bs_apply(items + 4 * (g + 1), t, red, n, sl, q, c, r1);
-    if (g + 2 >= G) break;
-    if (g + 4 < G) bs_load(items + 4 * (g + 4), Lm, Li, sl, q, c, r1);
-    bs_apply(items + 4 * (g + 2), t, red, n, sl, q, c, r2);
+  if (LIST) {
+    const int G = n_groups;
+    double r0[16], r1[16], r2[16];
+    if (0 < G) bs_load(items[sl], Lm, Li, q, c, r0);
+    if (1 < G) bs_load(items[4 + sl], Lm, Li, q, c, r1);
+    for (int g = 0; g < G; g += 3) {
+      if (g + 2 < G) bs_load(items[4 * (g + 2) + sl], Lm, Li, q, c, r2);
+      bs_apply(items[4 * g + sl], t, red, n, q, c, r0);
+      if (g + 1 >= G) break;
+      if (g + 3 < G) bs_load(items[4 * (g + 3) + sl], Lm, Li, q, c, r0);
+      bs_apply(items[4 * (g + 1) + sl], t, red, n, q, c, r1);
+      if (g + 2 >= G) break;
+      if (g + 4 < G) bs_load(items[4 * (g + 4) + sl], Lm, Li, q, c, r1);
+      bs_apply(items[4 * (g + 2) + sl], t, red, n, q, c, r2);
+    }
+  }
+  else {
+    double r0[16];
+    for (int k = nt - 1; k >= 0; --k) {
+      const int c0 = k * NB;
+      if (c0 >= n) continue;
+      BsItem it = BsItem{(long long)k * (NB * NB), NB, c0, c0, sl == 0 ? 1 : 0};
+      bs_load(it, Lm, Li, q, c, r0);
+      bs_apply(it, t, red, n, q, c, r0);
+      for (int tj = 0; tj < k;) {  // tiles (k, tj) of the structure, four at a time, in the order the list would hold them
+        int mine = -1, ns = 0;
+        while (tj < k && ns < 4) {
+          if (!tm || tm[k * nt + tj]) { if (ns == sl) mine = tj; ++ns; }
+          ++tj;
+        }
+        if (ns == 0) break;
+        it = BsItem{(long long)c0 * np + (long long)(mine < 0 ? 0 : mine) * NB, np, c0, (mine < 0 ? 0 : mine) * NB, mine >= 0 ? 2 : 0};
+        bs_load(it, Lm, Li, q, c, r0);
+        bs_apply(it, t, red, n, q, c, r0);
+      }
+    }
   }
   for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[j] : 0.0;
 }
@@ -852,18 +876,22 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
   const int nt = cb.np / NB;
   int max_groups = nt;  // one group per diagonal inverse + the tiles of row k four at a time
   for (int k = 0; k < nt; ++k) max_groups += (k + 3) / 4;
-  const size_t smem = sizeof(double) * ((size_t)cb.np + BI_THREADS) + sizeof(BsItem) * 4 * (size_t)max_groups;
-  {  // large systems: the work list can take the dynamic LDS beyond 64 KiB
+  const size_t base = sizeof(double) * ((size_t)cb.np + BI_THREADS);
+  const size_t list = sizeof(BsItem) * 4 * (size_t)max_groups;
+  const bool use_list = base + list <= 150 * 1024;
+  {  // large systems: the dynamic LDS goes beyond 64 KiB
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       done.fetch_or(bit, std::memory_order_release);
     }
   }
-  launch(chol_backsolve_kernel, dim3(1, cb.count), dim3(BI_THREADS), smem, stream, cb, x, max_groups);
+  if (use_list) launch(chol_backsolve_kernel<true>, dim3(1, cb.count), dim3(BI_THREADS), base + list, stream, cb, x, max_groups);
+  else launch(chol_backsolve_kernel<false>, dim3(1, cb.count), dim3(BI_THREADS), base + 64, stream, cb, x, 0);
 }
 
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)

@@ -1,5 +1,7 @@
 #include "ptzray_optimizer.h"
 
+#include <cstdio>
+
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -343,7 +345,14 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   const auto t_dev = std::chrono::steady_clock::now();
   const int32_t rc = ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);
   device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
-  if (rc != PTZ_OK) return false;
+  if (rc != PTZ_OK) {
+    // not a convergence failure: the device path refused or could not run the problem.  Say so -- the reference's callers
+    // (PtzIncrementalOptimizer withdraws the newest image after a failed bundle adjustment) would otherwise mistake it for one.
+    fprintf(stderr, "[ptzcalib] PTZRayOptimizer::Solve: device solve not run, ptz_ba_solve returned %d (%s)\n", (int)rc,
+            rc == PTZ_EUNSUPPORTED ? "factor type not on the device path" : rc == PTZ_ELIMIT ? "problem dimension beyond the device path's limits, see PTZ_ELIMIT"
+            : rc == PTZ_ENOMEM ? "out of device memory" : rc == PTZ_ENODEVICE ? "no usable HIP device / runtime error" : "malformed problem");
+    return false;
+  }
 
   // CalReprojError (:960-968)
   init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);
