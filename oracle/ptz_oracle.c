@@ -365,14 +365,15 @@ void orc_undistort_point(const double* k1, const double* dist1, const float* uv,
 {
   double fx = k1[0], fy = k1[1], cx = k1[2], cy = k1[3];
   double k[5] = {dist1[0], dist1[1], dist1[2], dist1[3], dist1[4]}; /* OpenCV meaning: k1,k2,p1,p2,k3 */
-  double x = ((double)uv[0] - cx) / fx, y = ((double)uv[1] - cy) / fy;
+  double ifx = 1.0 / fx, ify = 1.0 / fy; /* OpenCV: x = (x - cx)*ifx */
+  double x = ((double)uv[0] - cx) * ifx, y = ((double)uv[1] - cy) * ify;
   double x0 = x, y0 = y;
   for (int j = 0; j < 5; ++j) {
     double r2 = x * x + y * y;
     double icdist = 1.0 / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
     if (icdist < 0) {
-      x = ((double)uv[0] - cx) / fx;
-      y = ((double)uv[1] - cy) / fy;
+      x = ((double)uv[0] - cx) * ifx;
+      y = ((double)uv[1] - cy) * ify;
       break;
     }
     double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);

@@ -1268,7 +1268,7 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
 int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
-  (void)hipGetLastError();  // an error left behind by somebody else's earlier call on this thread is not this solve's
+  clear_stale_error(__func__);
   PTZ_DEVICE_GUARD(b->device);
   switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
     case 0: return solve_impl<0>(b, summaries);
@@ -1335,7 +1335,7 @@ int32_t ptz_ba_batch_get_profile(const ptz_ba_batch* b, double* ms_per_slot, int
 int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
 {
   if (!b || !b->has_state) return PTZ_EINVAL;
-  (void)hipGetLastError();
+  clear_stale_error(__func__);
   PTZ_DEVICE_GUARD(b->device);
   hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), 0, b->stream, b->d, b->cam0, b->ray0);
   PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1345,7 +1345,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
 
 int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, double* g_c, double* U, double* g_r, double* V, double* W)
 {
-  (void)hipGetLastError();
+  clear_stale_error(__func__);
   if (!b || !b->has_state || index < 0 || index >= b->n_scene) return PTZ_EINVAL;
   PTZ_DEVICE_GUARD(b->device);
   const Dev& d = b->d;

@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 extern "C" int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops)
 {
   using namespace ptz;
-  (void)hipGetLastError();
+  clear_stale_error(__func__);
   if (!tflops) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const double2* __restrict
 extern "C" int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps)
 {
   using namespace ptz;
-  (void)hipGetLastError();
+  clear_stale_error(__func__);
   if (!read_gbps || !copy_gbps) return PTZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;

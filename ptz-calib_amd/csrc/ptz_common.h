@@ -25,6 +25,15 @@ namespace ptz {
 
 constexpr int WAVE = 64;
 
+// Entry points check hipGetLastError() after their own launches, so an error some other user of the runtime left behind on this
+// thread (PyTorch, an earlier failed call) has to go first -- but not silently: it is reported once per occurrence.
+inline void clear_stale_error(const char* where)
+{
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    fprintf(stderr, "[ptzcalib] %s: cleared a HIP error that an earlier call on this thread left behind (%s); it is not this call's\n", where, hipGetErrorName(e));
+}
+
 // Every C-ABI entry point runs on the device it was given and leaves the calling thread's current device as it found it
 // (a PyTorch caller's later launches must not land on another GPU because a batch was destroyed at GC time).
 struct DeviceGuard {

@@ -510,12 +510,13 @@ PTZ_HD void krt_eval_2d3d(const double* R, const double* Jl, double fx, double f
 PTZ_HD void undistort_point(double fx, double fy, double cx, double cy, const double* d, float u, float v,
                             float& ou, float& ov)
 {
-  double x = ((double)u - cx) / fx, y = ((double)v - cy) / fy;
+  const double ifx = 1.0 / fx, ify = 1.0 / fy;  // cvUndistortPointsInternal multiplies by the reciprocals (a last-bit matter: the
+  double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;  // result is rounded to float32 and compared with the frame border)
   const double x0 = x, y0 = y;
   for (int j = 0; j < 5; ++j) {
     const double r2 = x * x + y * y;
     const double icdist = 1.0 / (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2);
-    if (icdist < 0) { x = ((double)u - cx) / fx; y = ((double)v - cy) / fy; break; }
+    if (icdist < 0) { x = ((double)u - cx) * ifx; y = ((double)v - cy) * ify; break; }
     const double dX = 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x);
     const double dY = d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y;
     x = (x0 - dX) * icdist;

@@ -450,7 +450,7 @@ extern "C" int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_
   if (factor_type < PTZ_KRT_F || factor_type > PTZ_KRT_FxfyDist) return PTZ_EUNSUPPORTED;
   ptz_lm_options o;
   if (opt) o = *opt; else ptz_lm_options_default(&o);
-  (void)hipGetLastError();  // not this call's: an error left behind earlier on this thread
+  clear_stale_error(__func__);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PTZ_ENODEVICE;
   // The launch goes to the device that owns the caller's buffers, on the caller's stream: a caller holding tensors and a
@@ -502,7 +502,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   for (int q = 0; q < n_query; ++q)
     if (match_ptr[q + 1] < match_ptr[q]) return PTZ_EINVAL;
-  (void)hipGetLastError();  // not this call's: an error left behind earlier on this thread
+  clear_stale_error(__func__);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
   PTZ_DEVICE_GUARD(o.device_id);

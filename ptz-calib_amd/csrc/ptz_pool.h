@@ -31,16 +31,17 @@ struct State {
   std::map<size_t, std::vector<void*>> pinned_free;
   std::unordered_map<void*, size_t> pinned_live;
   size_t budget = 0;
+  State()  // (in the constructor: the function-local static below is initialised exactly once, also under concurrent first use)
+  {
+    size_t mb = 4096;
+    if (const char* e = getenv("PTZ_CACHE_MAX_MB")) mb = (size_t)atoll(e);
+    budget = mb << 20;
+  }
 };
 
 inline State& state()
 {
   static State s;
-  if (s.budget == 0) {
-    size_t mb = 4096;
-    if (const char* e = getenv("PTZ_CACHE_MAX_MB")) mb = (size_t)atoll(e);
-    s.budget = (mb << 20) | 1;  // | 1: "initialised", also when the budget is 0
-  }
   return s;
 }
 
@@ -120,7 +121,7 @@ inline void dev_release(int device, void* p)
     else {
       cls = it->second;
       d.live.erase(it);
-      if (d.parked_bytes + cls <= (s.budget & ~(size_t)1)) {
+      if (d.parked_bytes + cls <= s.budget) {
         d.free_blocks[cls].push_back(p);
         d.parked_bytes += cls;
         park = true;
@@ -203,26 +204,38 @@ inline void event_release(int device, bool timing, hipEvent_t e)
 // Give every parked resource back to the driver (resources in use by live batches are not touched).
 inline void trim()
 {
-  State& s = state();
-  std::lock_guard<std::mutex> lk(s.mu);
+  // handles are collected under the lock and given back outside it: hipFree / hipStreamDestroy can synchronise the device,
+  // which must not happen while another thread's create waits for the pool
+  struct Freed { int dev; std::vector<void*> blocks; std::vector<hipStream_t> streams; std::vector<hipEvent_t> events; };
+  std::vector<Freed> freed;
+  std::vector<void*> pinned;
+  {
+    State& s = state();
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (auto& kv : s.dev) {
+      Freed f;
+      f.dev = kv.first;
+      for (auto& fb : kv.second.free_blocks) f.blocks.insert(f.blocks.end(), fb.second.begin(), fb.second.end());
+      kv.second.free_blocks.clear();
+      kv.second.parked_bytes = 0;
+      f.streams.swap(kv.second.streams);
+      f.events.swap(kv.second.timing_events);
+      f.events.insert(f.events.end(), kv.second.plain_events.begin(), kv.second.plain_events.end());
+      kv.second.plain_events.clear();
+      freed.push_back(std::move(f));
+    }
+    for (auto& kv : s.pinned_free) pinned.insert(pinned.end(), kv.second.begin(), kv.second.end());
+    s.pinned_free.clear();
+  }
   int cur = 0;
   (void)hipGetDevice(&cur);
-  for (auto& kv : s.dev) {
-    (void)hipSetDevice(kv.first);
-    for (auto& fb : kv.second.free_blocks)
-      for (void* p : fb.second) (void)hipFree(p);
-    kv.second.free_blocks.clear();
-    kv.second.parked_bytes = 0;
-    for (auto st : kv.second.streams) (void)hipStreamDestroy(st);
-    kv.second.streams.clear();
-    for (auto e : kv.second.timing_events) (void)hipEventDestroy(e);
-    for (auto e : kv.second.plain_events) (void)hipEventDestroy(e);
-    kv.second.timing_events.clear();
-    kv.second.plain_events.clear();
+  for (auto& f : freed) {
+    (void)hipSetDevice(f.dev);
+    for (void* p : f.blocks) (void)hipFree(p);
+    for (auto st : f.streams) (void)hipStreamDestroy(st);
+    for (auto e : f.events) (void)hipEventDestroy(e);
   }
-  for (auto& kv : s.pinned_free)
-    for (void* p : kv.second) (void)hipHostFree(p);
-  s.pinned_free.clear();
+  for (void* p : pinned) (void)hipHostFree(p);
   (void)hipSetDevice(cur);
 }
 
