@@ -399,3 +399,56 @@ def test_krt_frames_roundtrip(orc):
     assert np.allclose(back[7:10], cur[7:10], atol=1e-12)
     same = orc.krt_world_to_local(ref, ref)  # reloc init: R_cur = R_ref -> local rotation I, rvec 0
     assert np.allclose(same[4:7], 0, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The oracle against minima found by an independent solver (scipy.optimize.least_squares on residuals restated in numpy,
+# tests/golden/gen_minima.py -> tests/golden/minima_*.json): pins WHERE the minimum of the reference's objective lies without
+# any code of oracle/ -- so "the oracle agrees with itself" is no longer the only statement about the floating-point path.
+@pytest.mark.parametrize("name", ["c1", "c1_dist", "m60x300"])
+def test_oracle_reaches_the_independent_minimum(pkg, orc, name):
+    import minima_util as mu
+    m = mu.load(name)
+    sc = mu.scene_of(pkg, m)
+    for mode in (orc.JAC_NUMERIC, orc.JAC_ANALYTIC):
+        cam, ray, _, summ, _ = orc.ba_solve(sc, jacobian_mode=mode, num_threads=8)
+        assert summ["termination_type"] == 0
+        mu.check_against_minimum(cam, summ, m, tight=False)
+    cam, ray, _, summ, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_ANALYTIC, num_threads=8, **mu.TIGHT)
+    mu.check_against_minimum(cam, summ, m, tight=True)
+
+
+def test_oracle_gradient_vanishes_at_the_independent_minimum(pkg, orc):
+    """First-order optimality, checked with the oracle's own Jacobians at scipy's minimum of C1: the gradient there is 1e-9 of
+    the gradient at the initial guess (so the two codes agree on the objective AND its derivative)."""
+    import minima_util as mu
+    m = mu.load("c1")
+    sc = mu.scene_of(pkg, m)
+    cam = sc.cam_init.copy()
+    cam[:, 0] = cam[:, 1] = m["focal"]
+    cam[:, 4:7] = m["rvec"]
+    lin0 = orc.ba_linearize(sc, sc.cam_init, sc.ray_init)
+    lin1 = orc.ba_linearize(sc, cam, np.asarray(m["ray"]))
+    g0 = max(np.abs(lin0["g_c"]).max(), np.abs(lin0["g_r"]).max())
+    g1 = max(np.abs(lin1["g_c"]).max(), np.abs(lin1["g_r"]).max())
+    assert abs(lin1["cost"] - m["cost"]) / m["cost"] < 1e-12
+    assert g1 < 1e-8 * g0, (g1, g0)
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_oracle_krt_reaches_the_independent_minimum(pkg, orc, ftype):
+    import json, os
+    import minima_util as mu
+    gold = json.load(open(os.path.join(mu.GOLD, "minima_reloc.json")))["queries"][str(ftype)]
+    rb = pkg.synth.make_reloc_batch(16, 128, seed_id=ftype, factor_type=ftype)
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, summ, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, jacobian_mode=orc.JAC_NUMERIC, **mu.TIGHT)
+        w = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
+        g = gold[q]
+        assert abs(summ["final_cost"] - g["cost"]) / g["cost"] < 1e-9
+        assert abs(w[0] - g["focal"]) / g["focal"] < 1e-7
+        assert np.abs(orc.rodrigues(w[4:7]) - np.asarray(g["R_world"])).max() < 1e-7
+        if ftype:
+            assert abs(w[10] - g["k1"]) < 1e-7

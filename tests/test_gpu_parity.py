@@ -1123,3 +1123,53 @@ def test_ba_shared_intrinsics_with_annotations(pkg, orc, ftype):
     Rlw, oRlw = orc.rodrigues(tlw[:3]), orc.rodrigues(otlw[:3])
     for i in range(sc.n_cam):
         assert np.abs(orc.rodrigues(cam[i, 4:7]) @ Rlw - orc.rodrigues(ocam[i, 4:7]) @ oRlw).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The device path against minima found by an independent solver (scipy.optimize.least_squares on residuals restated in numpy,
+# tests/golden/gen_minima.py -> tests/golden/minima_*.json; nothing of oracle/ went into them).
+@pytest.mark.parametrize("name", ["c1", "c1_dist", "m60x300"])
+def test_device_reaches_the_independent_minimum(pkg, name):
+    import minima_util as mu
+    m = mu.load(name)
+    sc = mu.scene_of(pkg, m)
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    assert summ["termination_type"] == 0
+    mu.check_against_minimum(cam, summ, m, tight=False)     # Ceres' default tolerances: within function_tolerance of the minimum
+    cam, ray, summ = pkg.api.ba_solve(sc, **mu.TIGHT)
+    mu.check_against_minimum(cam, summ, m, tight=True)      # tight tolerances: the minimum itself (cost 1e-9, parameters 1e-6)
+
+
+def test_device_gradient_vanishes_at_the_independent_minimum(pkg):
+    """First-order optimality with the DEVICE's closed-form Jacobians at scipy's minimum of C1 (ptz_ba_batch_linearize)."""
+    import minima_util as mu
+    m = mu.load("c1")
+    sc = mu.scene_of(pkg, m)
+    cam = sc.cam_init.copy()
+    cam[:, 0] = cam[:, 1] = m["focal"]
+    cam[:, 4:7] = m["rvec"]
+    b = pkg.api.BaBatch([sc])
+    b.set_state(); lin0 = b.linearize(0)
+    b.set_state(cams=[cam], rays=[np.asarray(m["ray"])]); lin1 = b.linearize(0)
+    b.close()
+    g0 = max(np.abs(lin0["g_c"]).max(), np.abs(lin0["g_r"]).max())
+    g1 = max(np.abs(lin1["g_c"]).max(), np.abs(lin1["g_r"]).max())
+    assert abs(lin1["cost"] - m["cost"]) / m["cost"] < 1e-12
+    assert g1 < 1e-8 * g0, (g1, g0)
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_device_krt_reaches_the_independent_minimum(pkg, orc, ftype):
+    import json, os
+    import minima_util as mu
+    gold = json.load(open(os.path.join(mu.GOLD, "minima_reloc.json")))["queries"][str(ftype)]
+    rb = pkg.synth.make_reloc_batch(16, 128, seed_id=ftype, factor_type=ftype)
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb, **mu.TIGHT)
+    for q in range(rb.n_query):
+        g = gold[q]
+        assert acc[q] == 1
+        assert abs(summ[q]["final_cost"] - g["cost"]) / g["cost"] < 1e-9
+        assert abs(cam_w[q, 0] - g["focal"]) / g["focal"] < 1e-7
+        assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - np.asarray(g["R_world"])).max() < 1e-7
+        if ftype:
+            assert abs(cam_w[q, 10] - g["k1"]) < 1e-7
