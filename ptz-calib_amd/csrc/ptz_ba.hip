@@ -56,8 +56,21 @@ using namespace ptz;
 
 // chol_factor_solve split so that the three kernel families can be timed separately
 namespace ptz {
-void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof);
+void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof, bool fused);
 }
+
+// The launch shape of one LM pass.  A batch's passes start at full size; once few of its scenes are still active the host
+// switches to compacted shapes whose grids cover `slots` scenes (blockIdx.y -> scene through the device's compacted list), with
+// the workgroup size, the kernel variants and the factorisation path a batch of that size would get -- the stragglers of a
+// 1000-scene batch then cost what a handful of scenes cost, not a thousand empty workgroups per kernel.
+struct PassShape {
+  int slots = 0;          // grid extent over scenes
+  bool compact = false;   // blockIdx.y is a slot of the compacted list
+  int ray_block = 1024;   // rays per workgroup of the ray-centric kernels
+  bool small_blocks = false, fused = false;  // SMALL kernel variants; one-launch-per-column factorisation
+  int max_chunk = 0;
+  size_t lin_smem = 0, eval_smem = 0;
+};
 
 struct ptz_ba_batch {
   int n_scene = 0, type = 0, nc = 4, device = 0;
@@ -66,8 +79,7 @@ struct ptz_ba_batch {
   int ray_block = RAY_BLOCK;
   bool schur_tg = false;         // a camera with more observations than k_schur's LDS table holds: table in global memory
   bool gtab = false;             // camera tables too large for LDS: the GTAB instantiations read them from global memory
-  bool small_blocks = false;     // ray_block <= 256: the SMALL instantiations of k_lin_ray / k_eval (observation prefetch through LDS)
-  size_t lin_smem = 0, eval_smem = 0;
+  int n_group_hint(int n) const { if (const char* e = getenv("PTZ_BA_STREAMS")) return std::max(1, atoi(e)); return n >= 32 ? 2 : 1; }
   int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0;
   ptz_lm_options opt;
   Dev d;
@@ -86,7 +98,6 @@ struct ptz_ba_batch {
   std::vector<hipEvent_t> la_ev;
   bool lookahead = true;
   bool left_looking = true;  // left-looking column updates instead of right-looking trailing updates
-  bool fused_steps = false;  // a few scenes: one launch per block column, triangular solves folded into the trailing update
   int group_of(hipStream_t st) const { for (size_t g = 0; g < streams.size(); ++g) if (streams[g] == st) return (int)g; return -1; }
   hipStream_t aux_stream(hipStream_t st) const { const int g = group_of(st); return (lookahead && g >= 0 && g < (int)aux.size()) ? aux[g] : nullptr; }
   void lookahead_events(hipStream_t st, hipEvent_t* t, hipEvent_t* r) const { const int g = group_of(st); *t = la_ev[2 * g]; *r = la_ev[2 * g + 1]; }
@@ -98,7 +109,10 @@ struct ptz_ba_batch {
   int ahead = 3;             // LM passes the host may have enqueued beyond the last one known to have reached its step evaluation
   // one captured LM pass per scene group (kernel arguments never change during a batch's life), replayed per pass
   bool use_graph = true;
-  std::vector<hipGraphExec_t> pass_graph;
+  std::vector<PassShape> shapes;                        // [0] = full size, then compacted shapes by ascending slot count
+  std::vector<std::vector<hipGraphExec_t>> pass_graph;  // [group][shape]
+  int* d_act = nullptr;                                 // compacted scene lists, n_scene ints (each group its own range)
+  bool compaction = true;
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
   int has3d = 0, total_o3 = 0;
   // Rays are renumbered inside the library, longest track first (see build_pairs): ray_perm[ray_off + j] = the caller's
@@ -226,22 +240,23 @@ struct StagedUpload {
 // the ray-centric kernels come in four shapes: small / large workgroups x camera tables staged in LDS / read from global memory
 #define PTZ_LAUNCH_RAY(kern, grid, smem, dev)                                                                       \
   do {                                                                                                              \
-    if (b->small_blocks) {                                                                                          \
-      if (b->gtab) LAUNCH((kern<TYPE, true, true>), grid, dim3(b->d.ray_block), smem, dev);                         \
-      else LAUNCH((kern<TYPE, true, false>), grid, dim3(b->d.ray_block), smem, dev);                                \
+    if (sh.small_blocks) {                                                                                          \
+      if (b->gtab) LAUNCH((kern<TYPE, true, true>), grid, dim3(sh.ray_block), smem, dev);                           \
+      else LAUNCH((kern<TYPE, true, false>), grid, dim3(sh.ray_block), smem, dev);                                  \
     }                                                                                                               \
     else {                                                                                                          \
-      if (b->gtab) LAUNCH((kern<TYPE, false, true>), grid, dim3(b->d.ray_block), smem, dev);                        \
-      else LAUNCH((kern<TYPE, false, false>), grid, dim3(b->d.ray_block), smem, dev);                               \
+      if (b->gtab) LAUNCH((kern<TYPE, false, true>), grid, dim3(sh.ray_block), smem, dev);                          \
+      else LAUNCH((kern<TYPE, false, false>), grid, dim3(sh.ray_block), smem, dev);                                 \
     }                                                                                                               \
   } while (0)
 
 template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
 {
   const Dev& d = b->d;
+  const PassShape& sh = b->shapes[0];
   b->prof_begin(P_LIN);
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
-  PTZ_LAUNCH_RAY(k_lin_ray, dim3(b->max_chunk, b->n_scene), b->lin_smem, d);
+  PTZ_LAUNCH_RAY(k_lin_ray, dim3(sh.max_chunk, b->n_scene), sh.lin_smem, d);
   LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   if (d.shared) LAUNCH(k_group_grad<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
@@ -265,7 +280,6 @@ static void make_groups(ptz_ba_batch* b)
     d.yc += (size_t)lo * np;
     d.chol.count = hi - lo;
     d.chol.A += (size_t)lo * np * np;
-    if (d.chol.L) d.chol.L += (size_t)lo * np * np;
     if (d.chol.Linv) d.chol.Linv += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Ldiag += (size_t)lo * nt * CHOL_NB * CHOL_NB;
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
@@ -273,11 +287,14 @@ static void make_groups(ptz_ba_batch* b)
     if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
     d.grp_ctl = b->d_ctl + 4 * g;
     d.host_ctl = b->h_ctl_dev + 4 * g;
+    d.act = b->d_act + lo;
+    d.use_act = 0;
+    if (d.chol.L) d.chol.L = b->d.chol.L + (size_t)g * std::min(b->n_scene, 8) * np * np;  // up to eight slots of finished L tiles per group
     b->dg.push_back(d);
   }
-  if ((int)b->pass_graph.size() != G) {  // the grouping changed (profiling on / off): captured passes are stale
-    for (auto ge : b->pass_graph) if (ge) (void)hipGraphExecDestroy(ge);
-    b->pass_graph.assign(G, nullptr);
+  if ((int)b->pass_graph.size() != G || (G > 0 && b->pass_graph[0].size() != b->shapes.size())) {  // the grouping changed (profiling on / off): recorded passes are stale
+    for (auto& v : b->pass_graph) for (auto ge : v) if (ge) (void)hipGraphExecDestroy(ge);
+    b->pass_graph.assign(G, std::vector<hipGraphExec_t>(b->shapes.size(), nullptr));
   }
   while ((int)b->streams.size() < G) {
     hipStream_t st; (void)ptzpool::stream_acquire(b->device, &st); b->streams.push_back(st);
@@ -289,24 +306,32 @@ static void make_groups(ptz_ba_batch* b)
   }
 }
 
-// one LM pass of one group, enqueued on b->stream; returns after enqueueing (no synchronisation)
-template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
+// one LM pass of one group in launch shape `sh`, enqueued on b->stream; returns after enqueueing (no synchronisation)
+template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool last, const PassShape& sh)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int B = d.n_scene;
+  Dev d = dgrp;
+  d.use_act = sh.compact ? 1 : 0;
+  d.ray_block = sh.ray_block;
+  d.chol.count = sh.slots;
+  d.chol.act = sh.compact ? d.act : nullptr;
+  d.chol.act_n = d.grp_ctl + 2;
+  if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
+  const int B = sh.slots;
   hipStream_t st = b->stream;
   const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
+  if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
   b->prof_end();
   if (last) return;
   b->prof_begin(P_RAYPREP);
   {
     const int nt = d.chol.np / CHOL_NB;
-    const int per = std::max(1, b->d.ray_block / 256);  // tiles of the lower triangle a workgroup clears
-    if (d.chol.tmask) LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk + (nt * (nt + 1) / 2 + per - 1) / per, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
+    const int per = std::max(1, sh.ray_block / 256);  // tiles of the lower triangle a workgroup clears
+    if (d.chol.tmask) LAUNCH(k_ray_prep<TYPE>, dim3(sh.max_chunk + (nt * (nt + 1) / 2 + per - 1) / per, B), dim3(sh.ray_block), 0, d, sh.max_chunk);
     else {  // dense debugging path (PTZ_BA_DENSE_CHOL): whole matrices zeroed by a memset
-      LAUNCH(k_ray_prep<TYPE>, dim3(b->max_chunk, B), dim3(b->d.ray_block), 0, d, b->max_chunk);
+      LAUNCH(k_ray_prep<TYPE>, dim3(sh.max_chunk, B), dim3(sh.ray_block), 0, d, sh.max_chunk);
       chol_clear(d.chol, st);
     }
   }
@@ -318,13 +343,13 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 2), d);
   b->prof_end();
-  chol_factor_solve_profiled(d.chol, d.yc, st, b);
+  chol_factor_solve_profiled(d.chol, d.yc, st, b, sh.fused);
   if (d.shared) LAUNCH(k_group_expand<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_begin(P_BACKSUB);
   LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_EVAL);
-  PTZ_LAUNCH_RAY(k_eval, dim3(b->max_chunk, B), b->eval_smem, d);
+  PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
   b->prof_begin(P_LMCTL);
@@ -333,7 +358,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& d, bool last)
   {
     const Dev& dd = d;
     b->prof_begin(P_LIN);
-    PTZ_LAUNCH_RAY(k_lin_ray, dim3(b->max_chunk, B), b->lin_smem, dd);
+    PTZ_LAUNCH_RAY(k_lin_ray, dim3(sh.max_chunk, B), sh.lin_smem, dd);
     LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
     if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
@@ -355,6 +380,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   hipStream_t s0 = b->streams[0];
   b->stream = s0;
   for (int i = 0; i < 4 * b->ctl_groups; ++i) __atomic_store_n(&b->h_ctl[i], 0, __ATOMIC_RELEASE);  // nothing of this batch is in flight
+  for (int g = 0; g < G; ++g) __atomic_store_n(&b->h_ctl[4 * g + 2], b->group_count[g], __ATOMIC_RELEASE);
   PTZ_HIP_TRY(hipEventRecord(b->ev0, s0));
   // x <- initial state, scales <- 1, LM state reset (whole batch, stream 0)
   PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, s0));
@@ -386,24 +412,25 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   // Passes enqueued past that point are empty launches.  Groups drift out of phase, so the latency-bound part of one
   // group's pass (block-column chain of the factorisation, LM control) overlaps the throughput kernels of another.
   const bool graph = b->use_graph && !b->profiling && !b->lookahead && b->d.chol.tmask != nullptr;
-  if (graph) {
-    for (int g = 0; g < G; ++g) {
-      if (b->pass_graph[g]) continue;
-      GraphRecorder rec;
-      bool ok = hipGraphCreate(&rec.graph, 0) == hipSuccess;
-      if (ok) {
-        b->stream = b->streams[g];
-        g_recorder = &rec;
-        enqueue_pass<TYPE>(b, b->dg[g], false);
-        g_recorder = nullptr;
-        ok = rec.ok && hipGraphInstantiate(&b->pass_graph[g], rec.graph, nullptr, nullptr, 0) == hipSuccess;
-      }
-      if (rec.graph) (void)hipGraphDestroy(rec.graph);
-      if (!ok) { (void)hipGetLastError(); b->pass_graph[g] = nullptr; b->use_graph = false; break; }
+  auto graph_of = [&](int g, int si) -> hipGraphExec_t {  // built on first use: one node per launch, a linear chain
+    if (b->pass_graph[g][si]) return b->pass_graph[g][si];
+    GraphRecorder rec;
+    bool ok = hipGraphCreate(&rec.graph, 0) == hipSuccess;
+    if (ok) {
+      b->stream = b->streams[g];
+      g_recorder = &rec;
+      PassShape shg = b->shapes[si];
+      if (si == 0) shg.slots = b->group_count[g];
+      enqueue_pass<TYPE>(b, b->dg[g], false, shg);
+      g_recorder = nullptr;
+      ok = rec.ok && hipGraphInstantiate(&b->pass_graph[g][si], rec.graph, nullptr, nullptr, 0) == hipSuccess;
     }
-  }
+    if (rec.graph) (void)hipGraphDestroy(rec.graph);
+    if (!ok) { (void)hipGetLastError(); b->pass_graph[g][si] = nullptr; b->use_graph = false; }
+    return b->pass_graph[g][si];
+  };
   std::vector<char> galive(G, 1);
-  std::vector<int> enq(G, 0);
+  std::vector<int> enq(G, 0), shape_used;
   int alive = G;
   while (alive > 0) {
     bool progressed = false;
@@ -414,8 +441,20 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       const double te0 = now();
       b->stream = b->streams[g];
       const bool last = enq[g] == max_it;  // the last pass only closes the books (k_lm_pre)
-      if (!last && graph && b->use_graph && b->pass_graph[g]) PTZ_HIP_TRY(hipGraphLaunch(b->pass_graph[g], b->streams[g]));
-      else enqueue_pass<TYPE>(b, b->dg[g], last);
+      // launch shape: the smallest one that covers the scenes last reported active (the count only ever decreases, so a stale
+      // value is an upper bound); full size while more than the largest compacted shape are
+      int si = 0;
+      if (b->compaction && !last) {
+        const int cnt = __atomic_load_n(&b->h_ctl[4 * g + 2], __ATOMIC_ACQUIRE);
+        for (int k = 1; k < (int)b->shapes.size(); ++k)
+          if (b->shapes[k].slots >= cnt && b->shapes[k].slots < b->group_count[g]) { si = k; break; }
+      }
+      PassShape sh = b->shapes[si];
+      if (si == 0) { sh.slots = b->group_count[g]; }
+      if (dbg) { if (shape_used.size() < b->shapes.size()) shape_used.resize(b->shapes.size(), 0); ++shape_used[si]; }
+      hipGraphExec_t ge = (!last && graph && b->use_graph) ? graph_of(g, si) : nullptr;
+      if (ge) PTZ_HIP_TRY(hipGraphLaunch(ge, b->streams[g]));
+      else { b->stream = b->streams[g]; enqueue_pass<TYPE>(b, b->dg[g], last, sh); }
       ++enq[g];
       progressed = true;
       t_enq += now() - te0;
@@ -427,6 +466,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       t_sync += now() - ts0;
     }
   }
+  if (dbg) for (size_t k = 0; k < shape_used.size(); ++k) fprintf(stderr, "[ptz_ba] launch shape %zu (%d slots%s): %d passes\n", k, b->shapes[k].slots, b->shapes[k].compact ? ", compacted" : "", shape_used[k]);
   if (dbg) for (int g = 0; g < G; ++g) fprintf(stderr, "[ptz_ba] group %d: %d passes enqueued, %d reached by the device when the host stopped\n", g, enq[g], b->h_ctl[4 * g]);
   // join
   for (int g = 1; g < G; ++g) {
@@ -468,7 +508,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
 
 namespace ptz {
 // defined here (needs ptz_ba_batch) but uses the kernels of ptz_chol.hip through chol_factor_solve pieces
-void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof)
+void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stream, void* prof, bool fused)
 {
   // One-step look-ahead: after the triangular solve of block column k, the small update of block column k+1 stays on
   // the main stream, so the (latency-bound) diagonal factorisation and triangular solve of step k+1 start at once,
@@ -480,7 +520,7 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   hipEvent_t evT = nullptr, evR = nullptr;
   if (la) b->lookahead_events(stream, &evT, &evR);
   bool rest_pending = false;
-  if (b->fused_steps) {  // a few scenes: one launch per block column (chol_col_step_kernel)
+  if (fused) {  // a few scenes: one launch per block column (chol_col_step_kernel)
     b->prof_begin(P_CHOL_PANEL);
     chol_diag_launch(cb, 0, stream);
     b->prof_end();
@@ -601,7 +641,7 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   for (void* p : b->allocs) ptzpool::dev_release(dv, p);
   for (auto e : b->ev_pool) ptzpool::event_release(dv, true, e);
   if (b->h_ctl) ptzpool::pinned_release(b->h_ctl);
-  for (auto ge : b->pass_graph) if (ge) (void)hipGraphExecDestroy(ge);
+  for (auto& v : b->pass_graph) for (auto ge : v) if (ge) (void)hipGraphExecDestroy(ge);
   ptzpool::event_release(dv, true, b->ev0);
   ptzpool::event_release(dv, true, b->ev1);
   for (auto st : b->streams) ptzpool::stream_release(dv, st);
@@ -1072,13 +1112,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     d.chol.n = dn;
   }
   TRY(b->alloc(&d.chol.A, (size_t)n * d.chol.np * d.chol.np));
-  b->fused_steps = n < 8;  // a few scenes: one launch per block column (needs a second matrix for the finished L tiles)
-  if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) b->fused_steps = atoi(e) != 0;
-  if (b->fused_steps) {
-    TRY(b->alloc(&d.chol.L, (size_t)n * d.chol.np * d.chol.np));
-    // tiles outside the structure are read as zeros by the back-substitution and never written
-    if (hipMemset(d.chol.L, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
-
+  {
+    // the one-launch-per-column factorisation (a few scenes, or the last few active scenes of a large batch) publishes its
+    // finished L tiles in a second matrix, indexed by launch slot: eight slots per scene group
+    const int groups = std::max(1, std::min(b->n_group_hint(n), n));
+    const size_t slots = (size_t)std::min(n, 8) * groups;
+    TRY(b->alloc(&d.chol.L, slots * d.chol.np * d.chol.np));
+    if (hipMemset(d.chol.L, 0, sizeof(double) * slots * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    TRY(b->alloc(&b->d_act, (size_t)n));
   }
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
   TRY(b->alloc(&d.chol.Dinv, (size_t)n * (d.chol.np / CHOL_NB) * 4 * 16 * 16));
@@ -1177,16 +1218,38 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     return PTZ_ENODEVICE;
   }
   // kernels that stage camera tables need > 64 KiB of dynamic LDS for large rigs
-  b->small_blocks = b->ray_block <= 256;
-  const size_t obs_lds = b->small_blocks ? (size_t)OBS_PREFETCH_BYTES * b->ray_block : 0;
-  b->eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 18) + obs_lds;
-  b->lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 6) + obs_lds;
   // Rigs whose camera tables do not fit in LDS (the 160 KiB hold ~340 cameras) read them from global memory instead: the
   // reference has no cap on the number of views (ptzray_optimizer.cc:799-885)
-  b->gtab = b->eval_smem > 160 * 1024;
+  b->gtab = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 18) + (size_t)OBS_PREFETCH_BYTES * 256 > 160 * 1024;
   if (const char* e = getenv("PTZ_BA_GLOBAL_TABLES")) b->gtab = atoi(e) != 0;
-  if (b->gtab) { b->eval_smem = sizeof(double) * 16 + obs_lds + 16; b->lin_smem = obs_lds + 16; }
-  const int eval_smem = (int)b->eval_smem, lin_smem = (int)b->lin_smem;
+  b->compaction = true;
+  if (const char* e = getenv("PTZ_BA_COMPACT")) b->compaction = atoi(e) != 0;
+  auto make_shape = [&](int slots, bool compact) {
+    PassShape sh;
+    sh.slots = slots; sh.compact = compact;
+    // rays per workgroup of the ray-centric kernels: one rig's ~13 k rays on 1024-ray workgroups keep 14 compute units busy,
+    // so a few scenes use small workgroups; large batches amortise the LDS camera tables over many rays (results do not
+    // depend on it: per-ray sums are reduced per wave of 64 rays)
+    sh.ray_block = slots <= 4 ? 128 : (slots <= 32 ? 256 : RAY_BLOCK);
+    if (const char* e = getenv("PTZ_BA_RAY_BLOCK")) sh.ray_block = std::min(RAY_BLOCK, std::max(64, (atoi(e) / 64) * 64));
+    sh.small_blocks = sh.ray_block <= 256;
+    sh.fused = slots <= 8;
+    if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) sh.fused = atoi(e) != 0 && slots <= 8;
+    sh.max_chunk = (b->max_ray + sh.ray_block - 1) / sh.ray_block;
+    const size_t obs_lds = sh.small_blocks ? (size_t)OBS_PREFETCH_BYTES * sh.ray_block : 0;
+    if (b->gtab) { sh.eval_smem = sizeof(double) * 16 + obs_lds + 16; sh.lin_smem = obs_lds + 16; }
+    else {
+      sh.eval_smem = sizeof(double) * ((size_t)b->max_cam * (CBS + CDS + (NC | 1)) + 16 + 18) + obs_lds;
+      sh.lin_smem = sizeof(double) * ((size_t)b->max_cam * CBS + 6) + obs_lds;
+    }
+    return sh;
+  };
+  b->shapes.clear();
+  b->shapes.push_back(make_shape(n, false));
+  for (int sl = 8; sl < n; sl *= 4) b->shapes.push_back(make_shape(sl, true));
+  b->ray_block = b->shapes[0].ray_block;
+  b->d.ray_block = b->ray_block;
+  const int eval_smem = (int)b->shapes[0].eval_smem, lin_smem = (int)b->shapes[0].lin_smem;
   // k_schur keeps a camera's T_a rows in LDS (up to ~1700 observations of one view); beyond that the table goes to global
   // memory.  What remains is the 16-bit position inside the camera-pair entry records: 65535 observations per view.
   if (b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
@@ -1337,7 +1400,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
   if (!b || !b->has_state) return PTZ_EINVAL;
   clear_stale_error(__func__);
   PTZ_DEVICE_GUARD(b->device);
-  hipLaunchKernelGGL(k_pix2ray, dim3(b->max_chunk, b->n_scene), dim3(b->d.ray_block), 0, b->stream, b->d, b->cam0, b->ray0);
+  hipLaunchKernelGGL(k_pix2ray, dim3(b->shapes[0].max_chunk, b->n_scene), dim3(b->shapes[0].ray_block), 0, b->stream, b->d, b->cam0, b->ray0);
   PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
   PTZ_HIP_TRY(hipGetLastError());
   return PTZ_OK;

@@ -132,8 +132,14 @@ struct Dev {
   //   grp_ctl[1]  LM passes whose step-evaluation kernel has started (device memory)
   //   host_ctl[0] copy of grp_ctl[1] in pinned host memory (the host throttles its run-ahead on it)
   //   host_ctl[1] set to 1 by whoever retires the group's last scene (the host stops enqueuing passes when it sees it)
+  //   grp_ctl[2]  entries of the compacted scene list `act` (rebuilt by k_compact after every k_lm_pre); host_ctl[2] mirrors it
   int* grp_ctl;
   int* host_ctl;
+  // Compacted launches: once few scenes of a large batch are still active, the host enqueues passes whose grids cover only
+  // `slots` scenes; blockIdx.y (or .x for the one-workgroup-per-scene kernels) is then a slot and act[slot] the scene.  The
+  // host sizes those grids from a stale -- hence larger or equal -- count.  use_act = 0: slot == scene (full-size launches).
+  int* act;
+  int use_act;
   Opt opt;
   // reduced camera system
   CholBatch chol;
@@ -151,6 +157,12 @@ __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s
 
 __device__ __forceinline__ double* cur_camblk(const Dev& d, const LmState& st) { return d.camblk + (size_t)st.cur * d.camblk_stride; }
 __device__ __forceinline__ double* cur_tlwblk(const Dev& d, const LmState& st) { return d.tlwblk + (size_t)st.cur * d.tlwblk_stride; }
+
+__device__ __forceinline__ int scene_of_slot(const Dev& d, int slot)
+{
+  if (!d.use_act) return slot;
+  return slot < d.grp_ctl[2] ? d.act[slot] : -1;
+}
 
 // A scene leaves the pass pipeline (one thread of the scene's LM block calls this, once per scene and solve).
 __device__ __forceinline__ void retire_scene(const Dev& d, int sc)
@@ -302,10 +314,11 @@ template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 {
   constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  if (!d.active[sc] || !st.need_linearize || blockIdx.x >= s.n_chunk) return;
+  if (!d.active[sc] || !st.need_linearize || (int)(blockIdx.x * blockDim.x) >= s.n_ray) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const double* tab;
   float4* obsbuf;  // SMALL only
@@ -371,7 +384,8 @@ template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
@@ -478,7 +492,8 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
@@ -584,7 +599,8 @@ template <int TYPE>
 __global__ void k_group_diag(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   if (d.lm[sc].reuse_diagonal) return;
@@ -604,7 +620,8 @@ template <int TYPE>
 __global__ void k_group_grad(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
@@ -630,7 +647,8 @@ template <int TYPE>
 __global__ __launch_bounds__(1024) void k_fold_system(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   if (s.n_grp == 0) return;
@@ -690,7 +708,8 @@ template <int TYPE>
 __global__ void k_group_expand(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
@@ -709,7 +728,8 @@ template <int TYPE>
 __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
@@ -792,7 +812,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
 {
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -902,9 +923,10 @@ __global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
   constexpr int NU = NW * (NW + 1) / 2;
   constexpr int NT = NW * 3;
   constexpr int TS = NT;  // row stride of the T table in LDS (an odd stride was measured: 25 % slower, it breaks the 16-byte reads of phase 2)
-  int ci, sc;
-  xcd_remap(ci, sc);
-  if (!d.active[sc]) return;
+  int ci, slot;
+  xcd_remap(ci, slot);
+  const int sc = scene_of_slot(d, slot);
+  if (sc < 0 || !d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   if (ci >= s.n_cam) return;
   const LmState& st = d.lm[sc];
@@ -1079,7 +1101,8 @@ __global__ __launch_bounds__(64) void k_schur_3d(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -1111,7 +1134,8 @@ template <int TYPE>
 __global__ void k_cam_update(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
@@ -1201,11 +1225,12 @@ template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
-  const int sc = blockIdx.y;
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  if (blockIdx.x >= s.n_chunk) return;
+  if ((int)(blockIdx.x * blockDim.x) >= s.n_ray) return;
   EV_STAMP_DECL;
   EV_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1311,7 +1336,8 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
-  const int sc = blockIdx.x;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0) return;
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   __shared__ double scratch[16];
@@ -1345,10 +1371,10 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
 {
-  const int sc = blockIdx.x;
-  if (sc == 0 && threadIdx.x == 0)  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
+  if (blockIdx.x == 0 && threadIdx.x == 0)  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
     __hip_atomic_store(&d.host_ctl[0], ++d.grp_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (!d.active[sc]) return;
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0 || !d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
   __shared__ double scratch[16];
@@ -1445,7 +1471,37 @@ __global__ void k_reset(Dev d)
 // control words of one scene group (see Dev::grp_ctl); the host zeroes its pinned mirror itself before it enqueues anything
 __global__ void k_ctl_reset(Dev d)
 {
-  if (threadIdx.x == 0) { d.grp_ctl[0] = d.n_scene; d.grp_ctl[1] = 0; }
+  if (threadIdx.x == 0) { d.grp_ctl[0] = d.n_scene; d.grp_ctl[1] = 0; d.grp_ctl[2] = d.n_scene; }
+  for (int i = threadIdx.x; i < d.n_scene; i += blockDim.x) d.act[i] = i;
+}
+
+// The list of scenes still active, in scene order (one workgroup per scene group, after every k_lm_pre): what compacted
+// launches index.  The count goes to the host as well, which sizes the grids of later passes from it.
+__global__ __launch_bounds__(1024) void k_compact(Dev d)
+{
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < d.n_scene; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool on = i < d.n_scene && d.active[i] != 0;
+    const unsigned long long m = __ballot(on);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    if (on) d.act[off + before] = i;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base_s += t; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    d.grp_ctl[2] = base_s;
+    __hip_atomic_store(&d.host_ctl[2], base_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 __global__ void k_fill(double* p, size_t n, double v)
 {

@@ -65,8 +65,8 @@ __device__ __forceinline__ void tile_s2g(const double* s, double* __restrict__ g
 // ---- clear the tiles of the lower-triangular structure ------------------------------------------------
 __global__ __launch_bounds__(256) void chol_clear_tiles_kernel(CholBatch cb)
 {
-  const int sys = blockIdx.y;
-  if (cb.active && !cb.active[sys]) return;
+  const int slot = blockIdx.y, sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
   if (tj > ti || !cb.tmask[((size_t)sys * nt + ti) * nt + tj]) return;
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void chol_clear_tiles_kernel(CholBatch cb)
 // ---- padding: identity rows beyond n, CHOL_BIG at (n, n) --------------------------------------------
 __global__ void chol_pad_kernel(CholBatch cb)
 {
-  const int sys = blockIdx.y;
-  if (cb.active && !cb.active[sys]) return;
+  const int slot = blockIdx.y, sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = cb.n[sys];
   if (i >= cb.np || i < n) return;
@@ -299,8 +299,8 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
 {
-  const int sys = blockIdx.y;
-  if (cb.active && !cb.active[sys]) return;
+  const int slot = blockIdx.y, sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np;
   const int n = cb.n[sys];
   if (k * NB > n) return;  // whole block column is padding (identity)
@@ -320,9 +320,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
 // wave-private LDS strip, so the four waves never synchronise after the initial load.
 __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const double* __restrict__ Dinv, int k)
 {
-  int bx, sys;
-  xcd_remap(bx, sys);
-  if (cb.active && !cb.active[sys]) return;
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   const int ti = k + 1 + bx;
@@ -387,9 +388,10 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
 // depends on; mode 2: the rest (j >= k+2).  Modes 1 + 2 together equal mode 0 (one-step look-ahead split).
 __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int mode, int fuse_diag)
 {
-  int bx, sys;
-  xcd_remap(bx, sys);
-  if (cb.active && !cb.active[sys]) return;
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   // linear index -> (i, j), k < j <= i < nt (row-major over the lower triangle of the trailing block)
@@ -515,9 +517,10 @@ __device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, 
 
 __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
 {
-  int bx, sys;
-  xcd_remap(bx, sys);
-  if (cb.active && !cb.active[sys]) return;
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   const int m = nt - k - 1;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
     for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
     __syncthreads();
     double* Tik = A + (size_t)(ti * NB + 16 * w) * np + k * NB;
-    double* Lik = cb.L + (size_t)sys * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
+    double* Lik = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
     trsm_rows_to_lds(Tik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
     if (ti != tj) {
       trsm_rows_to_lds(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np, Lk, Di, Bs + 16 * w * LD, nullptr);
@@ -612,9 +615,10 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
 // update launches.  Same arithmetic per (i, j, k) triple as chol_syrk_kernel; the k order is ascending.
 __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int j, int fuse_diag)
 {
-  int bx, sys;
-  xcd_remap(bx, sys);
-  if (cb.active && !cb.active[sys]) return;
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
   const int ti = j + bx;
@@ -673,8 +677,8 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
 //      computes them in a spare workgroup of every launch) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
 {
-  const int sys = blockIdx.y, k = blockIdx.x;
-  if (cb.active && !cb.active[sys]) return;
+  const int slot = blockIdx.y, k = blockIdx.x, sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int nt = cb.np / NB;
   if (k * NB > cb.n[sys]) return;
   __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
@@ -736,11 +740,11 @@ __device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red
 template <bool LIST>
 __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb, double* xout, int max_groups)
 {
-  const int sys = blockIdx.y;
-  if (cb.active && !cb.active[sys]) return;
+  const int slot = blockIdx.y, sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const double* Lm = (cb.L ? cb.L : cb.A) + (size_t)sys * np * np;
+  const double* Lm = cb.L ? cb.L + (size_t)slot * np * np : cb.A + (size_t)sys * np * np;  // off-diagonal tiles of L
   const double* Li = cb.Linv + (size_t)sys * nt * (NB * NB);
   const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
   extern __shared__ __attribute__((aligned(16))) double smem[];

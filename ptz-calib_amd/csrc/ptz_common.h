@@ -166,6 +166,10 @@ struct CholBatch {
   // by the one-launch-per-column path beside the critical chain (a spare workgroup of the next launch); with them the
   // back-substitution is two matrix-vector products per block column instead of a blocked triangular solve.
   double* Linv = nullptr;
+  // Compacted launches (thin LM passes of a large batch): blockIdx.y is a SLOT, act[slot] the system it stands for, *act_n the
+  // number of slots in use.  nullptr: slot == system.  The second matrix L of the one-launch-per-column path is indexed by slot.
+  const int* act = nullptr;
+  const int* act_n = nullptr;
   double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
   double* Dinv = nullptr;   // device [count][np/NB][4][16*16]: inverses of the 16x16 diagonal blocks of L_kk
   const int* n = nullptr;   // device [count]
@@ -177,6 +181,11 @@ struct CholBatch {
   // the tile-granular counterpart of the sparse Cholesky behind the reference's SPARSE_SCHUR (ptzray_optimizer.cc:471).
   const unsigned char* tmask = nullptr;
 };
+__device__ __forceinline__ int chol_system_of(const CholBatch& cb, int slot)
+{
+  if (!cb.act) return slot;
+  return slot < *cb.act_n ? cb.act[slot] : -1;
+}
 inline int chol_padded_order(int n_max) { return ((n_max + 1 + CHOL_NB - 1) / CHOL_NB) * CHOL_NB; }
 // enqueue factorisation + solve on `stream`; x: device [count][np]
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream);
