@@ -5,7 +5,8 @@ import csv, glob, os, sys, collections, json
 
 def short(name):
     for key in ("k_schur", "k_lin_ray", "k_lin_cam", "k_eval", "k_ray_prep", "k_cam_prep", "k_cam_update", "k_cam_diag", "k_lm_pre", "k_lm_post",
-                "chol_update_col", "chol_clear_tiles", "chol_syrk", "chol_trsm", "chol_diag", "chol_backsolve", "chol_pad", "k_krt", "k_reset", "k_fill", "k_jacobi", "fillBuffer"):
+                "chol_update_col", "chol_col_step", "chol_tile_inverse", "chol_clear_tiles", "chol_syrk", "chol_trsm", "chol_diag", "chol_backsolve", "chol_pad", "k_krt", "k_reset",
+                "k_fill", "k_jacobi", "k_compact", "k_ctl_reset", "fillBuffer", "pat_stream16", "pat_stream8", "pat_stream4", "pat_rows96", "pat_gather96", "pat_gather64"):
         if key in name:
             return key
     return name[:40]
