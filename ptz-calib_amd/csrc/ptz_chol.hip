@@ -608,6 +608,22 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// this thread's pieces of a 64 x 64 tile (row stride ld) into registers, all loads in flight together (256 threads).  The
+// buffer is ONE vector value (not an array): it is carried around the loop back-edge, and hipcc keeps arrays that are in scratch.
+typedef double d16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ d16 tile_fetch(const double* __restrict__ g, int ld)
+{
+  d16 r;
+#pragma unroll
+  for (int p = 0; p < (NB * NB / 2) / 256; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    const double2 v = *reinterpret_cast<const double2*>(g + (size_t)row * ld + c2);
+    r[2 * p] = v.x; r[2 * p + 1] = v.y;
+  }
+  return r;
+}
+
 // ---- left-looking column update: A_ij -= sum_{k < j} L_ik L_jk^T for the tiles (i, j), i >= j, of block column j -------
 // One workgroup per tile: the C tile stays in the accumulators while the loop walks the block columns k < j whose tiles
 // L_ik and L_jk are both in the structure, so C is read and written once per column step instead of once per k (the
@@ -638,20 +654,37 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
     for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
   const double* ap = As + (16 * w + fr) * LD + fq;
   const double* bp = Bs + fr * LD + fq;
-  bool any = false;
-  for (int k = 0; k < j; ++k) {
-    if (tm && (!tm[ti * nt + k] || !tm[j * nt + k])) continue;  // uniform over the workgroup
-    any = true;
+  // The operand tiles of step k + 1 are fetched into registers while the matrix cores work on step k: a step then costs its 64
+  // MFMAs per wave plus one LDS hand-over, not a global-memory round trip on top (the loop used to: barrier, load, barrier, MFMA).
+  auto next_k = [&](int k) { while (k < j && tm && (!tm[ti * nt + k] || !tm[j * nt + k])) ++k; return k; };  // uniform over the workgroup
+  constexpr int NP = (NB * NB / 2) / 256;  // double2 pieces of one tile per thread
+  int k = next_k(0);
+  const bool any = k < j;
+  d16 ra = tile_fetch(A + (size_t)(ti * NB) * np + (any ? k : 0) * NB, np);
+  d16 rb = tile_fetch(A + (size_t)(j * NB) * np + (any ? k : 0) * NB, np);
+  while (k < j) {
     __syncthreads();  // the previous step's fragment reads are done
-    tile_g2s<256, true>(A + (size_t)(ti * NB) * np + k * NB, np, As);   // -L_ik
-    tile_g2s<256, false>(A + (size_t)(j * NB) * np + k * NB, np, Bs);   //  L_jk
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int idx = p * 256 + threadIdx.x;
+      const int row = idx >> 5, c2 = (idx & 31) * 2;
+      *reinterpret_cast<double2*>(As + row * LD + c2) = make_double2(-ra[2 * p], -ra[2 * p + 1]);   // -L_ik
+      *reinterpret_cast<double2*>(Bs + row * LD + c2) = make_double2(rb[2 * p], rb[2 * p + 1]);      //  L_jk
+    }
+    const int kn = next_k(k + 1);
     __syncthreads();
+    {  // the next step's tiles (after the last step the current ones again: the fetch stays unconditional)
+      const int kf = kn < j ? kn : k;
+      ra = tile_fetch(A + (size_t)(ti * NB) * np + kf * NB, np);
+      rb = tile_fetch(A + (size_t)(j * NB) * np + kf * NB, np);
+    }
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
       const double av = ap[4 * kk];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
     }
+    k = kn;
   }
   if (fuse_diag && ti == j) {
     // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
