@@ -44,7 +44,9 @@ extern "C" {
 #define PTZ_BA_PTZRay 0
 #define PTZ_BA_PTZRayDist 1
 #define PTZ_BA_PTZRayFxfyDist 2 /* fx, fy, k1 free (ptzray_optimizer.cc:136-191); camera block of 6 columns */
-#define PTZ_BA_PTZRayDistDisp 3 /* displacement block: PTZ_EUNSUPPORTED (restated in oracle/ only) */
+#define PTZ_BA_PTZRayDistDisp 3 /* fx, k1 free + ONE 3-parameter displacement block shared by every residual of the problem
+                                 * (ptzray_optimizer.cc:195-265, disp_param_ :655; with annotations Reproj2d3dDispFactor :334-396);
+                                 * closed-form Jacobians -- the reference's central differences are not reproduced, DESIGN.md section 7 */
 /* KRTOptimizer::FACTOR_TYPE { F, FDist, Fxfy, FxfyDist }  (krt_optimizer.h:110) */
 #define PTZ_KRT_F 0
 #define PTZ_KRT_FDist 1
@@ -147,6 +149,11 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
 int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries);
 /* Solution = parameters at the minimum-cost point, as Ceres writes back (any termination type). */
 int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double* tlw);
+/* PTZRayDistDisp only (else PTZ_EUNSUPPORTED): the displacement block of every problem, disp [3 * n]: (d0, d1, d2) of
+ * delta_z = d0 + d1 fx + d2 fx^2.  The initial value is zero (disp_param_ = {0, 0, 0}, ptzray_optimizer.cc:655) unless set;
+ * get returns the block at the minimum-cost point like ptz_ba_batch_get_state (the reference adds it to t_z, :693, :714). */
+int32_t ptz_ba_batch_set_disp(ptz_ba_batch* b, const double* disp);
+int32_t ptz_ba_batch_get_disp(ptz_ba_batch* b, double* disp);
 /* Device time of the last ptz_ba_batch_solve in milliseconds (HIP events on the batch's stream),
  * and, per kernel family, the accumulated device time and launch count when profiling was enabled
  * with ptz_ba_batch_set_profiling(b, 1) (serialises the stream between kernels and runs the batch as ONE scene group,
@@ -161,6 +168,9 @@ int32_t ptz_ba_batch_get_profile(const ptz_ba_batch* b, double* ms_per_slot, int
  * cam/ray/tlw are updated in place. */
 int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt,
                      ptz_lm_summary* summary);
+/* The same for PTZRayDistDisp: disp [3] initial value in (NULL: zeros), refined value out. */
+int32_t ptz_ba_solve_disp(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, double* disp,
+                          const ptz_lm_options* opt, ptz_lm_summary* summary);
 
 /* Kernel-level entry points used by the parity tests (one linearisation at the current state of
  * problem `index`; weighted by sqrt(track length), not Jacobi-scaled).  Host outputs, any may be NULL:

@@ -24,7 +24,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
-           "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth"]
+           "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp"]
 
 
 class PtzError(RuntimeError):
@@ -168,6 +168,16 @@ class BaBatch:
         tlw = None if tlws is None else np.ascontiguousarray(np.stack(tlws), dtype=np.float64)
         _check(lib().ptz_ba_batch_set_state(self.handle, _p(cam), _p(ray), _p(tlw)), "ptz_ba_batch_set_state")
 
+    def set_disp(self, disps):
+        """PTZRayDistDisp: the initial displacement block (d0, d1, d2) of every scene ([n, 3]; zeros unless set)."""
+        d = np.ascontiguousarray(np.asarray(disps, dtype=np.float64).reshape(self.n, 3))
+        _check(lib().ptz_ba_batch_set_disp(self.handle, _p(d)), "ptz_ba_batch_set_disp")
+
+    def get_disp(self):
+        d = np.zeros((self.n, 3))
+        _check(lib().ptz_ba_batch_get_disp(self.handle, _p(d)), "ptz_ba_batch_get_disp")
+        return d
+
     def pix2ray(self):
         _check(lib().ptz_ba_batch_pix2ray(self.handle), "ptz_ba_batch_pix2ray")
 
@@ -225,6 +235,22 @@ def ba_solve(scene, cam0=None, ray0=None, tlw0=None, return_tlw=False, **opt):
     s = LmSummary()
     _check(lib().ptz_ba_solve(C.byref(p), _p(cam), _p(ray), _p(tlw), C.byref(o), C.byref(s)), "ptz_ba_solve")
     return (cam, ray, s.as_dict(), tlw) if return_tlw else (cam, ray, s.as_dict())
+
+
+def ba_solve_disp(scene, cam0=None, ray0=None, tlw0=None, disp0=None, **opt):
+    """One-shot ptz_ba_solve_disp (PTZRayDistDisp).  Returns (cam, ray, summary dict, tlw, disp)."""
+    keep = []
+    p = _pack_problem(scene, keep)
+    cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
+    ray = np.array(scene.ray_init if ray0 is None else ray0, dtype=np.float64, order="C").copy()
+    if tlw0 is None:
+        tlw0 = getattr(scene, "tlw_init", None)
+    tlw = np.zeros(6) if tlw0 is None else np.array(tlw0, dtype=np.float64).copy()
+    disp = np.zeros(3) if disp0 is None else np.array(disp0, dtype=np.float64).copy()
+    o = default_options(**opt)
+    s = LmSummary()
+    _check(lib().ptz_ba_solve_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(disp), C.byref(o), C.byref(s)), "ptz_ba_solve_disp")
+    return cam, ray, s.as_dict(), tlw, disp
 
 
 def chol_solve_batch(A, rhs, device_id=0):

@@ -114,6 +114,7 @@ struct ptz_ba_batch {
   int* d_act = nullptr;                                 // compacted scene lists, n_scene ints (each group its own range)
   bool compaction = true;
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
+  double* dsp0 = nullptr;  // PTZRayDistDisp: initial displacement block, one copy per camera (zeros unless ptz_ba_batch_set_disp)
   int has3d = 0, total_o3 = 0;
   // Rays are renumbered inside the library, longest track first (see build_pairs): ray_perm[ray_off + j] = the caller's
   // scene-local index of internal ray j.  set_state / get_state / linearize translate.
@@ -385,6 +386,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   // x <- initial state, scales <- 1, LM state reset (whole batch, stream 0)
   PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, s0));
   PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, s0));
+  if (d.dsp_x) PTZ_HIP_TRY(hipMemcpyAsync(d.dsp_x, b->dsp0, sizeof(double) * d.dsp_stride, hipMemcpyDeviceToDevice, s0));
   LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
   LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
   LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
@@ -625,6 +627,7 @@ int32_t ptz_ba_cam_block_dim(int32_t factor_type)
   if (factor_type == PTZ_BA_PTZRay) return 4;
   if (factor_type == PTZ_BA_PTZRayDist) return 5;
   if (factor_type == PTZ_BA_PTZRayFxfyDist) return 6;
+  if (factor_type == PTZ_BA_PTZRayDistDisp) return 8;  // [f, k1, r1, r2, r3, d0, d1, d2]
   return PTZ_EUNSUPPORTED;
 }
 
@@ -828,7 +831,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (opt) o = *opt; else ptz_lm_options_default(&o);
   if (o.max_num_iterations <= 0) return PTZ_EINVAL;  // CheckValid, ptzray_optimizer.cc:521
   const int type = problems[0].factor_type;
-  if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist && type != PTZ_BA_PTZRayFxfyDist) return PTZ_EUNSUPPORTED;
+  if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist && type != PTZ_BA_PTZRayFxfyDist && type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
+  const bool disp = type == PTZ_BA_PTZRayDistDisp;
   int has3d = 0;
   // ---- validate + sizes (host only; no device touched before this passes)
   for (int i = 0; i < n; ++i) {
@@ -850,7 +854,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   PTZ_DEVICE_GUARD(o.device_id);
 
   // fy becomes a live column with annotation residuals; PTZRayFxfyDist has it anyway
-  const int NC = type == PTZ_BA_PTZRayFxfyDist ? 6 : ((type == PTZ_BA_PTZRay) ? 4 : 5) + has3d;
+  const int NC = type == PTZ_BA_PTZRayFxfyDist ? 6 : ((type == PTZ_BA_PTZRay) ? 4 : (disp ? 8 : 5)) + has3d;
+  const int CBS = disp ? CAMBLK_DISP + 1 : CAMBLK + 1, CDS = disp ? CAMBLK_DISP + 1 : CANDBLK + 1;  // Dims<TYPE>::CBS / CDS
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
@@ -869,6 +874,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<float2> h_o3uv;
   std::vector<int> h_o3cam;
   std::vector<int> h_grpptr, h_grpmem;
+  std::vector<unsigned char> h_grpcls;
   {
     size_t to = 0, tr = 0, tc = 0;
     for (int i = 0; i < n; ++i) { to += (size_t)problems[i].n_obs; tr += (size_t)problems[i].n_ray; tc += (size_t)problems[i].n_cam; }
@@ -991,11 +997,13 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       }
       for (int c = 0; c < p.n_cam; ++c) b->first_of_group.push_back(b->total_cam + first[c]);
       std::vector<char> counted(p.n_cam, 0);  // group (by first member) already has its counting camera
+      bool disp_counted = false;
       for (int c = 0; c < p.n_cam; ++c) {
         const int* camptr_s = h_camptr.data() + cam_base[i] + i;  // filled by build_pairs for this scene
         const bool has_res = camptr_s[c + 1] > camptr_s[c];
         unsigned char flag = 0;
         if (has_res && !counted[first[c]]) { flag = 1; counted[first[c]] = 1; }
+        if (disp && has_res && !disp_counted) { flag |= 2; disp_counted = true; }
         h_camflag.push_back(flag);
       }
       h_grpptr.push_back((int)h_grpmem.size());
@@ -1006,6 +1014,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         if (members < 2) continue;
         for (int m = c; m < p.n_cam; ++m) if (first[m] == c) h_grpmem.push_back(m);
         h_grpptr.push_back((int)h_grpmem.size());
+        h_grpcls.push_back(0);
+        ++s.n_grp;
+        any_shared = true;
+      }
+      if (disp) {  // the displacement block is one parameter of the whole problem: a group of all cameras, over the d slots
+        for (int m = 0; m < p.n_cam; ++m) h_grpmem.push_back(m);
+        h_grpptr.push_back((int)h_grpmem.size());
+        h_grpcls.push_back(1);
         ++s.n_grp;
         any_shared = true;
       }
@@ -1070,6 +1086,12 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.cam_x, 2 * d.cam_stride));
   TRY(b->alloc(&d.ray_x, 2 * d.ray_stride));
   TRY(b->alloc(&b->cam0, d.cam_stride));
+  if (disp) {
+    d.dsp_stride = (size_t)b->total_cam * 3;
+    TRY(b->alloc(&d.dsp_x, 2 * d.dsp_stride));
+    TRY(b->alloc(&b->dsp0, d.dsp_stride));
+    if (hipMemset(b->dsp0, 0, sizeof(double) * d.dsp_stride) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // :655
+  }
   TRY(b->alloc(&b->ray0, d.ray_stride));
   d.camblk_stride = ((size_t)b->total_cam * CBS + 2 + 1) & ~(size_t)1;
   TRY(b->alloc(&d.camblk, 2 * d.camblk_stride));
@@ -1091,9 +1113,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     TRY(upload(b, h_grpptr, &d.grp_ptr));
     TRY(upload(b, h_grpmem, &d.grp_mem));
     TRY(upload(b, h_camflag, &d.cam_flag));
+    if (disp) TRY(upload(b, h_grpcls, &d.grp_cls));
     TRY(b->alloc(&d.gfold, (size_t)b->total_cam * NC));
   }
-  TRY(b->alloc(&d.W, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
+  TRY(b->alloc(&d.W, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
   TRY(b->alloc(&d.rayrec, (size_t)b->total_ray * 8));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 4));
   TRY(b->alloc(&d.partial_lin, (size_t)b->total_chunk * 2));
@@ -1256,7 +1279,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   b->schur_tg = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC) > 160 * 1024;
   if (const char* e = getenv("PTZ_BA_SCHUR_GLOBAL_T")) b->schur_tg = atoi(e) != 0;
   if (b->schur_tg) {
-    const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * (type == PTZ_BA_PTZRayFxfyDist ? 18 : 15));
+    const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 15));
     if (rc2) { ptz_ba_batch_destroy(b); return rc2; }
     for (auto& dgp : b->dg) dgp.Tbuf = b->d.Tbuf;
   }
@@ -1284,7 +1307,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       raise_cap((const void*)k_eval<T, false, false>);      \
       raise_cap((const void*)k_lin_ray<T, true, false>);    \
       raise_cap((const void*)k_lin_ray<T, false, false>);
-      PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5)
+      PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5) PTZ_SET_ATTR(6) PTZ_SET_ATTR(7)
 #undef PTZ_SET_ATTR
       if (!attr_ok) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
       attr_done[o.device_id] = 1;
@@ -1333,13 +1356,15 @@ int32_t ptz_ba_batch_solve(ptz_ba_batch* b, ptz_lm_summary* summaries)
   if (!b || !b->has_state) return PTZ_EINVAL;
   clear_stale_error(__func__);
   PTZ_DEVICE_GUARD(b->device);
-  switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
+  switch (b->type + 4 * b->has3d) {  // Dims<TYPE>
     case 0: return solve_impl<0>(b, summaries);
     case 1: return solve_impl<1>(b, summaries);
     case 2: return solve_impl<2>(b, summaries);
     case 3: return solve_impl<3>(b, summaries);
     case 4: return solve_impl<4>(b, summaries);
-    default: return solve_impl<5>(b, summaries);
+    case 5: return solve_impl<5>(b, summaries);
+    case 6: return solve_impl<6>(b, summaries);
+    default: return solve_impl<7>(b, summaries);
   }
 }
 
@@ -1366,6 +1391,32 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
   if (tlw)
     for (int i = 0; i < b->n_scene; ++i)
       PTZ_HIP_TRY(hipMemcpy(tlw + 6 * (size_t)i, b->d.tlw_x + h[i].cur * b->d.tlw_stride + 6 * (size_t)i, sizeof(double) * 6, hipMemcpyDeviceToHost));
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_set_disp(ptz_ba_batch* b, const double* disp)
+{
+  if (!b || !disp) return PTZ_EINVAL;
+  if (b->type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
+  PTZ_DEVICE_GUARD(b->device);
+  std::vector<double> v((size_t)3 * b->total_cam);  // every camera carries a copy of its scene's block
+  for (const SceneDev& sd : b->scenes)
+    for (int c = 0; c < sd.n_cam; ++c)
+      for (int k = 0; k < 3; ++k) v[3 * ((size_t)sd.cam_off + c) + k] = disp[3 * (size_t)sd.idx + k];
+  PTZ_HIP_TRY(hipMemcpy(b->dsp0, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
+  return PTZ_OK;
+}
+
+int32_t ptz_ba_batch_get_disp(ptz_ba_batch* b, double* disp)
+{
+  if (!b || !disp) return PTZ_EINVAL;
+  if (b->type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
+  PTZ_DEVICE_GUARD(b->device);
+  std::vector<LmState> h(b->n_scene);
+  PTZ_HIP_TRY(hipMemcpy(h.data(), b->d.lm, sizeof(LmState) * b->n_scene, hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->n_scene; ++i)  // camera 0's copy (all copies of a scene are equal)
+    PTZ_HIP_TRY(hipMemcpy(disp + 3 * (size_t)i, b->d.dsp_x + h[i].cur * b->d.dsp_stride + 3 * (size_t)b->scenes[i].cam_off,
+                          sizeof(double) * 3, hipMemcpyDeviceToHost));
   return PTZ_OK;
 }
 
@@ -1422,13 +1473,16 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
   PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x + d.tlw_stride, b->tlw0, sizeof(double) * 6 * b->n_scene, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_fill, dim3((6 * b->n_scene + 255) / 256), dim3(256), 0, st, d.scale_t, (size_t)6 * b->n_scene, 1.0);
-  switch (b->type + 3 * b->has3d) {  // Dims<TYPE>
+  if (d.dsp_x) PTZ_HIP_TRY(hipMemcpyAsync(d.dsp_x, b->dsp0, sizeof(double) * d.dsp_stride, hipMemcpyDeviceToDevice, st));
+  switch (b->type + 4 * b->has3d) {  // Dims<TYPE>
     case 0: enqueue_linearize<0>(b); break;
     case 1: enqueue_linearize<1>(b); break;
     case 2: enqueue_linearize<2>(b); break;
     case 3: enqueue_linearize<3>(b); break;
     case 4: enqueue_linearize<4>(b); break;
-    default: enqueue_linearize<5>(b); break;
+    case 5: enqueue_linearize<5>(b); break;
+    case 6: enqueue_linearize<6>(b); break;
+    default: enqueue_linearize<7>(b); break;
   }
   PTZ_HIP_TRY(hipStreamSynchronize(st));
   PTZ_HIP_TRY(hipGetLastError());
@@ -1459,7 +1513,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     }
   }
   if (W) {  // rows are stored camera-major; return them in observation order
-    const int NW = b->type == PTZ_BA_PTZRayFxfyDist ? 6 : NC - b->has3d;  // W carries the 2D-2D columns only
+    const int NW = b->type == PTZ_BA_PTZRayFxfyDist ? 6 : NC - b->has3d;  // W carries the 2D-2D columns only (PTZRayDistDisp: 8)
     const int ws = (NW * 3 + 1) & ~1;        // Dims<TYPE>::WS
     std::vector<double> rows((size_t)s.n_obs * ws);
     std::vector<int> wp(s.n_obs);
@@ -1501,6 +1555,23 @@ int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* 
   ptz_ba_batch_destroy(b);
   if (dbg) fprintf(stderr, "[ptz_ba_solve] n_cam %d n_obs %lld: create %.2f set_state %.2f solve %.2f get_state %.2f destroy %.2f ms\n", p->n_cam,
                    (long long)p->n_obs, t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+  return rc;
+}
+
+int32_t ptz_ba_solve_disp(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, double* disp, const ptz_lm_options* opt,
+                          ptz_lm_summary* summary)
+{
+  if (!p || !cam || !ray) return PTZ_EINVAL;
+  if (p->factor_type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
+  ptz_ba_batch* b = nullptr;
+  int rc = ptz_ba_batch_create(1, p, opt, &b);
+  if (rc) return rc;
+  rc = ptz_ba_batch_set_state(b, cam, ray, tlw);
+  if (!rc && disp) rc = ptz_ba_batch_set_disp(b, disp);
+  if (!rc) rc = ptz_ba_batch_solve(b, summary);
+  if (!rc) rc = ptz_ba_batch_get_state(b, cam, ray, tlw);
+  if (!rc && disp) rc = ptz_ba_batch_get_disp(b, disp);
+  ptz_ba_batch_destroy(b);
   return rc;
 }
 

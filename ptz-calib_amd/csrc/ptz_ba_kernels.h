@@ -13,8 +13,8 @@ namespace {
 constexpr int RAY_BLOCK = 1024;  // most rays per workgroup in the ray-centric kernels (Dev::ray_block is the batch's actual value:
                                  // a few scenes use small workgroups so that one rig's 13 k rays spread over a hundred compute units)
 constexpr int EZS = 10;           // doubles per ray in the (E, z) record: 6 + 3, padded to a 16-byte multiple
-constexpr int CBS = CAMBLK + 1;    // LDS stride of a camera block (35 doubles: odd -> no same-field bank conflicts)
-constexpr int CDS = CANDBLK + 1;   // LDS stride of a candidate block (19)
+// LDS / global stride of a camera block and of a candidate block: Dims<TYPE>::CBS (35 doubles: odd -> no same-field bank
+// conflicts; 41 with the displacement block) and Dims<TYPE>::CDS (19; 41)
 // W row stride: see Dims<TYPE>::WS
 
 struct SceneDev {
@@ -75,6 +75,8 @@ struct Dev {
   size_t cam_stride, ray_stride;
   const double* cam_x0;
   const double* ray_x0;
+  double* dsp_x;  // [2][total_cam][3] PTZRayDistDisp: every camera's copy of its scene's displacement block (else nullptr)
+  size_t dsp_stride;
   // per-camera blocks
   double* camblk;    // [total_cam][CBS]   at x          (rows already carry the odd LDS pitch: a workgroup stages its scene's
   double* candblk;   // [total_cam][CDS]   at the candidate   table with a flat, 16-byte-per-lane copy)
@@ -121,7 +123,9 @@ struct Dev {
   int shared;            // 0 = no group anywhere in the batch: none of the group kernels is launched
   const int* grp_ptr;    // per scene n_grp + 1 offsets into grp_mem (global), at [scene.grp_off + scene.idx ...]
   const int* grp_mem;    // scene-local camera ids of a group, ascending; the LAST one is the representative
-  const unsigned char* cam_flag;  // [total_cam] bit 0: this camera's intrinsics block is counted in |x| (one per group)
+  const unsigned char* cam_flag;  // [total_cam] bit 0: this camera's intrinsics block is counted in |x| (one per group);
+                                  // bit 1: so is its copy of the displacement block (one camera per scene)
+  const unsigned char* grp_cls;   // [total groups] at scene.grp_off + g: which slots the group shares -- 0 intrinsics, 1 displacement
   double* gfold;         // [total_cam][NC] gradient with the shared slots folded onto the representative
   // LM
   LmState* lm;
@@ -172,34 +176,43 @@ __device__ __forceinline__ void retire_scene(const Dev& d, int sc)
     __hip_atomic_store(&d.host_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// TYPE = factor (0 PTZRay, 1 PTZRayDist, 2 PTZRayFxfyDist) + 3 * has3d.
-//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]; PTZRayFxfyDist [fx, fy, k1, r1, r2, r3]
+// TYPE = factor (0 PTZRay, 1 PTZRayDist, 2 PTZRayFxfyDist, 3 PTZRayDistDisp) + 4 * has3d.
+//   NW columns of a camera carry a non-zero 2D-2D Jacobian: [f, (k1), r1, r2, r3]; PTZRayFxfyDist [fx, fy, k1, r1, r2, r3];
+//   PTZRayDistDisp [f, k1, r1, r2, r3, d0, d1, d2] -- the last three are the camera's copy of the ONE displacement block of
+//   the problem (disp_param_, ptzray_optimizer.cc:655), made one parameter by a group of all cameras (see k_fold_system).
 //   NC free camera parameters: without annotations the same set (the reference's always-zero fy column of PTZRay /
 //   PTZRayDist is not materialised); with 2D-3D annotation residuals fy becomes live (Reproj2d3dFactor reads it,
-//   ptzray_optimizer.cc:273): [f, fy, (k1), r1, r2, r3], and the 6-dof T_l_w block joins the reduced system.
+//   ptzray_optimizer.cc:273): [f, fy, (k1), r1, r2, r3, (d0, d1, d2)], and the 6-dof T_l_w block joins the reduced system.
 template <int TYPE> struct Dims {
-  static constexpr int FACTOR = TYPE % 3, HAS3D = TYPE / 3;
+  static constexpr int FACTOR = TYPE % 4, HAS3D = TYPE / 4;
   static constexpr int FXFY = FACTOR == 2;  // fy is a 2D-2D column
+  static constexpr int DISP = FACTOR == 3;  // displacement block
   static constexpr int F3 = FACTOR ? 1 : 0;  // Reproj2d3dFactor variant: k1 free or not (same functor for Dist / FxfyDist)
-  static constexpr int NW = 4 + (FACTOR >= 1) + FXFY;
+  static constexpr int NW = 4 + (FACTOR >= 1) + FXFY + 3 * DISP;
   static constexpr int NC = NW + (HAS3D && !FXFY);
   static constexpr int NG = 6 * HAS3D;  // size of the global (tlw) block
+  static constexpr int RW = NW - 3 - 3 * DISP;  // first rotation column among the 2D-2D columns
+  static constexpr int RC = NC - 3 - 3 * DISP;  // ... among the NC free parameters
   // doubles per observation row of W = Jc^T Jr (NW x 3), rounded up to a 16-byte multiple: 12 (96 B) / 16 (128 B).
   // Measured on MI355X: unpadded 96-B rows beat 128-B-aligned rows (less write/stream traffic outweighs line straddling).
   static constexpr int WS = (NW * 3 + 1) & ~1;
+  static constexpr int CAMBLK = DISP ? ptz::CAMBLK_DISP : ptz::CAMBLK, CBS = CAMBLK + 1;
+  static constexpr int CANDBLK = DISP ? ptz::CAMBLK_DISP : ptz::CANDBLK, CDS = CANDBLK + 1;  // the displacement sits behind the scales
   // position of 2D-2D column k inside the NC block
   static __host__ __device__ constexpr int pos(int k) { return NC != NW ? (k == 0 ? 0 : k + 1) : k; }
-  // index of free parameter k of the NC block in the Camera 15-vector
+  // index of free parameter k of the NC block in the Camera 15-vector; 15, 16, 17 = the displacement block (Dev::dsp_x)
   static __host__ __device__ constexpr int at(int k)
   {
     // PTZRay: f r1 r2 r3 | PTZRayDist: f k1 r.. | +3D: f fy r.. | f fy k1 r.. | PTZRayFxfyDist (with or without 3D): fx fy k1 r..
+    // PTZRayDistDisp: f k1 r.. d.. | +3D: f fy k1 r.. d..
     constexpr int FYL = (NC != NW) || FXFY;  // fy occupies slot 1
-    return k == 0 ? 0 : (FYL && k == 1) ? 1 : (FACTOR && k == 1 + FYL) ? 10 : 4 + (k - (NC - 3));
+    return k == 0 ? 0 : (FYL && k == 1) ? 1 : (FACTOR && k == 1 + FYL) ? 10 : k < RC + 3 ? 4 + (k - RC) : 15 + (k - RC - 3);
   }
 };
 
-__device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl)
+__device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl, const double* dsp = nullptr)
 {
+  if (dsp) { cb[CB_D] = dsp[0]; cb[CB_D + 1] = dsp[1]; cb[CB_D + 2] = dsp[2]; }
   double R[9];
   rodrigues(c15 + 4, R);
 #pragma unroll
@@ -226,8 +239,9 @@ __global__ void k_cam_prep(Dev d)
   if (!d.active[sc] || !st.need_linearize) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n_cam) return;
-  double* cb = cur_camblk(d, st) + (size_t)(s.cam_off + i) * CBS;
-  fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true);
+  double* cb = cur_camblk(d, st) + (size_t)(s.cam_off + i) * Dims<TYPE>::CBS;
+  fill_camblk(cur_cam(d, s, st) + (size_t)i * 15, cb, true,
+              Dims<TYPE>::DISP ? d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)(s.cam_off + i) * 3 : nullptr);
 #pragma unroll
   for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)(s.cam_off + i) * NC + k];
   if (Dims<TYPE>::HAS3D && i == 0) {
@@ -313,6 +327,8 @@ constexpr int OBS_PREFETCH_BYTES = 8 * 16;  // per thread of a SMALL workgroup
 template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
@@ -383,6 +399,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
@@ -490,6 +508,8 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
   const int sc = scene_of_slot(d, blockIdx.x);
@@ -505,8 +525,8 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
     const double* cb = cur_camblk(d, st) + (size_t)(s.cam_off + ci) * CBS;
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
-    double res[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
-    reproj2d3d_eval<Dims<TYPE>::F3, true>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
+    double res[2], Jc[2][5 + Dims<TYPE>::F3 + 3 * Dims<TYPE>::DISP], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, true, Dims<TYPE>::DISP != 0>(cb, tb, xyz, uv.x, uv.y, res, Jc, Jt);
     for (int k = 0; k < NC; ++k) { d.Jc3[(size_t)go * 2 * NC + k] = Jc[0][k] * cb[CB_S + k]; d.Jc3[(size_t)go * 2 * NC + NC + k] = Jc[1][k] * cb[CB_S + k]; }
     for (int k = 0; k < 6; ++k) { d.Jt3[(size_t)go * 12 + k] = Jt[0][k] * stl[k]; d.Jt3[(size_t)go * 12 + 6 + k] = Jt[1][k] * stl[k]; }
     d.r3[(size_t)go * 2] = res[0]; d.r3[(size_t)go * 2 + 1] = res[1];
@@ -570,10 +590,15 @@ __global__ void k_jacobi_scale(Dev d)
 //   * gradient norm and |x| count the block once (k_group_grad, cam_flag in k_lm_pre / k_lm_post).
 // The representative is the LAST camera of the group, so that the dense rows the fold creates sit at the bottom of the
 // system and cause no extra fill above them.
-template <int TYPE> __device__ __forceinline__ bool is_intr_slot(int k)
+// cls 0: the intrinsics block of the group's cameras; cls 1: the displacement block (PTZRayDistDisp: one group of all cameras)
+template <int TYPE> __device__ __forceinline__ bool is_shared_slot(int k, int cls)
 {
   const int a = Dims<TYPE>::at(k);
-  return a < 4 || a >= 10;
+  return cls ? a >= 15 : (a < 4 || (a >= 10 && a < 15));
+}
+template <int TYPE> __device__ __forceinline__ int group_class(const Dev& d, const SceneDev& s, int g)
+{
+  return Dims<TYPE>::DISP ? (int)d.grp_cls[s.grp_off + g] : 0;
 }
 
 // thread = (group, slot): group-wide Jacobi scale from the summed squared column norms (members ascending)
@@ -585,7 +610,7 @@ __global__ void k_group_scale(Dev d)
   const SceneDev s = d.scene[sc];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = t / NC, k = t % NC;
-  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   double sum = 0;
   for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
@@ -606,7 +631,7 @@ __global__ void k_group_diag(Dev d)
   if (d.lm[sc].reuse_diagonal) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = t / NC, k = t % NC;
-  if (g >= s.n_grp || !is_intr_slot<TYPE>(k)) return;
+  if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   double sum = 0;
   for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
@@ -630,7 +655,7 @@ __global__ void k_group_grad(Dev d)
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
     const int g = t / NC, k = t % NC;
-    if (!is_intr_slot<TYPE>(k)) continue;
+    if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
     double sum = 0;
     for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
     for (int e = gp[g]; e < gp[g + 1]; ++e)
@@ -662,7 +687,7 @@ __global__ __launch_bounds__(1024) void k_fold_system(Dev d)
     const int e0 = gp[g], e1 = gp[g + 1];
     const int rep = d.grp_mem[e1 - 1];
     for (int k = 0; k < NC; ++k) {
-      if (!is_intr_slot<TYPE>(k)) continue;
+      if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
       for (int c = threadIdx.x; c <= n; c += blockDim.x) {
         double sum = 0;
         for (int e = e0; e < e1; ++e) sum += at(d.grp_mem[e] * NC + k, c);
@@ -716,7 +741,7 @@ __global__ void k_group_expand(Dev d)
   double* y = d.yc + (size_t)sc * d.chol.np;
   for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
     const int g = t / NC, k = t % NC;
-    if (!is_intr_slot<TYPE>(k)) continue;
+    if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
     const double yr = y[d.grp_mem[gp[g + 1] - 1] * NC + k];
     for (int e = gp[g]; e < gp[g + 1] - 1; ++e) y[d.grp_mem[e] * NC + k] = yr;
   }
@@ -749,6 +774,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
         const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
         for (int k = 0; k < 15; ++k)
           if (intr || (k >= 4 && k < 10)) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
+        if (Dims<TYPE>::DISP && (d.cam_flag[gi] & 2)) {  // the displacement block, once per scene
+          const double* dx = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)gi * 3;
+          xn += dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+        }
       }
     }
     for (int wv = tid; wv < s.n_wave; wv += LM_THREADS) {  // the rays' share, one entry per wave of k_lin_ray
@@ -917,7 +946,7 @@ constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
 // TG: a camera has more observations than the LDS table of T_a rows holds (~1700): the table lives in global memory instead
 // (d.Tbuf, camera-major like W; written and re-read by the same workgroup, so it stays in that compute unit's caches).
 template <int TYPE, bool TG>
-__global__ __launch_bounds__(SCHUR_THREADS, PTZ_SCHUR_WAVES) void k_schur(Dev d)
+__global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAVES) void k_schur(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
   constexpr int NU = NW * (NW + 1) / 2;
@@ -1133,6 +1162,8 @@ __global__ __launch_bounds__(64) void k_schur_3d(Dev d)
 template <int TYPE>
 __global__ void k_cam_update(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC;
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
@@ -1151,7 +1182,17 @@ __global__ void k_cam_update(Dev d)
   for (int k = 0; k < NC; ++k) {
     const double step = -y[k];
     d.dc[(size_t)gi * NC + k] = step;
-    c15[Dims<TYPE>::at(k)] += step * d.scale_c[(size_t)gi * NC + k];
+    if (Dims<TYPE>::at(k) < 15) c15[Dims<TYPE>::at(k) < 15 ? Dims<TYPE>::at(k) : 0] += step * d.scale_c[(size_t)gi * NC + k];
+  }
+  double dsp[3] = {0, 0, 0};
+  if (Dims<TYPE>::DISP) {  // the camera's copy of the displacement block (every copy takes the same step: k_group_expand)
+    const double* dx = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)gi * 3;
+    double* dxc = d.dsp_x + (size_t)(st.cur ^ 1) * d.dsp_stride + (size_t)gi * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dsp[k] = dx[k] + (-y[NC - 3 + k]) * d.scale_c[(size_t)gi * NC + NC - 3 + k];
+      dxc[k] = dsp[k];
+    }
   }
   double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
 #pragma unroll
@@ -1163,18 +1204,19 @@ __global__ void k_cam_update(Dev d)
 #pragma unroll
     for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * (-y[Dims<TYPE>::pos(k)]);
     double* dr = d.dct + (size_t)gi * DCS;
+    constexpr int RW = Dims<TYPE>::RW;  // [columns before the rotation, columns behind it | Jl v_rot]
 #pragma unroll
-    for (int k = 0; k < NW - 3; ++k) dr[k] = sv[k];
+    for (int k = 0; k < NW - 3; ++k) dr[k] = sv[k < RW ? k : k + 3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      dr[NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[NW - 3] + cbc[CB_JL + 3 * r + 1] * sv[NW - 2] + cbc[CB_JL + 3 * r + 2] * sv[NW - 1];
+      dr[NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[RW] + cbc[CB_JL + 3 * r + 1] * sv[RW + 1] + cbc[CB_JL + 3 * r + 2] * sv[RW + 2];
   }
   // the candidate's full camera block (rotation, SO(3) Jacobian, intrinsics, scales) goes to the other half of camblk: if the
   // step is accepted the linearisation kernels find it there; its first CANDBLK entries are what k_eval needs of it
   double cb[CAMBLK];
 #pragma unroll
   for (int k = CB_S; k < CAMBLK; ++k) cb[k] = 0.0;
-  fill_camblk(c15, cb, true);
+  fill_camblk(c15, cb, true, Dims<TYPE>::DISP ? dsp : nullptr);
 #pragma unroll
   for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)gi * NC + k];
   double* cfull = d.camblk + (size_t)(st.cur ^ 1) * d.camblk_stride + (size_t)gi * CBS;
@@ -1224,6 +1266,8 @@ __global__ void k_cam_update(Dev d)
 template <int TYPE, bool SMALL, bool GTAB>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
@@ -1334,6 +1378,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 {
+  constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
+  (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC;
   if (!Dims<TYPE>::HAS3D) return;
   const int sc = scene_of_slot(d, blockIdx.x);
@@ -1352,11 +1398,11 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
     for (int k = 0; k < 6; ++k) { const double st_ = d.dt[(size_t)s.idx * 6 + k]; m0 += q0[k] * st_; m1 += q0[6 + k] * st_; }
     mcc += m0 * (d.r3[(size_t)go * 2] + m0 / 2.0) + m1 * (d.r3[(size_t)go * 2 + 1] + m1 / 2.0);
     double cb[CAMBLK];
-    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CDS + k];
+    for (int k = 0; k < CANDBLK; ++k) cb[k] = d.candblk[(size_t)gi * CDS + k];  // (with the displacement block: the whole block)
     const float2 uv = d.o3_uv[go];
     const double xyz[3] = {d.o3_xyz[(size_t)go * 3], d.o3_xyz[(size_t)go * 3 + 1], d.o3_xyz[(size_t)go * 3 + 2]};
-    double rc[2], Jc[2][5 + Dims<TYPE>::F3], Jt[2][6];
-    reproj2d3d_eval<Dims<TYPE>::F3, false>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
+    double rc[2], Jc[2][5 + Dims<TYPE>::F3 + 3 * Dims<TYPE>::DISP], Jt[2][6];
+    reproj2d3d_eval<Dims<TYPE>::F3, false, Dims<TYPE>::DISP != 0>(cb, d.tlwcand + (size_t)s.idx * TLWBLK, xyz, uv.x, uv.y, rc, Jc, Jt);
     cost += 0.5 * (rc[0] * rc[0] + rc[1] * rc[1]);
   }
   mcc = block_sum(mcc, scratch);
@@ -1399,6 +1445,11 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
       const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
       dn += (a - b) * (a - b);
       cn += b * b;
+    }
+    if (Dims<TYPE>::DISP && (d.cam_flag[s.cam_off + i] & 2)) {
+      const double* da = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)(s.cam_off + i) * 3;
+      const double* db = d.dsp_x + (size_t)(st.cur ^ 1) * d.dsp_stride + (size_t)(s.cam_off + i) * 3;
+      for (int k = 0; k < 3; ++k) { dn += (da[k] - db[k]) * (da[k] - db[k]); cn += db[k] * db[k]; }
     }
   }
   if (Dims<TYPE>::HAS3D && tid == 0 && s.n_o3 > 0) {

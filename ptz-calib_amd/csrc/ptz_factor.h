@@ -34,8 +34,9 @@ namespace ptz {
 // [18..26] Jl (row-major)        left Jacobian of SO(3) at rvec: d(R X)/d r_k = Jl[:,k] x (R X)
 // [27..32] Jacobi column scales of the free camera parameters (NC <= 6 of them)
 constexpr int CAMBLK = 34;
+constexpr int CAMBLK_DISP = 40;  // PTZRayDistDisp: nine scale slots and the displacement block CB_D
 constexpr int CANDBLK = 18;
-constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13, CB_JL = 18, CB_S = 27;
+constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13, CB_JL = 18, CB_S = 27, CB_D = 36;  // CB_S: up to 9 Jacobi scales; CB_D: displacement block (3)
 
 constexpr double kDblEps = 2.220446049250313e-16;
 
@@ -144,7 +145,15 @@ PTZ_HD void brown_jac(double x, double y, const double* k, double B[4], double d
 // zero, so the column is not materialised.
 // TYPE 2 = PTZRayFxfyDist (ptzray_optimizer.cc:136-191): free [fx, fy, k1, r1, r2, r3] (NC = 6); the ray IS normalised (:161),
 // there is no behind-the-camera branch, fy is read (:167,185).
-template <int TYPE> struct BaDims { static constexpr int NC = (TYPE == 0) ? 4 : (TYPE == 1 ? 5 : 6); static constexpr int ROT0 = NC - 3; };  // TYPE = factor (0 / 1 / 2)
+// TYPE 3 = PTZRayDistDisp (ptzray_optimizer.cc:202-259): as PTZRayFxfyDist's geometry with fy := fx, plus a displacement of the
+// camera-frame point along z, delta = d0 + d1 fx + d2 fx^2, by ONE 3-parameter block shared by every residual (disp_param_,
+// :655).  Free [f, k1, r1, r2, r3, d0, d1, d2] (NC = 8); the three displacement columns are per-camera copies of the one block
+// (made one parameter by the group machinery of ptz_ba_kernels.h, as the oracle's cmap does).
+template <int TYPE> struct BaDims {
+  static constexpr int NC = (TYPE == 0) ? 4 : (TYPE == 1 ? 5 : (TYPE == 2 ? 6 : 8));
+  static constexpr int ROT0 = TYPE == 3 ? 2 : NC - 3;   // first rotation column
+  static constexpr int NI = NC - 3;                      // columns that are not rotations (the "intrinsic" components of a step)
+};  // TYPE = factor (0 / 1 / 2 / 3)
 
 // the point the functor feeds to the rotation: X / |X| for PTZRay / PTZRayFxfyDist, X itself for PTZRayDist; inv_n = 1 / |X| (or 1).
 // A ray-centric kernel computes it once per ray instead of once per observation (same operations, same bits).
@@ -178,7 +187,8 @@ PTZ_HD void ba_residual_unit(const double* cb, const double Xn[3], float u, floa
   }
   else {
     if (TYPE == 1 && Pz < 0) { res[0] = 1000000.0; res[1] = 1000000.0; return; }  // :97-102
-    const double x = Px / Pz, y = Py / Pz;
+    const double Pzd = TYPE == 3 ? Pz + (cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f) : Pz;  // :233-234
+    const double x = Px / Pzd, y = Py / Pzd;
     double xd, yd;
     brown(x, y, cb + CB_K, xd, yd);
     res[0] = (double)u - (f * xd + cx);
@@ -223,8 +233,11 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
     for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
     return;
   }
-  const double iz = 1.0 / Pz;
-  const double x = Px / Pz, y = Py / Pz;  // same arithmetic as the reference functor
+  // PTZRayDistDisp: the camera-frame point moves along z by delta(f) before the projection (:233-236)
+  const double delta = TYPE == 3 ? cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f : 0.0;
+  const double Pzd = TYPE == 3 ? Pz + delta : Pz;
+  const double iz = 1.0 / Pzd;
+  const double x = Px / Pzd, y = Py / Pzd;  // same arithmetic as the reference functor
   double xd = x, yd = y;
   double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (TYPE == 0) {
@@ -254,8 +267,16 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
       Jc[0][1] = -f * dk1[0];
       Jc[1][1] = -f * dk1[1];
     }
+    if (TYPE == 3) {  // P.z also moves with f; displacement block: dP.z / d(d0, d1, d2) = (1, f, f^2)
+      const double ddf = cb[CB_D + 1] + 2.0 * cb[CB_D + 2] * f;
+      Jc[0][0] -= M[0][2] * ddf;
+      Jc[1][0] -= M[1][2] * ddf;
+      const double pw[3] = {1.0, f, f * f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Jc[0][ROT0 + 3 + k] = -M[0][2] * pw[k]; Jc[1][ROT0 + 3 + k] = -M[1][2] * pw[k]; }
+    }
   }
-  // rotation: dP/dr_k = Jl[:,k] x P
+  // rotation: dP/dr_k = Jl[:,k] x P   (P = R X, before the displacement)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double ax = Jl[k], ay = Jl[3 + k], az = Jl[6 + k];
@@ -265,10 +286,11 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   }
   // ray: dP/dX = R (I - Xn Xn^T)/|X| for PTZRay / PTZRayFxfyDist; since M P = 0 (the projection is scale invariant)
   // the projector term vanishes identically: d res/dX = -(M R)/|X|.  PTZRayDist: dP/dX = R.
+  // PTZRayDistDisp: M (P + delta e_z) = 0, so M P = -delta M[:,2] and d res/dX = -(M R + delta M[:,2] Xn^T)/|X|.
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
-    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
+    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k] + (TYPE == 3 ? delta * M[0][2] * Xn[k] : 0.0)) * inv_n;
+    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k] + (TYPE == 3 ? delta * M[1][2] * Xn[k] : 0.0)) * inv_n;
   }
 }
 
@@ -291,8 +313,10 @@ PTZ_HD void ba_step_dir_unit(const double* cb, const double Xn[3], double inv_n,
     for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
     return;
   }
-  const double iz = 1.0 / Pz;
-  const double x = Px / Pz, y = Py / Pz;
+  const double delta = TYPE == 3 ? cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f : 0.0;
+  const double Pzd = TYPE == 3 ? Pz + delta : Pz;
+  const double iz = 1.0 / Pzd;
+  const double x = Px / Pzd, y = Py / Pzd;
   double xd = x, yd = y;
   double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (TYPE == 0) {
@@ -316,14 +340,20 @@ PTZ_HD void ba_step_dir_unit(const double* cb, const double Xn[3], double inv_n,
     p[0] = -xd * sv[0];
     p[1] = -yd * sv[0];
     if (TYPE != 0) { p[0] -= f * dk1[0] * sv[1]; p[1] -= f * dk1[1] * sv[1]; }
+    if (TYPE == 3) {  // sv = [f, k1, d0, d1, d2]: the z-displacement moves with f and with the displacement block
+      const double ddf = cb[CB_D + 1] + 2.0 * cb[CB_D + 2] * f;
+      const double dz_step = ddf * sv[0] + sv[2] + f * sv[3] + f * f * sv[4];
+      p[0] -= M[0][2] * dz_step;
+      p[1] -= M[1][2] * dz_step;
+    }
   }
   const double dx = om[1] * Pz - om[2] * Py, dy = om[2] * Px - om[0] * Pz, dz = om[0] * Py - om[1] * Px;
   p[0] -= M[0][0] * dx + M[0][1] * dy + M[0][2] * dz;
   p[1] -= M[1][0] * dx + M[1][1] * dy + M[1][2] * dz;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k]) * inv_n;
-    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k]) * inv_n;
+    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k] + (TYPE == 3 ? delta * M[0][2] * Xn[k] : 0.0)) * inv_n;
+    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k] + (TYPE == 3 ? delta * M[1][2] * Xn[k] : 0.0)) * inv_n;
   }
 }
 
@@ -342,9 +372,11 @@ PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, c
 // Free camera columns (NC3 = 5 + FACTOR): [fx, fy, (k1), r1, r2, r3]; tlw columns: [rho1..3, t1..3].
 // tl = {R_lw (9), Jl_lw (9), t_lw (3)}.
 constexpr int TLWBLK = 21;
-template <int FACTOR, bool JAC>
+// DISP: Reproj2d3dDispFactor (:335-396): the same with delta(fx) added to the camera-frame z; camera columns
+// [fx, fy, k1, r1, r2, r3, d0, d1, d2].
+template <int FACTOR, bool JAC, bool DISP = false>
 PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz[3], float u, float v, double res[2],
-                            double Jc[2][5 + FACTOR], double Jt[2][6])
+                            double Jc[2][5 + FACTOR + 3 * DISP], double Jt[2][6])
 {
   constexpr int ROT0 = 2 + FACTOR;
   const double* R = cb + CB_R;
@@ -357,7 +389,8 @@ PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz
   const double Px = R[0] * Xx + R[1] * Xy + R[2] * Xz;
   const double Py = R[3] * Xx + R[4] * Xy + R[5] * Xz;
   const double Pz = R[6] * Xx + R[7] * Xy + R[8] * Xz;
-  const double iz = 1.0 / Pz, x = Px / Pz, y = Py / Pz;
+  const double Pzd = DISP ? Pz + (cb[CB_D] + cb[CB_D + 1] * fx + cb[CB_D + 2] * fx * fx) : Pz;
+  const double iz = 1.0 / Pzd, x = Px / Pzd, y = Py / Pzd;
   double xd, yd;
   brown(x, y, cb + CB_K, xd, yd);
   res[0] = (double)u - (fx * xd + cx);
@@ -371,6 +404,13 @@ PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz
   Jc[0][0] = -xd; Jc[1][0] = 0;
   Jc[0][1] = 0;   Jc[1][1] = -yd;
   if (FACTOR) { Jc[0][2] = -fx * dk1[0]; Jc[1][2] = -fy * dk1[1]; }
+  if (DISP) {
+    const double ddf = cb[CB_D + 1] + 2.0 * cb[CB_D + 2] * fx;
+    Jc[0][0] -= M[0][2] * ddf;
+    Jc[1][0] -= M[1][2] * ddf;
+    const double pw[3] = {1.0, fx, fx * fx};
+    for (int k = 0; k < 3; ++k) { Jc[0][ROT0 + 3 + k] = -M[0][2] * pw[k]; Jc[1][ROT0 + 3 + k] = -M[1][2] * pw[k]; }
+  }
   const double* Jl = cb + CB_JL;
   const double* Jw = tl + 9;
 #pragma unroll

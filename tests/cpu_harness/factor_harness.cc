@@ -137,5 +137,51 @@ void h_reproj2d3d(int factor, const double* cam15, const double* tlw, const doub
   }
   for (int i = 0; i < 12; ++i) Jt[i] = (&jt[0][0])[i];
 }
+// PTZRayDistDisp: disp = (d0, d1, d2); Jc: [2][8] columns [f, k1, r1, r2, r3, d0, d1, d2]
+void h_ba_linearize_disp(const double* cam15, const double* disp, const double* ray, const float* uv, double* res, double* Jc, double* Jr)
+{
+  double cb[CAMBLK_DISP];
+  fill_camblk(cam15, cb);
+  for (int k = 0; k < 3; ++k) cb[CB_D + k] = disp[k];
+  double jc[2][8], jr[2][3];
+  ba_linearize<3>(cb, ray, uv[0], uv[1], res, jc, jr);
+  for (int i = 0; i < 16; ++i) Jc[i] = (&jc[0][0])[i];
+  for (int i = 0; i < 6; ++i) Jr[i] = (&jr[0][0])[i];
+}
+void h_ba_residual_disp(const double* cam15, const double* disp, const double* ray, const float* uv, double* res)
+{
+  double cb[CAMBLK_DISP];
+  fill_camblk(cam15, cb);
+  for (int k = 0; k < 3; ++k) cb[CB_D + k] = disp[k];
+  ba_residual<3>(cb, ray, uv[0], uv[1], res);
+}
+// v: step in the column order of h_ba_linearize_disp
+void h_ba_step_dir_disp(const double* cam15, const double* disp, const double* ray, const float* uv, const double* v, double* res, double* p, double* Jr)
+{
+  double cb[CAMBLK_DISP];
+  fill_camblk(cam15, cb);
+  for (int k = 0; k < 3; ++k) cb[CB_D + k] = disp[k];
+  const double* Jl = cb + CB_JL;
+  double om[3];
+  for (int r = 0; r < 3; ++r) om[r] = Jl[3 * r] * v[2] + Jl[3 * r + 1] * v[3] + Jl[3 * r + 2] * v[4];
+  const double sv[5] = {v[0], v[1], v[5], v[6], v[7]};  // the evaluation kernel's layout: [non-rotation columns | om]
+  double jr[2][3];
+  ba_step_dir<3>(cb, ray, uv[0], uv[1], sv, om, res, p, jr);
+  for (int i = 0; i < 6; ++i) Jr[i] = (&jr[0][0])[i];
+}
+// Reproj2d3dDispFactor: Jc [2][9] columns [fx, fy, k1, r1, r2, r3, d0, d1, d2]
+void h_reproj2d3d_disp(const double* cam15, const double* disp, const double* tlw, const double* xyz, const float* uv, double* res, double* Jc, double* Jt)
+{
+  double cb[CAMBLK_DISP], tl[TLWBLK];
+  fill_camblk(cam15, cb);
+  for (int k = 0; k < 3; ++k) cb[CB_D + k] = disp[k];
+  rodrigues(tlw, tl);
+  so3_left_jacobian(tlw, tl + 9);
+  tl[18] = tlw[3]; tl[19] = tlw[4]; tl[20] = tlw[5];
+  double jt[2][6], jc[2][9];
+  reproj2d3d_eval<1, true, true>(cb, tl, xyz, uv[0], uv[1], res, jc, jt);
+  for (int i = 0; i < 18; ++i) Jc[i] = (&jc[0][0])[i];
+  for (int i = 0; i < 12; ++i) Jt[i] = (&jt[0][0])[i];
+}
 int h_inv3(const double* A6, double* Ai6) { return inv3_spd(A6, Ai6) ? 1 : 0; }
 }

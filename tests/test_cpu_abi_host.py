@@ -151,6 +151,79 @@ def test_device_step_direction_equals_jacobian_times_step(harness, ftype):
         assert np.allclose(pd, Jc @ v, rtol=1e-12, atol=1e-12 * np.abs(Jc @ v).max())
 
 
+def test_device_displacement_math_matches_oracle(pkg, orc, harness):
+    """PTZRayDistDisp (ptzray_optimizer.cc:195-259) device math on the host: residuals bit-identical to the oracle's functor,
+    W = Jc^T Jr rows equal to the oracle's closed-form linearisation (columns [f, k1, r, d0, d1, d2]; the oracle also carries
+    the reference's always-zero fy column), step direction = Jc v."""
+    sc = pkg.synth.make_scene(2, 20, 100, factor_type=3)
+    cam = sc.cam_init.copy(); cam[:, 10] = 0.02
+    ray = sc.ray_init * 1.2
+    d = np.array([0.05, 2e-5, -1e-9])
+    lin = orc.ba_linearize(sc, cam, ray, jacobian_mode=orc.JAC_ANALYTIC, disp=d)
+    resd = orc.ba_residuals(sc, cam, ray, disp=d)
+    sel = [0, 2, 3, 4, 5, 6, 7, 8]
+    W = np.zeros((sc.n_obs, 8, 3)); cost = 0.0
+    rng = np.random.default_rng(3)
+    for a in range(sc.n_obs):
+        res = np.zeros(2); Jc = np.zeros((2, 8)); Jr = np.zeros((2, 3)); r2 = np.zeros(2)
+        c, x, uv = cam[sc.obs_cam[a]].copy(), ray[sc.obs_ray[a]].copy(), sc.obs_uv[a].copy()
+        harness.h_ba_linearize_disp(_p(c), _p(d), _p(x), _p(uv), _p(res), _p(Jc), _p(Jr))
+        harness.h_ba_residual_disp(_p(c), _p(d), _p(x), _p(uv), _p(r2))
+        assert np.array_equal(res, r2) and np.array_equal(res, resd[a])
+        w = sc.ray_weight[sc.obs_ray[a]]
+        W[a] = w * Jc.T @ Jr
+        cost += 0.5 * w * res @ res
+        if a % 17 == 0:
+            v = rng.normal(0, 1, 8) * np.array([10.0, 1e-2, 1e-3, 1e-3, 1e-3, 1e-2, 1e-5, 1e-9])
+            res3 = np.zeros(2); pd = np.zeros(2); Jr3 = np.zeros((2, 3))
+            harness.h_ba_step_dir_disp(_p(c), _p(d), _p(x), _p(uv), _p(v), _p(res3), _p(pd), _p(Jr3))
+            assert np.array_equal(res, res3) and np.array_equal(Jr, Jr3)
+            assert np.allclose(pd, Jc @ v, rtol=1e-12, atol=1e-12 * np.abs(Jc @ v).max())
+    assert abs(cost - lin["cost"]) / lin["cost"] < 1e-14
+    assert not lin["W"][:, 1, :].any()  # fy: not read by the 2D-2D functor
+    for k in range(8):  # per column: the displacement columns differ by twelve orders of magnitude
+        assert np.abs(W[:, k] - lin["W"][:, sel[k], :]).max() / np.abs(W[:, k]).max() < 1e-12, k
+
+
+def test_device_displacement_2d3d_math_matches_oracle(pkg, orc, harness):
+    """Reproj2d3dDispFactor (ptzray_optimizer.cc:334-396): residual equal to the oracle's functor; Jacobian against central
+    differences of that functor."""
+    rng = np.random.default_rng(11)
+    for _ in range(30):
+        cam = np.zeros(15); cam[0] = rng.uniform(1500, 3500); cam[1] = cam[0] * rng.uniform(0.97, 1.03); cam[2], cam[3] = 960, 540
+        cam[4:7] = rng.normal(0, 0.3, 3); cam[7:10] = rng.normal(0, 1, 3); cam[10] = rng.uniform(-0.05, 0.05)
+        tlw = np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 2, 3)])
+        R = np.zeros(9); Jl = np.zeros(9)
+        harness.h_rodrigues(_p(cam[4:7].copy()), _p(R), _p(Jl))
+        Rl = np.zeros(9); harness.h_rodrigues(_p(tlw[:3].copy()), _p(Rl), _p(Jl))
+        Pc = np.array([rng.uniform(-8, 8), rng.uniform(-5, 5), rng.uniform(40, 80)])
+        xyz = Rl.reshape(3, 3).T @ (R.reshape(3, 3).T @ Pc - tlw[3:])
+        uv = np.array([rng.uniform(100, 1800), rng.uniform(100, 1000)], dtype=np.float32)
+        d = np.array([rng.normal(0, 0.5), rng.normal(0, 1e-4), rng.normal(0, 1e-8)])
+        res = np.zeros(2); Jc = np.zeros((2, 9)); Jt = np.zeros((2, 6))
+        harness.h_reproj2d3d_disp(_p(cam), _p(d), _p(tlw), _p(xyz), _p(uv), _p(res), _p(Jc), _p(Jt))
+
+        def f(c, dd, t):
+            intr = np.concatenate([c[:4], c[10:15]]); out = np.zeros(2)
+            orc.lib().orc_res_reproj2d3d_disp(_p(intr), _p(np.ascontiguousarray(dd)), _p(np.ascontiguousarray(c[4:10])), _p(np.ascontiguousarray(t)), _p(uv), _p(xyz), _p(out))
+            return out.copy()
+        assert np.allclose(res, f(cam, d, tlw), rtol=0, atol=1e-9)
+        # central differences in the ambient parameters; rotations through the left Jacobian are checked by the solve tests,
+        # here: fx, fy, k1 and the displacement block, and the T_l_w translation
+        for col, (idx, h) in enumerate([(0, 1e-2), (1, 1e-2), (10, 1e-3)]):  # (the residual is linear in fy and k1)
+            cp, cm = cam.copy(), cam.copy(); cp[idx] += h; cm[idx] -= h
+            num = (f(cp, d, tlw) - f(cm, d, tlw)) / (2 * h)
+            assert np.allclose(Jc[:, col], num, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(num).max())), (col, Jc[:, col], num)
+        for k, h in enumerate([1e-4, 1e-7, 1e-11]):
+            dp, dm = d.copy(), d.copy(); dp[k] += h; dm[k] -= h
+            num = (f(cam, dp, tlw) - f(cam, dm, tlw)) / (2 * h)
+            assert np.allclose(Jc[:, 6 + k], num, rtol=1e-5, atol=1e-6 * np.abs(num).max()), (k, Jc[:, 6 + k], num)
+        for k in range(3):
+            tp, tm = tlw.copy(), tlw.copy(); tp[3 + k] += 1e-5; tm[3 + k] -= 1e-5
+            num = (f(cam, d, tp) - f(cam, d, tm)) / 2e-5
+            assert np.allclose(Jt[:, 3 + k], num, rtol=1e-6, atol=1e-6)
+
+
 def test_device_math_behind_camera_branch(harness):
     cam = np.zeros(15); cam[0] = cam[1] = 2000; cam[2], cam[3] = 960, 540
     res = np.zeros(2); Jc = np.ones((2, 5)); Jr = np.ones((2, 3))
