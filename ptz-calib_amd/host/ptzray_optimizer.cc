@@ -218,12 +218,14 @@ void PTZRayOptimizer::Pack()
 }
 
 // host-side Reproj2d3dFactor residual for the read-back statistics (CalReprojError2d3d, :1030-1072; functor :268-326)
-static void Residual2d3d(const double* c, const double* tlw, const double* Xw, float u, float v, double* res)
+// disp != nullptr: Reproj2d3dDispFactor (:334-396)
+static void Residual2d3d(const double* c, const double* tlw, const double* Xw, float u, float v, double* res, const double* disp = nullptr)
 {
   const Mat33 Rl = Rodrigues({tlw[0], tlw[1], tlw[2]});
   Vec3 Xl = Mul(Rl, Vec3{Xw[0], Xw[1], Xw[2]});
   Xl = {Xl[0] + tlw[3], Xl[1] + tlw[4], Xl[2] + tlw[5]};
-  const Vec3 P = Mul(Rodrigues({c[4], c[5], c[6]}), Xl);
+  Vec3 P = Mul(Rodrigues({c[4], c[5], c[6]}), Xl);
+  if (disp) P[2] += disp[0] + disp[1] * c[0] + disp[2] * c[0] * c[0];
   const double px = P[0] / P[2], py = P[1] / P[2];
   const double r2 = px * px + py * py, r4 = r2 * r2, r6 = r2 * r2 * r2;
   const double rad = 1.0 + c[10] * r2 + c[11] * r4 + c[12] * r6;
@@ -234,14 +236,16 @@ static void Residual2d3d(const double* c, const double* tlw, const double* Xw, f
 }
 
 // host-side evaluation of the 2D-2D residual for the read-back statistics (CalReprojError2d2d, :970-1028)
-static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, const double* X, float u, float v, double* res)
+static void Residual2d2d(FACTOR_TYPE type, const double* c, const Mat33& R, const double* X, float u, float v, double* res,
+                         const double* disp = nullptr)
 {
   Vec3 x = {X[0], X[1], X[2]};
   if (type != PTZRayDist) {  // PTZRay and PTZRayFxfyDist normalise the ray (:42, :161)
     const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     x = {x[0] / n, x[1] / n, x[2] / n};
   }
-  const Vec3 P = Mul(R, x);
+  Vec3 P = Mul(R, x);
+  if (type == PTZRayDistDisp) P[2] += disp[0] + disp[1] * c[0] + disp[2] * c[0] * c[0];  // :233-236
   if (type == PTZRay) {
     res[0] = static_cast<double>(u) - (c[0] * P[0] + c[2] * P[2]) / P[2];
     res[1] = static_cast<double>(v) - (c[0] * P[1] + c[3] * P[2]) / P[2];
@@ -271,7 +275,7 @@ void PTZRayOptimizer::ComputeErrors() const
   for (size_t a = 0; a < p.obs_cam.size(); ++a) {
     double res[2];
     Residual2d2d(type_, &cam[15 * static_cast<size_t>(p.obs_cam[a])], Rc[p.obs_cam[a]], &ray[3 * static_cast<size_t>(p.obs_ray[a])], p.obs_uv[2 * a],
-                 p.obs_uv[2 * a + 1], res);
+                 p.obs_uv[2 * a + 1], res, disp_.data());
     sum0 += res[0] * res[0];
     sum1 += res[1] * res[1];
   }
@@ -283,7 +287,8 @@ void PTZRayOptimizer::ComputeErrors() const
     double s0 = 0, s1 = 0;
     for (size_t a = 0; a < p.obs3d_cam.size(); ++a) {
       double res[2];
-      Residual2d3d(&cam[15 * static_cast<size_t>(p.obs3d_cam[a])], p.tlw.data(), &p.obs3d_xyz[3 * a], p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1], res);
+      Residual2d3d(&cam[15 * static_cast<size_t>(p.obs3d_cam[a])], p.tlw.data(), &p.obs3d_xyz[3 * a], p.obs3d_uv[2 * a], p.obs3d_uv[2 * a + 1], res,
+                   type_ == PTZRayDistDisp ? disp_.data() : nullptr);
       s0 += res[0] * res[0];
       s1 += res[1] * res[1];
     }
@@ -304,9 +309,7 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   if (!CheckValid()) return false;
   FindTracks();
   SetInitTransLocalToWorld();
-  // Device path limit (documented in DESIGN.md): the displacement factor type is not implemented -> behaves as a failed
-  // solve, never as a silent CPU solve.
-  if (type_ != PTZRay && type_ != PTZRayDist && type_ != PTZRayFxfyDist) return false;
+  if (type_ != PTZRay && type_ != PTZRayDist && type_ != PTZRayFxfyDist && type_ != PTZRayDistDisp) return false;
   Pack();
   PackedBA& p = packed_;
   if (p.obs_cam.empty() || p.ray_track.empty()) return false;
@@ -319,7 +322,7 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   prob.obs_cam = p.obs_cam.data();
   prob.obs_ray = p.obs_ray.data();
   prob.ray_weight = p.ray_weight.data();
-  prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : (type_ == PTZRayDist ? PTZ_BA_PTZRayDist : PTZ_BA_PTZRayFxfyDist);
+  prob.factor_type = (type_ == PTZRay) ? PTZ_BA_PTZRay : (type_ == PTZRayDist ? PTZ_BA_PTZRayDist : (type_ == PTZRayFxfyDist ? PTZ_BA_PTZRayFxfyDist : PTZ_BA_PTZRayDistDisp));
   // SetSharedIntrinsics: the intrinsics block id of every candidate camera (ptzray_optimizer.cc:643-650)
   p.ic_of_cam.clear();
   bool shared = false;
@@ -343,7 +346,9 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   tlw_init_ = p.tlw;
   for (int k = 0; k < 6; ++k) tlw[k] = p.tlw[k];
   const auto t_dev = std::chrono::steady_clock::now();
-  const int32_t rc = ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);
+  disp_ = {{0.0, 0.0, 0.0}};  // disp_param_ starts at zero (:655)
+  const int32_t rc = type_ == PTZRayDistDisp ? ptz_ba_solve_disp(&prob, cam.data(), ray.data(), tlw, disp_.data(), &opt, &summary_)
+                                             : ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);
   device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
   if (rc != PTZ_OK) {
     // not a convergence failure: the device path refused or could not run the problem.  Say so -- the reference's callers
@@ -376,6 +381,8 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
     // fy := fx for PTZRay / PTZRayDist, also after fy was a free parameter of the annotations (:705-706); PTZRayFxfyDist keeps
     // its own fy (:683-685)
     if (type_ != PTZRayFxfyDist) param[1] = param[0];
+    // the displacement block goes into t_z (:693, :714; zero for every other type)
+    param[9] += disp_[0] + disp_[1] * param[0] + disp_[2] * param[0] * param[0];
     Camera& out = cameras[p.cam_image[c]];
     out.FromVector(param);
     // local -> world: T_i_w = T_i_l T_l_w (:729-740)

@@ -61,6 +61,7 @@ class PTZRayOptimizer {
   const PackedBA& packed() const { return packed_; }
   const ptz_lm_summary& summary() const { return summary_; }
   const std::array<double, 6>& initial_tlw() const { return tlw_init_; }
+  const std::array<double, 3>& displacement() const { return disp_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
   double device_ms() const { return device_ms_; }  // wall time of the ptz_ba_solve call of the last Solve
   // The tracks depend on the match table only, not on the candidate set: a caller that solves many candidate subsets of
@@ -101,6 +102,7 @@ class PTZRayOptimizer {
   double device_ms_ = 0;
   PackedBA packed_;
   std::array<double, 6> tlw_init_{{0, 0, 0, 0, 0, 0}};
+  std::array<double, 3> disp_{{0, 0, 0}};  // disp_param_ (ptzray_optimizer.h: PTZRayDistDisp), refined by Solve
   ptz_lm_summary summary_{};
   double init_reproj_error_all_ = 0, final_reproj_error_all_ = 0;
   void ComputeErrors() const;  // unweighted 2D-2D / 2D-3D RMS of the solved state, on first use

@@ -54,11 +54,12 @@ def test_validation_precedes_device_and_no_cpu_fallback(pkg, scene_c1):
     with pytest.raises(api.PtzError) as e:
         api.BaBatch([bad])
     assert e.value.code == -1
-    dd = copy.copy(scene_c1); dd.factor_type = api.BA_PTZRayDistDisp
+    dd = copy.copy(scene_c1); dd.factor_type = 4  # not a PTZRayOptimizer::FACTOR_TYPE
     with pytest.raises(api.PtzError) as e:
         api.BaBatch([dd])
     assert e.value.code == -4  # PTZ_EUNSUPPORTED
     assert api.lib().ptz_ba_cam_block_dim(0) == 4 and api.lib().ptz_ba_cam_block_dim(1) == 5
+    assert api.lib().ptz_ba_cam_block_dim(2) == 6 and api.lib().ptz_ba_cam_block_dim(api.BA_PTZRayDistDisp) == 8
     if api.device_count() == 0:
         # no GPU: the product path must fail loudly, never compute on the CPU
         with pytest.raises(api.PtzError) as e:

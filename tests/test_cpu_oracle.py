@@ -194,7 +194,7 @@ def test_analytic_vs_numeric_jacobian(pkg, orc, ftype):
 
 
 def test_displacement_variant_restatement(pkg, orc):
-    """PTZRayDistDisp (ptzray_optimizer.cc:195-259, 334-396; dead from the reference's tools, not on the device path):
+    """PTZRayDistDisp (ptzray_optimizer.cc:195-259, 334-396; dead from the reference's tools; on the device since round 2, tests/test_gpu_disp.py):
     at zero displacement the functor is PTZRayFxfyDist with fy := fx; the displacement enters the camera-frame z as
     d0 + d1 f + d2 f^2; closed-form and central-difference Jacobians agree, the displacement columns are the same parameter
     for every camera.  On the pure-rotation synthetic rigs the displacement is all but unobservable against the focal

@@ -134,3 +134,30 @@ def test_disp_entry_points_reject_other_types(pkg):
     with pytest.raises(pkg.api.PtzError):
         b.get_disp()
     b.close()
+
+
+def test_cpp_ptzray_optimizer_dist_disp(pkg, orc):
+    """PTZRayOptimizer with FACTOR_TYPE PTZRayDistDisp through the C++ class: the packed problem solved by the same device
+    path (identical summary to the C-ABI solve of the class's own packing), fy := fx and t_z += d0 + d1 fx + d2 fx^2 on
+    read-back (ptzray_optimizer.cc:693, :714), 2D-2D error from PTZRayDistDispFactor residuals (:1010-1013)."""
+    import host_util as hu
+    from types import SimpleNamespace
+    sc = pkg.synth.make_scene(5, 20, 100, factor_type=3)
+    kps, plist = hu.scene_to_features_matches(sc)
+    ok, cam, err, summ, pk = hu.ptzray_solve(kps, plist, sc.cam_init, max_iter=200, ftype=3)
+    assert ok and summ["termination_type"] == 0
+    base = dict(obs_uv=pk["obs_uv"], obs_cam=pk["obs_cam"], obs_ray=pk["obs_ray"], ray_weight=pk["ray_weight"], n_cam=sc.n_cam,
+                n_ray=len(pk["ray_weight"]), factor_type=3)
+    ns = SimpleNamespace(**base, cam_init=sc.cam_init, ray_init=orc.pix2ray(SimpleNamespace(**base), sc.cam_init))
+    cam2, ray2, summ2, _, disp2 = pkg.api.ba_solve_disp(ns)
+    # (the class initialises the rays itself; the oracle's Pix2Ray differs from it in the last bits)
+    assert summ2["num_iterations"] == summ["num_iterations"] and abs(summ2["final_cost"] - summ["final_cost"]) < 1e-8 * summ["final_cost"]
+    assert _rel(cam[:, 0], cam2[:, 0]) < 1e-7 and np.array_equal(cam[:, 1], cam[:, 0])
+    delta = disp2[0] + disp2[1] * cam2[:, 0] + disp2[2] * cam2[:, 0] ** 2
+    assert np.abs(delta).max() > 0 and np.allclose(cam[:, 9] - sc.cam_init[:, 9], delta, rtol=1e-5, atol=1e-9)
+    od = np.zeros(3)
+    ocam, oray, _, osumm, _ = orc.ba_solve(ns, jacobian_mode=orc.JAC_ANALYTIC, disp=od, num_threads=4)
+    assert summ["num_iterations"] == osumm["num_iterations"]
+    assert _rel(cam[:, 0], ocam[:, 0]) < 1e-6
+    res = orc.ba_residuals(ns, ocam, oray, disp=od)
+    assert abs(err[1] - np.sqrt((res ** 2).sum() / len(res))) < 1e-6
