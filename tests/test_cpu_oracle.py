@@ -199,7 +199,7 @@ def test_displacement_variant_restatement(pkg, orc):
     d0 + d1 f + d2 f^2; closed-form and central-difference Jacobians agree, the displacement columns are the same parameter
     for every camera.  On the pure-rotation synthetic rigs the displacement is all but unobservable against the focal
     lengths: the closed-form and the central-difference solves take visibly different paths to the same cost -- the reason
-    no device parity target exists for this variant."""
+    the device path is held to the closed-form mode for this variant."""
     intr = np.array([2100.0, 1700.0, 960, 540, 0.03, -0.01, 0.002, 0.001, -0.0005]); extr = np.array([0.02, -0.3, 0.01, 1, 2, 3.0])
     ray = np.array([0.2, -0.1, 1.3]); uv = np.array([1000.0, 500.0], dtype=np.float32)
     r0 = np.zeros(2); r1 = np.zeros(2)
