@@ -1055,17 +1055,31 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   }
   // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
   const int l = threadIdx.x & 15;
-  for (int pl = (threadIdx.x >> 4); pl < npr; pl += SCHUR_THREADS / 16) {
+  // The chain of a pair is header (entry range, first W row of cj, cj) -> entry records -> W_b rows: three dependent round
+  // trips before the first multiply, for about three trips of work.  So the NEXT pair's header is fetched while this pair
+  // is worked on, its first records as soon as this pair's last rows have been asked for, and inside a pair the records of
+  // the next trip ride with the rows of the current one: one exposed round trip per trip, none per pair.
+  const int* pbrow = d.pair_brow + s.pair_off + pr0;
+  const int* pcj = d.pair_cj + s.pair_off + pr0;
+  int pl = threadIdx.x >> 4;
+  int h_e0 = 0, h_e1 = 1, h_brow = 0, h_cj = 0;
+  unsigned ab0 = 0, ab1 = 0;
+  if (pl < npr) {
+    h_e0 = pps[pl]; h_e1 = pps[pl + 1]; h_brow = pbrow[pl]; h_cj = pcj[pl];
+    ab0 = ents[min(h_e0 + l, h_e1 - 1)]; ab1 = ents[min(h_e0 + l + 16, h_e1 - 1)];
+  }
+  for (; pl < npr; pl += SCHUR_THREADS / 16) {
     double acc[NW * NW];
 #pragma unroll
     for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
-    const int e1 = pps[pl + 1];
-    int e = pps[pl] + l;
-    const int brow = d.pair_brow[s.pair_off + pr0 + pl];
+    const int e1 = h_e1, brow = h_brow, cj = h_cj;
+    int e = h_e0 + l;
+    // header of the group's next pair (clamped: the last pair re-reads its own)
+    const int pn = min(pl + SCHUR_THREADS / 16, npr - 1);
+    const int n_e0 = pps[pn], n_e1 = pps[pn + 1], n_brow = pbrow[pn], n_cj = pcj[pn];
     // two entries per trip while both exist (both W_b rows in flight together), then at most one single entry
     for (; e + 16 < e1; e += 32) {
-      const unsigned ab0 = ents[e];
-      const unsigned ab1 = ents[e + 16];
+      const unsigned nx0 = ents[min(e + 32, e1 - 1)], nx1 = ents[min(e + 48, e1 - 1)];
       const double* Wb0 = d.W + (size_t)(brow + (int)(ab0 >> 16)) * Dims<TYPE>::WS;
       const double* Wb1 = d.W + (size_t)(brow + (int)(ab1 >> 16)) * Dims<TYPE>::WS;
       double wb0[NT], wb1[NT];
@@ -1082,9 +1096,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
           acc[p * NW + q] += (t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2]) +
                              (u0 * wb1[3 * q] + u1 * wb1[3 * q + 1] + u2 * wb1[3 * q + 2]);
       }
+      ab0 = nx0; ab1 = nx1;
     }
+    // first records of the next pair: on their way during the tail entry and the reduction below
+    const unsigned nab0 = ents[min(n_e0 + l, n_e1 - 1)], nab1 = ents[min(n_e0 + l + 16, n_e1 - 1)];
     if (e < e1) {
-      const unsigned ab0 = ents[e];
       const double* Wb0 = d.W + (size_t)(brow + (int)(ab0 >> 16)) * Dims<TYPE>::WS;
       double wb0[NT];
 #pragma unroll
@@ -1097,10 +1113,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
         for (int q = 0; q < NW; ++q) acc[p * NW + q] += t0 * wb0[3 * q] + t1 * wb0[3 * q + 1] + t2 * wb0[3 * q + 2];
       }
     }
+    h_e0 = n_e0; h_e1 = n_e1; h_brow = n_brow; h_cj = n_cj;
+    ab0 = nab0; ab1 = nab1;
     // reduce-scatter over the 16 lanes of the group: after the steps with masks 8, 4, 2, 1 lane l holds the complete
     // sum of block element l (fixed order); every lane then stores its own element.  Elements >= NW*NW (NW = 5 keeps
     // 25 values) take a second pass with the lanes that are left.
-    const int cj = d.pair_cj[s.pair_off + pr0 + pl];
     double* S = A + (size_t)(ci * NC) * np + cj * NC;
 #pragma unroll
     for (int base = 0; base < NW * NW; base += 16) {
