@@ -1008,49 +1008,39 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
 #pragma unroll
       for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
     }
-    __syncthreads();  // also orders the T / ents / pps stores before phase 2
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double t = 0;
-      for (int i = 0; i < SCHUR_THREADS / 64; ++i) t += strip[i * NV + k];
-      v[k] = t;
-    }
-#pragma unroll
-    for (int k = 0; k < NW; ++k) bsum[k] = v[k];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) D[k] = v[NW + k];
+    __syncthreads();  // also orders the T stores before phase 2
   }
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
-  if (threadIdx.x == 0) {
+  {
+    // Diagonal block and right-hand side, one element per thread (the last wave's, so that the first waves start on the camera
+    // pairs at once): S_ii = U_i (2D-2D + annotation terms) + D_i^2 - sum T W^T (the latter only on the NW x NW 2D-2D
+    // columns), b_i = g_i - sum W z.  Every thread adds up its own element's wave partials, in wave order.
+    constexpr int NV = NW + NU, NE = NC * (NC + 1) / 2;
+    const int t = (int)threadIdx.x - (SCHUR_THREADS - 64);
     const int gi = s.cam_off + ci;
-    double* row = A + (size_t)s.n * np;
-    // full NC x NC block: U (2D-2D + annotation terms) + D^2 - sum T W^T (the latter only on the NW x NW 2D-2D columns);
-    // assembled in registers, stored once (both triangles: the block stays symmetric)
-    double blk[NC * NC], rhs[NC];
-#pragma unroll
-    for (int p = 0; p < NC; ++p) {
-      rhs[p] = d.gc[(size_t)gi * NC + p];
-#pragma unroll
-      for (int qq = 0; qq <= p; ++qq) blk[p * NC + qq] = d.U[(size_t)gi * NC * NC + p * NC + qq];
-      const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
-      blk[p * NC + p] += Dd * Dd;
-    }
-    int e = 0;
-#pragma unroll
-    for (int p = 0; p < NW; ++p) {
-      rhs[Dims<TYPE>::pos(p)] -= bsum[p];
-#pragma unroll
-      for (int qq = 0; qq <= p; ++qq) blk[Dims<TYPE>::pos(p) * NC + Dims<TYPE>::pos(qq)] -= D[e++];
-    }
-#pragma unroll
-    for (int p = 0; p < NC; ++p) {
-      row[ci * NC + p] = rhs[p];
-#pragma unroll
-      for (int qq = 0; qq <= p; ++qq) {
-        A[(size_t)(ci * NC + p) * np + ci * NC + qq] = blk[p * NC + qq];
-        A[(size_t)(ci * NC + qq) * np + ci * NC + p] = blk[p * NC + qq];
+    auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };  // NC slot -> 2D-2D column
+    auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < SCHUR_THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
+    if (t >= 0 && t < NE) {
+      int p = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+      while ((p + 1) * (p + 2) / 2 <= t) ++p;
+      while (p * (p + 1) / 2 > t) --p;
+      const int qq = t - p * (p + 1) / 2;
+      double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
+      if (p == qq) {
+        const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+        v += Dd * Dd;
       }
+      const int ip = ipos(p), iq = ipos(qq);
+      if (ip >= 0 && iq >= 0) v -= strip_sum(NW + ip * (ip + 1) / 2 + iq);
+      A[(size_t)(ci * NC + p) * np + ci * NC + qq] = v;
+      A[(size_t)(ci * NC + qq) * np + ci * NC + p] = v;
+    }
+    else if (t >= NE && t < NE + NC) {
+      const int p = t - NE, ip = ipos(p);
+      double v = d.gc[(size_t)gi * NC + p];
+      if (ip >= 0) v -= strip_sum(ip);
+      A[(size_t)s.n * np + ci * NC + p] = v;
     }
   }
   // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
