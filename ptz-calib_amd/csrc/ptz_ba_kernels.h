@@ -532,30 +532,42 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
     d.r3[(size_t)go * 2] = res[0]; d.r3[(size_t)go * 2 + 1] = res[1];
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  double Ut[36], gt[6];
-  for (int k = 0; k < 36; ++k) Ut[k] = 0;
-  for (int k = 0; k < 6; ++k) gt[k] = 0;
-  for (int o = 0; o < s.n_o3; ++o) {
-    const int go = s.o3_off + o;
-    const int gi = s.cam_off + d.o3_cam[go];
-    const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
-    const double* j1 = j0 + NC;
-    const double* q0 = d.Jt3 + (size_t)go * 12;
-    const double* q1 = q0 + 6;
-    const double r0 = d.r3[(size_t)go * 2], r1 = d.r3[(size_t)go * 2 + 1];
-    d.costc[gi] += 0.5 * (r0 * r0 + r1 * r1);
-    for (int k = 0; k < NC; ++k) {
-      d.gc[(size_t)gi * NC + k] += j0[k] * r0 + j1[k] * r1;
-      for (int l = 0; l < NC; ++l) d.U[(size_t)gi * NC * NC + k * NC + l] += j0[k] * j0[l] + j1[k] * j1[l];
+  // Accumulation, one ELEMENT per thread, every element summed over the annotations in their order (the order the single
+  // accumulating thread of the first version used: same bits).  Threads 0..41: the T_l_w block and gradient; then one thread
+  // per (camera, entry of its U block / gradient / cost): a camera's annotations are the ones that carry its id.
+  const int t = threadIdx.x;
+  if (t < 42) {
+    const int k = t < 36 ? t / 6 : t - 36, l = t % 6;
+    double acc = 0;
+    for (int o = 0; o < s.n_o3; ++o) {
+      const int go = s.o3_off + o;
+      const double* q0 = d.Jt3 + (size_t)go * 12;
+      const double* q1 = q0 + 6;
+      if (t < 36) acc += q0[k] * q0[l] + q1[k] * q1[l];
+      else acc += q0[k] * d.r3[(size_t)go * 2] + q1[k] * d.r3[(size_t)go * 2 + 1];
     }
-    for (int k = 0; k < 6; ++k) {
-      gt[k] += q0[k] * r0 + q1[k] * r1;
-      for (int l = 0; l < 6; ++l) Ut[k * 6 + l] += q0[k] * q0[l] + q1[k] * q1[l];
-    }
+    if (t < 36) d.Ut[(size_t)s.idx * 36 + t] = acc; else d.gt[(size_t)s.idx * 6 + k] = acc;
   }
-  for (int k = 0; k < 36; ++k) d.Ut[(size_t)s.idx * 36 + k] = Ut[k];
-  for (int k = 0; k < 6; ++k) d.gt[(size_t)s.idx * 6 + k] = gt[k];
+  constexpr int PER = NC * NC + NC + 1;  // elements per camera: U, g, cost
+  for (int w = t; w < s.n_cam * PER; w += 256) {
+    const int ci = w / PER, el = w % PER;
+    const int gi = s.cam_off + ci;
+    double* dst = el < NC * NC ? d.U + (size_t)gi * NC * NC + el : (el < NC * NC + NC ? d.gc + (size_t)gi * NC + (el - NC * NC) : d.costc + gi);
+    double acc = *dst;
+    bool any = false;
+    for (int o = 0; o < s.n_o3; ++o) {
+      const int go = s.o3_off + o;
+      if (d.o3_cam[go] != ci) continue;
+      any = true;
+      const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
+      const double* j1 = j0 + NC;
+      const double r0 = d.r3[(size_t)go * 2], r1 = d.r3[(size_t)go * 2 + 1];
+      if (el < NC * NC) acc += j0[el / NC] * j0[el % NC] + j1[el / NC] * j1[el % NC];
+      else if (el < NC * NC + NC) acc += j0[el - NC * NC] * r0 + j1[el - NC * NC] * r1;
+      else acc += 0.5 * (r0 * r0 + r1 * r1);
+    }
+    if (any) *dst = acc;
+  }
 }
 
 // ---- Jacobi scaling (Ceres: s_j = 1 / (1 + |J_:j|), computed once at iteration 0) -----------------------
