@@ -114,6 +114,7 @@ struct ptz_ba_batch {
   int* d_act = nullptr;                                 // compacted scene lists, n_scene ints (each group its own range)
   bool compaction = true;
   double *cam0 = nullptr, *ray0 = nullptr, *tlw0 = nullptr;  // device copies of the initial state
+  std::vector<int> sched_kmin;  // CholBatch::sched_kmin
   double* dsp0 = nullptr;  // PTZRayDistDisp: initial displacement block, one copy per camera (zeros unless ptz_ba_batch_set_disp)
   int has3d = 0, total_o3 = 0;
   // Rays are renumbered inside the library, longest track first (see build_pairs): ray_perm[ray_off + j] = the caller's
@@ -170,10 +171,70 @@ struct ptz_ba_batch {
 namespace {
 
 // dynamic LDS of k_schur: T table, scratch, staged entries, pair offsets, reduction strip
-inline size_t schur_lds_bytes(int max_obs, int max_ent, int max_pair, int NC)
+// Elimination order of a reduced camera system at tile granularity.  m0: lower-triangular tile adjacency (nt x nt, natural
+// order, not closed under fill); tiles >= first_dense (T_l_w block, rhs row, padding) stay last, in place.  Looks for a
+// separator made of a prefix [0, w1) and an interval [m, m + w2) of the free tiles -- the two cuts of a ring whose images are
+// numbered along it, or the middle cut of a band -- such that the rest falls apart; the parts are dealt to two lanes that are
+// factored side by side (CholBatch::sched), the separator follows.  The dependent chain of the factorisation is then
+// max(lane) + separator + tail block columns instead of nt.  Returns false (natural order) unless that saves two or more.
+// perm[t] = position of natural tile t; lanes occupy positions [0, lane_a) and [lane_a, lane_a + lane_b), lane_a >= lane_b.
+inline bool plan_dissection(int nt, int first_dense, const unsigned char* m0, int* perm, int* lane_a, int* lane_b)
+{
+  const int nf = std::min(first_dense, nt);
+  if (nf < 6) return false;
+  auto adj = [&](int a, int e) { return a == e ? false : (a > e ? m0[a * nt + e] : m0[e * nt + a]) != 0; };
+  int best_cost = nt - 1;  // must beat nt - 2 + ... : accept only cost <= nt - 2
+  std::vector<int> best_lane(nf, -1), lane(nf), comp(nf), stack;
+  bool found = false;
+  for (int w1 = 0; w1 <= 4; ++w1)
+    for (int w2 = 0; w2 <= 4; ++w2)
+      for (int m = w1; m + w2 <= nf; ++m) {
+        if (w2 == 0 && m > w1) break;
+        if (w1 + w2 == 0) continue;
+        // free tiles outside the separator: connected components
+        int ncomp = 0;
+        for (int t = 0; t < nf; ++t) comp[t] = (t < w1 || (t >= m && t < m + w2)) ? -2 : -1;
+        for (int t = 0; t < nf; ++t) {
+          if (comp[t] != -1) continue;
+          comp[t] = ncomp;
+          stack.assign(1, t);
+          while (!stack.empty()) {
+            const int u = stack.back(); stack.pop_back();
+            for (int v = 0; v < nf; ++v)
+              if (comp[v] == -1 && adj(u, v)) { comp[v] = ncomp; stack.push_back(v); }
+          }
+          ++ncomp;
+        }
+        if (ncomp < 2) continue;
+        std::vector<int> size(ncomp, 0), order(ncomp);
+        for (int t = 0; t < nf; ++t) if (comp[t] >= 0) ++size[comp[t]];
+        for (int c = 0; c < ncomp; ++c) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int e) { return size[a] > size[e]; });
+        int la = 0, lb = 0;
+        std::vector<int> lane_of(ncomp);
+        for (int c : order) { if (la <= lb) { lane_of[c] = 0; la += size[c]; } else { lane_of[c] = 1; lb += size[c]; } }
+        const int cost = std::max(la, lb) + (w1 + w2) + (nt - nf);
+        if (cost > nt - 2 || cost >= best_cost + (found ? 0 : 1)) continue;
+        found = true;
+        best_cost = cost;
+        const int big = la >= lb ? 0 : 1;  // lane A is the longer one
+        for (int t = 0; t < nf; ++t) best_lane[t] = comp[t] < 0 ? 2 : (lane_of[comp[t]] == big ? 0 : 1);
+      }
+  if (!found) return false;
+  int pos = 0, na = 0, nb = 0;
+  for (int pass = 0; pass < 3; ++pass)
+    for (int t = 0; t < nf; ++t)
+      if (best_lane[t] == pass) { perm[t] = pos++; if (pass == 0) ++na; if (pass == 1) ++nb; }
+  for (int t = nf; t < nt; ++t) perm[t] = pos++;
+  *lane_a = na; *lane_b = nb;
+  return true;
+}
+
+inline size_t schur_lds_bytes(int max_obs, int max_ent, int max_pair, int NC, int np)
 {
   (void)max_ent; (void)max_pair;
-  return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2));
+  // T rows of the largest camera, the reduction strip, the scene's tile order (one int per 64 columns)
+  return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 1) / 2 + 1);
 }
 
 template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
@@ -286,6 +347,8 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
     if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
+    if (d.chol.sched) d.chol.sched += (size_t)lo * nt * 2;
+    if (d.tperm) d.tperm += (size_t)lo * nt;
     d.grp_ctl = b->d_ctl + 4 * g;
     d.host_ctl = b->h_ctl_dev + 4 * g;
     d.act = b->d_act + lo;
@@ -320,7 +383,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
   const int B = sh.slots;
   hipStream_t st = b->stream;
-  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC);
+  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC, d.chol.np);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
@@ -524,11 +587,11 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   bool rest_pending = false;
   if (fused) {  // a few scenes: one launch per block column (chol_col_step_kernel)
     b->prof_begin(P_CHOL_PANEL);
-    chol_diag_launch(cb, 0, stream);
+    chol_diag_launch(cb, -1, stream);
     b->prof_end();
-    for (int k = 0; k + 1 < nt; ++k) {
+    for (int st = 0; st + 1 < chol_step_count(cb); ++st) {
       b->prof_begin(P_CHOL_SYRK);
-      chol_col_step_launch(cb, k, stream);
+      chol_col_step_launch(cb, st, stream);
       b->prof_end();
     }
     b->prof_begin(P_CHOL_BACK);
@@ -1152,23 +1215,31 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.yc, (size_t)n * d.chol.np));
   tc2 = now_ms();
   // Tile-level structure of every reduced camera system: cameras that share a track couple their tiles, the T_l_w
-  // block and the rhs row couple to everything; closed under the fill of the right-looking factorisation.
+  // block and the rhs row couple to everything; closed under the fill of the right-looking factorisation.  The tiles are
+  // eliminated in the order plan_dissection picks (arcs of a ring side by side, separators last) when that shortens the
+  // dependent chain of the factorisation; Dev::tperm carries the order to the kernels, CholBatch::sched the steps.
   if (!getenv("PTZ_BA_DENSE_CHOL")) {
     const int nt = d.chol.np / CHOL_NB;
+    bool dissect = true;
+    if (const char* e = getenv("PTZ_BA_ORDER")) dissect = strcmp(e, "natural") != 0;
     std::vector<unsigned char> hm((size_t)n * nt * nt, 0);
+    std::vector<int> h_tperm((size_t)n * nt), h_sched((size_t)n * nt * 2, -1);
+    int max_steps = 0;
+    bool any_plan = false;
+    std::vector<unsigned char> m0((size_t)nt * nt);
     for (int i = 0; i < n; ++i) {
       const SceneDev& sd = b->scenes[i];
-      unsigned char* m = hm.data() + (size_t)i * nt * nt;
+      std::fill(m0.begin(), m0.end(), 0);
       auto tile_lo = [&](int cam) { return (cam * NC) / CHOL_NB; };
       auto tile_hi = [&](int cam) { return (cam * NC + NC - 1) / CHOL_NB; };
       for (int c = 0; c < sd.n_cam; ++c)
         for (int a = tile_lo(c); a <= tile_hi(c); ++a)
-          for (int e = tile_lo(c); e <= a; ++e) m[a * nt + e] = 1;
+          for (int e = tile_lo(c); e <= a; ++e) m0[a * nt + e] = 1;
       for (int p = 0; p < sd.n_pair; ++p) {
         const int ci = h_pci[sd.pair_off + p], cj = h_pcj[sd.pair_off + p];
         for (int a = tile_lo(ci); a <= tile_hi(ci); ++a)
           for (int e = tile_lo(cj); e <= tile_hi(cj); ++e) {
-            if (a >= e) m[a * nt + e] = 1; else m[e * nt + a] = 1;
+            if (a >= e) m0[a * nt + e] = 1; else m0[e * nt + a] = 1;
           }
       }
       // shared intrinsics: the fold puts a dense row / column at every group's representative (its last camera)
@@ -1177,14 +1248,38 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
         for (int g = 0; g < sd.n_grp; ++g) {
           const int rep = h_grpmem[gp[g + 1] - 1];
           for (int a = tile_lo(rep); a <= tile_hi(rep); ++a) {
-            for (int e = 0; e <= a; ++e) m[a * nt + e] = 1;
-            for (int r = a; r < nt; ++r) m[r * nt + a] = 1;
+            for (int e = 0; e <= a; ++e) m0[a * nt + e] = 1;
+            for (int r = a; r < nt; ++r) m0[r * nt + a] = 1;
           }
         }
       }
       // dense rows: the global block (if any) and the rhs row, index n_cam * NC .. n
-      for (int a = (sd.n_cam * NC) / CHOL_NB; a < nt; ++a)
-        for (int e = 0; e <= a; ++e) m[a * nt + e] = 1;
+      const int first_dense = (sd.n_cam * NC) / CHOL_NB;
+      for (int a = first_dense; a < nt; ++a)
+        for (int e = 0; e <= a; ++e) m0[a * nt + e] = 1;
+      int* perm = h_tperm.data() + (size_t)i * nt;
+      int* sched = h_sched.data() + (size_t)i * nt * 2;
+      int lane_a = 0, lane_b = 0;
+      const bool planned = dissect && sd.n_grp == 0 && plan_dissection(nt, first_dense, m0.data(), perm, &lane_a, &lane_b);
+      if (!planned) for (int t = 0; t < nt; ++t) perm[t] = t;
+      int steps = 0;
+      if (planned) {
+        any_plan = true;
+        for (int st = 0; st < lane_a; ++st, ++steps) { sched[2 * steps] = st; sched[2 * steps + 1] = st < lane_b ? lane_a + st : -1; }
+        for (int t = lane_a + lane_b; t < nt; ++t, ++steps) sched[2 * steps] = t;
+      }
+      else for (int t = 0; t < nt; ++t, ++steps) sched[2 * steps] = t;
+      max_steps = std::max(max_steps, steps);
+      if ((int)b->sched_kmin.size() < steps) b->sched_kmin.resize(steps, nt);
+      for (int st = 0; st < steps; ++st) b->sched_kmin[st] = std::min(b->sched_kmin[st], sched[2 * st]);  // (column 0 of a step is its smaller one)
+      if (dbg_t && i == 0) fprintf(stderr, "[ptz_ba_create] scene 0: %d tiles, elimination %s: lanes %d + %d, %d steps\n", nt, planned ? "dissected" : "natural", lane_a, lane_b, steps);
+      unsigned char* m = hm.data() + (size_t)i * nt * nt;
+      for (int a = 0; a < nt; ++a)
+        for (int e = 0; e <= a; ++e) {
+          if (!m0[a * nt + e]) continue;
+          const int pa = perm[a], pe = perm[e];
+          m[std::max(pa, pe) * nt + std::min(pa, pe)] = 1;
+        }
       for (int k = 0; k < nt; ++k)
         for (int x = k + 1; x < nt; ++x) {
           if (!m[x * nt + k]) continue;
@@ -1195,6 +1290,15 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     const unsigned char* dm = nullptr;
     TRY(upload(b, hm, &dm));
     d.chol.tmask = dm;
+    if (any_plan) {
+      const int* dp = nullptr;
+      TRY(upload(b, h_tperm, &dp));
+      d.tperm = dp;
+      TRY(upload(b, h_sched, &dp));
+      d.chol.sched = dp;
+      d.chol.n_steps = max_steps;
+      d.chol.sched_kmin = b->sched_kmin.data();
+    }
     // tiles outside the structure are never written again: zero everything once (the block may be a recycled one)
     if (hipMemset(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   }
@@ -1276,7 +1380,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // k_schur keeps a camera's T_a rows in LDS (up to ~1700 observations of one view); beyond that the table goes to global
   // memory.  What remains is the 16-bit position inside the camera-pair entry records: 65535 observations per view.
   if (b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
-  b->schur_tg = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC) > 160 * 1024;
+  b->schur_tg = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC, b->d.chol.np) > 160 * 1024;
   if (const char* e = getenv("PTZ_BA_SCHUR_GLOBAL_T")) b->schur_tg = atoi(e) != 0;
   if (b->schur_tg) {
     const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 15));

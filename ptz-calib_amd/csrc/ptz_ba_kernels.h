@@ -148,7 +148,20 @@ struct Dev {
   // reduced camera system
   CholBatch chol;
   double* yc;        // [n_scene][np]
+  // Elimination order of the reduced system: a permutation of its 64-column tiles, [n_scene][np / 64] (nullptr: natural
+  // order).  Row / column c of the system "as the cameras number it" (camera i: columns i NC ...) lives at
+  // tperm[c / 64] * 64 + c % 64; every kernel that writes the system or reads its solution goes through sys_col().  The host
+  // picks the order from the tile graph (ptz_ba.hip plan_dissection): arcs of the ring first, separators last.
+  const int* tperm;
 };
+
+__device__ __forceinline__ int sys_col(const Dev& d, int sc, int c)
+{
+  return d.tperm ? d.tperm[(size_t)sc * (d.chol.np / CHOL_NB) + c / CHOL_NB] * CHOL_NB + c % CHOL_NB : c;
+}
+// element (r, c) of the symmetric system, r and c already mapped, in its lower-triangular storage
+__device__ __forceinline__ double& sys_at(double* A, int np, int r, int c) { return r >= c ? A[(size_t)r * np + c] : A[(size_t)c * np + r]; }
+
 
 __device__ __forceinline__ const double* cur_cam(const Dev& d, const SceneDev& s, const LmState& st)
 {
@@ -980,6 +993,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   const int eb = 0;                                        // entries are addressed by global index
   double* T = TG ? d.Tbuf + (size_t)o0 * TS : lds;             // [no][TS]
   double* strip = TG ? lds : lds + (size_t)no * TS;            // [waves][NC + NU] reduction strip
+  // the scene's tile order behind it (identity without one): positions in the reduced system are looked up in LDS
+  int* tord = reinterpret_cast<int*>(strip + (SCHUR_THREADS / 64) * (NW + NU));
+  {
+    const int ntl = d.chol.np / CHOL_NB;
+    for (int t = threadIdx.x; t < ntl; t += SCHUR_THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
+  }
+  auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
   const unsigned* ents = d.ent + eb;                // (a slot | b slot << 16), this camera's contiguous range
   const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
   double bsum[NW], D[NU];
@@ -1045,14 +1065,15 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
       }
       const int ip = ipos(p), iq = ipos(qq);
       if (ip >= 0 && iq >= 0) v -= strip_sum(NW + ip * (ip + 1) / 2 + iq);
-      A[(size_t)(ci * NC + p) * np + ci * NC + qq] = v;
-      A[(size_t)(ci * NC + qq) * np + ci * NC + p] = v;
+      const int rp = scol(ci * NC + p), rq = scol(ci * NC + qq);
+      A[(size_t)rp * np + rq] = v;
+      A[(size_t)rq * np + rp] = v;
     }
     else if (t >= NE && t < NE + NC) {
       const int p = t - NE, ip = ipos(p);
       double v = d.gc[(size_t)gi * NC + p];
       if (ip >= 0) v -= strip_sum(ip);
-      A[(size_t)s.n * np + ci * NC + p] = v;
+      A[(size_t)s.n * np + scol(ci * NC + p)] = v;
     }
   }
   // ---- phase 2: off-diagonal blocks of row-block ci (index data and T from LDS, W_b lines from L2/HBM)
@@ -1120,7 +1141,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
     // reduce-scatter over the 16 lanes of the group: after the steps with masks 8, 4, 2, 1 lane l holds the complete
     // sum of block element l (fixed order); every lane then stores its own element.  Elements >= NW*NW (NW = 5 keeps
     // 25 values) take a second pass with the lanes that are left.
-    double* S = A + (size_t)(ci * NC) * np + cj * NC;
+
 #pragma unroll
     for (int base = 0; base < NW * NW; base += 16) {
       double v[16];
@@ -1137,7 +1158,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
         }
       }
       const int el = base + l;
-      if (el < NW * NW) S[(size_t)Dims<TYPE>::pos(el / NW) * np + Dims<TYPE>::pos(el % NW)] = -v[0];
+      if (el < NW * NW)
+        sys_at(A, np, scol(ci * NC + Dims<TYPE>::pos(el / NW)), scol(cj * NC + Dims<TYPE>::pos(el % NW))) = -v[0];
     }
   }
 }
@@ -1165,15 +1187,15 @@ __global__ __launch_bounds__(64) void k_schur_3d(Dev d)
       const double Dd = sqrt(d.diag_t[(size_t)s.idx * 6 + k] / st.radius);
       v += Dd * Dd;
     }
-    A[(size_t)(t0 + k) * np + t0 + l] = v;
+    sys_at(A, np, sys_col(d, sc, t0 + k), sys_col(d, sc, t0 + l)) = v;
   }
-  A[(size_t)s.n * np + t0 + k] = d.gt[(size_t)s.idx * 6 + k];
+  A[(size_t)s.n * np + sys_col(d, sc, t0 + k)] = d.gt[(size_t)s.idx * 6 + k];
   for (int o = 0; o < s.n_o3; ++o) {  // observation order: deterministic accumulation into the (zeroed) coupling row
     const int go = s.o3_off + o;
     const int ci = d.o3_cam[go];
     const double q0 = d.Jt3[(size_t)go * 12 + k], q1 = d.Jt3[(size_t)go * 12 + 6 + k];
     const double* j0 = d.Jc3 + (size_t)go * 2 * NC;
-    for (int l = 0; l < NC; ++l) A[(size_t)(t0 + k) * np + ci * NC + l] += q0 * j0[l] + q1 * j0[NC + l];
+    for (int l = 0; l < NC; ++l) sys_at(A, np, sys_col(d, sc, t0 + k), sys_col(d, sc, ci * NC + l)) += q0 * j0[l] + q1 * j0[NC + l];
   }
 }
 
@@ -1196,7 +1218,10 @@ __global__ void k_cam_update(Dev d)
   double c15[15];
 #pragma unroll
   for (int k = 0; k < 15; ++k) c15[k] = x[k];
-  const double* y = d.yc + (size_t)sc * d.chol.np + (size_t)i * NC;
+  const double* ysc = d.yc + (size_t)sc * d.chol.np;
+  double y[NC];  // this camera's part of the solution (through the elimination order)
+#pragma unroll
+  for (int k = 0; k < NC; ++k) y[k] = ysc[sys_col(d, sc, i * NC + k)];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const double step = -y[k];
@@ -1246,10 +1271,9 @@ __global__ void k_cam_update(Dev d)
   if (Dims<TYPE>::HAS3D && i == 0) {
     const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
     double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
-    const double* yt = d.yc + (size_t)sc * d.chol.np + (size_t)NC * s.n_cam;
     double tn[6];
     for (int k = 0; k < 6; ++k) {
-      const double step = -yt[k];
+      const double step = -ysc[sys_col(d, sc, NC * s.n_cam + k)];
       d.dt[(size_t)s.idx * 6 + k] = step;
       tn[k] = t[k] + step * d.scale_t[(size_t)s.idx * 6 + k];
       tc[k] = tn[k];

@@ -297,12 +297,29 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
   }
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int k)
+// block columns of step `step` of system `sys` (one-launch-per-step path)
+__device__ __forceinline__ void chol_step_columns(const CholBatch& cb, int sys, int step, int nt, int& c1, int& c2)
+{
+  c1 = c2 = -1;
+  if (step >= nt) return;
+  if (!cb.sched) { c1 = step; return; }
+  const int* sp = cb.sched + ((size_t)sys * nt + step) * 2;
+  c1 = sp[0]; c2 = sp[1];
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int kk)
 {
   const int slot = blockIdx.y, sys = chol_system_of(cb, slot);
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np;
   const int n = cb.n[sys];
+  int k = kk;
+  if (kk < 0) {  // the columns of step 0
+    int c1, c2;
+    chol_step_columns(cb, sys, 0, np / NB, c1, c2);
+    k = blockIdx.x == 0 ? c1 : c2;
+    if (k < 0) return;
+  }
   if (k * NB > n) return;  // whole block column is padding (identity)
   const double* A = cb.A + (size_t)sys * np * np;
   __shared__ __attribute__((aligned(16))) double As[NB * LD];        // A_kk, overwritten by L_kk block column by block column
@@ -515,7 +532,8 @@ __device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, 
   }
 }
 
-__global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
+// kmin: no system factors a block column below it in this step, so only the tiles (ti, tj), ti >= tj > kmin, can have work
+__global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int step, int kmin)
 {
   int bx, slot;
   xcd_remap(bx, slot);
@@ -523,12 +541,17 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const int m = nt - k - 1;
+  int col[2], nxt[2];
+  chol_step_columns(cb, sys, step, nt, col[0], col[1]);
+  chol_step_columns(cb, sys, step + 1, nt, nxt[0], nxt[1]);
+  if (col[0] < 0 && col[1] < 0) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (bx == m * (m + 1) / 2) {
-    // the spare workgroup of the launch: full inverse of the diagonal tile k (factored by the previous launch), off the
-    // critical chain; the back-substitution multiplies by it instead of solving with it
-    if (!cb.Linv || k * NB > n) return;
+  const int m = nt - kmin - 1, ntri = m * (m + 1) / 2;
+  if (bx >= ntri) {
+    // the spare workgroups of the launch: full inverse of the diagonal tile of each column of the step (factored by the
+    // previous launch), off the critical chain; the back-substitution multiplies by it instead of solving with it
+    const int k = col[bx - ntri];
+    if (!cb.Linv || k < 0 || k * NB > n) return;
     double* Lk = smem;
     double* Di = smem + 3 * NB * LD;
     tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
@@ -541,18 +564,18 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
   int ii = (int)((sqrt(8.0 * bx + 1.0) - 1.0) * 0.5);
   while ((ii + 1) * (ii + 2) / 2 <= bx) ++ii;
   while (ii * (ii + 1) / 2 > bx) --ii;
-  const int jj = bx - ii * (ii + 1) / 2;
-  if (ii >= m) return;
-  const int ti = k + 1 + ii, tj = k + 1 + jj;
-  if (k * NB > n || ti * NB > n) return;  // padding
-  const bool next_diag = ti == tj && ti == k + 1;
-  bool do_update = true;
-  if (cb.tmask) {
-    const unsigned char* tm = cb.tmask + (size_t)sys * nt * nt;
-    if (!tm[ti * nt + k] || !tm[tj * nt + k]) do_update = false;  // L_ik or L_jk is structurally zero
-    else if (!tm[ti * nt + tj]) return;                            // (cannot happen: the mask is closed under fill)
+  const int ti = kmin + 1 + ii, tj = kmin + 1 + (bx - ii * (ii + 1) / 2);
+  if (ti * NB > n) return;  // padding
+  const bool next_diag = ti == tj && (ti == nxt[0] || ti == nxt[1]);
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  bool upd[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int k = col[c];
+    // tile (ti, tj) takes an update from column k when it lies behind it and L_ik and L_jk are both in the structure
+    upd[c] = k >= 0 && tj > k && k * NB <= n && (!tm || (tm[ti * nt + k] && tm[tj * nt + k]));
   }
-  if (!do_update && !next_diag) return;
+  if (!upd[0] && !upd[1] && !next_diag) return;
   double* A = cb.A + (size_t)sys * np * np;
   double* Lk = smem;                    // [NB * LD]   L_kk
   double* As = Lk + NB * LD;            // [NB * LD]   L_ik
@@ -561,8 +584,11 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
   double (*Dv)[DB * LDD] = reinterpret_cast<double (*)[DB * LDD]>(Di + 4 * DB * LDD);  // scratch of the diagonal factorisation
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const double* Bop = As;
-  if (do_update) {
+  double* C = A + (size_t)(ti * NB + 16 * w) * np + tj * NB;
+  d4 acc[4];
+  const double* Bop = ti == tj ? As : Bs;
+  // operand tiles of block column k: L_kk and its block inverses into LDS, then L_ik (and L_jk) by triangular solves
+  auto operands = [&](int k) {
     tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
     const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
     for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
@@ -570,27 +596,33 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int k)
     double* Tik = A + (size_t)(ti * NB + 16 * w) * np + k * NB;
     double* Lik = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
     trsm_rows_to_lds(Tik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
-    if (ti != tj) {
-      trsm_rows_to_lds(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np, Lk, Di, Bs + 16 * w * LD, nullptr);
-      Bop = Bs;
-    }
-  }
-  double* C = A + (size_t)(ti * NB + 16 * w) * np + tj * NB;
-  d4 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
-  __syncthreads();
-  if (do_update) {
+    if (ti != tj) trsm_rows_to_lds(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np, Lk, Di, Bs + 16 * w * LD, nullptr);
+  };
+  auto update = [&]() {
+    __syncthreads();
     const double* ap = As + (16 * w + fr) * LD + fq;
     const double* bp = Bop + fr * LD + fq;
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
       const double av = -ap[4 * kk];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
+      for (int cc = 0; cc < 4; ++cc) acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * cc) * LD + 4 * kk], acc[cc], 0, 0, 0);
     }
+  };
+  // The step's columns in ascending order (a tile behind both -- a separator tile -- takes both updates, always in this
+  // order).  The C tile is asked for after the first triangular solve has been issued, so that its sixteen strided loads do
+  // not queue up in front of the operand tiles on the critical workgroup.
+  const int first = upd[0] ? 0 : 1;
+  if (upd[first]) operands(col[first]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
+  if (upd[first]) update();
+  if (first == 0 && upd[1]) {
+    __syncthreads();  // all waves are done with the operand tiles of the first column
+    operands(col[1]);
+    update();
   }
   if (next_diag) {
     __syncthreads();  // all waves are done reading the operand tiles
@@ -884,9 +916,9 @@ void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool
   const int m = cb.np / NB - j;
   if (j > 0 && m > 0) launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
 }
-void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream)
+void chol_col_step_launch(const CholBatch& cb, int step, hipStream_t stream)
 {
-  const int m = cb.np / NB - k - 1;
+  const int nt = cb.np / NB;
   const size_t smem = sizeof(double) * (3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2);
   {  // > 64 KiB of dynamic LDS: the cap is raised once per device
     static std::atomic<unsigned long long> done{0};
@@ -898,11 +930,13 @@ void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream)
       done.fetch_or(bit, std::memory_order_release);
     }
   }
-  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? 1 : 0), cb.count), dim3(256), smem, stream, cb, k);
+  const int kmin = cb.sched ? cb.sched_kmin[step] : step;
+  const int m = nt - kmin - 1;
+  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? (cb.sched ? 2 : 1) : 0), cb.count), dim3(256), smem, stream, cb, step, kmin);
 }
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
-  launch(chol_diag_kernel, dim3(1, cb.count), dim3(256), 0, stream, cb, k);
+  launch(chol_diag_kernel, dim3(k < 0 && cb.sched ? 2 : 1, cb.count), dim3(256), 0, stream, cb, k);
 }
 void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream)
 {
@@ -935,8 +969,8 @@ void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
   if (cb.L) {  // a few systems: one launch per block column
-    chol_diag_launch(cb, 0, stream);
-    for (int k = 0; k + 1 < nt; ++k) chol_col_step_launch(cb, k, stream);
+    chol_diag_launch(cb, -1, stream);
+    for (int st = 0; st + 1 < chol_step_count(cb); ++st) chol_col_step_launch(cb, st, stream);  // (the last step's column has nothing behind it)
     chol_backsolve_launch(cb, x, stream);
     return;
   }

@@ -180,6 +180,13 @@ struct CholBatch {
   // holding the rhs row is full).  Tiles outside the mask stay exactly zero and their panel / update work is skipped:
   // the tile-granular counterpart of the sparse Cholesky behind the reference's SPARSE_SCHUR (ptzray_optimizer.cc:471).
   const unsigned char* tmask = nullptr;
+  // Step schedule of the one-launch-per-step path: device [count][nt][2] block columns (or -1) that step s factors side by
+  // side -- two columns of one step never couple (the two arcs of a dissected ring), so their panels, updates and the
+  // diagonal tiles of the next step proceed in ONE launch and the dependent chain is as long as the longer arc plus the
+  // separator.  nullptr: step s = block column s.  n_steps: steps of the longest schedule in the batch.
+  const int* sched = nullptr;
+  int n_steps = 0;
+  const int* sched_kmin = nullptr;  // HOST memory [n_steps]: smallest block column any system factors in step s (sizes the launch)
 };
 __device__ __forceinline__ int chol_system_of(const CholBatch& cb, int slot)
 {
@@ -194,7 +201,8 @@ void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag = false);  // mode 0 all, 1 column k+1, 2 rest; fuse_diag: also factor tile (k+1, k+1)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
 void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream);  // Linv of every diagonal tile (multi-launch paths, before the back-substitution)
-void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);       // factor the diagonal tile of block column k
+void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);       // factor the diagonal tile of block column k (k < 0: of the columns of step 0)
+inline int chol_step_count(const CholBatch& cb) { return cb.sched ? cb.n_steps : cb.np / CHOL_NB; }
 void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream);   // few systems: trsm + trailing update + next diagonal tile, one launch
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
