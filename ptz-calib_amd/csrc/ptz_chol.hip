@@ -820,18 +820,31 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   const int tid = threadIdx.x;
   const int c = tid & 63, q = (tid >> 6) & 3, sl = tid >> 8;
   if (LIST && tid == 0) {  // the work list, in execution order
+    // Backward over the steps of the factorisation.  The block columns of one step (the two arcs of a dissected system) do not
+    // couple, so their diagonal inverses share a group and their rows' tiles fill groups together: the chain of dependent
+    // groups is as long as the step schedule, not as the number of block columns.
     int g = 0;
-    for (int k = nt - 1; k >= 0; --k) {
-      const int c0 = k * NB;
-      if (c0 >= n) continue;
+    const int n_steps = cb.sched ? cb.n_steps : nt;
+    for (int st = n_steps - 1; st >= 0; --st) {
+      int col[2];
+      chol_step_columns(cb, sys, st, nt, col[0], col[1]);
+      if (col[0] >= 0 && col[0] * NB >= n) col[0] = -1;
+      if (col[1] >= 0 && col[1] * NB >= n) col[1] = -1;
+      if (col[0] < 0 && col[1] < 0) continue;
       BsItem* grp = items + 4 * g++;
-      grp[0] = BsItem{(long long)k * (NB * NB), NB, c0, c0, 1};
-      grp[1].kind = grp[2].kind = grp[3].kind = 0;
-      int ns = 4;
-      for (int tj = 0; tj < k; ++tj) {
-        if (tm && !tm[k * nt + tj]) continue;
-        if (ns == 4) { grp = items + 4 * g++; grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0; ns = 0; }
-        grp[ns++] = BsItem{(long long)c0 * np + (long long)tj * NB, np, c0, tj * NB, 2};
+      grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0;
+      int ns = 0;
+      for (int c = 0; c < 2; ++c)
+        if (col[c] >= 0) grp[ns++] = BsItem{(long long)col[c] * (NB * NB), NB, col[c] * NB, col[c] * NB, 1};
+      ns = 4;
+      for (int c = 0; c < 2; ++c) {
+        const int k = col[c];
+        if (k < 0) continue;
+        for (int tj = 0; tj < k; ++tj) {
+          if (tm && !tm[k * nt + tj]) continue;
+          if (ns == 4) { grp = items + 4 * g++; grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0; ns = 0; }
+          grp[ns++] = BsItem{(long long)(k * NB) * np + (long long)tj * NB, np, k * NB, tj * NB, 2};
+        }
       }
     }
     n_groups = g;
