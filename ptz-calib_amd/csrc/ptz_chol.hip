@@ -688,13 +688,32 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
   const double* bp = Bs + fr * LD + fq;
   // The operand tiles of step k + 1 are fetched into registers while the matrix cores work on step k: a step then costs its 64
   // MFMAs per wave plus one LDS hand-over, not a global-memory round trip on top (the loop used to: barrier, load, barrier, MFMA).
-  auto next_k = [&](int k) { while (k < j && tm && (!tm[ti * nt + k] || !tm[j * nt + k])) ++k; return k; };  // uniform over the workgroup
+  // The block columns k < j are taken in the order of the step schedule (ascending k without one): a tile then sums its
+  // updates in the order the one-launch-per-step path applies them, and a scene has the same bits on either path.
+  // The list is made once, in LDS (a system has at most a few hundred block columns).
+  __shared__ short klist[1024];
+  __shared__ int kcount;
+  if (threadIdx.x == 0) {
+    const int nq = cb.sched ? 2 * cb.n_steps : j;
+    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * 2 : nullptr;
+    int cnt = 0;
+    for (int qq = 0; qq < nq; ++qq) {
+      const int kc = sq ? sq[qq] : qq;
+      if (kc >= 0 && kc < j && (!tm || (tm[ti * nt + kc] && tm[j * nt + kc])) && cnt < 1024) klist[cnt++] = (short)kc;
+    }
+    kcount = cnt;
+  }
+  __syncthreads();
+  const int Q = kcount;
+  auto col_of = [&](int q) { return (int)klist[q]; };
+  auto next_q = [&](int q) { return q; };
   constexpr int NP = (NB * NB / 2) / 256;  // double2 pieces of one tile per thread
-  int k = next_k(0);
-  const bool any = k < j;
-  d16 ra = tile_fetch(A + (size_t)(ti * NB) * np + (any ? k : 0) * NB, np);
-  d16 rb = tile_fetch(A + (size_t)(j * NB) * np + (any ? k : 0) * NB, np);
-  while (k < j) {
+  int q = 0;
+  const bool any = q < Q;
+  int k = any ? col_of(q) : 0;
+  d16 ra = tile_fetch(A + (size_t)(ti * NB) * np + k * NB, np);
+  d16 rb = tile_fetch(A + (size_t)(j * NB) * np + k * NB, np);
+  while (q < Q) {
     __syncthreads();  // the previous step's fragment reads are done
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -703,12 +722,13 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
       *reinterpret_cast<double2*>(As + row * LD + c2) = make_double2(-ra[2 * p], -ra[2 * p + 1]);   // -L_ik
       *reinterpret_cast<double2*>(Bs + row * LD + c2) = make_double2(rb[2 * p], rb[2 * p + 1]);      //  L_jk
     }
-    const int kn = next_k(k + 1);
+    const int qn = next_q(q + 1);
     __syncthreads();
     {  // the next step's tiles (after the last step the current ones again: the fetch stays unconditional)
-      const int kf = kn < j ? kn : k;
+      const int kf = qn < Q ? col_of(qn) : k;
       ra = tile_fetch(A + (size_t)(ti * NB) * np + kf * NB, np);
       rb = tile_fetch(A + (size_t)(j * NB) * np + kf * NB, np);
+      k = kf;
     }
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
@@ -716,7 +736,7 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
     }
-    k = kn;
+    q = qn;
   }
   if (fuse_diag && ti == j) {
     // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
