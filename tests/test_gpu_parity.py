@@ -1009,6 +1009,36 @@ def test_ba_global_memory_variants_reproduce_the_bits(pkg, monkeypatch):
         assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), var
 
 
+def test_ba_elimination_orders_agree(pkg, orc, monkeypatch):
+    """The dissected elimination order of the reduced camera system (two arcs of the ring side by side, separators last) is a
+    symmetric permutation of the same exact factorisation: against the images' own order (PTZ_BA_ORDER=natural) the LM
+    bookkeeping is identical and the parameters agree to round-off -- on the 360-degree C2 ring, on a 120-degree band that does
+    not close (one separator in the middle), on a PTZRayDist rig whose camera blocks straddle the 64-column tiles (NC = 5),
+    and with annotations (T_l_w block in the tail).  Alone, in a batch of 3 and in a batch of 12 (multi-launch path) a scene
+    keeps its bits."""
+    cases = [pkg.synth.make_scene(3, 200, 500),
+             pkg.synth.make_scene(4, 160, 300, pan_range_deg=120.0),
+             pkg.synth.make_scene(5, 150, 300, factor_type=1)]
+    ann = pkg.synth.make_scene(6, 140, 300, factor_type=1)
+    pkg.synth.add_annotations(ann)
+    cases.append(ann)
+    for sc in cases:
+        got = pkg.api.ba_solve(sc)
+        monkeypatch.setenv("PTZ_BA_ORDER", "natural")
+        want = pkg.api.ba_solve(sc)
+        monkeypatch.delenv("PTZ_BA_ORDER")
+        assert got[2]["termination_type"] == want[2]["termination_type"] == 0
+        assert got[2]["num_iterations"] == want[2]["num_iterations"] and got[2]["num_successful_steps"] == want[2]["num_successful_steps"]
+        assert abs(got[2]["final_cost"] - want[2]["final_cost"]) <= 1e-11 * want[2]["final_cost"]
+        assert _rel(got[0][:, 0], want[0][:, 0]) < 1e-9 and np.abs(got[0][:, 4:7] - want[0][:, 4:7]).max() < 1e-9
+    base = cases[0]
+    solo = pkg.api.ba_solve(base)
+    for n in (3, 12):
+        b = pkg.api.BaBatch([base] + [pkg.synth.make_scene(40 + i, 200, 500) for i in range(n - 1)])
+        b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+        assert summ[0] == solo[2] and np.array_equal(cams[0], solo[0]) and np.array_equal(rays[0], solo[1]), n
+
+
 def test_ba_size_limit_is_reported(pkg):
     """What the device path does refuse -- more than 65535 observations in one view (16-bit positions in the camera-pair records)
     -- comes back as PTZ_ELIMIT (-5), never as a silent failure or a CPU fallback."""
