@@ -693,15 +693,21 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
   // The list is made once, in LDS (a system has at most a few hundred block columns).
   __shared__ short klist[1024];
   __shared__ int kcount;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // wave 0: 64 candidates at a time, all their loads in flight together, compacted in order by ballot
     const int nq = cb.sched ? 2 * cb.n_steps : j;
     const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * 2 : nullptr;
     int cnt = 0;
-    for (int qq = 0; qq < nq; ++qq) {
-      const int kc = sq ? sq[qq] : qq;
-      if (kc >= 0 && kc < j && (!tm || (tm[ti * nt + kc] && tm[j * nt + kc])) && cnt < 1024) klist[cnt++] = (short)kc;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int qq = q0 + (int)threadIdx.x;
+      const int kc = qq < nq ? (sq ? sq[qq] : qq) : -1;
+      const bool in = kc >= 0 && kc < j;
+      const bool ok = in && (!tm || (tm[ti * nt + (in ? kc : 0)] && tm[j * nt + (in ? kc : 0)]));
+      const unsigned long long m = __ballot(ok);
+      const int pos = cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (ok && pos < 1024) klist[pos] = (short)kc;
+      cnt += __popcll(m);
     }
-    kcount = cnt;
+    if (threadIdx.x == 0) kcount = min(cnt, 1024);
   }
   __syncthreads();
   const int Q = kcount;
@@ -711,24 +717,30 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
   int q = 0;
   const bool any = q < Q;
   int k = any ? col_of(q) : 0;
-  d16 ra = tile_fetch(A + (size_t)(ti * NB) * np + k * NB, np);
-  d16 rb = tile_fetch(A + (size_t)(j * NB) * np + k * NB, np);
-  while (q < Q) {
+  // Two steps of operand tiles are in flight (the tiles were written by other launches, mostly on other XCDs, and come from
+  // HBM: one step of 64 MFMAs per wave does not cover that round trip).  The fetches stay unconditional: past the end of the
+  // list they re-read the last tiles.
+  auto kq = [&](int qq) { return any ? col_of(qq < Q ? qq : Q - 1) : 0; };
+  d16 ra = tile_fetch(A + (size_t)(ti * NB) * np + kq(0) * NB, np);
+  d16 rb = tile_fetch(A + (size_t)(j * NB) * np + kq(0) * NB, np);
+  d16 ra1 = tile_fetch(A + (size_t)(ti * NB) * np + kq(1) * NB, np);
+  d16 rb1 = tile_fetch(A + (size_t)(j * NB) * np + kq(1) * NB, np);
+  (void)k; (void)next_q;
+  // one step: hand the tiles in (xa, xb) over to LDS, refill the two registers sets with the tiles of step qf, multiply
+  auto step = [&](d16& xa, d16& xb, int qf) {
     __syncthreads();  // the previous step's fragment reads are done
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int idx = p * 256 + threadIdx.x;
       const int row = idx >> 5, c2 = (idx & 31) * 2;
-      *reinterpret_cast<double2*>(As + row * LD + c2) = make_double2(-ra[2 * p], -ra[2 * p + 1]);   // -L_ik
-      *reinterpret_cast<double2*>(Bs + row * LD + c2) = make_double2(rb[2 * p], rb[2 * p + 1]);      //  L_jk
+      *reinterpret_cast<double2*>(As + row * LD + c2) = make_double2(-xa[2 * p], -xa[2 * p + 1]);   // -L_ik
+      *reinterpret_cast<double2*>(Bs + row * LD + c2) = make_double2(xb[2 * p], xb[2 * p + 1]);      //  L_jk
     }
-    const int qn = next_q(q + 1);
     __syncthreads();
-    {  // the next step's tiles (after the last step the current ones again: the fetch stays unconditional)
-      const int kf = qn < Q ? col_of(qn) : k;
-      ra = tile_fetch(A + (size_t)(ti * NB) * np + kf * NB, np);
-      rb = tile_fetch(A + (size_t)(j * NB) * np + kf * NB, np);
-      k = kf;
+    {
+      const int kf = kq(qf);
+      xa = tile_fetch(A + (size_t)(ti * NB) * np + kf * NB, np);
+      xb = tile_fetch(A + (size_t)(j * NB) * np + kf * NB, np);
     }
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
@@ -736,7 +748,10 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LD + 4 * kk], acc[c], 0, 0, 0);
     }
-    q = qn;
+  };
+  for (; q < Q; q += 2) {  // the two register sets take turns (no copies between them)
+    step(ra, rb, q + 2);
+    if (q + 1 < Q) step(ra1, rb1, q + 3);
   }
   if (fuse_diag && ti == j) {
     // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
