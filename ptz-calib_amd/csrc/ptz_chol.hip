@@ -854,7 +854,7 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   __shared__ int n_groups;
   const int tid = threadIdx.x;
   const int c = tid & 63, q = (tid >> 6) & 3, sl = tid >> 8;
-  if (LIST && tid == 0) {  // the work list, in execution order
+  if (LIST && tid < 64) {  // the work list, in execution order; made by wave 0, 64 candidate tiles at a time (ballot compaction)
     // Backward over the steps of the factorisation.  The block columns of one step (the two arcs of a dissected system) do not
     // couple, so their diagonal inverses share a group and their rows' tiles fill groups together: the chain of dependent
     // groups is as long as the step schedule, not as the number of block columns.
@@ -866,23 +866,28 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
       if (col[0] >= 0 && col[0] * NB >= n) col[0] = -1;
       if (col[1] >= 0 && col[1] * NB >= n) col[1] = -1;
       if (col[0] < 0 && col[1] < 0) continue;
-      BsItem* grp = items + 4 * g++;
-      grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0;
-      int ns = 0;
-      for (int c = 0; c < 2; ++c)
-        if (col[c] >= 0) grp[ns++] = BsItem{(long long)col[c] * (NB * NB), NB, col[c] * NB, col[c] * NB, 1};
-      ns = 4;
+      if (tid < 4) {
+        const int kd = tid == 0 ? (col[0] >= 0 ? col[0] : col[1]) : (tid == 1 && col[0] >= 0 ? col[1] : -1);
+        items[4 * g + tid] = kd >= 0 ? BsItem{(long long)kd * (NB * NB), NB, kd * NB, kd * NB, 1} : BsItem{0, 0, 0, 0, 0};
+      }
+      ++g;
+      int filled = 0;
       for (int c = 0; c < 2; ++c) {
         const int k = col[c];
         if (k < 0) continue;
-        for (int tj = 0; tj < k; ++tj) {
-          if (tm && !tm[k * nt + tj]) continue;
-          if (ns == 4) { grp = items + 4 * g++; grp[0].kind = grp[1].kind = grp[2].kind = grp[3].kind = 0; ns = 0; }
-          grp[ns++] = BsItem{(long long)(k * NB) * np + (long long)tj * NB, np, k * NB, tj * NB, 2};
+        for (int t0 = 0; t0 < k; t0 += 64) {
+          const int tj = t0 + tid;
+          const bool ok = tj < k && (!tm || tm[k * nt + tj]);
+          const unsigned long long m = __ballot(ok);
+          if (ok) items[4 * g + filled + __popcll(m & ((1ull << tid) - 1ull))] = BsItem{(long long)(k * NB) * np + (long long)tj * NB, np, k * NB, tj * NB, 2};
+          filled += __popcll(m);
         }
       }
+      const int padded = (filled + 3) & ~3;
+      if (tid < padded - filled) items[4 * g + filled + tid] = BsItem{0, 0, 0, 0, 0};
+      g += padded / 4;
     }
-    n_groups = g;
+    if (tid == 0) n_groups = g;
   }
   {
     const int kt = n / NB;
