@@ -783,7 +783,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
-  __shared__ double scratch[16];
+  __shared__ double scratch[64];
   const int tid = threadIdx.x;
   if (st.step_is_successful) {
     // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
@@ -818,9 +818,11 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
         gm = fmax(gm, fabs(d.gt[(size_t)s.idx * 6 + k] / d.scale_t[(size_t)s.idx * 6 + k]));
       }
     }
-    c = block_sum(c, scratch);
-    gm = block_max(gm, scratch);
-    xn = block_sum(xn, scratch);
+    {
+      double r4[4] = {c, gm, xn, 0.0};
+      block_reduce4(r4, 2u, scratch);  // cost and |x|^2 are sums, the gradient norm a maximum
+      c = r4[0]; gm = r4[1]; xn = r4[2];
+    }
     if (tid == 0) {
       st.x_cost = c;
       st.it_cost = c;
@@ -1466,7 +1468,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   if (sc < 0 || !d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
-  __shared__ double scratch[16];
+  __shared__ double scratch[64];
   const int tid = threadIdx.x;
   // chunk partials in chunk order (thread-strided, then the fixed block tree)
   double mcc = 0, cost = 0, dn = 0, cn = 0;
@@ -1474,8 +1476,6 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
     const double* pp = d.partial + (size_t)(s.part_off + c) * 4;
     mcc += pp[0]; cost += pp[1]; dn += pp[2]; cn += pp[3];  // the rays' |x - x_c|^2 and |x_c|^2 come from k_eval as well
   }
-  mcc = -block_sum(mcc, scratch);
-  cost = block_sum(cost, scratch);
   // |x - x_candidate| and |x_candidate| over the parameter blocks that are in the problem
   const double* cam = cur_cam(d, s, st);
   const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
@@ -1500,8 +1500,11 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
     const double* tb_ = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
     for (int k = 0; k < 6; ++k) { dn += (ta[k] - tb_[k]) * (ta[k] - tb_[k]); cn += tb_[k] * tb_[k]; }
   }
-  dn = block_sum(dn, scratch);
-  cn = block_sum(cn, scratch);
+  {
+    double r4[4] = {mcc, cost, dn, cn};
+    block_reduce4(r4, 0u, scratch);
+    mcc = -r4[0]; cost = r4[1]; dn = r4[2]; cn = r4[3];
+  }
   if (tid != 0) return;
   const Opt& o = d.opt;
   ++st.num_linear_solves;

@@ -146,6 +146,34 @@ __device__ __forceinline__ double block_max(double v, double* scratch)
   return t;
 }
 
+// Four reductions in one pass of the block tree (kind bit k set: value k is a maximum, else a sum).  Value by value the
+// same operations in the same order as block_sum / block_max; scratch: [4 * waves].
+__device__ __forceinline__ void block_reduce4(double (&v)[4], unsigned max_mask, double* scratch)
+{
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = ((max_mask >> k) & 1u) ? wave_max(v[k]) : wave_sum(v[k]);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scratch[4 * w + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((max_mask >> k) & 1u) {
+      double t = scratch[k];
+      for (int i = 1; i < nw; ++i) t = fmax(t, scratch[4 * i + k]);
+      v[k] = t;
+    }
+    else {
+      double t = 0;
+      for (int i = 0; i < nw; ++i) t += scratch[4 * i + k];
+      v[k] = t;
+    }
+  }
+}
+
 // ---- dense Cholesky (ptz_chol.hip) -------------------------------------------------------------------
 // `count` independent SPD systems stored as padded row-major matrices A[count][np][np] (lower triangle
 // read).  Row n_i of system i holds rhs^T in columns [0, n_i) and a huge diagonal (CHOL_BIG), so the
