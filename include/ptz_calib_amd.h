@@ -176,8 +176,9 @@ int32_t ptz_ba_solve_disp(const ptz_ba_problem* p, double* cam, double* ray, dou
  * problem `index`; weighted by sqrt(track length), not Jacobi-scaled).  Host outputs, any may be NULL:
  *   cost; g_c [nc*n_cam], U [nc*nc*n_cam]; g_r [3*n_ray], V [9*n_ray]; W [nw*3*n_obs]
  * where nw = ptz_ba_cam_block_dim(factor_type), nc = ptz_ba_batch_cam_block_dim(batch): the free camera parameters carried on the device
- * ([fx, r1, r2, r3] for PTZRay, [fx, k1, r1, r2, r3] for PTZRayDist; the reference's always-zero fy
- * column (ptzray_optimizer.cc:24-25) is not materialised). */
+ * ([fx, r1, r2, r3] for PTZRay, [fx, k1, r1, r2, r3] for PTZRayDist, [fx, fy, k1, r1, r2, r3] for PTZRayFxfyDist,
+ * [fx, k1, r1, r2, r3, d0, d1, d2] for PTZRayDistDisp -- every camera carries its copy of the displacement block, the
+ * copies are one parameter; the reference's always-zero fy column (ptzray_optimizer.cc:24-25) is not materialised). */
 int32_t ptz_ba_cam_block_dim(int32_t factor_type);
 /* ... and of a batch: one more (fy, live through Reproj2d3dFactor, ptzray_optimizer.cc:273) when any problem of the
  * batch carries 2D-3D annotation observations: [fx, fy, (k1), r1, r2, r3]; the reduced system then also holds the

@@ -585,7 +585,7 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   hipEvent_t evT = nullptr, evR = nullptr;
   if (la) b->lookahead_events(stream, &evT, &evR);
   bool rest_pending = false;
-  if (fused) {  // a few scenes: one launch per block column (chol_col_step_kernel)
+  if (fused) {  // a few scenes: one launch per step of the schedule (chol_col_step_kernel)
     b->prof_begin(P_CHOL_PANEL);
     chol_diag_launch(cb, -1, stream);
     b->prof_end();

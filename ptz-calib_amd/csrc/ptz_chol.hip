@@ -484,13 +484,16 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
-// ---- one launch per block column for a FEW systems: triangular solves folded into the trailing update --------------------
+// ---- one launch per step (one block column, or two that do not couple) for a FEW systems: triangular solves folded into
+//      the trailing update ----------------------------------------------------------------------------------------------
 // Right-looking step k as ONE kernel: the workgroup of trailing tile (i, j), i >= j > k, first turns A_ik and A_jk into
 // L_ik = A_ik L_kk^-T and L_jk itself (the same blocked MFMA solve as chol_trsm_kernel, into LDS), then A_ij -= L_ik L_jk^T,
 // and the workgroup of tile (k+1, k+1) factors it on the spot.  Every L_ik is solved for by each tile of row / column i --
 // redundant arithmetic on compute units that would otherwise idle -- which removes the separate triangular-solve launch
-// from the 13-deep dependency chain of a single 800 x 800 system (26 launches -> 13).  The workgroup of the diagonal tile
-// (i, i) is the one that writes L_ik back (the back-substitution reads it).  For batches the left-looking kernels are used.
+// from the 13-deep dependency chain of a single 800 x 800 system (26 launches -> 13).  With a step schedule
+// (CholBatch::sched) a step holds two block columns that do not couple -- the arcs of a dissected ring -- whose updates and
+// next diagonal tiles proceed in the same launch (13 -> 9 on that system).  The workgroup of the diagonal tile (i, i) is
+// the one that writes L_ik back (the back-substitution reads it).  For batches the left-looking kernels are used.
 __device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, int ldg, const double* Lk, const double* Di, double* xs,
                                                  double* __restrict__ store_to)
 {
@@ -1021,7 +1024,7 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
-  if (cb.L) {  // a few systems: one launch per block column
+  if (cb.L) {  // a few systems: one launch per step of the schedule
     chol_diag_launch(cb, -1, stream);
     for (int st = 0; st + 1 < chol_step_count(cb); ++st) chol_col_step_launch(cb, st, stream);  // (the last step's column has nothing behind it)
     chol_backsolve_launch(cb, x, stream);
