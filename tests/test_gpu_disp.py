@@ -102,6 +102,11 @@ def test_ba_dist_disp_batch_and_shared_intrinsics(pkg, orc):
         cam1, ray1, s1, _, d1 = pkg.api.ba_solve_disp(scenes[i])
         assert s1 == summ[i]
         assert np.array_equal(cam1, cams[i]) and np.array_equal(ray1, rays[i]) and np.array_equal(d1, disps[i])
+    # twelve scenes: the multi-launch factorisation and two scene groups
+    more = scenes + [pkg.synth.make_scene(30 + i, 18, 80, factor_type=3) for i in range(6)]
+    b = pkg.api.BaBatch(more); b.set_state(); summ12 = b.solve(); cams12, _ = b.get_state(); disps12 = b.get_disp(); b.close()
+    for i in range(6):
+        assert summ12[i] == summ[i] and np.array_equal(cams12[i], cams[i]) and np.array_equal(disps12[i], disps[i])
     # a start away from zero
     d0 = np.array([0.02, -1e-5, 2e-9])
     cam2, _, s2, _, d2 = pkg.api.ba_solve_disp(scenes[1], disp0=d0)
