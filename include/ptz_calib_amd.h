@@ -207,6 +207,12 @@ int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* A, const do
 /* Measured FP64 matrix-core rate of the device (v_mfma_f64_16x16x4_f64 from registers, every wave slot busy): the
  * number the reduced-camera solve is priced against in the roofline reports. */
 int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops);
+/* Host logic only (no device needed; used by the CPU tests): the elimination order ptz_ba_batch_create would give a reduced
+ * camera system of nt 64-column tiles whose lower-triangular tile adjacency is mask[nt*nt] (row-major, non-zero = coupled),
+ * tiles >= first_dense kept last.  perm[t] = position of tile t; lanes[0], lanes[1] = tiles of the two lanes that are
+ * factored side by side (positions [0, lanes[0]) and [lanes[0], lanes[0] + lanes[1])).  Returns 1 if a dissection was
+ * chosen, 0 for the natural order (perm = identity). */
+int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes);
 
 /* Measured HBM rates of the device in GB/s: streaming read of 4 GB, and copy of 4 GB counted as read + write. */
 int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps);

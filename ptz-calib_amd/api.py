@@ -24,7 +24,8 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_set_profiling", "ptz_ba_batch_get_profile", "ptz_ba_solve", "ptz_ba_cam_block_dim",
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
-           "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp"]
+           "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp",
+           "ptz_ba_plan_tile_order"]
 
 
 class PtzError(RuntimeError):
@@ -251,6 +252,19 @@ def ba_solve_disp(scene, cam0=None, ray0=None, tlw0=None, disp0=None, **opt):
     s = LmSummary()
     _check(lib().ptz_ba_solve_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(disp), C.byref(o), C.byref(s)), "ptz_ba_solve_disp")
     return cam, ray, s.as_dict(), tlw, disp
+
+
+def plan_tile_order(mask, first_dense):
+    """Elimination order of a tile graph (host logic of ptz_ba_batch_create).  mask: [nt, nt] lower-triangular adjacency.
+    Returns (planned, perm, (lane_a, lane_b))."""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    nt = m.shape[0]
+    perm = np.zeros(nt, dtype=np.int32)
+    lanes = np.zeros(2, dtype=np.int32)
+    rc = lib().ptz_ba_plan_tile_order(nt, int(first_dense), _p(m), _p(perm), _p(lanes))
+    if rc < 0:
+        raise PtzError(rc, "ptz_ba_plan_tile_order")
+    return bool(rc), perm, (int(lanes[0]), int(lanes[1]))
 
 
 def chol_solve_batch(A, rhs, device_id=0):

@@ -685,6 +685,16 @@ int32_t ptz_device_count(void)
   return n;
 }
 
+int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes)
+{
+  if (nt <= 0 || !mask || !perm || !lanes) return PTZ_EINVAL;
+  int la = 0, lb = 0;
+  const bool planned = plan_dissection(nt, first_dense, mask, perm, &la, &lb);
+  if (!planned) { for (int t = 0; t < nt; ++t) perm[t] = t; la = lb = 0; }
+  lanes[0] = la; lanes[1] = lb;
+  return planned ? 1 : 0;
+}
+
 int32_t ptz_ba_cam_block_dim(int32_t factor_type)
 {
   if (factor_type == PTZ_BA_PTZRay) return 4;

@@ -487,3 +487,65 @@ def test_sharded_solve_gathers_on_every_rank_gloo(pkg):
         return cams, summ
     single = pkg.sharding.solve_scenes_sharded(list(range(5)), make, fake_solve, dist=None, cam_width=12)
     assert np.array_equal(single, res[0])
+
+
+def _closure_chain(mask, perm):
+    """Tile-level symbolic factorisation of the permuted mask: returns (closed mask, trsm tiles)."""
+    nt = len(mask)
+    m = np.zeros((nt, nt), dtype=bool)
+    for a in range(nt):
+        for e in range(a + 1):
+            if mask[a, e]:
+                pa, pe = perm[a], perm[e]
+                m[max(pa, pe), min(pa, pe)] = True
+    for k in range(nt):
+        for x in range(k + 1, nt):
+            if m[x, k]:
+                for y in range(k + 1, x + 1):
+                    if m[y, k]:
+                        m[x, y] = True
+    return m
+
+
+def _band_mask(nt, band, wrap, tail=1):
+    m = np.zeros((nt, nt), dtype=np.uint8)
+    free = nt - tail
+    for a in range(nt):
+        for e in range(a + 1):
+            d = a - e
+            if d <= band or (wrap and a < free and free - d <= band) or a >= free:
+                m[a, e] = 1
+    return m
+
+
+def test_tile_order_planner(pkg):
+    """plan_dissection (host logic of ptz_ba_batch_create; no GPU needed): on ring and band tile graphs it returns a
+    permutation whose two lanes do not couple -- before and after the fill of the factorisation -- keeps the dense tail in
+    place and shortens the chain max(lane) + separator + tail by at least two; graphs that do not fall apart keep the
+    natural order."""
+    plan = pkg.api.plan_tile_order
+    for nt, band, wrap in [(13, 2, True), (13, 2, False), (20, 3, True), (38, 2, True), (9, 1, False), (14, 2, True)]:
+        mask = _band_mask(nt, band, wrap)
+        planned, perm, (la, lb) = plan(mask, nt - 1)
+        assert planned, (nt, band, wrap)
+        assert sorted(perm.tolist()) == list(range(nt)) and perm[nt - 1] == nt - 1
+        assert la >= lb >= 1
+        steps = la + (nt - la - lb)
+        assert steps <= nt - 2, (nt, steps)
+        closed = _closure_chain(mask.astype(bool), perm)
+        # lane A = positions [0, la), lane B = [la, la + lb): no tile couples them, also after fill
+        assert not closed[la:la + lb, :la].any()
+        # inside a lane the natural order is kept
+        inv = np.argsort(perm)
+        assert np.all(np.diff(inv[:la]) > 0) and np.all(np.diff(inv[la:la + lb]) > 0)
+    # the C2 ring: 12 free tiles, band of two, wrap-around -> two lanes of four, separator of four, tail
+    planned, perm, lanes = plan(_band_mask(13, 2, True), 12)
+    assert planned and lanes == (4, 4)
+    # a dense graph, a tiny one, and one whose free part is too short: natural order
+    for mask, fd in [(np.tril(np.ones((10, 10), dtype=np.uint8)), 9), (_band_mask(5, 1, False), 4), (_band_mask(13, 6, True), 12)]:
+        planned, perm, lanes = plan(mask, fd)
+        assert not planned and perm.tolist() == list(range(len(mask))) and lanes == (0, 0)
+    # a tail of several dense tiles (T_l_w block straddling) stays last and in order
+    mask = _band_mask(16, 2, True, tail=3)
+    planned, perm, (la, lb) = plan(mask, 13)
+    assert planned and perm[13:].tolist() == [13, 14, 15]
