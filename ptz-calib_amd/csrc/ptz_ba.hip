@@ -171,28 +171,28 @@ struct ptz_ba_batch {
 namespace {
 
 // dynamic LDS of k_schur: T table, scratch, staged entries, pair offsets, reduction strip
-// Elimination order of a reduced camera system at tile granularity.  m0: lower-triangular tile adjacency (nt x nt, natural
-// order, not closed under fill); tiles >= first_dense (T_l_w block, rhs row, padding) stay last, in place.  Looks for a
-// separator made of a prefix [0, w1) and an interval [m, m + w2) of the free tiles -- the two cuts of a ring whose images are
-// numbered along it, or the middle cut of a band -- such that the rest falls apart; the parts are dealt to two lanes that are
-// factored side by side (CholBatch::sched), the separator follows.  The dependent chain of the factorisation is then
-// max(lane) + separator + tail block columns instead of nt.  Returns false (natural order) unless that saves two or more.
-// perm[t] = position of natural tile t; lanes occupy positions [0, lane_a) and [lane_a, lane_a + lane_b), lane_a >= lane_b.
-inline bool plan_dissection(int nt, int first_dense, const unsigned char* m0, int* perm, int* lane_a, int* lane_b)
+// Elimination order of a reduced camera system at tile granularity.
+//
+// bisect_tiles: the tiles `ids` (natural numbers, ascending) with adjacency adj(a, e); looks for a separator made of a prefix
+// [0, w1) and an interval [m, m + w2) of the list -- the two cuts of a ring whose images are numbered along it, or the middle
+// cut of a band -- such that the rest falls apart; the parts are dealt to two lanes.  cls[i] = 0 / 1 (lane, 0 the longer) or
+// 2 (separator).  The dependent chain of the factorisation of these tiles is then max(lane) + separator instead of their
+// number; returns false unless that saves at least `min_saving`.
+template <typename Adj>
+inline bool bisect_tiles(const std::vector<int>& ids, Adj&& adj, int min_tiles, int min_saving, std::vector<int>& cls)
 {
-  const int nf = std::min(first_dense, nt);
-  if (nf < 6) return false;
-  auto adj = [&](int a, int e) { return a == e ? false : (a > e ? m0[a * nt + e] : m0[e * nt + a]) != 0; };
-  int best_cost = nt - 1;  // must beat nt - 2 + ... : accept only cost <= nt - 2
-  std::vector<int> best_lane(nf, -1), lane(nf), comp(nf), stack;
+  const int nf = (int)ids.size();
+  if (nf < min_tiles) return false;
+  int best_cost = nf + 1;
+  std::vector<int> comp(nf), stack;
   bool found = false;
+  cls.assign(nf, 2);
   for (int w1 = 0; w1 <= 4; ++w1)
     for (int w2 = 0; w2 <= 4; ++w2)
       for (int m = w1; m + w2 <= nf; ++m) {
         if (w2 == 0 && m > w1) break;
         if (w1 + w2 == 0) continue;
-        // free tiles outside the separator: connected components
-        int ncomp = 0;
+        int ncomp = 0;  // tiles outside the separator: connected components
         for (int t = 0; t < nf; ++t) comp[t] = (t < w1 || (t >= m && t < m + w2)) ? -2 : -1;
         for (int t = 0; t < nf; ++t) {
           if (comp[t] != -1) continue;
@@ -201,7 +201,7 @@ inline bool plan_dissection(int nt, int first_dense, const unsigned char* m0, in
           while (!stack.empty()) {
             const int u = stack.back(); stack.pop_back();
             for (int v = 0; v < nf; ++v)
-              if (comp[v] == -1 && adj(u, v)) { comp[v] = ncomp; stack.push_back(v); }
+              if (comp[v] == -1 && adj(ids[u], ids[v])) { comp[v] = ncomp; stack.push_back(v); }
           }
           ++ncomp;
         }
@@ -213,21 +213,69 @@ inline bool plan_dissection(int nt, int first_dense, const unsigned char* m0, in
         int la = 0, lb = 0;
         std::vector<int> lane_of(ncomp);
         for (int c : order) { if (la <= lb) { lane_of[c] = 0; la += size[c]; } else { lane_of[c] = 1; lb += size[c]; } }
-        const int cost = std::max(la, lb) + (w1 + w2) + (nt - nf);
-        if (cost > nt - 2 || cost >= best_cost + (found ? 0 : 1)) continue;
+        const int cost = std::max(la, lb) + (w1 + w2);
+        if (cost > nf - min_saving || cost >= best_cost) continue;
         found = true;
         best_cost = cost;
-        const int big = la >= lb ? 0 : 1;  // lane A is the longer one
-        for (int t = 0; t < nf; ++t) best_lane[t] = comp[t] < 0 ? 2 : (lane_of[comp[t]] == big ? 0 : 1);
+        const int big = la >= lb ? 0 : 1;  // lane 0 is the longer one
+        for (int t = 0; t < nf; ++t) cls[t] = comp[t] < 0 ? 2 : (lane_of[comp[t]] == big ? 0 : 1);
       }
-  if (!found) return false;
-  int pos = 0, na = 0, nb = 0;
-  for (int pass = 0; pass < 3; ++pass)
-    for (int t = 0; t < nf; ++t)
-      if (best_lane[t] == pass) { perm[t] = pos++; if (pass == 0) ++na; if (pass == 1) ++nb; }
+  return found;
+}
+
+// m0: lower-triangular tile adjacency (nt x nt, natural order, not closed under fill); tiles >= first_dense (T_l_w block, rhs
+// row, padding) stay last, in place.  The free tiles are bisected, and each lane once more when that shortens it (a band of
+// four tiles with two sub-diagonals: ends first, middle after): the order is lane 0 (its parts, its separator), lane 1, the
+// top separator, the tail.  Which block columns can then be factored side by side is read off the filled structure
+// (level_schedule); perm[t] = position of natural tile t; lanes at positions [0, lane_a) and [lane_a, lane_a + lane_b).
+// Returns false (natural order) unless the top-level bisection shortens the chain by two or more.
+inline bool plan_dissection(int nt, int first_dense, const unsigned char* m0, int* perm, int* lane_a, int* lane_b, bool nested = true)
+{
+  const int nf = std::min(first_dense, nt);
+  auto adj = [&](int a, int e) { return a == e ? false : (a > e ? m0[a * nt + e] : m0[e * nt + a]) != 0; };
+  std::vector<int> ids(nf), cls;
+  for (int t = 0; t < nf; ++t) ids[t] = t;
+  if (!bisect_tiles(ids, adj, 6, 2, cls)) return false;
+  int pos = 0, n_lane[2] = {0, 0};
+  for (int lane = 0; lane < 2; ++lane) {
+    std::vector<int> mine, sub;
+    for (int t = 0; t < nf; ++t) if (cls[t] == lane) mine.push_back(t);
+    n_lane[lane] = (int)mine.size();
+    if (nested && bisect_tiles(mine, adj, 4, 1, sub)) {
+      for (int pass = 0; pass < 3; ++pass)
+        for (size_t k = 0; k < mine.size(); ++k) if (sub[k] == pass) perm[mine[k]] = pos++;
+    }
+    else for (int t : mine) perm[t] = pos++;
+  }
+  for (int t = 0; t < nf; ++t) if (cls[t] == 2) perm[t] = pos++;
   for (int t = nf; t < nt; ++t) perm[t] = pos++;
-  *lane_a = na; *lane_b = nb;
+  *lane_a = n_lane[0]; *lane_b = n_lane[1];
   return true;
+}
+
+// Steps of the factorisation from the FILLED tile structure m (nt x nt, lower, in elimination order): block column t can be
+// factored once every column k < t with m[t][k] != 0 is done, so its step is one more than the largest of theirs; columns of
+// one step neither depend on nor couple with each other.  sched[step * CHOL_STEP_COLS + slot] = column or -1, ascending inside
+// a step.  A step with more than CHOL_STEP_COLS columns spills its extra columns into later steps (still correct: a column
+// may always be factored later than its earliest step as long as its dependants move with it -- so the levels are recomputed
+// with the spilled columns' new steps).  Returns the number of steps.
+inline int level_schedule(int nt, const unsigned char* m, int* sched)
+{
+  std::vector<int> level(nt, 0), used(nt + 1, 0);
+  for (int t = 0; t < nt; ++t) {
+    int lv = 0;
+    for (int k = 0; k < t; ++k)
+      if (m[t * nt + k]) lv = std::max(lv, level[k] + 1);
+    while (used[lv] >= CHOL_STEP_COLS) ++lv;  // (levels are at most nt - 1: column t has at most t predecessors)
+    level[t] = lv;
+    ++used[lv];
+  }
+  int steps = 0;
+  for (int t = 0; t < nt; ++t) steps = std::max(steps, level[t] + 1);
+  for (int i = 0; i < nt * CHOL_STEP_COLS; ++i) sched[i] = -1;
+  std::vector<int> fill(steps, 0);
+  for (int t = 0; t < nt; ++t) sched[level[t] * CHOL_STEP_COLS + fill[level[t]]++] = t;
+  return steps;
 }
 
 inline size_t schur_lds_bytes(int max_obs, int max_ent, int max_pair, int NC, int np)
@@ -347,7 +395,7 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.Dinv += (size_t)lo * nt * 4 * 16 * 16;
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
     if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
-    if (d.chol.sched) d.chol.sched += (size_t)lo * nt * 2;
+    if (d.chol.sched) d.chol.sched += (size_t)lo * nt * CHOL_STEP_COLS;
     if (d.tperm) d.tperm += (size_t)lo * nt;
     d.grp_ctl = b->d_ctl + 4 * g;
     d.host_ctl = b->h_ctl_dev + 4 * g;
@@ -1231,9 +1279,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (!getenv("PTZ_BA_DENSE_CHOL")) {
     const int nt = d.chol.np / CHOL_NB;
     bool dissect = true;
-    if (const char* e = getenv("PTZ_BA_ORDER")) dissect = strcmp(e, "natural") != 0;
+    bool nested = true;
+    if (const char* e = getenv("PTZ_BA_ORDER")) { dissect = strcmp(e, "natural") != 0; nested = strcmp(e, "flat") != 0; }
     std::vector<unsigned char> hm((size_t)n * nt * nt, 0);
-    std::vector<int> h_tperm((size_t)n * nt), h_sched((size_t)n * nt * 2, -1);
+    std::vector<int> h_tperm((size_t)n * nt), h_sched((size_t)n * nt * CHOL_STEP_COLS, -1);
     int max_steps = 0;
     bool any_plan = false;
     std::vector<unsigned char> m0((size_t)nt * nt);
@@ -1268,21 +1317,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       for (int a = first_dense; a < nt; ++a)
         for (int e = 0; e <= a; ++e) m0[a * nt + e] = 1;
       int* perm = h_tperm.data() + (size_t)i * nt;
-      int* sched = h_sched.data() + (size_t)i * nt * 2;
+      int* sched = h_sched.data() + (size_t)i * nt * CHOL_STEP_COLS;
       int lane_a = 0, lane_b = 0;
-      const bool planned = dissect && sd.n_grp == 0 && plan_dissection(nt, first_dense, m0.data(), perm, &lane_a, &lane_b);
+      const bool planned = dissect && sd.n_grp == 0 && plan_dissection(nt, first_dense, m0.data(), perm, &lane_a, &lane_b, nested);
       if (!planned) for (int t = 0; t < nt; ++t) perm[t] = t;
-      int steps = 0;
-      if (planned) {
-        any_plan = true;
-        for (int st = 0; st < lane_a; ++st, ++steps) { sched[2 * steps] = st; sched[2 * steps + 1] = st < lane_b ? lane_a + st : -1; }
-        for (int t = lane_a + lane_b; t < nt; ++t, ++steps) sched[2 * steps] = t;
-      }
-      else for (int t = 0; t < nt; ++t, ++steps) sched[2 * steps] = t;
-      max_steps = std::max(max_steps, steps);
-      if ((int)b->sched_kmin.size() < steps) b->sched_kmin.resize(steps, nt);
-      for (int st = 0; st < steps; ++st) b->sched_kmin[st] = std::min(b->sched_kmin[st], sched[2 * st]);  // (column 0 of a step is its smaller one)
-      if (dbg_t && i == 0) fprintf(stderr, "[ptz_ba_create] scene 0: %d tiles, elimination %s: lanes %d + %d, %d steps\n", nt, planned ? "dissected" : "natural", lane_a, lane_b, steps);
+      if (planned) any_plan = true;
       unsigned char* m = hm.data() + (size_t)i * nt * nt;
       for (int a = 0; a < nt; ++a)
         for (int e = 0; e <= a; ++e) {
@@ -1296,6 +1335,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
           for (int y = k + 1; y <= x; ++y)
             if (m[y * nt + k]) m[x * nt + y] = 1;
         }
+      // steps: from the filled structure when the order was planned, one block column after the other otherwise
+      int steps = 0;
+      if (planned) steps = level_schedule(nt, m, sched);
+      else for (int t = 0; t < nt; ++t, ++steps) sched[CHOL_STEP_COLS * steps] = t;
+      max_steps = std::max(max_steps, steps);
+      if ((int)b->sched_kmin.size() < steps) b->sched_kmin.resize(steps, nt);
+      for (int st = 0; st < steps; ++st) b->sched_kmin[st] = std::min(b->sched_kmin[st], sched[CHOL_STEP_COLS * st]);  // (slot 0 of a step holds its smallest column)
+      if (dbg_t && i == 0) fprintf(stderr, "[ptz_ba_create] scene 0: %d tiles, elimination %s: lanes %d + %d, %d steps\n", nt, planned ? "dissected" : "natural", lane_a, lane_b, steps);
     }
     const unsigned char* dm = nullptr;
     TRY(upload(b, hm, &dm));

@@ -298,13 +298,15 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
 }
 
 // block columns of step `step` of system `sys` (one-launch-per-step path)
-__device__ __forceinline__ void chol_step_columns(const CholBatch& cb, int sys, int step, int nt, int& c1, int& c2)
+__device__ __forceinline__ void chol_step_columns(const CholBatch& cb, int sys, int step, int nt, int (&col)[CHOL_STEP_COLS])
 {
-  c1 = c2 = -1;
+#pragma unroll
+  for (int c = 0; c < CHOL_STEP_COLS; ++c) col[c] = -1;
   if (step >= nt) return;
-  if (!cb.sched) { c1 = step; return; }
-  const int* sp = cb.sched + ((size_t)sys * nt + step) * 2;
-  c1 = sp[0]; c2 = sp[1];
+  if (!cb.sched) { col[0] = step; return; }
+  const int* sp = cb.sched + ((size_t)sys * nt + step) * CHOL_STEP_COLS;
+#pragma unroll
+  for (int c = 0; c < CHOL_STEP_COLS; ++c) col[c] = sp[c];
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int kk)
@@ -315,9 +317,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int kk)
   const int n = cb.n[sys];
   int k = kk;
   if (kk < 0) {  // the columns of step 0
-    int c1, c2;
-    chol_step_columns(cb, sys, 0, np / NB, c1, c2);
-    k = blockIdx.x == 0 ? c1 : c2;
+    int col[CHOL_STEP_COLS];
+    chol_step_columns(cb, sys, 0, np / NB, col);
+    k = -1;
+#pragma unroll
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) if ((int)blockIdx.x == c) k = col[c];
     if (k < 0) return;
   }
   if (k * NB > n) return;  // whole block column is padding (identity)
@@ -484,6 +488,22 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(CholBatch cb, int k, int
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// this thread's pieces of a 64 x 64 tile (row stride ld) into registers, all loads in flight together (256 threads).  The
+// buffer is ONE vector value (not an array): it is carried around the loop back-edge, and hipcc keeps arrays that are in scratch.
+typedef double d16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ d16 tile_fetch(const double* __restrict__ g, int ld)
+{
+  d16 r;
+#pragma unroll
+  for (int p = 0; p < (NB * NB / 2) / 256; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int row = idx >> 5, c2 = (idx & 31) * 2;
+    const double2 v = *reinterpret_cast<const double2*>(g + (size_t)row * ld + c2);
+    r[2 * p] = v.x; r[2 * p + 1] = v.y;
+  }
+  return r;
+}
+
 // ---- one launch per step (one block column, or two that do not couple) for a FEW systems: triangular solves folded into
 //      the trailing update ----------------------------------------------------------------------------------------------
 // Right-looking step k as ONE kernel: the workgroup of trailing tile (i, j), i >= j > k, first turns A_ik and A_jk into
@@ -544,16 +564,18 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  int col[2], nxt[2];
-  chol_step_columns(cb, sys, step, nt, col[0], col[1]);
-  chol_step_columns(cb, sys, step + 1, nt, nxt[0], nxt[1]);
-  if (col[0] < 0 && col[1] < 0) return;
+  int col[CHOL_STEP_COLS], nxt[CHOL_STEP_COLS];
+  chol_step_columns(cb, sys, step, nt, col);
+  chol_step_columns(cb, sys, step + 1, nt, nxt);
+  if (col[0] < 0) return;  // (slot 0 is used whenever the step has a column)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int m = nt - kmin - 1, ntri = m * (m + 1) / 2;
   if (bx >= ntri) {
     // the spare workgroups of the launch: full inverse of the diagonal tile of each column of the step (factored by the
     // previous launch), off the critical chain; the back-substitution multiplies by it instead of solving with it
-    const int k = col[bx - ntri];
+    int k = -1;
+#pragma unroll
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) if (bx - ntri == c) k = col[c];
     if (!cb.Linv || k < 0 || k * NB > n) return;
     double* Lk = smem;
     double* Di = smem + 3 * NB * LD;
@@ -569,16 +591,23 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   while (ii * (ii + 1) / 2 > bx) --ii;
   const int ti = kmin + 1 + ii, tj = kmin + 1 + (bx - ii * (ii + 1) / 2);
   if (ti * NB > n) return;  // padding
-  const bool next_diag = ti == tj && (ti == nxt[0] || ti == nxt[1]);
-  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
-  bool upd[2];
+  bool next_diag = false;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < CHOL_STEP_COLS; ++c) next_diag |= ti == tj && ti == nxt[c];
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  // the columns of the step this tile takes an update from: it lies behind them and L_ik and L_jk are both in the structure
+  // (kept in four scalars, not an array: a dynamically indexed local array goes to scratch memory)
+  static_assert(CHOL_STEP_COLS == 4, "four update slots below");
+  int u0 = -1, u1 = -1, u2 = -1, u3 = -1, nu = 0;
+#pragma unroll
+  for (int c = 0; c < CHOL_STEP_COLS; ++c) {
     const int k = col[c];
-    // tile (ti, tj) takes an update from column k when it lies behind it and L_ik and L_jk are both in the structure
-    upd[c] = k >= 0 && tj > k && k * NB <= n && (!tm || (tm[ti * nt + k] && tm[tj * nt + k]));
+    if (k >= 0 && tj > k && k * NB <= n && (!tm || (tm[ti * nt + k] && tm[tj * nt + k]))) {
+      if (nu == 0) u0 = k; else if (nu == 1) u1 = k; else if (nu == 2) u2 = k; else u3 = k;
+      ++nu;
+    }
   }
-  if (!upd[0] && !upd[1] && !next_diag) return;
+  if (nu == 0 && !next_diag) return;
   double* A = cb.A + (size_t)sys * np * np;
   double* Lk = smem;                    // [NB * LD]   L_kk
   double* As = Lk + NB * LD;            // [NB * LD]   L_ik
@@ -615,16 +644,15 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   // The step's columns in ascending order (a tile behind both -- a separator tile -- takes both updates, always in this
   // order).  The C tile is asked for after the first triangular solve has been issued, so that its sixteen strided loads do
   // not queue up in front of the operand tiles on the critical workgroup.
-  const int first = upd[0] ? 0 : 1;
-  if (upd[first]) operands(col[first]);
+  if (nu > 0) operands(u0);
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
-  if (upd[first]) update();
-  if (first == 0 && upd[1]) {
-    __syncthreads();  // all waves are done with the operand tiles of the first column
-    operands(col[1]);
+  if (nu > 0) update();
+  for (int u = 1; u < nu; ++u) {  // a tile behind several columns of the step (fetching the next L_kk ahead was tried: no gain)
+    __syncthreads();  // all waves are done with the operand tiles of the previous column
+    operands(u == 1 ? u1 : (u == 2 ? u2 : u3));
     update();
   }
   if (next_diag) {
@@ -641,22 +669,6 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
-}
-
-// this thread's pieces of a 64 x 64 tile (row stride ld) into registers, all loads in flight together (256 threads).  The
-// buffer is ONE vector value (not an array): it is carried around the loop back-edge, and hipcc keeps arrays that are in scratch.
-typedef double d16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ d16 tile_fetch(const double* __restrict__ g, int ld)
-{
-  d16 r;
-#pragma unroll
-  for (int p = 0; p < (NB * NB / 2) / 256; ++p) {
-    const int idx = p * 256 + threadIdx.x;
-    const int row = idx >> 5, c2 = (idx & 31) * 2;
-    const double2 v = *reinterpret_cast<const double2*>(g + (size_t)row * ld + c2);
-    r[2 * p] = v.x; r[2 * p + 1] = v.y;
-  }
-  return r;
 }
 
 // ---- left-looking column update: A_ij -= sum_{k < j} L_ik L_jk^T for the tiles (i, j), i >= j, of block column j -------
@@ -697,8 +709,8 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
   __shared__ short klist[1024];
   __shared__ int kcount;
   if (threadIdx.x < 64) {  // wave 0: 64 candidates at a time, all their loads in flight together, compacted in order by ballot
-    const int nq = cb.sched ? 2 * cb.n_steps : j;
-    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * 2 : nullptr;
+    const int nq = cb.sched ? CHOL_STEP_COLS * cb.n_steps : j;
+    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * CHOL_STEP_COLS : nullptr;
     int cnt = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
       const int qq = q0 + (int)threadIdx.x;
@@ -864,18 +876,24 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     int g = 0;
     const int n_steps = cb.sched ? cb.n_steps : nt;
     for (int st = n_steps - 1; st >= 0; --st) {
-      int col[2];
-      chol_step_columns(cb, sys, st, nt, col[0], col[1]);
-      if (col[0] >= 0 && col[0] * NB >= n) col[0] = -1;
-      if (col[1] >= 0 && col[1] * NB >= n) col[1] = -1;
-      if (col[0] < 0 && col[1] < 0) continue;
+      int col[CHOL_STEP_COLS];
+      chol_step_columns(cb, sys, st, nt, col);
+      bool any_col = false;
+#pragma unroll
+      for (int c = 0; c < CHOL_STEP_COLS; ++c) {  // padding columns drop out (their slot of the group stays empty)
+        if (col[c] >= 0 && col[c] * NB >= n) col[c] = -1;
+        any_col |= col[c] >= 0;
+      }
+      if (!any_col) continue;
+      static_assert(CHOL_STEP_COLS <= 4, "the diagonal inverses of a step share one group of four items");
       if (tid < 4) {
-        const int kd = tid == 0 ? (col[0] >= 0 ? col[0] : col[1]) : (tid == 1 && col[0] >= 0 ? col[1] : -1);
+        const int kd = tid == 0 ? col[0] : (tid == 1 ? col[1] : (tid == 2 ? col[2] : col[3]));
         items[4 * g + tid] = kd >= 0 ? BsItem{(long long)kd * (NB * NB), NB, kd * NB, kd * NB, 1} : BsItem{0, 0, 0, 0, 0};
       }
       ++g;
       int filled = 0;
-      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int c = 0; c < CHOL_STEP_COLS; ++c) {
         const int k = col[c];
         if (k < 0) continue;
         for (int t0 = 0; t0 < k; t0 += 64) {
@@ -988,11 +1006,11 @@ void chol_col_step_launch(const CholBatch& cb, int step, hipStream_t stream)
   }
   const int kmin = cb.sched ? cb.sched_kmin[step] : step;
   const int m = nt - kmin - 1;
-  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? (cb.sched ? 2 : 1) : 0), cb.count), dim3(256), smem, stream, cb, step, kmin);
+  if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? (cb.sched ? CHOL_STEP_COLS : 1) : 0), cb.count), dim3(256), smem, stream, cb, step, kmin);
 }
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
-  launch(chol_diag_kernel, dim3(k < 0 && cb.sched ? 2 : 1, cb.count), dim3(256), 0, stream, cb, k);
+  launch(chol_diag_kernel, dim3(k < 0 && cb.sched ? CHOL_STEP_COLS : 1, cb.count), dim3(256), 0, stream, cb, k);
 }
 void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream)
 {

@@ -182,6 +182,7 @@ __device__ __forceinline__ void block_reduce4(double (&v)[4], unsigned max_mask,
 // x[count][np].
 constexpr int CHOL_NB = 64;
 constexpr double CHOL_BIG = 1e300;
+constexpr int CHOL_STEP_COLS = 4;  // block columns one step of the schedule can hold
 struct CholBatch {
   int count = 0;
   int np = 0;             // padded order, multiple of CHOL_NB, >= max(n_i) + 1
@@ -208,10 +209,11 @@ struct CholBatch {
   // holding the rhs row is full).  Tiles outside the mask stay exactly zero and their panel / update work is skipped:
   // the tile-granular counterpart of the sparse Cholesky behind the reference's SPARSE_SCHUR (ptzray_optimizer.cc:471).
   const unsigned char* tmask = nullptr;
-  // Step schedule of the one-launch-per-step path: device [count][nt][2] block columns (or -1) that step s factors side by
-  // side -- two columns of one step never couple (the two arcs of a dissected ring), so their panels, updates and the
-  // diagonal tiles of the next step proceed in ONE launch and the dependent chain is as long as the longer arc plus the
-  // separator.  nullptr: step s = block column s.  n_steps: steps of the longest schedule in the batch.
+  // Step schedule of the one-launch-per-step path: device [count][nt][CHOL_STEP_COLS] block columns (or -1, ascending, slot 0
+  // always used) that step s factors side by side -- columns of one step never couple (the arcs of a dissected ring and their
+  // halves), so their panels, updates and the diagonal tiles of the next step proceed in ONE launch and the dependent chain is
+  // as long as the longest arc piece plus the separators.  nullptr: step s = block column s.  n_steps: steps of the longest
+  // schedule in the batch.
   const int* sched = nullptr;
   int n_steps = 0;
   const int* sched_kmin = nullptr;  // HOST memory [n_steps]: smallest block column any system factors in step s (sizes the launch)

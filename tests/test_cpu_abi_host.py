@@ -507,6 +507,23 @@ def _closure_chain(mask, perm):
     return m
 
 
+def _levels(closed, width=4):
+    """Earliest step of every block column of a filled structure, at most `width` columns per step (level_schedule)."""
+    nt = len(closed)
+    level = np.zeros(nt, dtype=int)
+    used = np.zeros(nt + 1, dtype=int)
+    for t in range(nt):
+        lv = 0
+        for k in range(t):
+            if closed[t, k]:
+                lv = max(lv, level[k] + 1)
+        while used[lv] >= width:
+            lv += 1
+        level[t] = lv
+        used[lv] += 1
+    return level
+
+
 def _band_mask(nt, band, wrap, tail=1):
     m = np.zeros((nt, nt), dtype=np.uint8)
     free = nt - tail
@@ -535,12 +552,20 @@ def test_tile_order_planner(pkg):
         closed = _closure_chain(mask.astype(bool), perm)
         # lane A = positions [0, la), lane B = [la, la + lb): no tile couples them, also after fill
         assert not closed[la:la + lb, :la].any()
-        # inside a lane the natural order is kept
-        inv = np.argsort(perm)
-        assert np.all(np.diff(inv[:la]) > 0) and np.all(np.diff(inv[la:la + lb]) > 0)
-    # the C2 ring: 12 free tiles, band of two, wrap-around -> two lanes of four, separator of four, tail
-    planned, perm, lanes = plan(_band_mask(13, 2, True), 12)
+        # the steps the library reads off the filled structure: columns of one step do not couple, every column comes after
+        # the columns it depends on, and the chain is shorter than the lanes-then-separator count whenever a lane was halved again
+        level = _levels(closed)
+        for a in range(nt):
+            for e in range(a):
+                if closed[a, e]:
+                    assert level[e] < level[a]
+        assert level.max() + 1 <= steps
+    # the C2 ring: 12 free tiles, band of two, wrap-around -> two lanes of four, each halved again (ends first, middle after),
+    # separator of four, tail: 3 + 4 + 1 = 8 steps instead of 13
+    mask = _band_mask(13, 2, True)
+    planned, perm, lanes = plan(mask, 12)
     assert planned and lanes == (4, 4)
+    assert _levels(_closure_chain(mask.astype(bool), perm)).max() + 1 == 8
     # a dense graph, a tiny one, and one whose free part is too short: natural order
     for mask, fd in [(np.tril(np.ones((10, 10), dtype=np.uint8)), 9), (_band_mask(5, 1, False), 4), (_band_mask(13, 6, True), 12)]:
         planned, perm, lanes = plan(mask, fd)
