@@ -440,11 +440,30 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   __shared__ double wstrip[4][64 * WP];
   double* ws = wstrip[threadIdx.x >> 6];
   const int q_end = cp[i + 1];
+  // Two memory round trips stand in front of an observation's arithmetic: its (pixel, ray id) record, then the ray's record
+  // that the id points to.  Both are fetched ahead -- the ids two trips of 64 observations ahead, the ray records one -- with
+  // unconditional loads (indices past the camera's end are clamped and their data unused), so a trip waits for neither.
+  typedef double d8 __attribute__((ext_vector_type(8)));
+  auto qclamp = [&](int q) { return max(min(q, q_end - 1), 0); };
+  auto load_rr = [&](int rid) {
+    const double2* r2 = reinterpret_cast<const double2*>(d.rayrec + (size_t)rid * 8);
+    const double2 a = r2[0], b = r2[1], c = r2[2], e = r2[3];
+    d8 v; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = e.x; v[7] = e.y;
+    return v;
+  };
+  float2 uv_c = d.cam_uv[qclamp(cp[i] + lane)];
+  d8 rr_c = load_rr(d.cam_ray[qclamp(cp[i] + lane)]);  // written by k_lin_ray of the same linearisation
+  float2 uv_n = d.cam_uv[qclamp(cp[i] + 64 + lane)];
+  int rid_n = d.cam_ray[qclamp(cp[i] + 64 + lane)];
   for (int q0 = cp[i]; q0 < q_end; q0 += 64) {
     const int q = q0 + lane;
+    const float2 uv = uv_c;
+    const d8 rr = rr_c;
+    rr_c = load_rr(rid_n);
+    uv_c = uv_n;
+    uv_n = d.cam_uv[qclamp(q + 128)];
+    rid_n = d.cam_ray[qclamp(q + 128)];
     if (q < q_end) {
-      const float2 uv = d.cam_uv[q];
-      const double* rr = d.rayrec + (size_t)d.cam_ray[q] * 8;  // written by k_lin_ray of the same linearisation
       const double Xr[3] = {rr[0], rr[1], rr[2]};
       double res[2], Jc[2][NW], Jr[2][3];
       ba_linearize<F>(cb, Xr, uv.x, uv.y, res, Jc, Jr);
