@@ -307,7 +307,16 @@ template <bool SMALL, typename Body>
 __device__ __forceinline__ void for_each_obs(const Dev& d, int a0, int a1, float4* obsbuf, Body&& body)
 {
   if (!SMALL) {
-    for (int a = a0; a < a1; ++a) body(d.obs_uv[a], d.obs_cam[a]);
+    // the next record is asked for before the current one is worked on (unconditional: past the end it re-reads the last)
+    float2 uvn = d.obs_uv[a0];
+    int cn = d.obs_cam[a0];
+    for (int a = a0; a < a1; ++a) {
+      const float2 uv = uvn;
+      const int c = cn;
+      const int an = min(a + 1, a1 - 1);
+      uvn = d.obs_uv[an]; cn = d.obs_cam[an];
+      body(uv, c);
+    }
     return;
   }
   constexpr int P = 8;
