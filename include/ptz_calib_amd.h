@@ -210,9 +210,12 @@ int32_t ptz_mfma_f64_peak(int32_t device_id, double* tflops);
 /* Host logic only (no device needed; used by the CPU tests): the elimination order ptz_ba_batch_create would give a reduced
  * camera system of nt 64-column tiles whose lower-triangular tile adjacency is mask[nt*nt] (row-major, non-zero = coupled),
  * tiles >= first_dense kept last.  perm[t] = position of tile t; lanes[0], lanes[1] = tiles of the two lanes that are
- * factored side by side (positions [0, lanes[0]) and [lanes[0], lanes[0] + lanes[1])).  Returns 1 if a dissection was
- * chosen, 0 for the natural order (perm = identity). */
-int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes);
+ * factored side by side (positions [0, lanes[0]) and [lanes[0], lanes[0] + lanes[1])).  sched (may be NULL): [nt * 4] the
+ * block columns (positions, -1 = none) each step of the factorisation handles, n_steps[0] their number -- read off the filled
+ * structure for a dissected order, one column per step otherwise.  Returns 1 if a dissection was chosen, 0 for the natural
+ * order (perm = identity). */
+int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes,
+                               int32_t* sched, int32_t* n_steps);
 
 /* Measured HBM rates of the device in GB/s: streaming read of 4 GB, and copy of 4 GB counted as read + write. */
 int32_t ptz_hbm_bandwidth(int32_t device_id, double* read_gbps, double* copy_gbps);

@@ -261,9 +261,12 @@ def plan_tile_order(mask, first_dense):
     nt = m.shape[0]
     perm = np.zeros(nt, dtype=np.int32)
     lanes = np.zeros(2, dtype=np.int32)
-    rc = lib().ptz_ba_plan_tile_order(nt, int(first_dense), _p(m), _p(perm), _p(lanes))
+    sched = np.zeros((nt, 4), dtype=np.int32)
+    n_steps = np.zeros(1, dtype=np.int32)
+    rc = lib().ptz_ba_plan_tile_order(nt, int(first_dense), _p(m), _p(perm), _p(lanes), _p(sched), _p(n_steps))
     if rc < 0:
         raise PtzError(rc, "ptz_ba_plan_tile_order")
+    plan_tile_order.last_schedule = sched[:int(n_steps[0])]
     return bool(rc), perm, (int(lanes[0]), int(lanes[1]))
 
 

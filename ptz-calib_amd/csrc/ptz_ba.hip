@@ -733,13 +733,32 @@ int32_t ptz_device_count(void)
   return n;
 }
 
-int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes)
+int32_t ptz_ba_plan_tile_order(int32_t nt, int32_t first_dense, const uint8_t* mask, int32_t* perm, int32_t* lanes,
+                               int32_t* sched, int32_t* n_steps)
 {
   if (nt <= 0 || !mask || !perm || !lanes) return PTZ_EINVAL;
   int la = 0, lb = 0;
   const bool planned = plan_dissection(nt, first_dense, mask, perm, &la, &lb);
   if (!planned) { for (int t = 0; t < nt; ++t) perm[t] = t; la = lb = 0; }
   lanes[0] = la; lanes[1] = lb;
+  if (sched && n_steps) {  // as ptz_ba_batch_create does: permuted mask, fill, levels
+    std::vector<unsigned char> m((size_t)nt * nt, 0);
+    for (int a = 0; a < nt; ++a)
+      for (int e = 0; e <= a; ++e)
+        if (mask[a * nt + e]) m[std::max(perm[a], perm[e]) * nt + std::min(perm[a], perm[e])] = 1;
+    for (int k = 0; k < nt; ++k)
+      for (int x = k + 1; x < nt; ++x) {
+        if (!m[x * nt + k]) continue;
+        for (int y = k + 1; y <= x; ++y)
+          if (m[y * nt + k]) m[x * nt + y] = 1;
+      }
+    if (planned) n_steps[0] = level_schedule(nt, m.data(), sched);
+    else {
+      for (int i = 0; i < nt * CHOL_STEP_COLS; ++i) sched[i] = -1;
+      for (int t = 0; t < nt; ++t) sched[CHOL_STEP_COLS * t] = t;
+      n_steps[0] = nt;
+    }
+  }
   return planned ? 1 : 0;
 }
 
