@@ -235,6 +235,16 @@ def test_ba_medium_parity(pkg, orc, seed):
     _check_ba_parity(pkg, orc, sc)
 
 
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_ba_c3_standin_parity(pkg, orc, ftype):
+    """BASELINE configs[2] (a WorldCup14-like match; the data set is not in the container) as the synthetic stand-in
+    tools/report_configs.py uses: 60 views x 300 obs/view, 1280 x 720 images, a 120-degree pan sweep that does not close
+    (a band, not a ring), PTZRay and PTZRayDist -- the factor run_ptz_ba selects for broadcast footage."""
+    sc = pkg.synth.make_scene(11 + ftype, 60, 300, factor_type=ftype, width=1280, height=720, pan_range_deg=120.0)
+    cam, summ = _check_ba_parity(pkg, orc, sc)
+    assert summ["termination_type"] == 0
+
+
 def test_ba_c2_parity(pkg, orc):
     """BASELINE C2 at full size: 200 views x 500 obs/view, one scene."""
     sc = pkg.synth.make_scene(0, 200, 500)
