@@ -447,13 +447,13 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
       chol_clear(d.chol, st);
     }
   }
-  if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
+  if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3(b->max_grp * NC, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_SCHUR);
   if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
-  if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 2), d);
+  if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 4) + (size_t)(d.chol.np / CHOL_NB) * (d.chol.np / CHOL_NB), d);
   b->prof_end();
   chol_factor_solve_profiled(d.chol, d.yc, st, b, sh.fused);
   if (d.shared) LAUNCH(k_group_expand<TYPE>, dim3(B), dim3(256), 0, d);
@@ -510,7 +510,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   enqueue_linearize<TYPE>(b);
   if (b->opt.jacobi_scaling) {
     LAUNCH(k_jacobi_scale<TYPE>, dim3((std::max(b->max_cam, b->max_ray) + 255) / 256, B), dim3(256), 0, d);
-    if (d.shared) LAUNCH(k_group_scale<TYPE>, dim3((b->max_grp * NC + 63) / 64, B), dim3(64), 0, d);
+    if (d.shared) LAUNCH(k_group_scale<TYPE>, dim3(b->max_grp * NC, B), dim3(64), 0, d);
     enqueue_linearize<TYPE>(b);
   }
   for (int g = 0; g < G; ++g) hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(64), 0, s0, b->dg[g]);

@@ -661,14 +661,16 @@ __global__ void k_group_scale(Dev d)
   constexpr int NC = Dims<TYPE>::NC;
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per (group, slot): the lanes stride over the members (a group can be all cameras of the scene), fixed butterfly
+  const int t = blockIdx.x, lane = threadIdx.x;
   const int g = t / NC, k = t % NC;
   if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   double sum = 0;
-  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  sum = wave_sum(sum);
   const double sc_g = 1.0 / (1.0 + sqrt(sum));
-  for (int e = gp[g]; e < gp[g + 1]; ++e) d.scale_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = sc_g;
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) d.scale_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = sc_g;
 }
 
 // LM diagonal of a shared slot: clamp(sum of the members' diagonal entries); each member carries an equal share so that
@@ -682,14 +684,15 @@ __global__ void k_group_diag(Dev d)
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   if (d.lm[sc].reuse_diagonal) return;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x, lane = threadIdx.x;  // one wave per (group, slot), as k_group_scale
   const int g = t / NC, k = t % NC;
   if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   double sum = 0;
-  for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  sum = wave_sum(sum);
   const double share = fmin(fmax(sum, d.opt.min_lm_diagonal), d.opt.max_lm_diagonal) / (double)(gp[g + 1] - gp[g]);
-  for (int e = gp[g]; e < gp[g + 1]; ++e) d.diag_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) d.diag_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
 }
 
 // gradient with the shared slots folded onto the representative (others 0); every other slot copied.
@@ -706,12 +709,14 @@ __global__ void k_group_grad(Dev d)
   for (int t = threadIdx.x; t < s.n_cam * NC; t += blockDim.x) d.gfold[(size_t)s.cam_off * NC + t] = d.gc[(size_t)s.cam_off * NC + t];
   __syncthreads();
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
-  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  for (int t = wv; t < s.n_grp * NC; t += nwv) {  // a wave per (group, slot), lanes over the members
     const int g = t / NC, k = t % NC;
     if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
     double sum = 0;
-    for (int e = gp[g]; e < gp[g + 1]; ++e) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
-    for (int e = gp[g]; e < gp[g + 1]; ++e)
+    for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
+    sum = wave_sum(sum);
+    for (int e = gp[g] + lane; e < gp[g + 1]; e += 64)
       d.gfold[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = (e == gp[g + 1] - 1) ? sum : 0.0;
   }
 }
@@ -732,18 +737,47 @@ __global__ __launch_bounds__(1024) void k_fold_system(Dev d)
   if (s.n_grp == 0) return;
   const int np = d.chol.np, n = s.n;
   double* A = d.chol.A + (size_t)sc * np * np;
-  extern __shared__ double v[];  // [n + 1]
+  extern __shared__ double v[];  // [n + 1], then the scene's tile mask (one byte per tile pair)
   __shared__ double dsum;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   auto at = [&](int i, int c) -> double& { return i >= c ? A[(size_t)i * np + c] : A[(size_t)c * np + i]; };
+  // Entries outside the tile structure are exactly zero (those tiles are never written), so neither summing nor clearing
+  // them does anything: a member row is visited only where its tile row meets the column's tile in the structure.  With 200
+  // members (the displacement group) that is a fifth of the matrix.
+  const int nt = np / CHOL_NB;
+  unsigned char* tml = reinterpret_cast<unsigned char*>(v + n + 2);
+  for (int t = threadIdx.x; t < nt * nt; t += blockDim.x) tml[t] = d.chol.tmask ? d.chol.tmask[(size_t)sc * nt * nt + t] : 1;
+  __syncthreads();
+  auto live = [&](int i, int c) { const int ti = i / CHOL_NB, tc = c / CHOL_NB; return tml[max(ti, tc) * nt + min(ti, tc)] != 0; };
   for (int g = 0; g < s.n_grp; ++g) {
     const int e0 = gp[g], e1 = gp[g + 1];
     const int rep = d.grp_mem[e1 - 1];
     for (int k = 0; k < NC; ++k) {
       if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
+      const bool all_cams = e1 - e0 == s.n_cam;  // (members are ascending camera ids: the group is every camera of the scene)
+      // rows idx(m) = m NC + k of the members that lie in tile ti: cameras [lo, hi]
+      auto cams_of_tile = [&](int ti, int& lo, int& hi) {
+        lo = max((ti * CHOL_NB - k + NC - 1) / NC, 0);
+        hi = min((ti * CHOL_NB + CHOL_NB - 1 - k) / NC, s.n_cam - 1);
+      };
+      const int nts = (n + CHOL_NB) / CHOL_NB;  // tiles of this scene's system (rows 0 .. n)
       for (int c = threadIdx.x; c <= n; c += blockDim.x) {
         double sum = 0;
-        for (int e = e0; e < e1; ++e) sum += at(d.grp_mem[e] * NC + k, c);
+        if (all_cams) {  // walk the tiles that meet column c's tile in the structure, then the few member rows inside each
+          const int tc = c / CHOL_NB;
+          for (int ti = 0; ti < nts; ++ti) {
+            if (!tml[max(ti, tc) * nt + min(ti, tc)]) continue;
+            int lo, hi;
+            cams_of_tile(ti, lo, hi);
+            for (int m = lo; m <= hi; ++m) sum += at(m * NC + k, c);
+          }
+        }
+        else {
+          for (int e = e0; e < e1; ++e) {
+            const int im = d.grp_mem[e] * NC + k;
+            if (live(im, c)) sum += at(im, c);
+          }
+        }
         v[c] = sum;
       }
       __syncthreads();
@@ -763,7 +797,21 @@ __global__ __launch_bounds__(1024) void k_fold_system(Dev d)
         }
         if (!member) {
           at(ri, c) = v[c];
-          for (int e = e0; e < e1 - 1; ++e) at(d.grp_mem[e] * NC + k, c) = 0.0;
+          if (all_cams) {
+            const int tc = c / CHOL_NB;
+            for (int ti = 0; ti < nts; ++ti) {
+              if (!tml[max(ti, tc) * nt + min(ti, tc)]) continue;
+              int lo, hi;
+              cams_of_tile(ti, lo, hi);
+              for (int m = lo; m <= hi; ++m) if (m != rep) at(m * NC + k, c) = 0.0;
+            }
+          }
+          else {
+            for (int e = e0; e < e1 - 1; ++e) {
+              const int im = d.grp_mem[e] * NC + k;
+              if (live(im, c)) at(im, c) = 0.0;
+            }
+          }
         }
       }
       __syncthreads();
@@ -774,7 +822,7 @@ __global__ __launch_bounds__(1024) void k_fold_system(Dev d)
         const int ia = d.grp_mem[e0 + a] * NC + k, ib = d.grp_mem[e0 + bq] * NC + k;
         double val = 0.0;
         if (a == bq) val = (a == e1 - e0 - 1) ? dsum : 1.0;
-        at(ia, ib) = val;
+        if (a == bq || live(ia, ib)) at(ia, ib) = val;  // (entries outside the structure are zero already)
       }
       __syncthreads();
     }
@@ -792,11 +840,12 @@ __global__ void k_group_expand(Dev d)
   const SceneDev s = d.scene[sc];
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   double* y = d.yc + (size_t)sc * d.chol.np;
-  for (int t = threadIdx.x; t < s.n_grp * NC; t += blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  for (int t = wv; t < s.n_grp * NC; t += nwv) {  // a wave per (group, slot), lanes over the members
     const int g = t / NC, k = t % NC;
     if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
     const double yr = y[d.grp_mem[gp[g + 1] - 1] * NC + k];
-    for (int e = gp[g]; e < gp[g + 1] - 1; ++e) y[d.grp_mem[e] * NC + k] = yr;
+    for (int e = gp[g] + lane; e < gp[g + 1] - 1; e += 64) y[d.grp_mem[e] * NC + k] = yr;
   }
 }
 
