@@ -276,6 +276,23 @@ def krt_solve(uv_ref, uv_cur, cam_ref, cam_cur_local, factor_type=0, trace=False
     return cam, s.as_dict(), tr
 
 
+def krt_solve_batch(rb, n_query=None, max_reproj_error=100.0, num_threads=1, **opt):
+    """run_ptz_reloc.cc:68-118 over the first n_query queries of a packed RelocBatch (synth.make_reloc_queries): returns
+    (cam_world [n, 15], list of summaries, accepted [n]).  num_threads deals whole queries to threads."""
+    n = rb.n_query if n_query is None else min(int(n_query), rb.n_query)
+    ptr = np.ascontiguousarray(rb.match_ptr[: n + 1], dtype=np.int64)
+    uv_ref = np.ascontiguousarray(rb.uv_ref, dtype=np.float32)
+    uv_cur = np.ascontiguousarray(rb.uv_cur, dtype=np.float32)
+    cam_ref = np.ascontiguousarray(rb.cam_ref[:n], dtype=np.float64)
+    cam = np.array(rb.cam_init[:n], dtype=np.float64).copy()
+    o = default_options(**opt)
+    summ = (LmSummary * n)()
+    acc = np.zeros(n, dtype=np.int32)
+    lib().orc_krt_solve_batch(C.c_int32(n), _p(ptr), _p(uv_ref), _p(uv_cur), _p(cam_ref), _p(cam), C.c_int32(int(rb.factor_type)),
+                              C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.c_int32(int(num_threads)))
+    return cam, [s.as_dict() for s in summ], acc
+
+
 def krt_check(summary: dict, cam_local, max_reproj_error: float) -> bool:
     s = LmSummary()
     for k, v in summary.items():

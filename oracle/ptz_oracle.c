@@ -2234,3 +2234,33 @@ int32_t orc_krt_check(const orc_lm_summary* s, const double* cam, double max_rep
   if (fov_x < 0 || fov_x > 170 || fov_y < 0 || fov_y > 170) return 0;
   return 1;
 }
+
+/* run_ptz_reloc.cc:68-118 as a loop over packed queries (see ptz_oracle.h) */
+int32_t orc_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                            const double* cam_ref_world, double* cam_cur_world, int32_t factor_type, double max_reproj_error,
+                            const orc_lm_options* o, orc_lm_summary* summaries, int32_t* accepted, int32_t num_threads)
+{
+  orc_lm_options oo = *o;
+  oo.num_threads = 1; /* the threads are spent on whole queries */
+  if (num_threads < 1) num_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(num_threads)
+  for (int32_t q = 0; q < n_query; ++q) {
+    orc_krt_problem p;
+    memset(&p, 0, sizeof(p));
+    p.n_match = (int32_t)(match_ptr[q + 1] - match_ptr[q]);
+    p.uv_ref = uv_ref + 2 * match_ptr[q];
+    p.uv_cur = uv_cur + 2 * match_ptr[q];
+    p.cam_ref = cam_ref_world + 15 * (size_t)q;
+    p.factor_type = factor_type;
+    double loc[15];
+    orc_krt_world_to_local(p.cam_ref, cam_cur_world + 15 * (size_t)q, loc);
+    orc_lm_summary s;
+    memset(&s, 0, sizeof(s));
+    orc_krt_solve(&p, loc, &oo, &s, NULL);
+    const int32_t ok = orc_krt_check(&s, loc, max_reproj_error);
+    if (ok) orc_krt_local_to_world(p.cam_ref, loc, factor_type, cam_cur_world + 15 * (size_t)q);
+    if (summaries) summaries[q] = s;
+    if (accepted) accepted[q] = ok;
+  }
+  return 0;
+}

@@ -194,6 +194,15 @@ void orc_krt_local_to_world(const double* cam_ref_world, const double* cam_cur_l
 /* KRTOptimizer::CheckResults gates (krt_optimizer.cc:504-533): returns 1 if accepted */
 int32_t orc_krt_check(const orc_lm_summary* s, const double* cam_cur_local, double max_reproj_error);
 
+/* The relocalization loop of run_ptz_reloc.cc:68-118 over many queries, each one KRTOptimizer as that loop uses it: initial
+ * camera into the reference view's local frame (krt_optimizer.cc:269-284), solve, CheckResults with max_reproj_error (:504-533),
+ * back to the world frame if accepted (:535-567; the camera is left untouched otherwise, :396-403).  The reference runs the
+ * queries one after the other (with Ceres' own threads inside each tiny solve); num_threads > 1 deals whole queries to that
+ * many threads instead -- the CPU baseline of the benchmark.  cam_cur_world: [15 * n_query] in = initial, out = refined. */
+int32_t orc_krt_solve_batch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur,
+                            const double* cam_ref_world, double* cam_cur_world, int32_t factor_type, double max_reproj_error,
+                            const orc_lm_options* o, orc_lm_summary* summaries, int32_t* accepted, int32_t num_threads);
+
 /* Pix2Ray initialisation (ptzray_optimizer.cc:768-797) for packed observations */
 void orc_pix2ray(const orc_ba_problem* p, const double* cam, double* ray);
 

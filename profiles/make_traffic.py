@@ -2,7 +2,7 @@
 """PMC summaries -> profiles/traffic_latest.json: HBM bytes per dispatch of every kernel family of bench.py's profile.
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a STREAMED read at half its size and a GATHERED one at
-its size -- calibrated on this pool's MI355X with tests/probes/fetch_calib.hip (profiles/r02_fetch_calibration.json: 0.5000 for
+its size -- calibrated on this pool's MI355X with tools/probes/hip/fetch_calib.hip (profiles/r02_fetch_calibration.json: 0.5000 for
 16-, 8- and 4-byte-per-lane unit-stride streams and for one 96-byte row per lane in row order; 1.00 / 1.02 for 96-byte rows /
 64-byte records at random positions).  So the x2 of MI355X_MICROARCH.md applies to the streamed part of a kernel's reads only:
     true_fetch = raw + min(raw, streamed / 2) ... with `streamed` = the bytes the kernel is KNOWN to read as streams,
@@ -36,7 +36,7 @@ STREAMS = {
 FAMILY = {"schur": ["k_schur"], "linearize": ["k_lin_ray", "k_lin_cam"], "eval": ["k_eval"], "ray_prep": ["k_ray_prep"],
           "chol_syrk": ["chol_update_col"], "chol_panel": ["chol_trsm"], "chol_backsolve": ["chol_backsolve", "chol_tile_inverse"]}
 out = {"workload_tag": args.tag,
-       "_note": "rocprofv3 --pmc passes on tests/probe_c4pmc.py (bench.py's C4 workload, one solve, one scene group); per-dispatch means over every "
+       "_note": "rocprofv3 --pmc passes on tools/probes/probe_c4pmc.py (bench.py's C4 workload, one solve, one scene group); per-dispatch means over every "
                 "dispatch of the solve, thin passes included.  hbm_bytes = calibrated fetch + WRITE_SIZE; see make_traffic.py for the calibration.",
        "kernels": {}, "families": {}}
 for k, v in s.items():

@@ -75,12 +75,13 @@ struct PassShape {
 struct ptz_ba_batch {
   int n_scene = 0, type = 0, nc = 4, device = 0;
   std::vector<SceneDev> scenes;
-  int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_chunk = 0;  // total_chunk: partial-sum slots (waves of 64 rays + 1 per scene)
+  int total_cam = 0, total_ray = 0, total_obs = 0, total_pair = 0, total_ent = 0, total_run = 0, total_chunk = 0;  // total_chunk: partial-sum slots (waves of 64 rays + 1 per scene)
   int ray_block = RAY_BLOCK;
   bool schur_tg = false;         // a camera with more observations than k_schur's LDS table holds: table in global memory
+  bool schur_w = false;          // PTZ_BA_SCHUR_W=1: round 2's Schur kernel over materialised W rows (kept for A/B measurements)
   bool gtab = false;             // camera tables too large for LDS: the GTAB instantiations read them from global memory
   int n_group_hint(int n) const { if (const char* e = getenv("PTZ_BA_STREAMS")) return std::max(1, atoi(e)); return n >= 32 ? 2 : 1; }
-  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0;
+  int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, max_cam_run = 0;
   ptz_lm_options opt;
   Dev d;
   std::vector<void*> allocs;
@@ -278,11 +279,14 @@ inline int level_schedule(int nt, const unsigned char* m, int* sched)
   return steps;
 }
 
-inline size_t schur_lds_bytes(int max_obs, int max_ent, int max_pair, int NC, int np)
+inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy)
 {
-  (void)max_ent; (void)max_pair;
-  // T rows of the largest camera, the reduction strip, the scene's tile order (one int per 64 columns)
-  return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 1) / 2 + 1);
+  // legacy (k_schur_w): T rows of the largest camera, the reduction strip, the scene's tile order (one int per 64 columns)
+  if (legacy) return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 1) / 2 + 1);
+  // k_schur: the reduction strip, the tile order, then ONE region that first holds, per observation of the largest camera, its T'
+  // row and the ray's direction (NW * 3 + 3 doubles rounded up to an odd count, NW <= NC) and later one sum per run (NW^2 | 1)
+  const size_t table = (size_t)max_obs * ((NC * 3 + 3) | 1), sums = (size_t)SCHUR_THREADS * ((NC * NC) | 1);
+  return sizeof(double) * ((size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 2) / 2 + std::max(table, sums) + 2);
 }
 
 template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
@@ -367,7 +371,8 @@ template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
   b->prof_begin(P_LIN);
   LAUNCH(k_cam_prep<TYPE>, dim3((b->max_cam + 63) / 64, b->n_scene), dim3(64), 0, d);
   PTZ_LAUNCH_RAY(k_lin_ray, dim3(sh.max_chunk, b->n_scene), sh.lin_smem, d);
-  LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
+  if (d.W) LAUNCH((k_lin_cam<TYPE, true>), dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);  // parity tests / legacy Schur path
+  else LAUNCH((k_lin_cam<TYPE, false>), dim3((b->max_cam + 3) / 4, b->n_scene), dim3(256), 0, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   if (d.shared) LAUNCH(k_group_grad<TYPE>, dim3(b->n_scene), dim3(256), 0, d);
   b->prof_end();
@@ -431,7 +436,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
   const int B = sh.slots;
   hipStream_t st = b->stream;
-  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC, d.chol.np);
+  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
@@ -450,7 +455,11 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   if (d.shared) LAUNCH(k_group_diag<TYPE>, dim3(b->max_grp * NC, B), dim3(64), 0, d);
   b->prof_end();
   b->prof_begin(P_SCHUR);
-  if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  if (b->schur_w) {
+    if (b->schur_tg) LAUNCH((k_schur_w<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+    else LAUNCH((k_schur_w<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  }
+  else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 4) + (size_t)(d.chol.np / CHOL_NB) * (d.chol.np / CHOL_NB), d);
@@ -471,7 +480,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
     const Dev& dd = d;
     b->prof_begin(P_LIN);
     PTZ_LAUNCH_RAY(k_lin_ray, dim3(sh.max_chunk, B), sh.lin_smem, dd);
-    LAUNCH(k_lin_cam<TYPE>, dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
+    if (dd.W && b->schur_w) LAUNCH((k_lin_cam<TYPE, true>), dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
+    else LAUNCH((k_lin_cam<TYPE, false>), dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
     if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
     b->prof_end();
@@ -544,13 +554,24 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   };
   std::vector<char> galive(G, 1);
   std::vector<int> enq(G, 0), shape_used;
+  // Watchdog.  The loop below only ever waits on words the DEVICE writes; if a launch was refused, a kernel faulted or the
+  // progress word stops moving for any other reason, nothing would ever clear the wait.  So whenever no group has made
+  // progress for `watchdog_ms`, every waiting group's stream is asked for its state: an error ends the solve with
+  // PTZ_ENODEVICE; an IDLE stream whose passes have all run without the progress word catching up is credited with them
+  // (`credit`) and fed further passes -- the pipeline degrades to enqueue-and-wait, results unchanged -- and a group that needs
+  // that more often than a solve has passes is given up on.  Never a spin without end, never a re-exec.
+  std::vector<int> credit(G, 0), stalls(G, 0);
+  double watchdog_ms = 50.0;
+  if (const char* e = getenv("PTZ_BA_WATCHDOG_MS")) watchdog_ms = std::max(0.1, atof(e));
+  double t_progress = now();
+  int watchdog_rc = PTZ_OK;
   int alive = G;
   while (alive > 0) {
     bool progressed = false;
     for (int g = 0; g < G; ++g) {
       if (!galive[g]) continue;
       if (__atomic_load_n(&b->h_ctl[4 * g + 1], __ATOMIC_ACQUIRE)) { galive[g] = 0; --alive; progressed = true; continue; }
-      if (enq[g] - __atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE) >= b->ahead) continue;
+      if (enq[g] - std::max(__atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE), credit[g]) >= b->ahead) continue;
       const double te0 = now();
       b->stream = b->streams[g];
       const bool last = enq[g] == max_it;  // the last pass only closes the books (k_lm_pre)
@@ -573,11 +594,40 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       t_enq += now() - te0;
       if (last) { galive[g] = 0; --alive; }
     }
-    if (!progressed) {
-      const double ts0 = now();
-      __builtin_ia32_pause();
-      t_sync += now() - ts0;
+    if (progressed) { t_progress = now(); continue; }
+    const double ts0 = now();
+    __builtin_ia32_pause();
+    if (ts0 - t_progress > watchdog_ms) {
+      for (int g = 0; g < G && watchdog_rc == PTZ_OK; ++g) {
+        if (!galive[g]) continue;
+        const hipError_t q = hipStreamQuery(b->streams[g]);
+        if (q == hipErrorNotReady) continue;  // still working: a long pass, not a stall
+        const hipError_t le = hipGetLastError();
+        if (q != hipSuccess || le != hipSuccess) {
+          fprintf(stderr, "[ptz_ba] scene group %d: the device reported %s after %d enqueued LM passes; giving up on this solve\n", g,
+                  hipGetErrorName(q != hipSuccess ? q : le), enq[g]);
+          watchdog_rc = PTZ_ENODEVICE;
+          break;
+        }
+        // idle and healthy: everything enqueued has run.  Retired meanwhile?  Then the next sweep sees it.
+        if (__atomic_load_n(&b->h_ctl[4 * g + 1], __ATOMIC_ACQUIRE)) continue;
+        if (__atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE) >= enq[g]) continue;  // the word caught up
+        if (++stalls[g] > max_it + 8) {
+          fprintf(stderr, "[ptz_ba] scene group %d: no progress reports from the device (%d enqueued passes ran to completion without one); giving up on this solve\n", g, enq[g]);
+          watchdog_rc = PTZ_ENODEVICE;
+          break;
+        }
+        credit[g] = enq[g];
+      }
+      if (watchdog_rc != PTZ_OK) break;
+      t_progress = now();
     }
+    t_sync += now() - ts0;
+  }
+  if (watchdog_rc != PTZ_OK) {
+    for (int g = 0; g < G; ++g) (void)hipStreamSynchronize(b->streams[g]);  // nothing of this batch may be in flight when the caller frees it
+    (void)hipGetLastError();
+    return watchdog_rc;
   }
   if (dbg) for (size_t k = 0; k < shape_used.size(); ++k) fprintf(stderr, "[ptz_ba] launch shape %zu (%d slots%s): %d passes\n", k, b->shapes[k].slots, b->shapes[k].compact ? ", compacted" : "", shape_used[k]);
   if (dbg) for (int g = 0; g < G; ++g) fprintf(stderr, "[ptz_ba] group %d: %d passes enqueued, %d reached by the device when the host stopped\n", g, enq[g], b->h_ctl[4 * g]);
@@ -802,8 +852,10 @@ namespace {
 struct PairBuild {
   std::vector<int> pci, pcj, pptr, pbrow;  // pptr: scene-local entry offsets (n_pair + 1); pbrow: first W row of camera cj
   std::vector<unsigned> ent;        // copied into the batch-wide array (in parallel, per wave) and released
+  std::vector<uint2> runs;          // k_schur's runs: {first entry (scene-local here), pair among the camera's | entries << 16}
+  std::vector<int> prun;            // first run of every pair (scene-local), n_pair + 1
   int64_t n_ent = 0;
-  int n_pair = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, err = PTZ_OK;
+  int n_pair = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, max_cam_run = 0, err = PTZ_OK;
 };
 
 // Where a scene's observation-side arrays go in the batch-wide host arrays (all offsets are prefix sums of the scene sizes,
@@ -811,9 +863,9 @@ struct PairBuild {
 struct ObsDest {
   float2* uv; int* cam; int* ray; int* camobs; int* camray; float2* camuv;  // + obs_off
   int* rayptr; double* w;                                      // + ray_off (+ scene index for the pointer array)
-  int* camptr; int* campair;                                   // + cam_off + scene index
+  int* camptr; int* campair; int* camrun;                      // + cam_off + scene index
   int* wpos;                                                   // + obs_off
-};
+};  // (member order = the order of the initialiser in ptz_ba_batch_create)
 
 void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm)
 {
@@ -962,6 +1014,34 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   for (int c = p.n_cam - 1; c >= 0; --c) if (cam_first[c] < 0) cam_first[c] = cam_first[c + 1];
   for (int c = 0; c <= p.n_cam; ++c) od.campair[c] = cam_first[c];
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_pair = std::max(out.max_cam_pair, cam_first[c + 1] - cam_first[c]);
+  // Runs of k_schur's second phase.  A camera's entries (its pairs one after the other) are cut into pieces of one length L
+  // that never straddle two pairs, L the smallest for which the camera has at most SCHUR_THREADS pieces: a thread of the
+  // camera's workgroup then sums exactly one piece, and all threads have the same amount of work whatever the lengths of the
+  // pairs.  (A view with more pairs than threads gets one run per pair and several rounds; k_schur then keeps its table in
+  // global memory, see schur_tg.)
+  out.prun.assign(npair + 1, 0);
+  for (int c = 0; c < p.n_cam; ++c) {
+    od.camrun[c] = (int)out.runs.size();
+    const int p0 = cam_first[c], p1 = cam_first[c + 1];
+    if (p1 == p0) continue;
+    int max_len = 0;
+    for (int pi = p0; pi < p1; ++pi) max_len = std::max(max_len, out.pptr[pi + 1] - out.pptr[pi]);
+    auto pieces = [&](int L) { int64_t n = 0; for (int pi = p0; pi < p1; ++pi) n += (out.pptr[pi + 1] - out.pptr[pi] + L - 1) / L; return n; };
+    int lo = 1, hi = max_len;  // smallest L in [1, max_len] with pieces(L) <= SCHUR_THREADS (max_len if there is none)
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (pieces(mid) <= SCHUR_THREADS) hi = mid; else lo = mid + 1;
+    }
+    const int L = std::min(lo, 65535);
+    for (int pi = p0; pi < p1; ++pi) {
+      out.prun[pi] = (int)out.runs.size();
+      for (int e = out.pptr[pi]; e < out.pptr[pi + 1]; e += L)
+        out.runs.push_back(make_uint2((unsigned)e, (unsigned)(pi - p0) | ((unsigned)std::min(L, out.pptr[pi + 1] - e) << 16)));
+    }
+    out.max_cam_run = std::max(out.max_cam_run, (int)out.runs.size() - od.camrun[c]);
+  }
+  od.camrun[p.n_cam] = (int)out.runs.size();
+  out.prun[npair] = (int)out.runs.size();
   out.n_pair = npair;
   out.n_ent = n_ent;
 }
@@ -1017,7 +1097,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<int> h_rayptr, h_camptr, h_pci, h_pcj, h_pptr;
   RawVec<unsigned> h_ent;
   std::vector<int> h_pbrow;
-  std::vector<int> h_campair;
+  std::vector<int> h_campair, h_camrun, h_prun;
+  std::vector<uint2> h_runs;
   std::vector<double> h_w, h_o3xyz;
   std::vector<float2> h_o3uv;
   std::vector<int> h_o3cam;
@@ -1049,7 +1130,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   {
     const size_t tr = (size_t)ray_base[n - 1] + problems[n - 1].n_ray, tc = (size_t)cam_base[n - 1] + problems[n - 1].n_cam;
     h_uv.resize(tot_obs); h_camuv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
-    h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n); h_campair.resize(tc + n); h_wpos.resize(tot_obs);
+    h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n); h_campair.resize(tc + n); h_camrun.resize(tc + n); h_wpos.resize(tot_obs);
   }
   b->ray_perm.resize((size_t)ray_base[n - 1] + problems[n - 1].n_ray);
   int n_threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -1089,7 +1170,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
                                 h_camobs.data() + obs_base[sidx], h_camray.data() + obs_base[sidx], h_camuv.data() + obs_base[sidx],
                                 h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
                                 h_camptr.data() + cam_base[sidx] + sidx, h_campair.data() + cam_base[sidx] + sidx,
-                                h_wpos.data() + obs_base[sidx]};
+                                h_camrun.data() + cam_base[sidx] + sidx, h_wpos.data() + obs_base[sidx]};
             build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k], b->ray_perm.data() + ray_base[sidx]);
           }
         };
@@ -1122,6 +1203,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       h_pcj.insert(h_pcj.end(), pb.pcj.begin(), pb.pcj.end());
       h_pbrow.insert(h_pbrow.end(), pb.pbrow.begin(), pb.pbrow.end());
       for (int v : pb.pptr) h_pptr.push_back(b->total_ent + v);
+      for (const uint2& r : pb.runs) h_runs.push_back(make_uint2(r.x + (unsigned)b->total_ent, r.y));
+      h_prun.insert(h_prun.end(), pb.prun.begin(), pb.prun.end());
+      s.run_off = b->total_run;
+      b->total_run += (int)pb.runs.size();
+      b->max_cam_run = std::max(b->max_cam_run, pb.max_cam_run);
       b->max_cam_obs = std::max(b->max_cam_obs, pb.max_cam_obs);
       b->max_cam_ent = std::max(b->max_cam_ent, pb.max_cam_ent);
       b->max_cam_pair = std::max(b->max_cam_pair, pb.max_cam_pair);
@@ -1207,6 +1293,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     up.add(h_pbrow, &d.pair_brow);
     up.add(h_pptr, &d.pair_ptr);
     up.add(h_campair, &d.cam_pair);
+    up.add(h_camrun, &d.cam_run);
+    up.add(h_runs, &d.run_rec);
+    up.add(h_prun, &d.pair_run);
     up.add(h_ent, &d.ent);
     up.add(h_w, &d.ray_w);
     up.add(h_o3uv, &d.o3_uv);
@@ -1264,7 +1353,10 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     if (disp) TRY(upload(b, h_grpcls, &d.grp_cls));
     TRY(b->alloc(&d.gfold, (size_t)b->total_cam * NC));
   }
-  TRY(b->alloc(&d.W, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
+  // W = Jc^T Jr rows are not materialised by the solver (k_schur rebuilds them from the rays); ptz_ba_batch_linearize allocates
+  // them when a caller asks for them, PTZ_BA_SCHUR_W=1 brings round 2's kernels back for A/B measurements
+  if (const char* e = getenv("PTZ_BA_SCHUR_W")) b->schur_w = atoi(e) != 0;
+  if (b->schur_w) TRY(b->alloc(&d.W, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
   TRY(b->alloc(&d.rayrec, (size_t)b->total_ray * 8));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 4));
   TRY(b->alloc(&d.partial_lin, (size_t)b->total_chunk * 2));
@@ -1413,6 +1505,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   b->left_looking = n >= 8;
   if (const char* e = getenv("PTZ_BA_CHOL_LEFT")) b->left_looking = atoi(e) != 0;
   if (const char* e = getenv("PTZ_BA_AHEAD")) b->ahead = std::max(1, atoi(e));
+  if (const char* e = getenv("PTZ_BA_DEBUG_STALL")) b->d.debug_stall = std::max(0, atoi(e));
   if (const char* e = getenv("PTZ_BA_GRAPH")) b->use_graph = atoi(e) != 0;
   b->ctl_groups = std::max(1, std::min(b->n_group, n));
   if (b->alloc(&b->d_ctl, (size_t)4 * b->ctl_groups) != PTZ_OK ||
@@ -1464,10 +1557,12 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // k_schur keeps a camera's T_a rows in LDS (up to ~1700 observations of one view); beyond that the table goes to global
   // memory.  What remains is the 16-bit position inside the camera-pair entry records: 65535 observations per view.
   if (b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
-  b->schur_tg = schur_lds_bytes(b->max_cam_obs, b->max_cam_ent, b->max_cam_pair, NC, b->d.chol.np) > 160 * 1024;
+  // (also when a view has more runs than a workgroup has threads -- more pairs than that: the several rounds k_schur then needs
+  // cannot reuse the table's LDS space for their sums)
+  b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w) > 160 * 1024 || (!b->schur_w && b->max_cam_run > SCHUR_THREADS);
   if (const char* e = getenv("PTZ_BA_SCHUR_GLOBAL_T")) b->schur_tg = atoi(e) != 0;
   if (b->schur_tg) {
-    const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 15));
+    const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * ((NC * 3 + 3) | 1));
     if (rc2) { ptz_ba_batch_destroy(b); return rc2; }
     for (auto& dgp : b->dg) dgp.Tbuf = b->d.Tbuf;
   }
@@ -1491,6 +1586,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
 #define PTZ_SET_ATTR(T)                        \
       raise_cap((const void*)k_schur<T, false>);      \
       raise_cap((const void*)k_schur<T, true>);       \
+      raise_cap((const void*)k_schur_w<T, false>);    \
+      raise_cap((const void*)k_schur_w<T, true>);     \
       raise_cap((const void*)k_eval<T, true, false>);       \
       raise_cap((const void*)k_eval<T, false, false>);      \
       raise_cap((const void*)k_lin_ray<T, true, false>);    \
@@ -1650,6 +1747,11 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   clear_stale_error(__func__);
   if (!b || !b->has_state || index < 0 || index >= b->n_scene) return PTZ_EINVAL;
   PTZ_DEVICE_GUARD(b->device);
+  if (W && !b->d.W) {  // the rows exist only for this call's callers (the solver does not materialise them)
+    const bool disp = b->type == PTZ_BA_PTZRayDistDisp;
+    const int rcw = b->alloc(&b->d.W, (size_t)b->total_obs * (disp ? 24 : b->type == PTZ_BA_PTZRayFxfyDist ? 18 : 16));
+    if (rcw) return rcw;
+  }
   const Dev& d = b->d;
   const int NC = b->nc;
   hipStream_t st = b->stream;

@@ -12,7 +12,9 @@ namespace {
 
 constexpr int RAY_BLOCK = 1024;  // most rays per workgroup in the ray-centric kernels (Dev::ray_block is the batch's actual value:
                                  // a few scenes use small workgroups so that one rig's 13 k rays spread over a hundred compute units)
-constexpr int EZS = 10;           // doubles per ray in the (E, z) record: 6 + 3, padded to a 16-byte multiple
+constexpr int EZS = 16;           // doubles per ray in the record k_schur gathers once per observation: E (6), z = E g_r (3), the
+                                  // functor's point Xn (3), a = sqrt(w) |X|^-1 s_r (3), sqrt(w) -- 128 bytes, one aligned line,
+                                  // written whole by k_ray_prep every pass
 // LDS / global stride of a camera block and of a candidate block: Dims<TYPE>::CBS (35 doubles: odd -> no same-field bank
 // conflicts; 41 with the displacement block) and Dims<TYPE>::CDS (19; 41)
 // W row stride: see Dims<TYPE>::WS
@@ -21,6 +23,7 @@ struct SceneDev {
   int n_cam, n_ray, n_obs, n_pair;
   int cam_off, ray_off, obs_off, pair_off;
   int ent_off;   // first camera-pair entry
+  int run_off;   // first run of k_schur (global index)
   int part_off;  // first partial-sum slot (one per WAVE of 64 rays, plus one for the 2D-3D terms: the reduction tree of the
                  // per-ray sums does not depend on the workgroup size, so a scene's bits do not depend on the batch it is in)
   int n_chunk;   // ceil(n_ray / Dev::ray_block)
@@ -67,7 +70,11 @@ struct Dev {
   const int* pair_ptr;  // [total_pair + n_scene] per scene n_pair + 1 entries, global entry index
   const int* cam_pair;  // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local pair range of each camera ci
   const unsigned* ent;  // low 16 bits: position of obs a in ci's observation list; high 16: position of obs b in cj's; ci > cj only
-  const int* pair_brow; // first W row of camera cj of every pair
+  const int* pair_brow; // first W row of camera cj of every pair (k_schur_w only)
+  // runs of k_schur: a camera's entries cut into at most SCHUR_THREADS pieces of equal length that never straddle two pairs
+  const int* cam_run;   // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local run range of each camera ci
+  const uint2* run_rec; // [total_run] {first entry (global index), pair (index among the camera's pairs, 16 bits) | entries << 16}
+  const int* pair_run;  // [total_pair + n_scene] per scene n_pair + 1 entries: scene-local first run of every pair
   const double* ray_w;
   // state: two buffers, LmState.cur selects the current one
   double* cam_x;  // [2][total_cam][15]
@@ -93,8 +100,8 @@ struct Dev {
   double* V;         // [total_ray][6]
   double* gr;        // [total_ray][3]
   double* diag_r;    // [total_ray][3]
-  double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), padding -- one record,
-                     // because the Schur kernel gathers both for every observation
+  double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), then what k_schur needs to
+                     // rebuild an observation's Jacobians (Xn, the ray-side factors, sqrt(w)) -- ONE record, one gather per observation
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
   double* Tbuf;      // [total_obs][NW * 3] or nullptr: T_a = W_a E rows of k_schur when a camera's do not fit in LDS
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
@@ -139,6 +146,7 @@ struct Dev {
   //   grp_ctl[2]  entries of the compacted scene list `act` (rebuilt by k_compact after every k_lm_pre); host_ctl[2] mirrors it
   int* grp_ctl;
   int* host_ctl;
+  int debug_stall;   // PTZ_BA_DEBUG_STALL (tests of the host's watchdog): k_lm_post stops posting progress after this many passes (0: never)
   // Compacted launches: once few scenes of a large batch are still active, the host enqueues passes whose grids cover only
   // `slots` scenes; blockIdx.y (or .x for the one-workgroup-per-scene kernels) is then a slot and act[slot] the scene.  The
   // host sizes those grids from a stale -- hence larger or equal -- count.  use_act = 0: slot == scene (full-size launches).
@@ -416,9 +424,12 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 
 // ---- lin_cam: per-camera blocks -------------------------------------------------------------------------
 // wave = camera: lanes stride over the camera's observation list, U = sum Jc^T Jc, g_c = sum Jc^T r,
-// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly; every lane also stores the row W_a = Jc^T Jr of its observation
-// (row index = position in the camera-major list, so a wave writes one contiguous stretch of W).
-template <int TYPE>
+// cost = 1/2 sum w |r|^2, reduced with a fixed butterfly.
+// WRITE_W (ptz_ba_batch_linearize only, for the parity tests): every lane also stores the row W_a = Jc^T Jr of its observation
+// (row index = position in the camera-major list, so a wave writes one contiguous stretch of W).  The solver itself never
+// materialises W: k_schur rebuilds the rows from the rays (round 2 wrote 96 B per observation here and gathered them back
+// 4.7 times each in k_schur).
+template <int TYPE, bool WRITE_W>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
@@ -446,8 +457,8 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   // wave-private LDS strip, then the wave stores the stretch with unit-stride lanes -- whole 128-byte lines per store
   // instruction.  (Lane-private 96-byte row stores fill the lines piecemeal and make the L2 fetch them first.)
   constexpr int WS = Dims<TYPE>::WS, NT = NW * 3, WP = WS + 1;  // odd LDS pitch
-  __shared__ double wstrip[4][64 * WP];
-  double* ws = wstrip[threadIdx.x >> 6];
+  __shared__ double wstrip[WRITE_W ? 4 : 1][WRITE_W ? 64 * WP : 1];
+  double* ws = wstrip[WRITE_W ? threadIdx.x >> 6 : 0];
   const int q_end = cp[i + 1];
   // Two memory round trips stand in front of an observation's arithmetic: its (pixel, ray id) record, then the ray's record
   // that the id points to.  Both are fetched ahead -- the ids two trips of 64 observations ahead, the ray records one -- with
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
       res[0] *= sw; res[1] *= sw;
 #pragma unroll
       for (int k = 0; k < NW; ++k) { const double m = sw * cb[CB_S + Dims<TYPE>::pos(k)]; Jc[0][k] *= m; Jc[1][k] *= m; }
-      {
+      if constexpr (WRITE_W) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const double m = sw * rr[3 + k]; Jr[0][k] *= m; Jr[1][k] *= m; }
         double* Wl = ws + lane * WP;
@@ -501,8 +512,8 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
         for (int l = 0; l <= k; ++l) U[e++] += Jc[0][k] * Jc[0][l] + Jc[1][k] * Jc[1][l];
       }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is private to this wave, its lanes run in lock step
-    {
+    if constexpr (WRITE_W) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is private to this wave, its lanes run in lock step
       const int n_el = min(64, q_end - q0) * WS;
       double* Wg = d.W + (size_t)q0 * WS;
 #pragma unroll
@@ -510,8 +521,8 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
         const int idx = t * 64 + lane;
         if (idx < n_el) Wg[idx] = ws[(idx / WS) * WP + (idx % WS)];
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is rewritten in the next trip
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is rewritten in the next trip
   }
   cost = wave_sum(cost);
 #pragma unroll
@@ -1006,9 +1017,18 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
     for (int k = 0; k < 6; ++k) E[k] = 0;
   }
   const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
-  // the record goes out whole (E, z = E g_r, padding) in five 16-byte stores
+  // The record goes out whole in eight 16-byte stores: E, z = E g_r, and -- from what k_lin_ray left in rayrec {X, Jacobi
+  // scales, weight} -- the ray side of an observation's Jacobians as k_schur rebuilds them (ba_pair_side): the functor's point
+  // Xn, a_l = sqrt(w) s_l / |X| (d res / d X_l = -MR[:, l] a_l after weighting and scaling) and sqrt(w).
+  const double2* rr2 = reinterpret_cast<const double2*>(d.rayrec + (size_t)gj * 8);
+  const double2 ra = rr2[0], rb = rr2[1], rc = rr2[2], rd = rr2[3];
+  const double Xray[3] = {ra.x, ra.y, rb.x};
+  double Xn[3], inv_n;
+  ba_ray_point<Dims<TYPE>::FACTOR>(Xray, Xn, inv_n);
+  const double sw = sqrt(rd.x), swn = sw * inv_n;
   const double rec[EZS] = {E[0], E[1], E[2], E[3], E[4], E[5],
-                           E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2, 0.0};
+                           E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2,
+                           Xn[0], Xn[1], Xn[2], swn * rb.y, swn * rc.x, swn * rc.y, sw};
   double2* out = reinterpret_cast<double2*>(d.E + (size_t)gj * EZS);
 #pragma unroll
   for (int k = 0; k < EZS / 2; ++k) out[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
@@ -1050,7 +1070,7 @@ constexpr int SCHUR_THREADS = PTZ_SCHUR_THREADS;
 // TG: a camera has more observations than the LDS table of T_a rows holds (~1700): the table lives in global memory instead
 // (d.Tbuf, camera-major like W; written and re-read by the same workgroup, so it stays in that compute unit's caches).
 template <int TYPE, bool TG>
-__global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAVES) void k_schur(Dev d)
+__global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAVES) void k_schur_w(Dev d)
 {
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW;
   constexpr int NU = NW * (NW + 1) / 2;
@@ -1067,7 +1087,6 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
   const int* cpair = d.cam_pair + s.cam_off + s.idx;
-  const int* pp = d.pair_ptr + s.pair_off + s.idx;
   const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   const int eb = 0;                                        // entries are addressed by global index
   double* T = TG ? d.Tbuf + (size_t)o0 * TS : lds;             // [no][TS]
@@ -1080,7 +1099,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   }
   auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
   const unsigned* ents = d.ent + eb;                // (a slot | b slot << 16), this camera's contiguous range
-  const int* pps = pp + pr0;                        // entry offsets of this camera's pairs (global entry index)
+  const int* pps = d.pair_ptr + s.pair_off + s.idx + pr0;  // entry offsets of this camera's pairs (global entry index)
   double bsum[NW], D[NU];
 #pragma unroll
   for (int k = 0; k < NW; ++k) bsum[k] = 0;
@@ -1241,6 +1260,283 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
         sys_at(A, np, scol(ci * NC + Dims<TYPE>::pos(el / NW)), scol(cj * NC + Dims<TYPE>::pos(el % NW))) = -v[0];
     }
   }
+}
+
+// ---- schur (round 3): the same row-block of the reduced system WITHOUT a materialised W ---------------------------------------
+// k_schur_w above gathers one stored 96-byte product row W_b per camera-pair entry -- 470 k entries = 45 MB per scene and pass
+// from a 9.6 MB array, at the fabric's row-gather rate, 7 x the kernel's algorithmic bytes -- and k_lin_cam writes those rows
+// (1 GB per launch of a 1000-scene batch).  But the two observations (a, b) of an entry look at ONE ray, and the Jacobians
+// of b depend on that ray and on camera cj only (not on the pixel): so nothing is stored per observation at all.
+//   Phase 1 (thread = observation a of camera ci): the ray's 128-byte record {E, z, Xn, ray-side factors, sqrt(w)} (k_ray_prep)
+//     is the only gather; Jc_a, Jr_a come from ba_pair_side's factored form with camera ci's block in scalar registers,
+//     W_a = Jc_a^T Jr_a and T_a = W_a E stay in registers, S_ii and b_i as before.  LDS keeps, per observation,
+//     T'_a = w |X|^-1 T_a diag(s_r)  and the functor's point Xn.
+//   Phase 2 (thread = RUN of entries): with ba_pair_side's factors of observation b -- MR = M R_j and G = [intrinsic columns |
+//     M x P], from Xn and camera cj's rotation and focal length --
+//        T_a W_b^T = -[(T'_a MR^T) G] blockdiag(I, Jl_j) diag(s_j)
+//     so an entry costs 3 + NW x 3 LDS reads and ~100 FP64 operations, no global load but its 4-byte record.  The camera's
+//     entry list (all its pairs, one after the other) is cut by the host into at most SCHUR_THREADS runs of equal length that
+//     never straddle two pairs (build_pairs): a thread sums ONE run in registers, so every lane of the workgroup has the same
+//     amount of work whatever the lengths of the pairs (they differ by a factor of 30 on a C2 rig, and a camera has only ~23 of
+//     them: 16-lane groups dealt pair by pair kept 40 % of the lanes busy).
+//   Phase 3: the run sums meet in LDS -- in the space of the T table, which is dead by then -- and are added up per pair in run
+//     order (fixed order: a scene's bits do not depend on the batch it is in); the product with Jl_j and the Jacobi scales is
+//     applied once per pair, on the sums.
+// FP64 VALU is the bound now; results differ from k_schur_w's in the last bits only (x = Px / Pz there,
+// Px * (1 / Pz) with a Newton reciprocal here; the sum over a pair's entries is grouped differently).
+#ifdef PTZ_SCHUR_STAMPS  // probe builds only: where a k_schur workgroup's time goes (one camera of slot 0, thread 0; 100 MHz wall clock)
+#define SC_STAMP(i) do { if (stamp_on) sc_t[i] = wall_clock64(); } while (0)
+#else
+#define SC_STAMP(i) do { } while (0)
+#endif
+template <int TYPE, bool TG>
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
+{
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR, CBS = Dims<TYPE>::CBS;
+  constexpr int NU = NW * (NW + 1) / 2;
+  constexpr int NT = NW * 3;
+  // row of the LDS table: T'_a (NW x 3), Xn (3), padded to an ODD number of doubles -- 15 for PTZRay -- so that rows whose
+  // numbers differ modulo 16 start on different bank pairs (the host orders a pair's entries accordingly, build_pairs)
+  constexpr int TS = (NT + 3) | 1;
+  constexpr int ROT0 = BaDims<F>::ROT0;
+  int ci, slot;
+  xcd_remap(ci, slot);
+  const int sc = scene_of_slot(d, slot);
+  if (sc < 0 || !d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (ci >= s.n_cam) return;
+  const LmState& st = d.lm[sc];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  const int o0 = cp[ci], no = cp[ci + 1] - o0;
+  const int* cpair = d.cam_pair + s.cam_off + s.idx;
+  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
+#ifdef PTZ_SCHUR_STAMPS
+  const bool stamp_on = slot == 0 && ci == (s.n_cam * 3) / 4 && threadIdx.x == 0;
+  long long sc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  SC_STAMP(0);
+  constexpr int PS = (NW * NW) | 1;  // doubles per run sum in LDS (odd pitch)
+  const int ntl = d.chol.np / CHOL_NB;
+  double* strip = lds;                                         // [waves][NW + NU] reduction strip of phase 1
+  int* tord = reinterpret_cast<int*>(strip + (SCHUR_THREADS / 64) * (NW + NU));  // the scene's tile order (identity without one)
+  double* tab = strip + (SCHUR_THREADS / 64) * (NW + NU) + (ntl + 2) / 2;        // T table, later the run sums
+  double* T = TG ? d.Tbuf + (size_t)o0 * TS : tab;             // [no][TS]
+  double* part = tab;                                          // [SCHUR_THREADS][PS]
+  for (int t = threadIdx.x; t < ntl; t += SCHUR_THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
+  auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
+  const double* camtab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
+  // ---- phase 1
+  {
+    const double* cbi = camtab + (size_t)ci * CBS;  // uniform: scalar loads, hoisted out of the loop
+    double Ri[9], Jli[9], kdi[F ? 5 : 1], dsi[F == 3 ? 3 : 1], sci[NW];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Ri[k] = cbi[CB_R + k]; Jli[k] = cbi[CB_JL + k]; }
+#pragma unroll
+    for (int k = 0; k < (F ? 5 : 1); ++k) kdi[k] = F ? cbi[CB_K + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < (F == 3 ? 3 : 1); ++k) dsi[k] = F == 3 ? cbi[CB_D + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sci[k] = cbi[CB_S + Dims<TYPE>::pos(k)];
+    const double fi = cbi[CB_F], fyi = F == 2 ? cbi[CB_FY] : fi;
+    double bsum[NW], D[NU];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bsum[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) D[k] = 0;
+    // the ray id of the NEXT trip is fetched with this trip's record (two dependent loads stand before the arithmetic)
+    int gj_n = d.cam_ray[o0 + min((int)threadIdx.x, max(no - 1, 0))];
+    for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
+      const int gj = gj_n;
+      gj_n = d.cam_ray[o0 + min(q + SCHUR_THREADS, no - 1)];
+      const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
+      const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];
+      const double e0 = r0.x, e1 = r0.y, e2 = r1.x, e3 = r1.y, e4 = r2.x, e5 = r2.y;
+      const double z0 = r3.x, z1 = r3.y, z2 = r4.x;
+      const double Xn[3] = {r4.y, r5.x, r5.y};
+      const double al[3] = {r6.x, r6.y, r7.x};
+      const double sw = r7.y;
+      // this observation's weighted, scaled Jacobians from the factored form: Jr = -MR diag(a), Jc = sqrt(w) [G with its
+      // rotation columns through Jl_i] diag(s_i); behind the camera (PTZRayDist) both are zero
+      double MR[2][3], G[2][NW], Jc[2][NW], Jr[2][3];
+      const bool front = ba_pair_side<F>(Ri, fi, fyi, kdi, dsi, Xn, MR, G);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) Jc[r][k] = G[r][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Jc[r][ROT0 + k] = G[r][ROT0] * Jli[k] + G[r][ROT0 + 1] * Jli[3 + k] + G[r][ROT0 + 2] * Jli[6 + k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) Jc[r][k] = front ? Jc[r][k] * (sw * sci[k]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Jr[r][k] = front ? -(MR[r][k] * al[k]) : 0.0;
+      }
+      double w[NT];
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) w[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
+      // T'_a = T_a diag(sqrt(w) a): the second observation's ray-side factors, folded into the row once
+      const double f0 = sw * al[0], f1 = sw * al[1], f2 = sw * al[2];
+      double* Tq = T + (size_t)q * TS;
+      int e = 0;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) {
+        const double w0 = w[3 * p], w1 = w[3 * p + 1], w2 = w[3 * p + 2];
+        bsum[p] += w0 * z0 + w1 * z1 + w2 * z2;
+        const double t0 = w0 * e0 + w1 * e1 + w2 * e3, t1 = w0 * e1 + w1 * e2 + w2 * e4, t2 = w0 * e3 + w1 * e4 + w2 * e5;
+        Tq[3 * p] = t0 * f0; Tq[3 * p + 1] = t1 * f1; Tq[3 * p + 2] = t2 * f2;
+#pragma unroll
+        for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
+      }
+      Tq[NT] = Xn[0]; Tq[NT + 1] = Xn[1]; Tq[NT + 2] = Xn[2];
+    }
+    // one pass of the block tree for all NW + NU sums (fixed order: lanes by butterfly, waves in wave order)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NV = NW + NU;
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
+    }
+    __syncthreads();  // also orders the T stores before phase 2
+  }
+  SC_STAMP(1);
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  {
+    // Diagonal block and right-hand side, one element per thread (the last wave's, so that the first waves start on the camera
+    // pairs at once): S_ii = U_i (2D-2D + annotation terms) + D_i^2 - sum T W^T (the latter only on the NW x NW 2D-2D
+    // columns), b_i = g_i - sum W z.  Every thread adds up its own element's wave partials, in wave order.
+    constexpr int NV = NW + NU, NE = NC * (NC + 1) / 2;
+    const int t = (int)threadIdx.x - (SCHUR_THREADS - 64);
+    const int gi = s.cam_off + ci;
+    auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };  // NC slot -> 2D-2D column
+    auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < SCHUR_THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
+    if (t >= 0 && t < NE) {
+      int p = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+      while ((p + 1) * (p + 2) / 2 <= t) ++p;
+      while (p * (p + 1) / 2 > t) --p;
+      const int qq = t - p * (p + 1) / 2;
+      double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
+      if (p == qq) {
+        const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+        v += Dd * Dd;
+      }
+      const int ip = ipos(p), iq = ipos(qq);
+      if (ip >= 0 && iq >= 0) v -= strip_sum(NW + ip * (ip + 1) / 2 + iq);
+      const int rp = scol(ci * NC + p), rq = scol(ci * NC + qq);
+      A[(size_t)rp * np + rq] = v;
+      A[(size_t)rq * np + rp] = v;
+    }
+    else if (t >= NE && t < NE + NC) {
+      const int p = t - NE, ip = ipos(p);
+      double v = d.gc[(size_t)gi * NC + p];
+      if (ip >= 0) v -= strip_sum(ip);
+      A[(size_t)s.n * np + scol(ci * NC + p)] = v;
+    }
+  }
+  SC_STAMP(2);
+  // ---- phase 2: off-diagonal blocks of row-block ci, one run of entries per thread
+  const unsigned* ents = d.ent;                    // (a slot | b slot << 16); only the a slot is read here
+  const int* pcj = d.pair_cj + s.pair_off + pr0;
+  const int* crun = d.cam_run + s.cam_off + s.idx;
+  const int run0 = crun[ci], nrun = crun[ci + 1] - run0;      // this camera's runs (scene-local numbers)
+  const uint2* runs = d.run_rec + s.run_off + run0;
+  const int* prun = d.pair_run + s.pair_off + s.idx + pr0;    // first run of each of this camera's pairs; prun[npr] = end of the last
+  // Without TG the host has cut the entries into at most SCHUR_THREADS runs: ONE round, after which the T table is dead and its
+  // LDS space takes the run sums.  With the T table in global memory (very many observations or pairs in one view) the runs
+  // may need several rounds; a pair that continues from the previous round adds to what that round stored.
+  for (int base = 0; base < nrun; base += SCHUR_THREADS) {
+    const int r = base + (int)threadIdx.x;
+    double acc[NW * NW];
+#pragma unroll
+    for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
+    if (r < nrun) {
+      const uint2 rr = runs[r];
+      const int e0 = (int)rr.x, cnt = (int)(rr.y >> 16);
+      const double* cbj = camtab + (size_t)pcj[rr.y & 0xffffu] * CBS;
+      unsigned ab = ents[e0];
+      double Rj[9], kj[F ? 5 : 1], dj[F == 3 ? 3 : 1];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
+      const double fj = cbj[CB_F], fyj = F == 2 ? cbj[CB_FY] : fj;
+#pragma unroll
+      for (int k = 0; k < (F ? 5 : 1); ++k) kj[k] = F ? cbj[CB_K + k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < (F == 3 ? 3 : 1); ++k) dj[k] = F == 3 ? cbj[CB_D + k] : 0.0;
+      for (int k = 0; k < cnt; ++k) {
+        const unsigned nx = ents[e0 + min(k + 1, cnt - 1)];
+        const double* Ta = T + (size_t)(ab & 0xffffu) * TS;
+        const double Xn[3] = {Ta[NT], Ta[NT + 1], Ta[NT + 2]};
+        double MR[2][3], G[2][NW];
+        if (ba_pair_side<F>(Rj, fj, fyj, kj, dj, Xn, MR, G)) {
+#pragma unroll
+          for (int p = 0; p < NW; ++p) {
+            const double t0 = Ta[3 * p], t1 = Ta[3 * p + 1], t2 = Ta[3 * p + 2];
+            const double u0 = t0 * MR[0][0] + t1 * MR[0][1] + t2 * MR[0][2];
+            const double u1 = t0 * MR[1][0] + t1 * MR[1][1] + t2 * MR[1][2];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) acc[p * NW + q] = fma(u1, G[1][q], fma(u0, G[0][q], acc[p * NW + q]));
+          }
+        }
+        ab = nx;
+      }
+    }
+    SC_STAMP(3);
+    // ---- phase 3: run sums -> pair sums -> parameters of camera cj -> the reduced system
+    if (!TG) __syncthreads();  // every thread is done with the T table
+    SC_STAMP(4);
+    if (r < nrun) {
+#pragma unroll
+      for (int k = 0; k < NW * NW; ++k) part[threadIdx.x * PS + k] = acc[k];
+    }
+    __syncthreads();
+    // (a) thread = (pair, element): the pair's runs of this round in run order, into the row of its first run
+    for (int it = threadIdx.x; it < npr * NW * NW; it += SCHUR_THREADS) {
+      const int pl = it / (NW * NW), el = it % (NW * NW);
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, SCHUR_THREADS);
+      if (ra >= rb) continue;  // (the pair has no run in this round)
+      double v = part[ra * PS + el];
+      for (int q = ra + 1; q < rb; ++q) v += part[q * PS + el];
+      part[ra * PS + el] = v;
+    }
+    __syncthreads();
+    SC_STAMP(5);
+    // (b) thread = (pair, row of the block): rotation columns from the camera frame to the parameters (x Jl_j), every column by
+    //     its Jacobi scale, into S_ij
+    for (int it = threadIdx.x; it < npr * NW; it += SCHUR_THREADS) {
+      const int pl = it / NW, p = it % NW;
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, SCHUR_THREADS);
+      if (ra >= rb) continue;
+      const bool first = prun[pl] - run0 >= base;  // else the pair continues from the previous round
+      const int cj = pcj[pl];
+      const double* cbj = camtab + (size_t)cj * CBS;
+      double row[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) row[q] = part[ra * PS + p * NW + q];
+      const double a0 = row[ROT0], a1 = row[ROT0 + 1], a2 = row[ROT0 + 2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) row[ROT0 + k] = a0 * cbj[CB_JL + k] + a1 * cbj[CB_JL + 3 + k] + a2 * cbj[CB_JL + 6 + k];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const double v = row[q] * cbj[CB_S + Dims<TYPE>::pos(q)];
+        double& dst = sys_at(A, np, scol(ci * NC + Dims<TYPE>::pos(p)), scol(cj * NC + Dims<TYPE>::pos(q)));
+        dst = first ? v : dst + v;
+      }
+    }
+    if (base + SCHUR_THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
+  }
+#ifdef PTZ_SCHUR_STAMPS
+  SC_STAMP(6);
+  if (stamp_on)
+    printf("k_schur cam %d: obs %d pairs %d runs %d | x10 ns: phase1 %lld, diag %lld, runs(thread 0) %lld, wait %lld, sums %lld, store %lld\n", ci, no, npr, nrun,
+           sc_t[1] - sc_t[0], sc_t[2] - sc_t[1], sc_t[3] - sc_t[2], sc_t[4] - sc_t[3], sc_t[5] - sc_t[4], sc_t[6] - sc_t[5]);
+#endif
 }
 
 // ---- schur_3d: rows of the T_l_w block in the reduced system (it is not coupled to the rays) ---------------------
@@ -1539,8 +1835,10 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 template <int TYPE>
 __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
 {
-  if (blockIdx.x == 0 && threadIdx.x == 0)  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
-    __hip_atomic_store(&d.host_ctl[0], ++d.grp_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
+    const int reached = ++d.grp_ctl[1];
+    if (!d.debug_stall || reached <= d.debug_stall) __hip_atomic_store(&d.host_ctl[0], reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int sc = scene_of_slot(d, blockIdx.x);
   if (sc < 0 || !d.active[sc]) return;
   const SceneDev s = d.scene[sc];

@@ -40,6 +40,21 @@ constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13,
 
 constexpr double kDblEps = 2.220446049250313e-16;
 
+// 1 / d for the throughput kernels: hardware seed + two Newton steps (5 instructions; the IEEE division is 12).  Within an ulp
+// or so of the quotient, not correctly rounded: used where the result feeds products that are summed anyway, never where the
+// reference's own arithmetic is reproduced bit for bit (residuals).  The host harness divides.
+PTZ_HD double rcp_nr(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / d;
+#endif
+}
+
 // cv::Rodrigues vector -> matrix (OpenCV 4.5.3 cvRodrigues2): theta < DBL_EPSILON -> I
 PTZ_HD void rodrigues(const double r[3], double R[9])
 {
@@ -292,6 +307,82 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
     Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k] + (TYPE == 3 ? delta * M[0][2] * Xn[k] : 0.0)) * inv_n;
     Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k] + (TYPE == 3 ? delta * M[1][2] * Xn[k] : 0.0)) * inv_n;
   }
+}
+
+// The Jacobians of one observation in the factored form the Schur complement's off-diagonal blocks use (k_schur, phase 2):
+// they depend on the camera and on the ray only, not on the pixel, so a camera-pair entry (a, b) -- two observations of ONE
+// ray -- rebuilds b's from the ray it shares with a instead of gathering a stored product row.  With Xn / inv_n from
+// ba_ray_point and P = R Xn:
+//   MR[2][3]:  d res / d X = -MR * inv_n                        (MR = M R, plus the displacement term of PTZRayDistDisp)
+//   G[2][NC]:  the camera columns of ba_linearize, except that the three rotation columns stay in the CAMERA FRAME,
+//              G[r][ROT0 + m] = (M[r] x P)[m], so that Jc[r][ROT0 + k] = sum_m G[r][ROT0 + m] Jl[3 m + k]
+//              (-M[r] . (Jl[:,k] x P) = Jl[:,k] . (M[r] x P)): the 3 x 3 product with Jl is the same for every observation of
+//              the camera and is applied once per camera pair, after the sum over the pair's entries.
+// Returns false where ba_linearize returns zero Jacobians (PTZRayDist behind the camera).  x = Px * iz here (ba_linearize
+// divides, as the reference functor does for its residual): the blocks differ from it in the last bit, nothing more.
+template <int TYPE>
+PTZ_HD bool ba_pair_side(const double* R, double f, double fy, const double* kd, const double* dsp, const double Xn[3],
+                         double MR[2][3], double G[2][BaDims<TYPE>::NC])
+{
+  constexpr int ROT0 = BaDims<TYPE>::ROT0;
+  const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
+  const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
+  const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
+  if (TYPE == 1 && Pz < 0) return false;
+  const double delta = TYPE == 3 ? dsp[0] + dsp[1] * f + dsp[2] * f * f : 0.0;
+  const double iz = rcp_nr(TYPE == 3 ? Pz + delta : Pz);
+  const double x = Px * iz, y = Py * iz;
+  double M[2][3];
+  if (TYPE == 0) {
+    const double fiz = f * iz;
+    M[0][0] = fiz; M[0][1] = 0.0; M[0][2] = -(fiz * x);
+    M[1][0] = 0.0; M[1][1] = fiz; M[1][2] = -(fiz * y);
+    G[0][0] = -x; G[1][0] = -y;
+    // M[r] x P with the zeros of M written out
+    G[0][ROT0] = -(M[0][2] * Py);       G[0][ROT0 + 1] = M[0][2] * Px - fiz * Pz;  G[0][ROT0 + 2] = fiz * Py;
+    G[1][ROT0] = fiz * Pz - M[1][2] * Py;  G[1][ROT0 + 1] = M[1][2] * Px;          G[1][ROT0 + 2] = -(fiz * Px);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      MR[0][k] = fiz * R[k] + M[0][2] * R[6 + k];
+      MR[1][k] = fiz * R[3 + k] + M[1][2] * R[6 + k];
+    }
+    return true;
+  }
+  double xd, yd, B[4], dk1[2];
+  brown(x, y, kd, xd, yd);
+  brown_jac(x, y, kd, B, dk1);
+  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+  if (TYPE == 2) {
+    G[0][0] = -xd; G[1][0] = 0;
+    G[0][1] = 0;   G[1][1] = -yd;
+    G[0][2] = -f * dk1[0];
+    G[1][2] = -fy * dk1[1];
+  }
+  else {
+    G[0][0] = -xd;
+    G[1][0] = -yd;
+    G[0][1] = -f * dk1[0];
+    G[1][1] = -f * dk1[1];
+    if (TYPE == 3) {
+      const double ddf = dsp[1] + 2.0 * dsp[2] * f;
+      G[0][0] -= M[0][2] * ddf;
+      G[1][0] -= M[1][2] * ddf;
+      const double pw[3] = {1.0, f, f * f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { G[0][ROT0 + 3 + k] = -M[0][2] * pw[k]; G[1][ROT0 + 3 + k] = -M[1][2] * pw[k]; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    G[r][ROT0] = M[r][1] * Pz - M[r][2] * Py;
+    G[r][ROT0 + 1] = M[r][2] * Px - M[r][0] * Pz;
+    G[r][ROT0 + 2] = M[r][0] * Py - M[r][1] * Px;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      MR[r][k] = M[r][0] * R[k] + M[r][1] * R[3 + k] + M[r][2] * R[6 + k] + (TYPE == 3 ? delta * M[r][2] * Xn[k] : 0.0);
+  }
+  return true;
 }
 
 // Residual, ray Jacobian and the camera-side DIRECTIONAL derivative p = Jc v of one observation, for a camera step v given as

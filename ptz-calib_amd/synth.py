@@ -52,6 +52,19 @@ class SplitMix64:
     def permutation_keys(self, n: int) -> np.ndarray:
         return self.u64(n)
 
+    def u64_at(self, offsets: np.ndarray) -> np.ndarray:
+        """The outputs u64() would return at positions count + 1 + offsets of the stream, without moving it."""
+        idx = np.uint64(self.count + 1) + np.asarray(offsets).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z = self.seed + idx * _GOLDEN
+            z = (z ^ (z >> np.uint64(30))) * _M1
+            z = (z ^ (z >> np.uint64(27))) * _M2
+            z = z ^ (z >> np.uint64(31))
+        return z
+
+    def skip(self, n: int) -> None:
+        self.count += n
+
 
 def rodrigues(rvec: np.ndarray) -> np.ndarray:
     """Vector -> rotation matrix (same formula as cv::Rodrigues)."""
@@ -92,6 +105,46 @@ def _rot_x(a):
 def _rot_y(a):
     c, s = math.cos(a), math.sin(a)
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _azimuth_window(width: int, f_min: float, distorted: bool, tilt_max: float) -> float:
+    """Half-width (radians) of the azimuth window outside which no ray of the +-35 degree elevation band can project into a
+    frame: with d = az + pan, the camera-frame point is (cos el sin d, .., ..) before the tilt (which leaves x alone) and
+    |z| <= 1, so u in [8, width - 8] needs cos el |sin d| <= x_lim = (width / 2 - 8) / (f_min rad_min), rad_min = 1 - 0.05 * 1.5
+    with distortion (r2 < 1.5 is part of the visibility test).  Behind the camera (|d| > 90 degrees) z is negative as long as
+    the tilt stays small; if any of this does not hold the window is the full circle (the dense evaluation)."""
+    x_lim = (0.5 * width - 8.0) / (f_min * (0.925 if distorted else 1.0))
+    s_lim = x_lim / math.cos(math.radians(35.0))
+    if s_lim >= 0.94 or tilt_max > math.radians(12.0):
+        return math.pi
+    return math.asin(s_lim) + math.radians(0.5)
+
+
+def _candidate_pairs(az: np.ndarray, pan: np.ndarray, window: float):
+    """(view, ray) index pairs with |az + pan| (mod 2 pi) <= window, view-major, rays ascending inside a view."""
+    n_ray = len(az)
+    if window >= math.pi:
+        return np.repeat(np.arange(len(pan)), n_ray), np.tile(np.arange(n_ray), len(pan))
+    two_pi = 2.0 * math.pi
+    a = np.mod(az, two_pi)
+    idx = np.argsort(a, kind="stable")
+    a_sorted = a[idx]
+    vi, pi_ = [], []
+    for i, pn in enumerate(pan):
+        c = (-pn) % two_pi  # the azimuth this view looks at
+        lo, hi = c - window, c + window
+        parts = []
+        if lo < 0.0:
+            parts.append(idx[np.searchsorted(a_sorted, lo + two_pi, "left"):])
+            lo = 0.0
+        if hi > two_pi:
+            parts.append(idx[: np.searchsorted(a_sorted, hi - two_pi, "right")])
+            hi = two_pi
+        parts.append(idx[np.searchsorted(a_sorted, lo, "left"): np.searchsorted(a_sorted, hi, "right")])
+        p = np.sort(np.concatenate(parts))
+        vi.append(np.full(len(p), i, dtype=np.int64))
+        pi_.append(p)
+    return np.concatenate(vi), np.concatenate(pi_)
 
 
 @dataclass
@@ -182,24 +235,31 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
     # --- candidate world rays, uniform in the band |elevation| <= 35 deg.  The ray count P is sized
     #     (deterministic fixed point) so that ~2.2x the target observations are visible: keeping ~45 %
     #     of them per view then gives tracks of mean length ~5 after Filter(4).
+    # Only (view, ray) pairs that CAN be visible are ever evaluated: a ray at azimuth az is seen by a view at pan angle pan
+    # only if |az + pan| (mod 360) is below a bound that follows from the frame width, the shortest focal length and the
+    # elevation band (derivation at _azimuth_window).  The arithmetic per pair is the dense generator's, element for element
+    # (round 2 evaluated all N x P pairs, 2.4 s per C2 scene; tests/golden/scene_hashes.json holds this one to its bits).
     target_total = N * obs_per_view
     half = math.pi if pan_range_deg >= 360.0 else math.radians(0.5 * pan_range_deg + 30.0)
+    window = _azimuth_window(width, float(focal.min()), factor_type != 0, float(np.abs(tilt).max()))
     P = int(round(target_total / 3.2))
     for _attempt in range(4):
         az = rng.uniform(P, -half, half)
         sin_el = rng.uniform(P, -math.sin(math.radians(35.0)), math.sin(math.radians(35.0)))
         cos_el = np.sqrt(1.0 - sin_el ** 2)
         X = np.stack([cos_el * np.sin(az), sin_el, cos_el * np.cos(az)], axis=1)  # unit, z forward at pan 0
+        vi, pi_ = _candidate_pairs(az, pan, window)  # view-major, rays ascending inside a view
         # exact projections and visibility (>= 8 px inside the frame)
-        Pc = np.einsum("nij,pj->npi", Rgt, X)  # [N,P,3]
-        z = Pc[:, :, 2]
+        X0, X1, X2 = X[pi_, 0], X[pi_, 1], X[pi_, 2]
+        Pc = [Rgt[:, i, 0][vi] * X0 + Rgt[:, i, 1][vi] * X1 + Rgt[:, i, 2][vi] * X2 for i in range(3)]
+        z = Pc[2]
         with np.errstate(divide="ignore", invalid="ignore"):
-            x = Pc[:, :, 0] / z
-            y = Pc[:, :, 1] / z
+            x = Pc[0] / z
+            y = Pc[1] / z
             r2 = x * x + y * y
-            rad = 1.0 + k1[:, None] * r2
-            u = focal[:, None] * x * rad + cx
-            v = focal[:, None] * y * rad + cy
+            rad = 1.0 + k1[vi] * r2
+            u = focal[vi] * x * rad + cx
+            v = focal[vi] * y * rad + cy
         vis = (z > 0.1) & (u >= 8) & (u <= width - 8) & (v >= 8) & (v <= height - 8) & (r2 < 1.5)
         ratio = 2.2 * target_total / max(int(vis.sum()), 1)
         if 0.92 < ratio < 1.08 or _attempt == 3:
@@ -208,31 +268,36 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
 
     # --- per view keep a seeded random subset; tune the per-view quota so that, after dropping
     #     tracks shorter than min_track_len, the mean is ~obs_per_view (deterministic fixed point)
-    keys = rng.permutation_keys(N * P).reshape(N, P)
-    keys = np.where(vis, keys >> np.uint64(1), np.uint64(0xFFFFFFFFFFFFFFFF))
-    order = np.argsort(keys, axis=1, kind="stable")  # visible ones first, in random order
-    nvis = vis.sum(axis=1)
+    # (the dense generator drew one key per (view, ray) cell, cell (i, p) the (i P + p + 1)-th of the stream: the visible
+    #  cells' keys are evaluated at those positions and the stream moves on by N P)
+    vi, pi_, u, v = vi[vis], pi_[vis], u[vis], v[vis]
+    keys = rng.u64_at(vi.astype(np.int64) * P + pi_) >> np.uint64(1)
+    rng.skip(N * P)
+    order = np.lexsort((pi_, keys, vi))  # per view: ascending key, ties by ray number (as a stable argsort of the dense row)
+    vi, pi_, u, v = vi[order], pi_[order], u[order], v[order]
+    nvis = np.bincount(vi, minlength=N)
+    first = np.concatenate([[0], np.cumsum(nvis)[:-1]])
+    rank = np.arange(len(vi)) - first[vi]  # position of the pair in its view's random order
     quota = float(obs_per_view) * 1.15
-    keep = None
+    sel = None
     for _ in range(6):
-        keep = np.zeros_like(vis)
         q = np.minimum(nvis, int(round(quota)))
-        for i in range(N):
-            keep[i, order[i, : q[i]]] = True
-        tl = keep.sum(axis=0)
-        keep &= (tl >= min_track_len)[None, :]
-        mean_obs = keep.sum() / N
+        sel = rank < q[vi]
+        tl = np.bincount(pi_[sel], minlength=P)
+        sel &= tl[pi_] >= min_track_len
+        mean_obs = sel.sum() / N
         if abs(mean_obs - obs_per_view) < 0.01 * obs_per_view:
             break
         quota *= obs_per_view / max(mean_obs, 1.0)
-    ray_ids = np.nonzero(keep.any(axis=0))[0]
+    vi, pi_, u, v = vi[sel], pi_[sel], u[sel], v[sel]
+    ray_ids = np.unique(pi_)
     n_ray = len(ray_ids)
-    keep = keep[:, ray_ids]
     # observation list sorted (ray asc, cam asc)
-    rr, cc = np.nonzero(keep.T)
+    o = np.lexsort((vi, pi_))
+    cc, rr = vi[o], np.searchsorted(ray_ids, pi_[o])
     n_obs = len(rr)
-    uu = u[:, ray_ids][cc, rr] + rng.normal(n_obs, noise_px)
-    vv = v[:, ray_ids][cc, rr] + rng.normal(n_obs, noise_px)
+    uu = u[o] + rng.normal(n_obs, noise_px)
+    vv = v[o] + rng.normal(n_obs, noise_px)
     obs_uv = np.stack([uu, vv], axis=1).astype(np.float32)
     obs_cam = cc.astype(np.int32)
     obs_ray = rr.astype(np.int32)
@@ -434,16 +499,75 @@ def make_reloc_queries(n_query: int, n_match: int = 128, seed_id: int = 0, facto
                       cam_ref=cam_ref, cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
 
 
+_SCENE_ARRAYS = ("obs_uv", "obs_cam", "obs_ray", "ray_weight", "cam_gt", "cam_init", "ray_gt", "ray_init")
+
+
+def save_scene(path: str, sc: Scene) -> None:
+    """A generated scene as a plain .npz (arrays + a JSON header; no pickle), written atomically."""
+    import json
+    import os
+    head = dict(n_cam=sc.n_cam, n_ray=sc.n_ray, width=sc.width, height=sc.height, factor_type=sc.factor_type, seed=sc.seed, meta=sc.meta)
+    arrays = {k: getattr(sc, k) for k in _SCENE_ARRAYS}
+    if sc.ic_of_cam is not None:
+        arrays["ic_of_cam"] = sc.ic_of_cam
+    tmp = f"{path}.{os.getpid()}.tmp.npz"
+    np.savez(tmp, header=np.frombuffer(json.dumps(head).encode(), dtype=np.uint8), **arrays)
+    os.replace(tmp, path)
+
+
+def load_scene(path: str) -> Scene:
+    import json
+    with np.load(path, allow_pickle=False) as z:
+        head = json.loads(z["header"].tobytes().decode())
+        arrays = {k: z[k] for k in _SCENE_ARRAYS}
+        ic = z["ic_of_cam"] if "ic_of_cam" in z.files else None
+    return Scene(n_cam=head["n_cam"], n_ray=head["n_ray"], width=head["width"], height=head["height"], factor_type=head["factor_type"],
+                 seed=head["seed"], meta=head["meta"], ic_of_cam=ic, **arrays)
+
+
+def _scene_cache_path(cache_dir: str, scene_id: int, n_views: int, obs_per_view: int, kw: dict) -> str:
+    import hashlib
+    import os
+    tag = hashlib.sha256(repr(sorted(kw.items())).encode()).hexdigest()[:10] if kw else "default"
+    return os.path.join(cache_dir, f"scene_{SEED_BASE + scene_id:x}_{n_views}x{obs_per_view}_{tag}.npz")
+
+
 def _make_scene_job(args):
-    return make_scene(*args[0], **args[1])
+    (scene_id, n_views, obs_per_view), kw, cache_dir = args
+    sc = make_scene(scene_id, n_views, obs_per_view, **kw)
+    if cache_dir:
+        try:
+            save_scene(_scene_cache_path(cache_dir, scene_id, n_views, obs_per_view, kw), sc)
+        except OSError:
+            pass  # the cache is an optimisation only
+    return sc
 
 
-def make_scenes(scene_ids, n_views: int = 200, obs_per_view: int = 500, workers: int | None = None, **kw) -> list:
-    """make_scene for many ids on several host processes (a C2 scene takes 0.2-0.5 s of numpy; BASELINE C4 wants 1000).
-    Call BEFORE the process touches the GPU: the workers are forked."""
+def make_scenes(scene_ids, n_views: int = 200, obs_per_view: int = 500, workers: int | None = None,
+                cache_dir: str | None = None, **kw) -> list:
+    """make_scene for many ids on several host processes (a C2 scene takes ~0.4 s of numpy; BASELINE C4 wants 1000).
+    Call BEFORE the process touches the GPU: the workers are forked.  cache_dir: scenes are deterministic functions of their
+    arguments, so generated ones are kept there as .npz files and read back by later calls (bench.py at 1, 2, 4, 8 GPUs on one
+    node generates every scene once)."""
     import multiprocessing as mp
     import os
     ids = list(scene_ids)
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        out = {}
+        for i in ids:
+            path = _scene_cache_path(cache_dir, i, n_views, obs_per_view, kw)
+            if os.path.exists(path):
+                try:
+                    out[i] = load_scene(path)
+                except (OSError, ValueError, KeyError):
+                    pass  # unreadable (e.g. another rank is still writing under a different name): generate it
+        missing = [i for i in ids if i not in out]
+        if missing:
+            for i, sc in zip(missing, make_scenes(missing, n_views, obs_per_view, workers, None, _cache_to=cache_dir, **kw)):
+                out[i] = sc
+        return [out[i] for i in ids]
+    cache_to = kw.pop("_cache_to", None)
     if workers is None:
         try:
             workers = len(os.sched_getaffinity(0))
@@ -451,7 +575,7 @@ def make_scenes(scene_ids, n_views: int = 200, obs_per_view: int = 500, workers:
             workers = os.cpu_count() or 1
         workers = min(workers, 16)
     workers = max(1, min(workers, len(ids)))
-    jobs = [((i, n_views, obs_per_view), kw) for i in ids]
+    jobs = [((i, n_views, obs_per_view), kw, cache_to) for i in ids]
     if workers == 1:
         return [_make_scene_job(j) for j in jobs]
     with mp.get_context("fork").Pool(workers) as pool:

@@ -14,6 +14,25 @@ static void fill_camblk(const double* cam15, double* cb)
   for (int k = 0; k < 6; ++k) cb[CB_S + k] = 1.0;
 }
 
+// ba_pair_side (the factored Jacobians of k_schur's phase 2) brought back to ba_linearize's form: Jc = G with the rotation
+// columns taken through Jl, Jr = -MR / |X|.  type 0..3; disp only read for type 3.  Returns 0 for the zero-Jacobian branch.
+template <int T> static int pair_side_t(const double* cb, const double* ray, double* Jc, double* Jr)
+{
+  constexpr int NC = BaDims<T>::NC, ROT0 = BaDims<T>::ROT0;
+  double Xn[3], inv_n, MR[2][3], G[2][NC];
+  ba_ray_point<T>(ray, Xn, inv_n);
+  const bool ok = ba_pair_side<T>(cb + CB_R, cb[CB_F], T == 2 ? cb[CB_FY] : cb[CB_F], cb + CB_K, cb + CB_D, Xn, MR, G);
+  if (!ok) { for (int i = 0; i < 2 * NC; ++i) Jc[i] = 0; for (int i = 0; i < 6; ++i) Jr[i] = 0; return 0; }
+  const double* Jl = cb + CB_JL;
+  for (int r = 0; r < 2; ++r) {
+    for (int k = 0; k < NC; ++k) Jc[r * NC + k] = G[r][k];
+    for (int k = 0; k < 3; ++k)
+      Jc[r * NC + ROT0 + k] = G[r][ROT0] * Jl[k] + G[r][ROT0 + 1] * Jl[3 + k] + G[r][ROT0 + 2] * Jl[6 + k];
+    for (int k = 0; k < 3; ++k) Jr[r * 3 + k] = -MR[r][k] * inv_n;
+  }
+  return 1;
+}
+
 extern "C" {
 void h_rodrigues(const double* r, double* R, double* Jl) { rodrigues(r, R); so3_left_jacobian(r, Jl); }
 
@@ -136,6 +155,16 @@ void h_reproj2d3d(int factor, const double* cam15, const double* tlw, const doub
     for (int i = 0; i < 12; ++i) Jc[i] = (&jc[0][0])[i];
   }
   for (int i = 0; i < 12; ++i) Jt[i] = (&jt[0][0])[i];
+}
+int h_ba_pair_side(int type, const double* cam15, const double* disp, const double* ray, double* Jc, double* Jr)
+{
+  double cb[CAMBLK_DISP];
+  fill_camblk(cam15, cb);
+  for (int k = 0; k < 3; ++k) cb[CB_D + k] = disp ? disp[k] : 0.0;
+  if (type == 0) return pair_side_t<0>(cb, ray, Jc, Jr);
+  if (type == 1) return pair_side_t<1>(cb, ray, Jc, Jr);
+  if (type == 2) return pair_side_t<2>(cb, ray, Jc, Jr);
+  return pair_side_t<3>(cb, ray, Jc, Jr);
 }
 // PTZRayDistDisp: disp = (d0, d1, d2); Jc: [2][8] columns [f, k1, r1, r2, r3, d0, d1, d2]
 void h_ba_linearize_disp(const double* cam15, const double* disp, const double* ray, const float* uv, double* res, double* Jc, double* Jr)

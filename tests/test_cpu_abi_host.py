@@ -606,3 +606,83 @@ def test_tile_order_planner(pkg):
     mask = _band_mask(16, 2, True, tail=3)
     planned, perm, (la, lb) = plan(mask, 13)
     assert planned and perm[13:].tolist() == [13, 14, 15]
+
+
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3])
+def test_device_pair_side_equals_linearize(harness, ftype):
+    """ba_pair_side -- the factored Jacobians from which k_schur's phase 2 rebuilds the other camera's product row instead of
+    gathering it -- against ba_linearize: G with its rotation columns taken through Jl equals Jc, -MR / |X| equals Jr."""
+    rng = np.random.default_rng(40 + ftype)
+    nc = [4, 5, 6, 8][ftype]
+    for it in range(200):
+        cam = np.zeros(15); cam[0] = rng.uniform(1500, 3500); cam[1] = cam[0] * (1.03 if ftype == 2 else 1.0)
+        cam[2], cam[3] = 960, 540
+        cam[4:7] = rng.normal(0, 0.8, 3)
+        if ftype:
+            cam[10:15] = rng.uniform(-0.05, 0.05, 5) * np.array([1, 0.1, 0.01, 0.01, 0.01])
+        d = np.array([0.05, 2e-5, -1e-9]) * rng.uniform(0.5, 1.5) if ftype == 3 else np.zeros(3)
+        R = np.zeros(9); Jl = np.zeros(9)
+        harness.h_rodrigues(_p(cam[4:7].copy()), _p(R), _p(Jl))
+        ray = R.reshape(3, 3).T @ np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0]) * rng.uniform(0.7, 1.4)
+        if ftype == 1 and it % 20 == 0:
+            ray = -ray  # behind the camera: zero Jacobians on both paths
+        uv = np.array([rng.uniform(100, 1800), rng.uniform(100, 1000)], dtype=np.float32)
+        res = np.zeros(2); Jc = np.zeros((2, nc)); Jr = np.zeros((2, 3))
+        if ftype == 3:
+            harness.h_ba_linearize_disp(_p(cam), _p(d), _p(ray), _p(uv), _p(res), _p(Jc), _p(Jr))
+        else:
+            harness.h_ba_linearize(ftype, _p(cam), _p(ray), _p(uv), _p(res), _p(Jc), _p(Jr))
+        Jc2 = np.zeros((2, nc)); Jr2 = np.zeros((2, 3))
+        ok = harness.h_ba_pair_side(ftype, _p(cam), _p(d), _p(ray), _p(Jc2), _p(Jr2))
+        if ftype == 1 and it % 20 == 0:
+            assert ok == 0 and not Jc.any() and not Jr.any() and not Jc2.any() and not Jr2.any()
+            continue
+        assert ok == 1
+        for k in range(nc):  # per column: the displacement columns are twelve orders of magnitude apart
+            assert np.abs(Jc2[:, k] - Jc[:, k]).max() <= 1e-12 * np.abs(Jc[:, k]).max(), (k, Jc, Jc2)
+        assert np.abs(Jr2 - Jr).max() <= 1e-12 * np.abs(Jr).max()
+
+
+def test_scene_generator_reproduces_the_committed_hashes(pkg):
+    """synth.make_scene is a deterministic function of its arguments, and the committed fixtures (minima, trajectories) and
+    bench.py's workloads are made of its scenes: the generator may get faster (round 3 evaluates only the (view, ray) pairs
+    that can be visible), it may not move a bit.  tests/golden/scene_hashes.json was written by the dense round-2 generator
+    (tests/golden/gen_scene_hashes.py)."""
+    import hashlib
+    import json
+
+    def scene_hash(sc):
+        h = hashlib.sha256()
+        for a in (sc.obs_uv, sc.obs_cam, sc.obs_ray, sc.ray_weight, sc.cam_gt, sc.cam_init, sc.ray_gt, sc.ray_init):
+            h.update(a.tobytes())
+        h.update(repr((sc.n_cam, sc.n_ray, sc.n_obs)).encode())
+        return h.hexdigest()
+
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "scene_hashes.json")))
+    assert len(cases) >= 15
+    for c in cases:
+        if c["args"]["n_views"] * c["args"]["obs_per_view"] > 60000 and c["args"]["scene_id"] not in (0, 999):
+            continue  # (two of the three C2-sized scenes are enough for the CPU suite's time budget)
+        sc = pkg.synth.make_scene(**c["args"])
+        assert (sc.n_ray, sc.n_obs) == (c["n_ray"], c["n_obs"]), c["args"]
+        assert scene_hash(sc) == c["sha256"], c["args"]
+
+
+def test_scene_cache_round_trip(pkg, tmp_path):
+    """make_scenes(cache_dir=...): scenes written as .npz (no pickle) come back identical, including the ones with shared
+    intrinsics; a second call generates nothing."""
+    import dataclasses
+    for kw in ({}, {"factor_type": 1, "n_intrinsics_groups": 3}):
+        a = pkg.synth.make_scenes(range(3), 20, 100, workers=2, cache_dir=str(tmp_path), **kw)
+        n_files = len(os.listdir(tmp_path))
+        b = pkg.synth.make_scenes(range(3), 20, 100, workers=2, cache_dir=str(tmp_path), **kw)
+        assert len(os.listdir(tmp_path)) == n_files
+        fresh = [pkg.synth.make_scene(i, 20, 100, **kw) for i in range(3)]
+        for x, y, z in zip(a, b, fresh):
+            for f in dataclasses.fields(x):
+                u, v, w = getattr(x, f.name), getattr(y, f.name), getattr(z, f.name)
+                if isinstance(u, np.ndarray):
+                    assert np.array_equal(u, v) and np.array_equal(u, w) and u.dtype == v.dtype == w.dtype, f.name
+                else:
+                    assert u == v == w, f.name
+    assert len(os.listdir(tmp_path)) == 6

@@ -452,3 +452,20 @@ def test_oracle_krt_reaches_the_independent_minimum(pkg, orc, ftype):
         assert np.abs(orc.rodrigues(w[4:7]) - np.asarray(g["R_world"])).max() < 1e-7
         if ftype:
             assert abs(w[10] - g["k1"]) < 1e-7
+
+
+def test_oracle_krt_batch_driver_equals_the_per_query_calls(pkg, orc):
+    """orc_krt_solve_batch (the relocalization loop of run_ptz_reloc.cc:68-118 over packed queries; the CPU baseline of the
+    benchmark's C5 leg) gives, query by query, what the single-query entry points give, for any thread count."""
+    rb = pkg.synth.make_reloc_queries(48, 96, seed_id=3, factor_type=1)
+    cam1, summ1, acc1 = orc.krt_solve_batch(rb, num_threads=1, jacobian_mode=orc.JAC_NUMERIC)
+    cam4, summ4, acc4 = orc.krt_solve_batch(rb, num_threads=4, jacobian_mode=orc.JAC_NUMERIC)
+    assert np.array_equal(cam1, cam4) and summ1 == summ4 and np.array_equal(acc1, acc4)
+    for q in (0, 7, 19, 47):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=1, jacobian_mode=orc.JAC_NUMERIC)
+        good = orc.krt_check(osumm, loc, 100.0)
+        assert osumm == summ1[q] and bool(acc1[q]) == good
+        want = orc.krt_local_to_world(rb.cam_ref[q], loc, 1) if good else rb.cam_init[q]
+        assert np.array_equal(cam1[q], want)

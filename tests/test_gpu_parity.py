@@ -388,6 +388,31 @@ def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, 
     pkg.api.trim_cache()
 
 
+def test_ba_watchdog_recovers_when_progress_reports_stop(pkg, scene_c1, monkeypatch):
+    """The host keeps a few LM passes enqueued ahead of the device and waits on a progress word the DEVICE posts.  With
+    PTZ_BA_DEBUG_STALL=2 k_lm_post stops posting after two passes -- what a refused launch or a faulted kernel would look like
+    from the host's side.  The watchdog (ptz_ba.hip solve_impl) must notice the idle stream, credit the passes that ran and keep
+    feeding the pipeline: the call returns, and with the bits of an undisturbed solve; it must never spin without end."""
+    import time
+    ref = pkg.api.ba_solve(scene_c1)
+    assert ref[2]["num_lm_steps"] > 4  # the stall starts inside the solve
+    monkeypatch.setenv("PTZ_BA_DEBUG_STALL", "2")
+    monkeypatch.setenv("PTZ_BA_WATCHDOG_MS", "2")
+    for graph in ("1", "0"):
+        monkeypatch.setenv("PTZ_BA_GRAPH", graph)
+        t = time.perf_counter()
+        cam, ray, summ = pkg.api.ba_solve(scene_c1)
+        assert time.perf_counter() - t < 20.0
+        assert summ == ref[2] and np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1])
+    # a batch with two scene groups: each group has its own progress word
+    monkeypatch.setenv("PTZ_BA_STREAMS", "2")
+    scenes = [pkg.synth.make_scene(s % 3, 20 + 2 * (s % 3), 100) for s in range(6)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, _ = b.get_state(); b.close()
+    monkeypatch.delenv("PTZ_BA_DEBUG_STALL")
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ0 = b.solve(); cams0, _ = b.get_state(); b.close()
+    assert summ == summ0 and all(np.array_equal(a, c) for a, c in zip(cams, cams0))
+
+
 def test_ba_max_iterations_is_no_convergence(pkg, scene_c1):
     """Hitting max_num_iterations is NO_CONVERGENCE (the reference then returns false, ptzray_optimizer.cc:482)."""
     cam, ray, summ = pkg.api.ba_solve(scene_c1, max_num_iterations=2)

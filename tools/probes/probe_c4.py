@@ -1,6 +1,6 @@
 """Probe (not a test): the C4 batch (1000 distinct seeds) -- active scenes per pass, launch shapes used, time per solve."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()

@@ -1,6 +1,6 @@
 """Probe (not a test): PTZRayDistDisp on a C2-sized rig and in a batch of 64 -- time per LM iteration."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()

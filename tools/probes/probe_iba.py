@@ -1,6 +1,6 @@
 """Probe (not a test): the full incremental pipeline on one 200-view rig (bench.py's iba leg), three timed runs."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()

@@ -1,8 +1,8 @@
 """Probe: wall time of the PTZ-IBA orchestration (C++ PtzIncrementalOptimizer, all solves on the device)."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import __graft_entry__ as ge
 import host_util as hu
 

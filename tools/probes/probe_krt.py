@@ -1,6 +1,6 @@
 """C5 probe: batched relocalization, N queries x 128 matches (queries/s and LM iterations/s; device time only)."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 torch.cuda.init()  # torch's ROCm runtime first ("next to PyTorch")

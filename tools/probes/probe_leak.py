@@ -1,7 +1,7 @@
 """Probe (not a test): repeated create / solve / destroy cycles and single-view launches; device memory after ptz_trim_cache()
 must return to where it started (the pool parks blocks in between)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 torch.cuda.init()
 import numpy as np

@@ -1,6 +1,6 @@
 """Probe (not a test): per-pass wall time of the lock-step batch solve against the number of scenes still active."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

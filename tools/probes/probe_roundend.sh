@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}"; set -u
 # what the driver runs at round end: GPU suite, smoke(), default bench
 R=$GRAFT_REPO_ROOT; T=${1:-roundend}
 mkdir -p $R/gpurun_out/$T; cd $R

@@ -1,6 +1,6 @@
 """Plain workload for rocprofv3: B scenes, R solves, no in-library event profiling."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -1,5 +1,5 @@
 import json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 B = int(sys.argv[1])

@@ -1,6 +1,6 @@
 """Probe (not a test): create / solve / destroy cycles over all factor types and shapes; device memory must stay flat."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as ge
 pkg = ge.load_package()

@@ -1,6 +1,6 @@
 """Timing probe (not a test): per-kernel-family device time of the BA solve at several batch sizes."""
 import json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 import numpy as np
