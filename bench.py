@@ -266,6 +266,30 @@ def iba_leg(pkg, scene):
             "timing_ms": {k: round(float(v), 2) for k, v in r["timing_ms"].items()}}
 
 
+def iba_batch_leg(pkg, scenes, tables, device_id):
+    """Views calibrated / s as THROUGHPUT: N rigs through the full incremental pipeline in lock step (PtzIncrementalOptimizer::
+    SolveBatch, host/device_batcher.h) -- every round's bundle adjustments in one ptz_ba_batch, its registration attempts in one
+    ptz_krt_solve_batch launch; decisions identical to N solo runs (tests/test_gpu_configs.py).  The reference calibrates its
+    scenes one after the other (run_ptzba_synthetic.sh:4-13)."""
+    import numpy as np
+    cam0 = []
+    for tb in tables:
+        c = np.zeros((tb.n_img, 15)); c[:, 0] = c[:, 1] = 1.0
+        cam0.append(c)
+    pkg.hostlib.incremental_solve_batch(tables[:4], cam0[:4], max_iter=200, device_id=device_id)  # warm-up (resource pool, code objects)
+    t1 = time.perf_counter()
+    res, st = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id)
+    d1 = time.perf_counter() - t1
+    reg = sum(len(r["registered"]) for r in res)
+    ferr = [float(np.abs(r["cameras"][r["registered"], 0] / sc.cam_gt[r["registered"], 0] - 1).max()) for r, sc in zip(res, scenes) if r["registered"]]
+    return {"rigs": len(tables), "views": sum(tb.n_img for tb in tables), "registered": reg, "solved_rigs": sum(1 for r in res if r["ok"]),
+            "wall_ms": 1e3 * d1, "views_per_s": reg / d1, "lm_iterations": sum(r["lm_iterations"] for r in res),
+            "rounds": st["rounds"], "bundle_adjustments": st["ba_problems"], "bundle_adjustment_batches": st["ba_batches"],
+            "registration_launches": st["krt_launches"], "registration_attempts": st["krt_queries"],
+            "ms_in_batched_bundle_adjustments": st["ba_ms"], "ms_in_registration_launches": st["krt_ms"],
+            "max_focal_rel_error": max(ferr) if ferr else None}
+
+
 def cpu_baseline_leg(scenes, budget_s=12.0):
     """The reference-faithful CPU oracle ("port": central-difference Jacobians over all 18 block parameters as
     ceres::NumericDiffCostFunction, Ceres-1.14 LM policy, dense Schur) on scenes of the same workload: all usable host
@@ -339,6 +363,7 @@ def main():
     ap.add_argument("--scene-cache", default=os.environ.get("PTZ_SCENE_CACHE", "/tmp/ptz_scene_cache"),
                     help="directory for generated scenes (.npz, keyed by seed and shape; '' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--iba-rigs", type=int, default=64, help="rigs of the batched PTZ-IBA leg (0 skips it)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps: no single-rig / reloc / orchestration / CPU legs, so that a rocprofv3 --stats "
                          "summary of this command averages over the timed launch shape alone")
@@ -373,8 +398,13 @@ def main():
     rb_c5 = pkg.synth.make_reloc_queries(args.queries, 128, seed_id=1 + rank, factor_type=0) if args.config == "C5" else None
     extras = not args.headline_only
     c2_scene = None
+    iba_scenes, iba_tables = [], []
     if extras and rank == 0:
         c2_scene = base[0] if base else pkg.synth.make_scene(0, args.views, args.obs)
+        if args.config != "C5" and args.iba_rigs > 0:
+            iba_scenes = (base[: args.iba_rigs] if len(base) >= args.iba_rigs else
+                          pkg.synth.make_scenes(range(args.iba_rigs), args.views, args.obs, cache_dir=args.scene_cache or None))
+            iba_tables = pkg.synth.make_match_tables(iba_scenes)
     t_gen = time.perf_counter() - t_gen
 
     import torch
@@ -521,6 +551,8 @@ def main():
                 body["c5_reloc"] = RelocRun(pkg, pkg.synth.make_reloc_queries(min(args.queries, 20000), 128, seed_id=1, factor_type=0), local_rank).run(5)[1]
                 body["c5_reloc"]["note"] = "bounded sample of configs[4]; `bench.py --config C5` runs all 100 000 queries"
             body["ptz_iba"] = iba_leg(pkg, c2_scene)
+            if iba_tables:
+                body["ptz_iba_batch"] = iba_batch_leg(pkg, iba_scenes, iba_tables, local_rank)
         if world == 1 and extras and not args.no_cpu_baseline:
             body["c5_reloc"]["cpu_baseline"] = reloc_cpu_baseline_leg(pkg)
             if args.config == "C5":
@@ -540,6 +572,8 @@ def main():
             headline["c5_queries_per_s"] = body["c5_reloc"]["queries_per_s"]
         if "ptz_iba" in body:
             headline["ptz_iba_views_per_s"] = body["ptz_iba"]["views_per_s"]
+        if "ptz_iba_batch" in body:
+            headline["ptz_iba_batch_views_per_s"] = body["ptz_iba_batch"]["views_per_s"]
         if cpu is not None:
             headline["cpu_port_lm_iterations_per_s"] = cpu["value"]
         config.update({k: (round(v, 1) if isinstance(v, float) else v) for k, v in headline.items()})

@@ -168,7 +168,9 @@ int32_t ptz_ba_batch_get_profile(const ptz_ba_batch* b, double* ms_per_slot, int
  * cam/ray/tlw are updated in place. */
 int32_t ptz_ba_solve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt,
                      ptz_lm_summary* summary);
-/* The same for PTZRayDistDisp: disp [3] initial value in (NULL: zeros), refined value out. */
+/* The same for PTZRayDistDisp: disp [3] initial value in (NULL: zeros), refined value out.  cam[9] (t_z) is returned as the
+ * parameter block holds it; the reference's read-back also adds d0 + d1 fx + d2 fx^2 to it (ptzray_optimizer.cc:693, 714):
+ * that last step is the caller's (the C++ class PTZRayOptimizer and api.fold_displacement do it). */
 int32_t ptz_ba_solve_disp(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, double* disp,
                           const ptz_lm_options* opt, ptz_lm_summary* summary);
 

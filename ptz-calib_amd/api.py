@@ -239,7 +239,12 @@ def ba_solve(scene, cam0=None, ray0=None, tlw0=None, return_tlw=False, **opt):
 
 
 def ba_solve_disp(scene, cam0=None, ray0=None, tlw0=None, disp0=None, **opt):
-    """One-shot ptz_ba_solve_disp (PTZRayDistDisp).  Returns (cam, ray, summary dict, tlw, disp)."""
+    """One-shot ptz_ba_solve_disp (PTZRayDistDisp).  Returns (cam, ray, summary dict, tlw, disp).
+
+    The returned camera vectors hold the refined PARAMETER blocks: t_z (cam[:, 9]) comes back as it went in.  The reference's
+    ObtainRefinedCameraParams additionally folds the refined displacement into it, t_z += d0 + d1 fx + d2 fx^2
+    (ptzray_optimizer.cc:693, 714); the C++ class PTZRayOptimizer does that on read-back, this C-ABI level (and
+    ptz_ba_batch_get_state / get_disp) hands out the two blocks separately -- `fold_displacement(cam, disp)` applies it."""
     keep = []
     p = _pack_problem(scene, keep)
     cam = np.array(scene.cam_init if cam0 is None else cam0, dtype=np.float64, order="C").copy()
@@ -252,6 +257,13 @@ def ba_solve_disp(scene, cam0=None, ray0=None, tlw0=None, disp0=None, **opt):
     s = LmSummary()
     _check(lib().ptz_ba_solve_disp(C.byref(p), _p(cam), _p(ray), _p(tlw), _p(disp), C.byref(o), C.byref(s)), "ptz_ba_solve_disp")
     return cam, ray, s.as_dict(), tlw, disp
+
+
+def fold_displacement(cam, disp):
+    """ObtainRefinedCameraParams' last step for PTZRayDistDisp (ptzray_optimizer.cc:693, 714): t_z += d0 + d1 fx + d2 fx^2."""
+    out = np.array(cam, dtype=np.float64).copy()
+    out[:, 9] += disp[0] + disp[1] * out[:, 0] + disp[2] * out[:, 0] ** 2
+    return out
 
 
 def plan_tile_order(mask, first_dense):

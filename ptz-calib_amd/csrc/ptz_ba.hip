@@ -279,14 +279,20 @@ inline int level_schedule(int nt, const unsigned char* m, int* sched)
   return steps;
 }
 
-inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy)
+// threads of a k_schur workgroup = the most runs a camera's entries are cut into (ptz_ba_kernels.h schur_threads<TYPE>())
+inline int schur_threads_of(int factor_type) { (void)factor_type; return 256; }
+
+// NW: camera columns with a 2D-2D Jacobian (Dims<TYPE>::NW); max_ent: entries of the largest camera
+inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy, int threads, int NW = 0, int max_ent = 0)
 {
   // legacy (k_schur_w): T rows of the largest camera, the reduction strip, the scene's tile order (one int per 64 columns)
   if (legacy) return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 1) / 2 + 1);
   // k_schur: the reduction strip, the tile order, then ONE region that first holds, per observation of the largest camera, its T'
   // row and the ray's direction (NW * 3 + 3 doubles rounded up to an odd count, NW <= NC) and later one sum per run (NW^2 | 1)
-  const size_t table = (size_t)max_obs * ((NC * 3 + 3) | 1), sums = (size_t)SCHUR_THREADS * ((NC * NC) | 1);
-  return sizeof(double) * ((size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 2) / 2 + std::max(table, sums) + 2);
+  if (NW <= 0) NW = NC;
+  const size_t table = (size_t)max_obs * ((NW * 3 + 3) | 1), sums = (size_t)threads * ((NW * NW) | 1);
+  return sizeof(double) * ((size_t)(threads / 64) * (NW + NW * (NW + 1) / 2) + (size_t)(np / CHOL_NB + 2) / 2 + std::max(table, sums) + 2) +
+         2 * (size_t)((max_ent + 3) & ~3);
 }
 
 template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
@@ -436,7 +442,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
   const int B = sh.slots;
   hipStream_t st = b->stream;
-  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w);
+  const int schur_thr = schur_threads<TYPE>();
+  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w, schur_thr, Dims<TYPE>::NW, b->max_cam_ent);
   b->prof_begin(P_LMCTL);
   LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
@@ -459,8 +466,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
     if (b->schur_tg) LAUNCH((k_schur_w<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
     else LAUNCH((k_schur_w<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   }
-  else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
-  else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
+  else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 4) + (size_t)(d.chol.np / CHOL_NB) * (d.chol.np / CHOL_NB), d);
   b->prof_end();
@@ -867,7 +874,7 @@ struct ObsDest {
   int* wpos;                                                   // + obs_off
 };  // (member order = the order of the initialiser in ptz_ba_batch_create)
 
-void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm)
+void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm, int max_runs)
 {
   // Internal ray order: by track length, longest first, then by the track's first camera (stable).  The ray-centric kernels give one lane to a ray and walk its
   // observations; with the caller's order a wave of 64 rays waits for its longest track (4 .. 19 observations on a C2 rig, the
@@ -1015,7 +1022,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   for (int c = 0; c <= p.n_cam; ++c) od.campair[c] = cam_first[c];
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_pair = std::max(out.max_cam_pair, cam_first[c + 1] - cam_first[c]);
   // Runs of k_schur's second phase.  A camera's entries (its pairs one after the other) are cut into pieces of one length L
-  // that never straddle two pairs, L the smallest for which the camera has at most SCHUR_THREADS pieces: a thread of the
+  // that never straddle two pairs, L the smallest for which the camera has at most max_runs (= threads) pieces: a thread of the
   // camera's workgroup then sums exactly one piece, and all threads have the same amount of work whatever the lengths of the
   // pairs.  (A view with more pairs than threads gets one run per pair and several rounds; k_schur then keeps its table in
   // global memory, see schur_tg.)
@@ -1027,10 +1034,10 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
     int max_len = 0;
     for (int pi = p0; pi < p1; ++pi) max_len = std::max(max_len, out.pptr[pi + 1] - out.pptr[pi]);
     auto pieces = [&](int L) { int64_t n = 0; for (int pi = p0; pi < p1; ++pi) n += (out.pptr[pi + 1] - out.pptr[pi] + L - 1) / L; return n; };
-    int lo = 1, hi = max_len;  // smallest L in [1, max_len] with pieces(L) <= SCHUR_THREADS (max_len if there is none)
+    int lo = 1, hi = max_len;  // smallest L in [1, max_len] with pieces(L) <= max_runs (max_len if there is none)
     while (lo < hi) {
       const int mid = (lo + hi) / 2;
-      if (pieces(mid) <= SCHUR_THREADS) hi = mid; else lo = mid + 1;
+      if (pieces(mid) <= max_runs) hi = mid; else lo = mid + 1;
     }
     const int L = std::min(lo, 65535);
     for (int pi = p0; pi < p1; ++pi) {
@@ -1171,7 +1178,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
                                 h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
                                 h_camptr.data() + cam_base[sidx] + sidx, h_campair.data() + cam_base[sidx] + sidx,
                                 h_camrun.data() + cam_base[sidx] + sidx, h_wpos.data() + obs_base[sidx]};
-            build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k], b->ray_perm.data() + ray_base[sidx]);
+            build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k], b->ray_perm.data() + ray_base[sidx], schur_threads_of(type));
           }
         };
         const int nt = std::min(n_threads, wn);
@@ -1559,7 +1566,15 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (b->max_cam_obs > 65535) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
   // (also when a view has more runs than a workgroup has threads -- more pairs than that: the several rounds k_schur then needs
   // cannot reuse the table's LDS space for their sums)
-  b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w) > 160 * 1024 || (!b->schur_w && b->max_cam_run > SCHUR_THREADS);
+  const int NW2d = NC - ((has3d && type != PTZ_BA_PTZRayFxfyDist) ? 1 : 0);  // Dims<TYPE>::NW
+  b->d.schur_ent_cap = b->max_cam_ent;
+  for (auto& dgp : b->dg) dgp.schur_ent_cap = b->max_cam_ent;
+  b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w, schur_threads_of(type), NW2d, b->max_cam_ent) > 160 * 1024 ||
+                (!b->schur_w && b->max_cam_run > schur_threads_of(type));
+  if (!b->schur_w && schur_lds_bytes(0, NC, b->d.chol.np, false, schur_threads_of(type), NW2d, b->max_cam_ent) > 160 * 1024) {
+    ptz_ba_batch_destroy(b);  // a view with more pair entries than the LDS copy of its list holds (~60 000)
+    return PTZ_ELIMIT;
+  }
   if (const char* e = getenv("PTZ_BA_SCHUR_GLOBAL_T")) b->schur_tg = atoi(e) != 0;
   if (b->schur_tg) {
     const int rc2 = b->alloc(&b->d.Tbuf, (size_t)b->total_obs * ((NC * 3 + 3) | 1));

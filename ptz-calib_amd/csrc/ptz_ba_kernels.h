@@ -71,10 +71,11 @@ struct Dev {
   const int* cam_pair;  // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local pair range of each camera ci
   const unsigned* ent;  // low 16 bits: position of obs a in ci's observation list; high 16: position of obs b in cj's; ci > cj only
   const int* pair_brow; // first W row of camera cj of every pair (k_schur_w only)
-  // runs of k_schur: a camera's entries cut into at most SCHUR_THREADS pieces of equal length that never straddle two pairs
+  // runs of k_schur: a camera's entries cut into at most schur_threads<TYPE>() pieces of equal length that never straddle two pairs
   const int* cam_run;   // [total_cam + n_scene] per scene n_cam + 1 entries: scene-local run range of each camera ci
   const uint2* run_rec; // [total_run] {first entry (global index), pair (index among the camera's pairs, 16 bits) | entries << 16}
   const int* pair_run;  // [total_pair + n_scene] per scene n_pair + 1 entries: scene-local first run of every pair
+  int schur_ent_cap;    // entries of the batch's largest camera (k_schur stages a camera's entry list in LDS, 2 bytes per entry)
   const double* ray_w;
   // state: two buffers, LmState.cur selects the current one
   double* cam_x;  // [2][total_cam][15]
@@ -1289,9 +1290,14 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
 #else
 #define SC_STAMP(i) do { } while (0)
 #endif
+// Threads per workgroup (= the most runs a camera's entries are cut into).  512-thread workgroups at 128 VGPRs were measured
+// for PTZRay (4 waves per SIMD): 42.5 ms against 41.9 ms per 256-scene solve -- the registers that the prefetches below need
+// are worth more than the occupancy.
+template <int TYPE> constexpr int schur_threads() { return 256; }
 template <int TYPE, bool TG>
-__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
+__global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512 ? 4 : 2) void k_schur(Dev d)  // (threads, waves per SIMD)
 {
+  constexpr int THREADS = schur_threads<TYPE>();
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR, CBS = Dims<TYPE>::CBS;
   constexpr int NU = NW * (NW + 1) / 2;
   constexpr int NT = NW * 3;
@@ -1319,11 +1325,20 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
   constexpr int PS = (NW * NW) | 1;  // doubles per run sum in LDS (odd pitch)
   const int ntl = d.chol.np / CHOL_NB;
   double* strip = lds;                                         // [waves][NW + NU] reduction strip of phase 1
-  int* tord = reinterpret_cast<int*>(strip + (SCHUR_THREADS / 64) * (NW + NU));  // the scene's tile order (identity without one)
-  double* tab = strip + (SCHUR_THREADS / 64) * (NW + NU) + (ntl + 2) / 2;        // T table, later the run sums
+  int* tord = reinterpret_cast<int*>(strip + (THREADS / 64) * (NW + NU));  // the scene's tile order (identity without one)
+  // the camera's entry list as 16-bit a slots: staged here by all threads with coalesced loads, so that phase 2 -- one run per
+  // thread, every thread at another place of the list -- reads it at LDS latency instead of chasing 4-byte global loads
+  unsigned short* eslot = reinterpret_cast<unsigned short*>(strip + (THREADS / 64) * (NW + NU) + (ntl + 2) / 2);
+  const int* crun = d.cam_run + s.cam_off + s.idx;
+  const int run0 = crun[ci], nrun = crun[ci + 1] - run0;      // this camera's runs (scene-local numbers)
+  const uint2* runs = d.run_rec + s.run_off + run0;
+  const int ent0 = nrun > 0 ? (int)runs[0].x : 0;              // first entry of the camera (global index)
+  const int nent = nrun > 0 ? (int)(runs[nrun - 1].x + (runs[nrun - 1].y >> 16)) - ent0 : 0;
+  double* tab = reinterpret_cast<double*>(eslot + ((d.schur_ent_cap + 3) & ~3));  // T table, later the run sums
   double* T = TG ? d.Tbuf + (size_t)o0 * TS : tab;             // [no][TS]
-  double* part = tab;                                          // [SCHUR_THREADS][PS]
-  for (int t = threadIdx.x; t < ntl; t += SCHUR_THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
+  double* part = tab;                                          // [THREADS][PS]
+  for (int t = threadIdx.x; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
+  for (int e = threadIdx.x; e < nent; e += THREADS) eslot[e] = (unsigned short)(d.ent[ent0 + e] & 0xffffu);
   auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
   const double* camtab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
   // ---- phase 1
@@ -1344,13 +1359,25 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
     for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
     for (int k = 0; k < NU; ++k) D[k] = 0;
-    // the ray id of the NEXT trip is fetched with this trip's record (two dependent loads stand before the arithmetic)
-    int gj_n = d.cam_ray[o0 + min((int)threadIdx.x, max(no - 1, 0))];
-    for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
-      const int gj = gj_n;
-      gj_n = d.cam_ray[o0 + min(q + SCHUR_THREADS, no - 1)];
+    // Two dependent loads stand before an observation's arithmetic: its ray id, then the ray's record.  Both are fetched ahead --
+    // the id two trips, the record one -- with unconditional loads (past the camera's end the index is clamped, the data unused).
+    typedef double d16 __attribute__((ext_vector_type(16)));
+    auto load_rec = [&](int gj) {
       const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
-      const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];
+      d16 v;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+      return v;
+    };
+    auto oclamp = [&](int q) { return o0 + min(q, max(no - 1, 0)); };
+    d16 rc_n = load_rec(d.cam_ray[oclamp((int)threadIdx.x)]);
+    int gj_n = d.cam_ray[oclamp((int)threadIdx.x + THREADS)];
+    for (int q = threadIdx.x; q < no; q += THREADS) {
+      const d16 rc = rc_n;
+      rc_n = load_rec(gj_n);
+      gj_n = d.cam_ray[oclamp(q + 2 * THREADS)];
+      const double2 r0 = make_double2(rc[0], rc[1]), r1 = make_double2(rc[2], rc[3]), r2 = make_double2(rc[4], rc[5]), r3 = make_double2(rc[6], rc[7]),
+                    r4 = make_double2(rc[8], rc[9]), r5 = make_double2(rc[10], rc[11]), r6 = make_double2(rc[12], rc[13]), r7 = make_double2(rc[14], rc[15]);
       const double e0 = r0.x, e1 = r0.y, e2 = r1.x, e3 = r1.y, e4 = r2.x, e5 = r2.y;
       const double z0 = r3.x, z1 = r3.y, z2 = r4.x;
       const double Xn[3] = {r4.y, r5.x, r5.y};
@@ -1413,10 +1440,10 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
     // pairs at once): S_ii = U_i (2D-2D + annotation terms) + D_i^2 - sum T W^T (the latter only on the NW x NW 2D-2D
     // columns), b_i = g_i - sum W z.  Every thread adds up its own element's wave partials, in wave order.
     constexpr int NV = NW + NU, NE = NC * (NC + 1) / 2;
-    const int t = (int)threadIdx.x - (SCHUR_THREADS - 64);
+    const int t = (int)threadIdx.x - (THREADS - 64);
     const int gi = s.cam_off + ci;
     auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };  // NC slot -> 2D-2D column
-    auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < SCHUR_THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
+    auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
     if (t >= 0 && t < NE) {
       int p = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
       while ((p + 1) * (p + 2) / 2 <= t) ++p;
@@ -1442,25 +1469,21 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
   }
   SC_STAMP(2);
   // ---- phase 2: off-diagonal blocks of row-block ci, one run of entries per thread
-  const unsigned* ents = d.ent;                    // (a slot | b slot << 16); only the a slot is read here
   const int* pcj = d.pair_cj + s.pair_off + pr0;
-  const int* crun = d.cam_run + s.cam_off + s.idx;
-  const int run0 = crun[ci], nrun = crun[ci + 1] - run0;      // this camera's runs (scene-local numbers)
-  const uint2* runs = d.run_rec + s.run_off + run0;
   const int* prun = d.pair_run + s.pair_off + s.idx + pr0;    // first run of each of this camera's pairs; prun[npr] = end of the last
-  // Without TG the host has cut the entries into at most SCHUR_THREADS runs: ONE round, after which the T table is dead and its
+  // Without TG the host has cut the entries into at most THREADS runs: ONE round, after which the T table is dead and its
   // LDS space takes the run sums.  With the T table in global memory (very many observations or pairs in one view) the runs
   // may need several rounds; a pair that continues from the previous round adds to what that round stored.
-  for (int base = 0; base < nrun; base += SCHUR_THREADS) {
+  for (int base = 0; base < nrun; base += THREADS) {
     const int r = base + (int)threadIdx.x;
     double acc[NW * NW];
 #pragma unroll
     for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
     if (r < nrun) {
       const uint2 rr = runs[r];
-      const int e0 = (int)rr.x, cnt = (int)(rr.y >> 16);
+      const int cnt = (int)(rr.y >> 16);
+      const unsigned short* es = eslot + ((int)rr.x - ent0);  // this run's a slots
       const double* cbj = camtab + (size_t)pcj[rr.y & 0xffffu] * CBS;
-      unsigned ab = ents[e0];
       double Rj[9], kj[F ? 5 : 1], dj[F == 3 ? 3 : 1];
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
@@ -1469,22 +1492,34 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
       for (int k = 0; k < (F ? 5 : 1); ++k) kj[k] = F ? cbj[CB_K + k] : 0.0;
 #pragma unroll
       for (int k = 0; k < (F == 3 ? 3 : 1); ++k) dj[k] = F == 3 ? cbj[CB_D + k] : 0.0;
+      // the row of the NEXT entry is read from LDS while the current one is worked on (past the end the last row again)
+      double Tn[NT + 3];
+      {
+        const double* Ta = T + (size_t)es[0] * TS;
+#pragma unroll
+        for (int k = 0; k < NT + 3; ++k) Tn[k] = Ta[k];
+      }
       for (int k = 0; k < cnt; ++k) {
-        const unsigned nx = ents[e0 + min(k + 1, cnt - 1)];
-        const double* Ta = T + (size_t)(ab & 0xffffu) * TS;
-        const double Xn[3] = {Ta[NT], Ta[NT + 1], Ta[NT + 2]};
+        double Tc[NT + 3];
+#pragma unroll
+        for (int i = 0; i < NT + 3; ++i) Tc[i] = Tn[i];
+        {
+          const double* Ta = T + (size_t)es[min(k + 1, cnt - 1)] * TS;
+#pragma unroll
+          for (int i = 0; i < NT + 3; ++i) Tn[i] = Ta[i];
+        }
+        const double Xn[3] = {Tc[NT], Tc[NT + 1], Tc[NT + 2]};
         double MR[2][3], G[2][NW];
         if (ba_pair_side<F>(Rj, fj, fyj, kj, dj, Xn, MR, G)) {
 #pragma unroll
           for (int p = 0; p < NW; ++p) {
-            const double t0 = Ta[3 * p], t1 = Ta[3 * p + 1], t2 = Ta[3 * p + 2];
+            const double t0 = Tc[3 * p], t1 = Tc[3 * p + 1], t2 = Tc[3 * p + 2];
             const double u0 = t0 * MR[0][0] + t1 * MR[0][1] + t2 * MR[0][2];
             const double u1 = t0 * MR[1][0] + t1 * MR[1][1] + t2 * MR[1][2];
 #pragma unroll
             for (int q = 0; q < NW; ++q) acc[p * NW + q] = fma(u1, G[1][q], fma(u0, G[0][q], acc[p * NW + q]));
           }
         }
-        ab = nx;
       }
     }
     SC_STAMP(3);
@@ -1496,40 +1531,63 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(Dev d)
       for (int k = 0; k < NW * NW; ++k) part[threadIdx.x * PS + k] = acc[k];
     }
     __syncthreads();
+    // what step (b) needs of camera cj -- Jl and the Jacobi scales, two cache lines away in global memory -- is asked for now,
+    // so that it arrives while step (a) runs
+    double pJl[9], pS[NW];
+    const bool pre = (int)threadIdx.x < npr * NW;
+    {
+      const double* cbp = camtab + (size_t)pcj[pre ? (int)threadIdx.x / NW : 0] * CBS;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) pJl[k] = cbp[CB_JL + k];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) pS[k] = cbp[CB_S + Dims<TYPE>::pos(k)];
+    }
     // (a) thread = (pair, element): the pair's runs of this round in run order, into the row of its first run
-    for (int it = threadIdx.x; it < npr * NW * NW; it += SCHUR_THREADS) {
+    for (int it = threadIdx.x; it < npr * NW * NW; it += THREADS) {
       const int pl = it / (NW * NW), el = it % (NW * NW);
-      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, SCHUR_THREADS);
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, THREADS);
       if (ra >= rb) continue;  // (the pair has no run in this round)
-      double v = part[ra * PS + el];
-      for (int q = ra + 1; q < rb; ++q) v += part[q * PS + el];
-      part[ra * PS + el] = v;
+      // four independent partial sums (the LDS reads of a serial sum would each wait for the one before): runs ra, ra+4, .. /
+      // ra+1, .. / ra+2, .. / ra+3, ..; a fixed order as well
+      double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+      int q = ra;
+      for (; q + 3 < rb; q += 4) {
+        v0 += part[q * PS + el]; v1 += part[(q + 1) * PS + el]; v2 += part[(q + 2) * PS + el]; v3 += part[(q + 3) * PS + el];
+      }
+      for (; q < rb; ++q) v0 += part[q * PS + el];
+      part[ra * PS + el] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
     SC_STAMP(5);
     // (b) thread = (pair, row of the block): rotation columns from the camera frame to the parameters (x Jl_j), every column by
     //     its Jacobi scale, into S_ij
-    for (int it = threadIdx.x; it < npr * NW; it += SCHUR_THREADS) {
+    for (int it = threadIdx.x; it < npr * NW; it += THREADS) {
       const int pl = it / NW, p = it % NW;
-      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, SCHUR_THREADS);
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, THREADS);
       if (ra >= rb) continue;
       const bool first = prun[pl] - run0 >= base;  // else the pair continues from the previous round
       const int cj = pcj[pl];
-      const double* cbj = camtab + (size_t)cj * CBS;
+      if (it != (int)threadIdx.x) {  // (a camera with more than THREADS / NW pairs: later items fetch their own)
+        const double* cbj = camtab + (size_t)cj * CBS;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pJl[k] = cbj[CB_JL + k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) pS[k] = cbj[CB_S + Dims<TYPE>::pos(k)];
+      }
       double row[NW];
 #pragma unroll
       for (int q = 0; q < NW; ++q) row[q] = part[ra * PS + p * NW + q];
       const double a0 = row[ROT0], a1 = row[ROT0 + 1], a2 = row[ROT0 + 2];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) row[ROT0 + k] = a0 * cbj[CB_JL + k] + a1 * cbj[CB_JL + 3 + k] + a2 * cbj[CB_JL + 6 + k];
+      for (int k = 0; k < 3; ++k) row[ROT0 + k] = a0 * pJl[k] + a1 * pJl[3 + k] + a2 * pJl[6 + k];
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
-        const double v = row[q] * cbj[CB_S + Dims<TYPE>::pos(q)];
+        const double v = row[q] * pS[q];
         double& dst = sys_at(A, np, scol(ci * NC + Dims<TYPE>::pos(p)), scol(cj * NC + Dims<TYPE>::pos(q)));
         dst = first ? v : dst + v;
       }
     }
-    if (base + SCHUR_THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
+    if (base + THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
   }
 #ifdef PTZ_SCHUR_STAMPS
   SC_STAMP(6);

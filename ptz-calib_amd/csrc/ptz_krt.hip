@@ -10,6 +10,7 @@
 //   J^T J (4x4 or 5x5), J^T r and the cost are reduced with a fixed butterfly, every lane then solves the
 //   damped normal equations redundantly in registers.  DENSE_QR on [J; D] and Cholesky on J^T J + D^2
 //   give the same step up to round-off (the Jacobi-scaled 4-/5-column Jacobian is well conditioned).
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -94,10 +95,23 @@ struct MatchEval {
   }
 };
 
-constexpr int KRT_CACHE = 256;  // matches per query whose constant part is cached (8 KiB of LDS per wave)
+// Lanes per query.  G = 64 (a wave per query) is the latency form: a registration attempt of the incremental pipeline or a
+// handful of queries are as fast as they can be.  G = 16 (four queries per wave) is the throughput form for launches of
+// thousands of queries of a few hundred matches each: with 128 matches a wave of 64 has two matches per lane and then spends
+// as long on its 15 six-step reductions and on 64 redundant copies of one 4 x 4 solve as on the matches; 16 lanes take eight
+// matches each, reduce in four steps, and a wave's redundant solves serve four queries.  The two forms sum in different
+// orders: a query's bits depend on the form, never on its neighbours in the launch (ptz_krt_solve_batch picks the form from
+// the launch size alone, krt_group_size()).
+template <int G> __device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+  return v;
+}
+template <int G> struct KrtCache { static constexpr int N = G == 64 ? 256 : 128; };  // matches per query whose constant part is cached
 // P3: the queries also carry 2D-3D constraints (KRTOptimizer::Add2d3dConstraints, krt_optimizer.cc:350-383): world points,
 // moved into the local frame of the reference camera as the reference does (:357-362), one residual block each.
-template <int KTYPE, bool P3>
+template <int KTYPE, bool P3, int G>
 __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
                                              const float2* __restrict__ uv_cur, const long long* __restrict__ point_ptr,
                                              const float2* __restrict__ pt_uv, const double* __restrict__ pt_xyz,
@@ -106,9 +120,10 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
 {
   constexpr int NF = KrtDims<KTYPE>::NF;
   constexpr int NH = NF * (NF + 1) / 2;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int QPB = 256 / G, KRT_CACHE = KrtCache<G>::N;  // queries per workgroup
+  const int q = blockIdx.x * QPB + (int)threadIdx.x / G;
   if (q >= n_query) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x % G;
   const long long m0 = match_ptr[q], m1 = match_ptr[q + 1];
   const int M = (int)(m1 - m0);
   const long long p0 = P3 ? point_ptr[q] : 0;
@@ -137,16 +152,17 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
   const double kref[4] = {ref[0], ref[1], ref[2], ref[3]};
   const double dref[5] = {ref[10], ref[11], ref[12], ref[13], ref[14]};
   // The unit ray of a reference pixel (and, with distortion, its iterative undistortion) does not depend on the parameters
-  // being optimised: computed once per match, kept in a wave-private LDS strip for the first KRT_CACHE matches of the query
-  // (the reference recomputes it in every functor call, krt_optimizer.cc:31-33, 89-104).
-  __shared__ double ray_cache[4][KRT_CACHE][4];
-  double (*rc)[4] = ray_cache[threadIdx.x >> 6];
-  for (int m = lane; m < M && m < KRT_CACHE; m += 64) {
+  // being optimised: computed once per match, kept in a group-private LDS strip for the first KRT_CACHE matches of the query
+  // (the reference recomputes it in every functor call, krt_optimizer.cc:31-33, 89-104).  A unit ray has r[2] = 1 / n > 0:
+  // r[2] = 0 marks a match the border guard skips.
+  __shared__ double ray_cache[QPB][KRT_CACHE][3];
+  double (*rc)[3] = ray_cache[threadIdx.x / G];
+  for (int m = lane; m < M && m < KRT_CACHE; m += G) {
     const float2 a = uv_ref[m0 + m];
     double r1[3];
     bool skip;
     MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip);
-    rc[m][0] = r1[0]; rc[m][1] = r1[1]; rc[m][2] = r1[2]; rc[m][3] = skip ? 1.0 : 0.0;
+    rc[m][0] = r1[0]; rc[m][1] = r1[1]; rc[m][2] = skip ? 0.0 : r1[2];
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every lane reads back only what it wrote
   auto local_point = [&](int i, double Xl[3]) {  // R_local_world X_w + t_local_world (krt_optimizer.cc:357-362)
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     Xl[2] = Rref[6] * X[0] + Rref[7] * X[1] + Rref[8] * X[2] + ref[9];
   };
   auto match_ray = [&](int m, double r1[3], bool& skip) {
-    if (m < KRT_CACHE) { r1[0] = rc[m][0]; r1[1] = rc[m][1]; r1[2] = rc[m][2]; skip = rc[m][3] != 0.0; }
+    if (m < KRT_CACHE) { r1[0] = rc[m][0]; r1[1] = rc[m][1]; r1[2] = rc[m][2]; skip = r1[2] == 0.0; }
     else { const float2 a = uv_ref[m0 + m]; MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip); }
   };
 
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     double R[9];
     rodrigues(c + 4, R);
     double cost = 0;
-    for (int m = lane; m < M; m += 64) {
+    for (int m = lane; m < M; m += G) {
       const float2 bq = uv_cur[m0 + m];
       double r1[3], res[2], J[2][NF];
       bool skip;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
     }
     if (P3) {
-      for (int i = lane; i < NP; i += 64) {
+      for (int i = lane; i < NP; i += G) {
         const float2 bq = pt_uv[p0 + i];
         double Xl[3], res[2], J[2][NF];
         local_point(i, Xl);
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
         cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
       }
     }
-    return wave_sum(cost);
+    return group_sum<G>(cost);
   };
   // full linearisation: H = J^T J (packed lower), g = J^T r, cost
   double H[NH], g[NF];
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
     for (int k = 0; k < NH; ++k) H[k] = 0;
 #pragma unroll
     for (int k = 0; k < NF; ++k) g[k] = 0;
-    for (int m = lane; m < M; m += 64) {
+    for (int m = lane; m < M; m += G) {
       const float2 bq = uv_cur[m0 + m];
       double r1[3], res[2], J[2][NF];
       bool skip;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       }
     }
     if (P3) {
-      for (int i = lane; i < NP; i += 64) {
+      for (int i = lane; i < NP; i += G) {
         const float2 bq = pt_uv[p0 + i];
         double Xl[3], res[2], J[2][NF];
         local_point(i, Xl);
@@ -227,10 +243,10 @@ __global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __
       }
     }
 #pragma unroll
-    for (int k = 0; k < NH; ++k) H[k] = wave_sum(H[k]);
+    for (int k = 0; k < NH; ++k) H[k] = group_sum<G>(H[k]);
 #pragma unroll
-    for (int k = 0; k < NF; ++k) g[k] = wave_sum(g[k]);
-    return wave_sum(cost);
+    for (int k = 0; k < NF; ++k) g[k] = group_sum<G>(g[k]);
+    return group_sum<G>(cost);
   };
   auto norm15 = [&](const double* c) -> double {
     double s = 0;
@@ -411,16 +427,29 @@ KrtOpt make_krt_opt(const ptz_lm_options& o, double max_reproj_error)
   return ko;
 }
 
+// lanes per query of a launch of n_query queries (see k_krt): the throughput form from 2048 queries on, PTZ_KRT_GROUP overrides
+inline int krt_group_size(int n_query)
+{
+  if (const char* e = getenv("PTZ_KRT_GROUP")) { const int g = atoi(e); if (g == 16 || g == 64) return g; }
+  return n_query >= 2048 ? 16 : 64;
+}
+
 // one launch over device-resident queries (all pointers are device pointers; d_pptr = nullptr: no 2D-3D constraints)
 void launch_krt(int n_query, const long long* d_ptr, const float2* d_ref, const float2* d_cur, const long long* d_pptr,
                 const float2* d_puv, const double* d_pxyz, const double* d_cref, double* d_ccur, int factor_type, const KrtOpt& ko,
                 ptz_lm_summary* d_sum, int* d_acc, hipStream_t st)
 {
-  const dim3 grid((n_query + 3) / 4), block(256);
+  const int G = krt_group_size(n_query);
+  const int qpb = 256 / G;
+  const dim3 grid((n_query + qpb - 1) / qpb), block(256);
   const bool p3 = d_pptr != nullptr;
-#define PTZ_KRT_LAUNCH(T, P)                                                                                         \
-  hipLaunchKernelGGL((k_krt<T, P>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
-                     d_ccur, ko, d_sum, d_acc)
+#define PTZ_KRT_LAUNCH(T, P)                                                                                                   \
+  do {                                                                                                                         \
+    if (G == 16) hipLaunchKernelGGL((k_krt<T, P, 16>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, \
+                                    d_cref, d_ccur, ko, d_sum, d_acc);                                                         \
+    else hipLaunchKernelGGL((k_krt<T, P, 64>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
+                            d_ccur, ko, d_sum, d_acc);                                                                         \
+  } while (0)
   switch (factor_type * 2 + (p3 ? 1 : 0)) {
     case 0: PTZ_KRT_LAUNCH(0, false); break;
     case 1: PTZ_KRT_LAUNCH(0, true); break;

@@ -1,0 +1,229 @@
+#include "device_batcher.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace ptzcalib {
+
+namespace {
+thread_local DeviceBatcher* t_batcher = nullptr;
+double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool SameOptions(const ptz_lm_options* a, const ptz_lm_options* b) { return memcmp(a, b, sizeof(ptz_lm_options)) == 0; }
+}  // namespace
+
+DeviceBatcher* DeviceBatcher::Current() { return t_batcher; }
+DeviceBatcher::Scope::Scope(DeviceBatcher* b) : prev(t_batcher) { t_batcher = b; }
+DeviceBatcher::Scope::~Scope() { t_batcher = prev; }
+
+DeviceBatcher::DeviceBatcher(int n_clients) : active_(n_clients) {}
+
+void DeviceBatcher::Arrive(std::unique_lock<std::mutex>& lk)
+{
+  ++waiting_;
+  const uint64_t gen = generation_;
+  if (waiting_ == active_) {  // the last one to arrive runs the round for everybody
+    RunRound();
+    waiting_ = 0;
+    ++generation_;
+    cv_.notify_all();
+  }
+  else cv_.wait(lk, [&] { return generation_ != gen; });
+}
+
+void DeviceBatcher::ClientDone()
+{
+  std::unique_lock<std::mutex> lk(mu_);
+  --active_;
+  if (active_ > 0 && waiting_ == active_) {  // everybody else was waiting for this client
+    RunRound();
+    waiting_ = 0;
+    ++generation_;
+    cv_.notify_all();
+  }
+}
+
+int32_t DeviceBatcher::BaSolve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary)
+{
+  ptz_lm_options dflt;
+  if (!opt) { ptz_lm_options_default(&dflt); opt = &dflt; }
+  BaReq req{p, cam, ray, tlw, opt, summary, PTZ_EINVAL};
+  std::unique_lock<std::mutex> lk(mu_);
+  ba_.push_back(&req);
+  Arrive(lk);
+  return req.rc;
+}
+
+int32_t DeviceBatcher::KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
+                                     double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                                     ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  ptz_lm_options dflt;
+  if (!opt) { ptz_lm_options_default(&dflt); opt = &dflt; }
+  KrtReq req{n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms, PTZ_EINVAL};
+  std::unique_lock<std::mutex> lk(mu_);
+  krt_.push_back(&req);
+  Arrive(lk);
+  return req.rc;
+}
+
+void DeviceBatcher::RunRound()
+{
+  ++stats_.rounds;
+  // requests that can share a launch: same factor type and options (a batch has ONE options block); a problem with shared
+  // intrinsics or annotations is solved on its own (nothing in the incremental pipeline makes those)
+  std::vector<char> done_ba(ba_.size(), 0);
+  for (size_t i = 0; i < ba_.size(); ++i) {
+    if (done_ba[i]) continue;
+    std::vector<BaReq*> group{ba_[i]};
+    done_ba[i] = 1;
+    const bool plain = !ba_[i]->p->ic_of_cam && ba_[i]->p->n_obs3d == 0;
+    for (size_t j = i + 1; plain && j < ba_.size(); ++j) {
+      if (done_ba[j] || ba_[j]->p->ic_of_cam || ba_[j]->p->n_obs3d != 0) continue;
+      if (ba_[j]->p->factor_type != ba_[i]->p->factor_type || !SameOptions(ba_[j]->opt, ba_[i]->opt)) continue;
+      group.push_back(ba_[j]);
+      done_ba[j] = 1;
+    }
+    RunBa(group);
+  }
+  std::vector<char> done_krt(krt_.size(), 0);
+  for (size_t i = 0; i < krt_.size(); ++i) {
+    if (done_krt[i]) continue;
+    std::vector<KrtReq*> group{krt_[i]};
+    done_krt[i] = 1;
+    for (size_t j = i + 1; j < krt_.size(); ++j) {
+      if (done_krt[j] || krt_[j]->factor_type != krt_[i]->factor_type || krt_[j]->max_reproj_error != krt_[i]->max_reproj_error ||
+          !SameOptions(krt_[j]->opt, krt_[i]->opt))
+        continue;
+      group.push_back(krt_[j]);
+      done_krt[j] = 1;
+    }
+    RunKrt(group);
+  }
+  ba_.clear();
+  krt_.clear();
+}
+
+void DeviceBatcher::RunBa(std::vector<BaReq*>& reqs)
+{
+  const double t0 = NowMs();
+  ++stats_.ba_batches;
+  stats_.ba_problems += static_cast<long>(reqs.size());
+  if (reqs.size() == 1) {
+    BaReq& r = *reqs[0];
+    r.rc = ptz_ba_solve(r.p, r.cam, r.ray, r.tlw, r.opt, r.summary);
+    stats_.ba_ms += NowMs() - t0;
+    return;
+  }
+  const int32_t n = static_cast<int32_t>(reqs.size());
+  std::vector<ptz_ba_problem> probs(n);
+  size_t n_cam = 0, n_ray = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    probs[i] = *reqs[i]->p;
+    n_cam += static_cast<size_t>(probs[i].n_cam);
+    n_ray += static_cast<size_t>(probs[i].n_ray);
+  }
+  std::vector<double> cam(15 * n_cam), ray(3 * n_ray), tlw(6 * static_cast<size_t>(n), 0.0);
+  {
+    size_t co = 0, ro = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      const BaReq& r = *reqs[i];
+      memcpy(cam.data() + 15 * co, r.cam, sizeof(double) * 15 * probs[i].n_cam);
+      memcpy(ray.data() + 3 * ro, r.ray, sizeof(double) * 3 * probs[i].n_ray);
+      if (r.tlw) memcpy(tlw.data() + 6 * static_cast<size_t>(i), r.tlw, sizeof(double) * 6);
+      co += probs[i].n_cam; ro += probs[i].n_ray;
+    }
+  }
+  std::vector<ptz_lm_summary> summ(n);
+  ptz_ba_batch* b = nullptr;
+  int32_t rc = ptz_ba_batch_create(n, probs.data(), reqs[0]->opt, &b);
+  if (rc == PTZ_OK) rc = ptz_ba_batch_set_state(b, cam.data(), ray.data(), tlw.data());
+  if (rc == PTZ_OK) rc = ptz_ba_batch_solve(b, summ.data());
+  if (rc == PTZ_OK) rc = ptz_ba_batch_get_state(b, cam.data(), ray.data(), tlw.data());
+  if (b) ptz_ba_batch_destroy(b);
+  if (rc != PTZ_OK && rc != PTZ_ENODEVICE && rc != PTZ_ENOMEM) {
+    // one malformed / oversized problem must not fail its neighbours: every request gets its own verdict
+    for (BaReq* r : reqs) r->rc = ptz_ba_solve(r->p, r->cam, r->ray, r->tlw, r->opt, r->summary);
+    stats_.ba_ms += NowMs() - t0;
+    return;
+  }
+  size_t co = 0, ro = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    BaReq& r = *reqs[i];
+    r.rc = rc;
+    if (rc == PTZ_OK) {
+      memcpy(r.cam, cam.data() + 15 * co, sizeof(double) * 15 * probs[i].n_cam);
+      memcpy(r.ray, ray.data() + 3 * ro, sizeof(double) * 3 * probs[i].n_ray);
+      if (r.tlw) memcpy(r.tlw, tlw.data() + 6 * static_cast<size_t>(i), sizeof(double) * 6);
+      if (r.summary) *r.summary = summ[i];
+    }
+    co += probs[i].n_cam; ro += probs[i].n_ray;
+  }
+  stats_.ba_ms += NowMs() - t0;
+}
+
+void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
+{
+  const double t0 = NowMs();
+  ++stats_.krt_launches;
+  if (reqs.size() == 1) {
+    KrtReq& r = *reqs[0];
+    stats_.krt_queries += r.n_query;
+    r.rc = ptz_krt_solve_batch(r.n_query, r.match_ptr, r.uv_ref, r.uv_cur, r.cam_ref, r.cam_cur, r.factor_type, r.max_reproj_error, r.opt,
+                               r.summaries, r.accepted, r.device_ms);
+    stats_.krt_ms += NowMs() - t0;
+    return;
+  }
+  size_t nq = 0, nm = 0;
+  for (const KrtReq* r : reqs) { nq += static_cast<size_t>(r->n_query); nm += static_cast<size_t>(r->match_ptr[r->n_query] - r->match_ptr[0]); }
+  stats_.krt_queries += static_cast<long>(nq);
+  std::vector<int64_t> ptr(nq + 1, 0);
+  std::vector<float> uv_ref(2 * nm), uv_cur(2 * nm);
+  std::vector<double> cam_ref(15 * nq), cam_cur(15 * nq);
+  std::vector<ptz_lm_summary> summ(nq);
+  std::vector<int32_t> acc(nq, 0);
+  {
+    size_t q0 = 0, m0 = 0;
+    for (const KrtReq* r : reqs) {
+      const int64_t base = r->match_ptr[0];
+      const size_t m = static_cast<size_t>(r->match_ptr[r->n_query] - base);
+      for (int32_t q = 0; q < r->n_query; ++q) ptr[q0 + q + 1] = static_cast<int64_t>(m0) + (r->match_ptr[q + 1] - base);
+      memcpy(uv_ref.data() + 2 * m0, r->uv_ref + 2 * base, sizeof(float) * 2 * m);
+      memcpy(uv_cur.data() + 2 * m0, r->uv_cur + 2 * base, sizeof(float) * 2 * m);
+      memcpy(cam_ref.data() + 15 * q0, r->cam_ref, sizeof(double) * 15 * r->n_query);
+      memcpy(cam_cur.data() + 15 * q0, r->cam_cur, sizeof(double) * 15 * r->n_query);
+      q0 += static_cast<size_t>(r->n_query); m0 += m;
+    }
+  }
+  double dev_ms = 0;
+  const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(nq), ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(), cam_cur.data(),
+                                         reqs[0]->factor_type, reqs[0]->max_reproj_error, reqs[0]->opt, summ.data(), acc.data(), &dev_ms);
+  size_t q0 = 0;
+  for (KrtReq* r : reqs) {
+    r->rc = rc;
+    if (rc == PTZ_OK) {
+      memcpy(r->cam_cur, cam_cur.data() + 15 * q0, sizeof(double) * 15 * r->n_query);
+      if (r->summaries) memcpy(r->summaries, summ.data() + q0, sizeof(ptz_lm_summary) * r->n_query);
+      if (r->accepted) memcpy(r->accepted, acc.data() + q0, sizeof(int32_t) * r->n_query);
+      if (r->device_ms) *r->device_ms = dev_ms;
+    }
+    q0 += static_cast<size_t>(r->n_query);
+  }
+  stats_.krt_ms += NowMs() - t0;
+}
+
+int32_t DeviceBaSolve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary)
+{
+  if (DeviceBatcher* b = DeviceBatcher::Current()) return b->BaSolve(p, cam, ray, tlw, opt, summary);
+  return ptz_ba_solve(p, cam, ray, tlw, opt, summary);
+}
+
+int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
+                            double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                            ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  if (DeviceBatcher* b = DeviceBatcher::Current())
+    return b->KrtSolveBatch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms);
+  return ptz_krt_solve_batch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms);
+}
+
+}  // namespace ptzcalib

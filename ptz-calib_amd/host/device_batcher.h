@@ -1,0 +1,76 @@
+// device_batcher.h -- several optimizers in lock step on one GPU.
+//
+// The reference calibrates its scenes one process after the other (run_ptzba_synthetic.sh:4-13); inside a scene
+// PtzIncrementalOptimizer::Solve (src/core/ptz_incremental_optimizer.cc:39-126) is a strictly sequential chain of ~40 bundle
+// adjustments and ~200 single-view registrations, each far too small to fill a GPU.  Scenes never interact, so N of them can
+// walk that chain side by side: every optimizer runs UNCHANGED on a host thread of its own, and the two device calls it makes
+// (ptz_ba_solve, ptz_krt_solve_batch) go through this rendezvous instead of straight to the library.  When every optimizer
+// that is still running has a call pending, the pending bundle adjustments become ONE ptz_ba_batch and the pending
+// registration attempts ONE ptz_krt_solve_batch launch; the results are handed back and the threads go on.  A scene inside a
+// batch has the bits of its solo solve (the library's reductions are fixed-order, scenes never share a sum), so every decision
+// of every optimizer is the one it would have taken alone.
+#pragma once
+
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ptz_calib_amd.h"
+
+namespace ptzcalib {
+
+class DeviceBatcher {
+ public:
+  explicit DeviceBatcher(int n_clients);
+  // what a client thread calls in place of the C-ABI entry points of the same signature (blocks until its round has run)
+  int32_t BaSolve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary);
+  int32_t KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
+                        double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                        ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+  void ClientDone();  // the calling client makes no further calls (its optimizer has returned)
+
+  struct Stats {
+    long rounds = 0, ba_batches = 0, ba_problems = 0, krt_launches = 0, krt_queries = 0;
+    double ba_ms = 0, krt_ms = 0;  // wall time inside the library calls
+  };
+  Stats stats() const { return stats_; }
+
+  // the batcher of the calling thread (nullptr: calls go straight to the library)
+  static DeviceBatcher* Current();
+  struct Scope {
+    explicit Scope(DeviceBatcher* b);
+    ~Scope();
+    DeviceBatcher* prev;
+  };
+
+ private:
+  struct BaReq {
+    const ptz_ba_problem* p; double *cam, *ray, *tlw; const ptz_lm_options* opt; ptz_lm_summary* summary; int32_t rc;
+  };
+  struct KrtReq {
+    int32_t n_query; const int64_t* match_ptr; const float *uv_ref, *uv_cur; const double* cam_ref; double* cam_cur;
+    int32_t factor_type; double max_reproj_error; const ptz_lm_options* opt; ptz_lm_summary* summaries; int32_t* accepted;
+    double* device_ms; int32_t rc;
+  };
+  void Arrive(std::unique_lock<std::mutex>& lk);  // called with the request already queued
+  void RunRound();                                // executes and clears the queues (lock held: every other client is waiting)
+  void RunBa(std::vector<BaReq*>& reqs);
+  void RunKrt(std::vector<KrtReq*>& reqs);
+
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int active_, waiting_ = 0;
+  uint64_t generation_ = 0;
+  std::vector<BaReq*> ba_;
+  std::vector<KrtReq*> krt_;
+  Stats stats_;
+};
+
+// The device calls of the optimizer classes: through the calling thread's DeviceBatcher when it has one.
+int32_t DeviceBaSolve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary);
+int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
+                            double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                            ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+
+}  // namespace ptzcalib

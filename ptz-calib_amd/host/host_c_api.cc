@@ -12,6 +12,9 @@
 #include <algorithm>
 #include <chrono>
 #include <stdexcept>
+#include <memory>
+#include <unordered_set>
+
 #include "ptz_incremental_optimizer.h"
 #include "ptzray_optimizer.h"
 
@@ -289,6 +292,88 @@ int32_t ptzh_incremental_solve(int32_t n_img, const int64_t* kp_ptr, const float
   }
   return ne;
 }
+
+// ---- several rigs in lock step (PtzIncrementalOptimizer::SolveBatch): create one handle per rig, solve them together, read
+//      every rig's result back ------------------------------------------------------------------------------------------------
+struct IncRig {
+  std::vector<ImageFeatures> feats;
+  std::vector<MatchesInfo> mis;
+  std::vector<Camera> cams, out;
+  std::unique_ptr<PtzIncrementalOptimizer> opt;
+  std::unordered_set<long> reg;
+  bool ok = false;
+};
+
+void* ptzh_inc_create(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, const int32_t* img_wh, int32_t n_pairs,
+                      const int64_t* src, const int64_t* dst, const int64_t* match_ptr, const int32_t* q, const int32_t* t,
+                      const double* H, const int32_t* h_valid, const double* confidence, const double* cam15, const int64_t* seeds,
+                      int32_t n_seeds, int32_t max_iter)
+{
+  IncRig* r = new IncRig();
+  BuildInputs(n_img, kp_ptr, kp_xy, img_wh, n_pairs, src, dst, match_ptr, q, t, cam15, r->feats, r->mis, r->cams);
+  for (int p = 0; p < n_pairs; ++p) {
+    for (int k = 0; k < 9; ++k) r->mis[p].H[k] = H[9 * p + k];
+    r->mis[p].H_empty = h_valid[p] == 0;
+    r->mis[p].confidence = confidence[p];
+  }
+  r->opt.reset(new PtzIncrementalOptimizer(r->feats, r->mis, r->cams, max_iter));
+  if (n_seeds > 0) r->opt->SetSeedImageId(std::vector<long>(seeds, seeds + n_seeds));
+  return r;
+}
+
+// stats8: rounds, bundle-adjustment batches, problems in them, registration launches, queries in them, ms inside the batched
+// bundle adjustments, ms inside the registration launches, wall ms of the whole call.  Returns the number of rigs solved.
+int32_t ptzh_inc_solve_batch(void** handles, int32_t n, int32_t device_id, double* stats8)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<PtzIncrementalOptimizer*> rigs;
+  for (int32_t i = 0; i < n; ++i) {
+    IncRig* r = static_cast<IncRig*>(handles[i]);
+    r->opt->SetDevice(device_id);
+    rigs.push_back(r->opt.get());
+  }
+  std::vector<std::vector<Camera>> cams;
+  std::vector<std::unordered_set<long>> regs;
+  PtzIncrementalOptimizer::BatchStats st;
+  const std::vector<char> ok = PtzIncrementalOptimizer::SolveBatch(rigs, cams, regs, &st);
+  int32_t solved = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    IncRig* r = static_cast<IncRig*>(handles[i]);
+    r->ok = ok[i] != 0;
+    r->out = std::move(cams[i]);
+    r->reg = std::move(regs[i]);
+    solved += r->ok ? 1 : 0;
+  }
+  if (stats8) {
+    stats8[0] = static_cast<double>(st.rounds); stats8[1] = static_cast<double>(st.ba_batches); stats8[2] = static_cast<double>(st.ba_problems);
+    stats8[3] = static_cast<double>(st.krt_launches); stats8[4] = static_cast<double>(st.krt_queries); stats8[5] = st.ba_ms; stats8[6] = st.krt_ms;
+    stats8[7] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return solved;
+}
+
+int32_t ptzh_inc_result(void* handle, double* cam15, int32_t* registered, int64_t* events, int32_t max_events, int64_t* lm_iterations,
+                        int32_t* solved)
+{
+  IncRig* r = static_cast<IncRig*>(handle);
+  const auto& ev = r->opt->events();
+  const int32_t ne = static_cast<int32_t>(ev.size()) < max_events ? static_cast<int32_t>(ev.size()) : max_events;
+  for (int32_t e = 0; e < ne; ++e) {
+    events[4 * e] = ev[e].kind; events[4 * e + 1] = ev[e].a; events[4 * e + 2] = ev[e].b; events[4 * e + 3] = ev[e].success ? 1 : 0;
+  }
+  if (lm_iterations) *lm_iterations = r->opt->lm_iterations();
+  if (solved) *solved = r->ok ? 1 : 0;
+  if (!r->ok) return ne;
+  const int n_img = static_cast<int>(r->feats.size());
+  for (int i = 0; i < n_img; ++i) {
+    registered[i] = r->reg.count(i) ? 1 : 0;
+    const std::vector<double> v = r->out[i].ToVector();
+    memcpy(cam15 + 15 * i, v.data(), sizeof(double) * 15);
+  }
+  return ne;
+}
+
+void ptzh_inc_destroy(void* handle) { delete static_cast<IncRig*>(handle); }
 
 // ---- file formats (data_io) for the tests: every probe answers with a JSON text (malloc'ed, free with ptzh_free) ------
 static char* DupText(const std::string& s)

@@ -9,7 +9,10 @@
 #include <numeric>
 #include <set>
 
+#include <thread>
+
 #include "../../include/ptz_calib_amd.h"
+#include "device_batcher.h"
 #include "ptzray_optimizer.h"
 
 namespace ptzcalib {
@@ -145,6 +148,34 @@ bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered
     return true;
   }
   return false;  // 50 seeds failed (the reference falls off the end of the function here)
+}
+
+// N rigs side by side (run_ptzba_synthetic.sh:4-13 runs them one after the other): every optimizer's Solve() on a host thread
+// of its own, its device calls through one DeviceBatcher, so that each round of the lock step is ONE batched bundle
+// adjustment and ONE registration launch for all rigs.  Decisions and results are those of N solo runs.
+std::vector<char> PtzIncrementalOptimizer::SolveBatch(const std::vector<PtzIncrementalOptimizer*>& rigs, std::vector<std::vector<Camera>>& cameras,
+                                                      std::vector<std::unordered_set<long>>& reg_image_ids, BatchStats* stats)
+{
+  const size_t n = rigs.size();
+  cameras.resize(n);
+  reg_image_ids.resize(n);
+  std::vector<char> ok(n, 0);
+  DeviceBatcher batcher(static_cast<int>(n));
+  std::vector<std::thread> th;
+  th.reserve(n);
+  for (size_t i = 0; i < n; ++i)
+    th.emplace_back([&, i] {
+      DeviceBatcher::Scope scope(&batcher);
+      ok[i] = rigs[i]->Solve(cameras[i], reg_image_ids[i]) ? 1 : 0;
+      batcher.ClientDone();
+    });
+  for (std::thread& t : th) t.join();
+  if (stats) {
+    const DeviceBatcher::Stats s = batcher.stats();
+    stats->rounds = s.rounds; stats->ba_batches = s.ba_batches; stats->ba_problems = s.ba_problems;
+    stats->krt_launches = s.krt_launches; stats->krt_queries = s.krt_queries; stats->ba_ms = s.ba_ms; stats->krt_ms = s.krt_ms;
+  }
+  return ok;
 }
 
 bool PtzIncrementalOptimizer::FindInitialImagePair(long& image_id1, long& image_id2)
@@ -321,7 +352,7 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
   std::vector<ptz_lm_summary> summaries(n);
   std::vector<int32_t> accepted(n, 0);
   const auto t_dev = std::chrono::steady_clock::now();
-  const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
+  const int32_t rc = DeviceKrtSolveBatch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
                                          cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
                                          accepted.data(), nullptr);
   timing_ms_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();

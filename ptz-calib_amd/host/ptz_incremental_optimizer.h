@@ -53,6 +53,12 @@ class PtzIncrementalOptimizer {
   // [3] registrations (pack + device), [4] device part of [3]
   const double* timing_ms() const { return timing_ms_; }
   void SetDevice(int device_id) { device_id_ = device_id; }
+  // extras: several rigs in lock step on one GPU (device_batcher.h): rigs[i]->Solve(cameras[i], reg_image_ids[i]) for every i,
+  // each on its own host thread, their bundle adjustments and registration attempts batched round by round.  Returns the
+  // Solve() results.  Decisions, cameras and events of every rig are those of its solo run.
+  struct BatchStats { long rounds = 0, ba_batches = 0, ba_problems = 0, krt_launches = 0, krt_queries = 0; double ba_ms = 0, krt_ms = 0; };
+  static std::vector<char> SolveBatch(const std::vector<PtzIncrementalOptimizer*>& rigs, std::vector<std::vector<Camera>>& cameras,
+                                      std::vector<std::unordered_set<long>>& reg_image_ids, BatchStats* stats = nullptr);
 
  private:
   bool CheckValid() const;

@@ -1,5 +1,7 @@
 #include "ptzray_optimizer.h"
 
+#include "device_batcher.h"
+
 #include <cstdio>
 
 #include <chrono>
@@ -348,7 +350,7 @@ bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::v
   const auto t_dev = std::chrono::steady_clock::now();
   disp_ = {{0.0, 0.0, 0.0}};  // disp_param_ starts at zero (:655)
   const int32_t rc = type_ == PTZRayDistDisp ? ptz_ba_solve_disp(&prob, cam.data(), ray.data(), tlw, disp_.data(), &opt, &summary_)
-                                             : ptz_ba_solve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);
+                                             : DeviceBaSolve(&prob, cam.data(), ray.data(), tlw, &opt, &summary_);  // (through the thread's DeviceBatcher, if any)
   device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
   if (rc != PTZ_OK) {
     // not a convergence failure: the device path refused or could not run the problem.  Say so -- the reference's callers

@@ -764,3 +764,34 @@ def make_match_table(scene: Scene, min_pair_matches: int = 8, max_pair_gap: int 
     keys = src
     img_wh = np.tile(np.array([scene.width, scene.height], dtype=np.int32), (n, 1))
     return MatchTable(n, img_wh, kp_ptr, kp_xy, src, dst, match_ptr, q, t, H, np.ones(len(keys), dtype=np.int32), conf)
+
+
+def make_match_tables(scenes, workers: int | None = None, **kw) -> list:
+    """make_match_table for many scenes on several host processes (1 s of numpy per C2 scene).  Call BEFORE the process touches
+    the GPU: the workers are forked."""
+    import multiprocessing as mp
+    import os
+    scenes = list(scenes)
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        workers = min(workers, 16)
+    workers = max(1, min(workers, len(scenes)))
+    if workers == 1:
+        return [make_match_table(sc, **kw) for sc in scenes]
+    global _MT_SCENES, _MT_KW
+    _MT_SCENES, _MT_KW = scenes, kw  # inherited by the forked workers: the scenes need not be pickled
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_match_table_job, range(len(scenes)), chunksize=1)
+    finally:
+        _MT_SCENES, _MT_KW = None, None
+
+
+_MT_SCENES, _MT_KW = None, None
+
+
+def _match_table_job(i):
+    return make_match_table(_MT_SCENES[i], **_MT_KW)

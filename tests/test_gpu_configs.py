@@ -76,8 +76,17 @@ def test_c4_full_batch(pkg, orc):
     assert all(s["termination_type"] == 0 for s in summ), "every scene of C4 converges"
     its = np.array([s["num_lm_steps"] for s in summ])
     assert its.min() >= 3 and its.max() < 200
-    for i in range(n):
-        assert np.abs(cams[i][:, 0] - scenes[i].cam_gt[:, 0]).mean() < 2.5
+    # Focal lengths come back at noise level -- except where the ALGORITHM ends in a poor local minimum: scene 609 of this seed
+    # stream does (121 LM steps, the straggler of the batch), in the oracle exactly as on the device.  Such scenes are held to
+    # the oracle instead of to the ground truth.
+    ferr = np.array([np.abs(cams[i][:, 0] - scenes[i].cam_gt[:, 0]).mean() for i in range(n)])
+    off = [int(i) for i in np.flatnonzero(ferr >= 2.5)]
+    assert len(off) <= 3, off
+    for k in off:
+        ocam, _, _, osumm, _ = orc.ba_solve(scenes[k], jacobian_mode=orc.JAC_ANALYTIC, num_threads=orc.usable_cores())
+        assert summ[k]["num_iterations"] == osumm["num_iterations"] and summ[k]["num_successful_steps"] == osumm["num_successful_steps"]
+        assert abs(summ[k]["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-9
+        assert _rel(cams[k][:, 0], ocam[:, 0]) < 1e-6
     sample = [0, 1, 7, 113, 429, 631, 847, 999]
     for k in sample:
         cam, ray, s = pkg.api.ba_solve(scenes[k])
@@ -177,3 +186,29 @@ def test_nccl_backend_world_size_one(pkg, tmp_path):
     assert d["n_gpus"] == 1 and d["converged_scenes"] == 8
     assert d["parallel"]["backend"] == "nccl" and d["parallel"]["world_size_seen_by_collective"] == 1
     assert d["parallel"]["gather_ms"] is not None and d["parallel"]["ranks_ms_per_step"] is not None
+
+
+def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg):
+    """PtzIncrementalOptimizer::SolveBatch (host/device_batcher.h): rigs of different size in lock step -- all pending bundle
+    adjustments of a round in ONE ptz_ba_batch, all pending registration attempts in ONE ptz_krt_solve_batch launch -- against
+    the same rigs calibrated one after the other (the reference's loop, run_ptzba_synthetic.sh:4-13): identical event
+    sequences (seed pair, every registration and the reference it was made against, every bundle adjustment with its iteration
+    count), identical registered sets, bit-identical cameras.  And the batching is real: fewer library calls than solo runs make."""
+    shapes = [(1, 20, True), (3, 24, False), (6, 40, True), (2, 20, True), (9, 32, True)]
+    tables, cam0 = [], []
+    for seed, n_views, bi in shapes:
+        sc = pkg.synth.make_scene(seed, n_views, 100)
+        tb = pkg.synth.make_match_table(sc, bidirectional=bi)
+        tables.append(tb)
+        c = np.zeros((tb.n_img, 15)); c[:, 0] = c[:, 1] = 1.0
+        cam0.append(c)
+    solo = [pkg.hostlib.incremental_solve(tb, c, max_iter=200) for tb, c in zip(tables, cam0)]
+    batch, stats = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200)
+    for a, b in zip(solo, batch):
+        assert a["ok"] and b["ok"]
+        assert a["events"] == b["events"]
+        assert a["registered"] == b["registered"] and a["lm_iterations"] == b["lm_iterations"]
+        assert np.array_equal(a["cameras"], b["cameras"])
+    n_ba_solo = sum(sum(1 for e in a["events"] if e[0] == 2) for a in solo)
+    assert stats["ba_problems"] == n_ba_solo and stats["ba_batches"] < 0.5 * n_ba_solo
+    assert stats["krt_launches"] <= stats["rounds"]
