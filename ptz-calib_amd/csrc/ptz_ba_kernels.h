@@ -1338,9 +1338,36 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   double* T = TG ? d.Tbuf + (size_t)o0 * TS : tab;             // [no][TS]
   double* part = tab;                                          // [THREADS][PS]
   for (int t = threadIdx.x; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
-  for (int e = threadIdx.x; e < nent; e += THREADS) eslot[e] = (unsigned short)(d.ent[ent0 + e] & 0xffffu);
+  auto stage_entries = [&]() {  // eight loads in flight per thread (a plain loop waits for every load before its LDS store)
+    for (int e0 = 0; e0 < nent; e0 += 8 * THREADS) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = d.ent[ent0 + min(e0 + u * THREADS + (int)threadIdx.x, nent - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * THREADS + (int)threadIdx.x;
+        if (e < nent) eslot[e] = (unsigned short)(v[u] & 0xffffu);
+      }
+    }
+  };
   auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
   const double* camtab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
+  // this thread's run of phase 2 and the other camera's block are fetched during phase 1 (three dependent global loads would
+  // otherwise stand between the barrier and the first entry): the run record behind the gathers, the rest behind the trips
+  const int* pcj = d.pair_cj + s.pair_off + pr0;
+  uint2 rr = make_uint2(0u, 0u);
+  const double* cbj = camtab;
+  double Rj[9], fj = 0, fyj = 0, kj[F ? 5 : 1], dj[F == 3 ? 3 : 1];
+  auto load_cj = [&]() {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
+    fj = cbj[CB_F];
+    fyj = F == 2 ? cbj[CB_FY] : fj;
+#pragma unroll
+    for (int k = 0; k < (F ? 5 : 1); ++k) kj[k] = F ? cbj[CB_K + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < (F == 3 ? 3 : 1); ++k) dj[k] = F == 3 ? cbj[CB_D + k] : 0.0;
+  };
   // ---- phase 1
   {
     const double* cbi = camtab + (size_t)ci * CBS;  // uniform: scalar loads, hoisted out of the loop
@@ -1359,8 +1386,11 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
     for (int k = 0; k < NU; ++k) D[k] = 0;
-    // Two dependent loads stand before an observation's arithmetic: its ray id, then the ray's record.  Both are fetched ahead --
-    // the id two trips, the record one -- with unconditional loads (past the camera's end the index is clamped, the data unused).
+    // Two dependent loads stand before an observation's arithmetic -- its ray id, then the ray's 128-byte record, a gather that
+    // takes 2-3 us on a loaded chip, more than a trip's arithmetic -- so the records of the first PF trips (768 observations:
+    // every view of a C2 rig) are ALL asked for before the first one is used: the latency is paid once per workgroup, not once
+    // per trip (measured 9.2 us of phase 1 per workgroup with a one-trip-ahead prefetch).  Unconditional loads: past the
+    // camera's end the index is clamped and the data unused.
     typedef double d16 __attribute__((ext_vector_type(16)));
     auto load_rec = [&](int gj) {
       const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
@@ -1370,12 +1400,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
       return v;
     };
     auto oclamp = [&](int q) { return o0 + min(q, max(no - 1, 0)); };
-    d16 rc_n = load_rec(d.cam_ray[oclamp((int)threadIdx.x)]);
-    int gj_n = d.cam_ray[oclamp((int)threadIdx.x + THREADS)];
-    for (int q = threadIdx.x; q < no; q += THREADS) {
-      const d16 rc = rc_n;
-      rc_n = load_rec(gj_n);
-      gj_n = d.cam_ray[oclamp(q + 2 * THREADS)];
+    auto process = [&](const d16& rc, int q) {
       const double2 r0 = make_double2(rc[0], rc[1]), r1 = make_double2(rc[2], rc[3]), r2 = make_double2(rc[4], rc[5]), r3 = make_double2(rc[6], rc[7]),
                     r4 = make_double2(rc[8], rc[9]), r5 = make_double2(rc[10], rc[11]), r6 = make_double2(rc[12], rc[13]), r7 = make_double2(rc[14], rc[15]);
       const double e0 = r0.x, e1 = r0.y, e2 = r1.x, e3 = r1.y, e4 = r2.x, e5 = r2.y;
@@ -1417,7 +1442,25 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
         for (int qq = 0; qq <= p; ++qq) D[e++] += t0 * w[3 * qq] + t1 * w[3 * qq + 1] + t2 * w[3 * qq + 2];
       }
       Tq[NT] = Xn[0]; Tq[NT + 1] = Xn[1]; Tq[NT + 2] = Xn[2];
+    };
+    constexpr int PF = 3;
+    int gid[PF];
+    d16 rcs[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * THREADS)];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
+    if ((int)threadIdx.x < nrun) rr = runs[threadIdx.x];
+    stage_entries();  // (behind the gathers in the memory queue, ahead of them in nothing)
+    const int cjx = npr > 0 ? pcj[rr.y & 0xffffu] : 0;  // (arrives during the trips below)
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      const int q = (int)threadIdx.x + t * THREADS;
+      if (q < no) process(rcs[t], q);
     }
+    for (int q = (int)threadIdx.x + PF * THREADS; q < no; q += THREADS) process(load_rec(d.cam_ray[o0 + q]), q);  // (very large views)
+    cbj = camtab + (size_t)cjx * CBS;
+    load_cj();  // on its way during the reductions and the barrier below
     // one pass of the block tree for all NW + NU sums (fixed order: lanes by butterfly, waves in wave order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NV = NW + NU;
@@ -1469,7 +1512,6 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   }
   SC_STAMP(2);
   // ---- phase 2: off-diagonal blocks of row-block ci, one run of entries per thread
-  const int* pcj = d.pair_cj + s.pair_off + pr0;
   const int* prun = d.pair_run + s.pair_off + s.idx + pr0;    // first run of each of this camera's pairs; prun[npr] = end of the last
   // Without TG the host has cut the entries into at most THREADS runs: ONE round, after which the T table is dead and its
   // LDS space takes the run sums.  With the T table in global memory (very many observations or pairs in one view) the runs
@@ -1480,18 +1522,13 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
 #pragma unroll
     for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
     if (r < nrun) {
-      const uint2 rr = runs[r];
+      if (base > 0) {  // (a later round of a view with more runs than threads: the first round's were fetched ahead)
+        rr = runs[r];
+        cbj = camtab + (size_t)pcj[rr.y & 0xffffu] * CBS;
+        load_cj();
+      }
       const int cnt = (int)(rr.y >> 16);
       const unsigned short* es = eslot + ((int)rr.x - ent0);  // this run's a slots
-      const double* cbj = camtab + (size_t)pcj[rr.y & 0xffffu] * CBS;
-      double Rj[9], kj[F ? 5 : 1], dj[F == 3 ? 3 : 1];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
-      const double fj = cbj[CB_F], fyj = F == 2 ? cbj[CB_FY] : fj;
-#pragma unroll
-      for (int k = 0; k < (F ? 5 : 1); ++k) kj[k] = F ? cbj[CB_K + k] : 0.0;
-#pragma unroll
-      for (int k = 0; k < (F == 3 ? 3 : 1); ++k) dj[k] = F == 3 ? cbj[CB_D + k] : 0.0;
       // the row of the NEXT entry is read from LDS while the current one is worked on (past the end the last row again)
       double Tn[NT + 3];
       {
