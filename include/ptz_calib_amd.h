@@ -74,6 +74,12 @@ typedef struct ptz_lm_options {
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
+  /* ptz_krt_solve_batch*: lanes of a wavefront that work on one query.  64 = a wave per query (lowest latency: registration
+   * attempts, a handful of queries); 16 = four queries per wave (highest throughput once the launch fills the GPU); 0 = the
+   * library picks from the launch size (16 from 16384 queries on).  The two forms add the matches up in different orders: a
+   * query's bits depend on the form, never on its neighbours in the launch -- callers that compare runs bit by bit pin it. */
+  int32_t krt_lanes_per_query;               /* 0 */
+  int32_t reserved_;                         /* 0 */
 } ptz_lm_options;
 
 /* The ceres::Solver::Summary fields the reference reads (ptzray_optimizer.cc:962-963,482;
@@ -101,7 +107,7 @@ const char* ptz_version(void);
 int32_t ptz_device_count(void);
 /* The reference builds a new optimizer object per solve; so do callers of this library.  Device blocks, pinned blocks,
  * streams and events released by finished solves are parked in a process-wide cache (budget PTZ_CACHE_MAX_MB of device
- * memory per GPU, default 4096) and reused by later ones.  ptz_trim_cache() hands everything parked back to the driver. */
+ * memory per GPU, default 32768) and reused by later ones.  ptz_trim_cache() hands everything parked back to the driver. */
 void ptz_trim_cache(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -40,7 +40,8 @@ class LmOptions(C.Structure):
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double),
-                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double)]
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("krt_lanes_per_query", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class LmSummary(C.Structure):

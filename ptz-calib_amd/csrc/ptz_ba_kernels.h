@@ -1315,13 +1315,35 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
-  const int* cpair = d.cam_pair + s.cam_off + s.idx;
-  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
 #ifdef PTZ_SCHUR_STAMPS
   const bool stamp_on = slot == 0 && ci == (s.n_cam * 3) / 4 && threadIdx.x == 0;
-  long long sc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long sc_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   SC_STAMP(0);
+  // ---- phase 1, first thing: the gathers.  Two dependent loads stand before an observation's arithmetic -- its ray id, then
+  // the ray's 128-byte record, 2-5 us away on a loaded chip, more than a trip's arithmetic -- so the records of the first PF
+  // trips (768 observations: every view of a C2 rig) are ALL asked for here, before anything else the kernel needs (its
+  // structure, the camera block, the entry list: measured 5.5 us of dependent scalar and vector loads in front of the gathers
+  // when they were issued where phase 1 begins).  Unconditional loads: past the camera's end the index is clamped and the
+  // data unused.
+  typedef double d16 __attribute__((ext_vector_type(16)));
+  auto load_rec = [&](int gj) {
+    const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
+    d16 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    return v;
+  };
+  auto oclamp = [&](int q) { return o0 + min(q, max(no - 1, 0)); };
+  constexpr int PF = 3;
+  int gid[PF];
+  d16 rcs[PF];
+#pragma unroll
+  for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * schur_threads<TYPE>())];
+#pragma unroll
+  for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
+  const int* cpair = d.cam_pair + s.cam_off + s.idx;
+  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   constexpr int PS = (NW * NW) | 1;  // doubles per run sum in LDS (odd pitch)
   const int ntl = d.chol.np / CHOL_NB;
   double* strip = lds;                                         // [waves][NW + NU] reduction strip of phase 1
@@ -1332,24 +1354,14 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   const int* crun = d.cam_run + s.cam_off + s.idx;
   const int run0 = crun[ci], nrun = crun[ci + 1] - run0;      // this camera's runs (scene-local numbers)
   const uint2* runs = d.run_rec + s.run_off + run0;
-  const int ent0 = nrun > 0 ? (int)runs[0].x : 0;              // first entry of the camera (global index)
-  const int nent = nrun > 0 ? (int)(runs[nrun - 1].x + (runs[nrun - 1].y >> 16)) - ent0 : 0;
+  const int* ppt = d.pair_ptr + s.pair_off + s.idx + pr0;      // entry offsets of this camera's pairs (global entry index)
+  const int ent0 = npr > 0 ? ppt[0] : 0;                       // first entry of the camera
+  const int nent = npr > 0 ? ppt[npr] - ent0 : 0;
   double* tab = reinterpret_cast<double*>(eslot + ((d.schur_ent_cap + 3) & ~3));  // T table, later the run sums
   double* T = TG ? d.Tbuf + (size_t)o0 * TS : tab;             // [no][TS]
   double* part = tab;                                          // [THREADS][PS]
-  for (int t = threadIdx.x; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (visible after the barrier below)
-  auto stage_entries = [&]() {  // eight loads in flight per thread (a plain loop waits for every load before its LDS store)
-    for (int e0 = 0; e0 < nent; e0 += 8 * THREADS) {
-      unsigned v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = d.ent[ent0 + min(e0 + u * THREADS + (int)threadIdx.x, nent - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * THREADS + (int)threadIdx.x;
-        if (e < nent) eslot[e] = (unsigned short)(v[u] & 0xffffu);
-      }
-    }
-  };
+  // (tile order and entry list are staged behind the trips of phase 1: a load's LDS store waits for every load issued before
+  //  it, the gathers included, so nothing that is stored to LDS may be loaded between the gathers and the trips)
   auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
   const double* camtab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
   // this thread's run of phase 2 and the other camera's block are fetched during phase 1 (three dependent global loads would
@@ -1386,20 +1398,6 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
     for (int k = 0; k < NU; ++k) D[k] = 0;
-    // Two dependent loads stand before an observation's arithmetic -- its ray id, then the ray's 128-byte record, a gather that
-    // takes 2-3 us on a loaded chip, more than a trip's arithmetic -- so the records of the first PF trips (768 observations:
-    // every view of a C2 rig) are ALL asked for before the first one is used: the latency is paid once per workgroup, not once
-    // per trip (measured 9.2 us of phase 1 per workgroup with a one-trip-ahead prefetch).  Unconditional loads: past the
-    // camera's end the index is clamped and the data unused.
-    typedef double d16 __attribute__((ext_vector_type(16)));
-    auto load_rec = [&](int gj) {
-      const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
-      d16 v;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
-      return v;
-    };
-    auto oclamp = [&](int q) { return o0 + min(q, max(no - 1, 0)); };
     auto process = [&](const d16& rc, int q) {
       const double2 r0 = make_double2(rc[0], rc[1]), r1 = make_double2(rc[2], rc[3]), r2 = make_double2(rc[4], rc[5]), r3 = make_double2(rc[6], rc[7]),
                     r4 = make_double2(rc[8], rc[9]), r5 = make_double2(rc[10], rc[11]), r6 = make_double2(rc[12], rc[13]), r7 = make_double2(rc[14], rc[15]);
@@ -1443,24 +1441,25 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
       }
       Tq[NT] = Xn[0]; Tq[NT + 1] = Xn[1]; Tq[NT + 2] = Xn[2];
     };
-    constexpr int PF = 3;
-    int gid[PF];
-    d16 rcs[PF];
-#pragma unroll
-    for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * THREADS)];
-#pragma unroll
-    for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
     if ((int)threadIdx.x < nrun) rr = runs[threadIdx.x];
-    stage_entries();  // (behind the gathers in the memory queue, ahead of them in nothing)
     const int cjx = npr > 0 ? pcj[rr.y & 0xffffu] : 0;  // (arrives during the trips below)
+    SC_STAMP(8);
 #pragma unroll
     for (int t = 0; t < PF; ++t) {
       const int q = (int)threadIdx.x + t * THREADS;
       if (q < no) process(rcs[t], q);
+      SC_STAMP(9 + t);
     }
     for (int q = (int)threadIdx.x + PF * THREADS; q < no; q += THREADS) process(load_rec(d.cam_ray[o0 + q]), q);  // (very large views)
     cbj = camtab + (size_t)cjx * CBS;
     load_cj();  // on its way during the reductions and the barrier below
+    // tile order and the first 8 x THREADS entries of the camera's list: loads here, LDS stores behind the reductions
+    int tord_v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int t = (int)threadIdx.x + u * THREADS; tord_v[u] = d.tperm ? d.tperm[(size_t)sc * ntl + min(t, ntl - 1)] : t; }
+    unsigned ent_v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ent_v[u] = d.ent[ent0 + max(min(u * THREADS + (int)threadIdx.x, nent - 1), 0)];
     // one pass of the block tree for all NW + NU sums (fixed order: lanes by butterfly, waves in wave order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NV = NW + NU;
@@ -1473,7 +1472,20 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
 #pragma unroll
       for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
     }
-    __syncthreads();  // also orders the T stores before phase 2
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int t = (int)threadIdx.x + u * THREADS; if (t < ntl) tord[t] = tord_v[u]; }
+    for (int t = (int)threadIdx.x + 2 * THREADS; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (more than 512 tiles)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = u * THREADS + (int)threadIdx.x; if (e < nent) eslot[e] = (unsigned short)(ent_v[u] & 0xffffu); }
+    for (int e0 = 8 * THREADS; e0 < nent; e0 += 8 * THREADS) {  // (a view with more than 2048 entries: eight loads in flight again)
+      unsigned v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = d.ent[ent0 + min(e0 + u * THREADS + (int)threadIdx.x, nent - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * THREADS + (int)threadIdx.x; if (e < nent) eslot[e] = (unsigned short)(v8[u] & 0xffffu); }
+    }
+    SC_STAMP(12);
+    __syncthreads();  // also orders the T, tile-order and entry stores before phase 2
   }
   SC_STAMP(1);
   const int np = d.chol.np;
@@ -1629,8 +1641,9 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
 #ifdef PTZ_SCHUR_STAMPS
   SC_STAMP(6);
   if (stamp_on)
-    printf("k_schur cam %d: obs %d pairs %d runs %d | x10 ns: phase1 %lld, diag %lld, runs(thread 0) %lld, wait %lld, sums %lld, store %lld\n", ci, no, npr, nrun,
-           sc_t[1] - sc_t[0], sc_t[2] - sc_t[1], sc_t[3] - sc_t[2], sc_t[4] - sc_t[3], sc_t[5] - sc_t[4], sc_t[6] - sc_t[5]);
+    printf("k_schur cam %d: obs %d pairs %d runs %d | x10 ns: phase1 %lld (issue+stage %lld, trips %lld %lld %lld, reduce %lld, barrier %lld), diag %lld, runs(thread 0) %lld, wait %lld, sums %lld, store %lld\n", ci, no, npr, nrun,
+           sc_t[1] - sc_t[0], sc_t[8] - sc_t[0], sc_t[9] - sc_t[8], sc_t[10] - sc_t[9], sc_t[11] - sc_t[10], sc_t[12] - sc_t[11], sc_t[1] - sc_t[12],
+           sc_t[2] - sc_t[1], sc_t[3] - sc_t[2], sc_t[4] - sc_t[3], sc_t[5] - sc_t[4], sc_t[6] - sc_t[5]);
 #endif
 }
 
@@ -2070,6 +2083,23 @@ __global__ __launch_bounds__(1024) void k_compact(Dev d)
     __hip_atomic_store(&d.host_ctl[2], base_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// ---- gather_state: every scene's CURRENT state (LmState.cur selects the half) into contiguous arrays in the caller's order ----
+__global__ __launch_bounds__(256) void k_gather_state(Dev d, const int* __restrict__ ray_perm, double* __restrict__ cam_out,
+                                                       double* __restrict__ ray_out, double* __restrict__ tlw_out)
+{
+  const int sc = blockIdx.y;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < s.n_cam * 15) cam_out[(size_t)s.cam_off * 15 + i] = cur_cam(d, s, st)[i];
+  if (i < s.n_ray) {  // internal ray i is the caller's ray ray_perm[i]
+    const double* x = cur_ray(d, s, st) + (size_t)i * 3;
+    double* o = ray_out + ((size_t)s.ray_off + ray_perm[s.ray_off + i]) * 3;
+    o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+  }
+  if (i < 6) tlw_out[(size_t)s.idx * 6 + i] = d.tlw_x[(size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6 + i];
+}
+
 __global__ void k_fill(double* p, size_t n, double v)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,6 +27,7 @@ struct KrtOpt {
   int max_num_iterations, max_consecutive_invalid, jacobi_scaling;
   double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
   double function_tolerance, gradient_tolerance, parameter_tolerance, max_reproj_error;
+  int lanes_per_query;  // host side only (launch_krt)
 };
 
 // 15-vector index of free parameter k: F {0,4,5,6}, FDist {0,4,5,6,10}, Fxfy {0,1,4,5,6}, FxfyDist {0,1,4,5,6,10}
@@ -424,14 +425,18 @@ KrtOpt make_krt_opt(const ptz_lm_options& o, double max_reproj_error)
   ko.gradient_tolerance = o.gradient_tolerance;
   ko.parameter_tolerance = o.parameter_tolerance;
   ko.max_reproj_error = max_reproj_error;
+  ko.lanes_per_query = o.krt_lanes_per_query;
   return ko;
 }
 
-// lanes per query of a launch of n_query queries (see k_krt): the throughput form from 2048 queries on, PTZ_KRT_GROUP overrides
-inline int krt_group_size(int n_query)
+// lanes per query of a launch of n_query queries (see k_krt): ptz_lm_options::krt_lanes_per_query, else PTZ_KRT_GROUP, else by launch size
+// (the throughput form only once the launch fills the chip -- 256 compute units x 8 waves x 4 queries: below that a launch
+// lasts as long as its slowest query, which sixteen lanes make four times slower)
+inline int krt_group_size(int n_query, int requested)
 {
+  if (requested == 16 || requested == 64) return requested;
   if (const char* e = getenv("PTZ_KRT_GROUP")) { const int g = atoi(e); if (g == 16 || g == 64) return g; }
-  return n_query >= 2048 ? 16 : 64;
+  return n_query >= 16384 ? 16 : 64;
 }
 
 // one launch over device-resident queries (all pointers are device pointers; d_pptr = nullptr: no 2D-3D constraints)
@@ -439,7 +444,7 @@ void launch_krt(int n_query, const long long* d_ptr, const float2* d_ref, const 
                 const float2* d_puv, const double* d_pxyz, const double* d_cref, double* d_ccur, int factor_type, const KrtOpt& ko,
                 ptz_lm_summary* d_sum, int* d_acc, hipStream_t st)
 {
-  const int G = krt_group_size(n_query);
+  const int G = krt_group_size(n_query, ko.lanes_per_query);
   const int qpb = 256 / G;
   const dim3 grid((n_query + qpb - 1) / qpb), block(256);
   const bool p3 = d_pptr != nullptr;

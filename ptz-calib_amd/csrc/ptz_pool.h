@@ -4,7 +4,7 @@
 // hipMalloc / hipStreamCreate / hipEventCreate calls per solve costs milliseconds -- more than the solve itself for small
 // problems -- so released resources are parked here and handed to the next solve instead of going back to the driver.
 //  * device blocks: size classes {1, 1.25, 1.5, 1.75} x 2^k (<= 25 % slack), parked up to a byte budget
-//    (PTZ_CACHE_MAX_MB, default 4096); anything beyond the budget is freed immediately, so large batches do not pin HBM;
+//    (PTZ_CACHE_MAX_MB, default 32768); anything beyond the budget is freed immediately, so large batches do not pin HBM;
 //  * everything is released by ptz_trim_cache().
 #pragma once
 
@@ -33,7 +33,7 @@ struct State {
   size_t budget = 0;
   State()  // (in the constructor: the function-local static below is initialised exactly once, also under concurrent first use)
   {
-    size_t mb = 4096;
+    size_t mb = 32768;  // of 288 GB: successive batches of different size (the lock-step PTZ-IBA) otherwise thrash hipMalloc / hipFree
     if (const char* e = getenv("PTZ_CACHE_MAX_MB")) mb = (size_t)atoll(e);
     budget = mb << 20;
   }

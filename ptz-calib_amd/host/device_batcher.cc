@@ -2,6 +2,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <thread>
 
 namespace ptzcalib {
 
@@ -108,10 +109,27 @@ void DeviceBatcher::RunBa(std::vector<BaReq*>& reqs)
   const double t0 = NowMs();
   ++stats_.ba_batches;
   stats_.ba_problems += static_cast<long>(reqs.size());
+  // A batch costs host time on both sides of its device time (structure of every problem, uploads, read-back): a large group
+  // goes as up to four batches on four host threads, so that one batch's host work overlaps another's device work.  A
+  // problem's result does not depend on the batch it is in.
+  const size_t parts = reqs.size() >= 16 ? 4 : (reqs.size() >= 8 ? 2 : 1);
+  if (parts > 1) {
+    std::vector<std::vector<BaReq*>> chunk(parts);
+    for (size_t i = 0; i < reqs.size(); ++i) chunk[i * parts / reqs.size()].push_back(reqs[i]);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; ++k) th.emplace_back([&, k] { RunBaBatch(chunk[k]); });
+    RunBaBatch(chunk[0]);
+    for (std::thread& t : th) t.join();
+  }
+  else RunBaBatch(reqs);
+  stats_.ba_ms += NowMs() - t0;
+}
+
+void DeviceBatcher::RunBaBatch(std::vector<BaReq*>& reqs)
+{
   if (reqs.size() == 1) {
     BaReq& r = *reqs[0];
     r.rc = ptz_ba_solve(r.p, r.cam, r.ray, r.tlw, r.opt, r.summary);
-    stats_.ba_ms += NowMs() - t0;
     return;
   }
   const int32_t n = static_cast<int32_t>(reqs.size());
@@ -143,7 +161,6 @@ void DeviceBatcher::RunBa(std::vector<BaReq*>& reqs)
   if (rc != PTZ_OK && rc != PTZ_ENODEVICE && rc != PTZ_ENOMEM) {
     // one malformed / oversized problem must not fail its neighbours: every request gets its own verdict
     for (BaReq* r : reqs) r->rc = ptz_ba_solve(r->p, r->cam, r->ray, r->tlw, r->opt, r->summary);
-    stats_.ba_ms += NowMs() - t0;
     return;
   }
   size_t co = 0, ro = 0;
@@ -158,7 +175,6 @@ void DeviceBatcher::RunBa(std::vector<BaReq*>& reqs)
     }
     co += probs[i].n_cam; ro += probs[i].n_ray;
   }
-  stats_.ba_ms += NowMs() - t0;
 }
 
 void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
@@ -195,8 +211,12 @@ void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
     }
   }
   double dev_ms = 0;
+  // the merged launch must give every query the bits of its own small launch: the form is pinned to what those pick (a wave per
+  // query, the latency form), whatever the merged size
+  ptz_lm_options opt = *reqs[0]->opt;
+  if (opt.krt_lanes_per_query == 0) opt.krt_lanes_per_query = 64;
   const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(nq), ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(), cam_cur.data(),
-                                         reqs[0]->factor_type, reqs[0]->max_reproj_error, reqs[0]->opt, summ.data(), acc.data(), &dev_ms);
+                                         reqs[0]->factor_type, reqs[0]->max_reproj_error, &opt, summ.data(), acc.data(), &dev_ms);
   size_t q0 = 0;
   for (KrtReq* r : reqs) {
     r->rc = rc;

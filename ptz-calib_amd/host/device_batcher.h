@@ -56,6 +56,7 @@ class DeviceBatcher {
   void Arrive(std::unique_lock<std::mutex>& lk);  // called with the request already queued
   void RunRound();                                // executes and clears the queues (lock held: every other client is waiting)
   void RunBa(std::vector<BaReq*>& reqs);
+  static void RunBaBatch(std::vector<BaReq*>& reqs);  // one ptz_ba_batch for all of them
   void RunKrt(std::vector<KrtReq*>& reqs);
 
   std::mutex mu_;

@@ -14,3 +14,4 @@ if [ "${KRT:-1}" = "1" ]; then for g in 64 16; do
   PTZ_KRT_GROUP=$g timeout 200 python tools/probes/probe_krt.py 100000 1 2>&1 | grep '^{' | head -1 | tee -a $O/krt.txt
 done; fi
 [ "${OVH:-0}" = "1" ] && timeout 600 python tools/probes/probe_batch_overheads.py 64 2>&1 | tail -12 | tee $O/overheads.txt
+[ "${IBA:-0}" = "1" ] && timeout 900 python tools/probes/probe_iba_batch.py 64 200 2>&1 | tail -6 | tee $O/iba.txt
