@@ -19,6 +19,7 @@ ap.add_argument("--tag", required=True)
 ap.add_argument("--n-obs", type=float, default=100440.0)
 ap.add_argument("--n-ray", type=float, default=13432.0)
 ap.add_argument("--n-ent", type=float, default=470000.0)
+ap.add_argument("--schur-w", action="store_true", help="the profiled library ran with PTZ_BA_SCHUR_W=1 (round 2's k_schur_w)")
 args = ap.parse_args()
 s = {}
 for f in args.summaries:
@@ -27,7 +28,9 @@ for f in args.summaries:
 
 # bytes a kernel reads as STREAMS per active scene and pass (C2-shaped scene; data layout of DESIGN.md section 3)
 STREAMS = {
-    "k_schur": 100.0 * args.n_obs + 4.0 * args.n_ent,            # a camera's W rows (96 B) + ray ids (4 B) per observation, 4-byte entry records
+    # round 3: no W rows any more -- ray ids (4 B) per observation, 4-byte entry records, 8-byte run records (<= 256 per view);
+    # the 128-byte per-ray records are gathered.  (--schur-w: round 2's kernel, a camera's W rows (96 B) streamed as well)
+    "k_schur": (100.0 if args.schur_w else 4.0) * args.n_obs + 4.0 * args.n_ent + (0.0 if args.schur_w else 8.0 * 256 * 200),
     "k_lin_cam": 12.0 * args.n_obs,                               # pixel (8 B) + ray id (4 B) per observation; the 64-byte ray records are gathered
     "k_eval": 2 * 16.0 * args.n_obs + 200.0 * args.n_ray,         # observation records twice, per-ray arrays
     "k_lin_ray": 16.0 * args.n_obs + 100.0 * args.n_ray,

@@ -86,6 +86,7 @@ struct ptz_ba_batch {
   Dev d;
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;   // stream of the group being enqueued (LAUNCH / prof_* use it)
+  hipStream_t io = nullptr;       // uploads of ptz_ba_batch_create (before the group streams exist); see copy_on()
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // scenes are split into independent groups, one HIP stream each, so that the latency-bound kernels of one
   // group (diagonal-tile factorisation, back-substitution, LM control) overlap the throughput kernels of another
@@ -297,12 +298,42 @@ inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy, int thre
          2 * (size_t)((max_ent + 3) & ~3);
 }
 
+// Every host <-> device copy of a batch goes through a stream of its own and waits for THAT stream only.  hipMemcpy / hipMemset
+// run on the null stream, which synchronises with every other (blocking) stream of the process: batches driven from several
+// host threads (the lock-step PTZ-IBA, ptz_ba_solve_sharded's dealers) then wait for each other's solves inside their copies.
+inline hipError_t copy_on(hipStream_t st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+  if (bytes == 0) return hipSuccess;
+  // small copies go through a pinned block of the pool: an asynchronous copy from / to pageable memory waits inside the runtime
+  // (the same interrupt-driven wait stream_wait() avoids); large ones keep the direct path, their transfer time dominates
+  void* pin = nullptr;
+  if (bytes <= ((size_t)16 << 20) && ptzpool::pinned_acquire(bytes, &pin) == hipSuccess) {
+    hipError_t e;
+    if (kind == hipMemcpyHostToDevice) {
+      memcpy(pin, src, bytes);
+      e = hipMemcpyAsync(dst, pin, bytes, kind, st);
+      if (e == hipSuccess) e = stream_wait(st);
+    }
+    else {
+      e = hipMemcpyAsync(pin, src, bytes, kind, st);
+      if (e == hipSuccess) e = stream_wait(st);
+      if (e == hipSuccess) memcpy(dst, pin, bytes);
+    }
+    ptzpool::pinned_release(pin);
+    return e;
+  }
+  (void)hipGetLastError();
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  if (e == hipSuccess) e = stream_wait(st);
+  return e;
+}
+
 template <typename T> int upload(ptz_ba_batch* b, const std::vector<T>& h, const T** dev)
 {
   T* p = nullptr;
   int rc = b->alloc(&p, h.size());
   if (rc) return rc;
-  if (!h.empty() && hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
+  if (copy_on(b->io, p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
   *dev = p;
   return PTZ_OK;
 }
@@ -338,7 +369,7 @@ struct StagedUpload {
         char* p = nullptr;
         int rc = b->alloc(&p, it.bytes);
         if (rc) return rc;
-        if (it.bytes && hipMemcpy(p, it.src, it.bytes, hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
+        if (copy_on(b->io, p, it.src, it.bytes, hipMemcpyHostToDevice) != hipSuccess) return PTZ_ENODEVICE;
         *it.dst = p;
       }
       return PTZ_OK;
@@ -352,7 +383,8 @@ struct StagedUpload {
       *it.dst = dev + off;
       off += up(it.bytes);
     }
-    const hipError_t e = hipMemcpy(dev, pinned, total, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, b->io);
+    if (e == hipSuccess) e = stream_wait(b->io);
     ptzpool::pinned_release(pinned);
     return e == hipSuccess ? PTZ_OK : PTZ_ENODEVICE;
   }
@@ -637,7 +669,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     t_sync += now() - ts0;
   }
   if (watchdog_rc != PTZ_OK) {
-    for (int g = 0; g < G; ++g) (void)hipStreamSynchronize(b->streams[g]);  // nothing of this batch may be in flight when the caller frees it
+    for (int g = 0; g < G; ++g) (void)stream_wait(b->streams[g]);  // nothing of this batch may be in flight when the caller frees it
     (void)hipGetLastError();
     return watchdog_rc;
   }
@@ -650,7 +682,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   }
   b->stream = s0;
   PTZ_HIP_TRY(hipEventRecord(b->ev1, s0));
-  PTZ_HIP_TRY(hipStreamSynchronize(s0));
+  PTZ_HIP_TRY(stream_wait(s0));
   PTZ_HIP_TRY(hipGetLastError());  // a kernel launch that was refused (resources, arguments) must not pass for a solve
   float ms = 0;
   (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
@@ -659,7 +691,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   if (dbg) fprintf(stderr, "[ptz_ba] groups %d: total %.2f ms, enqueue %.2f ms, sync-wait %.2f ms, device %.2f ms\n", G, now() - t_start, t_enq, t_sync, ms);
   if (out) {
     std::vector<LmState> h(B);
-    PTZ_HIP_TRY(hipMemcpy(h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
     for (int i = 0; i < B; ++i) {
       ptz_lm_summary& s = out[i];
       s.termination_type = h[i].termination;
@@ -840,8 +872,9 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   if (!b) return;
   DeviceGuard guard(b->device);
   // nothing of this batch may still be running when its memory is handed to the next one
-  for (auto st : b->streams) (void)hipStreamSynchronize(st);
-  for (auto st : b->aux) (void)hipStreamSynchronize(st);
+  for (auto st : b->streams) (void)stream_wait(st);
+  for (auto st : b->aux) (void)stream_wait(st);
+  if (b->io) (void)stream_wait(b->io);
   const int dv = b->device;
   for (void* p : b->allocs) ptzpool::dev_release(dv, p);
   for (auto e : b->ev_pool) ptzpool::event_release(dv, true, e);
@@ -851,6 +884,7 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   ptzpool::event_release(dv, true, b->ev1);
   for (auto st : b->streams) ptzpool::stream_release(dv, st);
   for (auto st : b->aux) ptzpool::stream_release(dv, st);
+  ptzpool::stream_release(dv, b->io);
   for (auto e : b->la_ev) ptzpool::event_release(dv, false, e);
   for (auto e : b->fork_ev) ptzpool::event_release(dv, false, e);
   for (auto e : b->join_ev) ptzpool::event_release(dv, false, e);
@@ -1095,6 +1129,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   ptz_ba_batch* b = new ptz_ba_batch();
   b->has3d = has3d;
   b->n_scene = n; b->type = type; b->nc = NC; b->opt = o; b->device = o.device_id;
+  if (ptzpool::stream_acquire(b->device, &b->io) != hipSuccess) { delete b; return PTZ_ENODEVICE; }
   // rays per workgroup of the ray-centric kernels: one rig's ~13 k rays on 1024-ray workgroups keep 14 compute units busy,
   // so a few scenes use small workgroups; large batches amortise the LDS camera tables over many rays (results do not
   // depend on it: per-ray sums are reduced per wave of 64 rays)
@@ -1326,7 +1361,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.Jc3, (size_t)b->total_o3 * 2 * NC));
   TRY(b->alloc(&d.Jt3, (size_t)b->total_o3 * 12));
   TRY(b->alloc(&d.r3, (size_t)b->total_o3 * 2));
-  if (hipMemset(b->tlw0, 0, sizeof(double) * d.tlw_stride) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+  if (hipMemsetAsync(b->tlw0, 0, sizeof(double) * d.tlw_stride, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   d.cam_stride = (size_t)b->total_cam * 15;
   d.ray_stride = (size_t)b->total_ray * 3;
   TRY(b->alloc(&d.cam_x, 2 * d.cam_stride));
@@ -1336,7 +1371,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     d.dsp_stride = (size_t)b->total_cam * 3;
     TRY(b->alloc(&d.dsp_x, 2 * d.dsp_stride));
     TRY(b->alloc(&b->dsp0, d.dsp_stride));
-    if (hipMemset(b->dsp0, 0, sizeof(double) * d.dsp_stride) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // :655
+    if (hipMemsetAsync(b->dsp0, 0, sizeof(double) * d.dsp_stride, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // :655
   }
   TRY(b->alloc(&b->ray0, d.ray_stride));
   d.camblk_stride = ((size_t)b->total_cam * CBS + 2 + 1) & ~(size_t)1;
@@ -1390,7 +1425,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     const int groups = std::max(1, std::min(b->n_group_hint(n), n));
     const size_t slots = (size_t)std::min(n, 8) * groups;
     TRY(b->alloc(&d.chol.L, slots * d.chol.np * d.chol.np));
-    if (hipMemset(d.chol.L, 0, sizeof(double) * slots * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    if (hipMemsetAsync(d.chol.L, 0, sizeof(double) * slots * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     TRY(b->alloc(&b->d_act, (size_t)n));
   }
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
@@ -1485,7 +1520,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       d.chol.sched_kmin = b->sched_kmin.data();
     }
     // tiles outside the structure are never written again: zero everything once (the block may be a recycled one)
-    if (hipMemset(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    if (hipMemsetAsync(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   }
 #undef TRY
   d.cam_x0 = b->cam0; d.ray_x0 = b->ray0;
@@ -1615,6 +1650,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       attr_done[o.device_id] = 1;
     }
   }
+  if (stream_wait(b->io) != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // the zero fills
   tc3 = now_ms();
   if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms (observations %.2f, pair entries %.2f), uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, ts_obs, ts_ent, tc2 - tc1, tc3 - tc2);
   *out = b;
@@ -1634,9 +1670,9 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
       for (int k = 0; k < 15; ++k)
         if (k < 4 || k >= 10) c[15 * (size_t)i + k] = c[15 * (size_t)f + k];
     }
-    PTZ_HIP_TRY(hipMemcpy(b->cam0, c.data(), sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
+    PTZ_HIP_TRY(copy_on(b->stream, b->cam0, c.data(), sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
   }
-  else PTZ_HIP_TRY(hipMemcpy(b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
+  else PTZ_HIP_TRY(copy_on(b->stream, b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
   {
     std::vector<double> r((size_t)3 * b->total_ray);
     for (const SceneDev& sd : b->scenes)
@@ -1645,10 +1681,10 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
         double* dst = r.data() + 3 * ((size_t)sd.ray_off + j);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
       }
-    PTZ_HIP_TRY(hipMemcpy(b->ray0, r.data(), sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
+    PTZ_HIP_TRY(copy_on(b->stream, b->ray0, r.data(), sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
   }
-  if (tlw) PTZ_HIP_TRY(hipMemcpy(b->tlw0, tlw, sizeof(double) * 6 * b->n_scene, hipMemcpyHostToDevice));
-  else PTZ_HIP_TRY(hipMemset(b->tlw0, 0, sizeof(double) * 6 * b->n_scene));
+  if (tlw) PTZ_HIP_TRY(copy_on(b->stream, b->tlw0, tlw, sizeof(double) * 6 * b->n_scene, hipMemcpyHostToDevice));
+  else { PTZ_HIP_TRY(hipMemsetAsync(b->tlw0, 0, sizeof(double) * 6 * b->n_scene, b->stream)); PTZ_HIP_TRY(stream_wait(b->stream)); }
   b->has_state = true;
   return PTZ_OK;
 }
@@ -1685,11 +1721,11 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
   double* s_tlw = s_ray + nr;
   hipLaunchKernelGGL(k_gather_state, dim3(std::max(1, (std::max(b->max_cam * 15, b->max_ray) + 255) / 256), b->n_scene), dim3(256), 0, b->stream, b->d,
                      b->d_ray_perm, s_cam, s_ray, s_tlw);
-  hipError_t e = hipStreamSynchronize(b->stream);
+  hipError_t e = stream_wait(b->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  if (e == hipSuccess && cam) e = hipMemcpy(cam, s_cam, sizeof(double) * nc, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && ray) e = hipMemcpy(ray, s_ray, sizeof(double) * nr, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && tlw) e = hipMemcpy(tlw, s_tlw, sizeof(double) * nt, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && cam) e = copy_on(b->stream, cam, s_cam, sizeof(double) * nc, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && ray) e = copy_on(b->stream, ray, s_ray, sizeof(double) * nr, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && tlw) e = copy_on(b->stream, tlw, s_tlw, sizeof(double) * nt, hipMemcpyDeviceToHost);
   ptzpool::dev_release(b->device, stage);
   if (e != hipSuccess) { (void)hipGetLastError(); return PTZ_ENODEVICE; }
   return PTZ_OK;
@@ -1704,7 +1740,7 @@ int32_t ptz_ba_batch_set_disp(ptz_ba_batch* b, const double* disp)
   for (const SceneDev& sd : b->scenes)
     for (int c = 0; c < sd.n_cam; ++c)
       for (int k = 0; k < 3; ++k) v[3 * ((size_t)sd.cam_off + c) + k] = disp[3 * (size_t)sd.idx + k];
-  PTZ_HIP_TRY(hipMemcpy(b->dsp0, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
+  PTZ_HIP_TRY(copy_on(b->stream, b->dsp0, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
   return PTZ_OK;
 }
 
@@ -1714,9 +1750,9 @@ int32_t ptz_ba_batch_get_disp(ptz_ba_batch* b, double* disp)
   if (b->type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
   PTZ_DEVICE_GUARD(b->device);
   std::vector<LmState> h(b->n_scene);
-  PTZ_HIP_TRY(hipMemcpy(h.data(), b->d.lm, sizeof(LmState) * b->n_scene, hipMemcpyDeviceToHost));
+  PTZ_HIP_TRY(copy_on(b->stream, h.data(), b->d.lm, sizeof(LmState) * b->n_scene, hipMemcpyDeviceToHost));
   for (int i = 0; i < b->n_scene; ++i)  // camera 0's copy (all copies of a scene are equal)
-    PTZ_HIP_TRY(hipMemcpy(disp + 3 * (size_t)i, b->d.dsp_x + h[i].cur * b->d.dsp_stride + 3 * (size_t)b->scenes[i].cam_off,
+    PTZ_HIP_TRY(copy_on(b->stream, disp + 3 * (size_t)i, b->d.dsp_x + h[i].cur * b->d.dsp_stride + 3 * (size_t)b->scenes[i].cam_off,
                           sizeof(double) * 3, hipMemcpyDeviceToHost));
   return PTZ_OK;
 }
@@ -1753,7 +1789,7 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b)
   clear_stale_error(__func__);
   PTZ_DEVICE_GUARD(b->device);
   hipLaunchKernelGGL(k_pix2ray, dim3(b->shapes[0].max_chunk, b->n_scene), dim3(b->shapes[0].ray_block), 0, b->stream, b->d, b->cam0, b->ray0);
-  PTZ_HIP_TRY(hipStreamSynchronize(b->stream));
+  PTZ_HIP_TRY(stream_wait(b->stream));
   PTZ_HIP_TRY(hipGetLastError());
   return PTZ_OK;
 }
@@ -1790,28 +1826,28 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     case 6: enqueue_linearize<6>(b); break;
     default: enqueue_linearize<7>(b); break;
   }
-  PTZ_HIP_TRY(hipStreamSynchronize(st));
+  PTZ_HIP_TRY(stream_wait(st));
   PTZ_HIP_TRY(hipGetLastError());
   const SceneDev& s = b->scenes[index];
   if (cost) {
     std::vector<double> c(s.n_cam);
-    PTZ_HIP_TRY(hipMemcpy(c.data(), d.costc + s.cam_off, sizeof(double) * s.n_cam, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, c.data(), d.costc + s.cam_off, sizeof(double) * s.n_cam, hipMemcpyDeviceToHost));
     double t = 0;
     for (double v : c) t += v;
     *cost = t;
   }
-  if (g_c) PTZ_HIP_TRY(hipMemcpy(g_c, d.gc + (size_t)s.cam_off * NC, sizeof(double) * NC * s.n_cam, hipMemcpyDeviceToHost));
-  if (U) PTZ_HIP_TRY(hipMemcpy(U, d.U + (size_t)s.cam_off * NC * NC, sizeof(double) * NC * NC * s.n_cam, hipMemcpyDeviceToHost));
+  if (g_c) PTZ_HIP_TRY(copy_on(b->stream, g_c, d.gc + (size_t)s.cam_off * NC, sizeof(double) * NC * s.n_cam, hipMemcpyDeviceToHost));
+  if (U) PTZ_HIP_TRY(copy_on(b->stream, U, d.U + (size_t)s.cam_off * NC * NC, sizeof(double) * NC * NC * s.n_cam, hipMemcpyDeviceToHost));
   const int* perm = b->ray_perm.data() + s.ray_off;  // internal ray j -> the caller's ray index
   if (g_r) {
     std::vector<double> g3((size_t)s.n_ray * 3);
-    PTZ_HIP_TRY(hipMemcpy(g3.data(), d.gr + (size_t)s.ray_off * 3, sizeof(double) * 3 * s.n_ray, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, g3.data(), d.gr + (size_t)s.ray_off * 3, sizeof(double) * 3 * s.n_ray, hipMemcpyDeviceToHost));
     for (int j = 0; j < s.n_ray; ++j)
       for (int k = 0; k < 3; ++k) g_r[(size_t)perm[j] * 3 + k] = g3[(size_t)j * 3 + k];
   }
   if (V) {
     std::vector<double> v6((size_t)s.n_ray * 6);
-    PTZ_HIP_TRY(hipMemcpy(v6.data(), d.V + (size_t)s.ray_off * 6, sizeof(double) * 6 * s.n_ray, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, v6.data(), d.V + (size_t)s.ray_off * 6, sizeof(double) * 6 * s.n_ray, hipMemcpyDeviceToHost));
     for (int j = 0; j < s.n_ray; ++j) {
       const double* p = &v6[(size_t)j * 6];
       double* q = V + (size_t)perm[j] * 9;
@@ -1823,11 +1859,11 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
     const int ws = (NW * 3 + 1) & ~1;        // Dims<TYPE>::WS
     std::vector<double> rows((size_t)s.n_obs * ws);
     std::vector<int> wp(s.n_obs);
-    PTZ_HIP_TRY(hipMemcpy(rows.data(), d.W + (size_t)s.obs_off * ws, sizeof(double) * ws * s.n_obs, hipMemcpyDeviceToHost));
-    PTZ_HIP_TRY(hipMemcpy(wp.data(), d.wpos + s.obs_off, sizeof(int) * s.n_obs, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, rows.data(), d.W + (size_t)s.obs_off * ws, sizeof(double) * ws * s.n_obs, hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, wp.data(), d.wpos + s.obs_off, sizeof(int) * s.n_obs, hipMemcpyDeviceToHost));
     // internal observation order is (internal ray, order inside the track); the caller's is (caller's ray, same inner order)
     std::vector<int> rp(s.n_ray + 1);
-    PTZ_HIP_TRY(hipMemcpy(rp.data(), d.ray_ptr + s.ray_off + s.idx, sizeof(int) * (s.n_ray + 1), hipMemcpyDeviceToHost));
+    PTZ_HIP_TRY(copy_on(b->stream, rp.data(), d.ray_ptr + s.ray_off + s.idx, sizeof(int) * (s.n_ray + 1), hipMemcpyDeviceToHost));
     std::vector<int> ext_first(s.n_ray + 1, 0);
     for (int j = 0; j < s.n_ray; ++j) ext_first[perm[j] + 1] = rp[j + 1] - rp[j];
     for (int r = 0; r < s.n_ray; ++r) ext_first[r + 1] += ext_first[r];
@@ -1949,6 +1985,39 @@ int32_t ptz_ba_solve_sharded(int32_t n, const ptz_ba_problem* problems, double* 
   run(0);
   for (auto& x : th) x.join();
   for (int rc : rcs) if (rc) return rc;
+  return PTZ_OK;
+}
+
+// Diagnostic (not part of the drop-in boundary, used by tools/probes/probe_host_structure.py): the host-side structure stage of
+// ptz_ba_batch_create -- build_pairs of every problem on `n_threads` threads, into scratch arrays -- without touching a device.
+int32_t ptz_debug_host_structure(int32_t n, const ptz_ba_problem* problems, int32_t n_threads, int32_t reps, double* ms_per_rep)
+{
+  if (n <= 0 || !problems || n_threads <= 0 || reps <= 0 || !ms_per_rep) return PTZ_EINVAL;
+  std::vector<size_t> ob(n + 1, 0), rb(n + 1, 0), cb(n + 1, 0);
+  for (int i = 0; i < n; ++i) { ob[i + 1] = ob[i] + (size_t)problems[i].n_obs; rb[i + 1] = rb[i] + problems[i].n_ray; cb[i + 1] = cb[i] + problems[i].n_cam; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int rep = 0; rep < reps; ++rep) {
+    RawVec<float2> uv(ob[n]), camuv(ob[n]);
+    RawVec<int> cam(ob[n]), ray(ob[n]), camobs(ob[n]), camray(ob[n]), wpos(ob[n]);
+    std::vector<int> rayptr(rb[n] + n), camptr(cb[n] + n), campair(cb[n] + n), camrun(cb[n] + n), perm(rb[n]);
+    std::vector<double> w(rb[n]);
+    std::vector<PairBuild> wave(n);
+    auto work = [&](int t, int step) {
+      for (int k = t; k < n; k += step) {
+        const ObsDest od = {uv.data() + ob[k], cam.data() + ob[k], ray.data() + ob[k], camobs.data() + ob[k], camray.data() + ob[k], camuv.data() + ob[k],
+                            rayptr.data() + rb[k] + k, w.data() + rb[k], camptr.data() + cb[k] + k, campair.data() + cb[k] + k,
+                            camrun.data() + cb[k] + k, wpos.data() + ob[k]};
+        build_pairs(problems[k], (int)ob[k], (int)rb[k], od, wave[k], perm.data() + rb[k], schur_threads_of(problems[k].factor_type));
+      }
+    };
+    const int nt = std::min(n_threads, n);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
+    work(0, nt);
+    for (auto& x : th) x.join();
+    for (int k = 0; k < n; ++k) if (wave[k].err != PTZ_OK) return wave[k].err;
+  }
+  *ms_per_rep = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
   return PTZ_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
+#include <thread>
 #include <tuple>
 #include <utility>
 
@@ -51,6 +53,22 @@ struct DeviceGuard {
 #define PTZ_DEVICE_GUARD(dev)              \
   ptz::DeviceGuard _ptz_guard(dev);        \
   if (!_ptz_guard.ok) return PTZ_ENODEVICE
+
+// Wait for a stream by POLLING it.  hipStreamSynchronize parks the thread on an interrupt-driven signal wait, and with several
+// host threads driving their own streams (the lock-step PTZ-IBA's four batch threads, the sharded dealers) those waits were
+// measured to return 20-40 ms after the work had finished (rocprofv3 --hip-trace: hipStreamSynchronize max 40.7 ms around
+// solves of 1.5 ms, several threads released at the same instant).  hipStreamQuery reads the completion signal directly.
+// The first 200 us spin (the common case: a copy or a small solve), after that the thread yields between polls.
+inline hipError_t stream_wait(hipStream_t st)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if ((spins & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) std::this_thread::yield();
+    else __builtin_ia32_pause();
+  }
+}
 
 // ---- kernel launches that can be recorded into a hipGraph instead of being issued -----------------------------------------
 // One LM pass is the same ~25 launches with the same arguments every time, so it is built ONCE as a graph of kernel nodes

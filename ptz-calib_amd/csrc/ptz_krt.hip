@@ -552,7 +552,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
     int dev; char* base = nullptr; void* pinned = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Held()
     {
-      if (st) (void)hipStreamSynchronize(st);
+      if (st) (void)stream_wait(st);
       ptzpool::dev_release(dev, base);
       ptzpool::pinned_release(pinned);
       ptzpool::stream_release(dev, st);
@@ -610,7 +610,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
   if (staged) {
     char* ps = (char*)h.pinned;
     PTZ_HIP_TRY(hipMemcpyAsync(ps + o_ccur, h.base + o_ccur, total - o_ccur, hipMemcpyDeviceToHost, h.st));
-    PTZ_HIP_TRY(hipStreamSynchronize(h.st));
+    PTZ_HIP_TRY(stream_wait(h.st));
     PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
     memcpy(cam_cur, ps + o_ccur, sizeof(double) * 15 * n_query);
     memcpy(summaries, ps + o_sum, sizeof(ptz_lm_summary) * n_query);
@@ -620,7 +620,7 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
     PTZ_HIP_TRY(hipMemcpyAsync(cam_cur, d_ccur, sizeof(double) * 15 * n_query, hipMemcpyDeviceToHost, h.st));
     PTZ_HIP_TRY(hipMemcpyAsync(summaries, d_sum, sizeof(ptz_lm_summary) * n_query, hipMemcpyDeviceToHost, h.st));
     PTZ_HIP_TRY(hipMemcpyAsync(accepted, d_acc, sizeof(int) * n_query, hipMemcpyDeviceToHost, h.st));
-    PTZ_HIP_TRY(hipStreamSynchronize(h.st));
+    PTZ_HIP_TRY(stream_wait(h.st));
     PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
   }
   float ms = 0;

@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -44,6 +46,23 @@ inline State& state()
   static State s;
   return s;
 }
+
+// Debug aid: PTZ_POOL_TRACE=1 reports every request the cache could not serve (the driver call it took, and how long) on stderr.
+inline bool trace_on()
+{
+  static const bool on = getenv("PTZ_POOL_TRACE") != nullptr;
+  return on;
+}
+struct MissTimer {
+  const char* what; size_t bytes; std::chrono::steady_clock::time_point t0;
+  MissTimer(const char* w, size_t b) : what(w), bytes(b) { if (trace_on()) t0 = std::chrono::steady_clock::now(); }
+  ~MissTimer()
+  {
+    if (trace_on())
+      fprintf(stderr, "ptzpool miss %s %zu bytes %.3f ms\n", what, bytes,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 inline size_t size_class(size_t bytes)
 {
@@ -87,6 +106,7 @@ inline hipError_t dev_acquire_raw(int device, size_t bytes, void** out)
       return hipSuccess;
     }
   }
+  MissTimer mt("hipMalloc", cls);
   hipError_t e = hipMalloc(out, cls);
   if (e != hipSuccess) {
     // the cache may be what is in the way: give everything parked back and retry once
@@ -128,7 +148,10 @@ inline void dev_release(int device, void* p)
       }
     }
   }
-  if (!park) (void)hipFree(p);
+  if (!park) {
+    MissTimer mt("hipFree", cls);
+    (void)hipFree(p);
+  }
 }
 
 inline hipError_t pinned_acquire(size_t bytes, void** out)
@@ -145,6 +168,7 @@ inline hipError_t pinned_acquire(size_t bytes, void** out)
       return hipSuccess;
     }
   }
+  MissTimer mt("hipHostMalloc", cls);
   hipError_t e = hipHostMalloc(out, cls);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lk(s.mu);
@@ -171,6 +195,7 @@ inline hipError_t stream_acquire(int device, hipStream_t* out)
     auto& v = s.dev[device].streams;
     if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
   }
+  MissTimer mt("hipStreamCreate", 0);
   return hipStreamCreate(out);
 }
 
@@ -190,6 +215,7 @@ inline hipError_t event_acquire(int device, bool timing, hipEvent_t* out)
     auto& v = timing ? s.dev[device].timing_events : s.dev[device].plain_events;
     if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
   }
+  MissTimer mt("hipEventCreate", 0);
   return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
 }
 

@@ -1,6 +1,8 @@
 #include "device_batcher.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -9,6 +11,7 @@ namespace ptzcalib {
 namespace {
 thread_local DeviceBatcher* t_batcher = nullptr;
 double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool Trace() { static const bool on = getenv("PTZ_BATCHER_TRACE") != nullptr; return on; }  // per-call timings on stderr
 bool SameOptions(const ptz_lm_options* a, const ptz_lm_options* b) { return memcmp(a, b, sizeof(ptz_lm_options)) == 0; }
 }  // namespace
 
@@ -153,11 +156,19 @@ void DeviceBatcher::RunBaBatch(std::vector<BaReq*>& reqs)
   }
   std::vector<ptz_lm_summary> summ(n);
   ptz_ba_batch* b = nullptr;
+  const double t0 = NowMs();
   int32_t rc = ptz_ba_batch_create(n, probs.data(), reqs[0]->opt, &b);
+  const double t1 = NowMs();
   if (rc == PTZ_OK) rc = ptz_ba_batch_set_state(b, cam.data(), ray.data(), tlw.data());
+  const double t2 = NowMs();
   if (rc == PTZ_OK) rc = ptz_ba_batch_solve(b, summ.data());
+  const double t3 = NowMs();
   if (rc == PTZ_OK) rc = ptz_ba_batch_get_state(b, cam.data(), ray.data(), tlw.data());
+  const double t4 = NowMs();
   if (b) ptz_ba_batch_destroy(b);
+  if (Trace())
+    fprintf(stderr, "batcher ba n=%d cams=%zu rays=%zu create %.2f set %.2f solve %.2f get %.2f destroy %.2f ms\n", n, n_cam, n_ray, t1 - t0,
+            t2 - t1, t3 - t2, t4 - t3, NowMs() - t4);
   if (rc != PTZ_OK && rc != PTZ_ENODEVICE && rc != PTZ_ENOMEM) {
     // one malformed / oversized problem must not fail its neighbours: every request gets its own verdict
     for (BaReq* r : reqs) r->rc = ptz_ba_solve(r->p, r->cam, r->ray, r->tlw, r->opt, r->summary);
@@ -210,6 +221,7 @@ void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
       q0 += static_cast<size_t>(r->n_query); m0 += m;
     }
   }
+  const double t1 = NowMs();
   double dev_ms = 0;
   // the merged launch must give every query the bits of its own small launch: the form is pinned to what those pick (a wave per
   // query, the latency form), whatever the merged size
@@ -217,6 +229,7 @@ void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
   if (opt.krt_lanes_per_query == 0) opt.krt_lanes_per_query = 64;
   const int32_t rc = ptz_krt_solve_batch(static_cast<int32_t>(nq), ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(), cam_cur.data(),
                                          reqs[0]->factor_type, reqs[0]->max_reproj_error, &opt, summ.data(), acc.data(), &dev_ms);
+  if (Trace()) fprintf(stderr, "batcher krt reqs=%zu queries=%zu matches=%zu pack %.2f call %.2f device %.3f ms\n", reqs.size(), nq, nm, t1 - t0, NowMs() - t1, dev_ms);
   size_t q0 = 0;
   for (KrtReq* r : reqs) {
     r->rc = rc;
