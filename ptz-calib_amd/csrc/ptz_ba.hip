@@ -919,6 +919,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   // observations; with the caller's order a wave of 64 rays waits for its longest track (4 .. 19 observations on a C2 rig, the
   // mean over waves of the longest is 14.5 against a mean length of 7.5), sorted it does not (1.01 x the mean).  Observations
   // keep their order inside a track; ray_perm[j] = the caller's index of internal ray j.
+  const auto T0 = std::chrono::steady_clock::now(); auto el = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
   ptz_ba_problem p = p_in;
   std::vector<float> uv2((size_t)2 * p.n_obs);
   std::vector<int32_t> cam2(p.n_obs), ray2(p.n_obs);
@@ -956,6 +957,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
     }
     p.obs_uv = uv2.data(); p.obs_cam = cam2.data(); p.obs_ray = ray2.data(); p.ray_weight = w2.data();
   }
+  const double T1 = el();
   std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
   for (int64_t a = 0; a < p.n_obs; ++a) {
     od.uv[a] = make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]);
@@ -994,6 +996,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   // scene written and re-read: 6.4 -> 4.0 ms per scene on one host thread).  Observations of a track come camera-ascending
   // from the packing (track asc, image asc: ptzray_optimizer.cc:801-850), in which case the pairs are simply (a, b < a); any
   // other order takes the general double loop.
+  const double T2 = el();
   const size_t ncc = (size_t)p.n_cam * p.n_cam;
   std::vector<int> pair_cnt(ncc, 0);
   std::vector<char> asc(p.n_ray, 1);
@@ -1025,6 +1028,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   }
   if (!for_each_entry([&](int, int, size_t cell) { ++pair_cnt[cell]; ++n_ent; })) { out.err = PTZ_EINVAL; return; }
   if (n_ent > 0x7fffffff) { out.err = PTZ_EINVAL; return; }
+  const double T3 = el();
   int npair = 0;
   std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
   std::vector<int> pair_fill(ncc, -1);  // next free entry slot of a pair (scene-local)
@@ -1046,10 +1050,12 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
       }
     out.pptr.push_back(run);
   }
+  const double T4 = el();
   out.ent.resize((size_t)n_ent);
   for_each_entry([&](int a, int bb, size_t cell) {
     out.ent[pair_fill[cell]++] = (unsigned)pos[a] | ((unsigned)pos[bb] << 16);  // (LDS slot of T_a, W row of b relative to camera cj's first row)
   });
+  const double T5 = el();
   // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
   cam_first[p.n_cam] = npair;
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_ent = std::max(out.max_cam_ent, cam_ent[c]);
@@ -1086,6 +1092,7 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   out.prun[npair] = (int)out.runs.size();
   out.n_pair = npair;
   out.n_ent = n_ent;
+  if (getenv("PTZ_BP_T")) fprintf(stderr, "build_pairs: sort %.2f obs %.2f count %.2f pairs %.2f fill %.2f runs %.2f ms; %lld entries %d pairs\n", T1, T2 - T1, T3 - T2, T4 - T3, T5 - T4, el() - T5, (long long)n_ent, npair);
 }
 }  // namespace
 
