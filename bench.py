@@ -283,7 +283,8 @@ def iba_batch_leg(pkg, scenes, tables, device_id):
     reg = sum(len(r["registered"]) for r in res)
     ferr = [float(np.abs(r["cameras"][r["registered"], 0] / sc.cam_gt[r["registered"], 0] - 1).max()) for r, sc in zip(res, scenes) if r["registered"]]
     return {"rigs": len(tables), "views": sum(tb.n_img for tb in tables), "registered": reg, "solved_rigs": sum(1 for r in res if r["ok"]),
-            "wall_ms": 1e3 * d1, "views_per_s": reg / d1, "lm_iterations": sum(r["lm_iterations"] for r in res),
+            "wall_ms": 1e3 * d1, "views_per_s": reg / d1, "solve_ms": st["wall_ms"], "views_per_s_solve_only": reg / (1e-3 * st["wall_ms"]),
+            "lm_iterations": sum(r["lm_iterations"] for r in res),
             "rounds": st["rounds"], "bundle_adjustments": st["ba_problems"], "bundle_adjustment_batches": st["ba_batches"],
             "registration_launches": st["krt_launches"], "registration_attempts": st["krt_queries"],
             "ms_in_batched_bundle_adjustments": st["ba_ms"], "ms_in_registration_launches": st["krt_ms"],

@@ -913,19 +913,59 @@ struct ObsDest {
   int* wpos;                                                   // + obs_off
 };  // (member order = the order of the initialiser in ptz_ba_batch_create)
 
+// Scratch vectors of build_pairs, handed from call to call (a batch builds its scenes on short-lived worker threads, several
+// batches at a time in the lock-step PTZ-IBA): a vector that keeps its capacity costs no allocation and, above all, no page
+// faults -- fresh memory was a third of the structure stage's time.
+struct BuildScratch {
+  std::vector<int> len, first, start, cnt_ray, cnt_cam, fill, pos, pair_cnt, pair_fill, cam_first, cam_ent;
+  std::vector<char> asc;
+};
+struct ScratchPool {
+  std::mutex mu;
+  std::vector<BuildScratch*> free_list;
+  BuildScratch* get()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_list.empty()) { BuildScratch* s = free_list.back(); free_list.pop_back(); return s; }
+    }
+    return new BuildScratch();
+  }
+  void put(BuildScratch* s)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_list.size() < 32) { free_list.push_back(s); return; }
+    delete s;
+  }
+};
+inline ScratchPool& scratch_pool()
+{
+  static ScratchPool* p = new ScratchPool();  // never destroyed: worker threads may outlive static destructors
+  return *p;
+}
+struct ScratchLease {
+  BuildScratch* s;
+  ScratchLease() : s(scratch_pool().get()) {}
+  ~ScratchLease() { scratch_pool().put(s); }
+};
+
 void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm, int max_runs)
 {
   // Internal ray order: by track length, longest first, then by the track's first camera (stable).  The ray-centric kernels give one lane to a ray and walk its
   // observations; with the caller's order a wave of 64 rays waits for its longest track (4 .. 19 observations on a C2 rig, the
   // mean over waves of the longest is 14.5 against a mean length of 7.5), sorted it does not (1.01 x the mean).  Observations
   // keep their order inside a track; ray_perm[j] = the caller's index of internal ray j.
-  const auto T0 = std::chrono::steady_clock::now(); auto el = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
+  ScratchLease lease;
+  BuildScratch& sc = *lease.s;
   ptz_ba_problem p = p_in;
-  std::vector<float> uv2((size_t)2 * p.n_obs);
-  std::vector<int32_t> cam2(p.n_obs), ray2(p.n_obs);
-  std::vector<double> w2(p.n_ray);
+  std::vector<int>& cnt_ray = sc.cnt_ray;
+  std::vector<int>& cnt_cam = sc.cnt_cam;
+  cnt_ray.assign(p.n_ray + 1, 0);
+  cnt_cam.assign(p.n_cam + 1, 0);
   {
-    std::vector<int> len(p.n_ray, 0), first(p.n_ray + 1, 0);
+    std::vector<int>&len = sc.len, &first = sc.first, &start = sc.start;
+    len.assign(p.n_ray, 0);
+    first.assign(p.n_ray + 1, 0);
     for (int64_t a = 0; a < p.n_obs; ++a) ++len[p_in.obs_ray[a]];
     int max_len = 0;
     for (int j = 0; j < p.n_ray; ++j) {
@@ -941,65 +981,58 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
       const int c = p_in.obs_cam[first[j]];
       return (size_t)(max_len - len[j]) * (size_t)p.n_cam + (size_t)(c >= 0 && c < p.n_cam ? c : 0);
     };
-    std::vector<int> start(nkey + 2, 0);
+    start.assign(nkey + 2, 0);
     for (int j = 0; j < p.n_ray; ++j) ++start[key(j) + 1];
     for (size_t l = 0; l <= nkey; ++l) start[l + 1] += start[l];
     for (int j = 0; j < p.n_ray; ++j) ray_perm[start[key(j)]++] = j;
-    int64_t at = 0;
+    // the observations in the internal order go straight into the batch-wide arrays (no copy of the problem in between)
+    int at = 0;
     for (int jn = 0; jn < p.n_ray; ++jn) {
       const int jo = ray_perm[jn];
-      w2[jn] = p_in.ray_weight[jo];
+      od.w[jn] = p_in.ray_weight[jo];
+      cnt_ray[jn] = at;
       for (int a = first[jo]; a < first[jo + 1]; ++a, ++at) {
-        uv2[2 * at] = p_in.obs_uv[2 * a]; uv2[2 * at + 1] = p_in.obs_uv[2 * a + 1];
-        cam2[at] = p_in.obs_cam[a];
-        ray2[at] = jn;
+        const int c = p_in.obs_cam[a];
+        od.uv[at] = make_float2(p_in.obs_uv[2 * a], p_in.obs_uv[2 * a + 1]);
+        od.cam[at] = c;
+        od.ray[at] = jn;
+        ++cnt_cam[c + 1];
       }
     }
-    p.obs_uv = uv2.data(); p.obs_cam = cam2.data(); p.obs_ray = ray2.data(); p.ray_weight = w2.data();
-  }
-  const double T1 = el();
-  std::vector<int> cnt_ray(p.n_ray + 1, 0), cnt_cam(p.n_cam + 1, 0);
-  for (int64_t a = 0; a < p.n_obs; ++a) {
-    od.uv[a] = make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]);
-    od.cam[a] = p.obs_cam[a];
-    od.ray[a] = p.obs_ray[a];
-    ++cnt_ray[p.obs_ray[a] + 1];
-    ++cnt_cam[p.obs_cam[a] + 1];
-  }
-  for (int j = 0; j < p.n_ray; ++j) {
-    if (cnt_ray[j + 1] == 0) { out.err = PTZ_EINVAL; return; }  // every ray has >= 1 observation
-    cnt_ray[j + 1] += cnt_ray[j];
+    cnt_ray[p.n_ray] = at;
+    p.obs_uv = reinterpret_cast<const float*>(od.uv); p.obs_cam = od.cam; p.obs_ray = od.ray; p.ray_weight = od.w;
   }
   for (int j = 0; j <= p.n_ray; ++j) od.rayptr[j] = obase + cnt_ray[j];
-  for (int j = 0; j < p.n_ray; ++j) od.w[j] = p.ray_weight[j];
   for (int c = 0; c < p.n_cam; ++c) cnt_cam[c + 1] += cnt_cam[c];
-  {  // camera-major observation lists
-    std::vector<int> fill(cnt_cam.begin(), cnt_cam.end() - 1);
+  std::vector<int>& pos = sc.pos;
+  pos.resize(p.n_obs);
+  {  // camera-major observation lists; pos[a] = rank of observation a in its camera's list (camera-major order = ascending a)
+    std::vector<int>& fill = sc.fill;
+    fill.assign(cnt_cam.begin(), cnt_cam.end() - 1);
     for (int64_t a = 0; a < p.n_obs; ++a) {
-      const int slot = fill[p.obs_cam[a]]++;
+      const int c = p.obs_cam[a];
+      const int slot = fill[c]++;
+      pos[a] = slot - cnt_cam[c];
       od.camobs[slot] = obase + (int)a;
       od.camray[slot] = ray_off + p.obs_ray[a];
-      od.camuv[slot] = make_float2(p.obs_uv[2 * a], p.obs_uv[2 * a + 1]);
+      od.camuv[slot] = od.uv[a];
+      od.wpos[a] = obase + slot;
     }
+    for (int c = 0; c < p.n_cam; ++c) out.max_cam_obs = std::max(out.max_cam_obs, fill[c] - cnt_cam[c]);
     for (int c = 0; c <= p.n_cam; ++c) od.camptr[c] = obase + cnt_cam[c];
-  }
-  std::vector<int> pos(p.n_obs);
-  {
-    std::vector<int> fill(p.n_cam, 0);
-    for (int64_t a = 0; a < p.n_obs; ++a) pos[a] = fill[p.obs_cam[a]]++;   // camera-major order = ascending a
-    for (int c = 0; c < p.n_cam; ++c) out.max_cam_obs = std::max(out.max_cam_obs, fill[c]);
-    for (int64_t a = 0; a < p.n_obs; ++a) od.wpos[a] = obase + cnt_cam[p.obs_cam[a]] + pos[a];
   }
   // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
   // The (a, b) pairs with cam(a) > cam(b) of every ray are walked twice in ray order -- once to count them per camera pair,
   // once to drop them into their slots -- rather than kept as a list (round 2 kept two 4-byte indices per entry, 3 MB per C2
   // scene written and re-read: 6.4 -> 4.0 ms per scene on one host thread).  Observations of a track come camera-ascending
   // from the packing (track asc, image asc: ptzray_optimizer.cc:801-850), in which case the pairs are simply (a, b < a); any
-  // other order takes the general double loop.
-  const double T2 = el();
+  // other order takes the general double loop.  (Walking camera by camera instead, with n_cam counters that stay in L1, was
+  // measured: slower, the walk then chases observation -> track -> cameras in random order.)
   const size_t ncc = (size_t)p.n_cam * p.n_cam;
-  std::vector<int> pair_cnt(ncc, 0);
-  std::vector<char> asc(p.n_ray, 1);
+  std::vector<int>& pair_cnt = sc.pair_cnt;
+  pair_cnt.assign(ncc, 0);
+  std::vector<char>& asc = sc.asc;
+  asc.resize(p.n_ray);
   int64_t n_ent = 0;
   auto for_each_entry = [&](auto&& fn) -> bool {  // fn(a, bb, slot of (cam(a), cam(bb)) in the n_cam x n_cam table)
     for (int j = 0; j < p.n_ray; ++j) {
@@ -1028,10 +1061,11 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   }
   if (!for_each_entry([&](int, int, size_t cell) { ++pair_cnt[cell]; ++n_ent; })) { out.err = PTZ_EINVAL; return; }
   if (n_ent > 0x7fffffff) { out.err = PTZ_EINVAL; return; }
-  const double T3 = el();
   int npair = 0;
-  std::vector<int> cam_first(p.n_cam + 1, -1), cam_ent(p.n_cam, 0);
-  std::vector<int> pair_fill(ncc, -1);  // next free entry slot of a pair (scene-local)
+  std::vector<int>&cam_first = sc.cam_first, &cam_ent = sc.cam_ent, &pair_fill = sc.pair_fill;
+  cam_first.assign(p.n_cam + 1, -1);
+  cam_ent.assign(p.n_cam, 0);
+  pair_fill.resize(ncc);  // next free entry slot of a pair (scene-local); only the cells of existing pairs are read
   {
     int run = 0;
     for (int ci = 0; ci < p.n_cam; ++ci)
@@ -1050,12 +1084,10 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
       }
     out.pptr.push_back(run);
   }
-  const double T4 = el();
   out.ent.resize((size_t)n_ent);
   for_each_entry([&](int a, int bb, size_t cell) {
     out.ent[pair_fill[cell]++] = (unsigned)pos[a] | ((unsigned)pos[bb] << 16);  // (LDS slot of T_a, W row of b relative to camera cj's first row)
   });
-  const double T5 = el();
   // per-camera pair ranges (pairs are sorted by ci): cameras without pairs get an empty range
   cam_first[p.n_cam] = npair;
   for (int c = 0; c < p.n_cam; ++c) out.max_cam_ent = std::max(out.max_cam_ent, cam_ent[c]);
@@ -1092,7 +1124,6 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
   out.prun[npair] = (int)out.runs.size();
   out.n_pair = npair;
   out.n_ent = n_ent;
-  if (getenv("PTZ_BP_T")) fprintf(stderr, "build_pairs: sort %.2f obs %.2f count %.2f pairs %.2f fill %.2f runs %.2f ms; %lld entries %d pairs\n", T1, T2 - T1, T3 - T2, T4 - T3, T5 - T4, el() - T5, (long long)n_ent, npair);
 }
 }  // namespace
 
@@ -1997,7 +2028,7 @@ int32_t ptz_ba_solve_sharded(int32_t n, const ptz_ba_problem* problems, double* 
 
 // Diagnostic (not part of the drop-in boundary, used by tools/probes/probe_host_structure.py): the host-side structure stage of
 // ptz_ba_batch_create -- build_pairs of every problem on `n_threads` threads, into scratch arrays -- without touching a device.
-int32_t ptz_debug_host_structure(int32_t n, const ptz_ba_problem* problems, int32_t n_threads, int32_t reps, double* ms_per_rep)
+int32_t ptz_debug_host_structure(int32_t n, const ptz_ba_problem* problems, int32_t n_threads, int32_t reps, double* ms_per_rep, uint64_t* hash_out)
 {
   if (n <= 0 || !problems || n_threads <= 0 || reps <= 0 || !ms_per_rep) return PTZ_EINVAL;
   std::vector<size_t> ob(n + 1, 0), rb(n + 1, 0), cb(n + 1, 0);
@@ -2023,6 +2054,22 @@ int32_t ptz_debug_host_structure(int32_t n, const ptz_ba_problem* problems, int3
     work(0, nt);
     for (auto& x : th) x.join();
     for (int k = 0; k < n; ++k) if (wave[k].err != PTZ_OK) return wave[k].err;
+    if (hash_out && rep == 0) {  // FNV-1a over everything the stage produces, in a fixed order
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](const void* ptr, size_t bytes) { const unsigned char* c = (const unsigned char*)ptr; for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; } };
+      mix(uv.data(), sizeof(float2) * ob[n]); mix(camuv.data(), sizeof(float2) * ob[n]); mix(cam.data(), 4 * ob[n]); mix(ray.data(), 4 * ob[n]);
+      mix(camobs.data(), 4 * ob[n]); mix(camray.data(), 4 * ob[n]); mix(wpos.data(), 4 * ob[n]);
+      mix(rayptr.data(), 4 * rayptr.size()); mix(camptr.data(), 4 * camptr.size()); mix(campair.data(), 4 * campair.size()); mix(camrun.data(), 4 * camrun.size());
+      mix(perm.data(), 4 * perm.size()); mix(w.data(), 8 * w.size());
+      for (int k = 0; k < n; ++k) {
+        const PairBuild& pb = wave[k];
+        mix(pb.pci.data(), 4 * pb.pci.size()); mix(pb.pcj.data(), 4 * pb.pcj.size()); mix(pb.pptr.data(), 4 * pb.pptr.size()); mix(pb.pbrow.data(), 4 * pb.pbrow.size());
+        mix(pb.ent.data(), 4 * pb.ent.size()); mix(pb.runs.data(), 8 * pb.runs.size()); mix(pb.prun.data(), 4 * pb.prun.size());
+        const int64_t v[7] = {pb.n_ent, pb.n_pair, pb.max_cam_obs, pb.max_cam_ent, pb.max_cam_pair, pb.max_cam_run, pb.err};
+        mix(v, sizeof(v));
+      }
+      *hash_out = h;
+    }
   }
   *ms_per_rep = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
   return PTZ_OK;

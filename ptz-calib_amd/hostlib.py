@@ -56,25 +56,23 @@ def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int 
     """N rigs in lock step on one GPU (PtzIncrementalOptimizer::SolveBatch, host/device_batcher.h): every rig's optimizer on a
     host thread of its own, the bundle adjustments and registration attempts of each round batched into one library call each.
     Returns (list of per-rig dicts as incremental_solve gives them, without timing; batch statistics)."""
+    from concurrent.futures import ThreadPoolExecutor
     L = lib()
     L.ptzh_inc_create.restype = C.c_void_p
-    handles = []
-    keep = []
-    for tb, cam15 in zip(tables, cam15s):
+
+    def create(args):  # marshals one rig's tables into the C++ structures (ctypes releases the GIL: the rigs go in parallel)
+        tb, cam15 = args
         cam = np.array(cam15, dtype=np.float64, order="C").copy()
         H = np.ascontiguousarray(tb.H, dtype=np.float64)
         hv = np.ascontiguousarray(tb.h_valid, dtype=np.int32)
         conf = np.ascontiguousarray(tb.confidence, dtype=np.float64)
         wh = np.ascontiguousarray(tb.img_wh, dtype=np.int32)
-        keep.append((cam, H, hv, conf, wh))
         h = L.ptzh_inc_create(tb.n_img, _p(tb.kp_ptr), _p(tb.kp_xy), _p(wh), tb.n_pairs, _p(tb.src), _p(tb.dst), _p(tb.match_ptr), _p(tb.q),
                               _p(tb.t), _p(H), _p(hv), _p(conf), _p(cam), None, 0, max_iter)
-        handles.append(C.c_void_p(h))
-    arr = (C.c_void_p * len(handles))(*handles)
-    stats = np.zeros(8)
-    L.ptzh_inc_solve_batch(arr, len(handles), device_id, _p(stats))
-    out = []
-    for tb, h in zip(tables, handles):
+        return C.c_void_p(h)
+
+    def result(args):
+        tb, h = args
         cam = np.zeros((tb.n_img, 15))
         reg = np.zeros(tb.n_img, dtype=np.int32)
         max_events = 16 * tb.n_img + 256
@@ -82,8 +80,16 @@ def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int 
         nit = C.c_int64(0)
         solved = C.c_int32(0)
         ne = L.ptzh_inc_result(h, _p(cam), _p(reg), _p(ev), max_events, C.byref(nit), C.byref(solved))
-        out.append(dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)),
-                        events=[tuple(int(x) for x in row) for row in ev[:max(ne, 0)]], lm_iterations=int(nit.value)))
         L.ptzh_inc_destroy(h)
+        return dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)),
+                    events=[tuple(int(x) for x in row) for row in ev[:max(ne, 0)]], lm_iterations=int(nit.value))
+
+    workers = max(1, min(16, len(tables), os.cpu_count() or 1))
+    with ThreadPoolExecutor(workers) as pool:
+        handles = list(pool.map(create, zip(tables, cam15s)))
+        arr = (C.c_void_p * len(handles))(*handles)
+        stats = np.zeros(8)
+        L.ptzh_inc_solve_batch(arr, len(handles), device_id, _p(stats))
+        out = list(pool.map(result, zip(tables, handles)))
     return out, dict(rounds=int(stats[0]), ba_batches=int(stats[1]), ba_problems=int(stats[2]), krt_launches=int(stats[3]),
                      krt_queries=int(stats[4]), ba_ms=float(stats[5]), krt_ms=float(stats[6]), wall_ms=float(stats[7]))

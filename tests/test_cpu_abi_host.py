@@ -686,3 +686,18 @@ def test_scene_cache_round_trip(pkg, tmp_path):
                 else:
                     assert u == v == w, f.name
     assert len(os.listdir(tmp_path)) == 6
+
+
+def test_batch_structure_is_pinned_and_thread_independent(pkg):
+    """The host-side structure of a batch (internal ray order, camera-major lists, camera-pair entry lists, k_schur's runs) fixes
+    the order of every sum on the device.  Its hash (ptz_debug_host_structure, no GPU needed) must equal the committed one --
+    written after the round-3 builder had been compared with round 2's on these scenes, tests/golden/gen_structure_hashes.py --
+    and must not depend on the number of builder threads."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_structure_hashes", os.path.join(ROOT, "tests", "golden", "gen_structure_hashes.py"))
+    gsh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gsh)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "structure_hashes.json")))
+    assert gsh.all_hashes(pkg) == want
+    scenes = [pkg.synth.make_scene(**c) for c in gsh.CASES if c.get("factor_type", 0) == 0] + [gsh.shuffled_tracks(pkg)]
+    assert len({gsh.structure_hash(pkg, scenes, t) for t in (1, 2, 5, 8)}) == 1

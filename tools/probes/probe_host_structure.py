@@ -12,6 +12,6 @@ for n in (1, 5, 19):
     probs = (pkg.api.BaProblem * n)(*[pkg.api._pack_problem(s, keep) for s in scenes[:n]])
     for nt in (1, 2, 4, 8):
         ms = C.c_double()
-        rc = lib.ptz_debug_host_structure(n, probs, nt, 5, C.byref(ms))
+        rc = lib.ptz_debug_host_structure(n, probs, nt, 5, C.byref(ms), None)
         assert rc == 0, rc
         print(f"{n} problems x {views} views, {nt} threads: {ms.value:.2f} ms per create-structure", flush=True)
