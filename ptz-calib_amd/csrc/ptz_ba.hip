@@ -501,7 +501,15 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
     else LAUNCH((k_schur_w<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
   }
   else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
-  else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
+  else {
+#ifdef PTZ_SCHUR_FAKE_ROWS  // probe builds: the small-table kernel is what P_SCHUR times; the real one (under P_RHS) overwrites its output
+    LAUNCH((k_schur<TYPE, false, PTZ_SCHUR_FAKE_ROWS>), dim3(b->max_cam, B), dim3(schur_thr),
+           schur_lds_bytes(std::min(b->max_cam_obs, PTZ_SCHUR_FAKE_ROWS), NC, d.chol.np, false, schur_thr, Dims<TYPE>::NW, b->max_cam_ent), d);
+    b->prof_end();
+    b->prof_begin(P_RHS);
+#endif
+    LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
+  }
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 4) + (size_t)(d.chol.np / CHOL_NB) * (d.chol.np / CHOL_NB), d);
   b->prof_end();
@@ -938,15 +946,15 @@ struct ScratchPool {
     delete s;
   }
 };
-inline ScratchPool& scratch_pool()
+inline ScratchPool* scratch_pool()
 {
   static ScratchPool* p = new ScratchPool();  // never destroyed: worker threads may outlive static destructors
-  return *p;
+  return p;
 }
 struct ScratchLease {
   BuildScratch* s;
-  ScratchLease() : s(scratch_pool().get()) {}
-  ~ScratchLease() { scratch_pool().put(s); }
+  ScratchLease() : s(scratch_pool()->get()) {}
+  ~ScratchLease() { scratch_pool()->put(s); }
 };
 
 void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm, int max_runs)
