@@ -413,6 +413,52 @@ def test_ba_watchdog_recovers_when_progress_reports_stop(pkg, scene_c1, monkeypa
     assert summ == summ0 and all(np.array_equal(a, c) for a, c in zip(cams, cams0))
 
 
+def test_ba_concurrent_host_threads_get_the_bits_of_serial_solves(pkg):
+    """Several host threads, each creating, solving and reading back its own batches on ONE device at the same time (what the
+    lock-step PTZ-IBA's batch threads and ptz_ba_solve_sharded's dealers do): every batch owns its streams, copies on them
+    and waits by polling them (ptz_common.h stream_wait, ptz_ba.hip copy_on), the resource pool hands blocks from thread to
+    thread -- and every result has the bits of the same solve done alone, every time."""
+    import threading
+    groups = [[pkg.synth.make_scene(30 + 5 * t + s, 18 + 3 * s + t, 90 + 10 * t) for s in range(3)] for t in range(4)]
+    want = [[pkg.api.ba_solve(sc) for sc in g] for g in groups]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                if rep % 2 == 0:
+                    b = pkg.api.BaBatch(groups[t]); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+                    got = [(cams[i], rays[i], summ[i]) for i in range(len(groups[t]))]
+                else:
+                    got = [pkg.api.ba_solve(sc) for sc in groups[t]]
+                for (c, r, s), (c0, r0, s0) in zip(got, want[t]):
+                    assert s == s0 and np.array_equal(c, c0) and np.array_equal(r, r0)
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+
+
+def test_ba_round2_schur_kernels_still_agree(pkg, scene_c1, monkeypatch):
+    """PTZ_BA_SCHUR_W=1 brings back round 2's Schur complement over materialised W = Jc^T Jr rows (k_schur_w, kept for A/B
+    measurements).  The two kernels group a pair's sum differently and take the reciprocal of the depth differently, so bits
+    may differ; the LM bookkeeping and the results may not."""
+    scenes = [scene_c1, pkg.synth.make_scene(5, 60, 300), pkg.synth.make_scene(2, 24, 100, factor_type=1)]
+    new = [pkg.api.ba_solve(sc) for sc in scenes]
+    monkeypatch.setenv("PTZ_BA_SCHUR_W", "1")
+    old = [pkg.api.ba_solve(sc) for sc in scenes]
+    for (c, r, s), (c0, r0, s0) in zip(new, old):
+        assert s["termination_type"] == s0["termination_type"] == 0
+        assert s["num_iterations"] == s0["num_iterations"] and s["num_successful_steps"] == s0["num_successful_steps"]
+        assert abs(s["final_cost"] - s0["final_cost"]) / s0["final_cost"] < 1e-9
+        assert np.abs(c[:, 0] / c0[:, 0] - 1).max() < 1e-8
+
+
 def test_ba_max_iterations_is_no_convergence(pkg, scene_c1):
     """Hitting max_num_iterations is NO_CONVERGENCE (the reference then returns false, ptzray_optimizer.cc:482)."""
     cam, ray, summ = pkg.api.ba_solve(scene_c1, max_num_iterations=2)
