@@ -788,6 +788,134 @@ __global__ __launch_bounds__(256) void chol_update_col_kernel(CholBatch cb, int 
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// The same update with the operand tiles in HALVES of 32 columns (PTZ_BA_CHOL_HALFK): 35 KB of LDS and two half-tile register
+// sets instead of 68 KB and two whole-tile sets, so that three workgroups share a compute unit and the ~8 us of dependent loads
+// in front of a tile's first MFMA overlap other tiles' arithmetic.  Same MFMAs per accumulator in the same order: same bits.
+constexpr int KH = 32, LDH = KH + 2;
+typedef double d8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ d8 half_fetch(const double* __restrict__ g, int ld)
+{
+  d8 r;
+#pragma unroll
+  for (int p = 0; p < (NB * KH / 2) / 256; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int row = idx >> 4, c2 = (idx & 15) * 2;
+    const double2 v = *reinterpret_cast<const double2*>(g + (size_t)row * ld + c2);
+    r[2 * p] = v.x; r[2 * p + 1] = v.y;
+  }
+  return r;
+}
+__global__ __launch_bounds__(256, 3) void chol_update_col_h_kernel(CholBatch cb, int j, int fuse_diag)
+{
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
+  const int np = cb.np, nt = np / NB;
+  const int n = cb.n[sys];
+  const int ti = j + bx;
+  if (ti >= nt || ti * NB > n || j * NB > n) return;
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  if (tm && !tm[ti * nt + j]) return;
+  double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double Ls[2 * NB * LDH];  // the two half tiles; afterwards (fuse_diag) the whole C tile at stride LD
+  static_assert(2 * NB * LDH >= NB * LD, "the diagonal tile is factored in the operand buffers");
+  double* As = Ls;
+  double* Bs = Ls + NB * LDH;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  double* C = A + (size_t)(ti * NB + 16 * w) * np + j * NB;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
+  const double* ap = As + (16 * w + fr) * LDH + fq;
+  const double* bp = Bs + fr * LDH + fq;
+  // The operand tiles of step k + 1 are fetched into registers while the matrix cores work on step k: a step then costs its 64
+  // MFMAs per wave plus one LDS hand-over, not a global-memory round trip on top (the loop used to: barrier, load, barrier, MFMA).
+  // The block columns k < j are taken in the order of the step schedule (ascending k without one): a tile then sums its
+  // updates in the order the one-launch-per-step path applies them, and a scene has the same bits on either path.
+  // The list is made once, in LDS (a system has at most a few hundred block columns).
+  __shared__ short klist[1024];
+  __shared__ int kcount;
+  if (threadIdx.x < 64) {  // wave 0: 64 candidates at a time, all their loads in flight together, compacted in order by ballot
+    const int nq = cb.sched ? CHOL_STEP_COLS * cb.n_steps : j;
+    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * CHOL_STEP_COLS : nullptr;
+    int cnt = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int qq = q0 + (int)threadIdx.x;
+      const int kc = qq < nq ? (sq ? sq[qq] : qq) : -1;
+      const bool in = kc >= 0 && kc < j;
+      const bool ok = in && (!tm || (tm[ti * nt + (in ? kc : 0)] && tm[j * nt + (in ? kc : 0)]));
+      const unsigned long long m = __ballot(ok);
+      const int pos = cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (ok && pos < 1024) klist[pos] = (short)kc;
+      cnt += __popcll(m);
+    }
+    if (threadIdx.x == 0) kcount = min(cnt, 1024);
+  }
+  __syncthreads();
+  const int Q = kcount;
+  auto col_of = [&](int q) { return (int)klist[q]; };
+  auto next_q = [&](int q) { return q; };
+  constexpr int NP = (NB * NB / 2) / 256;  // double2 pieces of one tile per thread
+  int q = 0;
+  const bool any = q < Q;
+  int k = any ? col_of(q) : 0;
+  // Two steps of operand tiles are in flight (the tiles were written by other launches, mostly on other XCDs, and come from
+  // HBM: one step of 64 MFMAs per wave does not cover that round trip).  The fetches stay unconditional: past the end of the
+  // list they re-read the last tiles.
+  auto kq = [&](int qq) { return any ? col_of(qq < Q ? qq : Q - 1) : 0; };
+  // unit u = half h = u & 1 of the operand tiles of list entry u >> 1
+  auto fetch_a = [&](int u) { return half_fetch(A + (size_t)(ti * NB) * np + kq(u >> 1) * NB + KH * (u & 1), np); };
+  auto fetch_b = [&](int u) { return half_fetch(A + (size_t)(j * NB) * np + kq(u >> 1) * NB + KH * (u & 1), np); };
+  d8 ra = fetch_a(0), rb = fetch_b(0), ra1 = fetch_a(1), rb1 = fetch_b(1);
+  (void)k; (void)next_q;
+  // one half step: hand the half tiles in (xa, xb) over to LDS, refill the two register sets with unit uf, multiply
+  auto step = [&](d8& xa, d8& xb, int uf) {
+    __syncthreads();  // the previous step's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < (NB * KH / 2) / 256; ++p) {
+      const int idx = p * 256 + threadIdx.x;
+      const int row = idx >> 4, c2 = (idx & 15) * 2;
+      *reinterpret_cast<double2*>(As + row * LDH + c2) = make_double2(-xa[2 * p], -xa[2 * p + 1]);   // -L_ik
+      *reinterpret_cast<double2*>(Bs + row * LDH + c2) = make_double2(xb[2 * p], xb[2 * p + 1]);      //  L_jk
+    }
+    __syncthreads();
+    xa = fetch_a(uf);
+    xb = fetch_b(uf);
+#pragma unroll
+    for (int kk = 0; kk < KH / 4; ++kk) {
+      const double av = ap[4 * kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * c) * LDH + 4 * kk], acc[c], 0, 0, 0);
+    }
+  };
+  for (int u = 0; u < 2 * Q; u += 2) {  // the two register sets take turns: first and second half of a list entry
+    step(ra, rb, u + 2);
+    step(ra1, rb1, u + 3);
+  }
+  if (fuse_diag && ti == j) {
+    // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
+    __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
+    __shared__ int okflag;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    diag_factor_tile(Ls, Dv, &okflag, cb, sys, j, n);
+    return;
+  }
+  if (!any) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+}
+
 // ---- full inverses of the factored diagonal tiles, all at once (the multi-launch paths; the one-launch-per-column path
 //      computes them in a spare workgroup of every launch) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
@@ -988,7 +1116,13 @@ void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, 
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag)
 {
   const int m = cb.np / NB - j;
-  if (j > 0 && m > 0) launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
+  // operand tiles in halves (three workgroups per compute unit): 81.5 -> 73.4 ms of column updates per C4 solve, same bits;
+  // PTZ_BA_CHOL_HALFK=0 brings the whole-tile kernel back (A/B measurements)
+  static const bool halfk = [] { const char* e = getenv("PTZ_BA_CHOL_HALFK"); return !e || atoi(e) != 0; }();
+  if (j > 0 && m > 0) {
+    if (halfk) launch(chol_update_col_h_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
+    else launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
+  }
 }
 void chol_col_step_launch(const CholBatch& cb, int step, hipStream_t stream)
 {
