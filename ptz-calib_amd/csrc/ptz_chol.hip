@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(CholBatch cb, int kk)
 //   X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T
 // with v_mfma_f64_16x16x4_f64; finished X_q blocks pass from accumulator layout to operand layout through a
 // wave-private LDS strip, so the four waves never synchronise after the initial load.
-__global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const double* __restrict__ Dinv, int k)
+__global__ __launch_bounds__(256, 3) void chol_trsm_kernel(CholBatch cb, const double* __restrict__ Dinv, int k)
 {
   int bx, slot;
   xcd_remap(bx, slot);
@@ -351,12 +351,23 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
   if (k * NB > n || ti * NB > n) return;  // padding
   if (cb.tmask && !cb.tmask[((size_t)sys * nt + ti) * nt + k]) return;  // structurally zero tile
   double* A = cb.A + (size_t)sys * np * np;
-  __shared__ __attribute__((aligned(16))) double Lk[NB * LD];
+  // LDS: only what the solve reads -- the six 16 x 16 blocks of L_kk below its diagonal blocks (13.8 KB instead of the whole
+  // tile's 33.8), the block inverses, and a strip of THREE column blocks per wave (the fourth block is parked in the first one's
+  // place, which is dead by then): 48.6 KB instead of 76.8, three workgroups per compute unit instead of two.  Same arithmetic.
+  constexpr int NBLK = 6, LDX = 3 * DB + 2;
+  __shared__ __attribute__((aligned(16))) double Lb[NBLK * DB * LDD];  // block (c, q), q < c, at c (c - 1) / 2 + q
   __shared__ __attribute__((aligned(16))) double Di[4 * DB * LDD];
-  __shared__ __attribute__((aligned(16))) double Xs[4][DB * LD];
+  __shared__ __attribute__((aligned(16))) double Xs[4][DB * LDX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+  {
+    const double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
+    for (int idx = threadIdx.x; idx < NBLK * DB * DB; idx += 256) {
+      const int blk = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+      const int bc = blk < 1 ? 1 : (blk < 3 ? 2 : 3), bq = blk - bc * (bc - 1) / 2;
+      Lb[blk * DB * LDD + r * LDD + c] = Lg[(size_t)(DB * bc + r) * NB + DB * bq + c];
+    }
+  }
   {
     const double* Dg = Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
     for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) {
@@ -374,30 +385,32 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(CholBatch cb, const doub
   double* xs = Xs[w];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    const int slot_c = c < 3 ? c : 0;  // where block c of the strip lives
     // acc[c] -= X_q L_cq^T for the finished blocks q < c
 #pragma unroll
     for (int q = 0; q < c; ++q)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const double av = -xs[fr * LD + 16 * q + 4 * ks + fq];
-        const double bv = Lk[(16 * c + fr) * LD + 16 * q + 4 * ks + fq];
+        const double av = -xs[fr * LDX + 16 * q + 4 * ks + fq];
+        const double bv = Lb[(c * (c - 1) / 2 + q) * DB * LDD + fr * LDD + 4 * ks + fq];
         acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
       }
-    // T_c to operand layout (reuse column block c of the strip), then X_c = T_c Dinv_c^T
+    if (c == 3) __builtin_amdgcn_s_waitcnt(0xc07f);  // the reads of block 0 are done before block 3 takes its place
+    // T_c to operand layout, then X_c = T_c Dinv_c^T
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xs[(fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    for (int i = 0; i < 4; ++i) xs[(fq + 4 * i) * LDX + 16 * slot_c + fr] = acc[c][i];
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the strip is private to this wave
     d4 xc = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const double av = xs[fr * LD + 16 * c + 4 * ks + fq];
+      const double av = xs[fr * LDX + 16 * slot_c + 4 * ks + fq];
       const double bv = Di[c * DB * LDD + fr * LDD + 4 * ks + fq];
       xc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xc, 0, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xs[(fq + 4 * i) * LD + 16 * c + fr] = xc[i];
+      if (c < 3) xs[(fq + 4 * i) * LDX + 16 * c + fr] = xc[i];  // (block 3 is nobody's operand)
       T[(size_t)(fq + 4 * i) * np + 16 * c + fr] = xc[i];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
