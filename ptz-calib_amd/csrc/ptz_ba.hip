@@ -1115,11 +1115,12 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
     int max_len = 0;
     for (int pi = p0; pi < p1; ++pi) max_len = std::max(max_len, out.pptr[pi + 1] - out.pptr[pi]);
     auto pieces = [&](int L) { int64_t n = 0; for (int pi = p0; pi < p1; ++pi) n += (out.pptr[pi + 1] - out.pptr[pi] + L - 1) / L; return n; };
-    int lo = 1, hi = max_len;  // smallest L in [1, max_len] with pieces(L) <= max_runs (max_len if there is none)
-    while (lo < hi) {
-      const int mid = (lo + hi) / 2;
-      if (pieces(mid) <= max_runs) hi = mid; else lo = mid + 1;
-    }
+    // smallest L in [1, max_len] with pieces(L) <= max_runs (max_len if there is none).  pieces() is non-increasing in L and
+    // pieces(L) >= entries / L, so the search starts at ceil(entries / max_runs) -- usually the answer or one below it -- and
+    // walks up (a bisection over [1, max_len] cost nine rounds of integer divisions per camera, 0.3 ms per 170-view scene)
+    const int total = out.pptr[p1] - out.pptr[p0];
+    int lo = std::max(1, std::min(max_len, (total + max_runs - 1) / max_runs));
+    while (lo < max_len && pieces(lo) > max_runs) ++lo;
     const int L = std::min(lo, 65535);
     for (int pi = p0; pi < p1; ++pi) {
       out.prun[pi] = (int)out.runs.size();
