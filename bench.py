@@ -276,7 +276,7 @@ def iba_batch_leg(pkg, scenes, tables, device_id):
     for tb in tables:
         c = np.zeros((tb.n_img, 15)); c[:, 0] = c[:, 1] = 1.0
         cam0.append(c)
-    pkg.hostlib.incremental_solve_batch(tables[:4], cam0[:4], max_iter=200, device_id=device_id)  # warm-up (resource pool, code objects)
+    pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id)  # warm-up at full size (resource pool: pinned and device blocks of every size class the rounds ask for)
     t1 = time.perf_counter()
     res, st = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id)
     d1 = time.perf_counter() - t1

@@ -160,20 +160,33 @@ std::vector<char> PtzIncrementalOptimizer::SolveBatch(const std::vector<PtzIncre
   cameras.resize(n);
   reg_image_ids.resize(n);
   std::vector<char> ok(n, 0);
-  DeviceBatcher batcher(static_cast<int>(n));
+  // Cohorts: the rigs are dealt to a few independent lock steps (rig i -> cohort i % K), each with its own DeviceBatcher.  While
+  // one cohort's round is on the device (or in its host-side batch creation) the rigs of the others do their own host work --
+  // ranking, packing, bookkeeping -- which a single lock step leaves serialised with the rounds.  Results do not depend on it.
+  // Measured, 64 rigs x 200 views, ms inside this call: 1 cohort 1349, 2: 1100, 4: 816, 8: 634, 16: 603, 32: 1086, 64 (no
+  // batching at all, 64 streams): 2475 -- four rigs per cohort, at most one cohort per host core.
+  size_t n_cohorts = std::max<size_t>(1, std::min<size_t>(n / 4, std::max(1u, std::thread::hardware_concurrency())));
+  if (const char* e = getenv("PTZ_IBA_COHORTS")) n_cohorts = static_cast<size_t>(std::max(1, atoi(e)));
+  n_cohorts = std::max<size_t>(1, std::min(n_cohorts, n));
+  std::vector<std::unique_ptr<DeviceBatcher>> batchers;
+  for (size_t c = 0; c < n_cohorts; ++c) batchers.emplace_back(new DeviceBatcher(static_cast<int>((n - c + n_cohorts - 1) / n_cohorts)));
   std::vector<std::thread> th;
   th.reserve(n);
   for (size_t i = 0; i < n; ++i)
     th.emplace_back([&, i] {
-      DeviceBatcher::Scope scope(&batcher);
+      DeviceBatcher* batcher = batchers[i % n_cohorts].get();
+      DeviceBatcher::Scope scope(batcher);
       ok[i] = rigs[i]->Solve(cameras[i], reg_image_ids[i]) ? 1 : 0;
-      batcher.ClientDone();
+      batcher->ClientDone();
     });
   for (std::thread& t : th) t.join();
   if (stats) {
-    const DeviceBatcher::Stats s = batcher.stats();
-    stats->rounds = s.rounds; stats->ba_batches = s.ba_batches; stats->ba_problems = s.ba_problems;
-    stats->krt_launches = s.krt_launches; stats->krt_queries = s.krt_queries; stats->ba_ms = s.ba_ms; stats->krt_ms = s.krt_ms;
+    *stats = BatchStats();
+    for (const auto& bp : batchers) {
+      const DeviceBatcher::Stats s = bp->stats();
+      stats->rounds += s.rounds; stats->ba_batches += s.ba_batches; stats->ba_problems += s.ba_problems;
+      stats->krt_launches += s.krt_launches; stats->krt_queries += s.krt_queries; stats->ba_ms += s.ba_ms; stats->krt_ms += s.krt_ms;
+    }
   }
   return ok;
 }

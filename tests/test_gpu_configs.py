@@ -194,7 +194,7 @@ def test_nccl_backend_world_size_one(pkg, tmp_path):
     assert d["parallel"]["gather_ms"] is not None and d["parallel"]["ranks_ms_per_step"] is not None
 
 
-def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg):
+def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg, monkeypatch):
     """PtzIncrementalOptimizer::SolveBatch (host/device_batcher.h): rigs of different size in lock step -- all pending bundle
     adjustments of a round in ONE ptz_ba_batch, all pending registration attempts in ONE ptz_krt_solve_batch launch -- against
     the same rigs calibrated one after the other (the reference's loop, run_ptzba_synthetic.sh:4-13): identical event
@@ -218,3 +218,11 @@ def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg):
     n_ba_solo = sum(sum(1 for e in a["events"] if e[0] == 2) for a in solo)
     assert stats["ba_problems"] == n_ba_solo and stats["ba_batches"] < 0.5 * n_ba_solo
     assert stats["krt_launches"] <= stats["rounds"]
+    # several cohorts (independent lock steps side by side, SolveBatch's default for many rigs) and no batching at all (one
+    # cohort per rig: concurrent solo runs on one device): the same decisions and bits
+    for cohorts in ("2", "3", "5"):
+        monkeypatch.setenv("PTZ_IBA_COHORTS", cohorts)
+        again, st2 = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200)
+        for a, b in zip(solo, again):
+            assert b["ok"] and a["events"] == b["events"] and a["registered"] == b["registered"] and np.array_equal(a["cameras"], b["cameras"])
+        assert st2["ba_problems"] == n_ba_solo
