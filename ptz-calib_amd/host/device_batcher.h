@@ -8,7 +8,8 @@
 // that is still running has a call pending, the pending bundle adjustments become ONE ptz_ba_batch and the pending
 // registration attempts ONE ptz_krt_solve_batch launch; the results are handed back and the threads go on.  A scene inside a
 // batch has the bits of its solo solve (the library's reductions are fixed-order, scenes never share a sum), so every decision
-// of every optimizer is the one it would have taken alone.
+// of every optimizer is the one it would have taken alone.  PtzIncrementalOptimizer::SolveBatch runs several such lock steps
+// (cohorts of four rigs) side by side, each with a DeviceBatcher of its own.
 #pragma once
 
 #include <condition_variable>
