@@ -438,7 +438,7 @@ def make_reloc_queries(n_query: int, n_match: int = 128, seed_id: int = 0, facto
     assert 4 + 2 * cand + 8 * n_match < (1 << 16)
     cam_ref = np.zeros((n_query, 15)); cam_gt = np.zeros((n_query, 15)); cam_init = np.zeros((n_query, 15))
     uv_ref = np.zeros((n_query, n_match, 2), dtype=np.float32); uv_cur = np.zeros((n_query, n_match, 2), dtype=np.float32)
-    for q0 in range(0, n_query, chunk):
+    def do_chunk(q0):  # (chunks write disjoint rows of the output arrays: they run on a few threads, numpy releases the GIL in the heavy ops)
         q = np.arange(q0, min(n_query, q0 + chunk))
         nq = len(q)
         head = _grid_uniform(seed, q, 0, 4)
@@ -494,6 +494,16 @@ def make_reloc_queries(n_query: int, n_match: int = 128, seed_id: int = 0, facto
         ini[:, 1] = cr[:, 0]
         ini[:, 2], ini[:, 3] = cx, cy
         cam_init[q] = ini
+
+    starts = list(range(0, n_query, chunk))
+    if len(starts) > 4:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as pool:
+            list(pool.map(do_chunk, starts))
+    else:
+        for q0 in starts:
+            do_chunk(q0)
     match_ptr = np.arange(n_query + 1, dtype=np.int64) * n_match
     return RelocBatch(n_query=n_query, match_ptr=match_ptr, uv_ref=uv_ref.reshape(-1, 2), uv_cur=uv_cur.reshape(-1, 2),
                       cam_ref=cam_ref, cam_init=cam_init, cam_gt=cam_gt, factor_type=factor_type)
