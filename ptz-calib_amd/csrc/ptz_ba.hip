@@ -957,7 +957,8 @@ struct ScratchLease {
   ~ScratchLease() { scratch_pool()->put(s); }
 };
 
-void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm, int max_runs)
+void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDest& od, PairBuild& out, int* ray_perm, int max_runs,
+                 bool pairs_on_device = false)
 {
   // Internal ray order: by track length, longest first, then by the track's first camera (stable).  The ray-centric kernels give one lane to a ray and walk its
   // observations; with the caller's order a wave of 64 rays waits for its longest track (4 .. 19 observations on a C2 rig, the
@@ -1028,6 +1029,15 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
     }
     for (int c = 0; c < p.n_cam; ++c) out.max_cam_obs = std::max(out.max_cam_obs, fill[c] - cnt_cam[c]);
     for (int c = 0; c <= p.n_cam; ++c) od.camptr[c] = obase + cnt_cam[c];
+  }
+  if (pairs_on_device) {
+    // pairs, entries and runs are made by k_pairs from the arrays above (ptz_ba_batch_create): only the entry count is needed here
+    int64_t ne = 0;
+    for (int j = 0; j < p.n_ray; ++j) { const int64_t L = cnt_ray[j + 1] - cnt_ray[j]; ne += L * (L - 1) / 2; }
+    if (ne > 0x7fffffff) { out.err = PTZ_EINVAL; return; }
+    out.n_ent = ne;
+    out.n_pair = 0;
+    return;
   }
   // counting sort by (ci, cj): pairs ascending in ci * n_cam + cj, the entries of a pair in ray order (stable).
   // The (a, b) pairs with cam(a) > cam(b) of every ray are walked twice in ray order -- once to count them per camera pair,
@@ -1151,6 +1161,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (type != PTZ_BA_PTZRay && type != PTZ_BA_PTZRayDist && type != PTZ_BA_PTZRayFxfyDist && type != PTZ_BA_PTZRayDistDisp) return PTZ_EUNSUPPORTED;
   const bool disp = type == PTZ_BA_PTZRayDistDisp;
   int has3d = 0;
+  std::vector<int> cam_hist;
+  int pre_max_cam_obs = 0, pre_max_cam = 0;  // (decides whether the pair lists are built on the device, before anything is built)
   // ---- validate + sizes (host only; no device touched before this passes)
   for (int i = 0; i < n; ++i) {
     const ptz_ba_problem& p = problems[i];
@@ -1161,10 +1173,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     for (int a = 0; a < p.n_obs3d; ++a)
       if (p.obs3d_cam[a] < 0 || p.obs3d_cam[a] >= p.n_cam) return PTZ_EINVAL;
     if (p.n_obs3d > 0) has3d = 1;
+    cam_hist.assign(p.n_cam, 0);
     for (int64_t a = 0; a < p.n_obs; ++a) {
       if (p.obs_cam[a] < 0 || p.obs_cam[a] >= p.n_cam || p.obs_ray[a] < 0 || p.obs_ray[a] >= p.n_ray) return PTZ_EINVAL;
       if (a > 0 && p.obs_ray[a] < p.obs_ray[a - 1]) return PTZ_EINVAL;
+      ++cam_hist[p.obs_cam[a]];
     }
+    for (int c = 0; c < p.n_cam; ++c) pre_max_cam_obs = std::max(pre_max_cam_obs, cam_hist[c]);
+    pre_max_cam = std::max(pre_max_cam, p.n_cam);
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= o.device_id) return PTZ_ENODEVICE;
@@ -1226,6 +1242,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("PTZ_BA_HOST_THREADS")) n_threads = std::max(1, atoi(e));
   const int wave_scenes = 4 * n_threads;
+  // Pair lists on the device (k_pairs) unless the round-2 kernels are asked for, the per-camera bitmaps do not fit in LDS, or
+  // PTZ_BA_GPU_STRUCT=0 (the host builder: 2.1 of its 3.6 ms per 170-view problem are these lists)
+  bool gpu_pairs = !getenv("PTZ_BA_SCHUR_W") || atoi(getenv("PTZ_BA_SCHUR_W")) == 0;
+  const size_t pairs_lds = sizeof(unsigned) * ((size_t)pre_max_cam * ((pre_max_cam_obs + 31) / 32) + 5 * (size_t)pre_max_cam + 8);
+  if (pairs_lds > 150 * 1024 || pre_max_cam_obs > 65535) gpu_pairs = false;
+  if (const char* e = getenv("PTZ_BA_GPU_STRUCT")) gpu_pairs = gpu_pairs && atoi(e) != 0;
+  // PTZ_BA_GPU_STRUCT_CHECK=1 (tests): the host builds its lists as well and the device's must equal them word for word
+  const bool pairs_check = gpu_pairs && getenv("PTZ_BA_GPU_STRUCT_CHECK") != nullptr;
   std::vector<PairBuild> wave;
   int wave_first = 0;
   for (int i = 0; i < n; ++i) {
@@ -1261,7 +1285,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
                                 h_rayptr.data() + ray_base[sidx] + sidx, h_w.data() + ray_base[sidx],
                                 h_camptr.data() + cam_base[sidx] + sidx, h_campair.data() + cam_base[sidx] + sidx,
                                 h_camrun.data() + cam_base[sidx] + sidx, h_wpos.data() + obs_base[sidx]};
-            build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k], b->ray_perm.data() + ray_base[sidx], schur_threads_of(type));
+            build_pairs(problems[sidx], obs_base[sidx], ray_base[sidx], od, wave[k], b->ray_perm.data() + ray_base[sidx], schur_threads_of(type), gpu_pairs && !pairs_check);
           }
         };
         const int nt = std::min(n_threads, wn);
@@ -1393,6 +1417,105 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     up.add(h_o3cam, &d.o3_cam);
     up.add(b->ray_perm, &b->d_ray_perm);
     TRY(up.commit(b));
+  }
+  if (gpu_pairs) {
+    // camera pairs, entry lists and runs on the device (k_pairs): count, scan, read the totals back (the arrays are sized
+    // exactly), write; then the pairs' cameras come back for the tile structure below
+    PairsDev pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.scene = d.scene; pa.obs_cam = d.obs_cam; pa.obs_ray = d.obs_ray; pa.ray_ptr = d.ray_ptr; pa.cam_ptr = d.cam_ptr; pa.cam_obs = d.cam_obs;
+    pa.wpos = d.wpos;
+    pa.max_runs = schur_threads_of(type);
+    int *d_cnt = nullptr, *d_off3 = nullptr, *d_tot = nullptr, *d_err = nullptr;
+    TRY(b->alloc(&d_cnt, (size_t)3 * b->total_cam));
+    TRY(b->alloc(&d_off3, (size_t)3 * b->total_cam));
+    TRY(b->alloc(&d_tot, (size_t)6 * n));
+    TRY(b->alloc(&d_err, 1));
+    pa.cam_cnt = d_cnt; pa.cam_off3 = d_off3; pa.scene_tot = d_tot; pa.err = d_err;
+    static std::mutex cap_mu;
+    {  // dynamic LDS beyond 64 KiB for very wide rigs
+      std::lock_guard<std::mutex> lk(cap_mu);
+      (void)hipFuncSetAttribute((const void*)k_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      (void)hipFuncSetAttribute((const void*)k_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    }
+    if (hipMemsetAsync(d_err, 0, sizeof(int), b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    hipLaunchKernelGGL(k_pairs<false>, dim3(b->max_cam, n), dim3(256), pairs_lds, b->io, pa);
+    hipLaunchKernelGGL(k_pair_scan, dim3((n + 63) / 64), dim3(64), 0, b->io, d.scene, n, (const int*)d_cnt, d_off3, d_tot);
+    std::vector<int> h_tot((size_t)6 * n + 1);
+    {
+      hipError_t e = hipMemcpyAsync(h_tot.data(), d_tot, sizeof(int) * 6 * n, hipMemcpyDeviceToHost, b->io);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_tot.data() + 6 * n, d_err, sizeof(int), hipMemcpyDeviceToHost, b->io);
+      if (e == hipSuccess) e = stream_wait(b->io);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    }
+    if (h_tot[(size_t)6 * n]) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image twice in one track (tracks.cc:77)
+    const int chk_pair = b->total_pair, chk_run = b->total_run, chk_mcp = b->max_cam_pair, chk_mce = b->max_cam_ent, chk_mcr = b->max_cam_run;
+    const std::vector<SceneDev> chk_scenes = pairs_check ? b->scenes : std::vector<SceneDev>();
+    if (pairs_check) { b->max_cam_pair = 0; b->max_cam_ent = 0; b->max_cam_run = 0; }
+    b->total_pair = 0; b->total_run = 0; b->max_pair = 0;
+    for (int i = 0; i < n; ++i) {
+      SceneDev& sd = b->scenes[i];
+      const int* t = h_tot.data() + 6 * (size_t)i;
+      int64_t ne = 0;  // (the host's count of the scene's entries, from the track lengths)
+      ne = (i + 1 < n ? b->scenes[i + 1].ent_off : b->total_ent) - sd.ent_off;
+      if (t[1] != ne || (int64_t)b->total_pair + t[0] > 0x7fffffff || (int64_t)b->total_run + t[2] > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+      sd.n_pair = t[0];
+      sd.pair_off = b->total_pair;
+      sd.run_off = b->total_run;
+      b->total_pair += t[0];
+      b->total_run += t[2];
+      b->max_pair = std::max(b->max_pair, t[0]);
+      b->max_cam_pair = std::max(b->max_cam_pair, t[3]);
+      b->max_cam_ent = std::max(b->max_cam_ent, t[4]);
+      b->max_cam_run = std::max(b->max_cam_run, t[5]);
+    }
+    if (copy_on(b->io, const_cast<SceneDev*>(d.scene), b->scenes.data(), sizeof(SceneDev) * n, hipMemcpyHostToDevice) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    TRY(b->alloc(&pa.pci, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pcj, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pbrow, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pptr, (size_t)b->total_pair + n));
+    TRY(b->alloc(&pa.prun, (size_t)b->total_pair + n));
+    TRY(b->alloc(&pa.campair, (size_t)b->total_cam + n));
+    TRY(b->alloc(&pa.camrun, (size_t)b->total_cam + n));
+    TRY(b->alloc(&pa.runs, (size_t)b->total_run));
+    TRY(b->alloc(&pa.ent, (size_t)b->total_ent));
+    hipLaunchKernelGGL(k_pairs<true>, dim3(b->max_cam, n), dim3(256), pairs_lds, b->io, pa);
+    d.pair_ci = pa.pci; d.pair_cj = pa.pcj; d.pair_brow = pa.pbrow; d.pair_ptr = pa.pptr; d.pair_run = pa.prun;
+    d.cam_pair = pa.campair; d.cam_run = pa.camrun; d.run_rec = pa.runs; d.ent = pa.ent;
+    if (pairs_check) {
+      long bad = 0;
+      if (chk_pair != b->total_pair || chk_run != b->total_run || chk_mcp != b->max_cam_pair || chk_mce != b->max_cam_ent || chk_mcr != b->max_cam_run) ++bad;
+      for (int i = 0; i < n && !bad; ++i)
+        if (chk_scenes[i].n_pair != b->scenes[i].n_pair || chk_scenes[i].pair_off != b->scenes[i].pair_off || chk_scenes[i].run_off != b->scenes[i].run_off) ++bad;
+      auto cmp = [&](const void* dev, const void* host, size_t bytes, const char* name) {
+        std::vector<unsigned char> tmp(bytes + 1);
+        if (bytes && (hipMemcpyAsync(tmp.data(), dev, bytes, hipMemcpyDeviceToHost, b->io) != hipSuccess || stream_wait(b->io) != hipSuccess)) { ++bad; return; }
+        if (bytes && memcmp(tmp.data(), host, bytes) != 0) { ++bad; fprintf(stderr, "[ptz_ba_create] device-built %s differs from the host builder's\n", name); }
+      };
+      if (!bad) {
+        cmp(pa.pci, h_pci.data(), sizeof(int) * h_pci.size(), "pair_ci");
+        cmp(pa.pcj, h_pcj.data(), sizeof(int) * h_pcj.size(), "pair_cj");
+        cmp(pa.pbrow, h_pbrow.data(), sizeof(int) * h_pbrow.size(), "pair_brow");
+        cmp(pa.pptr, h_pptr.data(), sizeof(int) * h_pptr.size(), "pair_ptr");
+        cmp(pa.prun, h_prun.data(), sizeof(int) * h_prun.size(), "pair_run");
+        cmp(pa.campair, h_campair.data(), sizeof(int) * h_campair.size(), "cam_pair");
+        cmp(pa.camrun, h_camrun.data(), sizeof(int) * h_camrun.size(), "cam_run");
+        cmp(pa.runs, h_runs.data(), sizeof(uint2) * h_runs.size(), "run_rec");
+        cmp(pa.ent, h_ent.data(), sizeof(unsigned) * h_ent.size(), "ent");
+      }
+      else fprintf(stderr, "[ptz_ba_create] device-built pair totals differ from the host builder's\n");
+      if (bad) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+    }
+    h_pci.resize(b->total_pair);
+    h_pcj.resize(b->total_pair);
+    {
+      hipError_t e = b->total_pair ? hipMemcpyAsync(h_pci.data(), pa.pci, sizeof(int) * b->total_pair, hipMemcpyDeviceToHost, b->io) : hipSuccess;
+      if (e == hipSuccess && b->total_pair) e = hipMemcpyAsync(h_pcj.data(), pa.pcj, sizeof(int) * b->total_pair, hipMemcpyDeviceToHost, b->io);
+      if (e == hipSuccess) e = stream_wait(b->io);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    }
   }
   d.tlw_stride = (size_t)n * 6;
   TRY(b->alloc(&d.tlw_x, 2 * d.tlw_stride));

@@ -2138,6 +2138,160 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_pix2ray(Dev d, double* cam0, doub
   out[0] = acc[0] / n; out[1] = acc[1] / n; out[2] = acc[2] / n;
 }
 
+// ---- structure of the Schur complement on the device (ptz_ba_batch_create) ------------------------------------------------
+// What build_pairs does on the host after the observation arrays exist -- camera pairs, their entry lists in ray order, k_schur's
+// runs -- rebuilt per CAMERA without any sort: the workgroup of camera ci marks, for every lower camera cj, the positions
+// (in ci's observation list) of the observations whose track cj also sees, as a BITMAP in LDS (atomicOr: order-free).  A pair
+// exists where a bitmap is non-empty, its entries are the set bits in ascending order -- which IS ray order, the camera-major
+// list being in ray order -- an entry's place in its pair is a prefix popcount.  The arrays come out equal, word for word, to the
+// host builder's (tests).  Two launches of the same kernel: COUNT leaves every camera's pair / entry / run counts, k_pair_scan
+// turns them into offsets (one small read-back: the host sizes the arrays), WRITE fills them.
+struct PairsDev {
+  const SceneDev* scene;
+  const int *obs_cam, *obs_ray, *ray_ptr, *cam_ptr, *cam_obs, *wpos;
+  int max_runs;               // threads of a k_schur workgroup
+  int* cam_cnt;               // [total_cam][3] pairs, entries, runs of every camera (COUNT)
+  int* err;                   // [1] an image twice in one track
+  const int* cam_off3;        // [total_cam][3] scene-local exclusive prefixes of cam_cnt (WRITE)
+  const int* scene_tot;       // [n_scene][6] pairs, entries, runs, max pairs / entries / runs of one camera
+  int *pci, *pcj, *pbrow, *pptr, *campair, *camrun, *prun;
+  uint2* runs;
+  unsigned* ent;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_pairs(PairsDev a)
+{
+  const SceneDev s = a.scene[blockIdx.y];
+  const int ci = blockIdx.x;
+  if (ci >= s.n_cam) return;
+  const int* cp = a.cam_ptr + s.cam_off + s.idx;
+  const int* rp = a.ray_ptr + s.ray_off + s.idx;
+  const int o0 = cp[ci], no = cp[ci + 1] - o0;
+  const int W = (no + 31) / 32;
+  extern __shared__ unsigned pl[];
+  unsigned* bitmap = pl;                                   // [ci][W]
+  int* cnt = reinterpret_cast<int*>(pl + (size_t)ci * W);  // [ci] entries of (ci, cj)
+  int* pidx = cnt + ci;                                    // [ci] pair number of cj among ci's pairs, or -1
+  int* pcjl = pidx + ci;                                   // [<= ci] cj of pair k
+  int* poff = pcjl + ci;                                   // [<= ci] first entry of pair k, relative to the camera's first
+  int* prl = poff + ci;                                    // [<= ci] first run of pair k, relative to the camera's first
+  __shared__ int sh_npair, sh_nent, sh_L, sh_nrun, sh_pieces, sh_maxlen;
+  for (int i = threadIdx.x; i < ci * W; i += 256) bitmap[i] = 0u;
+  __syncthreads();
+  for (int slot = threadIdx.x; slot < no; slot += 256) {
+    const int g = a.cam_obs[o0 + slot];
+    const int j = a.obs_ray[g];
+    const int r0 = rp[j], r1 = rp[j + 1];
+    for (int bb = r0; bb < r1; ++bb) {
+      const int cj = a.obs_cam[bb];
+      if (cj == ci && bb != g) *a.err = 1;  // an image appears once per track (tracks.cc:77)
+      if (cj < ci) atomicOr(&bitmap[(size_t)cj * W + (slot >> 5)], 1u << (slot & 31));
+    }
+  }
+  __syncthreads();
+  for (int cj = threadIdx.x; cj < ci; cj += 256) {
+    int c = 0;
+    for (int w = 0; w < W; ++w) c += __popc(bitmap[(size_t)cj * W + w]);
+    cnt[cj] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // pairs in ascending cj (a few hundred cameras at most: a serial sweep)
+    int k = 0, e = 0, ml = 0;
+    for (int cj = 0; cj < ci; ++cj) {
+      const int c = cnt[cj];
+      pidx[cj] = c > 0 ? k : -1;
+      if (c > 0) { pcjl[k] = cj; poff[k] = e; e += c; ml = max(ml, c); ++k; }
+    }
+    sh_npair = k; sh_nent = e; sh_maxlen = ml;
+    sh_L = max(1, min(ml, (e + a.max_runs - 1) / a.max_runs));  // lower bound of the run length (build_pairs)
+  }
+  __syncthreads();
+  const int npair = sh_npair;
+  // smallest run length L for which the camera's pairs fall into at most max_runs runs
+  for (;;) {
+    if (threadIdx.x == 0) sh_pieces = 0;
+    __syncthreads();
+    const int L = sh_L;
+    int mine = 0;
+    for (int k = threadIdx.x; k < npair; k += 256) mine += (cnt[pcjl[k]] + L - 1) / L;
+    if (mine) atomicAdd(&sh_pieces, mine);
+    __syncthreads();
+    const bool ok = npair == 0 || sh_pieces <= a.max_runs || L >= sh_maxlen;
+    __syncthreads();
+    if (ok) break;
+    if (threadIdx.x == 0) sh_L = L + 1;
+    __syncthreads();
+  }
+  const int L = min(sh_L, 65535);
+  if (threadIdx.x == 0) {
+    int r = 0;
+    for (int k = 0; k < npair; ++k) { prl[k] = r; r += (cnt[pcjl[k]] + L - 1) / L; }
+    sh_nrun = r;
+  }
+  __syncthreads();
+  const int gc = s.cam_off + ci;
+  if (!WRITE) {
+    if (threadIdx.x == 0) { a.cam_cnt[3 * gc] = npair; a.cam_cnt[3 * gc + 1] = sh_nent; a.cam_cnt[3 * gc + 2] = sh_nrun; }
+    return;
+  }
+  const int p0 = a.cam_off3[3 * gc], e0 = a.cam_off3[3 * gc + 1], q0 = a.cam_off3[3 * gc + 2];  // scene-local firsts of this camera
+  const int* tot = a.scene_tot + 6 * blockIdx.y;
+  for (int k = threadIdx.x; k < npair; k += 256) {
+    const int cj = pcjl[k], n = cnt[cj];
+    a.pci[s.pair_off + p0 + k] = ci;
+    a.pcj[s.pair_off + p0 + k] = cj;
+    a.pbrow[s.pair_off + p0 + k] = cp[cj];
+    a.pptr[s.pair_off + s.idx + p0 + k] = s.ent_off + e0 + poff[k];
+    a.prun[s.pair_off + s.idx + p0 + k] = q0 + prl[k];
+    int r = s.run_off + q0 + prl[k];
+    for (int e = 0; e < n; e += L, ++r) a.runs[r] = make_uint2((unsigned)(s.ent_off + e0 + poff[k] + e), (unsigned)k | ((unsigned)min(L, n - e) << 16));
+  }
+  if (threadIdx.x == 0) {
+    a.campair[s.cam_off + s.idx + ci] = p0;
+    a.camrun[s.cam_off + s.idx + ci] = q0;
+    if (ci == s.n_cam - 1) {
+      a.campair[s.cam_off + s.idx + s.n_cam] = tot[0];
+      a.camrun[s.cam_off + s.idx + s.n_cam] = tot[2];
+      a.pptr[s.pair_off + s.idx + tot[0]] = s.ent_off + tot[1];
+      a.prun[s.pair_off + s.idx + tot[0]] = tot[2];
+    }
+  }
+  // entries: observation a of ci with every lower camera of its track; place in the pair = set bits below its own
+  for (int slot = threadIdx.x; slot < no; slot += 256) {
+    const int g = a.cam_obs[o0 + slot];
+    const int j = a.obs_ray[g];
+    const int r0 = rp[j], r1 = rp[j + 1];
+    for (int bb = r0; bb < r1; ++bb) {
+      const int cj = a.obs_cam[bb];
+      if (cj >= ci) continue;
+      const unsigned* bm = bitmap + (size_t)cj * W;
+      int rank = __popc(bm[slot >> 5] & ((1u << (slot & 31)) - 1u));
+      for (int w = 0; w < (slot >> 5); ++w) rank += __popc(bm[w]);
+      a.ent[s.ent_off + e0 + poff[pidx[cj]] + rank] = (unsigned)slot | ((unsigned)(a.wpos[bb] - cp[cj]) << 16);
+    }
+  }
+}
+
+// per scene: exclusive prefixes of the cameras' counts and the scene's totals (one thread: a few hundred cameras)
+__global__ __launch_bounds__(64) void k_pair_scan(const SceneDev* __restrict__ scene, int n_scene, const int* __restrict__ cam_cnt,
+                                                  int* __restrict__ cam_off3, int* __restrict__ scene_tot)
+{
+  const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= n_scene) return;
+  const SceneDev s = scene[sc];
+  int p = 0, e = 0, r = 0, mp = 0, me = 0, mr = 0;
+  for (int c = 0; c < s.n_cam; ++c) {
+    const int* cc = cam_cnt + 3 * (size_t)(s.cam_off + c);
+    int* o = cam_off3 + 3 * (size_t)(s.cam_off + c);
+    o[0] = p; o[1] = e; o[2] = r;
+    p += cc[0]; e += cc[1]; r += cc[2];
+    mp = max(mp, cc[0]); me = max(me, cc[1]); mr = max(mr, cc[2]);
+  }
+  int* t = scene_tot + 6 * sc;
+  t[0] = p; t[1] = e; t[2] = r; t[3] = mp; t[4] = me; t[5] = mr;
+}
+
 }  // namespace
 
 }  // namespace ptz

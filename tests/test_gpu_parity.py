@@ -477,6 +477,51 @@ def test_ba_invalid_inputs(pkg, scene_c1):
         pkg.api.BaBatch([scene_c1], max_num_iterations=0)  # CheckValid: max_iter_ <= 0
 
 
+def test_ba_device_built_pair_lists_equal_the_host_builders(pkg, monkeypatch):
+    """ptz_ba_batch_create builds the camera pairs, their entry lists and k_schur's runs ON THE DEVICE (k_pairs: per-camera bitmaps
+    in LDS, no sort) from the observation arrays.  With PTZ_BA_GPU_STRUCT_CHECK=1 the host builder runs as well and create fails
+    unless every array -- pair cameras, entry offsets, entries, run records, per-camera ranges -- is equal word for word.
+    Scenes: all factor types, annotations, a ragged batch, tracks that are NOT camera-ascending (the general walk), a wide rig;
+    and the host path (PTZ_BA_GPU_STRUCT=0) gives the bits of the device path.  A track with an image twice is refused."""
+    import copy
+    rng = np.random.default_rng(11)
+
+    def shuffled(sc):
+        sh = copy.copy(sc)
+        oc, ou = sc.obs_cam.copy(), sc.obs_uv.copy()
+        ptr = np.flatnonzero(np.r_[1, np.diff(sc.obs_ray), 1])
+        for a, b in zip(ptr[:-1], ptr[1:]):
+            perm = rng.permutation(b - a)
+            oc[a:b] = oc[a:b][perm]; ou[a:b] = ou[a:b][perm]
+        sh.obs_cam, sh.obs_uv = oc, ou
+        return sh
+
+    batches = [[pkg.synth.make_scene(50 + s, 20 + 7 * s, 90 + 15 * s) for s in range(5)],
+               [pkg.synth.make_scene(3, 60, 300, factor_type=1)], [pkg.synth.make_scene(4, 33, 77, factor_type=2)],
+               [pkg.synth.make_scene(6, 24, 100, factor_type=3)], [shuffled(pkg.synth.make_scene(77, 40, 200)), pkg.synth.make_scene(78, 12, 60)],
+               [pkg.synth.make_scene(2, 330, 40, pan_range_deg=340.0)], [pkg.synth.make_scene(0, 200, 500)]]
+    monkeypatch.setenv("PTZ_BA_GPU_STRUCT_CHECK", "1")
+    dev = []
+    for scenes in batches:
+        b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+        dev.append((summ, cams, rays))
+    monkeypatch.delenv("PTZ_BA_GPU_STRUCT_CHECK")
+    monkeypatch.setenv("PTZ_BA_GPU_STRUCT", "0")
+    for scenes, (summ, cams, rays) in zip(batches, dev):
+        b = pkg.api.BaBatch(scenes); b.set_state(); summ0 = b.solve(); cams0, rays0 = b.get_state(); b.close()
+        assert summ0 == summ and all(np.array_equal(a, c) for a, c in zip(cams0, cams)) and all(np.array_equal(a, c) for a, c in zip(rays0, rays))
+    # an image twice in one track: refused by both builders (tracks.cc:77)
+    bad = copy.copy(batches[0][0])
+    bad.obs_cam = bad.obs_cam.copy()
+    first = int(np.flatnonzero(np.diff(bad.obs_ray) == 0)[0])  # two observations of one track
+    bad.obs_cam[first + 1] = bad.obs_cam[first]
+    for gpu in ("0", "1"):
+        monkeypatch.setenv("PTZ_BA_GPU_STRUCT", gpu)
+        with pytest.raises(pkg.api.PtzError) as e:
+            pkg.api.BaBatch([bad])
+        assert e.value.code == -1
+
+
 @pytest.mark.parametrize("ftype", [0, 1, 2, 3])
 def test_krt_batch_parity(pkg, orc, ftype):
     """Batched single-view LM (K6) vs the oracle's KRT solve (numeric-diff Jacobian + Householder QR, as the
