@@ -575,6 +575,7 @@ def main():
             headline["ptz_iba_views_per_s"] = body["ptz_iba"]["views_per_s"]
         if "ptz_iba_batch" in body:
             headline["ptz_iba_batch_views_per_s"] = body["ptz_iba_batch"]["views_per_s"]
+            headline["ptz_iba_batch_views_per_s_inside_the_call"] = body["ptz_iba_batch"]["views_per_s_solve_only"]
         if cpu is not None:
             headline["cpu_port_lm_iterations_per_s"] = cpu["value"]
         config.update({k: (round(v, 1) if isinstance(v, float) else v) for k, v in headline.items()})
