@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}"; set -u; cd $GRAFT_REPO_ROOT
 # Probe (not a test): HIP API statistics of the lock-step PTZ-IBA batch (which runtime call stalls)
 out=gpurun_out/${1:-iba_hiptrace}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}"; set -u; cd $GRAFT_REPO_ROOT
 # Probe (not a test): per-call timings of the lock-step PTZ-IBA batch (PTZ_BATCHER_TRACE, PTZ_POOL_TRACE, PTZ_BA_DEBUG_TIMING).
 out=gpurun_out/${1:-iba_trace}; mkdir -p $out
 PTZ_BATCHER_TRACE=1 PTZ_POOL_TRACE=1 timeout 900 python tools/probes/probe_iba_batch.py 64 200 > $out/iba.txt 2> $out/trace.txt

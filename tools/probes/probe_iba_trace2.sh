@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}"; set -u; cd $GRAFT_REPO_ROOT
 # Probe (not a test): per-call timings of the cohort PTZ-IBA (PTZ_BATCHER_TRACE), summed
 out=gpurun_out/${1:-iba_trace2}; mkdir -p $out
 for g in 0 1; do
