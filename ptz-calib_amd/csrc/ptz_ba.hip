@@ -1831,30 +1831,41 @@ int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double*
 {
   if (!b || !cam || !ray) return PTZ_EINVAL;
   PTZ_DEVICE_GUARD(b->device);
+  // cameras (a shared block starting from its first camera's values), rays in the library's order and T_l_w are put together in
+  // ONE pinned block, sent with three asynchronous copies and waited for ONCE (three staged copies with a wait each cost the
+  // lock-step PTZ-IBA 0.4 ms per bundle adjustment); batches whose state is larger than the staging limit copy array by array
+  const size_t nc = (size_t)15 * b->total_cam, nr = (size_t)3 * b->total_ray, nt = (size_t)6 * b->n_scene;
+  const size_t bytes = sizeof(double) * (nc + nr + nt);
+  void* pin = nullptr;
+  std::vector<double> heap;
+  double* st = nullptr;
+  if (bytes <= ((size_t)32 << 20) && ptzpool::pinned_acquire(bytes, &pin) == hipSuccess) st = static_cast<double*>(pin);
+  else { (void)hipGetLastError(); heap.resize(nc + nr + nt); st = heap.data(); }
+  double *c = st, *r = st + nc, *t = st + nc + nr;
+  memcpy(c, cam, sizeof(double) * nc);
   if (b->d.shared) {
     // a shared block starts from its first camera's values (intrinsics_param_.insert, ptzray_optimizer.cc:645-650)
-    std::vector<double> c(cam, cam + 15 * (size_t)b->total_cam);
     for (int i = 0; i < b->total_cam; ++i) {
       const int f = b->first_of_group[i];
       if (f == i) continue;
       for (int k = 0; k < 15; ++k)
         if (k < 4 || k >= 10) c[15 * (size_t)i + k] = c[15 * (size_t)f + k];
     }
-    PTZ_HIP_TRY(copy_on(b->stream, b->cam0, c.data(), sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
   }
-  else PTZ_HIP_TRY(copy_on(b->stream, b->cam0, cam, sizeof(double) * 15 * b->total_cam, hipMemcpyHostToDevice));
-  {
-    std::vector<double> r((size_t)3 * b->total_ray);
-    for (const SceneDev& sd : b->scenes)
-      for (int j = 0; j < sd.n_ray; ++j) {
-        const double* src = ray + 3 * ((size_t)sd.ray_off + b->ray_perm[sd.ray_off + j]);
-        double* dst = r.data() + 3 * ((size_t)sd.ray_off + j);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-      }
-    PTZ_HIP_TRY(copy_on(b->stream, b->ray0, r.data(), sizeof(double) * 3 * b->total_ray, hipMemcpyHostToDevice));
-  }
-  if (tlw) PTZ_HIP_TRY(copy_on(b->stream, b->tlw0, tlw, sizeof(double) * 6 * b->n_scene, hipMemcpyHostToDevice));
-  else { PTZ_HIP_TRY(hipMemsetAsync(b->tlw0, 0, sizeof(double) * 6 * b->n_scene, b->stream)); PTZ_HIP_TRY(stream_wait(b->stream)); }
+  for (const SceneDev& sd : b->scenes)
+    for (int j = 0; j < sd.n_ray; ++j) {
+      const double* src = ray + 3 * ((size_t)sd.ray_off + b->ray_perm[sd.ray_off + j]);
+      double* dst = r + 3 * ((size_t)sd.ray_off + j);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+  if (tlw) memcpy(t, tlw, sizeof(double) * nt);
+  else memset(t, 0, sizeof(double) * nt);
+  hipError_t e = hipMemcpyAsync(b->cam0, c, sizeof(double) * nc, hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->ray0, r, sizeof(double) * nr, hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->tlw0, t, sizeof(double) * nt, hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = stream_wait(b->stream);
+  ptzpool::pinned_release(pin);
+  PTZ_HIP_TRY(e);
   b->has_state = true;
   return PTZ_OK;
 }
@@ -1891,11 +1902,31 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
   double* s_tlw = s_ray + nr;
   hipLaunchKernelGGL(k_gather_state, dim3(std::max(1, (std::max(b->max_cam * 15, b->max_ray) + 255) / 256), b->n_scene), dim3(256), 0, b->stream, b->d,
                      b->d_ray_perm, s_cam, s_ray, s_tlw);
-  hipError_t e = stream_wait(b->stream);
-  if (e == hipSuccess) e = hipGetLastError();
-  if (e == hipSuccess && cam) e = copy_on(b->stream, cam, s_cam, sizeof(double) * nc, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && ray) e = copy_on(b->stream, ray, s_ray, sizeof(double) * nr, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && tlw) e = copy_on(b->stream, tlw, s_tlw, sizeof(double) * nt, hipMemcpyDeviceToHost);
+  // the gathered state comes back in ONE copy into a pinned block (the kernel and the copy are ordered on the batch's stream: one
+  // wait), from where the caller's arrays are filled
+  const size_t bytes = sizeof(double) * (nc + nr + nt);
+  void* pin = nullptr;
+  hipError_t e = hipSuccess;
+  if (bytes <= ((size_t)32 << 20) && ptzpool::pinned_acquire(bytes, &pin) == hipSuccess) {
+    e = hipMemcpyAsync(pin, stage, bytes, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = stream_wait(b->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) {
+      const double* p = static_cast<const double*>(pin);
+      if (cam) memcpy(cam, p, sizeof(double) * nc);
+      if (ray) memcpy(ray, p + nc, sizeof(double) * nr);
+      if (tlw) memcpy(tlw, p + nc + nr, sizeof(double) * nt);
+    }
+    ptzpool::pinned_release(pin);
+  }
+  else {
+    (void)hipGetLastError();
+    e = stream_wait(b->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && cam) e = copy_on(b->stream, cam, s_cam, sizeof(double) * nc, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ray) e = copy_on(b->stream, ray, s_ray, sizeof(double) * nr, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && tlw) e = copy_on(b->stream, tlw, s_tlw, sizeof(double) * nt, hipMemcpyDeviceToHost);
+  }
   ptzpool::dev_release(b->device, stage);
   if (e != hipSuccess) { (void)hipGetLastError(); return PTZ_ENODEVICE; }
   return PTZ_OK;
