@@ -1494,38 +1494,47 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   SC_STAMP(1);
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
-  {
-    // Diagonal block and right-hand side, one element per thread (the last wave's, so that the first waves start on the camera
-    // pairs at once): S_ii = U_i (2D-2D + annotation terms) + D_i^2 - sum T W^T (the latter only on the NW x NW 2D-2D
-    // columns), b_i = g_i - sum W z.  Every thread adds up its own element's wave partials, in wave order.
-    constexpr int NV = NW + NU, NE = NC * (NC + 1) / 2;
-    const int t = (int)threadIdx.x - (THREADS - 64);
-    const int gi = s.cam_off + ci;
+  // Diagonal block and right-hand side, one element per thread of the LAST wave: S_ii = U_i (2D-2D + annotation terms) + D_i^2
+  // - sum T W^T (the latter only on the NW x NW 2D-2D columns), b_i = g_i - sum W z.  Only the LOADS happen here; the element is
+  // finished behind phase 2 (schur_diag_finish below), while the other waves reduce their run sums: done in front of phase 2 it
+  // made the last wave start its runs ~2 us late (dependent global loads), and every other wave then waited that long at the
+  // barrier behind the runs.
+  constexpr int DIAG_NE = NC * (NC + 1) / 2;
+  const int dt = (int)threadIdx.x - (THREADS - 64);
+  int dp = 0, dq = 0;
+  double dv = 0, dDc = 0;
+  if (dt >= 0 && dt < DIAG_NE) {
+    dp = (int)((sqrtf(8.0f * dt + 1.0f) - 1.0f) * 0.5f);
+    while ((dp + 1) * (dp + 2) / 2 <= dt) ++dp;
+    while (dp * (dp + 1) / 2 > dt) --dp;
+    dq = dt - dp * (dp + 1) / 2;
+    dv = d.U[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
+    if (dp == dq) dDc = d.diag_c[(size_t)(s.cam_off + ci) * NC + dp];
+  }
+  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = d.gc[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
+  auto schur_diag_finish = [&]() {  // every thread adds up its own element's wave partials, in wave order
+    constexpr int NV = NW + NU;
     auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };  // NC slot -> 2D-2D column
     auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
-    if (t >= 0 && t < NE) {
-      int p = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-      while ((p + 1) * (p + 2) / 2 <= t) ++p;
-      while (p * (p + 1) / 2 > t) --p;
-      const int qq = t - p * (p + 1) / 2;
-      double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
-      if (p == qq) {
-        const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+    if (dt >= 0 && dt < DIAG_NE) {
+      double v = dv;
+      if (dp == dq) {
+        const double Dd = sqrt(dDc / st.radius);
         v += Dd * Dd;
       }
-      const int ip = ipos(p), iq = ipos(qq);
+      const int ip = ipos(dp), iq = ipos(dq);
       if (ip >= 0 && iq >= 0) v -= strip_sum(NW + ip * (ip + 1) / 2 + iq);
-      const int rp = scol(ci * NC + p), rq = scol(ci * NC + qq);
+      const int rp = scol(ci * NC + dp), rq = scol(ci * NC + dq);
       A[(size_t)rp * np + rq] = v;
       A[(size_t)rq * np + rp] = v;
     }
-    else if (t >= NE && t < NE + NC) {
-      const int p = t - NE, ip = ipos(p);
-      double v = d.gc[(size_t)gi * NC + p];
+    else if (dt >= DIAG_NE && dt < DIAG_NE + NC) {
+      const int p = dt - DIAG_NE, ip = ipos(p);
+      double v = dv;
       if (ip >= 0) v -= strip_sum(ip);
       A[(size_t)s.n * np + scol(ci * NC + p)] = v;
     }
-  }
+  };
   SC_STAMP(2);
   // ---- phase 2: off-diagonal blocks of row-block ci, one run of entries per thread
   const int* prun = d.pair_run + s.pair_off + s.idx + pr0;    // first run of each of this camera's pairs; prun[npr] = end of the last
@@ -1642,6 +1651,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     }
     if (base + THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
   }
+  schur_diag_finish();
 #ifdef PTZ_SCHUR_STAMPS
   SC_STAMP(6);
   if (stamp_on)
