@@ -1467,15 +1467,37 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     // one pass of the block tree for all NW + NU sums (fixed order: lanes by butterfly, waves in wave order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NV = NW + NU;
-    double v[NV];
+    // Reduce-scatter instead of NV full butterflies: in every halving step a lane keeps one half of the values it still holds
+    // (which half: one bit of its lane number), sends the other half to its partner and adds what the partner sends -- NV/2 +
+    // NV/4 + .. shuffles instead of 6 NV (14 sums: 17 against 84); the value that is left is finished with plain butterfly
+    // steps over the remaining lane bits.  A fixed tree per value, as before.
+    constexpr int PAD = NV <= 16 ? 16 : (NV <= 32 ? 32 : 64);
+    double v[PAD];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) v[k] = wave_sum(bsum[k]);
+    for (int k = 0; k < NW; ++k) v[k] = bsum[k];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) v[NW + k] = wave_sum(D[k]);
-    if (lane == 0) {
+    for (int k = 0; k < NU; ++k) v[NW + k] = D[k];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) strip[wv * NV + k] = v[k];
+    for (int k = NV; k < PAD; ++k) v[k] = 0.0;
+    int vidx = 0;  // index of the value this lane ends up with
+    {
+      int off = 32;
+#pragma unroll
+      for (int h = PAD / 2; h >= 1; h >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+          const double keep = up ? v[i + h] : v[i];
+          const double send = up ? v[i] : v[i + h];
+          v[i] = keep + __shfl_xor(send, off, WAVE);
+        }
+        if (up) vidx += h;
+      }
+#pragma unroll
+      for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, WAVE);
     }
+    constexpr int LOWMASK = 64 / PAD - 1;  // lanes that differ only in these bits hold the same value
+    if ((lane & LOWMASK) == 0 && vidx < NV) strip[wv * NV + vidx] = v[0];
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int t = (int)threadIdx.x + u * THREADS; if (t < ntl) tord[t] = tord_v[u]; }
     for (int t = (int)threadIdx.x + 2 * THREADS; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;  // (more than 512 tiles)
