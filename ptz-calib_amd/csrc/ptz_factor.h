@@ -55,6 +55,17 @@ PTZ_HD double rcp_nr(double d)
 #endif
 }
 
+// The quotient of the perspective division, a / z with iz = rcp_nr(z).  HOST build: the division, as the reference's functors
+// have it (tests/cpu_harness holds these functions to the oracle bit for bit).  DEVICE: a * iz -- an IEEE division is 12
+// instructions on this chip and the functors had five of them per observation, a third of the instruction stream of the
+// issue-bound k_eval / k_lin_ray / k_lin_cam loops.  The device's residual then differs from the quotient form by an ulp or so
+// (it never had the bits of a CPU's: the device contracts multiply-adds); parity tests hold it to the oracle to 1e-12 in cost.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTZ_PDIV(a, z, iz) ((a) * (iz))
+#else
+#define PTZ_PDIV(a, z, iz) ((a) / (z))
+#endif
+
 // cv::Rodrigues vector -> matrix (OpenCV 4.5.3 cvRodrigues2): theta < DBL_EPSILON -> I
 PTZ_HD void rodrigues(const double r[3], double R[9])
 {
@@ -197,13 +208,17 @@ PTZ_HD void ba_residual_unit(const double* cb, const double Xn[3], float u, floa
   const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
   if (TYPE == 0) {
     // uv_predict = K R ray; uv_predict /= uv_predict(2)   (ptzray_optimizer.cc:49-50)
-    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
-    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+    const double iz0 = rcp_nr(Pz);
+    (void)iz0;
+    res[0] = (double)u - PTZ_PDIV(f * Px + cx * Pz, Pz, iz0);
+    res[1] = (double)v - PTZ_PDIV(f * Py + cy * Pz, Pz, iz0);
   }
   else {
     if (TYPE == 1 && Pz < 0) { res[0] = 1000000.0; res[1] = 1000000.0; return; }  // :97-102
     const double Pzd = TYPE == 3 ? Pz + (cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f) : Pz;  // :233-234
-    const double x = Px / Pzd, y = Py / Pzd;
+    const double izd = rcp_nr(Pzd);
+    (void)izd;
+    const double x = PTZ_PDIV(Px, Pzd, izd), y = PTZ_PDIV(Py, Pzd, izd);
     double xd, yd;
     brown(x, y, cb + CB_K, xd, yd);
     res[0] = (double)u - (f * xd + cx);
@@ -251,13 +266,13 @@ PTZ_HD void ba_linearize(const double* cb, const double X[3], float u, float v, 
   // PTZRayDistDisp: the camera-frame point moves along z by delta(f) before the projection (:233-236)
   const double delta = TYPE == 3 ? cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f : 0.0;
   const double Pzd = TYPE == 3 ? Pz + delta : Pz;
-  const double iz = 1.0 / Pzd;
-  const double x = Px / Pzd, y = Py / Pzd;  // same arithmetic as the reference functor
+  const double iz = rcp_nr(Pzd);
+  const double x = PTZ_PDIV(Px, Pzd, iz), y = PTZ_PDIV(Py, Pzd, iz);  // (host build: the reference functor's divisions, PTZ_PDIV)
   double xd = x, yd = y;
   double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (TYPE == 0) {
-    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
-    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+    res[0] = (double)u - PTZ_PDIV(f * Px + cx * Pz, Pz, iz);
+    res[1] = (double)v - PTZ_PDIV(f * Py + cy * Pz, Pz, iz);
   }
   else {
     brown(x, y, cb + CB_K, xd, yd);
@@ -406,13 +421,13 @@ PTZ_HD void ba_step_dir_unit(const double* cb, const double Xn[3], double inv_n,
   }
   const double delta = TYPE == 3 ? cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f : 0.0;
   const double Pzd = TYPE == 3 ? Pz + delta : Pz;
-  const double iz = 1.0 / Pzd;
-  const double x = Px / Pzd, y = Py / Pzd;
+  const double iz = rcp_nr(Pzd);
+  const double x = PTZ_PDIV(Px, Pzd, iz), y = PTZ_PDIV(Py, Pzd, iz);
   double xd = x, yd = y;
   double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (TYPE == 0) {
-    res[0] = (double)u - (f * Px + cx * Pz) / Pz;
-    res[1] = (double)v - (f * Py + cy * Pz) / Pz;
+    res[0] = (double)u - PTZ_PDIV(f * Px + cx * Pz, Pz, iz);
+    res[1] = (double)v - PTZ_PDIV(f * Py + cy * Pz, Pz, iz);
   }
   else {
     brown(x, y, cb + CB_K, xd, yd);
@@ -481,7 +496,7 @@ PTZ_HD void reproj2d3d_eval(const double* cb, const double* tl, const double xyz
   const double Py = R[3] * Xx + R[4] * Xy + R[5] * Xz;
   const double Pz = R[6] * Xx + R[7] * Xy + R[8] * Xz;
   const double Pzd = DISP ? Pz + (cb[CB_D] + cb[CB_D + 1] * fx + cb[CB_D + 2] * fx * fx) : Pz;
-  const double iz = 1.0 / Pzd, x = Px / Pzd, y = Py / Pzd;
+  const double iz = rcp_nr(Pzd), x = PTZ_PDIV(Px, Pzd, iz), y = PTZ_PDIV(Py, Pzd, iz);
   double xd, yd;
   brown(x, y, cb + CB_K, xd, yd);
   res[0] = (double)u - (fx * xd + cx);
@@ -548,11 +563,11 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, do
   const double Px = R[0] * ray1[0] + R[1] * ray1[1] + R[2] * ray1[2];
   const double Py = R[3] * ray1[0] + R[4] * ray1[1] + R[5] * ray1[2];
   const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
-  const double iz = 1.0 / Pz, x = Px / Pz, y = Py / Pz;  // same arithmetic as the reference functor
+  const double iz = rcp_nr(Pz), x = PTZ_PDIV(Px, Pz, iz), y = PTZ_PDIV(Py, Pz, iz);  // (host build: the reference functor's divisions, PTZ_PDIV)
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (!DIST) {
-    res[0] = (double)u2 - (fx * Px + cx * Pz) / Pz;
-    res[1] = (double)v2 - (fy * Py + cy * Pz) / Pz;
+    res[0] = (double)u2 - PTZ_PDIV(fx * Px + cx * Pz, Pz, iz);
+    res[1] = (double)v2 - PTZ_PDIV(fy * Py + cy * Pz, Pz, iz);
   }
   else {
     brown(x, y, kd, xd, yd);
