@@ -569,8 +569,17 @@ __device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, 
 }
 
 // kmin: no system factors a block column below it in this step, so only the tiles (ti, tj), ti >= tj > kmin, can have work
+#ifdef PTZ_CHOL_STAMPS  // probe builds only: where the workgroup of a step's NEXT diagonal tile spends its time (100 MHz wall clock)
+#define CS_STAMP(i) do { if (threadIdx.x == 0) cs_t[i] = wall_clock64(); } while (0)
+#else
+#define CS_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int step, int kmin)
 {
+#ifdef PTZ_CHOL_STAMPS
+  long long cs_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  cs_t[0] = wall_clock64();
+#endif
   int bx, slot;
   xcd_remap(bx, slot);
   const int sys = chol_system_of(cb, slot);
@@ -657,17 +666,21 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   // The step's columns in ascending order (a tile behind both -- a separator tile -- takes both updates, always in this
   // order).  The C tile is asked for after the first triangular solve has been issued, so that its sixteen strided loads do
   // not queue up in front of the operand tiles on the critical workgroup.
+  CS_STAMP(1);
   if (nu > 0) operands(u0);
+  CS_STAMP(2);
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
   if (nu > 0) update();
+  CS_STAMP(3);
   for (int u = 1; u < nu; ++u) {  // a tile behind several columns of the step (fetching the next L_kk ahead was tried: no gain)
     __syncthreads();  // all waves are done with the operand tiles of the previous column
     operands(u == 1 ? u1 : (u == 2 ? u2 : u3));
     update();
   }
+  CS_STAMP(4);
   if (next_diag) {
     __syncthreads();  // all waves are done reading the operand tiles
 #pragma unroll
@@ -675,7 +688,15 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 #pragma unroll
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
     __syncthreads();
+    CS_STAMP(5);
     diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
+#ifdef PTZ_CHOL_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    CS_STAMP(6);
+    if (threadIdx.x == 0 && slot == 0)
+      printf("chol_col_step %d tile %d updates %d | x10 ns: prologue %lld, first operands (load + solve) %lld, C + first update %lld, further columns %lld, to LDS %lld, diagonal factor %lld\n",
+             step, ti, nu, cs_t[1] - cs_t[0], cs_t[2] - cs_t[1], cs_t[3] - cs_t[2], cs_t[4] - cs_t[3], cs_t[5] - cs_t[4], cs_t[6] - cs_t[5]);
+#endif
     return;
   }
 #pragma unroll
