@@ -1555,8 +1555,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.diag_c, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.dc, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.dct, (size_t)b->total_cam * (NC | 1) + 4));
-  TRY(b->alloc(&d.V, (size_t)b->total_ray * 6));
-  TRY(b->alloc(&d.gr, (size_t)b->total_ray * 3));
+  // (two halves each: k_eval leaves the ray-side linearisation of its candidate in the half that LmState.cur does not select)
+  d.V_stride = (size_t)b->total_ray * 6; d.gr_stride = (size_t)b->total_ray * 3;
+  d.rayrec_stride = (size_t)b->total_ray * 8; d.plin_stride = (size_t)b->total_chunk * 2;
+  TRY(b->alloc(&d.V, 2 * d.V_stride));
+  TRY(b->alloc(&d.gr, 2 * d.gr_stride));
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
   TRY(b->alloc(&d.E, (size_t)b->total_ray * EZS));  // (E, z) records
   d.shared = any_shared ? 1 : 0;
@@ -1571,9 +1574,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   // them when a caller asks for them, PTZ_BA_SCHUR_W=1 brings round 2's kernels back for A/B measurements
   if (const char* e = getenv("PTZ_BA_SCHUR_W")) b->schur_w = atoi(e) != 0;
   if (b->schur_w) TRY(b->alloc(&d.W, (size_t)b->total_obs * (disp ? 24 : type == PTZ_BA_PTZRayFxfyDist ? 18 : 16)));  // room for the widest row stride
-  TRY(b->alloc(&d.rayrec, (size_t)b->total_ray * 8));
+  TRY(b->alloc(&d.rayrec, 2 * d.rayrec_stride));
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 4));
-  TRY(b->alloc(&d.partial_lin, (size_t)b->total_chunk * 2));
+  TRY(b->alloc(&d.partial_lin, 2 * d.plin_stride));
   d.ray_block = b->ray_block;
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));

@@ -42,7 +42,7 @@ struct LmState {
   int reuse_diagonal, need_linearize, cur, iteration, n_summaries, step_is_successful;
   int num_consecutive_invalid, termination;
   int num_successful, num_unsuccessful, num_lm_steps, num_linear_solves, num_jac_evals;
-  int pad;
+  int ray_lin_ready;  // the ray blocks of the current point were left by k_eval's second pass (no k_lin_ray needed for this linearisation)
 };
 
 struct Opt {  // device copy of the solver options
@@ -109,6 +109,9 @@ struct Dev {
   double* partial;   // [total_wave + n_scene][4] per wave of rays {model cost change, candidate cost, |x - x_c|^2, |x_c|^2} of k_eval
                      // (one extra slot per scene for the 2D-3D terms)
   double* partial_lin;  // [total_wave][2] per wave of rays {max |g_r / scale|, |x|^2} of k_lin_ray
+  // V, gr, rayrec and partial_lin are DOUBLE-BUFFERED like the state (LmState.cur selects the half of the current point): k_eval's second
+  // pass leaves the ray-side linearisation of the candidate in the other half, which an accepted step makes the current one
+  size_t V_stride, gr_stride, rayrec_stride, plin_stride;  // doubles between the halves
   int ray_block;     // rays per workgroup of k_lin_ray / k_ray_prep / k_eval in this batch (multiple of 64, <= RAY_BLOCK)
   // 2D-3D annotation residuals (georeferencing); per-scene arrays below are indexed by the GLOBAL scene index
   const float2* o3_uv;  // [total_o3]
@@ -182,6 +185,11 @@ __device__ __forceinline__ const double* cur_ray(const Dev& d, const SceneDev& s
 }
 
 __device__ __forceinline__ double* cur_camblk(const Dev& d, const LmState& st) { return d.camblk + (size_t)st.cur * d.camblk_stride; }
+// the ray-side linearisation (V, g_r, the rays' records for the camera pass, the per-wave gradient / |x| partials): half `h`
+__device__ __forceinline__ double* lin_V(const Dev& d, int h) { return d.V + (size_t)h * d.V_stride; }
+__device__ __forceinline__ double* lin_gr(const Dev& d, int h) { return d.gr + (size_t)h * d.gr_stride; }
+__device__ __forceinline__ double* lin_rayrec(const Dev& d, int h) { return d.rayrec + (size_t)h * d.rayrec_stride; }
+__device__ __forceinline__ double* lin_partial(const Dev& d, int h) { return d.partial_lin + (size_t)h * d.plin_stride; }
 __device__ __forceinline__ double* cur_tlwblk(const Dev& d, const LmState& st) { return d.tlwblk + (size_t)st.cur * d.tlwblk_stride; }
 
 __device__ __forceinline__ int scene_of_slot(const Dev& d, int slot)
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
   if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  if (!d.active[sc] || !st.need_linearize || (int)(blockIdx.x * blockDim.x) >= s.n_ray) return;
+  if (!d.active[sc] || !st.need_linearize || st.ray_lin_ready || (int)(blockIdx.x * blockDim.x) >= s.n_ray) return;  // (ray_lin_ready: k_eval left this linearisation)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const double* tab;
   float4* obsbuf;  // SMALL only
@@ -405,11 +413,11 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
     for (int k = 0; k < 3; ++k) g[k] += Jr[0][k] * res[0] + Jr[1][k] * res[1];
   });
 #pragma unroll
-  for (int k = 0; k < 6; ++k) d.V[(size_t)gj * 6 + k] = V[k];
+  for (int k = 0; k < 6; ++k) lin_V(d, st.cur)[(size_t)gj * 6 + k] = V[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) d.gr[(size_t)gj * 3 + k] = g[k];
+  for (int k = 0; k < 3; ++k) lin_gr(d, st.cur)[(size_t)gj * 3 + k] = g[k];
   {  // the camera pass (next launch) gathers this ray once per observation: one aligned 64-byte record instead of three arrays
-    double* rr = d.rayrec + (size_t)gj * 8;
+    double* rr = lin_rayrec(d, st.cur) + (size_t)gj * 8;
     rr[0] = Xr[0]; rr[1] = Xr[1]; rr[2] = Xr[2]; rr[3] = sr[0]; rr[4] = sr[1]; rr[5] = sr[2]; rr[6] = d.ray_w[gj]; rr[7] = 0.0;
   }
 #pragma unroll
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
   gm = wave_max(gm);
   xn = wave_sum(xn);
   if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
-    double* pl = d.partial_lin + (size_t)(s.part_off - s.idx + (j >> 6)) * 2;  // (part_off counts one extra slot per preceding scene)
+    double* pl = lin_partial(d, st.cur) + (size_t)(s.part_off - s.idx + (j >> 6)) * 2;  // (part_off counts one extra slot per preceding scene)
     pl[0] = gm; pl[1] = xn;
   }
 }
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   typedef double d8 __attribute__((ext_vector_type(8)));
   auto qclamp = [&](int q) { return max(min(q, q_end - 1), 0); };
   auto load_rr = [&](int rid) {
-    const double2* r2 = reinterpret_cast<const double2*>(d.rayrec + (size_t)rid * 8);
+    const double2* r2 = reinterpret_cast<const double2*>(lin_rayrec(d, st.cur) + (size_t)rid * 8);
     const double2 a = r2[0], b = r2[1], c = r2[2], e = r2[3];
     d8 v; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = e.x; v[7] = e.y;
     return v;
@@ -638,9 +646,10 @@ __global__ void k_jacobi_scale(Dev d)
   }
   if (t < s.n_ray) {
     const int gj = s.ray_off + t;
-    d.scale_r[(size_t)gj * 3 + 0] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 0]));
-    d.scale_r[(size_t)gj * 3 + 1] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 2]));
-    d.scale_r[(size_t)gj * 3 + 2] = 1.0 / (1.0 + sqrt(d.V[(size_t)gj * 6 + 5]));
+    const double* Vc = lin_V(d, d.lm[sc].cur);
+    d.scale_r[(size_t)gj * 3 + 0] = 1.0 / (1.0 + sqrt(Vc[(size_t)gj * 6 + 0]));
+    d.scale_r[(size_t)gj * 3 + 1] = 1.0 / (1.0 + sqrt(Vc[(size_t)gj * 6 + 2]));
+    d.scale_r[(size_t)gj * 3 + 2] = 1.0 / (1.0 + sqrt(Vc[(size_t)gj * 6 + 5]));
   }
   if (Dims<TYPE>::HAS3D && t < 6) d.scale_t[(size_t)s.idx * 6 + t] = 1.0 / (1.0 + sqrt(d.Ut[(size_t)s.idx * 36 + t * 7]));
 }
@@ -895,7 +904,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
       }
     }
     for (int wv = tid; wv < s.n_wave; wv += LM_THREADS) {  // the rays' share, one entry per wave of k_lin_ray
-      const double* pl = d.partial_lin + (size_t)(s.part_off - s.idx + wv) * 2;
+      const double* pl = lin_partial(d, st.cur) + (size_t)(s.part_off - s.idx + wv) * 2;
       gm = fmax(gm, pl[0]);
       xn += pl[1];
     }
@@ -918,6 +927,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
       st.grad_max = gm;
       st.x_norm = sqrt(xn);
       st.need_linearize = 0;
+      st.ray_lin_ready = 0;
       ++st.num_jac_evals;
       if (st.n_summaries == 0) { st.initial_cost = c; st.final_cost = c; }
     }
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
   const int gj = s.ray_off + j;
   double V[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) V[k] = d.V[(size_t)gj * 6 + k];
+  for (int k = 0; k < 6; ++k) V[k] = lin_V(d, st.cur)[(size_t)gj * 6 + k];
   double dg[3];
   if (!st.reuse_diagonal) {
     dg[0] = fmin(fmax(V[0], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
@@ -1017,11 +1027,12 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
 #pragma unroll
     for (int k = 0; k < 6; ++k) E[k] = 0;
   }
-  const double g0 = d.gr[(size_t)gj * 3], g1 = d.gr[(size_t)gj * 3 + 1], g2 = d.gr[(size_t)gj * 3 + 2];
+  const double* grc = lin_gr(d, st.cur);
+  const double g0 = grc[(size_t)gj * 3], g1 = grc[(size_t)gj * 3 + 1], g2 = grc[(size_t)gj * 3 + 2];
   // The record goes out whole in eight 16-byte stores: E, z = E g_r, and -- from what k_lin_ray left in rayrec {X, Jacobi
   // scales, weight} -- the ray side of an observation's Jacobians as k_schur rebuilds them (ba_pair_side): the functor's point
   // Xn, a_l = sqrt(w) s_l / |X| (d res / d X_l = -MR[:, l] a_l after weighting and scaling) and sqrt(w).
-  const double2* rr2 = reinterpret_cast<const double2*>(d.rayrec + (size_t)gj * 8);
+  const double2* rr2 = reinterpret_cast<const double2*>(lin_rayrec(d, st.cur) + (size_t)gj * 8);
   const double2 ra = rr2[0], rb = rr2[1], rc = rr2[2], rd = rr2[3];
   const double Xray[3] = {ra.x, ra.y, rb.x};
   double Xn[3], inv_n;
@@ -1866,21 +1877,25 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   EV_STAMP(2);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double mcc = 0, cost = 0, dn = 0, cn = 0;
+  double lgm = 0;  // the candidate's share of the gradient max-norm (k_lm_pre, if the step is accepted; its |x|^2 share is cn)
+  const int gj = s.ray_off + j;
+  double sr[3] = {1, 1, 1}, w = 0, sw = 0, Xn[3] = {0, 0, 0};
+  int a0 = 0, a1 = 0;
   if (j < s.n_ray) {
-    const int gj = s.ray_off + j;
     const double* X = cur_ray(d, s, st) + (size_t)j * 3;
     const double Xr[3] = {X[0], X[1], X[2]};
-    const double sr[3] = {d.scale_r[(size_t)gj * 3], d.scale_r[(size_t)gj * 3 + 1], d.scale_r[(size_t)gj * 3 + 2]};
-    const double w = d.ray_w[gj];
-    const double sw = sqrt(w);
+    sr[0] = d.scale_r[(size_t)gj * 3]; sr[1] = d.scale_r[(size_t)gj * 3 + 1]; sr[2] = d.scale_r[(size_t)gj * 3 + 2];
+    w = d.ray_w[gj];
+    sw = sqrt(w);
     const int* rp = d.ray_ptr + s.ray_off + s.idx;
-    const int a0 = rp[j], a1 = rp[j + 1];
+    a0 = rp[j]; a1 = rp[j + 1];
     // pass 1 (one linearisation per observation): with p_a = Jc_a d_c (camera part of J d),
     //   t  = g_r + sum_a Jr_a^T p_a                      -> y_r = E t, ray step d_r = -y_r
     //   s1 = sum_a p_a . (r_a + p_a / 2)
     // and, since J d = p_a + Jr_a d_r per observation, the ray's share of (J d)^T (r + J d / 2) is
     //   s1 + d_r . t + 1/2 d_r^T V d_r      (V = sum_a Jr_a^T Jr_a is the stored, undamped ray block)
-    double t0 = d.gr[(size_t)gj * 3], t1 = d.gr[(size_t)gj * 3 + 1], t2 = d.gr[(size_t)gj * 3 + 2];
+    const double* grc = lin_gr(d, st.cur);
+    double t0 = grc[(size_t)gj * 3], t1 = grc[(size_t)gj * 3 + 1], t2 = grc[(size_t)gj * 3 + 2];
     double s1 = 0;
     double Xu[3], inv_n;  // the functor's point for this ray, once for all of its observations
     ba_ray_point<F>(Xr, Xu, inv_n);
@@ -1899,37 +1914,73 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     const double* E = d.E + (size_t)gj * EZS;
     // step = -y_r (Ceres solves J y = r and negates)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
-    const double Xn[3] = {Xr[0] + ds[0] * sr[0], Xr[1] + ds[1] * sr[1], Xr[2] + ds[2] * sr[2]};
+    Xn[0] = Xr[0] + ds[0] * sr[0]; Xn[1] = Xr[1] + ds[1] * sr[1]; Xn[2] = Xr[2] + ds[2] * sr[2];
     double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
     xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { dn += (Xr[k] - Xn[k]) * (Xr[k] - Xn[k]); cn += Xn[k] * Xn[k]; }  // |x - x_c|^2, |x_c|^2 (k_lm_post)
     {
-      const double* V = d.V + (size_t)gj * 6;  // [v00 v10 v11 v20 v21 v22]
+      const double* V = lin_V(d, st.cur) + (size_t)gj * 6;  // [v00 v10 v11 v20 v21 v22]
       const double q0 = V[0] * ds[0] + V[1] * ds[1] + V[3] * ds[2];
       const double q1 = V[1] * ds[0] + V[2] * ds[1] + V[4] * ds[2];
       const double q2 = V[3] * ds[0] + V[4] * ds[1] + V[5] * ds[2];
       mcc = s1 + (ds[0] * t0 + ds[1] * t1 + ds[2] * t2) + 0.5 * (ds[0] * q0 + ds[1] * q1 + ds[2] * q2);
     }
-    // pass 2: candidate cost (residuals only)
-    double Xcu[3], inv_nc;
-    ba_ray_point<F>(Xn, Xcu, inv_nc);
-    EV_STAMP(5);
-    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
-      double rc[2];
-      ba_residual_unit<F>(ctab + ci * CDS, Xcu, uv.x, uv.y, rc);
-      cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
-    });
   }
-  EV_STAMP(6);
-  // one partial per wave of 64 rays (fixed butterfly), whatever the workgroup size
+  // the first pass's sums leave the registers now: one partial per wave of 64 rays (fixed butterfly), whatever the workgroup size
   mcc = wave_sum(mcc);
-  cost = wave_sum(cost);
   dn = wave_sum(dn);
   cn = wave_sum(cn);
   if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
     double* pp = d.partial + (size_t)(s.part_off + (j >> 6)) * 4;
-    pp[0] = mcc; pp[1] = cost; pp[2] = dn; pp[3] = cn;
+    pp[0] = mcc; pp[2] = dn; pp[3] = cn;
+    lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2 + 1] = cn;  // |x_c|^2 is the accepted point's |x|^2 (k_lm_pre)
+  }
+  if (j < s.n_ray) {
+    // pass 2: candidate cost, and -- for the price of the ray Jacobian on top of the residual -- the ray side of the candidate's
+    // LINEARISATION (V, g_r, the ray's record for the camera pass, its share of the gradient norm and of |x|), into the other half
+    // of the double buffers: if k_lm_post accepts the step that half becomes the current one and no k_lin_ray runs for it (it
+    // would re-read these observations and camera blocks to compute exactly this); a rejected step leaves the current half alone.
+    double Xcu[3], inv_nc;
+    ba_ray_point<F>(Xn, Xcu, inv_nc);
+    EV_STAMP(5);
+    double Vc[6] = {0, 0, 0, 0, 0, 0}, gc3[3] = {0, 0, 0};
+    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
+      double rc[2], Jr[2][3];
+      ba_res_jr_unit<F>(ctab + ci * CDS, Xcu, inv_nc, uv.x, uv.y, rc, Jr);
+      cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
+      rc[0] *= sw; rc[1] *= sw;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
+      Vc[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
+      Vc[1] += Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
+      Vc[2] += Jr[0][1] * Jr[0][1] + Jr[1][1] * Jr[1][1];
+      Vc[3] += Jr[0][2] * Jr[0][0] + Jr[1][2] * Jr[1][0];
+      Vc[4] += Jr[0][2] * Jr[0][1] + Jr[1][2] * Jr[1][1];
+      Vc[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gc3[k] += Jr[0][k] * rc[0] + Jr[1][k] * rc[1];
+    });
+    {
+      const int hc = st.cur ^ 1;
+      double* Vo = lin_V(d, hc) + (size_t)gj * 6;
+      double* go = lin_gr(d, hc) + (size_t)gj * 3;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Vo[k] = Vc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) go[k] = gc3[k];
+      double* rr = lin_rayrec(d, hc) + (size_t)gj * 8;
+      rr[0] = Xn[0]; rr[1] = Xn[1]; rr[2] = Xn[2]; rr[3] = sr[0]; rr[4] = sr[1]; rr[5] = sr[2]; rr[6] = w; rr[7] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) lgm = fmax(lgm, fabs(gc3[k] / sr[k]));
+    }
+  }
+  EV_STAMP(6);
+  lgm = wave_max(lgm);
+  cost = wave_sum(cost);
+  if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
+    lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2] = lgm;
+    d.partial[(size_t)(s.part_off + (j >> 6)) * 4 + 1] = cost;
   }
   (void)scratch;
   EV_STAMP(7);
@@ -2052,6 +2103,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
     // HandleSuccessfulStep: x <- candidate; the Jacobian is re-evaluated by the kernels that follow
     st.cur ^= 1;
     st.need_linearize = 1;
+    st.ray_lin_ready = 1;  // k_eval's second pass has left V, g_r, the ray records and the partials of this point in its half
     st.step_is_successful = 1;
     const double t = 2.0 * rho - 1.0;
     st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);  // StepAccepted

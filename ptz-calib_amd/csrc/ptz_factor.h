@@ -463,6 +463,49 @@ PTZ_HD void ba_step_dir_unit(const double* cb, const double Xn[3], double inv_n,
   }
 }
 
+// Residual and ray Jacobian only (no camera side): what k_eval's second pass needs to leave the ray blocks of the CANDIDATE point
+// behind -- the linearisation an accepted step would otherwise ask k_lin_ray for.  Same projection arithmetic as ba_step_dir_unit;
+// reads the camera block's candidate prefix (rotation, intrinsics) only.
+template <int TYPE>
+PTZ_HD void ba_res_jr_unit(const double* cb, const double Xn[3], double inv_n, float u, float v, double res[2], double Jr[2][3])
+{
+  const double* R = cb + CB_R;
+  const double f = cb[CB_F], cx = cb[CB_CX], cy = cb[CB_CY];
+  const double fy = TYPE == 2 ? cb[CB_FY] : f;
+  const double Px = R[0] * Xn[0] + R[1] * Xn[1] + R[2] * Xn[2];
+  const double Py = R[3] * Xn[0] + R[4] * Xn[1] + R[5] * Xn[2];
+  const double Pz = R[6] * Xn[0] + R[7] * Xn[1] + R[8] * Xn[2];
+  if (TYPE == 1 && Pz < 0) {
+    res[0] = 1000000.0; res[1] = 1000000.0;
+    for (int k = 0; k < 3; ++k) { Jr[0][k] = 0; Jr[1][k] = 0; }
+    return;
+  }
+  const double delta = TYPE == 3 ? cb[CB_D] + cb[CB_D + 1] * f + cb[CB_D + 2] * f * f : 0.0;
+  const double Pzd = TYPE == 3 ? Pz + delta : Pz;
+  const double iz = rcp_nr(Pzd);
+  const double x = PTZ_PDIV(Px, Pzd, iz), y = PTZ_PDIV(Py, Pzd, iz);
+  double xd = x, yd = y;
+  double B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
+  if (TYPE == 0) {
+    res[0] = (double)u - PTZ_PDIV(f * Px + cx * Pz, Pz, iz);
+    res[1] = (double)v - PTZ_PDIV(f * Py + cy * Pz, Pz, iz);
+  }
+  else {
+    brown(x, y, cb + CB_K, xd, yd);
+    brown_jac(x, y, cb + CB_K, B, dk1);
+    res[0] = (double)u - (f * xd + cx);
+    res[1] = (double)v - (fy * yd + cy);
+  }
+  double M[2][3];
+  M[0][0] = f * (B[0] * iz);  M[0][1] = f * (B[1] * iz);  M[0][2] = f * (-(B[0] * x + B[1] * y) * iz);
+  M[1][0] = fy * (B[2] * iz);  M[1][1] = fy * (B[3] * iz);  M[1][2] = fy * (-(B[2] * x + B[3] * y) * iz);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    Jr[0][k] = -(M[0][0] * R[k] + M[0][1] * R[3 + k] + M[0][2] * R[6 + k] + (TYPE == 3 ? delta * M[0][2] * Xn[k] : 0.0)) * inv_n;
+    Jr[1][k] = -(M[1][0] * R[k] + M[1][1] * R[3 + k] + M[1][2] * R[6 + k] + (TYPE == 3 ? delta * M[1][2] * Xn[k] : 0.0)) * inv_n;
+  }
+}
+
 template <int TYPE>
 PTZ_HD void ba_step_dir(const double* cb, const double X[3], float u, float v, const double* sv, const double om[3], double res[2],
                         double p[2], double Jr[2][3])
