@@ -528,7 +528,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   {
     const Dev& dd = d;
     b->prof_begin(P_LIN);
-    PTZ_LAUNCH_RAY(k_lin_ray, dim3(sh.max_chunk, B), sh.lin_smem, dd);
+    // (no k_lin_ray inside a pass: the ray side of an accepted step's linearisation was left by k_eval's second pass,
+    //  LmState::ray_lin_ready; k_lin_ray runs for iteration zero only, enqueue_linearize)
     if (dd.W && b->schur_w) LAUNCH((k_lin_cam<TYPE, true>), dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     else LAUNCH((k_lin_cam<TYPE, false>), dim3((b->max_cam + 3) / 4, B), dim3(256), 0, dd);
     if (Dims<TYPE>::HAS3D) LAUNCH(k_lin_3d<TYPE>, dim3(B), dim3(256), 0, dd);
