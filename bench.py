@@ -523,7 +523,9 @@ def main():
             body["kernel_families"] = table
             body["roofline_note"] = ("achieved = SURVEY 8(d) algorithmic bytes (flops) of the family x units executed by all scenes in the "
                                      "timed region / family device time (HIP events on the solver's stream); traffic = rocprofv3 PMC bytes "
-                                     "per launch (profiles/)")
+                                     "per launch (profiles/).  Since round 3 the RAY side of an accepted step's linearisation (V, g_r) is computed by the second pass of "
+                                     "k_eval and only its camera side by the `linearize` family: the `linearize` and `eval` rows share SURVEY 8(d)'s K1 + K4 bytes and "
+                                     "are best read together")
         body["parallel"] = par
         if extras and args.config != "C5":
             # The timed region above runs with per-family profiling, which makes the library enqueue eagerly and solve the batch as
