@@ -447,6 +447,7 @@ static void make_groups(ptz_ba_batch* b)
     d.act = b->d_act + lo;
     d.use_act = 0;
     if (d.chol.L) d.chol.L = b->d.chol.L + (size_t)g * std::min(b->n_scene, 8) * np * np;  // up to eight slots of finished L tiles per group
+    if (d.chol.chain_ctl) d.chol.chain_ctl = b->d.chol.chain_ctl + (size_t)g * chol_chain_ctl_ints((int)np);  // (a block per stream)
     b->dg.push_back(d);
   }
   if ((int)b->pass_graph.size() != G || (G > 0 && b->pass_graph[0].size() != b->shapes.size())) {  // the grouping changed (profiling on / off): recorded passes are stale
@@ -736,14 +737,21 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
   hipEvent_t evT = nullptr, evR = nullptr;
   if (la) b->lookahead_events(stream, &evT, &evR);
   bool rest_pending = false;
-  if (fused) {  // a few scenes: one launch per step of the schedule (chol_col_step_kernel)
-    b->prof_begin(P_CHOL_PANEL);
-    chol_diag_launch(cb, -1, stream);
-    b->prof_end();
-    for (int st = 0; st + 1 < chol_step_count(cb); ++st) {
+  if (fused) {  // a few scenes: the whole factorisation in one launch (chol_chain_kernel), or one launch per step of the schedule (chol_col_step_kernel)
+    if (chol_chain_enabled(cb)) {
       b->prof_begin(P_CHOL_SYRK);
-      chol_col_step_launch(cb, st, stream);
+      chol_chain_launch(cb, stream);
       b->prof_end();
+    }
+    else {
+      b->prof_begin(P_CHOL_PANEL);
+      chol_diag_launch(cb, -1, stream);
+      b->prof_end();
+      for (int st = 0; st + 1 < chol_step_count(cb); ++st) {
+        b->prof_begin(P_CHOL_SYRK);
+        chol_col_step_launch(cb, st, stream);
+        b->prof_end();
+      }
     }
     b->prof_begin(P_CHOL_BACK);
     chol_backsolve_launch(cb, x, stream);
@@ -1601,6 +1609,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     TRY(b->alloc(&d.chol.L, slots * d.chol.np * d.chol.np));
     if (hipMemsetAsync(d.chol.L, 0, sizeof(double) * slots * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     TRY(b->alloc(&b->d_act, (size_t)n));
+    const size_t ctl_ints = chol_chain_ctl_ints(d.chol.np) * groups;
+    TRY(b->alloc(&d.chol.chain_ctl, ctl_ints));
+    if (hipMemsetAsync(d.chol.chain_ctl, 0, sizeof(int) * ctl_ints, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   }
   TRY(b->alloc(&d.chol.Ldiag, (size_t)n * (d.chol.np / CHOL_NB) * CHOL_NB * CHOL_NB));
   TRY(b->alloc(&d.chol.Dinv, (size_t)n * (d.chol.np / CHOL_NB) * 4 * 16 * 16));
@@ -1768,7 +1779,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   };
   b->shapes.clear();
   b->shapes.push_back(make_shape(n, false));
-  for (int sl = 8; sl < n; sl *= 4) b->shapes.push_back(make_shape(sl, true));
+  // (two slots: the last rigs of a large batch get the one-launch factorisation, chol_chain_kernel; a batch of up to eight keeps
+  //  its single shape -- a second one costs it a k_compact launch per pass)
+  for (int sl = n > 8 ? 2 : 8; sl < n; sl *= 4) b->shapes.push_back(make_shape(sl, true));
   b->ray_block = b->shapes[0].ray_block;
   b->d.ray_block = b->ray_block;
   const int eval_smem = (int)b->shapes[0].eval_smem, lin_smem = (int)b->shapes[0].lin_smem;

@@ -15,6 +15,7 @@
 //                          A_ij -= L_ik L_jk^T with v_mfma_f64_16x16x4_f64, operands staged through LDS.
 //   The right-hand side rides along as row n of the padded matrix (diagonal = CHOL_BIG), so the forward
 //   substitution is done by the same kernels; chol_backsolve finishes with L^T x = y.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -527,7 +528,21 @@ __device__ __forceinline__ d16 tile_fetch(const double* __restrict__ g, int ld)
 // (CholBatch::sched) a step holds two block columns that do not couple -- the arcs of a dissected ring -- whose updates and
 // next diagonal tiles proceed in the same launch (13 -> 9 on that system).  The workgroup of the diagonal tile (i, i) is
 // the one that writes L_ik back (the back-substitution reads it).  For batches the left-looking kernels are used.
-__device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, int ldg, const double* Lk, const double* Di, double* xs,
+// this wave's 16 rows of a tile in accumulator layout, asked for ahead of the solve (one vector value: an array would be kept in
+// scratch across the barrier in between)
+typedef double d16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ d16v trsm_rows_fetch(const double* __restrict__ Tg, int ldg)
+{
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+  d16v r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[4 * c + i] = Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr];
+  return r;
+}
+__device__ __forceinline__ void trsm_rows_to_lds(const d16v rows, int ldg, const double* Lk, const double* Di, double* xs,
                                                  double* __restrict__ store_to)
 {
   // this wave's 16 rows of the tile: X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T, c = 0..3; xs = those rows of the LDS image
@@ -537,7 +552,7 @@ __device__ __forceinline__ void trsm_rows_to_lds(const double* __restrict__ Tg, 
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[c][i] = Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr];
+    for (int i = 0; i < 4; ++i) acc[c][i] = rows[4 * c + i];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -647,10 +662,11 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
     const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
     for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
     __syncthreads();
-    double* Tik = A + (size_t)(ti * NB + 16 * w) * np + k * NB;
+    // (asking for the rows in front of L_kk was measured: +0.2 ms per one-rig solve -- everything of a step starts at once here and
+    //  their strided loads queue up in front of the tile every wave waits for; chol_chain_kernel, which waits for L_kk, does it)
     double* Lik = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
-    trsm_rows_to_lds(Tik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
-    if (ti != tj) trsm_rows_to_lds(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np, Lk, Di, Bs + 16 * w * LD, nullptr);
+    trsm_rows_to_lds(trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np), np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
+    if (ti != tj) trsm_rows_to_lds(trsm_rows_fetch(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np), np, Lk, Di, Bs + 16 * w * LD, nullptr);
   };
   auto update = [&]() {
     __syncthreads();
@@ -703,6 +719,185 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+}
+
+// ---- the whole factorisation of a FEW systems as ONE launch: workgroup = tile, tiles handed on through flags -----------------
+// The one-launch-per-step path above pays, per step of the dependent chain, the drain of a launch, the start of the next, its
+// prologue and a cold read of L_kk (~9 of the ~23 us of a step).  Here every tile (i, j), i >= j, of every system has ONE
+// workgroup for the whole factorisation, left-looking like chol_update_col_kernel: it keeps its C tile in the accumulators and
+// walks the block columns k < j of its update list in the order of the step schedule; for each it waits until the diagonal tile
+// k is factored (flag F[k]) and the tiles (i, k), (j, k) are final (flags T[i][k], T[j][k]), solves for L_ik and L_jk in LDS as
+// chol_col_step_kernel does and applies the update.  A diagonal workgroup then factors its tile, publishes L_jj with its block
+// inverses and raises F[j] (its full inverse for the back-substitution follows, off the chain); any other stores its tile and
+// raises T[i][j].  Same arithmetic per tile in the same order as the other two paths: same bits.
+//   Flags hold the GENERATION of the launch that raised them (a counter kept beside them), so nothing is cleared between
+// launches -- the kernel is replayed from a hipGraph with frozen arguments.  Workgroups take a TICKET when they start and the
+// ticket, not the block index, decides which tile they own: tickets count up through the tiles in column-major order, and a
+// tile only ever waits for tiles of earlier columns, i.e. for workgroups that started before it did -- whatever the number of
+// workgroups the chip holds at a time, the one with the smallest unfinished ticket can always run.  Waits are bounded: if a
+// flag does not come (a device fault elsewhere), the system is marked failed and the workgroup goes on -- never a hang.
+constexpr int CHAIN_SPIN_LIMIT = 1 << 21;
+__device__ __forceinline__ bool chain_wait(const int* flag, int gen)  // (one thread polls; the workgroup's acquire fence follows its barrier)
+{
+  for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// raise a flag behind this workgroup's global stores: every thread makes its own stores visible device-wide first
+__device__ __forceinline__ void chain_post(int* flag, int gen)
+{
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, int* wg, short* klist, int ticket, int gen)
+{
+  const int np = cb.np, nt = np / NB;
+  const int slot = ticket % cb.count;
+  int ord = ticket / cb.count;  // the tile's number in column-major order over the lower triangle
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
+  int tj = 0;
+  while (ord >= nt - tj) { ord -= nt - tj; ++tj; }
+  const int ti = tj + ord;
+  const int n = cb.n[sys];
+  if (ti * NB > n || tj * NB > n) return;  // padding
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  if (tm && !tm[ti * nt + tj]) return;
+  int* F = cb.chain_ctl + 4 + (size_t)slot * (nt + nt * nt);  // F[k]: diagonal tile k factored and published
+  int* T = F + nt;                                            // T[i * nt + k]: tile (i, k) final in A
+  if (threadIdx.x < 64) {  // the update list, as chol_update_col_kernel makes it (schedule order)
+    const int nq = cb.sched ? CHOL_STEP_COLS * cb.n_steps : tj;
+    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * CHOL_STEP_COLS : nullptr;
+    int cnt = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int qq = q0 + (int)threadIdx.x;
+      const int kc = qq < nq ? (sq ? sq[qq] : qq) : -1;
+      const bool in = kc >= 0 && kc < tj;
+      const bool ok = in && (!tm || (tm[ti * nt + (in ? kc : 0)] && tm[tj * nt + (in ? kc : 0)]));
+      const unsigned long long m = __ballot(ok);
+      const int pos = cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (ok && pos < 1024) klist[pos] = (short)kc;
+      cnt += __popcll(m);
+    }
+    if (threadIdx.x == 0) wg[2] = min(cnt, 1024);
+  }
+  __syncthreads();
+  const int Q = wg[2];
+  if (ti != tj && Q == 0) {  // final as assembled
+    if (threadIdx.x == 0) __hip_atomic_store(&T[ti * nt + tj], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  double* A = cb.A + (size_t)sys * np * np;
+  double* Lk = smem;                    // [NB * LD]   L_kk
+  double* As = Lk + NB * LD;            // [NB * LD]   L_ik
+  double* Bs = As + NB * LD;            // [NB * LD]   L_jk (i != j)
+  double* Di = Bs + NB * LD;            // [4 * DB * LDD] inverses of the diagonal blocks of L_kk
+  double (*Dv)[DB * LDD] = reinterpret_cast<double (*)[DB * LDD]>(Di + 4 * DB * LDD);  // scratch of the diagonal factorisation
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  double* C = A + (size_t)(ti * NB + 16 * w) * np + tj * NB;
+  d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
+  const double* Bop = ti == tj ? As : Bs;
+#ifdef PTZ_CHOL_STAMPS
+  long long cs_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  cs_t[0] = wall_clock64();
+#endif
+  for (int q = 0; q < Q; ++q) {
+    const int k = klist[q];
+    if (q > 0) __syncthreads();  // all waves are done with the operand tiles of the previous column
+    if (threadIdx.x == 0) {
+      const bool ok = chain_wait(&T[ti * nt + k], gen) && (ti == tj || chain_wait(&T[tj * nt + k], gen));
+      if (!ok) cb.fail[sys] = 1;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the rows to be solved for are on their way while the workgroup waits for L_kk
+    const d16v rik = trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
+    d16v rjk = rik;
+    if (ti != tj) rjk = trsm_rows_fetch(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np);
+    if (threadIdx.x == 0 && !chain_wait(&F[k], gen)) cb.fail[sys] = 1;
+    CS_STAMP(1);  // (of the last column of the list)
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+    const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+    for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
+    __syncthreads();
+    double* Lik = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
+    trsm_rows_to_lds(rik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
+    if (ti != tj) trsm_rows_to_lds(rjk, np, Lk, Di, Bs + 16 * w * LD, nullptr);
+    CS_STAMP(2);
+    __syncthreads();
+    const double* ap = As + (16 * w + fr) * LD + fq;
+    const double* bp = Bop + fr * LD + fq;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double av = -ap[4 * kk];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * cc) * LD + 4 * kk], acc[cc], 0, 0, 0);
+    }
+    CS_STAMP(3);
+  }
+  if (ti == tj) {
+    __syncthreads();  // all waves are done reading the operand tiles
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    CS_STAMP(4);
+    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (the last tile also inverts itself there)
+    CS_STAMP(5);
+    chain_post(&F[ti], gen);
+#ifdef PTZ_CHOL_STAMPS
+    CS_STAMP(6);
+    if (threadIdx.x == 0 && slot == 0)
+      printf("chol_chain tile %d updates %d | x10 ns since the workgroup started: last flag seen %lld, operands solved +%lld, update +%lld, to LDS +%lld, diagonal factor +%lld, posted +%lld | absolute: seen %lld posted %lld\n",
+             ti, Q, cs_t[1] - cs_t[0], cs_t[2] - cs_t[1], cs_t[3] - cs_t[2], cs_t[4] - cs_t[3], cs_t[5] - cs_t[4], cs_t[6] - cs_t[5], cs_t[1] % 100000000ll, cs_t[6] % 100000000ll);
+#endif
+    if (cb.Linv && ti != nt - 1) tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + ti) * (NB * NB));  // off the chain: for the back-substitution
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+  chain_post(&T[ti * nt + tj], gen);
+}
+
+__global__ __launch_bounds__(256) void chol_chain_kernel(CholBatch cb)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int nt = cb.np / NB;
+  const int total = nt * (nt + 1) / 2 * cb.count;
+  int* wg = reinterpret_cast<int*>(smem + 3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2);  // [ticket, generation, list length, -]
+  short* klist = reinterpret_cast<short*>(wg + 4);                                          // [1024]
+  int* ctl = cb.chain_ctl;
+  if (threadIdx.x == 0) {
+    wg[0] = atomicAdd(&ctl[0], 1);
+    wg[1] = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  }
+  __syncthreads();
+  const int ticket = wg[0], gen = wg[1];
+  chain_tile(cb, smem, wg, klist, ticket, gen);
+  // the last workgroup to finish closes the launch: tickets start at zero again, the generation moves on (nobody reads
+  // either any more: every workgroup has taken its ticket and read the generation before it counted itself done)
+  if (threadIdx.x == 0) {
+    const int d = atomicAdd(&ctl[1], 1);
+    if (d == total - 1) {
+      __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl[2], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- left-looking column update: A_ij -= sum_{k < j} L_ik L_jk^T for the tiles (i, j), i >= j, of block column j -------
@@ -893,7 +1088,6 @@ __global__ __launch_bounds__(256, 3) void chol_update_col_h_kernel(CholBatch cb,
   const int Q = kcount;
   auto col_of = [&](int q) { return (int)klist[q]; };
   auto next_q = [&](int q) { return q; };
-  constexpr int NP = (NB * NB / 2) / 256;  // double2 pieces of one tile per thread
   int q = 0;
   const bool any = q < Q;
   int k = any ? col_of(q) : 0;
@@ -1176,6 +1370,34 @@ void chol_col_step_launch(const CholBatch& cb, int step, hipStream_t stream)
   const int m = nt - kmin - 1;
   if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? (cb.sched ? CHOL_STEP_COLS : 1) : 0), cb.count), dim3(256), smem, stream, cb, step, kmin);
 }
+bool chol_chain_enabled(const CholBatch& cb)
+{
+  // PTZ_BA_CHOL_CHAIN=0 brings the one-launch-per-step path back (A/B measurements)
+  const char* e = getenv("PTZ_BA_CHOL_CHAIN");
+  const bool on = !e || atoi(e) != 0;
+  // Up to CHAIN_MAX systems: every tile's workgroup must be on the chip from the start (135 KB of LDS: one per compute unit, 91
+  // tiles per 800 x 800 system) -- a tile that starts late applies its whole update list in one go at the end of the chain
+  // (measured: 8 systems 11.6 ms against 10.2 ms with one launch per step; 1 and 2 systems 7.7 / 8.0 against 8.0 / 8.3)
+  int max_count = 2;
+  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) max_count = std::max(1, std::min(8, atoi(m)));
+  return on && cb.L && cb.Linv && cb.chain_ctl && cb.count <= max_count && cb.np / NB <= 1024;
+}
+void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
+{
+  const int nt = cb.np / NB;
+  const size_t smem = sizeof(double) * (3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2) + sizeof(int) * 4 + sizeof(short) * 1024;
+  {  // > 64 KiB of dynamic LDS: the cap is raised once per device
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  launch(chol_chain_kernel, dim3(nt * (nt + 1) / 2 * cb.count), dim3(256), smem, stream, cb);
+}
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
   launch(chol_diag_kernel, dim3(k < 0 && cb.sched ? CHOL_STEP_COLS : 1, cb.count), dim3(256), 0, stream, cb, k);
@@ -1210,9 +1432,12 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 void chol_factor_solve(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
-  if (cb.L) {  // a few systems: one launch per step of the schedule
-    chol_diag_launch(cb, -1, stream);
-    for (int st = 0; st + 1 < chol_step_count(cb); ++st) chol_col_step_launch(cb, st, stream);  // (the last step's column has nothing behind it)
+  if (cb.L) {  // a few systems: one launch for the whole factorisation, or one per step of the schedule
+    if (chol_chain_enabled(cb)) chol_chain_launch(cb, stream);
+    else {
+      chol_diag_launch(cb, -1, stream);
+      for (int st = 0; st + 1 < chol_step_count(cb); ++st) chol_col_step_launch(cb, st, stream);  // (the last step's column has nothing behind it)
+    }
     chol_backsolve_launch(cb, x, stream);
     return;
   }
@@ -1367,10 +1592,14 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   PTZ_HIP_TRY(hipMalloc(&dfail, sizeof(int) * count));
   cb.A = dA; cb.Ldiag = dL; cb.Dinv = dD; cb.n = dn; cb.fail = dfail;
   double *dL2 = nullptr, *dLi = nullptr;
+  int* dctl = nullptr;
   if (count < 8 && !getenv("PTZ_CHOL_MULTI_LAUNCH")) {  // the path a few bundle-adjustment scenes take
     PTZ_HIP_TRY(hipMalloc(&dL2, sizeof(double) * (size_t)count * np * np));
     PTZ_HIP_TRY(hipMemset(dL2, 0, sizeof(double) * (size_t)count * np * np));
     cb.L = dL2;
+    PTZ_HIP_TRY(hipMalloc(&dctl, sizeof(int) * chol_chain_ctl_ints(np)));
+    PTZ_HIP_TRY(hipMemset(dctl, 0, sizeof(int) * chol_chain_ctl_ints(np)));
+    cb.chain_ctl = dctl;
   }
   PTZ_HIP_TRY(hipMalloc(&dLi, sizeof(double) * (size_t)count * nt * CHOL_NB * CHOL_NB));
   cb.Linv = dLi;
@@ -1406,5 +1635,6 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
   if (dL2) (void)hipFree(dL2);
   if (dLi) (void)hipFree(dLi);
+  if (dctl) (void)hipFree(dctl);
   return PTZ_OK;
 }

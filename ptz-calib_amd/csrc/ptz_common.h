@@ -235,7 +235,14 @@ struct CholBatch {
   const int* sched = nullptr;
   int n_steps = 0;
   const int* sched_kmin = nullptr;  // HOST memory [n_steps]: smallest block column any system factors in step s (sizes the launch)
+  // device [chol_chain_ctl_ints(np)] or nullptr: tickets, generation and per-slot tile flags of chol_chain_kernel -- the
+  // factorisation of a few systems as ONE launch whose workgroups hand their tiles on through flags (zeroed once at creation;
+  // one block per stream that factors)
+  int* chain_ctl = nullptr;
 };
+// ints behind CholBatch::chain_ctl: [0] next ticket, [1] workgroups done, [2] generation of the last finished launch, then for
+// each of up to 8 slots nt "diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
+inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + 8 * (nt + nt * nt); }
 __device__ __forceinline__ int chol_system_of(const CholBatch& cb, int slot)
 {
   if (!cb.act) return slot;
@@ -249,7 +256,9 @@ void chol_panel_launch(const CholBatch& cb, int k, hipStream_t stream, bool diag
 void chol_syrk_launch(const CholBatch& cb, int k, hipStream_t stream, int mode, bool fuse_diag = false);  // mode 0 all, 1 column k+1, 2 rest; fuse_diag: also factor tile (k+1, k+1)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream);
 void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream);  // Linv of every diagonal tile (multi-launch paths, before the back-substitution)
-void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);       // factor the diagonal tile of block column k (k < 0: of the columns of step 0)
+void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream);
+bool chol_chain_enabled(const CholBatch& cb);                               // the one-launch factorisation applies to this batch
+void chol_chain_launch(const CholBatch& cb, hipStream_t stream);            // diagonal tiles, steps and tile inverses of a few systems in ONE launch       // factor the diagonal tile of block column k (k < 0: of the columns of step 0)
 inline int chol_step_count(const CholBatch& cb) { return cb.sched ? cb.n_steps : cb.np / CHOL_NB; }
 void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream);   // few systems: trsm + trailing update + next diagonal tile, one launch
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)

@@ -370,6 +370,35 @@ def test_ba_large_batch_matches_single_across_cholesky_variants(pkg):
         assert s1 == summ[i] and np.array_equal(cam1, cams[i]) and np.array_equal(ray1, rays[i])
 
 
+def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, monkeypatch):
+    """One or two rigs factor their reduced systems in ONE launch whose workgroups hand tiles on through flags
+    (chol_chain_kernel); PTZ_BA_CHOL_CHAIN=0 brings back one launch per step of the schedule, and three rigs get that path
+    anyway.  Same arithmetic per tile in the same order: the same bits, solve after solve (the flags carry a generation, nothing
+    is cleared between launches), for systems of one and of several block columns."""
+    scenes = [pkg.synth.make_scene(31, 100, 160), pkg.synth.make_scene(32, 70, 200), pkg.synth.make_scene(33, 12, 60)]
+    def run(group):
+        b = pkg.api.BaBatch(group); b.set_state()
+        out = []
+        for _ in range(3):  # repeated solves of one batch: generations 1, 2, 3 of the flags (and a replayed graph)
+            summ = b.solve(); cams, rays = b.get_state(); out.append((summ, cams, rays))
+        b.close()
+        for summ, cams, rays in out[1:]:
+            assert summ == out[0][0] and all(np.array_equal(a, c) for a, c in zip(cams, out[0][1]))
+        return out[0]
+    for group in ([scenes[0]], [scenes[1], scenes[2]], [scenes[2]]):
+        monkeypatch.delenv("PTZ_BA_CHOL_CHAIN", raising=False)
+        s1, c1, r1 = run(group)
+        monkeypatch.setenv("PTZ_BA_CHOL_CHAIN", "0")
+        s0, c0, r0 = run(group)
+        assert s0 == s1
+        assert all(np.array_equal(a, c) for a, c in zip(c0, c1)) and all(np.array_equal(a, c) for a, c in zip(r0, r1))
+    monkeypatch.delenv("PTZ_BA_CHOL_CHAIN", raising=False)
+    # a rig solved inside a batch of three (per-step launches) and alone (one launch)
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    cam1, ray1, s1 = pkg.api.ba_solve(scenes[0])
+    assert s1 == summ[0] and np.array_equal(cam1, cams[0]) and np.array_equal(ray1, rays[0])
+
+
 def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, monkeypatch):
     """Resources are recycled between solves (ptz_pool.h); no result may depend on what an earlier solve left in them.
     PTZ_POOL_FILL=255 hands out blocks filled with NaN bit patterns: a kernel that reads memory nobody initialised would

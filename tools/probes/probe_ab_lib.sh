@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; cd $R
 for l in prev product prev product; do
   if [ $l = product ]; then unset PTZCALIB_LIB; else export PTZCALIB_LIB=$R/tools/probes/hip/lib_$l.so; fi
-  echo "== $l"; timeout 300 python tools/probes/probe_timing.py 256 2>&1 | grep '^{' | python3 -c "
+  echo "== $l"; timeout 300 python tools/probes/probe_timing.py ${SIZES:-256} 2>&1 | grep '^{' | python3 -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); print(d['dev_ms'], d['it_per_s'], d['profile_ms'])"
