@@ -1170,38 +1170,50 @@ __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
 // the next TWO groups are always in flight while a group is reduced: the kernel streams L at the rate one compute unit
 // can pull, instead of paying a cold-miss latency per dependent step.  One workgroup per system: the steps depend on each
 // other, and a hand-off between workgroups costs more than a step.
-constexpr int BI_THREADS = 1024;
+constexpr int BI_THREADS = 512;   // thread = (slot, quarter of the rows, PAIR of columns)
+constexpr int BI_RED = 1024;      // partial sums of a group: [slot][quarter][column]
 struct BsItem { long long off; int ld, in_off, out_off, kind; };  // kind: 0 empty slot, 1 x = M^T t (diagonal inverse), 2 t -= M^T x
 
-__device__ __forceinline__ void bs_load(const BsItem it, const double* Lm, const double* Li, int q, int c, double (&v)[16])
+// Two columns per thread with 16-byte loads: the kernel is bound by instruction issue (one compute unit streams the whole factor),
+// and a thread per column spent ~185 instructions per 16 multiply-adds.  Every (quarter, column) partial sum is the expression it
+// always was, so the bits are unchanged.
+__device__ __forceinline__ void bs_load(const BsItem it, const double* Lm, const double* Li, int q, int c2, double2 (&v)[16])
 {
   if (it.kind == 0) return;
-  const double* col = (it.kind == 1 ? Li : Lm) + it.off + (size_t)(16 * q) * it.ld + c;
+  const double* col = (it.kind == 1 ? Li : Lm) + it.off + (size_t)(16 * q) * it.ld + c2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = col[(size_t)r * it.ld];
+  for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const double2*>(col + (size_t)r * it.ld);
 }
-__device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red, int n, int q, int c, const double (&v)[16])
+__device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red, int n, int sl, int q, int c2, const double2 (&v)[16])
 {
-  double p = 0;
+  double pa = 0, pb = 0;
   if (it.kind != 0) {
     const double* xin = t + it.in_off + 16 * q;
-    double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
 #pragma unroll
     for (int r = 0; r < 16; r += 4) {
-      p0 += v[r] * xin[r];
-      p1 += v[r + 1] * xin[r + 1];
-      p2 += v[r + 2] * xin[r + 2];
-      p3 += v[r + 3] * xin[r + 3];
+      a0 += v[r].x * xin[r];
+      a1 += v[r + 1].x * xin[r + 1];
+      a2 += v[r + 2].x * xin[r + 2];
+      a3 += v[r + 3].x * xin[r + 3];
+      b0 += v[r].y * xin[r];
+      b1 += v[r + 1].y * xin[r + 1];
+      b2 += v[r + 2].y * xin[r + 2];
+      b3 += v[r + 3].y * xin[r + 3];
     }
-    p = (p0 + p1) + (p2 + p3);
+    pa = (a0 + a1) + (a2 + a3);
+    pb = (b0 + b1) + (b2 + b3);
   }
-  const int tid = threadIdx.x;
-  red[tid] = p;
+  double* rs = red + sl * 256;
+  *reinterpret_cast<double2*>(rs + q * 64 + c2) = make_double2(pa, pb);
   __syncthreads();
   if (q == 0 && it.kind != 0) {
-    const double sum = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
-    if (it.kind == 1) t[it.out_off + c] = (it.out_off + c < n) ? sum : 0.0;
-    else t[it.out_off + c] -= sum;
+    const double2 s0 = *reinterpret_cast<const double2*>(rs + c2), s1 = *reinterpret_cast<const double2*>(rs + 64 + c2),
+                  s2 = *reinterpret_cast<const double2*>(rs + 128 + c2), s3 = *reinterpret_cast<const double2*>(rs + 192 + c2);
+    const double suma = (s0.x + s1.x) + (s2.x + s3.x), sumb = (s0.y + s1.y) + (s2.y + s3.y);
+    double* out = t + it.out_off + c2;
+    if (it.kind == 1) { out[0] = (it.out_off + c2 < n) ? suma : 0.0; out[1] = (it.out_off + c2 + 1 < n) ? sumb : 0.0; }
+    else { out[0] -= suma; out[1] -= sumb; }
   }
   __syncthreads();
 }
@@ -1220,11 +1232,11 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* t = smem;          // [np] y, overwritten by x
-  double* red = t + np;      // [BI_THREADS]
-  BsItem* items = reinterpret_cast<BsItem*>(red + BI_THREADS);  // LIST: [max_groups][4]
+  double* red = t + np;      // [BI_RED]
+  BsItem* items = reinterpret_cast<BsItem*>(red + BI_RED);  // LIST: [max_groups][4]
   __shared__ int n_groups;
   const int tid = threadIdx.x;
-  const int c = tid & 63, q = (tid >> 6) & 3, sl = tid >> 8;
+  const int c = (tid & 31) * 2, q = (tid >> 5) & 3, sl = tid >> 7;  // c: the first of this thread's two columns
   if (LIST && tid < 64) {  // the work list, in execution order; made by wave 0, 64 candidate tiles at a time (ballot compaction)
     // Backward over the steps of the factorisation.  The block columns of one step (the two arcs of a dissected system) do not
     // couple, so their diagonal inverses share a group and their rows' tiles fill groups together: the chain of dependent
@@ -1274,28 +1286,28 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   __syncthreads();
   if (LIST) {
     const int G = n_groups;
-    double r0[16], r1[16], r2[16];
+    double2 r0[16], r1[16], r2[16];
     if (0 < G) bs_load(items[sl], Lm, Li, q, c, r0);
     if (1 < G) bs_load(items[4 + sl], Lm, Li, q, c, r1);
     for (int g = 0; g < G; g += 3) {
       if (g + 2 < G) bs_load(items[4 * (g + 2) + sl], Lm, Li, q, c, r2);
-      bs_apply(items[4 * g + sl], t, red, n, q, c, r0);
+      bs_apply(items[4 * g + sl], t, red, n, sl, q, c, r0);
       if (g + 1 >= G) break;
       if (g + 3 < G) bs_load(items[4 * (g + 3) + sl], Lm, Li, q, c, r0);
-      bs_apply(items[4 * (g + 1) + sl], t, red, n, q, c, r1);
+      bs_apply(items[4 * (g + 1) + sl], t, red, n, sl, q, c, r1);
       if (g + 2 >= G) break;
       if (g + 4 < G) bs_load(items[4 * (g + 4) + sl], Lm, Li, q, c, r1);
-      bs_apply(items[4 * (g + 2) + sl], t, red, n, q, c, r2);
+      bs_apply(items[4 * (g + 2) + sl], t, red, n, sl, q, c, r2);
     }
   }
   else {
-    double r0[16];
+    double2 r0[16];
     for (int k = nt - 1; k >= 0; --k) {
       const int c0 = k * NB;
       if (c0 >= n) continue;
       BsItem it = BsItem{(long long)k * (NB * NB), NB, c0, c0, sl == 0 ? 1 : 0};
       bs_load(it, Lm, Li, q, c, r0);
-      bs_apply(it, t, red, n, q, c, r0);
+      bs_apply(it, t, red, n, sl, q, c, r0);
       for (int tj = 0; tj < k;) {  // tiles (k, tj) of the structure, four at a time, in the order the list would hold them
         int mine = -1, ns = 0;
         while (tj < k && ns < 4) {
@@ -1305,7 +1317,7 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
         if (ns == 0) break;
         it = BsItem{(long long)c0 * np + (long long)(mine < 0 ? 0 : mine) * NB, np, c0, (mine < 0 ? 0 : mine) * NB, mine >= 0 ? 2 : 0};
         bs_load(it, Lm, Li, q, c, r0);
-        bs_apply(it, t, red, n, q, c, r0);
+        bs_apply(it, t, red, n, sl, q, c, r0);
       }
     }
   }
@@ -1411,7 +1423,7 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
   const int nt = cb.np / NB;
   int max_groups = nt;  // one group per diagonal inverse + the tiles of row k four at a time
   for (int k = 0; k < nt; ++k) max_groups += (k + 3) / 4;
-  const size_t base = sizeof(double) * ((size_t)cb.np + BI_THREADS);
+  const size_t base = sizeof(double) * ((size_t)cb.np + BI_RED);
   const size_t list = sizeof(BsItem) * 4 * (size_t)max_groups;
   const bool use_list = base + list <= 150 * 1024;
   {  // large systems: the dynamic LDS goes beyond 64 KiB
