@@ -448,6 +448,7 @@ static void make_groups(ptz_ba_batch* b)
     d.use_act = 0;
     if (d.chol.L) d.chol.L = b->d.chol.L + (size_t)g * std::min(b->n_scene, 8) * np * np;  // up to eight slots of finished L tiles per group
     if (d.chol.chain_ctl) d.chol.chain_ctl = b->d.chol.chain_ctl + (size_t)g * chol_chain_ctl_ints((int)np);  // (a block per stream)
+    if (d.chol.bs_items) { d.chol.bs_items += (size_t)lo * 4 * chol_backsolve_max_groups((int)np); d.chol.bs_groups += lo; }
     b->dg.push_back(d);
   }
   if ((int)b->pass_graph.size() != G || (G > 0 && b->pass_graph[0].size() != b->shapes.size())) {  // the grouping changed (profiling on / off): recorded passes are stale
@@ -1703,6 +1704,22 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       d.chol.sched = dp;
       d.chol.n_steps = max_steps;
       d.chol.sched_kmin = b->sched_kmin.data();
+    }
+    {  // the back-substitution's work list, per scene (the kernel would otherwise make it itself, every launch: ~6 us of one wave)
+      const int mg = chol_backsolve_max_groups(d.chol.np);
+      if (sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
+        std::vector<BsItem> h_items((size_t)n * 4 * mg);
+        std::vector<int> h_groups(n);
+        for (int i = 0; i < n; ++i)
+          h_groups[i] = chol_backsolve_plan(d.chol.np, b->scenes[i].n, hm.data() + (size_t)i * nt * nt,
+                                            any_plan ? h_sched.data() + (size_t)i * nt * CHOL_STEP_COLS : nullptr, max_steps, h_items.data() + (size_t)i * 4 * mg);
+        const BsItem* di = nullptr;
+        const int* dgp = nullptr;
+        TRY(upload(b, h_items, &di));
+        TRY(upload(b, h_groups, &dgp));
+        d.chol.bs_items = di;
+        d.chol.bs_groups = dgp;
+      }
     }
     // tiles outside the structure are never written again: zero everything once (the block may be a recycled one)
     if (hipMemsetAsync(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }

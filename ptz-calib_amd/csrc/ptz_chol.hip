@@ -1172,7 +1172,6 @@ __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
 // other, and a hand-off between workgroups costs more than a step.
 constexpr int BI_THREADS = 512;   // thread = (slot, quarter of the rows, PAIR of columns)
 constexpr int BI_RED = 1024;      // partial sums of a group: [slot][quarter][column]
-struct BsItem { long long off; int ld, in_off, out_off, kind; };  // kind: 0 empty slot, 1 x = M^T t (diagonal inverse), 2 t -= M^T x
 
 // Two columns per thread with 16-byte loads: the kernel is bound by instruction issue (one compute unit streams the whole factor),
 // and a thread per column spent ~185 instructions per 16 multiply-adds.  Every (quarter, column) partial sum is the expression it
@@ -1237,7 +1236,15 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   __shared__ int n_groups;
   const int tid = threadIdx.x;
   const int c = (tid & 31) * 2, q = (tid >> 5) & 3, sl = tid >> 7;  // c: the first of this thread's two columns
-  if (LIST && tid < 64) {  // the work list, in execution order; made by wave 0, 64 candidate tiles at a time (ballot compaction)
+  if (LIST && cb.bs_items) {  // the list was made with the structure (chol_backsolve_plan): one coalesced copy instead of wave 0's walk
+    const int G = cb.bs_groups[sys];
+    const long long* src = reinterpret_cast<const long long*>(cb.bs_items + (size_t)sys * 4 * max_groups);
+    long long* dst = reinterpret_cast<long long*>(items);
+    static_assert(sizeof(BsItem) == 24, "three 8-byte words per item");
+    for (int i = tid; i < 12 * G; i += BI_THREADS) dst[i] = src[i];
+    if (tid == 0) n_groups = G;
+  }
+  else if (LIST && tid < 64) {  // the work list, in execution order; made by wave 0, 64 candidate tiles at a time (ballot compaction)
     // Backward over the steps of the factorisation.  The block columns of one step (the two arcs of a dissected system) do not
     // couple, so their diagonal inverses share a group and their rows' tiles fill groups together: the chain of dependent
     // groups is as long as the step schedule, not as the number of block columns.
@@ -1421,8 +1428,8 @@ void chol_tile_inverse_launch(const CholBatch& cb, hipStream_t stream)
 void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
 {
   const int nt = cb.np / NB;
-  int max_groups = nt;  // one group per diagonal inverse + the tiles of row k four at a time
-  for (int k = 0; k < nt; ++k) max_groups += (k + 3) / 4;
+  const int max_groups = chol_backsolve_max_groups(cb.np);
+  (void)nt;
   const size_t base = sizeof(double) * ((size_t)cb.np + BI_RED);
   const size_t list = sizeof(BsItem) * 4 * (size_t)max_groups;
   const bool use_list = base + list <= 150 * 1024;

@@ -239,7 +239,58 @@ struct CholBatch {
   // factorisation of a few systems as ONE launch whose workgroups hand their tiles on through flags (zeroed once at creation;
   // one block per stream that factors)
   int* chain_ctl = nullptr;
+  // device [count][4 * chol_backsolve_max_groups(np)] work items of the back-substitution in execution order and [count] their
+  // group counts (chol_backsolve_plan, made on the host with the structure), or nullptr: the kernel makes the list itself
+  const struct BsItem* bs_items = nullptr;
+  const int* bs_groups = nullptr;
 };
+// one 64 x 64 tile product of the back-substitution: kind 0 empty slot, 1 x = M^T t (inverse of a diagonal tile), 2 t -= M^T x
+struct BsItem { long long off; int ld, in_off, out_off, kind; };
+inline int chol_backsolve_max_groups(int np)
+{
+  const int nt = np / CHOL_NB;
+  int g = nt;  // one group per diagonal inverse + the tiles of row k four at a time
+  for (int k = 0; k < nt; ++k) g += (k + 3) / 4;
+  return g;
+}
+// The list chol_backsolve_kernel would make for itself (same items, same order), made once on the host: backward over the steps of
+// the factorisation, the diagonal inverses of a step in one group, the tiles of its rows four to a group.  Returns the groups.
+inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int* sched, int n_steps_sched, BsItem* items)
+{
+  const int nt = np / CHOL_NB, NB = CHOL_NB;
+  const int n_steps = sched ? n_steps_sched : nt;
+  int g = 0;
+  for (int st = n_steps - 1; st >= 0; --st) {
+    int col[CHOL_STEP_COLS];
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) col[c] = -1;
+    if (st < nt) {
+      if (!sched) col[0] = st;
+      else for (int c = 0; c < CHOL_STEP_COLS; ++c) col[c] = sched[st * CHOL_STEP_COLS + c];
+    }
+    bool any_col = false;
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) {
+      if (col[c] >= 0 && col[c] * NB >= n) col[c] = -1;
+      any_col |= col[c] >= 0;
+    }
+    if (!any_col) continue;
+    for (int c = 0; c < 4; ++c) {
+      const int kd = c < CHOL_STEP_COLS ? col[c] : -1;
+      items[4 * g + c] = kd >= 0 ? BsItem{(long long)kd * (NB * NB), NB, kd * NB, kd * NB, 1} : BsItem{0, 0, 0, 0, 0};
+    }
+    ++g;
+    int filled = 0;
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) {
+      const int k = col[c];
+      if (k < 0) continue;
+      for (int tj = 0; tj < k; ++tj)
+        if (!tm || tm[k * nt + tj]) items[4 * g + filled++] = BsItem{(long long)(k * NB) * np + (long long)tj * NB, np, k * NB, tj * NB, 2};
+    }
+    const int padded = (filled + 3) & ~3;
+    for (int i = filled; i < padded; ++i) items[4 * g + i] = BsItem{0, 0, 0, 0, 0};
+    g += padded / 4;
+  }
+  return g;
+}
 // ints behind CholBatch::chain_ctl: [0] next ticket, [1] workgroups done, [2] generation of the last finished launch, then for
 // each of up to 8 slots nt "diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
 inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + 8 * (nt + nt * nt); }
