@@ -750,7 +750,9 @@ __device__ __forceinline__ void chain_post(int* flag, int gen)
 {
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // (relaxed: thread 0's own fence above already stands between the workgroup's stores and this one -- a release store would
+  //  write the L2 back a second time, ~0.5 us on the chain)
+  if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, int* wg, short* klist, int ticket, int gen)
