@@ -1707,7 +1707,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     }
     {  // the back-substitution's work list, per scene (the kernel would otherwise make it itself, every launch: ~6 us of one wave)
       const int mg = chol_backsolve_max_groups(d.chol.np);
-      if (sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
+      const char* e = getenv("PTZ_BA_BACKSOLVE_HOST_LIST");  // 0: the kernel makes the list itself (tests: the same list, the same bits)
+      if ((!e || atoi(e) != 0) && sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
         std::vector<BsItem> h_items((size_t)n * 4 * mg);
         std::vector<int> h_groups(n);
         for (int i = 0; i < n; ++i)

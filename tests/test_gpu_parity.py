@@ -393,6 +393,12 @@ def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, 
         assert s0 == s1
         assert all(np.array_equal(a, c) for a, c in zip(c0, c1)) and all(np.array_equal(a, c) for a, c in zip(r0, r1))
     monkeypatch.delenv("PTZ_BA_CHOL_CHAIN", raising=False)
+    # the back-substitution's work list made on the host (default) and by the kernel's first wave: the same list
+    s1, c1, r1 = run([scenes[0], scenes[2]])
+    monkeypatch.setenv("PTZ_BA_BACKSOLVE_HOST_LIST", "0")
+    s2, c2, r2 = run([scenes[0], scenes[2]])
+    monkeypatch.delenv("PTZ_BA_BACKSOLVE_HOST_LIST", raising=False)
+    assert s2 == s1 and all(np.array_equal(a, c) for a, c in zip(c2, c1)) and all(np.array_equal(a, c) for a, c in zip(r2, r1))
     # a rig solved inside a batch of three (per-step launches) and alone (one launch)
     b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
     cam1, ray1, s1 = pkg.api.ba_solve(scenes[0])
