@@ -1357,6 +1357,21 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * schur_threads<TYPE>())];
 #pragma unroll
   for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
+  // (the loads of the diagonal block's inputs, below, are issued HERE, behind the gathers: issued in front of phase 2 they made the
+  //  last wave enter it one memory round trip after the others -- per-wave time stamps)
+  constexpr int DIAG_NE = NC * (NC + 1) / 2;
+  const int dt = (int)threadIdx.x - (THREADS - 64);
+  int dp = 0, dq = 0;
+  double dv = 0, dDc = 0;
+  if (dt >= 0 && dt < DIAG_NE) {
+    dp = (int)((sqrtf(8.0f * dt + 1.0f) - 1.0f) * 0.5f);
+    while ((dp + 1) * (dp + 2) / 2 <= dt) ++dp;
+    while (dp * (dp + 1) / 2 > dt) --dp;
+    dq = dt - dp * (dp + 1) / 2;
+    dv = d.U[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
+    if (dp == dq) dDc = d.diag_c[(size_t)(s.cam_off + ci) * NC + dp];
+  }
+  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = d.gc[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
   const int* cpair = d.cam_pair + s.cam_off + s.idx;
   const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   constexpr int PS = (NW * NW) | 1;  // doubles per run sum in LDS (odd pitch)
@@ -1528,23 +1543,10 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
   // Diagonal block and right-hand side, one element per thread of the LAST wave: S_ii = U_i (2D-2D + annotation terms) + D_i^2
-  // - sum T W^T (the latter only on the NW x NW 2D-2D columns), b_i = g_i - sum W z.  Only the LOADS happen here; the element is
-  // finished behind phase 2 (schur_diag_finish below), while the other waves reduce their run sums: done in front of phase 2 it
-  // made the last wave start its runs ~2 us late (dependent global loads), and every other wave then waited that long at the
-  // barrier behind the runs.
-  constexpr int DIAG_NE = NC * (NC + 1) / 2;
-  const int dt = (int)threadIdx.x - (THREADS - 64);
-  int dp = 0, dq = 0;
-  double dv = 0, dDc = 0;
-  if (dt >= 0 && dt < DIAG_NE) {
-    dp = (int)((sqrtf(8.0f * dt + 1.0f) - 1.0f) * 0.5f);
-    while ((dp + 1) * (dp + 2) / 2 <= dt) ++dp;
-    while (dp * (dp + 1) / 2 > dt) --dp;
-    dq = dt - dp * (dp + 1) / 2;
-    dv = d.U[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
-    if (dp == dq) dDc = d.diag_c[(size_t)(s.cam_off + ci) * NC + dp];
-  }
-  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = d.gc[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
+  // - sum T W^T (the latter only on the NW x NW 2D-2D columns), b_i = g_i - sum W z.  Its inputs were asked for at the top of the
+  // kernel; the element is finished behind phase 2 (schur_diag_finish), while the other waves reduce their run sums.  (Assembled
+  // in front of phase 2 it made the last wave start its runs ~2 us late, and every other wave then waited that long at the
+  // barrier behind the runs; with only the loads ISSUED there the last wave was still 1.1-2.2 us late.)
   auto schur_diag_finish = [&]() {  // every thread adds up its own element's wave partials, in wave order
     constexpr int NV = NW + NU;
     auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };  // NC slot -> 2D-2D column
