@@ -403,6 +403,32 @@ def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, 
     b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
     cam1, ray1, s1 = pkg.api.ba_solve(scenes[0])
     assert s1 == summ[0] and np.array_equal(cam1, cams[0]) and np.array_equal(ray1, rays[0])
+    # several of these launches on the chip at once (host threads with one- and two-rig batches of several block columns): tickets,
+    # generations and flags are per batch and stream, every result has the bits of the serial solve
+    import threading
+    ref = [pkg.api.ba_solve(sc) for sc in scenes[:2]]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(5):
+                group = [scenes[(t + rep) % 2]] if (t + rep) % 3 else [scenes[0], scenes[1]]
+                idx = [(t + rep) % 2] if (t + rep) % 3 else [0, 1]
+                bb = pkg.api.BaBatch(group); bb.set_state()
+                for _ in range(2):
+                    sm = bb.solve(); cm, rm = bb.get_state()
+                    for k, i in enumerate(idx):
+                        assert sm[k] == ref[i][2] and np.array_equal(cm[k], ref[i][0]) and np.array_equal(rm[k], ref[i][1])
+                bb.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
 
 
 def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, monkeypatch):
