@@ -1,7 +1,7 @@
 // Probe (not part of the product): cycles of the diagonal-tile factorisation alone, one workgroup, tile resident in LDS.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tests/probes/diag_probe tests/probes/diag_probe.hip
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/probes/hip/diag_probe tools/probes/hip/diag_probe.hip
 // (phase stamps were used with an earlier single-wave version)
-#include "../../ptz-calib_amd/csrc/ptz_chol.hip"
+#include "../../../ptz-calib_amd/csrc/ptz_chol.hip"
 #include <vector>
 #include <cmath>
 namespace ptz {
