@@ -1396,12 +1396,16 @@ bool chol_chain_enabled(const CholBatch& cb)
   // PTZ_BA_CHOL_CHAIN=0 brings the one-launch-per-step path back (A/B measurements)
   const char* e = getenv("PTZ_BA_CHOL_CHAIN");
   const bool on = !e || atoi(e) != 0;
-  // Up to CHAIN_MAX systems: every tile's workgroup must be on the chip from the start (135 KB of LDS: one per compute unit, 91
-  // tiles per 800 x 800 system) -- a tile that starts late applies its whole update list in one go at the end of the chain
-  // (measured: 8 systems 11.6 ms against 10.2 ms with one launch per step; 1 and 2 systems 7.7 / 8.0 against 8.0 / 8.3)
-  int max_count = 2;
-  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) max_count = std::max(1, std::min(8, atoi(m)));
-  return on && cb.L && cb.Linv && cb.chain_ctl && cb.count <= max_count && cb.np / NB <= 1024;
+  // Every tile's workgroup must be on the chip from the start (135 KB of LDS: one per compute unit, 91 tiles per 800 x 800
+  // system) -- a tile that starts late applies its whole update list in one go at the end of the chain (measured, 800 x 800:
+  // 8 systems 11.6 ms against 10.2 ms with one launch per step, 3 systems 8.66 / 8.55; 1 and 2 systems 7.7 / 8.0 against 8.0 / 8.3;
+  // 3-4 rigs of 80-110 views 1-2 % faster with it, 6 of 60 views even: tools/probes/probe_chain_small.py)
+  // -- i.e. as many systems as have all their tiles on the chip at once: two 800 x 800 systems, up to eight small ones (the growing
+  // rigs of the incremental pipeline)
+  const int nt = cb.np / NB;
+  bool fits = cb.count <= 2 || (cb.count <= 8 && cb.count * (nt * (nt + 1) / 2) <= 192);
+  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) fits = cb.count <= std::max(1, std::min(8, atoi(m)));
+  return on && cb.L && cb.Linv && cb.chain_ctl && fits && nt <= 1024;
 }
 void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
 {
