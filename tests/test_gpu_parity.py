@@ -371,10 +371,10 @@ def test_ba_large_batch_matches_single_across_cholesky_variants(pkg):
 
 
 def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, monkeypatch):
-    """One or two rigs factor their reduced systems in ONE launch whose workgroups hand tiles on through flags
-    (chol_chain_kernel); PTZ_BA_CHOL_CHAIN=0 brings back one launch per step of the schedule, and three rigs get that path
-    anyway.  Same arithmetic per tile in the same order: the same bits, solve after solve (the flags carry a generation, nothing
-    is cleared between launches), for systems of one and of several block columns."""
+    """A few rigs factor their reduced systems in ONE launch whose workgroups hand tiles on through flags
+    (chol_chain_kernel, while all tiles of the launch fit on the chip at once); PTZ_BA_CHOL_CHAIN=0 brings back one launch per
+    step of the schedule.  Same arithmetic per tile in the same order: the same bits, solve after solve (the flags carry a
+    generation, nothing is cleared between launches), for systems of one and of several block columns."""
     scenes = [pkg.synth.make_scene(31, 100, 160), pkg.synth.make_scene(32, 70, 200), pkg.synth.make_scene(33, 12, 60)]
     def run(group):
         b = pkg.api.BaBatch(group); b.set_state()
@@ -399,7 +399,7 @@ def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, 
     s2, c2, r2 = run([scenes[0], scenes[2]])
     monkeypatch.delenv("PTZ_BA_BACKSOLVE_HOST_LIST", raising=False)
     assert s2 == s1 and all(np.array_equal(a, c) for a, c in zip(c2, c1)) and all(np.array_equal(a, c) for a, c in zip(r2, r1))
-    # a rig solved inside a batch of three (per-step launches) and alone (one launch)
+    # a rig solved inside a batch of three and alone
     b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
     cam1, ray1, s1 = pkg.api.ba_solve(scenes[0])
     assert s1 == summ[0] and np.array_equal(cam1, cams[0]) and np.array_equal(ray1, rays[0])
