@@ -700,10 +700,17 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   b->last_ms = ms;
   b->prof_collect();
   if (dbg) fprintf(stderr, "[ptz_ba] groups %d: total %.2f ms, enqueue %.2f ms, sync-wait %.2f ms, device %.2f ms\n", G, now() - t_start, t_enq, t_sync, ms);
-  if (out) {
+  {
     std::vector<LmState> h(B);
     PTZ_HIP_TRY(copy_on(b->stream, h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
-    for (int i = 0; i < B; ++i) {
+    int timeouts = 0;
+    for (int i = 0; i < B; ++i) timeouts += h[i].chain_timeouts;
+    if (timeouts) {  // never a silently different trajectory: a hand-over that did not arrive is a device problem, not a rejected step
+      fprintf(stderr, "[ptz_ba] %d linear solve(s) of this batch lost a tile hand-over of the one-launch factorisation (bounded wait ran out); "
+                      "the solve is reported as failed\n", timeouts);
+      return PTZ_ENODEVICE;
+    }
+    for (int i = 0; out && i < B; ++i) {
       ptz_lm_summary& s = out[i];
       s.termination_type = h[i].termination;
       s.num_iterations = h[i].n_summaries - 1;
@@ -1753,6 +1760,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   if (const char* e = getenv("PTZ_BA_CHOL_LEFT")) b->left_looking = atoi(e) != 0;
   if (const char* e = getenv("PTZ_BA_AHEAD")) b->ahead = std::max(1, atoi(e));
   if (const char* e = getenv("PTZ_BA_DEBUG_STALL")) b->d.debug_stall = std::max(0, atoi(e));
+  if (const char* e = getenv("PTZ_BA_DEBUG_CHAIN_SPIN")) b->d.chol.chain_spin_limit = std::max(0, atoi(e));  // tests: hand-overs that time out
   if (const char* e = getenv("PTZ_BA_GRAPH")) b->use_graph = atoi(e) != 0;
   b->ctl_groups = std::max(1, std::min(b->n_group, n));
   if (b->alloc(&b->d_ctl, (size_t)4 * b->ctl_groups) != PTZ_OK ||

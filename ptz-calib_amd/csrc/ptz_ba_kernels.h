@@ -43,6 +43,8 @@ struct LmState {
   int num_consecutive_invalid, termination;
   int num_successful, num_unsuccessful, num_lm_steps, num_linear_solves, num_jac_evals;
   int ray_lin_ready;  // the ray blocks of the current point were left by k_eval's second pass (no k_lin_ray needed for this linearisation)
+  int chain_timeouts; // linear solves in which a hand-over of the one-launch factorisation did not arrive within its bounded wait
+                      // (CholBatch::fail bit 1): the step was handled as an invalid one, and the host reports the solve as PTZ_ENODEVICE
 };
 
 struct Opt {  // device copy of the solver options
@@ -1349,7 +1351,9 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
     return v;
   };
-  auto oclamp = [&](int q) { return o0 + min(q, max(no - 1, 0)); };
+  // (a camera WITHOUT observations is legal -- a candidate image none of whose tracks survived: then o0 may equal the batch's
+  //  observation count, so the clamp goes one below it; any valid observation's ray will do, its record is not used)
+  auto oclamp = [&](int q) { return max(o0 + min(q, no - 1), 0); };
   constexpr int PF = 3;
   int gid[PF];
   d16 rcs[PF];
@@ -2082,6 +2086,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   ++st.num_linear_solves;
   st.reuse_diagonal = 1;  // LevenbergMarquardtStrategy::ComputeStep
   const bool solve_fail = d.ray_fail[sc] || d.chol.fail[sc];
+  if (d.chol.fail[sc] & 2) ++st.chain_timeouts;
   const bool valid = !solve_fail && isfinite(mcc) && isfinite(dn) && mcc > 0.0;
   st.model_cost_change = mcc;
   st.it_cost = st.x_cost;
@@ -2141,7 +2146,14 @@ __global__ void k_reset(Dev d)
 // control words of one scene group (see Dev::grp_ctl); the host zeroes its pinned mirror itself before it enqueues anything
 __global__ void k_ctl_reset(Dev d)
 {
-  if (threadIdx.x == 0) { d.grp_ctl[0] = d.n_scene; d.grp_ctl[1] = 0; d.grp_ctl[2] = d.n_scene; }
+  if (threadIdx.x == 0) {
+    d.grp_ctl[0] = d.n_scene; d.grp_ctl[1] = 0; d.grp_ctl[2] = d.n_scene;
+    // tickets / done count of the one-launch factorisation: zero after every complete launch.  Left dirty by a launch that did
+    // not finish (a fault, a solve the watchdog gave up on), they would send the next launch's workgroups off the triangle: start
+    // clean, and move the generation on so that no flag of the unfinished launch can pass for one of the next
+    int* ctl = d.chol.chain_ctl;
+    if (ctl && (ctl[0] | ctl[1])) { ctl[0] = 0; ctl[1] = 0; ctl[2] += 2; }
+  }
   for (int i = threadIdx.x; i < d.n_scene; i += blockDim.x) d.act[i] = i;
 }
 

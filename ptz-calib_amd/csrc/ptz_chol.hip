@@ -287,7 +287,7 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
     else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
     __syncthreads();
   }
-  if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) cb.fail[sys] = 1;
+  if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
   if (w == 1) diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
   else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
   (void)okflag;
@@ -737,9 +737,9 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 // workgroups the chip holds at a time, the one with the smallest unfinished ticket can always run.  Waits are bounded: if a
 // flag does not come (a device fault elsewhere), the system is marked failed and the workgroup goes on -- never a hang.
 constexpr int CHAIN_SPIN_LIMIT = 1 << 21;
-__device__ __forceinline__ bool chain_wait(const int* flag, int gen)  // (one thread polls; the workgroup's acquire fence follows its barrier)
+__device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit)  // (one thread polls; the workgroup's acquire fence follows its barrier)
 {
-  for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
+  for (int it = 0; it < limit; ++it) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) return true;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -762,8 +762,13 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   int ord = ticket / cb.count;  // the tile's number in column-major order over the lower triangle
   const int sys = chol_system_of(cb, slot);
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
+  const int spin = cb.chain_spin_limit > 0 ? cb.chain_spin_limit : CHAIN_SPIN_LIMIT;
   int tj = 0;
-  while (ord >= nt - tj) { ord -= nt - tj; ++tj; }
+  while (tj < nt && ord >= nt - tj) { ord -= nt - tj; ++tj; }
+  if (tj >= nt) {  // a ticket beyond the launch's tiles: the counters were left dirty by a launch that did not finish (the host
+    if (threadIdx.x == 0) atomicOr(&cb.fail[sys], 2);  // resets them before a solve, k_ctl_reset); never walk off the triangle
+    return;
+  }
   const int ti = tj + ord;
   const int n = cb.n[sys];
   if (ti * NB > n || tj * NB > n) return;  // padding
@@ -816,8 +821,8 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     const int k = klist[q];
     if (q > 0) __syncthreads();  // all waves are done with the operand tiles of the previous column
     if (threadIdx.x == 0) {
-      const bool ok = chain_wait(&T[ti * nt + k], gen) && (ti == tj || chain_wait(&T[tj * nt + k], gen));
-      if (!ok) cb.fail[sys] = 1;
+      const bool ok = chain_wait(&T[ti * nt + k], gen, spin) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin));
+      if (!ok) atomicOr(&cb.fail[sys], 2);  // bit 1: a hand-over that did not come (reported to the host: LmState::chain_timeouts)
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -825,7 +830,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     const d16v rik = trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
     d16v rjk = rik;
     if (ti != tj) rjk = trsm_rows_fetch(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np);
-    if (threadIdx.x == 0 && !chain_wait(&F[k], gen)) cb.fail[sys] = 1;
+    if (threadIdx.x == 0 && !chain_wait(&F[k], gen, spin)) atomicOr(&cb.fail[sys], 2);
     CS_STAMP(1);  // (of the last column of the list)
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1403,7 +1408,9 @@ bool chol_chain_enabled(const CholBatch& cb)
   // -- i.e. as many systems as have all their tiles on the chip at once: two 800 x 800 systems, up to eight small ones (the growing
   // rigs of the incremental pipeline)
   const int nt = cb.np / NB;
-  bool fits = cb.count <= 2 || (cb.count <= 8 && cb.count * (nt * (nt + 1) / 2) <= 192);
+  // (a system so large that even one or two do not fit takes the per-step path: late tiles would sit in bounded waits)
+  const int tiles = cb.count * (nt * (nt + 1) / 2);
+  bool fits = cb.count <= 8 && tiles <= (cb.count <= 2 ? 256 : 192);
   if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) fits = cb.count <= std::max(1, std::min(8, atoi(m)));
   return on && cb.L && cb.Linv && cb.chain_ctl && fits && nt <= 1024;
 }
@@ -1655,11 +1662,17 @@ extern "C" int32_t ptz_chol_solve_batch(int32_t count, int32_t n, const double* 
   if (device_ms) *device_ms = ms;
   for (int s = 0; s < count; ++s)
     PTZ_HIP_TRY(hipMemcpy(x + (size_t)s * n, dx + (size_t)s * np, sizeof(double) * n, hipMemcpyDeviceToHost));
-  if (fail) PTZ_HIP_TRY(hipMemcpy(fail, dfail, sizeof(int) * count, hipMemcpyDeviceToHost));
+  bool lost = false;
+  {
+    int* hf = new int[count];
+    PTZ_HIP_TRY(hipMemcpy(hf, dfail, sizeof(int) * count, hipMemcpyDeviceToHost));
+    for (int s = 0; s < count; ++s) { lost |= (hf[s] & 2) != 0; if (fail) fail[s] = hf[s] & 1; }
+    delete[] hf;
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(stream);
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dfail);
   if (dL2) (void)hipFree(dL2);
   if (dLi) (void)hipFree(dLi);
   if (dctl) (void)hipFree(dctl);
-  return PTZ_OK;
+  return lost ? PTZ_ENODEVICE : PTZ_OK;  // (a tile hand-over of the one-launch factorisation that did not arrive)
 }

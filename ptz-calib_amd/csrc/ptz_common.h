@@ -220,7 +220,8 @@ struct CholBatch {
   double* Ldiag = nullptr;  // device [count][np/NB][NB*NB]
   double* Dinv = nullptr;   // device [count][np/NB][4][16*16]: inverses of the 16x16 diagonal blocks of L_kk
   const int* n = nullptr;   // device [count]
-  int* fail = nullptr;      // device [count]: set to 1 if a pivot <= 0 is met in rows < n_i
+  int* fail = nullptr;      // device [count]: bit 0 set if a pivot <= 0 is met in rows < n_i, bit 1 if a hand-over of the one-launch
+                            // factorisation did not arrive within its bounded wait (chol_chain_kernel)
   const int* active = nullptr;  // device [count] or nullptr; systems with active == 0 are skipped
   // device [count][nt * nt] or nullptr (dense): tmask[i * nt + j] != 0  <=>  tile (i, j), i >= j, of L can be non-zero
   // (structure of the reduced camera system closed under the fill of a tile-level symbolic factorisation; the tile row
@@ -239,6 +240,7 @@ struct CholBatch {
   // factorisation of a few systems as ONE launch whose workgroups hand their tiles on through flags (zeroed once at creation;
   // one block per stream that factors)
   int* chain_ctl = nullptr;
+  int chain_spin_limit = 0;  // polls a chain hand-over waits for before it gives up (0: the default, 2^21; tests shorten it)
   // device [count][4 * chol_backsolve_max_groups(np)] work items of the back-substitution in execution order and [count] their
   // group counts (chol_backsolve_plan, made on the host with the structure), or nullptr: the kernel makes the list itself
   const struct BsItem* bs_items = nullptr;

@@ -256,9 +256,15 @@ int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const flo
                             double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                             ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
 {
+  // The orchestration's registration launches always use ONE lane form -- a wave per query, the latency form -- whatever their size
+  // and whether or not they are merged with other rigs' launches: the form is part of a query's bits (ptz_lm_options::
+  // krt_lanes_per_query), and a rig must take the same decisions alone, in a lock step of any size and under PTZ_KRT_GROUP.
+  ptz_lm_options pinned;
+  if (opt) pinned = *opt; else ptz_lm_options_default(&pinned);
+  if (pinned.krt_lanes_per_query == 0) pinned.krt_lanes_per_query = 64;
   if (DeviceBatcher* b = DeviceBatcher::Current())
-    return b->KrtSolveBatch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms);
-  return ptz_krt_solve_batch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms);
+    return b->KrtSolveBatch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
+  return ptz_krt_solve_batch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
 }
 
 }  // namespace ptzcalib

@@ -539,7 +539,21 @@ def _scene_cache_path(cache_dir: str, scene_id: int, n_views: int, obs_per_view:
     import hashlib
     import os
     tag = hashlib.sha256(repr(sorted(kw.items())).encode()).hexdigest()[:10] if kw else "default"
-    return os.path.join(cache_dir, f"scene_{SEED_BASE + scene_id:x}_{n_views}x{obs_per_view}_{tag}.npz")
+    return os.path.join(cache_dir, f"scene_g{_generator_version()}_{SEED_BASE + scene_id:x}_{n_views}x{obs_per_view}_{tag}.npz")
+
+
+_GEN_VERSION = None
+
+
+def _generator_version() -> str:
+    """Part of every cache file's name: a hash of this module's source, so that a scene left by another checkout's generator is
+    never taken for this one's."""
+    global _GEN_VERSION
+    if _GEN_VERSION is None:
+        import hashlib
+        with open(__file__, "rb") as f:
+            _GEN_VERSION = hashlib.sha256(f.read()).hexdigest()[:8]
+    return _GEN_VERSION
 
 
 def _make_scene_job(args):

@@ -26,6 +26,19 @@ def _relative_rotations(orc, cam):
     return np.stack([r @ R[0].T for r in R])
 
 
+def _rodrigues_many(rv):
+    """cv::Rodrigues for an [n, 3] array of rotation vectors -> [n, 3, 3] (numpy restatement for the whole-population checks)."""
+    th = np.linalg.norm(rv, axis=1)
+    safe = np.where(th < 2.220446049250313e-16, 1.0, th)
+    k = rv / safe[:, None]
+    c, s_ = np.cos(th), np.sin(th)
+    K = np.zeros((len(rv), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    R = c[:, None, None] * np.eye(3)[None] + (1 - c)[:, None, None] * (k[:, :, None] * k[:, None, :]) + s_[:, None, None] * K
+    R[th < 2.220446049250313e-16] = np.eye(3)
+    return R
+
+
 def c3_standin_scenes(pkg):
     """Four matches of different size, as run_ptzba_worldcup14.sh:4-7 runs four recordings one after the other: 1280 x 720
     (eval_worldcup.py:68-69), a broadcast camera's +-60 degrees of pan, the distortion model the tool uses there (--dist)."""
@@ -62,9 +75,9 @@ def test_c3_standin_batch(pkg, orc):
 
 def test_c4_full_batch(pkg, orc):
     """bench.py's own workload under test: 1000 C2-shaped scenes, every one its own seed, in ONE batch on one GPU.  All
-    converge; focal lengths come back at noise level for every scene; a sample of 8 scenes is bit-equal to its solo solve; 4 of
-    them agree with the numeric-diff oracle (termination, iteration count, focal lengths and gauge-invariant relative
-    rotations within 1e-6).  (That copies of one scene inside a batch take identical trajectories is test_c4_cycled_seeds.)"""
+    converge; focal lengths come back at noise level for every scene; a sample of 8 scenes is bit-equal to its solo solve; 16
+    scenes spread over the LM-step histogram (shortest to longest) agree with the numeric-diff oracle (termination, iteration
+    and accepted-step counts, cost to 1e-9, focal lengths and gauge-invariant relative rotations within 1e-6).  (That copies of one scene inside a batch take identical trajectories is test_c4_cycled_seeds.)"""
     n = 1000
     scenes = pkg.synth.make_scenes(range(n), 200, 500)
     b = pkg.api.BaBatch(scenes)
@@ -92,13 +105,23 @@ def test_c4_full_batch(pkg, orc):
         cam, ray, s = pkg.api.ba_solve(scenes[k])
         assert s == summ[k]
         assert np.array_equal(cam, cams[k]) and np.array_equal(ray, rays[k])
-    for k in sample[:4]:
+    # the reference-faithful (numeric-differentiation) oracle on 16 scenes spread over the batch's LM-step histogram, from the
+    # shortest solve to the longest (the straggler): LM control flow sits on thresholds, so the long trajectories are where an
+    # arithmetic difference would show first
+    order = np.argsort(its, kind="stable")
+    spread = sorted({int(order[i]) for i in np.linspace(0, n - 1, 16).round().astype(int)})
+    assert int(order[-1]) in spread and int(order[0]) in spread and len(spread) >= 12
+    worst = {"f": 0.0, "rot": 0.0, "cost": 0.0}
+    for k in spread:
         ocam, _, _, osumm, _ = orc.ba_solve(scenes[k], jacobian_mode=orc.JAC_NUMERIC, num_threads=orc.usable_cores())
-        assert summ[k]["termination_type"] == osumm["termination_type"]
-        assert summ[k]["num_iterations"] == osumm["num_iterations"]
-        assert abs(summ[k]["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 1e-9
-        assert _rel(cams[k][:, 0], ocam[:, 0]) < 1e-6
-        assert np.abs(_relative_rotations(orc, cams[k]) - _relative_rotations(orc, ocam)).max() < 1e-6
+        assert summ[k]["termination_type"] == osumm["termination_type"], k
+        assert summ[k]["num_iterations"] == osumm["num_iterations"], (k, summ[k]["num_iterations"], osumm["num_iterations"])
+        assert summ[k]["num_successful_steps"] == osumm["num_successful_steps"], k
+        worst["cost"] = max(worst["cost"], abs(summ[k]["final_cost"] - osumm["final_cost"]) / osumm["final_cost"])
+        worst["f"] = max(worst["f"], _rel(cams[k][:, 0], ocam[:, 0]))
+        worst["rot"] = max(worst["rot"], float(np.abs(_relative_rotations(orc, cams[k]) - _relative_rotations(orc, ocam)).max()))
+    print(f"C4 oracle sample {spread}: LM steps {[int(its[k]) for k in spread]}, worst {worst}")
+    assert worst["cost"] < 1e-9 and worst["f"] < 1e-6 and worst["rot"] < 1e-6, worst
 
 
 def test_c4_cycled_seeds(pkg):
@@ -118,8 +141,9 @@ def test_c4_cycled_seeds(pkg):
 @pytest.mark.parametrize("ftype", [0, 1])
 def test_c5_full_reloc(pkg, orc, ftype):
     """100 000 queries x 128 matches in one launch (F and FDist, the two factor types the reference's tools use): every query
-    gets a termination type and every gate of KRTOptimizer::CheckResults (krt_optimizer.cc:504-533) an answer; a 64-query
-    sample agrees with the oracle's numeric-diff + QR solve; a sub-batch of the same queries reproduces the bits."""
+    gets a termination type and every gate of KRTOptimizer::CheckResults (krt_optimizer.cc:504-533) an answer; ALL
+    100 000 agree with the oracle's numeric-diff + QR solve in termination type, iteration count and gate decision (accepted
+    cameras to 1e-6); a sub-batch of the same queries reproduces the bits."""
     n = 100000
     rb = pkg.synth.make_reloc_queries(n, 128, seed_id=7 + ftype, factor_type=ftype)
     cam_w, summ, acc, ms = pkg.api.krt_solve_batch(rb)
@@ -133,22 +157,22 @@ def test_c5_full_reloc(pkg, orc, ftype):
     assert acc.mean() > 0.95
     ok = acc == 1
     assert np.median(np.abs(cam_w[ok, 0] / rb.cam_gt[ok, 0] - 1)) < 2e-3   # focal recovered at noise level
-    # oracle on a spread sample
-    sample = np.linspace(0, n - 1, 64).astype(int)
-    for q in sample:
-        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
-        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
-        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, jacobian_mode=orc.JAC_NUMERIC)
-        good = orc.krt_check(osumm, loc, 100.0)
-        assert summ[q]["termination_type"] == osumm["termination_type"]
-        assert summ[q]["num_iterations"] == osumm["num_iterations"]
-        assert bool(acc[q]) == good
-        if good:
-            want = orc.krt_local_to_world(rb.cam_ref[q], loc, ftype)
-            assert abs(cam_w[q, 0] - want[0]) / want[0] < 1e-6
-            assert np.abs(orc.rodrigues(cam_w[q, 4:7]) - orc.rodrigues(want[4:7])).max() < 1e-6
-            if ftype & 1:
-                assert abs(cam_w[q, 10] - want[10]) < 1e-6
+    # the oracle (numeric differentiation over all 15 parameters + Householder QR, run_ptz_reloc.cc:68-118 as oracle/ptz_oracle.c
+    # restates it) on ALL queries: termination type, iteration count and gate decision of every single one, and the accepted
+    # cameras to the north-star tolerance
+    ocam, osumm, oacc = orc.krt_solve_batch(rb, num_threads=orc.usable_cores(), jacobian_mode=orc.JAC_NUMERIC)
+    oterm = np.array([s["termination_type"] for s in osumm])
+    oits = np.array([s["num_iterations"] for s in osumm])
+    its = np.array([s["num_iterations"] for s in summ])
+    bad = np.flatnonzero((term != oterm) | (its != oits) | (acc != oacc))
+    print(f"C5 ftype {ftype}: {n} queries against the oracle: {len(bad)} differ in termination / iterations / gate"
+          + (f" (first: {[(int(q), int(term[q]), int(oterm[q]), int(its[q]), int(oits[q]), int(acc[q]), int(oacc[q])) for q in bad[:8]]})" if len(bad) else ""))
+    assert len(bad) == 0
+    both = (acc == 1)
+    assert np.abs(cam_w[both, 0] / ocam[both, 0] - 1).max() < 1e-6
+    assert np.abs(_rodrigues_many(cam_w[both, 4:7]) - _rodrigues_many(ocam[both, 4:7])).max() < 1e-6
+    if ftype & 1:
+        assert np.abs(cam_w[both, 10] - ocam[both, 10]).max() < 1e-6
     # the same queries as a smaller launch: identical bits (a query's result does not depend on its neighbours).  The lane
     # form is part of the bits (16 or 64 lanes sum a query's rows in a different order), and the automatic choice depends on
     # the launch size, so the small launch asks for the form the large one got; the other form agrees to rounding.
@@ -161,9 +185,14 @@ def test_c5_full_reloc(pkg, orc, ftype):
     sub.cam_ref = rb.cam_ref[:m]; sub.cam_init = rb.cam_init[:m]; sub.cam_gt = rb.cam_gt[:m]
     cam2, summ2, acc2, _ = pkg.api.krt_solve_batch(sub, krt_lanes_per_query=16)
     assert np.array_equal(cam2, cam_w[:m]) and np.array_equal(acc2, acc[:m]) and summ2 == summ[:m]
+    # the other lane form sums a query's rows in another order: reported, and held to the same oracle -- every query of the
+    # sub-launch that takes another decision than the 16-lane form is listed, none may disagree with the oracle
     cam3, summ3, acc3, _ = pkg.api.krt_solve_batch(sub, krt_lanes_per_query=64)
+    its3 = np.array([s["num_iterations"] for s in summ3]); term3 = np.array([s["termination_type"] for s in summ3])
+    flips = np.flatnonzero((acc3 != acc[:m]) | (its3 != its[:m]) | (term3 != term[:m]))
+    print(f"C5 ftype {ftype}: 64-lane form on the first {m} queries: {len(flips)} decisions differ from the 16-lane form {[int(q) for q in flips[:8]]}")
+    assert np.array_equal(acc3, oacc[:m]) and np.array_equal(its3, oits[:m]) and np.array_equal(term3, oterm[:m])
     same = (acc3 == 1) & (acc[:m] == 1)
-    assert same.mean() > 0.95 and (acc3 != acc[:m]).mean() < 1e-3
     assert np.abs(cam3[same, 0] / cam_w[:m][same, 0] - 1).max() < 1e-6
 
 

@@ -1114,6 +1114,54 @@ def test_ba_camera_without_observations(pkg, orc, scene_c1):
     assert np.abs(_relative_rotations(orc, cam[others]) - _relative_rotations(orc, ocam[others])).max() < 1e-6
 
 
+def _append_empty_camera(sc):
+    """One more candidate camera that no track observes (an image whose matches were all filtered out), as the LAST camera."""
+    import copy
+    s = copy.copy(sc)
+    s.n_cam = sc.n_cam + 1
+    s.cam_init = np.vstack([sc.cam_init, sc.cam_init[-1:] * 1.0])
+    s.cam_gt = np.vstack([sc.cam_gt, sc.cam_gt[-1:]])
+    return s
+
+
+def test_ba_trailing_camera_without_observations_in_the_last_scene(pkg, scene_c1):
+    """The LAST camera of the LAST scene of a batch has no observations: its observation range starts at the batch's observation
+    count, so a kernel that gathers "its first observation" unconditionally reads past the end of the camera-major arrays
+    (k_schur's first trips did).  The camera keeps its values, the other cameras get the bits of the scene without it (its rows of
+    the reduced system are identity and couple to nothing), alone and as the last scene of a batch."""
+    other = pkg.synth.make_scene(4, 24, 100)
+    sc = _append_empty_camera(scene_c1)
+    ref = pkg.api.ba_solve(scene_c1)
+    cam, ray, summ = pkg.api.ba_solve(sc)
+    assert summ == ref[2] or (summ["num_iterations"] == ref[2]["num_iterations"] and abs(summ["final_cost"] - ref[2]["final_cost"]) <= 1e-12 * ref[2]["final_cost"])
+    assert np.array_equal(cam[-1], sc.cam_init[-1])
+    assert np.abs(cam[:-1] - ref[0]).max() < 1e-9 and np.abs(ray - ref[1]).max() < 1e-9
+    for _ in range(3):  # (recycled blocks: whatever lies behind the arrays differs from solve to solve)
+        b = pkg.api.BaBatch([other, sc]); b.set_state(); s2 = b.solve(); cams, rays = b.get_state(); b.close()
+        assert s2[1] == summ and np.array_equal(cams[1], cam) and np.array_equal(rays[1], ray)
+
+
+def test_ba_lost_chain_handover_is_reported_not_absorbed(pkg, scene_c1, monkeypatch):
+    """chol_chain_kernel's waits are bounded (never a hang).  A wait that runs out used to mark the linear solve failed, which
+    k_lm_post treats as an invalid step: a silently different, still "successful" trajectory.  With PTZ_BA_DEBUG_CHAIN_SPIN=1
+    every hand-over that is not there at the first poll times out: the solve must come back as PTZ_ENODEVICE, and the next,
+    undisturbed solve of the same problem must have the bits of an undisturbed one (tickets and generation start clean)."""
+    big = pkg.synth.make_scene(7, 60, 300)  # several block columns: hand-overs exist
+    ref = pkg.api.ba_solve(big)
+    monkeypatch.setenv("PTZ_BA_DEBUG_CHAIN_SPIN", "1")
+    lost = 0
+    for _ in range(3):
+        try:
+            pkg.api.ba_solve(big)
+        except pkg.api.PtzError as e:
+            assert e.code == -2
+            lost += 1
+    assert lost >= 1, "a one-poll wait must lose at least one hand-over of a multi-column factorisation"
+    monkeypatch.delenv("PTZ_BA_DEBUG_CHAIN_SPIN")
+    cam, ray, summ = pkg.api.ba_solve(big)
+    assert summ == ref[2] and np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1])
+
+
 def test_ba_ragged_batch_is_bit_identical_to_solo_solves(pkg):
     """Scenes of very different sizes in one batch (2, 20, 24 and 60 cameras; the padded reduced systems, LDS tables and grids
     are sized by the largest): every scene's result has the bits of its solo solve."""
