@@ -68,6 +68,7 @@ struct PassShape {
   bool compact = false;   // blockIdx.y is a slot of the compacted list
   int ray_block = 1024;   // rays per workgroup of the ray-centric kernels
   bool small_blocks = false, fused = false;  // SMALL kernel variants; one-launch-per-column factorisation
+  bool fuse_ctl = false;  // LM control and the camera update inside k_eval / k_lin_cam (no k_lm_pre / k_lm_post / k_cam_update launches)
   int max_chunk = 0;
   size_t lin_smem = 0, eval_smem = 0;
 };
@@ -431,7 +432,7 @@ static void make_groups(ptz_ba_batch* b)
     Dev d = b->d;  // per-scene arrays are re-based; everything else is addressed through SceneDev offsets
     const size_t np = d.chol.np, nt = np / CHOL_NB;
     d.n_scene = hi - lo;
-    d.scene += lo; d.lm += lo; d.active += lo; d.ray_fail += lo;
+    d.scene += lo; d.lm += lo; d.active += lo; d.ray_fail += lo; d.tail_cnt += 2 * (size_t)lo;
     d.yc += (size_t)lo * np;
     d.chol.count = hi - lo;
     d.chol.A += (size_t)lo * np * np;
@@ -465,8 +466,10 @@ static void make_groups(ptz_ba_batch* b)
   }
 }
 
-// one LM pass of one group in launch shape `sh`, enqueued on b->stream; returns after enqueueing (no synchronisation)
-template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool last, const PassShape& sh)
+// one LM pass of one group in launch shape `sh`, enqueued on b->stream; returns after enqueueing (no synchronisation).
+// A pass = one trust-region step and the bookkeeping that OPENS the next one (k_lm_pre last: the first iteration is opened by
+// solve_impl's prologue), so that launch shapes with and without launches of their own for LM control can follow one another.
+template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const PassShape& sh)
 {
   constexpr int NC = Dims<TYPE>::NC;
   Dev d = dgrp;
@@ -476,15 +479,12 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   d.chol.act = sh.compact ? d.act : nullptr;
   d.chol.act_n = d.grp_ctl + 2;
   if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
+  const bool fuse = sh.fuse_ctl && TYPE < 3 && !d.shared;  // (annotation residuals, the displacement block and shared intrinsics keep their own launches)
+  d.fuse_ctl = fuse ? 1 : 0;
   const int B = sh.slots;
   hipStream_t st = b->stream;
   const int schur_thr = schur_threads<TYPE>();
   const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w, schur_thr, Dims<TYPE>::NW, b->max_cam_ent);
-  b->prof_begin(P_LMCTL);
-  LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
-  if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
-  b->prof_end();
-  if (last) return;
   b->prof_begin(P_RAYPREP);
   {
     const int nt = d.chol.np / CHOL_NB;
@@ -517,16 +517,24 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
   b->prof_end();
   chol_factor_solve_profiled(d.chol, d.yc, st, b, sh.fused);
   if (d.shared) LAUNCH(k_group_expand<TYPE>, dim3(B), dim3(256), 0, d);
-  b->prof_begin(P_BACKSUB);
-  LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
-  b->prof_end();
+  if (!fuse) {
+    b->prof_begin(P_BACKSUB);
+    LAUNCH(k_cam_update<TYPE>, dim3((b->max_cam + 63) / 64, B), dim3(64), 0, d);
+    b->prof_end();
+  }
   b->prof_begin(P_EVAL);
-  PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
+  if constexpr (TYPE < 3) {
+    if (fuse) LAUNCH((k_eval<TYPE, true, false, true>), dim3(sh.max_chunk, B), dim3(sh.ray_block), sh.eval_smem, d);
+    else PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
+  }
+  else PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
-  b->prof_begin(P_LMCTL);
-  LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
-  b->prof_end();
+  if (!fuse) {
+    b->prof_begin(P_LMCTL);
+    LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
+    b->prof_end();
+  }
   {
     const Dev& dd = d;
     b->prof_begin(P_LIN);
@@ -538,6 +546,10 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, bool las
     if (dd.shared) LAUNCH(k_group_grad<TYPE>, dim3(B), dim3(256), 0, dd);
     b->prof_end();
   }
+  b->prof_begin(P_LMCTL);
+  if (!fuse) LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
+  if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
+  b->prof_end();
 }
 
 template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
@@ -576,6 +588,13 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     enqueue_linearize<TYPE>(b);
   }
   for (int g = 0; g < G; ++g) hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(64), 0, s0, b->dg[g]);
+  // iteration zero's books are closed and the first step is opened here; every pass ends with the same bookkeeping for the next
+  b->prof_begin(P_LMCTL);
+  for (int g = 0; g < G; ++g) {
+    LAUNCH(k_lm_pre<TYPE>, dim3(b->group_count[g]), dim3(LM_THREADS), 0, b->dg[g]);
+    if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, b->dg[g]);
+  }
+  b->prof_end();
   // fork: every group's stream continues after the common prologue
   PTZ_HIP_TRY(hipEventRecord(b->fork_ev[0], s0));
   for (int g = 1; g < G; ++g) PTZ_HIP_TRY(hipStreamWaitEvent(b->streams[g], b->fork_ev[0], 0));
@@ -599,7 +618,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       g_recorder = &rec;
       PassShape shg = b->shapes[si];
       if (si == 0) shg.slots = b->group_count[g];
-      enqueue_pass<TYPE>(b, b->dg[g], false, shg);
+      enqueue_pass<TYPE>(b, b->dg[g], shg);
       g_recorder = nullptr;
       ok = rec.ok && hipGraphInstantiate(&b->pass_graph[g][si], rec.graph, nullptr, nullptr, 0) == hipSuccess;
     }
@@ -626,10 +645,11 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     for (int g = 0; g < G; ++g) {
       if (!galive[g]) continue;
       if (__atomic_load_n(&b->h_ctl[4 * g + 1], __ATOMIC_ACQUIRE)) { galive[g] = 0; --alive; progressed = true; continue; }
+      if (enq[g] == max_it) { galive[g] = 0; --alive; progressed = true; continue; }  // every step the options allow is enqueued (the last pass's k_lm_pre closes the books)
       if (enq[g] - std::max(__atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE), credit[g]) >= b->ahead) continue;
       const double te0 = now();
       b->stream = b->streams[g];
-      const bool last = enq[g] == max_it;  // the last pass only closes the books (k_lm_pre)
+      const bool last = false;
       // launch shape: the smallest one that covers the scenes last reported active (the count only ever decreases, so a stale
       // value is an upper bound); full size while more than the largest compacted shape are
       int si = 0;
@@ -643,11 +663,10 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       if (dbg) { if (shape_used.size() < b->shapes.size()) shape_used.resize(b->shapes.size(), 0); ++shape_used[si]; }
       hipGraphExec_t ge = (!last && graph && b->use_graph) ? graph_of(g, si) : nullptr;
       if (ge) PTZ_HIP_TRY(hipGraphLaunch(ge, b->streams[g]));
-      else { b->stream = b->streams[g]; enqueue_pass<TYPE>(b, b->dg[g], last, sh); }
+      else { b->stream = b->streams[g]; enqueue_pass<TYPE>(b, b->dg[g], sh); }
       ++enq[g];
       progressed = true;
       t_enq += now() - te0;
-      if (last) { galive[g] = 0; --alive; }
     }
     if (progressed) { t_progress = now(); continue; }
     const double ts0 = now();
@@ -1595,6 +1614,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.partial, (size_t)b->total_chunk * 4));
   TRY(b->alloc(&d.partial_lin, 2 * d.plin_stride));
   d.ray_block = b->ray_block;
+  TRY(b->alloc(&d.camstep, (size_t)b->total_cam * 2));
+  TRY(b->alloc(&d.cam_gmax, (size_t)b->total_cam));
+  TRY(b->alloc(&d.tail_cnt, (size_t)2 * n));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
   TRY(b->alloc(&d.ray_fail, (size_t)n));
@@ -1794,6 +1816,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     sh.small_blocks = sh.ray_block <= 256;
     sh.fused = slots <= 8;
     if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) sh.fused = atoi(e) != 0 && slots <= 8;
+    // a few scenes: LM control and the camera update ride in the tails / prologue of k_eval and k_lin_cam (three launches less per pass)
+    sh.fuse_ctl = slots <= 8 && sh.small_blocks && !b->gtab;
+    if (const char* e = getenv("PTZ_BA_FUSE_CTL")) sh.fuse_ctl = sh.fuse_ctl && atoi(e) != 0;
     sh.max_chunk = (b->max_ray + sh.ray_block - 1) / sh.ray_block;
     const size_t obs_lds = sh.small_blocks ? (size_t)OBS_PREFETCH_BYTES * sh.ray_block : 0;
     if (b->gtab) { sh.eval_smem = sizeof(double) * 16 + obs_lds + 16; sh.lin_smem = obs_lds + 16; }
@@ -1857,6 +1882,9 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       raise_cap((const void*)k_eval<T, false, false>);      \
       raise_cap((const void*)k_lin_ray<T, true, false>);    \
       raise_cap((const void*)k_lin_ray<T, false, false>);
+      raise_cap((const void*)k_eval<0, true, false, true>);
+      raise_cap((const void*)k_eval<1, true, false, true>);
+      raise_cap((const void*)k_eval<2, true, false, true>);
       PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5) PTZ_SET_ATTR(6) PTZ_SET_ATTR(7)
 #undef PTZ_SET_ATTR
       if (!attr_ok) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }

@@ -43,6 +43,7 @@ struct LmState {
   int num_consecutive_invalid, termination;
   int num_successful, num_unsuccessful, num_lm_steps, num_linear_solves, num_jac_evals;
   int ray_lin_ready;  // the ray blocks of the current point were left by k_eval's second pass (no k_lin_ray needed for this linearisation)
+  double cand_norm2;  // |x_c|^2 of the last evaluated candidate (k_lm_post): |x|^2 of the point once the step is accepted
   int chain_timeouts; // linear solves in which a hand-over of the one-launch factorisation did not arrive within its bounded wait
                       // (CholBatch::fail bit 1): the step was handled as an invalid one, and the host reports the solve as PTZ_ENODEVICE
 };
@@ -108,6 +109,13 @@ struct Dev {
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
   double* Tbuf;      // [total_obs][NW * 3] or nullptr: T_a = W_a E rows of k_schur when a camera's do not fit in LDS
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
+  double* camstep;   // [total_cam][2] {|x_i - x_c,i|^2, |x_c,i|^2} over the camera's parameter blocks that are in the problem: written with
+                     // the candidate (k_cam_update, or k_eval's prologue when the camera update is folded into it), summed by k_lm_post
+  double* cam_gmax;  // [total_cam] max_k |g_i[k] / s_i[k]| of the camera's gradient block (k_lin_cam), for k_lm_pre
+  // LM control without launches of its own (launch shapes of a few scenes, Dev::fuse_ctl): the LAST workgroup of a scene to
+  // finish k_eval closes the step (lm_post_wave), the last to finish k_lin_cam opens the next iteration (lm_pre_wave).
+  int* tail_cnt;     // [n_scene][2] workgroups of the scene that have finished k_eval / k_lin_cam in this pass (zero between passes)
+  int fuse_ctl;      // 1: this launch shape has no k_lm_pre / k_lm_post / k_cam_update launches
   double* partial;   // [total_wave + n_scene][4] per wave of rays {model cost change, candidate cost, |x - x_c|^2, |x_c|^2} of k_eval
                      // (one extra slot per scene for the 2D-3D terms)
   double* partial_lin;  // [total_wave][2] per wave of rays {max |g_r / scale|, |x|^2} of k_lin_ray
@@ -241,6 +249,12 @@ template <int TYPE> struct Dims {
     return k == 0 ? 0 : (FYL && k == 1) ? 1 : (FACTOR && k == 1 + FYL) ? 10 : k < RC + 3 ? 4 + (k - RC) : 15 + (k - RC - 3);
   }
 };
+
+// LM control as one wave per scene (defined with k_lm_pre / k_lm_post below; also run from the tails of k_lin_cam / k_eval)
+template <int TYPE> __device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc);
+template <int TYPE> __device__ __forceinline__ void lm_post_wave(const Dev& d, int sc);
+__device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int* lds_flag);
+__device__ __forceinline__ void post_progress(const Dev& d);
 
 __device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl, const double* dsp = nullptr)
 {
@@ -450,11 +464,12 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   if (sc < 0) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  if (!d.active[sc] || !st.need_linearize) return;
+  if (!d.active[sc] || (int)blockIdx.x * 4 >= s.n_cam) return;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= s.n_cam) return;
   const int lane = threadIdx.x & 63;
   const int gi = s.cam_off + i;
+  // (no wave leaves before the end: with Dev::fuse_ctl the workgroup meets again at the tail below, also after a rejected step)
+  if (st.need_linearize && i < s.n_cam) {
   double cb[CAMBLK];
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cb[k] = cur_camblk(d, st)[(size_t)gi * CBS + k];
@@ -542,6 +557,20 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
   if (lane == 0) {
     d.costc[gi] = cost;
+    if (NC == NW) {
+      // what LM control needs of this block, left with it: the gradient's share of the max-norm (k_lm_pre) and the LM diagonal
+      // clamp(diag(J^T J)) (LevenbergMarquardtStrategy; refreshed exactly when the blocks are).  With annotation residuals later
+      // kernels add to U and g: k_lm_pre then reads the blocks themselves.
+      double gmx = 0;
+      int e2 = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        gmx = fmax(gmx, fabs(g[k] / cb[CB_S + k]));
+        e2 += k;  // index of U[k][k] in the packed lower triangle: k (k + 1) / 2 + k
+        d.diag_c[(size_t)gi * NC + k] = fmin(fmax(U[e2 + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+      }
+      d.cam_gmax[gi] = gmx;
+    }
     if (NC != NW) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
 #pragma unroll
       for (int k = 0; k < NC * NC; ++k) d.U[(size_t)gi * NC * NC + k] = 0;
@@ -562,6 +591,11 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
       }
     }
   }
+  }
+  if (!d.fuse_ctl) return;
+  // the last workgroup of the scene finalises the iteration and opens the next one (what a k_lm_pre launch would do)
+  __shared__ int tail_flag;
+  if (tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag)) lm_pre_wave<TYPE>(d, sc);
 }
 
 // ---- lin_3d: 2D-3D annotation residuals (AddConstraints2d3d, ptzray_optimizer.cc:887-923; weight 1) ----------
@@ -873,29 +907,36 @@ __global__ void k_group_expand(Dev d)
 }
 
 // ---- lm_pre: TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue ---------------------
-constexpr int LM_THREADS = 1024;  // the LM bookkeeping kernels are one workgroup per scene: wide, to shorten their reductions
+// LM control is ONE WAVE per scene, whoever runs it: the kernels k_lm_pre / k_lm_post (64 threads per scene), or -- in launch
+// shapes of a few scenes (Dev::fuse_ctl) -- the last workgroup of the scene to finish k_lin_cam / k_eval.  Lanes stride over
+// the scene's cameras and per-wave partials, one butterfly per sum: the order of every sum is fixed by the scene alone, so a
+// scene's bits depend neither on the launch shape nor on who runs its control.
+constexpr int LM_THREADS = 64;
 template <int TYPE>
-__global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
+__device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc)
 {
   constexpr int NC = Dims<TYPE>::NC;
-  const int sc = scene_of_slot(d, blockIdx.x);
-  if (sc < 0) return;
-  if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
-  __shared__ double scratch[64];
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool slow = Dims<TYPE>::HAS3D || d.shared;  // gradient blocks that later kernels touch (annotation terms, group folds): read where they lie
   if (st.step_is_successful) {
     // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
     double c = 0, gm = 0, xn = 0;
+    // |x|: at iteration zero from the parameters themselves; later it is |x_c| of the step k_lm_post accepted (LmState::cand_norm2:
+    // Ceres' x_norm_ after HandleSuccessfulStep is the norm of that same vector)
+    const bool first = st.n_summaries == 0;
     const double* cam = cur_cam(d, s, st);
     const int* cp = d.cam_ptr + s.cam_off + s.idx;
-    for (int i = tid; i < s.n_cam; i += LM_THREADS) {
+    for (int i = lane; i < s.n_cam; i += 64) {
       const int gi = s.cam_off + i;
       c += d.costc[gi];
-      const double* gsrc = d.shared ? d.gfold : d.gc;  // shared intrinsics: the group's gradient sits at its representative
-      for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(gsrc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
-      if (cp[i + 1] > cp[i]) {  // parameter blocks of cameras without residuals are not in the problem
+      if (slow) {
+        const double* gsrc = d.shared ? d.gfold : d.gc;  // shared intrinsics: the group's gradient sits at its representative
+        for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(gsrc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
+      }
+      else gm = fmax(gm, d.cam_gmax[gi]);
+      if (first && cp[i + 1] > cp[i]) {  // parameter blocks of cameras without residuals are not in the problem
         const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
         for (int k = 0; k < 15; ++k)
           if (intr || (k >= 4 && k < 10)) xn += cam[(size_t)i * 15 + k] * cam[(size_t)i * 15 + k];
@@ -905,37 +946,34 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
         }
       }
     }
-    for (int wv = tid; wv < s.n_wave; wv += LM_THREADS) {  // the rays' share, one entry per wave of k_lin_ray
+    for (int wv = lane; wv < s.n_wave; wv += 64) {  // the rays' share, one entry per wave of k_lin_ray / k_eval
       const double* pl = lin_partial(d, st.cur) + (size_t)(s.part_off - s.idx + wv) * 2;
       gm = fmax(gm, pl[0]);
-      xn += pl[1];
+      if (first) xn += pl[1];
     }
-    // fixed-order cost: per-thread partial sums over a strided camera set, then the block tree
-    if (Dims<TYPE>::HAS3D && tid == 0) {
+    if (Dims<TYPE>::HAS3D && lane == 0) {
       const double* tl = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
       for (int k = 0; k < 6; ++k) {
-        if (s.n_o3 > 0) xn += tl[k] * tl[k];  // the T_l_w block is in the problem only when annotation residuals exist
+        if (first && s.n_o3 > 0) xn += tl[k] * tl[k];  // the T_l_w block is in the problem only when annotation residuals exist
         gm = fmax(gm, fabs(d.gt[(size_t)s.idx * 6 + k] / d.scale_t[(size_t)s.idx * 6 + k]));
       }
     }
-    {
-      double r4[4] = {c, gm, xn, 0.0};
-      block_reduce4(r4, 2u, scratch);  // cost and |x|^2 are sums, the gradient norm a maximum
-      c = r4[0]; gm = r4[1]; xn = r4[2];
-    }
-    if (tid == 0) {
+    c = wave_sum(c);
+    gm = wave_max(gm);
+    xn = wave_sum(xn);
+    if (lane == 0) {
       st.x_cost = c;
       st.it_cost = c;
       st.grad_max = gm;
-      st.x_norm = sqrt(xn);
+      st.x_norm = sqrt(first ? xn : st.cand_norm2);
       st.need_linearize = 0;
       st.ray_lin_ready = 0;
       ++st.num_jac_evals;
       if (st.n_summaries == 0) { st.initial_cost = c; st.final_cost = c; }
     }
   }
-  __syncthreads();
-  if (tid == 0) {
+  int go_on = 0;  // the scene takes another step and its LM diagonal is to be refreshed
+  if (lane == 0) {
     if (st.step_is_successful) ++st.num_successful; else ++st.num_unsuccessful;
     if (st.it_cost < st.final_cost) st.final_cost = st.it_cost;
     ++st.n_summaries;
@@ -947,20 +985,32 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
       ++st.num_lm_steps;
       st.step_is_successful = 0;
       d.ray_fail[sc] = 0;
+      go_on = st.reuse_diagonal ? 0 : 1;
     }
   }
-  // LevenbergMarquardtStrategy: the camera blocks' LM diagonal, clamp(diag(J^T J)), refreshed unless the last step was rejected
-  // (was a kernel of its own; the scene's LM block has the threads to spare)
-  __syncthreads();
-  if (!d.active[sc] || st.reuse_diagonal) return;
-  for (int i = tid; i < s.n_cam; i += LM_THREADS) {
-    const int gi = s.cam_off + i;
+  // LevenbergMarquardtStrategy: the camera blocks' LM diagonal clamp(diag(J^T J)) is written by k_lin_cam with the blocks themselves
+  // (a rejected or invalid step leaves U, hence the diagonal, as it was); only where later kernels add to U -- annotation
+  // residuals (k_lin_3d) -- it is taken here, with the T_l_w block's
+  if (Dims<TYPE>::HAS3D) {
+    go_on = __shfl(go_on, 0, WAVE);
+    if (!go_on) return;
+    for (int i = lane; i < s.n_cam; i += 64) {
+      const int gi = s.cam_off + i;
 #pragma unroll
-    for (int k = 0; k < NC; ++k)
-      d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+      for (int k = 0; k < NC; ++k)
+        d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+    }
+    if (lane < 6)
+      d.diag_t[(size_t)s.idx * 6 + lane] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + lane * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
   }
-  if (Dims<TYPE>::HAS3D && tid < 6)
-    d.diag_t[(size_t)s.idx * 6 + tid] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + tid * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(LM_THREADS) void k_lm_pre(Dev d)
+{
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0 || !d.active[sc]) return;
+  lm_pre_wave<TYPE>(d, sc);
 }
 
 // ---- ray_prep: LevenbergMarquardtStrategy diagonal + SchurEliminator e-block inverse --------------------
@@ -1736,24 +1786,23 @@ __global__ __launch_bounds__(64) void k_schur_3d(Dev d)
 }
 
 // ---- cam_update: candidate cameras and their residual-side blocks ----------------------------------------
+// One camera's candidate from the solution of the reduced system, and everything later kernels need of it.  Called by k_cam_update
+// (thread = camera, everything to global memory) and by k_eval's prologue when the camera update is folded into it (launch shapes
+// of a few scenes: EVERY workgroup computes all candidates into its LDS tables -- lds_cand: the CANDBLK-entry prefix of the
+// camera block, lds_dct: the step as k_eval applies it -- and the scene's first workgroup also stores them, to_global).  cbc: the
+// camera's block at x (global or LDS).  One piece of code, so that a scene's bits do not depend on which of the two runs it.
 template <int TYPE>
-__global__ void k_cam_update(Dev d)
+__device__ __forceinline__ void cam_update_one(const Dev& d, const SceneDev& s, const LmState& st, int sc, int i, const double* cbc,
+                                               bool to_global, double* lds_cand, double* lds_dct)
 {
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
-  constexpr int NC = Dims<TYPE>::NC;
-  const int sc = scene_of_slot(d, blockIdx.y);
-  if (sc < 0) return;
-  if (!d.active[sc]) return;
-  const SceneDev s = d.scene[sc];
-  const LmState& st = d.lm[sc];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s.n_cam) return;
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, DCS = NC | 1;
   const int gi = s.cam_off + i;
   const double* x = cur_cam(d, s, st) + (size_t)i * 15;
-  double c15[15];
+  double x15[15], c15[15];
 #pragma unroll
-  for (int k = 0; k < 15; ++k) c15[k] = x[k];
+  for (int k = 0; k < 15; ++k) { x15[k] = x[k]; c15[k] = x15[k]; }
   const double* ysc = d.yc + (size_t)sc * d.chol.np;
   double y[NC];  // this camera's part of the solution (through the elimination order)
 #pragma unroll
@@ -1761,49 +1810,76 @@ __global__ void k_cam_update(Dev d)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const double step = -y[k];
-    d.dc[(size_t)gi * NC + k] = step;
-    if (Dims<TYPE>::at(k) < 15) c15[Dims<TYPE>::at(k) < 15 ? Dims<TYPE>::at(k) : 0] += step * d.scale_c[(size_t)gi * NC + k];
+    if (to_global) d.dc[(size_t)gi * NC + k] = step;
+    if (Dims<TYPE>::at(k) < 15) c15[Dims<TYPE>::at(k) < 15 ? Dims<TYPE>::at(k) : 0] += step * cbc[CB_S + k];
   }
-  double dsp[3] = {0, 0, 0};
+  double dsp0[3] = {0, 0, 0}, dsp[3] = {0, 0, 0};
   if (Dims<TYPE>::DISP) {  // the camera's copy of the displacement block (every copy takes the same step: k_group_expand)
     const double* dx = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)gi * 3;
     double* dxc = d.dsp_x + (size_t)(st.cur ^ 1) * d.dsp_stride + (size_t)gi * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      dsp[k] = dx[k] + (-y[NC - 3 + k]) * d.scale_c[(size_t)gi * NC + NC - 3 + k];
-      dxc[k] = dsp[k];
+      dsp0[k] = dx[k];
+      dsp[k] = dsp0[k] + (-y[NC - 3 + k]) * cbc[CB_S + NC - 3 + k];
+      if (to_global) dxc[k] = dsp[k];
     }
   }
-  double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) xc[k] = c15[k];
   {  // the scaled step of the camera's 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir), for k_eval
-    constexpr int NW = Dims<TYPE>::NW, DCS = NC | 1;
-    const double* cbc = cur_camblk(d, st) + (size_t)gi * CBS;
     double sv[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * (-y[Dims<TYPE>::pos(k)]);
-    double* dr = d.dct + (size_t)gi * DCS;
+    double dr[NW];
     constexpr int RW = Dims<TYPE>::RW;  // [columns before the rotation, columns behind it | Jl v_rot]
 #pragma unroll
     for (int k = 0; k < NW - 3; ++k) dr[k] = sv[k < RW ? k : k + 3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
       dr[NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[RW] + cbc[CB_JL + 3 * r + 1] * sv[RW + 1] + cbc[CB_JL + 3 * r + 2] * sv[RW + 2];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      if (to_global) d.dct[(size_t)gi * DCS + k] = dr[k];
+      if (lds_dct) lds_dct[k] = dr[k];
+    }
   }
-  // the candidate's full camera block (rotation, SO(3) Jacobian, intrinsics, scales) goes to the other half of camblk: if the
-  // step is accepted the linearisation kernels find it there; its first CANDBLK entries are what k_eval needs of it
+  // the candidate's camera block: its first CANDBLK entries (rotation, intrinsics) are what k_eval needs of it; the full block
+  // (SO(3) Jacobian, scales) goes to the other half of camblk -- if the step is accepted the linearisation kernels find it there
   double cb[CAMBLK];
 #pragma unroll
   for (int k = CB_S; k < CAMBLK; ++k) cb[k] = 0.0;
-  fill_camblk(c15, cb, true, Dims<TYPE>::DISP ? dsp : nullptr);
+  fill_camblk(c15, cb, to_global, Dims<TYPE>::DISP ? dsp : nullptr);
+  if (lds_cand) {
 #pragma unroll
-  for (int k = 0; k < NC; ++k) cb[CB_S + k] = d.scale_c[(size_t)gi * NC + k];
+    for (int k = 0; k < CANDBLK; ++k) lds_cand[k] = cb[k];
+  }
+  if (!to_global) return;
+  double* xc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)gi * 15;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) xc[k] = c15[k];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cb[CB_S + k] = cbc[CB_S + k];
   double* cfull = d.camblk + (size_t)(st.cur ^ 1) * d.camblk_stride + (size_t)gi * CBS;
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cfull[k] = cb[k];
 #pragma unroll
   for (int k = 0; k < CANDBLK; ++k) d.candblk[(size_t)gi * CDS + k] = cb[k];
+  {  // |x - x_c|^2 and |x_c|^2 over this camera's parameter blocks that are in the problem (k_lm_post)
+    const int* cp = d.cam_ptr + s.cam_off + s.idx;
+    double dn = 0, cn = 0;
+    if (cp[i + 1] > cp[i]) {  // (blocks of cameras without residuals are not in the problem)
+      const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        if (!intr && (k < 4 || k >= 10)) continue;
+        dn += (x15[k] - c15[k]) * (x15[k] - c15[k]);
+        cn += c15[k] * c15[k];
+      }
+      if (Dims<TYPE>::DISP && (d.cam_flag[gi] & 2)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dn += (dsp0[k] - dsp[k]) * (dsp0[k] - dsp[k]); cn += dsp[k] * dsp[k]; }
+      }
+    }
+    *reinterpret_cast<double2*>(d.camstep + (size_t)gi * 2) = make_double2(dn, cn);
+  }
   if (Dims<TYPE>::HAS3D && i == 0) {
     const double* t = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
     double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
@@ -1826,6 +1902,19 @@ __global__ void k_cam_update(Dev d)
   }
 }
 
+template <int TYPE>
+__global__ void k_cam_update(Dev d)
+{
+  const int sc = scene_of_slot(d, blockIdx.y);
+  if (sc < 0) return;
+  if (!d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  const LmState& st = d.lm[sc];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n_cam) return;
+  cam_update_one<TYPE>(d, s, st, sc, i, cur_camblk(d, st) + (size_t)(s.cam_off + i) * Dims<TYPE>::CBS, true, nullptr, nullptr);
+}
+
 // ---- eval: ray back-substitution, model cost change and candidate cost in one ray-centric pass -----------------
 //   y_r = E (g_r - sum_a Jr_a^T (Jc_a y_c))            (SchurEliminator::BackSubstitute; W_a = Jc_a^T Jr_a is not
 //                                                        re-read: the Jacobian blocks are recomputed, flops are free)
@@ -1842,12 +1931,17 @@ __global__ void k_cam_update(Dev d)
 #define EV_STAMP_DECL do { } while (0)
 #define EV_STAMP_PRINT do { } while (0)
 #endif
-template <int TYPE, bool SMALL, bool GTAB>
+// FUSE (launch shapes of a few scenes, Dev::fuse_ctl): the launch also does what k_cam_update does before it -- every workgroup
+// computes the scene's candidate cameras into its LDS tables, the first one stores them -- and what k_lm_post does behind it: the
+// last workgroup of the scene to finish closes the step (lm_post_wave).  Three launches of a one-rig pass in one.
+template <int TYPE, bool SMALL, bool GTAB, bool FUSE = false>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
+  static_assert(!FUSE || (SMALL && !GTAB), "the folded camera update fills the LDS tables");
+  if (FUSE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) post_progress(d);  // (what k_lm_post's first thread does)
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
   if (!d.active[sc]) return;
@@ -1875,8 +1969,17 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     scratch = dct0 + ((s.n_cam * DCS + 5) & ~1);           // [16]
     obsbuf = reinterpret_cast<float4*>(scratch + 16);
     tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
-    ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
-    dct = dct0 + stage_flat<SMALL ? 16 : 8>(d.dct + (size_t)s.cam_off * DCS, dct0, s.n_cam * DCS);
+    if constexpr (FUSE) {
+      __syncthreads();  // the table at x is there: the candidates read their cameras' Jacobi scales and SO(3) Jacobians from it
+      for (int i = threadIdx.x; i < s.n_cam; i += blockDim.x)
+        cam_update_one<TYPE>(d, s, st, sc, i, tab + i * CBS, blockIdx.x == 0, ctab0 + i * CDS, dct0 + i * DCS);
+      ctab = ctab0;
+      dct = dct0;
+    }
+    else {
+      ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
+      dct = dct0 + stage_flat<SMALL ? 16 : 8>(d.dct + (size_t)s.cam_off * DCS, dct0, s.n_cam * DCS);
+    }
     __syncthreads();
   }
   EV_STAMP(1);
@@ -1991,6 +2094,10 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   (void)scratch;
   EV_STAMP(7);
   EV_STAMP_PRINT;
+  if constexpr (FUSE) {  // the last workgroup of the scene closes the step (what a k_lm_post launch would do)
+    __shared__ int tail_flag;
+    if (tail_last_workgroup(d.tail_cnt + 2 * sc, (s.n_ray + (int)blockDim.x - 1) / (int)blockDim.x, &tail_flag)) lm_post_wave<TYPE>(d, sc);
+  }
 }
 
 // ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
@@ -2033,55 +2140,31 @@ __global__ __launch_bounds__(256) void k_eval_3d(Dev d)
 }
 
 // ---- lm_post: the body of TrustRegionMinimizer::Minimize after the step has been computed --------------
+// One wave per scene (see lm_pre_wave).
 template <int TYPE>
-__global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
+__device__ __forceinline__ void lm_post_wave(const Dev& d, int sc)
 {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // progress mark for the host's run-ahead throttle (also from passes that have nothing left to do)
-    const int reached = ++d.grp_ctl[1];
-    if (!d.debug_stall || reached <= d.debug_stall) __hip_atomic_store(&d.host_ctl[0], reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  const int sc = scene_of_slot(d, blockIdx.x);
-  if (sc < 0 || !d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
-  __shared__ double scratch[64];
-  const int tid = threadIdx.x;
-  // chunk partials in chunk order (thread-strided, then the fixed block tree)
+  const int lane = threadIdx.x & 63;
+  // per-wave partials of k_eval in wave order, the cameras' {|x - x_c|^2, |x_c|^2} in camera order (lane-strided, then the butterfly)
   double mcc = 0, cost = 0, dn = 0, cn = 0;
-  for (int c = tid; c < s.n_wave + Dims<TYPE>::HAS3D; c += LM_THREADS) {
-    const double* pp = d.partial + (size_t)(s.part_off + c) * 4;
-    mcc += pp[0]; cost += pp[1]; dn += pp[2]; cn += pp[3];  // the rays' |x - x_c|^2 and |x_c|^2 come from k_eval as well
+  for (int c = lane; c < s.n_wave + Dims<TYPE>::HAS3D; c += 64) {
+    const double2* pp = reinterpret_cast<const double2*>(d.partial + (size_t)(s.part_off + c) * 4);
+    const double2 a = pp[0], b = pp[1];
+    mcc += a.x; cost += a.y; dn += b.x; cn += b.y;  // the rays' |x - x_c|^2 and |x_c|^2 come from k_eval as well
   }
-  // |x - x_candidate| and |x_candidate| over the parameter blocks that are in the problem
-  const double* cam = cur_cam(d, s, st);
-  const double* camc = d.cam_x + (size_t)(st.cur ^ 1) * d.cam_stride + (size_t)s.cam_off * 15;
-  const int* cp = d.cam_ptr + s.cam_off + s.idx;
-  for (int i = tid; i < s.n_cam; i += LM_THREADS) {
-    if (cp[i + 1] <= cp[i]) continue;
-    const bool intr = !d.shared || (d.cam_flag[s.cam_off + i] & 1);
-    for (int k = 0; k < 15; ++k) {
-      if (!intr && (k < 4 || k >= 10)) continue;
-      const double a = cam[(size_t)i * 15 + k], b = camc[(size_t)i * 15 + k];
-      dn += (a - b) * (a - b);
-      cn += b * b;
-    }
-    if (Dims<TYPE>::DISP && (d.cam_flag[s.cam_off + i] & 2)) {
-      const double* da = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)(s.cam_off + i) * 3;
-      const double* db = d.dsp_x + (size_t)(st.cur ^ 1) * d.dsp_stride + (size_t)(s.cam_off + i) * 3;
-      for (int k = 0; k < 3; ++k) { dn += (da[k] - db[k]) * (da[k] - db[k]); cn += db[k] * db[k]; }
-    }
+  for (int i = lane; i < s.n_cam; i += 64) {
+    const double2 v = *reinterpret_cast<const double2*>(d.camstep + (size_t)(s.cam_off + i) * 2);
+    dn += v.x; cn += v.y;
   }
-  if (Dims<TYPE>::HAS3D && tid == 0 && s.n_o3 > 0) {
+  if (Dims<TYPE>::HAS3D && lane == 0 && s.n_o3 > 0) {
     const double* ta = d.tlw_x + (size_t)st.cur * d.tlw_stride + (size_t)s.idx * 6;
     const double* tb_ = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
     for (int k = 0; k < 6; ++k) { dn += (ta[k] - tb_[k]) * (ta[k] - tb_[k]); cn += tb_[k] * tb_[k]; }
   }
-  {
-    double r4[4] = {mcc, cost, dn, cn};
-    block_reduce4(r4, 0u, scratch);
-    mcc = -r4[0]; cost = r4[1]; dn = r4[2]; cn = r4[3];
-  }
-  if (tid != 0) return;
+  mcc = -wave_sum(mcc); cost = wave_sum(cost); dn = wave_sum(dn); cn = wave_sum(cn);
+  if (lane != 0) return;
   const Opt& o = d.opt;
   ++st.num_linear_solves;
   st.reuse_diagonal = 1;  // LevenbergMarquardtStrategy::ComputeStep
@@ -2100,6 +2183,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   st.num_consecutive_invalid = 0;
   if (!isfinite(cost)) cost = 1.7976931348623157e308;
   st.candidate_cost = cost;
+  st.cand_norm2 = cn;
   // ParameterToleranceReached
   if (sqrt(dn) <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { st.termination = PTZ_CONVERGENCE; retire_scene(d, sc); return; }
   // FunctionToleranceReached
@@ -2127,6 +2211,40 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   }
 }
 
+// progress mark for the host's run-ahead throttle: one thread of the launch, also from passes that have nothing left to do
+__device__ __forceinline__ void post_progress(const Dev& d)
+{
+  const int reached = ++d.grp_ctl[1];
+  if (!d.debug_stall || reached <= d.debug_stall) __hip_atomic_store(&d.host_ctl[0], reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
+{
+  if (blockIdx.x == 0 && threadIdx.x == 0) post_progress(d);
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0 || !d.active[sc]) return;
+  lm_post_wave<TYPE>(d, sc);
+}
+
+// The last workgroup of a scene to get here runs the scene's LM control in its first wave (Dev::fuse_ctl): every thread makes its
+// stores visible device-wide, one thread counts the workgroup in; `expected` workgroups of the scene pass here per launch.
+// Returns true in the first wave of the workgroup that closes the count (which has reset it for the next pass).
+__device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int* lds_flag)
+{
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atomicAdd(cnt, 1);
+    *lds_flag = prev == expected - 1;
+    if (prev == expected - 1) *cnt = 0;  // (nobody else touches it before the next launch)
+  }
+  __syncthreads();
+  if (!*lds_flag || threadIdx.x >= 64) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
 // ---- reset / init -----------------------------------------------------------------------------------------
 __global__ void k_reset(Dev d)
 {
@@ -2142,6 +2260,7 @@ __global__ void k_reset(Dev d)
   d.lm[sc] = st;
   d.active[sc] = 1;
   d.ray_fail[sc] = 0;
+  d.tail_cnt[2 * sc] = 0; d.tail_cnt[2 * sc + 1] = 0;  // (a solve the watchdog gave up on may have left them mid-count)
 }
 // control words of one scene group (see Dev::grp_ctl); the host zeroes its pinned mirror itself before it enqueues anything
 __global__ void k_ctl_reset(Dev d)

@@ -431,6 +431,28 @@ def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, 
     assert not errors, errors
 
 
+def test_ba_control_inside_the_kernels_has_the_bits_of_its_own_launches(pkg, scene_c1, monkeypatch):
+    """Launch shapes of a few scenes run LM control and the camera update INSIDE k_eval / k_lin_cam (the last workgroup of a scene
+    to finish runs lm_post_wave / lm_pre_wave, every workgroup computes the candidate cameras in its prologue); larger shapes and
+    PTZ_BA_FUSE_CTL=0 launch k_cam_update / k_lm_post / k_lm_pre.  Same one-wave code either way: same bits, also for a scene
+    with rejected steps and for a batch that moves from the large shape to the small one while it thins out."""
+    medium = pkg.synth.make_scene(6, 60, 300)   # (has rejected steps: test_ba_medium_parity)
+    dist = pkg.synth.make_scene(3, 20, 100, factor_type=1)
+    fused = [pkg.api.ba_solve(sc) for sc in (scene_c1, medium, dist)]
+    assert fused[1][2]["num_unsuccessful_steps"] > 0
+    monkeypatch.setenv("PTZ_BA_FUSE_CTL", "0")
+    for sc, ref in zip((scene_c1, medium, dist), fused):
+        cam, ray, summ = pkg.api.ba_solve(sc)
+        assert summ == ref[2] and np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1])
+    monkeypatch.delenv("PTZ_BA_FUSE_CTL")
+    # 12 scenes: full-size passes with launches of their own, then the compacted 8-slot shape with the control inside
+    scenes = [pkg.synth.make_scene(s, 20 + 2 * (s % 4), 100) for s in range(12)]
+    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    for k in (0, 5, 11):
+        cam, ray, s1 = pkg.api.ba_solve(scenes[k])
+        assert s1 == summ[k] and np.array_equal(cam, cams[k]) and np.array_equal(ray, rays[k])
+
+
 def test_ba_repeated_solves_are_bit_identical_with_poisoned_pool(pkg, scene_c1, monkeypatch):
     """Resources are recycled between solves (ptz_pool.h); no result may depend on what an earlier solve left in them.
     PTZ_POOL_FILL=255 hands out blocks filled with NaN bit patterns: a kernel that reads memory nobody initialised would
