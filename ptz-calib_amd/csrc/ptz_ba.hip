@@ -442,7 +442,7 @@ static void make_groups(ptz_ba_batch* b)
     d.chol.n += lo; d.chol.fail += lo; d.chol.active = d.active;
     if (d.chol.tmask) d.chol.tmask += (size_t)lo * nt * nt;
     if (d.chol.sched) d.chol.sched += (size_t)lo * nt * CHOL_STEP_COLS;
-    if (d.tperm) d.tperm += (size_t)lo * nt;
+    if (d.tperm) { d.tperm += (size_t)lo * nt; d.chol.xperm = d.tperm; }
     d.grp_ctl = b->d_ctl + 4 * g;
     d.host_ctl = b->h_ctl_dev + 4 * g;
     d.act = b->d_act + lo;
@@ -479,7 +479,13 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   d.chol.act = sh.compact ? d.act : nullptr;
   d.chol.act_n = d.grp_ctl + 2;
   if (!sh.fused) d.chol.L = nullptr;  // (the second matrix marks the one-launch-per-column path)
-  const bool fuse = sh.fuse_ctl && TYPE < 3 && !d.shared;  // (annotation residuals, the displacement block and shared intrinsics keep their own launches)
+  // Scenes without annotation residuals and shared blocks: the camera-side linearisation of the CANDIDATE is evaluated before the
+  // step is judged (k_lin_cam, Dev::spec_lin), and one control point per pass judges the step and opens the next iteration
+  // (lm_step_wave) -- a launch of its own (k_lm_step), or in launch shapes of a few scenes the tail of k_lin_cam (Dev::fuse_ctl, with
+  // the camera update in k_eval's prologue).  The others keep k_lm_post / k_lin_cam at the accepted point / k_lm_pre.
+  const bool fast = TYPE < 3 && !d.shared && !b->schur_w;  // (round 2's Schur kernel reads W rows of the CURRENT point, which are not double-buffered)
+  const bool fuse = sh.fuse_ctl && fast;
+  d.spec_lin = fast ? 1 : 0;
   d.fuse_ctl = fuse ? 1 : 0;
   const int B = sh.slots;
   hipStream_t st = b->stream;
@@ -530,7 +536,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   else PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_eval_3d<TYPE>, dim3(B), dim3(256), 0, d);
   b->prof_end();
-  if (!fuse) {
+  if (!fast) {
     b->prof_begin(P_LMCTL);
     LAUNCH(k_lm_post<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
     b->prof_end();
@@ -547,7 +553,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
     b->prof_end();
   }
   b->prof_begin(P_LMCTL);
-  if (!fuse) LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
+  if (!fast) LAUNCH(k_lm_pre<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
+  else if (!fuse) LAUNCH(k_lm_step<TYPE>, dim3(B), dim3(LM_THREADS), 0, d);
   if (b->shapes.size() > 1 && b->compaction) LAUNCH(k_compact, dim3(1), dim3(1024), 0, d);  // (batches too small for a compacted shape skip it)
   b->prof_end();
 }
@@ -1585,10 +1592,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.candblk, (size_t)b->total_cam * CDS + 2));
   TRY(b->alloc(&d.scale_c, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.scale_r, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.U, (size_t)b->total_cam * NC * NC));
-  TRY(b->alloc(&d.gc, (size_t)b->total_cam * NC));
-  TRY(b->alloc(&d.costc, (size_t)b->total_cam));
-  TRY(b->alloc(&d.diag_c, (size_t)b->total_cam * NC));
+  TRY(b->alloc(&d.U, (size_t)2 * b->total_cam * NC * NC));
+  TRY(b->alloc(&d.gc, (size_t)2 * b->total_cam * NC));
+  TRY(b->alloc(&d.costc, (size_t)2 * b->total_cam));
+  d.lin_cams = b->total_cam;
+  TRY(b->alloc(&d.diag_c, (size_t)2 * b->total_cam * NC));
   TRY(b->alloc(&d.dc, (size_t)b->total_cam * NC));
   TRY(b->alloc(&d.dct, (size_t)b->total_cam * (NC | 1) + 4));
   // (two halves each: k_eval leaves the ray-side linearisation of its candidate in the half that LmState.cur does not select)
@@ -1615,7 +1623,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   TRY(b->alloc(&d.partial_lin, 2 * d.plin_stride));
   d.ray_block = b->ray_block;
   TRY(b->alloc(&d.camstep, (size_t)b->total_cam * 2));
-  TRY(b->alloc(&d.cam_gmax, (size_t)b->total_cam));
+  TRY(b->alloc(&d.cam_gmax, (size_t)2 * b->total_cam));
   TRY(b->alloc(&d.tail_cnt, (size_t)2 * n));
   TRY(b->alloc(&d.lm, (size_t)n));
   TRY(b->alloc(&d.active, (size_t)n));
@@ -1729,6 +1737,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       const int* dp = nullptr;
       TRY(upload(b, h_tperm, &dp));
       d.tperm = dp;
+      d.chol.xperm = dp;
       TRY(upload(b, h_sched, &dp));
       d.chol.sched = dp;
       d.chol.n_steps = max_steps;

@@ -95,10 +95,15 @@ struct Dev {
                          // so an accepted step needs no camera pass before it is re-linearised
   double* scale_c;   // [total_cam][NC]
   double* scale_r;   // [total_ray][3]
-  double* U;         // [total_cam][NC*NC]
-  double* gc;        // [total_cam][NC]
-  double* costc;     // [total_cam]
-  double* diag_c;    // [total_cam][NC]
+  // The camera side of the linearisation is DOUBLE-BUFFERED like the state (two halves of lin_cams cameras each, LmState::cur
+  // selects the current point's): k_lin_cam evaluates the CANDIDATE's blocks into the other half before the step is judged
+  // (Dev::spec_lin), so that accepting a step is a flip of `cur` and one control point per pass closes the step and opens the next
+  double* U;         // [2][total_cam][NC*NC]
+  double* gc;        // [2][total_cam][NC]
+  double* costc;     // [2][total_cam]
+  double* diag_c;    // [2][total_cam][NC]
+  int lin_cams;      // cameras per half (the batch's total, not rebased per scene group)
+  int spec_lin;      // 1: k_lin_cam linearises the candidate (half cur ^ 1) of every active scene; 0: the current point where LmState asks for it
   double* dc;        // [total_cam][NC] scaled-space camera step
   double* dct;       // [total_cam][NC | 1] the same step as k_eval applies it per observation: [intrinsic components | Jl v_rot]
   double* V;         // [total_ray][6]
@@ -111,7 +116,7 @@ struct Dev {
   double* rayrec;    // [total_ray][8] {X[3], Jacobi scale[3], weight, 0}: what the camera pass needs of a ray, one 64-byte sector
   double* camstep;   // [total_cam][2] {|x_i - x_c,i|^2, |x_c,i|^2} over the camera's parameter blocks that are in the problem: written with
                      // the candidate (k_cam_update, or k_eval's prologue when the camera update is folded into it), summed by k_lm_post
-  double* cam_gmax;  // [total_cam] max_k |g_i[k] / s_i[k]| of the camera's gradient block (k_lin_cam), for k_lm_pre
+  double* cam_gmax;  // [2][total_cam] max_k |g_i[k] / s_i[k]| of the camera's gradient block (k_lin_cam), for k_lm_pre
   // LM control without launches of its own (launch shapes of a few scenes, Dev::fuse_ctl): the LAST workgroup of a scene to
   // finish k_eval closes the step (lm_post_wave), the last to finish k_lin_cam opens the next iteration (lm_pre_wave).
   int* tail_cnt;     // [n_scene][2] workgroups of the scene that have finished k_eval / k_lin_cam in this pass (zero between passes)
@@ -253,6 +258,7 @@ template <int TYPE> struct Dims {
 // LM control as one wave per scene (defined with k_lm_pre / k_lm_post below; also run from the tails of k_lin_cam / k_eval)
 template <int TYPE> __device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc);
 template <int TYPE> __device__ __forceinline__ void lm_post_wave(const Dev& d, int sc);
+template <int TYPE> __device__ __forceinline__ void lm_step_wave(const Dev& d, int sc);
 __device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int* lds_flag);
 __device__ __forceinline__ void post_progress(const Dev& d);
 
@@ -468,11 +474,22 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int gi = s.cam_off + i;
-  // (no wave leaves before the end: with Dev::fuse_ctl the workgroup meets again at the tail below, also after a rejected step)
-  if (st.need_linearize && i < s.n_cam) {
+  // Which point: the candidate's (Dev::spec_lin: every active scene, before its step is judged -- camera blocks, ray records and
+  // the results all in the half that LmState::cur does NOT select) or the current one (iteration zero; scenes with annotation
+  // residuals or shared blocks, whose later kernels add to these blocks: after the step was accepted)
+  const int hh = d.spec_lin ? (st.cur ^ 1) : st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
+  const double* camblk_h = d.camblk + (size_t)hh * d.camblk_stride;
+  // (no wave leaves before the end: with Dev::fuse_ctl the workgroup meets again at the tail below)
+  if ((d.spec_lin || st.need_linearize) && i < s.n_cam) {
   double cb[CAMBLK];
 #pragma unroll
-  for (int k = 0; k < CAMBLK; ++k) cb[k] = cur_camblk(d, st)[(size_t)gi * CBS + k];
+  for (int k = 0; k < CAMBLK; ++k) cb[k] = camblk_h[(size_t)gi * CBS + k];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
   typedef double d8 __attribute__((ext_vector_type(8)));
   auto qclamp = [&](int q) { return max(min(q, q_end - 1), 0); };
   auto load_rr = [&](int rid) {
-    const double2* r2 = reinterpret_cast<const double2*>(lin_rayrec(d, st.cur) + (size_t)rid * 8);
+    const double2* r2 = reinterpret_cast<const double2*>(lin_rayrec(d, hh) + (size_t)rid * 8);
     const double2 a = r2[0], b = r2[1], c = r2[2], e = r2[3];
     d8 v; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = e.x; v[7] = e.y;
     return v;
@@ -556,7 +573,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 #pragma unroll
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
   if (lane == 0) {
-    d.costc[gi] = cost;
+    costc_[gi] = cost;
     if (NC == NW) {
       // what LM control needs of this block, left with it: the gradient's share of the max-norm (k_lm_pre) and the LM diagonal
       // clamp(diag(J^T J)) (LevenbergMarquardtStrategy; refreshed exactly when the blocks are).  With annotation residuals later
@@ -567,35 +584,37 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
       for (int k = 0; k < NW; ++k) {
         gmx = fmax(gmx, fabs(g[k] / cb[CB_S + k]));
         e2 += k;  // index of U[k][k] in the packed lower triangle: k (k + 1) / 2 + k
-        d.diag_c[(size_t)gi * NC + k] = fmin(fmax(U[e2 + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+        diagc_[(size_t)gi * NC + k] = fmin(fmax(U[e2 + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
       }
-      d.cam_gmax[gi] = gmx;
+      gmax_[gi] = gmx;
     }
     if (NC != NW) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
 #pragma unroll
-      for (int k = 0; k < NC * NC; ++k) d.U[(size_t)gi * NC * NC + k] = 0;
+      for (int k = 0; k < NC * NC; ++k) U_[(size_t)gi * NC * NC + k] = 0;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) d.gc[(size_t)gi * NC + k] = 0;
+      for (int k = 0; k < NC; ++k) gc_[(size_t)gi * NC + k] = 0;
     }
     int e = 0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       const int pk = Dims<TYPE>::pos(k);
-      d.gc[(size_t)gi * NC + pk] = g[k];
+      gc_[(size_t)gi * NC + pk] = g[k];
 #pragma unroll
       for (int l = 0; l <= k; ++l) {
         const int pl = Dims<TYPE>::pos(l);
-        d.U[(size_t)gi * NC * NC + pk * NC + pl] = U[e];
-        d.U[(size_t)gi * NC * NC + pl * NC + pk] = U[e];
+        U_[(size_t)gi * NC * NC + pk * NC + pl] = U[e];
+        U_[(size_t)gi * NC * NC + pl * NC + pk] = U[e];
         ++e;
       }
     }
   }
   }
-  if (!d.fuse_ctl) return;
-  // the last workgroup of the scene finalises the iteration and opens the next one (what a k_lm_pre launch would do)
-  __shared__ int tail_flag;
-  if (tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag)) lm_pre_wave<TYPE>(d, sc);
+  if constexpr (!Dims<TYPE>::HAS3D) {
+    if (!d.fuse_ctl) return;
+    // the last workgroup of the scene judges the step and opens the next iteration (what a k_lm_step launch would do)
+    __shared__ int tail_flag;
+    if (tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag)) lm_step_wave<TYPE>(d, sc);
+  }
 }
 
 // ---- lin_3d: 2D-3D annotation residuals (AddConstraints2d3d, ptzray_optimizer.cc:887-923; weight 1) ----------
@@ -614,6 +633,13 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
+  const int hh = st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   const double* tb = cur_tlwblk(d, st) + (size_t)s.idx * TLWBLK;
   const double* stl = d.scale_t + (size_t)s.idx * 6;
   for (int o = threadIdx.x; o < s.n_o3; o += 256) {
@@ -649,7 +675,7 @@ __global__ __launch_bounds__(256) void k_lin_3d(Dev d)
   for (int w = t; w < s.n_cam * PER; w += 256) {
     const int ci = w / PER, el = w % PER;
     const int gi = s.cam_off + ci;
-    double* dst = el < NC * NC ? d.U + (size_t)gi * NC * NC + el : (el < NC * NC + NC ? d.gc + (size_t)gi * NC + (el - NC * NC) : d.costc + gi);
+    double* dst = el < NC * NC ? U_ + (size_t)gi * NC * NC + el : (el < NC * NC + NC ? gc_ + (size_t)gi * NC + (el - NC * NC) : costc_ + gi);
     double acc = *dst;
     bool any = false;
     for (int o = 0; o < s.n_o3; ++o) {
@@ -675,10 +701,17 @@ __global__ void k_jacobi_scale(Dev d)
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hh = d.lm[sc].cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   if (t < s.n_cam) {
     const int gi = s.cam_off + t;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) d.scale_c[(size_t)gi * NC + k] = 1.0 / (1.0 + sqrt(d.U[(size_t)gi * NC * NC + k * NC + k]));
+    for (int k = 0; k < NC; ++k) d.scale_c[(size_t)gi * NC + k] = 1.0 / (1.0 + sqrt(U_[(size_t)gi * NC * NC + k * NC + k]));
   }
   if (t < s.n_ray) {
     const int gj = s.ray_off + t;
@@ -723,8 +756,15 @@ __global__ void k_group_scale(Dev d)
   const int g = t / NC, k = t % NC;
   if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  const int hh = d.lm[sc].cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   double sum = 0;
-  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += U_[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
   sum = wave_sum(sum);
   const double sc_g = 1.0 / (1.0 + sqrt(sum));
   for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) d.scale_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = sc_g;
@@ -745,11 +785,18 @@ __global__ void k_group_diag(Dev d)
   const int g = t / NC, k = t % NC;
   if (g >= s.n_grp || !is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) return;
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
+  const int hh = d.lm[sc].cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   double sum = 0;
-  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.U[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += U_[(size_t)(s.cam_off + d.grp_mem[e]) * NC * NC + k * NC + k];
   sum = wave_sum(sum);
   const double share = fmin(fmax(sum, d.opt.min_lm_diagonal), d.opt.max_lm_diagonal) / (double)(gp[g + 1] - gp[g]);
-  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) d.diag_c[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
+  for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) diagc_[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = share;
 }
 
 // gradient with the shared slots folded onto the representative (others 0); every other slot copied.
@@ -763,7 +810,14 @@ __global__ void k_group_grad(Dev d)
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
   if (!d.active[sc] || !st.need_linearize) return;
-  for (int t = threadIdx.x; t < s.n_cam * NC; t += blockDim.x) d.gfold[(size_t)s.cam_off * NC + t] = d.gc[(size_t)s.cam_off * NC + t];
+  const int hh = st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
+  for (int t = threadIdx.x; t < s.n_cam * NC; t += blockDim.x) d.gfold[(size_t)s.cam_off * NC + t] = gc_[(size_t)s.cam_off * NC + t];
   __syncthreads();
   const int* gp = d.grp_ptr + s.grp_off + s.idx;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -771,7 +825,7 @@ __global__ void k_group_grad(Dev d)
     const int g = t / NC, k = t % NC;
     if (!is_shared_slot<TYPE>(k, group_class<TYPE>(d, s, g))) continue;
     double sum = 0;
-    for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += d.gc[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
+    for (int e = gp[g] + lane; e < gp[g + 1]; e += 64) sum += gc_[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k];
     sum = wave_sum(sum);
     for (int e = gp[g] + lane; e < gp[g + 1]; e += 64)
       d.gfold[(size_t)(s.cam_off + d.grp_mem[e]) * NC + k] = (e == gp[g + 1] - 1) ? sum : 0.0;
@@ -919,6 +973,13 @@ __device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc)
   const SceneDev s = d.scene[sc];
   LmState& st = d.lm[sc];
   const int lane = threadIdx.x & 63;
+  const int hh = st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   const bool slow = Dims<TYPE>::HAS3D || d.shared;  // gradient blocks that later kernels touch (annotation terms, group folds): read where they lie
   if (st.step_is_successful) {
     // a fresh linearisation exists: cost, gradient max-norm (unscaled gradient), |x|
@@ -930,12 +991,12 @@ __device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc)
     const int* cp = d.cam_ptr + s.cam_off + s.idx;
     for (int i = lane; i < s.n_cam; i += 64) {
       const int gi = s.cam_off + i;
-      c += d.costc[gi];
+      c += costc_[gi];
       if (slow) {
         const double* gsrc = d.shared ? d.gfold : d.gc;  // shared intrinsics: the group's gradient sits at its representative
         for (int k = 0; k < NC; ++k) gm = fmax(gm, fabs(gsrc[(size_t)gi * NC + k] / d.scale_c[(size_t)gi * NC + k]));
       }
-      else gm = fmax(gm, d.cam_gmax[gi]);
+      else gm = fmax(gm, gmax_[gi]);
       if (first && cp[i + 1] > cp[i]) {  // parameter blocks of cameras without residuals are not in the problem
         const bool intr = !d.shared || (d.cam_flag[gi] & 1);  // a shared intrinsics block is ONE block: counted once
         for (int k = 0; k < 15; ++k)
@@ -998,7 +1059,7 @@ __device__ __forceinline__ void lm_pre_wave(const Dev& d, int sc)
       const int gi = s.cam_off + i;
 #pragma unroll
       for (int k = 0; k < NC; ++k)
-        d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
+        diagc_[(size_t)gi * NC + k] = fmin(fmax(U_[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
     }
     if (lane < 6)
       d.diag_t[(size_t)s.idx * 6 + lane] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + lane * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
@@ -1098,25 +1159,6 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
   for (int k = 0; k < EZS / 2; ++k) out[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
 }
 
-template <int TYPE>
-__global__ void k_cam_diag(Dev d)
-{
-  constexpr int NC = Dims<TYPE>::NC;
-  const int sc = blockIdx.y;
-  if (!d.active[sc]) return;
-  const SceneDev s = d.scene[sc];
-  const LmState& st = d.lm[sc];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s.n_cam || st.reuse_diagonal) return;
-  const int gi = s.cam_off + i;
-  if (Dims<TYPE>::HAS3D && i == 0)
-    for (int k = 0; k < 6; ++k)
-      d.diag_t[(size_t)s.idx * 6 + k] = fmin(fmax(d.Ut[(size_t)s.idx * 36 + k * 7], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
-#pragma unroll
-  for (int k = 0; k < NC; ++k)
-    d.diag_c[(size_t)gi * NC + k] = fmin(fmax(d.U[(size_t)gi * NC * NC + k * NC + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
-}
-
 // ---- schur: one workgroup per camera ci -------------------------------------------------------------------
 // Phase 1 (all threads, strided over ci's observations a): T_a = W_a E_ray(a) into LDS; at the same time the
 //   diagonal block S_ii = U_i + D_i^2 - sum_a T_a W_a^T and the right-hand side b_i = g_i - sum_a W_a z_ray(a)
@@ -1147,6 +1189,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   const SceneDev s = d.scene[sc];
   if (ci >= s.n_cam) return;
   const LmState& st = d.lm[sc];
+  const int hh = st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
@@ -1220,9 +1269,9 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
       while ((p + 1) * (p + 2) / 2 <= t) ++p;
       while (p * (p + 1) / 2 > t) --p;
       const int qq = t - p * (p + 1) / 2;
-      double v = d.U[(size_t)gi * NC * NC + p * NC + qq];
+      double v = U_[(size_t)gi * NC * NC + p * NC + qq];
       if (p == qq) {
-        const double Dd = sqrt(d.diag_c[(size_t)gi * NC + p] / st.radius);
+        const double Dd = sqrt(diagc_[(size_t)gi * NC + p] / st.radius);
         v += Dd * Dd;
       }
       const int ip = ipos(p), iq = ipos(qq);
@@ -1233,7 +1282,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
     }
     else if (t >= NE && t < NE + NC) {
       const int p = t - NE, ip = ipos(p);
-      double v = d.gc[(size_t)gi * NC + p];
+      double v = gc_[(size_t)gi * NC + p];
       if (ip >= 0) v -= strip_sum(ip);
       A[(size_t)s.n * np + scol(ci * NC + p)] = v;
     }
@@ -1379,6 +1428,13 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   const SceneDev s = d.scene[sc];
   if (ci >= s.n_cam) return;
   const LmState& st = d.lm[sc];
+  const int hh = st.cur;
+  double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;   // the camera side of the linearisation, half hh (LmState::cur selects the current point's)
+  double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  double* costc_ = d.costc + (size_t)hh * d.lin_cams;
+  double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  double* gmax_ = d.cam_gmax + (size_t)hh * d.lin_cams;
+  (void)U_; (void)gc_; (void)costc_; (void)diagc_; (void)gmax_;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
@@ -1422,10 +1478,10 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     while ((dp + 1) * (dp + 2) / 2 <= dt) ++dp;
     while (dp * (dp + 1) / 2 > dt) --dp;
     dq = dt - dp * (dp + 1) / 2;
-    dv = d.U[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
-    if (dp == dq) dDc = d.diag_c[(size_t)(s.cam_off + ci) * NC + dp];
+    dv = U_[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
+    if (dp == dq) dDc = diagc_[(size_t)(s.cam_off + ci) * NC + dp];
   }
-  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = d.gc[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
+  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = gc_[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
   const int* cpair = d.cam_pair + s.cam_off + s.idx;
   const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;   // this camera's pairs
   constexpr int PS = (NW * NW) | 1;  // doubles per run sum in LDS (odd pitch)
@@ -1791,50 +1847,69 @@ __global__ __launch_bounds__(64) void k_schur_3d(Dev d)
 // of a few scenes: EVERY workgroup computes all candidates into its LDS tables -- lds_cand: the CANDBLK-entry prefix of the
 // camera block, lds_dct: the step as k_eval applies it -- and the scene's first workgroup also stores them, to_global).  cbc: the
 // camera's block at x (global or LDS).  One piece of code, so that a scene's bits do not depend on which of the two runs it.
+template <int TYPE> struct CamIn {  // what a camera's candidate is computed from (all loads of cam_update_load, in flight together)
+  double x15[15], y[Dims<TYPE>::NC], sc[Dims<TYPE>::NC], jl[9], dsp0[3];
+};
 template <int TYPE>
-__device__ __forceinline__ void cam_update_one(const Dev& d, const SceneDev& s, const LmState& st, int sc, int i, const double* cbc,
-                                               bool to_global, double* lds_cand, double* lds_dct)
+__device__ __forceinline__ void cam_update_load(const Dev& d, const SceneDev& s, const LmState& st, int sc, int i, CamIn<TYPE>& in)
+{
+  constexpr int NC = Dims<TYPE>::NC, CBS = Dims<TYPE>::CBS;
+  const int gi = s.cam_off + i;
+  const double* x = cur_cam(d, s, st) + (size_t)i * 15;
+  const double* ysc = d.yc + (size_t)sc * d.chol.np + (size_t)i * NC;  // (the back-substitution leaves the solution in camera order: CholBatch::xperm)
+  const double* cbc = cur_camblk(d, st) + (size_t)gi * CBS;  // Jacobi scales and SO(3) Jacobian of the camera at x
+#pragma unroll
+  for (int k = 0; k < 15; ++k) in.x15[k] = x[k];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { in.y[k] = ysc[k]; in.sc[k] = cbc[CB_S + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) in.jl[k] = cbc[CB_JL + k];
+  if (Dims<TYPE>::DISP) {
+    const double* dx = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)gi * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) in.dsp0[k] = dx[k];
+  }
+}
+template <int TYPE>
+__device__ __forceinline__ void cam_update_apply(const Dev& d, const SceneDev& s, const LmState& st, int sc, int i, const CamIn<TYPE>& in,
+                                                 bool to_global, double* lds_cand, double* lds_dct)
 {
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, DCS = NC | 1;
   const int gi = s.cam_off + i;
-  const double* x = cur_cam(d, s, st) + (size_t)i * 15;
-  double x15[15], c15[15];
+  const double* x15 = in.x15;
+  const double* y = in.y;
+  double c15[15];
 #pragma unroll
-  for (int k = 0; k < 15; ++k) { x15[k] = x[k]; c15[k] = x15[k]; }
-  const double* ysc = d.yc + (size_t)sc * d.chol.np;
-  double y[NC];  // this camera's part of the solution (through the elimination order)
-#pragma unroll
-  for (int k = 0; k < NC; ++k) y[k] = ysc[sys_col(d, sc, i * NC + k)];
+  for (int k = 0; k < 15; ++k) c15[k] = x15[k];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const double step = -y[k];
     if (to_global) d.dc[(size_t)gi * NC + k] = step;
-    if (Dims<TYPE>::at(k) < 15) c15[Dims<TYPE>::at(k) < 15 ? Dims<TYPE>::at(k) : 0] += step * cbc[CB_S + k];
+    if (Dims<TYPE>::at(k) < 15) c15[Dims<TYPE>::at(k) < 15 ? Dims<TYPE>::at(k) : 0] += step * in.sc[k];
   }
   double dsp0[3] = {0, 0, 0}, dsp[3] = {0, 0, 0};
   if (Dims<TYPE>::DISP) {  // the camera's copy of the displacement block (every copy takes the same step: k_group_expand)
-    const double* dx = d.dsp_x + (size_t)st.cur * d.dsp_stride + (size_t)gi * 3;
     double* dxc = d.dsp_x + (size_t)(st.cur ^ 1) * d.dsp_stride + (size_t)gi * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      dsp0[k] = dx[k];
-      dsp[k] = dsp0[k] + (-y[NC - 3 + k]) * cbc[CB_S + NC - 3 + k];
+      dsp0[k] = in.dsp0[k];
+      dsp[k] = dsp0[k] + (-y[NC - 3 + k]) * in.sc[NC - 3 + k];
       if (to_global) dxc[k] = dsp[k];
     }
   }
   {  // the scaled step of the camera's 2D-2D columns as [intrinsic components | om = Jl v_rot] (ba_step_dir), for k_eval
     double sv[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) sv[k] = cbc[CB_S + Dims<TYPE>::pos(k)] * (-y[Dims<TYPE>::pos(k)]);
+    for (int k = 0; k < NW; ++k) sv[k] = in.sc[Dims<TYPE>::pos(k)] * (-y[Dims<TYPE>::pos(k)]);
     double dr[NW];
     constexpr int RW = Dims<TYPE>::RW;  // [columns before the rotation, columns behind it | Jl v_rot]
 #pragma unroll
     for (int k = 0; k < NW - 3; ++k) dr[k] = sv[k < RW ? k : k + 3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      dr[NW - 3 + r] = cbc[CB_JL + 3 * r] * sv[RW] + cbc[CB_JL + 3 * r + 1] * sv[RW + 1] + cbc[CB_JL + 3 * r + 2] * sv[RW + 2];
+      dr[NW - 3 + r] = in.jl[3 * r] * sv[RW] + in.jl[3 * r + 1] * sv[RW + 1] + in.jl[3 * r + 2] * sv[RW + 2];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       if (to_global) d.dct[(size_t)gi * DCS + k] = dr[k];
@@ -1856,7 +1931,7 @@ __device__ __forceinline__ void cam_update_one(const Dev& d, const SceneDev& s, 
 #pragma unroll
   for (int k = 0; k < 15; ++k) xc[k] = c15[k];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) cb[CB_S + k] = cbc[CB_S + k];
+  for (int k = 0; k < NC; ++k) cb[CB_S + k] = in.sc[k];
   double* cfull = d.camblk + (size_t)(st.cur ^ 1) * d.camblk_stride + (size_t)gi * CBS;
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cfull[k] = cb[k];
@@ -1885,7 +1960,7 @@ __device__ __forceinline__ void cam_update_one(const Dev& d, const SceneDev& s, 
     double* tc = d.tlw_x + (size_t)(st.cur ^ 1) * d.tlw_stride + (size_t)s.idx * 6;
     double tn[6];
     for (int k = 0; k < 6; ++k) {
-      const double step = -ysc[sys_col(d, sc, NC * s.n_cam + k)];
+      const double step = -d.yc[(size_t)sc * d.chol.np + NC * s.n_cam + k];
       d.dt[(size_t)s.idx * 6 + k] = step;
       tn[k] = t[k] + step * d.scale_t[(size_t)s.idx * 6 + k];
       tc[k] = tn[k];
@@ -1912,7 +1987,9 @@ __global__ void k_cam_update(Dev d)
   const LmState& st = d.lm[sc];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n_cam) return;
-  cam_update_one<TYPE>(d, s, st, sc, i, cur_camblk(d, st) + (size_t)(s.cam_off + i) * Dims<TYPE>::CBS, true, nullptr, nullptr);
+  CamIn<TYPE> in;
+  cam_update_load<TYPE>(d, s, st, sc, i, in);
+  cam_update_apply<TYPE>(d, s, st, sc, i, in, true, nullptr, nullptr);
 }
 
 // ---- eval: ray back-substitution, model cost change and candidate cost in one ray-centric pass -----------------
@@ -1932,8 +2009,8 @@ __global__ void k_cam_update(Dev d)
 #define EV_STAMP_PRINT do { } while (0)
 #endif
 // FUSE (launch shapes of a few scenes, Dev::fuse_ctl): the launch also does what k_cam_update does before it -- every workgroup
-// computes the scene's candidate cameras into its LDS tables, the first one stores them -- and what k_lm_post does behind it: the
-// last workgroup of the scene to finish closes the step (lm_post_wave).  Three launches of a one-rig pass in one.
+// computes the scene's candidate cameras into its LDS tables, the first one stores them.  (The step is judged behind the
+// speculative camera-side linearisation of the candidate, in k_lin_cam's tail: lm_step_wave.)
 template <int TYPE, bool SMALL, bool GTAB, bool FUSE = false>
 __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
 {
@@ -1941,7 +2018,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
   static_assert(!FUSE || (SMALL && !GTAB), "the folded camera update fills the LDS tables");
-  if (FUSE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) post_progress(d);  // (what k_lm_post's first thread does)
+  if (FUSE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) post_progress(d);  // (no control launch in this shape: see k_lm_post)
   const int sc = scene_of_slot(d, blockIdx.y);
   if (sc < 0) return;
   if (!d.active[sc]) return;
@@ -1968,15 +2045,23 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     double* dct0 = ctab0 + ((s.n_cam * CDS + 5) & ~1);     // [n_cam][DCS] (+ 4) scaled camera step (k_cam_update)
     scratch = dct0 + ((s.n_cam * DCS + 5) & ~1);           // [16]
     obsbuf = reinterpret_cast<float4*>(scratch + 16);
-    tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
     if constexpr (FUSE) {
-      __syncthreads();  // the table at x is there: the candidates read their cameras' Jacobi scales and SO(3) Jacobians from it
-      for (int i = threadIdx.x; i < s.n_cam; i += blockDim.x)
-        cam_update_one<TYPE>(d, s, st, sc, i, tab + i * CBS, blockIdx.x == 0, ctab0 + i * CDS, dct0 + i * DCS);
+      // The candidates of ALL the scene's cameras, by every workgroup: the inputs of a thread's first camera are asked for in
+      // front of the table's staging loads (one memory round trip for both), the arithmetic runs behind them
+      CamIn<TYPE> in;
+      cam_update_load<TYPE>(d, s, st, sc, min((int)threadIdx.x, s.n_cam - 1), in);
+      tab = tab0 + stage_flat<16>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+      if ((int)threadIdx.x < s.n_cam)
+        cam_update_apply<TYPE>(d, s, st, sc, threadIdx.x, in, blockIdx.x == 0, ctab0 + threadIdx.x * CDS, dct0 + threadIdx.x * DCS);
+      for (int i = threadIdx.x + blockDim.x; i < s.n_cam; i += blockDim.x) {
+        cam_update_load<TYPE>(d, s, st, sc, i, in);
+        cam_update_apply<TYPE>(d, s, st, sc, i, in, blockIdx.x == 0, ctab0 + i * CDS, dct0 + i * DCS);
+      }
       ctab = ctab0;
       dct = dct0;
     }
     else {
+      tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
       ctab = ctab0 + stage_flat<SMALL ? 16 : 8>(d.candblk + (size_t)s.cam_off * CDS, ctab0, s.n_cam * CDS);
       dct = dct0 + stage_flat<SMALL ? 16 : 8>(d.dct + (size_t)s.cam_off * DCS, dct0, s.n_cam * DCS);
     }
@@ -2094,10 +2179,6 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   (void)scratch;
   EV_STAMP(7);
   EV_STAMP_PRINT;
-  if constexpr (FUSE) {  // the last workgroup of the scene closes the step (what a k_lm_post launch would do)
-    __shared__ int tail_flag;
-    if (tail_last_workgroup(d.tail_cnt + 2 * sc, (s.n_ray + (int)blockDim.x - 1) / (int)blockDim.x, &tail_flag)) lm_post_wave<TYPE>(d, sc);
-  }
 }
 
 // ---- eval_3d: annotation residuals' share of the model cost change and of the candidate cost -------------------
@@ -2225,6 +2306,124 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_post(Dev d)
   const int sc = scene_of_slot(d, blockIdx.x);
   if (sc < 0 || !d.active[sc]) return;
   lm_post_wave<TYPE>(d, sc);
+}
+
+// ---- lm_step: one trust-region step judged AND the next iteration opened, at one point of the pass ------------------------------
+// For scenes whose camera-side linearisation is speculative (Dev::spec_lin: no annotation residuals, no shared blocks): k_eval has
+// left the candidate's cost and the ray side of its linearisation, k_lin_cam its camera side, all in the half that LmState::cur does
+// not select -- so lm_post_wave's judgement and lm_pre_wave's bookkeeping for the next iteration need nothing in between, and an
+// accepted step is a flip of `cur`.  Every input of both is asked for at once (one memory round trip), the state lives in
+// registers in between and is stored once.  Same decisions in the same order as k_lm_post followed by k_lm_pre.
+template <int TYPE>
+__device__ __forceinline__ void lm_step_wave(const Dev& d, int sc)
+{
+  static_assert(!Dims<TYPE>::HAS3D, "annotation residuals keep k_lm_post / k_lm_pre");
+  const SceneDev s = d.scene[sc];
+  const LmState L0 = d.lm[sc];  // (uniform address: scalar loads, in flight with everything below)
+  const int ray_fail = d.ray_fail[sc], chol_fail = d.chol.fail[sc];
+  const int lane = threadIdx.x & 63;
+  const int hc = L0.cur ^ 1;  // the candidate's half
+  const double* costc_ = d.costc + (size_t)hc * d.lin_cams;
+  const double* gmax_ = d.cam_gmax + (size_t)hc * d.lin_cams;
+  double mcc = 0, cost = 0, dn = 0, cn = 0;   // the step: model cost change, candidate cost, |x - x_c|^2, |x_c|^2
+  double c2 = 0, gm2 = 0;                     // the candidate's linearisation: cost, gradient max-norm
+  for (int c = lane; c < s.n_wave; c += 64) {
+    const double2* pp = reinterpret_cast<const double2*>(d.partial + (size_t)(s.part_off + c) * 4);
+    const double2 a = pp[0], b = pp[1];
+    mcc += a.x; cost += a.y; dn += b.x; cn += b.y;
+    gm2 = fmax(gm2, lin_partial(d, hc)[(size_t)(s.part_off - s.idx + c) * 2]);
+  }
+  for (int i = lane; i < s.n_cam; i += 64) {
+    const int gi = s.cam_off + i;
+    const double2 v = *reinterpret_cast<const double2*>(d.camstep + (size_t)gi * 2);
+    dn += v.x; cn += v.y;
+    c2 += costc_[gi];
+    gm2 = fmax(gm2, gmax_[gi]);
+  }
+  mcc = -wave_sum(mcc); cost = wave_sum(cost); dn = wave_sum(dn); cn = wave_sum(cn);
+  c2 = wave_sum(c2); gm2 = wave_max(gm2);
+  if (lane != 0) return;
+  LmState L = L0;
+  const Opt& o = d.opt;
+  bool retire = false;
+  // ---- the step (k_lm_post)
+  ++L.num_linear_solves;
+  L.reuse_diagonal = 1;  // LevenbergMarquardtStrategy::ComputeStep
+  const bool solve_fail = ray_fail || chol_fail;
+  if (chol_fail & 2) ++L.chain_timeouts;
+  const bool valid = !solve_fail && isfinite(mcc) && isfinite(dn) && mcc > 0.0;
+  L.model_cost_change = mcc;
+  L.it_cost = L.x_cost;
+  if (!valid) {  // HandleInvalidStep
+    ++L.num_consecutive_invalid;
+    if (L.num_consecutive_invalid >= o.max_consecutive_invalid) { L.termination = PTZ_FAILURE; retire = true; }
+    else { L.radius *= 0.5; L.reuse_diagonal = 0; }  // StepIsInvalid
+  }
+  else {
+    L.num_consecutive_invalid = 0;
+    if (!isfinite(cost)) cost = 1.7976931348623157e308;
+    L.candidate_cost = cost;
+    L.cand_norm2 = cn;
+    const double cost_change = L.x_cost - cost;
+    if (sqrt(dn) <= o.parameter_tolerance * (L.x_norm + o.parameter_tolerance)) { L.termination = PTZ_CONVERGENCE; retire = true; }  // ParameterToleranceReached
+    else if (fabs(cost_change) <= o.function_tolerance * L.x_cost) { L.termination = PTZ_CONVERGENCE; retire = true; }              // FunctionToleranceReached
+    else {
+      const double rho = cost_change / mcc;  // TrustRegionStepEvaluator::StepQuality, monotonic steps
+      if (rho > o.min_relative_decrease) {
+        // HandleSuccessfulStep: x <- candidate, whose linearisation is the other half's
+        L.cur ^= 1;
+        L.step_is_successful = 1;
+        const double t = 2.0 * rho - 1.0;
+        L.radius = L.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);  // StepAccepted
+        L.radius = fmin(o.max_radius, L.radius);
+        L.decrease_factor = 2.0;
+        L.reuse_diagonal = 0;
+      }
+      else {
+        // HandleUnsuccessfulStep / StepRejected
+        L.it_cost = cost;
+        L.radius = L.radius / L.decrease_factor;
+        L.decrease_factor *= 2.0;
+        L.reuse_diagonal = 1;
+      }
+    }
+  }
+  // ---- the next iteration (k_lm_pre)
+  if (!retire) {
+    if (L.step_is_successful) {  // the accepted point's cost, gradient max-norm, |x|
+      L.x_cost = c2;
+      L.it_cost = c2;
+      L.grad_max = gm2;
+      L.x_norm = sqrt(L.cand_norm2);
+      ++L.num_jac_evals;
+      ++L.num_successful;
+    }
+    else ++L.num_unsuccessful;
+    L.need_linearize = 0;
+    L.ray_lin_ready = 0;
+    if (L.it_cost < L.final_cost) L.final_cost = L.it_cost;
+    ++L.n_summaries;
+    if (L.iteration >= o.max_num_iterations) { L.termination = PTZ_NO_CONVERGENCE; retire = true; }
+    else if (L.step_is_successful && L.grad_max <= o.gradient_tolerance) { L.termination = PTZ_CONVERGENCE; retire = true; }
+    else if (L.radius <= o.min_radius) { L.termination = PTZ_CONVERGENCE; retire = true; }
+    else {
+      ++L.iteration;
+      ++L.num_lm_steps;
+      L.step_is_successful = 0;
+      d.ray_fail[sc] = 0;
+    }
+  }
+  d.lm[sc] = L;
+  if (retire) retire_scene(d, sc);
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(LM_THREADS) void k_lm_step(Dev d)
+{
+  if (blockIdx.x == 0 && threadIdx.x == 0) post_progress(d);
+  const int sc = scene_of_slot(d, blockIdx.x);
+  if (sc < 0 || !d.active[sc]) return;
+  if constexpr (!Dims<TYPE>::HAS3D) lm_step_wave<TYPE>(d, sc);
 }
 
 // The last workgroup of a scene to get here runs the scene's LM control in its first wave (Dev::fuse_ctl): every thread makes its

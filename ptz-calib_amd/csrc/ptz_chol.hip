@@ -1335,6 +1335,11 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
       }
     }
   }
+  if (cb.xperm) {  // in the caller's numbering (CholBatch::xperm)
+    const int* xp = cb.xperm + (size_t)sys * nt;
+    for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[xp[j / NB] * NB + j % NB] : 0.0;
+    return;
+  }
   for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[j] : 0.0;
 }
 

@@ -245,6 +245,10 @@ struct CholBatch {
   // group counts (chol_backsolve_plan, made on the host with the structure), or nullptr: the kernel makes the list itself
   const struct BsItem* bs_items = nullptr;
   const int* bs_groups = nullptr;
+  // device [count][np / NB] or nullptr: elimination order of the tiles (the bundle adjustment's Dev::tperm).  With it the
+  // back-substitution writes x in the CALLER's numbering -- x[c] = solution of row tperm[c / NB] * NB + c % NB -- so that the
+  // reader of the solution (the camera update, on the critical path of a pass) needs no lookup in front of its loads
+  const int* xperm = nullptr;
 };
 // one 64 x 64 tile product of the back-substitution: kind 0 empty slot, 1 x = M^T t (inverse of a diagonal tile), 2 t -= M^T x
 struct BsItem { long long off; int ld, in_off, out_off, kind; };
