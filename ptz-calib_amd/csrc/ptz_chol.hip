@@ -39,6 +39,24 @@ __device__ __forceinline__ double rsqrt_nr(double d)
   return y;
 }
 
+// The same to working precision with ONE cubic step: y = y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2 -- five dependent operations
+// instead of eight; and the reciprocal likewise, r = r0 (1 + e + e^2), e = 1 - d r0, three.  For the pivot chain of the diagonal
+// tile, where every dependent operation is paid 64 times per tile.
+__device__ __forceinline__ double rsqrt_cubic(double d)
+{
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double t = d * y0;
+  const double e = fma(-t, y0, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  return fma(y0, e * p, y0);
+}
+__device__ __forceinline__ double rcp_cubic(double d)
+{
+  const double r0 = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r0, 1.0);
+  return fma(r0, fma(e, e, e), r0);
+}
+
 // coalesced 64x64 tile copy global (row stride ld) -> LDS (row stride LD); nthreads * 16 B per pass
 template <int NTHREADS, bool NEGATE>
 __device__ __forceinline__ void tile_g2s(const double* __restrict__ g, int ld, double* s)
@@ -144,8 +162,39 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
   // step, the updates of the columns further right fill its latency.  The scheduling fences keep the compiler from
   // deferring those updates (it otherwise turns the sweep left-looking: a dependent chain of j products in front of
   // every pivot).
+#ifndef PTZ_SWEEP_VARIANT
+#define PTZ_SWEEP_VARIANT 0
+#endif
+#if PTZ_SWEEP_VARIANT == 2
+  // The chain d_j -> d_{j+1} through the RECIPROCAL of the pivot only: with the unscaled column u = A[:, j] and w = u / d_j the
+  // update is A[r][q] -= u_r w_q, so the next pivot waits for rcp + 3 + 2 operations; the column of L, u / sqrt(d_j), and
+  // 1 / L_jj for the block inverses are finished beside the chain.
   double d = readlane_f64(a[0], 0);
-  ird[0] = rsqrt_nr(d);
+#pragma unroll
+  for (int j = 0; j < DB; ++j) {
+    const bool live = (kbase + DB * b + j) < n;
+    dmin = fmin(dmin, live ? d : 1.0);  // NaN pivots: fmin keeps the other operand, caught by `bad`
+    bad |= (d != d) && live;
+    const double dj = d;
+    const double w = a[j] * rcp_cubic(dj);
+    if (j + 1 < DB) {
+      a[j + 1] = fma(-a[j], readlane_f64(w, j + 1), a[j + 1]);
+      d = readlane_f64(a[j + 1], j + 1);
+    }
+#pragma unroll
+    for (int q = j + 2; q < DB; ++q) a[q] = fma(-a[j], readlane_f64(w, q), a[q]);  // A[r][q] -= u_r u_q / d
+    ird[j] = rsqrt_nr(dj);
+    a[j] = a[j] * ird[j];  // lane j: sqrt(d); lanes below: L[r][j]; lanes above (diagonal block): 0
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
+#if PTZ_SWEEP_VARIANT == 1
+#define PTZ_SWEEP_RSQRT rsqrt_cubic
+#else
+#define PTZ_SWEEP_RSQRT rsqrt_nr
+#endif
+  double d = readlane_f64(a[0], 0);
+  ird[0] = PTZ_SWEEP_RSQRT(d);
 #pragma unroll
   for (int j = 0; j < DB; ++j) {
     const bool live = (kbase + DB * b + j) < n;
@@ -156,12 +205,13 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
     if (j + 1 < DB) {
       a[j + 1] -= l * readlane_f64(l, j + 1);
       d = readlane_f64(a[j + 1], j + 1);
-      ird[j + 1] = rsqrt_nr(d);
+      ird[j + 1] = PTZ_SWEEP_RSQRT(d);
     }
 #pragma unroll
     for (int q = j + 2; q < DB; ++q) a[q] -= l * readlane_f64(l, q);  // A[r][q] -= L[r][j] L[q][j]
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < DB; ++j) As[(DB * b + j) * LD + NB] = ird[j];  // 1 / L[j][j] in the padding column of the tile image, for the block inverses

@@ -432,24 +432,34 @@ def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, 
 
 
 def test_ba_control_inside_the_kernels_has_the_bits_of_its_own_launches(pkg, scene_c1, monkeypatch):
-    """Launch shapes of a few scenes run LM control and the camera update INSIDE k_eval / k_lin_cam (the last workgroup of a scene
-    to finish runs lm_post_wave / lm_pre_wave, every workgroup computes the candidate cameras in its prologue); larger shapes and
-    PTZ_BA_FUSE_CTL=0 launch k_cam_update / k_lm_post / k_lm_pre.  Same one-wave code either way: same bits, also for a scene
-    with rejected steps and for a batch that moves from the large shape to the small one while it thins out."""
-    medium = pkg.synth.make_scene(6, 60, 300)   # (has rejected steps: test_ba_medium_parity)
+    """Launch shapes of a few scenes run LM control and the camera update INSIDE k_lin_cam / k_eval (the last workgroup of a scene
+    to finish the speculative camera-side linearisation runs lm_step_wave, every workgroup of k_eval computes the candidate cameras
+    in its prologue); larger shapes and PTZ_BA_FUSE_CTL=0 launch k_cam_update and k_lm_step.  Same one-wave code either way: same
+    bits, also for scenes with rejected steps (the candidate's linearisation is then discarded) and for a batch that moves from
+    the large shape to the small one while it thins out."""
+    rng = np.random.default_rng(7)
+    hard = []
+    for i in range(6):  # noisy, badly initialised, with gross outliers: rejected steps occur
+        sc = pkg.synth.make_scene(900 + i, int(rng.integers(8, 18)), int(rng.integers(40, 71)), noise_px=float(rng.uniform(1.0, 2.5)),
+                                  init_rot_sigma_deg=float(rng.uniform(3.0, 6.0)), init_focal=float(rng.uniform(1000, 6000)))
+        sc.obs_uv = sc.obs_uv.copy()
+        bad = rng.choice(sc.n_obs, size=max(1, sc.n_obs // 60), replace=False)
+        sc.obs_uv[bad] += rng.uniform(-60, 60, (len(bad), 2)).astype(np.float32)
+        hard.append(sc)
     dist = pkg.synth.make_scene(3, 20, 100, factor_type=1)
-    fused = [pkg.api.ba_solve(sc) for sc in (scene_c1, medium, dist)]
-    assert fused[1][2]["num_unsuccessful_steps"] > 0
+    scenes = [scene_c1, dist] + hard
+    fused = [pkg.api.ba_solve(sc) for sc in scenes]
+    assert sum(f[2]["num_unsuccessful_steps"] for f in fused) > 0
     monkeypatch.setenv("PTZ_BA_FUSE_CTL", "0")
-    for sc, ref in zip((scene_c1, medium, dist), fused):
+    for sc, ref in zip(scenes, fused):
         cam, ray, summ = pkg.api.ba_solve(sc)
         assert summ == ref[2] and np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1])
     monkeypatch.delenv("PTZ_BA_FUSE_CTL")
     # 12 scenes: full-size passes with launches of their own, then the compacted 8-slot shape with the control inside
-    scenes = [pkg.synth.make_scene(s, 20 + 2 * (s % 4), 100) for s in range(12)]
-    b = pkg.api.BaBatch(scenes); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
+    many = [pkg.synth.make_scene(s, 20 + 2 * (s % 4), 100) for s in range(12)]
+    b = pkg.api.BaBatch(many); b.set_state(); summ = b.solve(); cams, rays = b.get_state(); b.close()
     for k in (0, 5, 11):
-        cam, ray, s1 = pkg.api.ba_solve(scenes[k])
+        cam, ray, s1 = pkg.api.ba_solve(many[k])
         assert s1 == summ[k] and np.array_equal(cam, cams[k]) and np.array_equal(ray, rays[k])
 
 
