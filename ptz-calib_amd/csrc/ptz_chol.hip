@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ptz_common.h"
 
@@ -225,6 +226,9 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 
 // inverse of the 16 x 16 diagonal block b of the factored tile by forward substitution, one wave, lane c = column c of
 // X = L_bb^-1:  X[i][c] = (delta_ic - sum_{m < i} L[i][m] X[m][c]) / L[i][i]   (the L entries are LDS broadcasts)
+// (THROUGH: the stores go through to memory -- agent-scope stores -- so that a flag raised by this wave behind them, after an
+//  s_waitcnt, publishes the block without a write-back of the whole L2: the last hand-over of a tile in chol_chain_kernel)
+template <bool THROUGH = false>
 __device__ __forceinline__ void diag_block_inverse(const double* As, int b, double* out, double* out_lds)
 {
   const int lane = threadIdx.x & 63, fr = lane & 15;
@@ -243,7 +247,11 @@ __device__ __forceinline__ void diag_block_inverse(const double* As, int b, doub
   }
   if (lane < DB) {
 #pragma unroll
-    for (int i = 0; i < DB; ++i) { out[i * DB + fr] = x[i]; out_lds[i * LDD + fr] = x[i]; }
+    for (int i = 0; i < DB; ++i) {
+      if (THROUGH) __hip_atomic_store(&out[i * DB + fr], x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else out[i * DB + fr] = x[i];
+      out_lds[i * LDD + fr] = x[i];
+    }
   }
 }
 
@@ -300,7 +308,11 @@ __device__ __forceinline__ void tile_inverse(const double* Ls, const double* Dis
   }
 }
 
-__device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n)
+// Fk (chol_chain_kernel only): four flags of this tile; flag b is raised with `gen` once column block b of L_kk (its rows below the
+// diagonal block) and the inverse of its diagonal block are in global memory -- blocks 0..2 here, beside the chain (by the idle
+// fourth wave, a sweep after the block was stored); block 3 by the wave that inverts the last diagonal block.
+__device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n,
+                                                 int* Fk = nullptr, int gen = 0)
 {
   const int np = cb.np, nt = np / NB;
   int& okflag = *okflag_p;
@@ -312,6 +324,13 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
   bool bad = false;
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
+    if (w == 3 && Fk && b >= 2) {
+      // Block b - 2 was stored by waves 1 and 2 during the previous sweep and the barrier at its end lies behind them (their stores
+      // are in this XCD's L2): the fourth wave, which has no rows left to update, writes the L2 back and raises the block's flag.
+      // (A fence in the storing waves made them miss that barrier -- inverse + fence outlast a sweep.)
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(&Fk[b - 2], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (b > 0) {
       // bring column block b up to date: wave w takes the 16-row block ri = b + w:  C(ri, b) -= sum_{m < b} X(ri, m) X(b, m)^T
       const int ri = b + w;
@@ -338,8 +357,22 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
     __syncthreads();
   }
   if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
-  if (w == 1) diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
+  if (w == 1) {
+    if (Fk) {
+      // the LAST block's flag: all a consumer still needs is the inverse of the last diagonal block (the block column has no rows
+      // below it), so the wave that computes it publishes it itself -- stores through to memory, wait for them, flag -- instead of
+      // the workgroup-wide fence + barrier + flag that every other hand-over takes
+      diag_block_inverse<true>(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      if (lane == 0) __hip_atomic_store(&Fk[NB / DB - 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
+  }
   else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
+  else if (w == 3 && Fk) {
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(&Fk[NB / DB - 2], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   (void)okflag;
   if (cb.L && cb.Linv && k == nt - 1) {
     // the last diagonal tile has no later launch whose spare workgroup could invert it
@@ -633,6 +666,48 @@ __device__ __forceinline__ void trsm_rows_to_lds(const d16v rows, int ldg, const
   }
 }
 
+// The same solve one 16-column block at a time (chol_chain_kernel takes the blocks of L_kk as its producer publishes them):
+//   trsm_block_pre<C>    acc[C] -= sum_{q < C} X_q L_Cq^T        needs the blocks (C, q), q < C, of L_kk and X_0 .. X_{C-1} in xs
+//   trsm_block_solve<C>  X_C = acc[C] Dinv_C^T -> xs (and store_to)  needs Dinv_C
+// Same operations in the same order as trsm_rows_to_lds.
+template <int C>
+__device__ __forceinline__ void trsm_block_pre(d4 (&acc)[4], const double* Lk, const double* xs)
+{
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < C; ++q)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double av = -xs[fr * LD + 16 * q + 4 * ks + fq];
+      const double bv = Lk[(16 * C + fr) * LD + 16 * q + 4 * ks + fq];
+      acc[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[C], 0, 0, 0);
+    }
+}
+template <int C>
+__device__ __forceinline__ void trsm_block_solve(const d4 (&acc)[4], int ldg, const double* Di, double* xs, double* __restrict__ store_to)
+{
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xs[(fq + 4 * i) * LD + 16 * C + fr] = acc[C][i];
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): these rows are private to this wave
+  d4 xc = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const double av = xs[fr * LD + 16 * C + 4 * ks + fq];
+    const double bv = Di[C * DB * LDD + fr * LDD + 4 * ks + fq];
+    xc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xc, 0, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xs[(fq + 4 * i) * LD + 16 * C + fr] = xc[i];
+    if (store_to) store_to[(size_t)(fq + 4 * i) * ldg + 16 * C + fr] = xc[i];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
 // kmin: no system factors a block column below it in this step, so only the tiles (ti, tj), ti >= tj > kmin, can have work
 #ifdef PTZ_CHOL_STAMPS  // probe builds only: where the workgroup of a step's NEXT diagonal tile spends its time (100 MHz wall clock)
 #define CS_STAMP(i) do { if (threadIdx.x == 0) cs_t[i] = wall_clock64(); } while (0)
@@ -644,6 +719,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 #ifdef PTZ_CHOL_STAMPS
   long long cs_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   cs_t[0] = wall_clock64();
+  __shared__ long long cs_q[3][16];  // per column of the list: T flags seen, block 0 seen, update done
 #endif
   int bx, slot;
   xcd_remap(bx, slot);
@@ -824,8 +900,8 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   if (ti * NB > n || tj * NB > n) return;  // padding
   const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
   if (tm && !tm[ti * nt + tj]) return;
-  int* F = cb.chain_ctl + 4 + (size_t)slot * (nt + nt * nt);  // F[k]: diagonal tile k factored and published
-  int* T = F + nt;                                            // T[i * nt + k]: tile (i, k) final in A
+  int* F = cb.chain_ctl + 4 + (size_t)slot * (4 * nt + nt * nt);  // F[4 k + b]: block b of diagonal tile k factored and published
+  int* T = F + 4 * nt;                                            // T[i * nt + k]: tile (i, k) final in A
   if (threadIdx.x < 64) {  // the update list, as chol_update_col_kernel makes it (schedule order)
     const int nq = cb.sched ? CHOL_STEP_COLS * cb.n_steps : tj;
     const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * CHOL_STEP_COLS : nullptr;
@@ -864,8 +940,9 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     for (int i = 0; i < 4; ++i) acc[c][i] = C[(size_t)(fq + 4 * i) * np + 16 * c + fr];
   const double* Bop = ti == tj ? As : Bs;
 #ifdef PTZ_CHOL_STAMPS
-  long long cs_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long cs_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   cs_t[0] = wall_clock64();
+  __shared__ long long cs_q[3][16];  // per column of the list: T flags seen, block 0 seen, update done
 #endif
   for (int q = 0; q < Q; ++q) {
     const int k = klist[q];
@@ -876,32 +953,115 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef PTZ_CHOL_STAMPS
+    if (threadIdx.x == 0 && q < 16) cs_q[0][q] = wall_clock64();
+#endif
     // the rows to be solved for are on their way while the workgroup waits for L_kk
     const d16v rik = trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
     d16v rjk = rik;
     if (ti != tj) rjk = trsm_rows_fetch(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np);
-    if (threadIdx.x == 0 && !chain_wait(&F[k], gen, spin)) atomicOr(&cb.fail[sys], 2);
-    CS_STAMP(1);  // (of the last column of the list)
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    tile_g2s<256, false>(cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB), NB, Lk);
+    // L_kk comes in four 16-column blocks, each with its flag (diag_factor_tile raises them as the blocks reach global memory):
+    // block c is staged, X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T solved for and its share of the update applied while the
+    // producer still works on the blocks behind it -- when the LAST block arrives, all that is left on the chain is its 16 x 16
+    // inverse, one product with it and a quarter of the update (was: the whole tile, the whole solve, the whole update).
+    const double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
     const double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
-    for (int idx = threadIdx.x; idx < 4 * DB * DB; idx += 256) Di[(idx >> 8) * DB * LDD + ((idx >> 4) & 15) * LDD + (idx & 15)] = Dg[idx];
-    __syncthreads();
     double* Lik = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k * NB;
-    trsm_rows_to_lds(rik, np, Lk, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
-    if (ti != tj) trsm_rows_to_lds(rjk, np, Lk, Di, Bs + 16 * w * LD, nullptr);
-    CS_STAMP(2);
-    __syncthreads();
+    d4 xa[4], xb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xa[c][i] = rik[4 * c + i]; xb[c][i] = rjk[4 * c + i]; }
     const double* ap = As + (16 * w + fr) * LD + fq;
     const double* bp = Bop + fr * LD + fq;
+    // One look at all four flags first (a look is a memory round trip): the blocks that are there already are asked for at once, so
+    // that a column whose producer finished long ago costs two round trips, not eight; only the blocks still to come are waited for
+    // one by one -- and while one of those is fetched, the next flag is looked at, so that a consumer on the critical chain keeps
+    // up with its producer's sweeps.
+    struct Blk { double2 l0, l1; double di; };
+    Blk rb[4];
+    int pk[4];
 #pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-      const double av = -ap[4 * kk];
+    for (int c = 0; c < 4; ++c) pk[c] = lane == 0 ? __hip_atomic_load(&F[4 * k + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int have = 0;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * cc) * LD + 4 * kk], acc[cc], 0, 0, 0);
-    }
+    for (int c = 0; c < 4; ++c) { pk[c] = __builtin_amdgcn_readfirstlane(pk[c]); if (have == c && pk[c] == gen) have = c + 1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    auto fetch = [&](auto cc) {  // block column c of L_kk below its diagonal block (rows 16 (c + 1) .. 63) and the inverse of that diagonal block
+      constexpr int c = decltype(cc)::value;
+      constexpr int rows = NB - DB * (c + 1), items = rows * (DB / 2);
+      Blk r;
+      r.l0 = make_double2(0.0, 0.0); r.l1 = r.l0;
+      if (items > 0) {
+        const int i0 = min((int)threadIdx.x, max(items - 1, 0));
+        r.l0 = *reinterpret_cast<const double2*>(Lg + (size_t)(DB * (c + 1) + i0 / (DB / 2)) * NB + DB * c + (i0 % (DB / 2)) * 2);
+      }
+      if (items > 256) {
+        const int i1 = min((int)threadIdx.x + 256, max(items - 1, 0));
+        r.l1 = *reinterpret_cast<const double2*>(Lg + (size_t)(DB * (c + 1) + i1 / (DB / 2)) * NB + DB * c + (i1 % (DB / 2)) * 2);
+      }
+      r.di = Dg[c * (DB * DB) + threadIdx.x];
+      return r;
+    };
+    auto stash = [&](auto cc, const Blk& r) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int rows = NB - DB * (c + 1), items = rows * (DB / 2);
+      if (items > 0 && (int)threadIdx.x < items) {
+        const int i0 = threadIdx.x;
+        *reinterpret_cast<double2*>(Lk + (DB * (c + 1) + i0 / (DB / 2)) * LD + DB * c + (i0 % (DB / 2)) * 2) = r.l0;
+      }
+      if (items > 256 && (int)threadIdx.x + 256 < items) {
+        const int i1 = threadIdx.x + 256;
+        *reinterpret_cast<double2*>(Lk + (DB * (c + 1) + i1 / (DB / 2)) * LD + DB * c + (i1 % (DB / 2)) * 2) = r.l1;
+      }
+      Di[c * DB * LDD + (threadIdx.x >> 4) * LDD + (threadIdx.x & 15)] = r.di;
+    };
+    if (have > 0) rb[0] = fetch(std::integral_constant<int, 0>{});
+    if (have > 1) rb[1] = fetch(std::integral_constant<int, 1>{});
+    if (have > 2) rb[2] = fetch(std::integral_constant<int, 2>{});
+    if (have > 3) rb[3] = fetch(std::integral_constant<int, 3>{});
+    auto block = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      // what needs only the earlier blocks, in front of the wait
+      trsm_block_pre<c>(xa, Lk, As + 16 * w * LD);
+      if (ti != tj) trsm_block_pre<c>(xb, Lk, Bs + 16 * w * LD);
+      if (c >= have) {  // (uniform)
+        if (pk[c] != gen) {  // (the look taken while the previous block was fetched did not find it yet)
+          if (lane == 0 && !chain_wait(&F[4 * k + c], gen, spin)) atomicOr(&cb.fail[sys], 2);  // (every wave polls: no barrier to pass the news on)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        rb[c] = fetch(cc);
+        if (c < 3) {  // a look at the next flag rides with this block's fetch
+          int nf = lane == 0 ? __hip_atomic_load(&F[4 * k + (c < 3 ? c + 1 : 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          pk[c < 3 ? c + 1 : 3] = __builtin_amdgcn_readfirstlane(nf);
+        }
+      }
+      CS_STAMP(8 + c);  // (of the last column of the list)
+      if (c == 3) CS_STAMP(1);
+#ifdef PTZ_CHOL_STAMPS
+      if (c == 0 && threadIdx.x == 0 && q < 16) cs_q[1][q] = wall_clock64();
+#endif
+      stash(cc, rb[c]);
+      __syncthreads();
+      trsm_block_solve<c>(xa, np, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
+      if (ti != tj) trsm_block_solve<c>(xb, np, Di, Bs + 16 * w * LD, nullptr);
+      __syncthreads();  // X_c of every wave is in LDS
+#pragma unroll
+      for (int kk = 4 * c; kk < 4 * c + 4; ++kk) {
+        const double av = -ap[4 * kk];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) acc[q4] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * q4) * LD + 4 * kk], acc[q4], 0, 0, 0);
+      }
+    };
+    block(std::integral_constant<int, 0>{});
+    block(std::integral_constant<int, 1>{});
+    block(std::integral_constant<int, 2>{});
+    block(std::integral_constant<int, 3>{});
+    CS_STAMP(2);
     CS_STAMP(3);
+#ifdef PTZ_CHOL_STAMPS
+    if (threadIdx.x == 0 && q < 16) cs_q[2][q] = wall_clock64();
+#endif
   }
   if (ti == tj) {
     __syncthreads();  // all waves are done reading the operand tiles
@@ -911,16 +1071,23 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
     __syncthreads();
     CS_STAMP(4);
-    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (the last tile also inverts itself there)
+    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
     CS_STAMP(5);
-    chain_post(&F[ti], gen);
+    // (F[4 ti + 3] was raised inside, by the wave that inverted the last diagonal block)
 #ifdef PTZ_CHOL_STAMPS
     CS_STAMP(6);
     if (threadIdx.x == 0 && slot == 0)
-      printf("chol_chain tile %d updates %d | x10 ns since the workgroup started: last flag seen %lld, operands solved +%lld, update +%lld, to LDS +%lld, diagonal factor +%lld, posted +%lld | absolute: seen %lld posted %lld\n",
-             ti, Q, cs_t[1] - cs_t[0], cs_t[2] - cs_t[1], cs_t[3] - cs_t[2], cs_t[4] - cs_t[3], cs_t[5] - cs_t[4], cs_t[6] - cs_t[5], cs_t[1] % 100000000ll, cs_t[6] % 100000000ll);
+      printf("chol_chain tile %d updates %d | absolute x10 ns: block flags of the last column seen %lld %lld %lld %lld, solved+updated %lld, in LDS %lld, factored %lld, posted %lld\n",
+             ti, Q, cs_t[8] % 100000000ll, cs_t[9] % 100000000ll, cs_t[10] % 100000000ll, cs_t[11] % 100000000ll, cs_t[2] % 100000000ll, cs_t[4] % 100000000ll,
+             cs_t[5] % 100000000ll, cs_t[6] % 100000000ll);
+    if (threadIdx.x == 0 && slot == 0)
+      for (int qq = 0; qq < Q && qq < 16; ++qq)
+        printf("chol_chaincol tile %d column %d: T seen %lld, block 0 seen %lld, applied %lld\n", ti, (int)klist[qq], cs_q[0][qq] % 100000000ll, cs_q[1][qq] % 100000000ll, cs_q[2][qq] % 100000000ll);
 #endif
-    if (cb.Linv && ti != nt - 1) tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + ti) * (NB * NB));  // off the chain: for the back-substitution
+    if (cb.Linv && ti != nt - 1) {
+      __syncthreads();  // the block inverses of all four blocks are in LDS
+      tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + ti) * (NB * NB));  // off the chain: for the back-substitution
+    }
     return;
   }
 #pragma unroll

@@ -298,8 +298,9 @@ inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int
   return g;
 }
 // ints behind CholBatch::chain_ctl: [0] next ticket, [1] workgroups done, [2] generation of the last finished launch, then for
-// each of up to 8 slots nt "diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
-inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + 8 * (nt + nt * nt); }
+// each of up to 8 slots 4 nt "block b of diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
+// ("diagonal tile k factored" is FOUR flags, one per 16-column block of the tile: consumers take the blocks as they come)
+inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + 8 * (4 * nt + nt * nt); }
 __device__ __forceinline__ int chol_system_of(const CholBatch& cb, int slot)
 {
   if (!cb.act) return slot;
