@@ -206,6 +206,41 @@ int32_t ptz_ba_batch_pix2ray(ptz_ba_batch* b);
 int32_t ptz_ba_solve_sharded(int32_t n, const ptz_ba_problem* problems, double* cam, double* ray, double* tlw,
                              const int32_t* device_ids, int32_t n_devices, const ptz_lm_options* opt, ptz_lm_summary* summaries);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rig-resident tracks: bundle adjustments over candidate SUBSETS of one rig without rebuilding the problem on the host
+ *   PTZ-IBA adjusts a growing subset of one rig's images ~2N times (AdjustGlobalBundle after every ~10 % of new registrations,
+ *   src/core/ptz_incremental_optimizer.cc:91, 420-440), and the reference re-walks the match table into a fresh
+ *   PTZRayOptimizer each time (ptzray_optimizer.cc:537-552, 799-850).  Here the rig's tracks (TracksBuilder output after
+ *   Filter(4), tracks.cc:19-113) are uploaded ONCE; a bundle adjustment is then a VIEW of them -- the ascending list of candidate
+ *   images -- and the packed problem AddConstraints2d2d would produce for that candidate set (observations in (track, image)
+ *   order, full-track weights :805, the library's internal ray order, camera-major lists, camera pairs) is built ON THE DEVICE,
+ *   word for word the arrays ptz_ba_batch_create builds from the host-packed problem: same batch, same bits.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ptz_rig ptz_rig; /* opaque: one rig's tracks, resident in HBM */
+/* trk_ptr [n_track + 1] offsets into the view arrays; per view of a track (image ids ascending inside a track, the order of
+ * the reference's map of maps): trk_img [n_view] image id in [0, n_img), trk_uv [2 * n_view] the keypoint's pixel (cv::Point2f). */
+int32_t ptz_rig_create(int32_t n_img, int32_t n_track, const int64_t* trk_ptr, const int32_t* trk_img, const float* trk_uv,
+                       int32_t device_id, ptz_rig** out);
+void ptz_rig_destroy(ptz_rig* rig);
+typedef struct ptz_rig_view {
+  const ptz_rig* rig;
+  int32_t n_cam;             /* candidate images */
+  const int32_t* cam_image;  /* host [n_cam] image ids, ascending: compact camera c is image cam_image[c] (SetUpInitialCameraParams' order) */
+} ptz_rig_view;
+/* The batch ptz_ba_batch_create would build from the n packed problems of these views (2D-2D residuals only, no shared
+ * intrinsics): tracks without a candidate view are not rays of the problem; a view without any candidate observation is
+ * PTZ_EINVAL.  Ray i of problem k, for set/get_state, is the i-th track of the rig (ascending) that has a candidate view. */
+int32_t ptz_ba_batch_create_views(int32_t n, const ptz_rig_view* views, int32_t factor_type, const ptz_lm_options* opt,
+                                  ptz_ba_batch** out);
+/* Initial state of a batch: cameras cam [15 * sum n_cam] and, computed ON THE DEVICE, the rays by Pix2Ray
+ * (ptzray_optimizer.cc:768-797): ray = normalise(mean over the candidate views of normalise(R^-1 K^-1 [u, v, 1])), with the
+ * per-camera matrices rkinv [9 * sum n_cam] = R^-1 K^-1 as the caller's (reference's) matrix code evaluates them -- the same
+ * operations in the same order as a host loop over the track's views, without contraction: the same bits.  T_l_w = 0. */
+int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const double* rkinv);
+/* Diagnostic for the tests: FNV-1a hash over the batch's structure arrays (observations in the library's order, ray and
+ * camera lists, camera pairs, entries, runs, weights, ray order), real extents only -- two batches that hash alike solve alike. */
+int32_t ptz_debug_batch_structure_hash(ptz_ba_batch* b, uint64_t* hash);
+
 /* Dense SPD solve used for the reduced camera system, exposed for parity tests and micro-benchmarks:
  * solves A x = rhs for `count` independent n x n systems (host, row-major, lower triangle read).
  * Returns per-system status in fail[count] (1 = not positive definite). */

@@ -25,7 +25,8 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_ba_batch_linearize", "ptz_ba_batch_pix2ray", "ptz_ba_batch_cam_block_dim", "ptz_chol_solve_batch", "ptz_krt_solve_batch",
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
            "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp",
-           "ptz_ba_plan_tile_order"]
+           "ptz_ba_plan_tile_order", "ptz_rig_create", "ptz_rig_destroy", "ptz_ba_batch_create_views", "ptz_ba_batch_set_state_pix2ray",
+           "ptz_debug_batch_structure_hash"]
 
 
 class PtzError(RuntimeError):
@@ -222,6 +223,103 @@ class BaBatch:
         _check(lib().ptz_ba_batch_linearize(self.handle, index, C.byref(cost), _p(g_c), _p(U), _p(g_r), _p(V), _p(W)),
                "ptz_ba_batch_linearize")
         return dict(cost=cost.value, g_c=g_c, U=U, g_r=g_r, V=V, W=W, nc=nc)
+
+
+class RigView(C.Structure):
+    _fields_ = [("rig", C.c_void_p), ("n_cam", C.c_int32), ("cam_image", C.c_void_p)]
+
+
+class Rig:
+    """One rig's tracks resident in HBM (ptz_rig_create): trk_ptr [n_track + 1], per view the image id (ascending inside a
+    track) and the pixel."""
+
+    def __init__(self, n_img, trk_ptr, trk_img, trk_uv, device_id=0):
+        self.n_img = int(n_img)
+        self.trk_ptr = np.ascontiguousarray(trk_ptr, dtype=np.int64)
+        self.trk_img = np.ascontiguousarray(trk_img, dtype=np.int32)
+        self.trk_uv = np.ascontiguousarray(trk_uv, dtype=np.float32)
+        self.handle = C.c_void_p()
+        _check(lib().ptz_rig_create(self.n_img, len(self.trk_ptr) - 1, _p(self.trk_ptr), _p(self.trk_img), _p(self.trk_uv), int(device_id),
+                                    C.byref(self.handle)), "ptz_rig_create")
+
+    @classmethod
+    def from_scene(cls, sc, device_id=0):
+        """The tracks of a synthetic scene (its observations are (track, image)-ordered: every ray is one track)."""
+        ptr = np.concatenate([[0], np.cumsum(np.bincount(sc.obs_ray, minlength=sc.n_ray))]).astype(np.int64)
+        return cls(sc.n_cam, ptr, sc.obs_cam, sc.obs_uv, device_id)
+
+    def close(self):
+        if self.handle:
+            lib().ptz_rig_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def view_problem(sc, images):
+    """The packed problem of the candidate set `images` (ascending) of a synthetic scene, as PTZRayOptimizer::Pack makes it on the
+    host: observations of candidate views in (track, image) order, tracks without one dropped, cameras and rays renumbered,
+    weights = FULL track length (ptzray_optimizer.cc:805).  Returns a scene-like object for BaBatch."""
+    import copy
+    images = np.asarray(images, dtype=np.int64)
+    cmap = -np.ones(sc.n_cam, dtype=np.int64)
+    cmap[images] = np.arange(len(images))
+    keep = cmap[sc.obs_cam] >= 0
+    v = copy.copy(sc)
+    v.n_cam = len(images)
+    v.obs_uv = sc.obs_uv[keep]
+    v.obs_cam = cmap[sc.obs_cam[keep]].astype(np.int32)
+    tracks, new_ray = np.unique(sc.obs_ray[keep], return_inverse=True)
+    v.obs_ray = new_ray.astype(np.int32)
+    v.n_ray = len(tracks)
+    v.ray_weight = np.bincount(sc.obs_ray, minlength=sc.n_ray)[tracks].astype(np.float64)
+    v.cam_init = sc.cam_init[images].copy(); v.cam_gt = sc.cam_gt[images].copy()
+    v.ray_init = sc.ray_init[tracks].copy(); v.ray_gt = sc.ray_gt[tracks].copy()
+    v.ic_of_cam = None
+    v.view_tracks = tracks
+    return v
+
+
+class ViewBatch(BaBatch):
+    """ptz_ba_batch_create_views: the batch of the packed problems of (rig, candidate images) views, built on the device."""
+
+    def __init__(self, rigs, image_lists, factor_type=0, **opt):
+        self.scenes = []
+        self.n = len(rigs)
+        self._keep = [np.ascontiguousarray(im, dtype=np.int32) for im in image_lists]
+        views = (RigView * self.n)()
+        for i, (rg, im) in enumerate(zip(rigs, self._keep)):
+            views[i].rig = rg.handle
+            views[i].n_cam = len(im)
+            views[i].cam_image = _p(im)
+        self.opt = default_options(**opt)
+        self.handle = C.c_void_p()
+        _check(lib().ptz_ba_batch_create_views(self.n, views, int(factor_type), C.byref(self.opt), C.byref(self.handle)), "ptz_ba_batch_create_views")
+        self.nw = int(lib().ptz_ba_cam_block_dim(int(factor_type)))
+        self.nc = int(lib().ptz_ba_batch_cam_block_dim(self.handle))
+        self.n_cams = [len(im) for im in self._keep]
+
+    def set_state_pix2ray(self, cams, rkinv):
+        cam = np.ascontiguousarray(np.concatenate(cams), dtype=np.float64)
+        rk = np.ascontiguousarray(np.concatenate(rkinv), dtype=np.float64)
+        _check(lib().ptz_ba_batch_set_state_pix2ray(self.handle, _p(cam), _p(rk)), "ptz_ba_batch_set_state_pix2ray")
+
+    def get_cams(self):
+        cam = np.zeros((int(sum(self.n_cams)), 15))
+        tlw = np.zeros((self.n, 6))
+        _check(lib().ptz_ba_batch_get_state(self.handle, _p(cam), None, _p(tlw)), "ptz_ba_batch_get_state")
+        off = np.concatenate([[0], np.cumsum(self.n_cams)])
+        return [cam[off[i]:off[i + 1]] for i in range(self.n)]
+
+
+def structure_hash(batch) -> int:
+    h = C.c_uint64()
+    _check(lib().ptz_debug_batch_structure_hash(batch.handle, C.byref(h)), "ptz_debug_batch_structure_hash")
+    return int(h.value)
 
 
 def ba_solve(scene, cam0=None, ray0=None, tlw0=None, return_tlw=False, **opt):

@@ -38,6 +38,8 @@
 #include "ptz_factor.h"
 
 #include "ptz_ba_kernels.h"
+#include "ptz_view_kernels.h"
+#include <rocprim/rocprim.hpp>
 
 namespace ptz {
 
@@ -128,6 +130,7 @@ struct ptz_ba_batch {
   std::vector<int> first_of_group;
   int max_grp = 0;
   bool has_state = false;
+  bool views_mode = false;  // built by ptz_ba_batch_create_views: structure arrays at upper-bound extents, ray order on the device only
   int n_solves = 0;  // solves of this batch so far
   double last_ms = 0;
   // profiling
@@ -846,6 +849,18 @@ void chol_factor_solve_profiled(const CholBatch& cb, double* x, hipStream_t stre
 }
 }  // namespace ptz
 
+// One rig's tracks, resident in HBM (ptz_rig_create), and the bounds a view of it is sized by.
+struct ptz_rig {
+  int device = 0, n_img = 0, n_track = 0;
+  int64_t n_view = 0;
+  const int* d_trk_ptr = nullptr;
+  const int* d_trk_img = nullptr;
+  const float2* d_trk_uv = nullptr;
+  int64_t ent_bound = 0;           // camera-pair entries of the whole rig: sum over the tracks of L (L - 1) / 2
+  std::vector<int> img_obs, img_ent;  // per image: its views, and its entries as the HIGHER camera of a pair
+  std::vector<void*> allocs;
+};
+
 // =============================================================================================================
 // C-ABI
 // =============================================================================================================
@@ -1189,10 +1204,44 @@ void build_pairs(const ptz_ba_problem& p_in, int obase, int ray_off, const ObsDe
 }
 }  // namespace
 
+static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_rig_view* views, int32_t view_type, const ptz_lm_options* opt,
+                           ptz_ba_batch** out);
 int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz_lm_options* opt, ptz_ba_batch** out)
 {
   if (n <= 0 || !problems || !out) return PTZ_EINVAL;
+  return create_impl(n, problems, nullptr, 0, opt, out);
+}
+int32_t ptz_ba_batch_create_views(int32_t n, const ptz_rig_view* views, int32_t factor_type, const ptz_lm_options* opt, ptz_ba_batch** out)
+{
+  if (n <= 0 || !views || !out) return PTZ_EINVAL;
+  if (factor_type != PTZ_BA_PTZRay && factor_type != PTZ_BA_PTZRayDist && factor_type != PTZ_BA_PTZRayFxfyDist) return PTZ_EUNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    const ptz_rig_view& v = views[i];
+    if (!v.rig || v.n_cam <= 0 || !v.cam_image || v.rig->n_track <= 0) return PTZ_EINVAL;
+    for (int c = 0; c < v.n_cam; ++c)
+      if (v.cam_image[c] < 0 || v.cam_image[c] >= v.rig->n_img || (c > 0 && v.cam_image[c] <= v.cam_image[c - 1])) return PTZ_EINVAL;
+  }
+  return create_impl(n, nullptr, views, factor_type, opt, out);
+}
+
+// views == nullptr: the n packed problems.  Else: the packed problems of n views of resident rigs, built on the device
+// (ptz_view_kernels.h) -- the structure arrays then have the extents of the WHOLE rigs (nothing is read back to size them),
+// each scene's real counts live in its SceneDev.
+static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_rig_view* views, int32_t view_type, const ptz_lm_options* opt,
+                           ptz_ba_batch** out)
+{
   *out = nullptr;
+  const bool vm = views != nullptr;
+  std::vector<ptz_ba_problem> vprob;
+  if (vm) {  // stand-ins that carry the sizes the layout is made for
+    vprob.resize(n);
+    for (int i = 0; i < n; ++i) {
+      memset(&vprob[i], 0, sizeof(ptz_ba_problem));
+      vprob[i].n_cam = views[i].n_cam; vprob[i].n_ray = views[i].rig->n_track; vprob[i].n_obs = views[i].rig->n_view;
+      vprob[i].factor_type = view_type;
+    }
+    problems = vprob.data();
+  }
   const bool dbg_t = getenv("PTZ_BA_DEBUG_TIMING") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tc0 = now_ms();
@@ -1207,7 +1256,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<int> cam_hist;
   int pre_max_cam_obs = 0, pre_max_cam = 0;  // (decides whether the pair lists are built on the device, before anything is built)
   // ---- validate + sizes (host only; no device touched before this passes)
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; vm && i < n; ++i) {
+    for (int c = 0; c < views[i].n_cam; ++c) pre_max_cam_obs = std::max(pre_max_cam_obs, views[i].rig->img_obs[views[i].cam_image[c]]);
+    pre_max_cam = std::max(pre_max_cam, views[i].n_cam);
+  }
+  for (int i = 0; !vm && i < n; ++i) {
     const ptz_ba_problem& p = problems[i];
     if (p.factor_type != type) return PTZ_EINVAL;
     if (p.n_cam <= 0 || p.n_ray <= 0 || p.n_obs <= 0) return PTZ_EINVAL;  // num_cams_ == 0 -> false (:517)
@@ -1253,7 +1306,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   std::vector<int> h_o3cam;
   std::vector<int> h_grpptr, h_grpmem;
   std::vector<unsigned char> h_grpcls;
-  {
+  if (!vm) {
     size_t to = 0, tr = 0, tc = 0;
     for (int i = 0; i < n; ++i) { to += (size_t)problems[i].n_obs; tr += (size_t)problems[i].n_ray; tc += (size_t)problems[i].n_cam; }
     h_uv.reserve(to); h_cam.reserve(to); h_ray.reserve(to); h_camobs.reserve(to); h_wpos.reserve(to); h_camray.reserve(to);
@@ -1268,7 +1321,7 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     tot_obs += problems[i].n_obs;
   }
   if (tot_obs > 0x7fffffff) { delete b; return PTZ_EINVAL; }
-  h_uv.reserve(tot_obs); h_cam.reserve(tot_obs); h_ray.reserve(tot_obs); h_camobs.reserve(tot_obs);
+  if (!vm) { h_uv.reserve(tot_obs); h_cam.reserve(tot_obs); h_ray.reserve(tot_obs); h_camobs.reserve(tot_obs); }
   // the pair lists of the scenes are built a wave at a time on up to 8 host threads (PTZ_BA_HOST_THREADS)
   std::vector<int> obs_base(n, 0), ray_base(n, 0), cam_base(n, 0);
   for (int i = 1; i < n; ++i) {
@@ -1276,12 +1329,14 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     ray_base[i] = ray_base[i - 1] + problems[i - 1].n_ray;
     cam_base[i] = cam_base[i - 1] + problems[i - 1].n_cam;
   }
-  {
+  if (!vm) {
     const size_t tr = (size_t)ray_base[n - 1] + problems[n - 1].n_ray, tc = (size_t)cam_base[n - 1] + problems[n - 1].n_cam;
     h_uv.resize(tot_obs); h_camuv.resize(tot_obs); h_cam.resize(tot_obs); h_ray.resize(tot_obs); h_camobs.resize(tot_obs); h_camray.resize(tot_obs);
     h_rayptr.resize(tr + n); h_w.resize(tr); h_camptr.resize(tc + n); h_campair.resize(tc + n); h_camrun.resize(tc + n); h_wpos.resize(tot_obs);
+    b->ray_perm.resize((size_t)ray_base[n - 1] + problems[n - 1].n_ray);
   }
-  b->ray_perm.resize((size_t)ray_base[n - 1] + problems[n - 1].n_ray);
+  else h_camptr.assign((size_t)cam_base[n - 1] + problems[n - 1].n_cam + n, 0);  // (read by the per-camera flags below: no camera has residuals as far as they are concerned)
+  b->views_mode = vm;
   int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* e = getenv("PTZ_BA_HOST_THREADS")) n_threads = std::max(1, atoi(e));
   const int wave_scenes = 4 * n_threads;
@@ -1291,6 +1346,8 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   const size_t pairs_lds = sizeof(unsigned) * ((size_t)pre_max_cam * ((pre_max_cam_obs + 31) / 32) + 5 * (size_t)pre_max_cam + 8);
   if (pairs_lds > 150 * 1024 || pre_max_cam_obs > 65535) gpu_pairs = false;
   if (const char* e = getenv("PTZ_BA_GPU_STRUCT")) gpu_pairs = gpu_pairs && atoi(e) != 0;
+  if (vm && (pairs_lds > 150 * 1024 || pre_max_cam_obs > 65535)) { delete b; return PTZ_ELIMIT; }  // (a view is built on the device or not at all)
+  if (vm) gpu_pairs = true;
   // PTZ_BA_GPU_STRUCT_CHECK=1 (tests): the host builds its lists as well and the device's must equal them word for word
   const bool pairs_check = gpu_pairs && getenv("PTZ_BA_GPU_STRUCT_CHECK") != nullptr;
   std::vector<PairBuild> wave;
@@ -1315,7 +1372,27 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
     // observations, ray ranges, camera-major lists, camera-pair entry lists: built ahead of this loop, a wave of scenes at a
     // time on several threads (build_pairs); the observation-side arrays are written in place, the pair lists appended here
     const double tsb = now_ms();
-    {
+    if (vm) {
+      // extents of the WHOLE rig (the real counts are the device's to find, and nothing is read back to size an array): pairs of
+      // the candidates, the rig's entries, at most max(runs per workgroup, pairs of a camera) runs per camera
+      const ptz_rig* rg = views[i].rig;
+      const int64_t pair_bound = (int64_t)p.n_cam * (p.n_cam - 1) / 2;
+      const int64_t run_bound = (int64_t)p.n_cam * std::max(schur_threads_of(type), p.n_cam);
+      if ((int64_t)b->total_ent + rg->ent_bound > 0x7fffffff || (int64_t)b->total_pair + pair_bound > 0x7fffffff ||
+          (int64_t)b->total_run + run_bound > 0x7fffffff) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+      s.run_off = b->total_run;
+      s.n_pair = 0;
+      b->total_run += (int)run_bound;
+      b->total_pair += (int)pair_bound;
+      b->total_ent += (int)rg->ent_bound;
+      for (int c = 0; c < p.n_cam; ++c) {
+        b->max_cam_obs = std::max(b->max_cam_obs, rg->img_obs[views[i].cam_image[c]]);
+        b->max_cam_ent = std::max(b->max_cam_ent, rg->img_ent[views[i].cam_image[c]]);
+      }
+      b->max_cam_pair = std::max(b->max_cam_pair, p.n_cam - 1);
+      b->max_cam_run = std::max(b->max_cam_run, std::max(schur_threads_of(type), p.n_cam - 1));
+    }
+    else {
       if (i >= wave_first + (int)wave.size()) {
         wave_first = i;
         const int wn = std::min(n - i, wave_scenes);
@@ -1433,7 +1510,142 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   d.n_scene = n;
   int rc = PTZ_OK;
 #define TRY(x) do { rc = (x); if (rc) { ptz_ba_batch_destroy(b); return rc; } } while (0)
-  {
+  std::vector<unsigned char> h_adj;  // views: tile adjacency of every scene's reduced system, marked on the device
+  if (vm) {
+    // ---- the packed problems of the views, on the device (ptz_view_kernels.h): observations in the library's order, ray and camera
+    // lists, camera pairs; one read-back at the end (counts, tile adjacency), nothing in between
+    const int nt_e = chol_padded_order(b->max_n) / CHOL_NB;
+    std::vector<ViewDev> hv(n);
+    std::vector<int> h_map, h_camimg;
+    size_t trk_total = 0;
+    int max_trk = 0;
+    for (int i = 0; i < n; ++i) {
+      const ptz_rig* rg = views[i].rig;
+      if (rg->device != b->device) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
+      ViewDev& v = hv[i];
+      v.trk_ptr = rg->d_trk_ptr; v.trk_img = rg->d_trk_img; v.trk_uv = rg->d_trk_uv;
+      v.n_track = rg->n_track; v.n_img = rg->n_img; v.n_cam = views[i].n_cam;
+      v.map_off = (int)h_map.size(); v.trk_off = (int)trk_total;
+      v.n_ray = 0; v.n_obs = 0; v.max_len = 0;
+      h_map.insert(h_map.end(), (size_t)rg->n_img, -1);
+      for (int c = 0; c < v.n_cam; ++c) { h_map[v.map_off + views[i].cam_image[c]] = c; h_camimg.push_back(views[i].cam_image[c]); }
+      trk_total += (size_t)rg->n_track;
+      max_trk = std::max(max_trk, rg->n_track);
+      // the sort key of the internal ray order holds (longest - length) * cameras + first camera in 22 bits, the track in 24
+      if (rg->n_track >= (1 << 24) || (int64_t)(rg->n_view / std::max(1, rg->n_track) + 64) * v.n_cam >= (1 << 22)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+    }
+    const ViewDev* dviews_c = nullptr;
+    const int *d_map = nullptr, *d_camimg = nullptr;
+    {
+      StagedUpload up;
+      up.add(b->scenes, &d.scene);
+      up.add(hv, &dviews_c);
+      up.add(h_map, &d_map);
+      up.add(h_camimg, &d_camimg);
+      TRY(up.commit(b));
+    }
+    ViewBuild vb;
+    memset(&vb, 0, sizeof(vb));
+    vb.views = const_cast<ViewDev*>(dviews_c);
+    vb.cam_of_image = d_map; vb.cam_image = d_camimg;
+    vb.scene = const_cast<SceneDev*>(d.scene);
+    unsigned long long *key_out = nullptr;
+    int* val_out = nullptr;
+    TRY(b->alloc(&vb.t_len, trk_total)); TRY(b->alloc(&vb.t_first, trk_total)); TRY(b->alloc(&vb.t_ext, trk_total));
+    TRY(b->alloc(&vb.key_in, trk_total)); TRY(b->alloc(&vb.val_in, trk_total)); TRY(b->alloc(&key_out, trk_total)); TRY(b->alloc(&val_out, trk_total));
+    TRY(b->alloc(&vb.ray_trk, (size_t)b->total_ray)); TRY(b->alloc(&vb.ray_len, (size_t)b->total_ray)); TRY(b->alloc(&vb.cam_cnt, (size_t)b->total_cam));
+    TRY(b->alloc(&vb.obs_uv, (size_t)b->total_obs)); TRY(b->alloc(&vb.obs_cam, (size_t)b->total_obs)); TRY(b->alloc(&vb.obs_ray, (size_t)b->total_obs));
+    TRY(b->alloc(&vb.ray_ptr, (size_t)b->total_ray + n)); TRY(b->alloc(&vb.cam_ptr, (size_t)b->total_cam + n));
+    TRY(b->alloc(&vb.cam_obs, (size_t)b->total_obs)); TRY(b->alloc(&vb.wpos, (size_t)b->total_obs)); TRY(b->alloc(&vb.cam_ray, (size_t)b->total_obs));
+    TRY(b->alloc(&vb.cam_uv, (size_t)b->total_obs)); TRY(b->alloc(&vb.ray_w, (size_t)b->total_ray)); TRY(b->alloc(&vb.ray_perm, (size_t)b->total_ray));
+    d.obs_uv = vb.obs_uv; d.obs_cam = vb.obs_cam; d.obs_ray = vb.obs_ray; d.ray_ptr = vb.ray_ptr; d.cam_ptr = vb.cam_ptr; d.cam_obs = vb.cam_obs;
+    d.wpos = vb.wpos; d.cam_ray = vb.cam_ray; d.cam_uv = vb.cam_uv; d.ray_w = vb.ray_w; b->d_ray_perm = vb.ray_perm;
+    hipStream_t st = b->io;
+    const dim3 gtrk((max_trk + 255) / 256, n);
+    hipLaunchKernelGGL(k_view_tracks, gtrk, dim3(256), 0, st, vb);
+    hipLaunchKernelGGL(k_view_scan, dim3(n), dim3(1024), 0, st, vb);
+    hipLaunchKernelGGL(k_view_keys, gtrk, dim3(256), 0, st, vb);
+    {
+      unsigned end_bit = 47;
+      while ((1u << (end_bit - 47)) < (unsigned)n) ++end_bit;
+      size_t tmp_bytes = 0;
+      void* tmp = nullptr;
+      if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, 0u, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+      char* tmpc = nullptr;
+      TRY(b->alloc(&tmpc, tmp_bytes + 256));
+      tmp = tmpc;
+      if (rocprim::radix_sort_pairs(tmp, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, 0u, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    }
+    hipLaunchKernelGGL(k_view_rays, gtrk, dim3(256), 0, st, vb, (const int*)val_out);
+    hipLaunchKernelGGL(k_view_rayscan, dim3(n), dim3(1024), 0, st, vb, b->ray_block);
+    hipLaunchKernelGGL(k_view_obs, gtrk, dim3(256), 0, st, vb);
+    hipLaunchKernelGGL(k_view_camscan, dim3(n), dim3(1024), 0, st, vb);
+    hipLaunchKernelGGL(k_view_camlists, dim3(b->max_cam, n), dim3(256), 0, st, vb);
+    // camera pairs, entry lists, runs: k_pairs as for any batch, into arrays of the bounds' extents (no sizing read-back)
+    PairsDev pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.scene = d.scene; pa.obs_cam = d.obs_cam; pa.obs_ray = d.obs_ray; pa.ray_ptr = d.ray_ptr; pa.cam_ptr = d.cam_ptr; pa.cam_obs = d.cam_obs;
+    pa.wpos = d.wpos;
+    pa.max_runs = schur_threads_of(type);
+    int *d_cnt = nullptr, *d_off3 = nullptr, *d_tot = nullptr, *d_err = nullptr;
+    unsigned char* d_adj = nullptr;
+    TRY(b->alloc(&d_cnt, (size_t)3 * b->total_cam));
+    TRY(b->alloc(&d_off3, (size_t)3 * b->total_cam));
+    TRY(b->alloc(&d_tot, (size_t)6 * n + 1));
+    d_err = d_tot + 6 * n;
+    TRY(b->alloc(&d_adj, (size_t)n * nt_e * nt_e));
+    pa.cam_cnt = d_cnt; pa.cam_off3 = d_off3; pa.scene_tot = d_tot; pa.err = d_err;
+    TRY(b->alloc(&pa.pci, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pcj, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pbrow, (size_t)b->total_pair));
+    TRY(b->alloc(&pa.pptr, (size_t)b->total_pair + n));
+    TRY(b->alloc(&pa.prun, (size_t)b->total_pair + n));
+    TRY(b->alloc(&pa.campair, (size_t)b->total_cam + n));
+    TRY(b->alloc(&pa.camrun, (size_t)b->total_cam + n));
+    TRY(b->alloc(&pa.runs, (size_t)b->total_run));
+    TRY(b->alloc(&pa.ent, (size_t)b->total_ent));
+    {
+      static std::mutex cap_mu;
+      std::lock_guard<std::mutex> lk(cap_mu);
+      (void)hipFuncSetAttribute((const void*)k_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      (void)hipFuncSetAttribute((const void*)k_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    }
+    if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    hipLaunchKernelGGL(k_pairs<false>, dim3(b->max_cam, n), dim3(256), pairs_lds, st, pa);
+    hipLaunchKernelGGL(k_pair_scan, dim3((n + 63) / 64), dim3(64), 0, st, d.scene, n, (const int*)d_cnt, d_off3, d_tot);
+    hipLaunchKernelGGL(k_view_pairs_patch, dim3((n + 63) / 64), dim3(64), 0, st, vb.scene, n, (const int*)d_tot);
+    hipLaunchKernelGGL(k_pairs<true>, dim3(b->max_cam, n), dim3(256), pairs_lds, st, pa);
+    hipLaunchKernelGGL(k_view_adjacency, dim3(n), dim3(256), 0, st, d.scene, (const int*)pa.pci, (const int*)pa.pcj, NC, nt_e, d_adj);
+    d.pair_ci = pa.pci; d.pair_cj = pa.pcj; d.pair_brow = pa.pbrow; d.pair_ptr = pa.pptr; d.pair_run = pa.prun;
+    d.cam_pair = pa.campair; d.cam_run = pa.camrun; d.run_rec = pa.runs; d.ent = pa.ent;
+    // the one read-back: the views' counts, the pair totals, the error word, the tile adjacency
+    std::vector<int> h_tot((size_t)6 * n + 1);
+    h_adj.resize((size_t)n * nt_e * nt_e);
+    {
+      hipError_t e = hipMemcpyAsync(hv.data(), dviews_c, sizeof(ViewDev) * n, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_tot.data(), d_tot, sizeof(int) * (6 * n + 1), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_adj.data(), d_adj, h_adj.size(), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = stream_wait(st);
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+    }
+    if (h_tot[(size_t)6 * n]) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image twice in one track (tracks.cc:77)
+    b->max_pair = 0; b->max_cam_pair = 0; b->max_cam_ent = 0; b->max_cam_run = 0;
+    for (int i = 0; i < n; ++i) {
+      if (hv[i].n_obs <= 0 || hv[i].n_ray <= 0) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // no candidate observation: not a problem (:517)
+      SceneDev& sd = b->scenes[i];
+      const int* t = h_tot.data() + 6 * (size_t)i;
+      sd.n_ray = hv[i].n_ray; sd.n_obs = hv[i].n_obs;
+      sd.n_wave = (sd.n_ray + 63) / 64; sd.n_chunk = (sd.n_ray + b->ray_block - 1) / b->ray_block;
+      sd.n_pair = t[0];
+      b->max_pair = std::max(b->max_pair, t[0]);
+      b->max_cam_pair = std::max(b->max_cam_pair, t[3]);
+      b->max_cam_ent = std::max(b->max_cam_ent, t[4]);
+      b->max_cam_run = std::max(b->max_cam_run, t[5]);
+    }
+    gpu_pairs = false;  // (done)
+  }
+  else {
     StagedUpload up;
     up.add(b->scenes, &d.scene);
     up.add(h_uv, &d.obs_uv);
@@ -1677,10 +1889,11 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
       std::fill(m0.begin(), m0.end(), 0);
       auto tile_lo = [&](int cam) { return (cam * NC) / CHOL_NB; };
       auto tile_hi = [&](int cam) { return (cam * NC + NC - 1) / CHOL_NB; };
-      for (int c = 0; c < sd.n_cam; ++c)
+      if (vm) memcpy(m0.data(), h_adj.data() + (size_t)i * nt * nt, (size_t)nt * nt);  // (marked on the device by the same rule: k_view_adjacency)
+      for (int c = 0; !vm && c < sd.n_cam; ++c)
         for (int a = tile_lo(c); a <= tile_hi(c); ++a)
           for (int e = tile_lo(c); e <= a; ++e) m0[a * nt + e] = 1;
-      for (int p = 0; p < sd.n_pair; ++p) {
+      for (int p = 0; !vm && p < sd.n_pair; ++p) {
         const int ci = h_pci[sd.pair_off + p], cj = h_pcj[sd.pair_off + p];
         for (int a = tile_lo(ci); a <= tile_hi(ci); ++a)
           for (int e = tile_lo(cj); e <= tile_hi(cj); ++e) {
@@ -1907,10 +2120,20 @@ int32_t ptz_ba_batch_create(int32_t n, const ptz_ba_problem* problems, const ptz
   return PTZ_OK;
 }
 
+// the ray order of a batch built from views lives on the device: fetched when a host-side entry point needs it
+static int32_t ensure_host_ray_perm(ptz_ba_batch* b)
+{
+  if (!b->ray_perm.empty() || !b->d_ray_perm) return PTZ_OK;
+  b->ray_perm.resize((size_t)b->total_ray);
+  if (copy_on(b->stream, b->ray_perm.data(), b->d_ray_perm, sizeof(int) * b->ray_perm.size(), hipMemcpyDeviceToHost) != hipSuccess) return PTZ_ENODEVICE;
+  return PTZ_OK;
+}
+
 int32_t ptz_ba_batch_set_state(ptz_ba_batch* b, const double* cam, const double* ray, const double* tlw)
 {
   if (!b || !cam || !ray) return PTZ_EINVAL;
   PTZ_DEVICE_GUARD(b->device);
+  if (int32_t rcp = ensure_host_ray_perm(b)) return rcp;
   // cameras (a shared block starting from its first camera's values), rays in the library's order and T_l_w are put together in
   // ONE pinned block, sent with three asynchronous copies and waited for ONCE (three staged copies with a wait each cost the
   // lock-step PTZ-IBA 0.4 ms per bundle adjustment); batches whose state is larger than the staging limit copy array by array
@@ -1978,13 +2201,13 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
   void* stage = nullptr;
   if (ptzpool::dev_acquire(b->device, sizeof(double) * (nc + nr + nt), &stage) != hipSuccess) return PTZ_ENOMEM;
   double* s_cam = static_cast<double*>(stage);
-  double* s_ray = s_cam + nc;
-  double* s_tlw = s_ray + nr;
+  double* s_tlw = s_cam + nc;
+  double* s_ray = s_tlw + nt;  // (last: a caller that does not want the rays does not pay for their copy)
   hipLaunchKernelGGL(k_gather_state, dim3(std::max(1, (std::max(b->max_cam * 15, b->max_ray) + 255) / 256), b->n_scene), dim3(256), 0, b->stream, b->d,
                      b->d_ray_perm, s_cam, s_ray, s_tlw);
   // the gathered state comes back in ONE copy into a pinned block (the kernel and the copy are ordered on the batch's stream: one
   // wait), from where the caller's arrays are filled
-  const size_t bytes = sizeof(double) * (nc + nr + nt);
+  const size_t bytes = sizeof(double) * (nc + nt + (ray ? nr : 0));
   void* pin = nullptr;
   hipError_t e = hipSuccess;
   if (bytes <= ((size_t)32 << 20) && ptzpool::pinned_acquire(bytes, &pin) == hipSuccess) {
@@ -1994,8 +2217,8 @@ int32_t ptz_ba_batch_get_state(ptz_ba_batch* b, double* cam, double* ray, double
     if (e == hipSuccess) {
       const double* p = static_cast<const double*>(pin);
       if (cam) memcpy(cam, p, sizeof(double) * nc);
-      if (ray) memcpy(ray, p + nc, sizeof(double) * nr);
-      if (tlw) memcpy(tlw, p + nc + nr, sizeof(double) * nt);
+      if (tlw) memcpy(tlw, p + nc, sizeof(double) * nt);
+      if (ray) memcpy(ray, p + nc + nt, sizeof(double) * nr);
     }
     ptzpool::pinned_release(pin);
   }
@@ -2080,6 +2303,7 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
   clear_stale_error(__func__);
   if (!b || !b->has_state || index < 0 || index >= b->n_scene) return PTZ_EINVAL;
   PTZ_DEVICE_GUARD(b->device);
+  if (int32_t rcp = ensure_host_ray_perm(b)) return rcp;
   if (W && !b->d.W) {  // the rows exist only for this call's callers (the solver does not materialise them)
     const bool disp = b->type == PTZ_BA_PTZRayDistDisp;
     const int rcw = b->alloc(&b->d.W, (size_t)b->total_obs * (disp ? 24 : b->type == PTZ_BA_PTZRayFxfyDist ? 18 : 16));
@@ -2154,6 +2378,148 @@ int32_t ptz_ba_batch_linearize(ptz_ba_batch* b, int32_t index, double* cost, dou
         memcpy(W + (size_t)a_ext * NW * 3, &rows[(size_t)(wp[a_int] - s.obs_off) * ws], sizeof(double) * NW * 3);
       }
   }
+  return PTZ_OK;
+}
+
+int32_t ptz_rig_create(int32_t n_img, int32_t n_track, const int64_t* trk_ptr, const int32_t* trk_img, const float* trk_uv, int32_t device_id,
+                       ptz_rig** out)
+{
+  if (n_img <= 0 || n_track <= 0 || !trk_ptr || !trk_img || !trk_uv || !out) return PTZ_EINVAL;
+  *out = nullptr;
+  const int64_t nv = trk_ptr[n_track];
+  if (trk_ptr[0] != 0 || nv <= 0 || nv > 0x7fffffff) return PTZ_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) return PTZ_ENODEVICE;
+  ptz_rig* r = new ptz_rig();
+  r->device = device_id; r->n_img = n_img; r->n_track = n_track; r->n_view = nv;
+  r->img_obs.assign(n_img, 0); r->img_ent.assign(n_img, 0);
+  std::vector<int> ptr32(n_track + 1);
+  for (int t = 0; t <= n_track; ++t) ptr32[t] = (int)trk_ptr[t];
+  for (int t = 0; t < n_track; ++t) {
+    const int64_t L = trk_ptr[t + 1] - trk_ptr[t];
+    if (L <= 0) { delete r; return PTZ_EINVAL; }
+    r->ent_bound += L * (L - 1) / 2;
+    for (int64_t e = trk_ptr[t]; e < trk_ptr[t + 1]; ++e) {
+      const int im = trk_img[e];
+      if (im < 0 || im >= n_img || (e > trk_ptr[t] && im <= trk_img[e - 1])) { delete r; return PTZ_EINVAL; }  // images ascend inside a track
+      ++r->img_obs[im];
+      r->img_ent[im] += (int)(e - trk_ptr[t]);  // pairs in which this view is the higher camera
+    }
+  }
+  if (r->ent_bound > 0x7fffffff) { delete r; return PTZ_ELIMIT; }
+  PTZ_DEVICE_GUARD(device_id);
+  hipStream_t st = nullptr;
+  if (ptzpool::stream_acquire(device_id, &st) != hipSuccess) { delete r; return PTZ_ENODEVICE; }
+  auto up = [&](const void* src, size_t bytes, const void** dst) -> bool {
+    void* q = nullptr;
+    if (ptzpool::dev_acquire(device_id, bytes, &q) != hipSuccess) return false;
+    r->allocs.push_back(q);
+    *dst = q;
+    return copy_on(st, q, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  const bool ok = up(ptr32.data(), sizeof(int) * ptr32.size(), (const void**)&r->d_trk_ptr) && up(trk_img, sizeof(int) * (size_t)nv, (const void**)&r->d_trk_img) &&
+                  up(trk_uv, sizeof(float) * 2 * (size_t)nv, (const void**)&r->d_trk_uv);
+  ptzpool::stream_release(device_id, st);
+  if (!ok) { ptz_rig_destroy(r); return PTZ_ENODEVICE; }
+  *out = r;
+  return PTZ_OK;
+}
+
+void ptz_rig_destroy(ptz_rig* r)
+{
+  if (!r) return;
+  DeviceGuard guard(r->device);
+  for (void* p : r->allocs) ptzpool::dev_release(r->device, p);
+  delete r;
+}
+
+int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const double* rkinv)
+{
+  if (!b || !cam || !rkinv) return PTZ_EINVAL;
+  PTZ_DEVICE_GUARD(b->device);
+  clear_stale_error(__func__);
+  // cameras and their R^-1 K^-1 in one pinned block, two copies, the ray kernel behind them, one wait
+  const size_t nc = (size_t)15 * b->total_cam, nk = (size_t)9 * b->total_cam;
+  void* pin = nullptr;
+  std::vector<double> heap;
+  double* stg = nullptr;
+  if (ptzpool::pinned_acquire(sizeof(double) * (nc + nk), &pin) == hipSuccess) stg = static_cast<double*>(pin);
+  else { (void)hipGetLastError(); heap.resize(nc + nk); stg = heap.data(); }
+  memcpy(stg, cam, sizeof(double) * nc);
+  memcpy(stg + nc, rkinv, sizeof(double) * nk);
+  void* dk = nullptr;
+  if (ptzpool::dev_acquire(b->device, sizeof(double) * nk, &dk) != hipSuccess) { ptzpool::pinned_release(pin); return PTZ_ENOMEM; }
+  hipError_t e = hipMemcpyAsync(b->cam0, stg, sizeof(double) * nc, hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dk, stg + nc, sizeof(double) * nk, hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b->tlw0, 0, sizeof(double) * 6 * b->n_scene, b->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_view_pix2ray, dim3((b->max_ray + 255) / 256, b->n_scene), dim3(256), 0, b->stream, b->d, (const double*)b->cam0, (const double*)dk, b->ray0);
+    e = stream_wait(b->stream);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  ptzpool::dev_release(b->device, dk);
+  ptzpool::pinned_release(pin);
+  PTZ_HIP_TRY(e);
+  b->has_state = true;
+  return PTZ_OK;
+}
+
+int32_t ptz_debug_batch_structure_hash(ptz_ba_batch* b, uint64_t* hash)
+{
+  if (!b || !hash) return PTZ_EINVAL;
+  PTZ_DEVICE_GUARD(b->device);
+  const Dev& d = b->d;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* ptr, size_t bytes) { const unsigned char* c = (const unsigned char*)ptr; for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; } };
+  std::vector<unsigned char> buf;
+  auto fetch = [&](const void* dev, size_t bytes) -> const unsigned char* {
+    buf.resize(bytes + 8);
+    if (bytes && copy_on(b->stream, buf.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    return buf.data();
+  };
+  // every scene's arrays over their real extents, positions made scene-relative (a batch built from views keeps gaps between scenes)
+  std::vector<SceneDev> sc(b->n_scene);
+  if (copy_on(b->stream, sc.data(), d.scene, sizeof(SceneDev) * b->n_scene, hipMemcpyDeviceToHost) != hipSuccess) return PTZ_ENODEVICE;
+  for (int i = 0; i < b->n_scene; ++i) {
+    const SceneDev& s = sc[i];
+    const int counts[6] = {s.n_cam, s.n_ray, s.n_obs, s.n_pair, s.n_wave, s.n};
+    mix(counts, sizeof(counts));
+    auto plain = [&](const void* base, size_t elem, size_t first, size_t count) { const unsigned char* p = fetch((const char*)base + elem * first, elem * count); if (p) mix(p, elem * count); return p != nullptr; };
+    auto rel = [&](const int* base, size_t first, size_t count, int minus) {
+      const unsigned char* p = fetch(base + first, sizeof(int) * count);
+      if (!p) return false;
+      std::vector<int> v(count);
+      memcpy(v.data(), p, sizeof(int) * count);
+      for (int& x : v) x -= minus;
+      mix(v.data(), sizeof(int) * count);
+      return true;
+    };
+    bool ok = plain(d.obs_uv, sizeof(float2), s.obs_off, s.n_obs) && plain(d.obs_cam, 4, s.obs_off, s.n_obs) && plain(d.obs_ray, 4, s.obs_off, s.n_obs);
+    ok = ok && rel(d.ray_ptr, (size_t)s.ray_off + s.idx, (size_t)s.n_ray + 1, s.obs_off) && rel(d.cam_ptr, (size_t)s.cam_off + s.idx, (size_t)s.n_cam + 1, s.obs_off);
+    ok = ok && rel(d.cam_obs, s.obs_off, s.n_obs, s.obs_off) && rel(d.wpos, s.obs_off, s.n_obs, s.obs_off) && rel(d.cam_ray, s.obs_off, s.n_obs, s.ray_off);
+    ok = ok && plain(d.cam_uv, sizeof(float2), s.obs_off, s.n_obs) && plain(d.ray_w, 8, s.ray_off, s.n_ray) && plain(b->d_ray_perm, 4, s.ray_off, s.n_ray);
+    ok = ok && plain(d.pair_ci, 4, s.pair_off, s.n_pair) && plain(d.pair_cj, 4, s.pair_off, s.n_pair) && rel(d.pair_brow, s.pair_off, s.n_pair, s.obs_off);
+    ok = ok && rel(d.pair_ptr, (size_t)s.pair_off + s.idx, (size_t)s.n_pair + 1, s.ent_off) && plain(d.pair_run, 4, (size_t)s.pair_off + s.idx, (size_t)s.n_pair + 1);
+    ok = ok && plain(d.cam_pair, 4, (size_t)s.cam_off + s.idx, (size_t)s.n_cam + 1) && plain(d.cam_run, 4, (size_t)s.cam_off + s.idx, (size_t)s.n_cam + 1);
+    if (!ok) return PTZ_ENODEVICE;
+    // entries and runs: extents from the scene's own last offsets
+    std::vector<int> last(2);
+    if (copy_on(b->stream, &last[0], d.pair_ptr + s.pair_off + s.idx + s.n_pair, 4, hipMemcpyDeviceToHost) != hipSuccess) return PTZ_ENODEVICE;
+    if (copy_on(b->stream, &last[1], d.cam_run + s.cam_off + s.idx + s.n_cam, 4, hipMemcpyDeviceToHost) != hipSuccess) return PTZ_ENODEVICE;
+    const int n_ent = last[0] - s.ent_off, n_run = last[1];
+    if (!plain(d.ent, 4, s.ent_off, (size_t)std::max(n_ent, 0))) return PTZ_ENODEVICE;
+    {
+      const unsigned char* p = fetch(d.run_rec + s.run_off, sizeof(uint2) * (size_t)std::max(n_run, 0));
+      if (!p) return PTZ_ENODEVICE;
+      std::vector<uint2> v((size_t)std::max(n_run, 0));
+      memcpy(v.data(), p, sizeof(uint2) * v.size());
+      for (uint2& x : v) x.x -= (unsigned)s.ent_off;
+      mix(v.data(), sizeof(uint2) * v.size());
+    }
+    const int tail[2] = {n_ent, n_run};
+    mix(tail, sizeof(tail));
+  }
+  *hash = h;
   return PTZ_OK;
 }
 

@@ -1194,6 +1194,88 @@ def test_ba_lost_chain_handover_is_reported_not_absorbed(pkg, scene_c1, monkeypa
     assert summ == ref[2] and np.array_equal(cam, ref[0]) and np.array_equal(ray, ref[1])
 
 
+def _rodrigues_np(rv):
+    th = np.linalg.norm(rv)
+    if th < 2.220446049250313e-16:
+        return np.eye(3)
+    k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * K
+
+
+def _pix2ray_reference_order(prob, rkinv):
+    """Pix2Ray as PTZRayOptimizer::Pack evaluates it (ptzray_optimizer.cc:768-797): every product and sum in the host's order."""
+    rays = np.zeros((prob.n_ray, 3))
+    cnt = np.zeros(prob.n_ray)
+    acc = np.zeros((prob.n_ray, 3))
+    for a in range(len(prob.obs_cam)):  # observations are (track, image)-ordered
+        M = rkinv[prob.obs_cam[a]]
+        x, y = np.float64(prob.obs_uv[a, 0]), np.float64(prob.obs_uv[a, 1])
+        t = np.array([(M[0] * x + M[1] * y) + M[2], (M[3] * x + M[4] * y) + M[5], (M[6] * x + M[7] * y) + M[8]])
+        n = np.sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2])
+        j = prob.obs_ray[a]
+        acc[j] = acc[j] + t / n
+        cnt[j] += 1
+    acc = acc / cnt[:, None]
+    n = np.sqrt((acc[:, 0] * acc[:, 0] + acc[:, 1] * acc[:, 1]) + acc[:, 2] * acc[:, 2])
+    rays = acc / n[:, None]
+    return rays
+
+
+def test_views_of_resident_rigs_are_the_batches_of_their_packed_problems(pkg):
+    """ptz_ba_batch_create_views: bundle adjustments over candidate subsets of rigs whose tracks are resident in HBM (what PTZ-IBA
+    asks for ~2N times per rig, ptz_incremental_optimizer.cc:420-440), the packed problem built ON THE DEVICE.  Against
+    ptz_ba_batch_create on the same problems packed on the host (PTZRayOptimizer::Pack's rules): the structure arrays hash alike
+    -- observations in the library's order, ray and camera lists, pairs, entries, runs, weights, ray order -- and from the same
+    initial state the solves have the same bits; with the rays initialised on the device (Pix2Ray in the host's operation order)
+    as well."""
+    sc_a = pkg.synth.make_scene(1, 40, 120)
+    sc_b = pkg.synth.make_scene(2, 24, 100)
+    rig_a, rig_b = pkg.api.Rig.from_scene(sc_a), pkg.api.Rig.from_scene(sc_b)
+    cases = [(rig_a, sc_a, [0, 1]), (rig_a, sc_a, list(range(0, 40, 3))), (rig_b, sc_b, list(range(24))), (rig_a, sc_a, list(range(5, 33))),
+             (rig_b, sc_b, [3, 4, 5, 9, 10, 11, 12, 20])]
+    probs = [pkg.api.view_problem(sc, im) for _, sc, im in cases]
+    for group in ([0], [2], [0, 1, 2, 3, 4]):  # one small view, one whole rig, a ragged batch
+        hb = pkg.api.BaBatch([probs[k] for k in group])
+        vb = pkg.api.ViewBatch([cases[k][0] for k in group], [cases[k][2] for k in group])
+        assert pkg.api.structure_hash(hb) == pkg.api.structure_hash(vb), group
+        hb.set_state(); s1 = hb.solve(); c1, _ = hb.get_state()
+        # the same initial state: a views batch takes its rays at the extents of the whole rigs (a problem's rays first)
+        rays = []
+        for k in group:
+            full = np.zeros((cases[k][1].n_ray, 3)); full[:probs[k].n_ray] = probs[k].ray_init
+            rays.append(full)
+        vb.set_state(cams=[probs[k].cam_init for k in group], rays=rays)
+        s2 = vb.solve(); c2 = vb.get_cams()
+        for a, b_, x, y in zip(s1, s2, c1, c2):
+            assert a == b_ and np.array_equal(x, y)
+        # rays by Pix2Ray on the device = the host's loop, bit for bit (else the trajectories would part)
+        rk = []
+        for k in group:
+            m = []
+            for c in probs[k].cam_init:
+                Kc = np.array([[c[0], 0, c[2]], [0, c[1], c[3]], [0, 0, 1.0]])
+                m.append((np.linalg.inv(_rodrigues_np(c[4:7])) @ np.linalg.inv(Kc)).reshape(9))
+            rk.append(np.array(m))
+        import copy
+        hp = []
+        for k, m in zip(group, rk):
+            q = copy.copy(probs[k]); q.ray_init = _pix2ray_reference_order(probs[k], m); hp.append(q)
+        hb2 = pkg.api.BaBatch(hp); hb2.set_state(); s3 = hb2.solve(); c3, _ = hb2.get_state(); hb2.close()
+        vb.set_state_pix2ray([probs[k].cam_init for k in group], rk)
+        s4 = vb.solve(); c4 = vb.get_cams()
+        for a, b_, x, y in zip(s3, s4, c3, c4):
+            assert a == b_ and np.array_equal(x, y)
+        hb.close(); vb.close()
+    # a view without any candidate observation is not a problem
+    with pytest.raises(pkg.api.PtzError):
+        lonely = [i for i in range(sc_a.n_cam) if not np.any(sc_a.obs_cam == i)][:1] or None
+        if lonely is None:
+            raise pkg.api.PtzError(-1, "no image without observations in this scene")
+        pkg.api.ViewBatch([rig_a], [lonely])
+    rig_a.close(); rig_b.close()
+
+
 def test_ba_ragged_batch_is_bit_identical_to_solo_solves(pkg):
     """Scenes of very different sizes in one batch (2, 20, 24 and 60 cameras; the padded reduced systems, LDS tables and grids
     are sized by the largest): every scene's result has the bits of its solo solve."""
