@@ -240,6 +240,9 @@ int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const
 /* Diagnostic for the tests: FNV-1a hash over the batch's structure arrays (observations in the library's order, ray and
  * camera lists, camera pairs, entries, runs, weights, ray order), real extents only -- two batches that hash alike solve alike. */
 int32_t ptz_debug_batch_structure_hash(ptz_ba_batch* b, uint64_t* hash);
+/* ... and the stored initial rays of the batch in the caller's ray numbering, ray [3 * sum n_ray] (at the extents the batch was
+ * created with), e.g. what ptz_ba_batch_set_state_pix2ray computed. */
+int32_t ptz_debug_batch_initial_rays(ptz_ba_batch* b, double* ray);
 
 /* Dense SPD solve used for the reduced camera system, exposed for parity tests and micro-benchmarks:
  * solves A x = rhs for `count` independent n x n systems (host, row-major, lower triangle read).

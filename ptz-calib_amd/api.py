@@ -26,7 +26,7 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
            "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp",
            "ptz_ba_plan_tile_order", "ptz_rig_create", "ptz_rig_destroy", "ptz_ba_batch_create_views", "ptz_ba_batch_set_state_pix2ray",
-           "ptz_debug_batch_structure_hash"]
+           "ptz_debug_batch_structure_hash", "ptz_debug_batch_initial_rays"]
 
 
 class PtzError(RuntimeError):
@@ -314,6 +314,12 @@ class ViewBatch(BaBatch):
         _check(lib().ptz_ba_batch_get_state(self.handle, _p(cam), None, _p(tlw)), "ptz_ba_batch_get_state")
         off = np.concatenate([[0], np.cumsum(self.n_cams)])
         return [cam[off[i]:off[i + 1]] for i in range(self.n)]
+
+
+def initial_rays(batch, total_rays) -> np.ndarray:
+    r = np.zeros((int(total_rays), 3))
+    _check(lib().ptz_debug_batch_initial_rays(batch.handle, _p(r)), "ptz_debug_batch_initial_rays")
+    return r
 
 
 def structure_hash(batch) -> int:

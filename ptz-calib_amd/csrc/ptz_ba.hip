@@ -2464,6 +2464,19 @@ int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const
   return PTZ_OK;
 }
 
+int32_t ptz_debug_batch_initial_rays(ptz_ba_batch* b, double* ray)
+{
+  if (!b || !ray || !b->has_state) return PTZ_EINVAL;
+  PTZ_DEVICE_GUARD(b->device);
+  if (int32_t rcp = ensure_host_ray_perm(b)) return rcp;
+  std::vector<double> r((size_t)3 * b->total_ray);
+  if (copy_on(b->stream, r.data(), b->ray0, sizeof(double) * r.size(), hipMemcpyDeviceToHost) != hipSuccess) return PTZ_ENODEVICE;
+  for (const SceneDev& sd : b->scenes)
+    for (int j = 0; j < sd.n_ray; ++j)
+      for (int k = 0; k < 3; ++k) ray[3 * ((size_t)sd.ray_off + b->ray_perm[sd.ray_off + j]) + k] = r[3 * ((size_t)sd.ray_off + j) + k];
+  return PTZ_OK;
+}
+
 int32_t ptz_debug_batch_structure_hash(ptz_ba_batch* b, uint64_t* hash)
 {
   if (!b || !hash) return PTZ_EINVAL;

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void k_view_adjacency(const SceneDev* __restri
 // order, acc /= count, ray = acc / |acc|.  No contraction: every product and sum rounds as the host's.
 __global__ __launch_bounds__(256) void k_view_pix2ray(Dev d, const double* __restrict__ cam0, const double* __restrict__ rkinv, double* __restrict__ ray0)
 {
+#pragma clang fp contract(off)  // (HIP's __dmul_rn / __dadd_rn are plain operators: without this the compiler fuses them)
   const int sc = blockIdx.y;
   const SceneDev s = d.scene[sc];
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -305,18 +306,18 @@ __global__ __launch_bounds__(256) void k_view_pix2ray(Dev d, const double* __res
     const double* M = rkinv + (size_t)(s.cam_off + d.obs_cam[a]) * 9;
     const float2 uv = d.obs_uv[a];
     const double x = (double)uv.x, y = (double)uv.y;
-    const double t0 = __dadd_rn(__dadd_rn(__dmul_rn(M[0], x), __dmul_rn(M[1], y)), M[2]);
-    const double t1 = __dadd_rn(__dadd_rn(__dmul_rn(M[3], x), __dmul_rn(M[4], y)), M[5]);
-    const double t2 = __dadd_rn(__dadd_rn(__dmul_rn(M[6], x), __dmul_rn(M[7], y)), M[8]);
-    const double n = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(t0, t0), __dmul_rn(t1, t1)), __dmul_rn(t2, t2)));
-    a0 = __dadd_rn(a0, __ddiv_rn(t0, n)); a1 = __dadd_rn(a1, __ddiv_rn(t1, n)); a2 = __dadd_rn(a2, __ddiv_rn(t2, n));
+    const double t0 = (M[0] * x + M[1] * y) + M[2];
+    const double t1 = (M[3] * x + M[4] * y) + M[5];
+    const double t2 = (M[6] * x + M[7] * y) + M[8];
+    const double n = sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+    a0 = a0 + t0 / n; a1 = a1 + t1 / n; a2 = a2 + t2 / n;
     ++cnt;
   }
   const double dc = (double)cnt;
-  a0 = __ddiv_rn(a0, dc); a1 = __ddiv_rn(a1, dc); a2 = __ddiv_rn(a2, dc);
-  const double n = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(a0, a0), __dmul_rn(a1, a1)), __dmul_rn(a2, a2)));
+  a0 = a0 / dc; a1 = a1 / dc; a2 = a2 / dc;
+  const double n = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
   double* out = ray0 + (size_t)(s.ray_off + j) * 3;
-  out[0] = __ddiv_rn(a0, n); out[1] = __ddiv_rn(a1, n); out[2] = __ddiv_rn(a2, n);
+  out[0] = a0 / n; out[1] = a1 / n; out[2] = a2 / n;
 }
 
 }  // namespace

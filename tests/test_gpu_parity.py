@@ -1263,6 +1263,11 @@ def test_views_of_resident_rigs_are_the_batches_of_their_packed_problems(pkg):
             q = copy.copy(probs[k]); q.ray_init = _pix2ray_reference_order(probs[k], m); hp.append(q)
         hb2 = pkg.api.BaBatch(hp); hb2.set_state(); s3 = hb2.solve(); c3, _ = hb2.get_state(); hb2.close()
         vb.set_state_pix2ray([probs[k].cam_init for k in group], rk)
+        got = pkg.api.initial_rays(vb, sum(cases[k][1].n_ray for k in group))
+        off = 0
+        for k, q in zip(group, hp):
+            assert np.array_equal(got[off:off + q.n_ray], q.ray_init), (group, k, np.abs(got[off:off + q.n_ray] - q.ray_init).max())
+            off += cases[k][1].n_ray
         s4 = vb.solve(); c4 = vb.get_cams()
         for a, b_, x, y in zip(s3, s4, c3, c4):
             assert a == b_ and np.array_equal(x, y)
