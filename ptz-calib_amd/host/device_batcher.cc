@@ -58,6 +58,18 @@ int32_t DeviceBatcher::BaSolve(const ptz_ba_problem* p, double* cam, double* ray
   return req.rc;
 }
 
+int32_t DeviceBatcher::BaSolveView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt,
+                                   ptz_lm_summary* summary)
+{
+  ptz_lm_options dflt;
+  if (!opt) { ptz_lm_options_default(&dflt); opt = &dflt; }
+  BavReq req{view, factor_type, cam, rkinv, opt, summary, PTZ_EINVAL};
+  std::unique_lock<std::mutex> lk(mu_);
+  bav_.push_back(&req);
+  Arrive(lk);
+  return req.rc;
+}
+
 int32_t DeviceBatcher::KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
                                      double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                                      ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
@@ -90,6 +102,19 @@ void DeviceBatcher::RunRound()
     }
     RunBa(group);
   }
+  std::vector<char> done_bav(bav_.size(), 0);
+  for (size_t i = 0; i < bav_.size(); ++i) {  // views of resident rigs: one device-built batch per (factor type, options)
+    if (done_bav[i]) continue;
+    std::vector<BavReq*> group{bav_[i]};
+    done_bav[i] = 1;
+    for (size_t j = i + 1; j < bav_.size(); ++j) {
+      if (done_bav[j] || bav_[j]->factor_type != bav_[i]->factor_type || !SameOptions(bav_[j]->opt, bav_[i]->opt)) continue;
+      group.push_back(bav_[j]);
+      done_bav[j] = 1;
+    }
+    RunBaViews(group);
+  }
+  bav_.clear();
   std::vector<char> done_krt(krt_.size(), 0);
   for (size_t i = 0; i < krt_.size(); ++i) {
     if (done_krt[i]) continue;
@@ -190,6 +215,95 @@ void DeviceBatcher::RunBaBatch(std::vector<BaReq*>& reqs)
   }
 }
 
+namespace {
+// one view alone: what a solo PTZRayOptimizer::Solve over a view does
+int32_t SolveOneView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt, ptz_lm_summary* summary)
+{
+  ptz_ba_batch* b = nullptr;
+  int32_t rc = ptz_ba_batch_create_views(1, view, factor_type, opt, &b);
+  if (rc == PTZ_OK) rc = ptz_ba_batch_set_state_pix2ray(b, cam, rkinv);
+  ptz_lm_summary s{};
+  if (rc == PTZ_OK) rc = ptz_ba_batch_solve(b, &s);
+  if (rc == PTZ_OK) rc = ptz_ba_batch_get_state(b, cam, nullptr, nullptr);
+  if (b) ptz_ba_batch_destroy(b);
+  if (rc == PTZ_OK && summary) *summary = s;
+  return rc;
+}
+}  // namespace
+
+void DeviceBatcher::RunBaViews(std::vector<BavReq*>& reqs)
+{
+  const double t0 = NowMs();
+  // The packed problems are built on the device: a round costs the host little besides the tile plans, so it goes as ONE batch;
+  // PTZ_BATCHER_PARTS splits it over host threads (batches overlap each other's host and device work)
+  size_t parts = 1;
+  if (const char* e = getenv("PTZ_BATCHER_PARTS")) parts = std::max<size_t>(1, std::min<size_t>(reqs.size(), static_cast<size_t>(atoi(e))));
+  stats_.ba_batches += static_cast<long>(parts);
+  stats_.ba_problems += static_cast<long>(reqs.size());
+  if (parts > 1) {
+    std::vector<std::vector<BavReq*>> chunk(parts);
+    for (size_t i = 0; i < reqs.size(); ++i) chunk[i * parts / reqs.size()].push_back(reqs[i]);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; ++k) th.emplace_back([&, k] { RunBaViewBatch(chunk[k]); });
+    RunBaViewBatch(chunk[0]);
+    for (std::thread& t : th) t.join();
+  }
+  else RunBaViewBatch(reqs);
+  stats_.ba_ms += NowMs() - t0;
+}
+
+void DeviceBatcher::RunBaViewBatch(std::vector<BavReq*>& reqs)
+{
+  const int32_t n = static_cast<int32_t>(reqs.size());
+  if (n == 1) {
+    BavReq& r = *reqs[0];
+    r.rc = SolveOneView(r.view, r.factor_type, r.cam, r.rkinv, r.opt, r.summary);
+    return;
+  }
+  std::vector<ptz_rig_view> views(n);
+  size_t n_cam = 0;
+  for (int32_t i = 0; i < n; ++i) { views[i] = *reqs[i]->view; n_cam += static_cast<size_t>(views[i].n_cam); }
+  std::vector<double> cam(15 * n_cam), rk(9 * n_cam);
+  {
+    size_t co = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      memcpy(cam.data() + 15 * co, reqs[i]->cam, sizeof(double) * 15 * views[i].n_cam);
+      memcpy(rk.data() + 9 * co, reqs[i]->rkinv, sizeof(double) * 9 * views[i].n_cam);
+      co += static_cast<size_t>(views[i].n_cam);
+    }
+  }
+  std::vector<ptz_lm_summary> summ(n);
+  ptz_ba_batch* b = nullptr;
+  const double t0 = NowMs();
+  int32_t rc = ptz_ba_batch_create_views(n, views.data(), reqs[0]->factor_type, reqs[0]->opt, &b);
+  const double t1 = NowMs();
+  if (rc == PTZ_OK) rc = ptz_ba_batch_set_state_pix2ray(b, cam.data(), rk.data());
+  const double t2 = NowMs();
+  if (rc == PTZ_OK) rc = ptz_ba_batch_solve(b, summ.data());
+  const double t3 = NowMs();
+  if (rc == PTZ_OK) rc = ptz_ba_batch_get_state(b, cam.data(), nullptr, nullptr);
+  const double t4 = NowMs();
+  if (b) ptz_ba_batch_destroy(b);
+  if (Trace())
+    fprintf(stderr, "batcher views n=%d cams=%zu create %.2f set %.2f solve %.2f get %.2f destroy %.2f ms\n", n, n_cam, t1 - t0, t2 - t1, t3 - t2, t4 - t3,
+            NowMs() - t4);
+  if (rc != PTZ_OK && rc != PTZ_ENODEVICE && rc != PTZ_ENOMEM) {
+    // a view without candidate observations (or an oversized one) must not fail its neighbours: every request gets its own verdict
+    for (BavReq* r : reqs) r->rc = SolveOneView(r->view, r->factor_type, r->cam, r->rkinv, r->opt, r->summary);
+    return;
+  }
+  size_t co = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    BavReq& r = *reqs[i];
+    r.rc = rc;
+    if (rc == PTZ_OK) {
+      memcpy(r.cam, cam.data() + 15 * co, sizeof(double) * 15 * views[i].n_cam);
+      if (r.summary) *r.summary = summ[i];
+    }
+    co += static_cast<size_t>(views[i].n_cam);
+  }
+}
+
 void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
 {
   const double t0 = NowMs();
@@ -250,6 +364,13 @@ int32_t DeviceBaSolve(const ptz_ba_problem* p, double* cam, double* ray, double*
 {
   if (DeviceBatcher* b = DeviceBatcher::Current()) return b->BaSolve(p, cam, ray, tlw, opt, summary);
   return ptz_ba_solve(p, cam, ray, tlw, opt, summary);
+}
+
+int32_t DeviceBaSolveView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt,
+                          ptz_lm_summary* summary)
+{
+  if (DeviceBatcher* b = DeviceBatcher::Current()) return b->BaSolveView(view, factor_type, cam, rkinv, opt, summary);
+  return SolveOneView(view, factor_type, cam, rkinv, opt, summary);
 }
 
 int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,

@@ -29,6 +29,9 @@ class DeviceBatcher {
   int32_t KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
                         double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                         ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+  // a bundle adjustment over a VIEW of device-resident tracks (ptz_ba_batch_create_views): cam [15 n_cam] in / out, rkinv [9 n_cam]
+  int32_t BaSolveView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt,
+                      ptz_lm_summary* summary);
   void ClientDone();  // the calling client makes no further calls (its optimizer has returned)
 
   struct Stats {
@@ -54,6 +57,12 @@ class DeviceBatcher {
     int32_t factor_type; double max_reproj_error; const ptz_lm_options* opt; ptz_lm_summary* summaries; int32_t* accepted;
     double* device_ms; int32_t rc;
   };
+  struct BavReq {
+    const ptz_rig_view* view; int32_t factor_type; double* cam; const double* rkinv; const ptz_lm_options* opt; ptz_lm_summary* summary; int32_t rc;
+  };
+  void RunBaViews(std::vector<BavReq*>& reqs);
+  static void RunBaViewBatch(std::vector<BavReq*>& reqs);  // one ptz_ba_batch_create_views for all of them
+  std::vector<BavReq*> bav_;
   void Arrive(std::unique_lock<std::mutex>& lk);  // called with the request already queued
   void RunRound();                                // executes and clears the queues (lock held: every other client is waiting)
   void RunBa(std::vector<BaReq*>& reqs);
@@ -71,6 +80,8 @@ class DeviceBatcher {
 
 // The device calls of the optimizer classes: through the calling thread's DeviceBatcher when it has one.
 int32_t DeviceBaSolve(const ptz_ba_problem* p, double* cam, double* ray, double* tlw, const ptz_lm_options* opt, ptz_lm_summary* summary);
+int32_t DeviceBaSolveView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt,
+                          ptz_lm_summary* summary);
 int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
                             double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                             ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);

@@ -73,6 +73,11 @@ PtzIncrementalOptimizer::PtzIncrementalOptimizer(const std::vector<ImageFeatures
 {
 }
 
+PtzIncrementalOptimizer::~PtzIncrementalOptimizer()
+{
+  if (rig_) ptz_rig_destroy(rig_);
+}
+
 void PtzIncrementalOptimizer::SetSeedImageId(const std::vector<long>& image_ids) { seed_image_ids_ = image_ids; }
 
 bool PtzIncrementalOptimizer::CheckValid() const
@@ -90,6 +95,22 @@ bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered
 {
   if (!CheckValid()) return false;
   if (!tracks_) tracks_ = PTZRayOptimizer::BuildTracks(matches_info_);
+  if (!rig_ && !tracks_->id.empty() && !(getenv("PTZ_IBA_VIEWS") && atoi(getenv("PTZ_IBA_VIEWS")) == 0)) {
+    // the tracks go to the device once: image id and pixel of every view (PTZ_IBA_VIEWS=0: pack every bundle adjustment on the host)
+    const SharedTracks& st = *tracks_;
+    std::vector<float> uv(2 * st.img.size());
+    bool ok = true;
+    for (size_t e = 0; e < st.img.size() && ok; ++e) {
+      ok = st.img[e] >= 0 && static_cast<size_t>(st.img[e]) < features_.size() && st.feat[e] >= 0 &&
+           static_cast<size_t>(st.feat[e]) < features_[st.img[e]].keypoints.size();
+      if (!ok) break;
+      const Point2f pt = features_[st.img[e]].keypoints[st.feat[e]].pt;
+      uv[2 * e] = pt.x; uv[2 * e + 1] = pt.y;
+    }
+    if (ok && ptz_rig_create(static_cast<int32_t>(features_.size()), static_cast<int32_t>(st.id.size()), st.ptr.data(), st.img.data(), uv.data(), device_id_,
+                             &rig_) != PTZ_OK)
+      rig_ = nullptr;  // (the bundle adjustments then pack on the host)
+  }
   by_dst_.assign(features_.size(), {});
   for (size_t e = 0; e < matches_info_.size(); ++e) {
     const MatchesInfo& mi = matches_info_[e];
@@ -291,6 +312,7 @@ bool PtzIncrementalOptimizer::RunBundle(const std::unordered_set<long>& ids)
     }
   PTZRayOptimizer optimizer(PTZRayOptimizer::Borrow{}, features_, matches_info_, cameras_, ids, max_iter_, PTZRay);
   optimizer.UseTracks(tracks_);
+  optimizer.UseRig(rig_);
   optimizer.SetDevice(device_id_);
   const bool ok = optimizer.Solve(cameras_);
   timing_ms_[2] += optimizer.device_ms();

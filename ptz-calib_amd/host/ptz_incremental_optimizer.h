@@ -33,6 +33,9 @@ class PtzIncrementalOptimizer {
   PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
                           const std::vector<Camera>& cameras, const std::vector<std::string>& names, int max_iter);
 
+  ~PtzIncrementalOptimizer();
+  PtzIncrementalOptimizer(const PtzIncrementalOptimizer&) = delete;
+  PtzIncrementalOptimizer& operator=(const PtzIncrementalOptimizer&) = delete;
   bool Solve(std::vector<Camera>& cameras, std::unordered_set<long>& reg_image_ids);
   void SetSeedImageId(const std::vector<long>& image_ids);
 
@@ -95,6 +98,9 @@ class PtzIncrementalOptimizer {
   std::unordered_set<long> reg_image_ids_;
   std::vector<long> seed_image_ids_;
   std::shared_ptr<const SharedTracks> tracks_;
+  // the same tracks resident on the device (ptz_rig_create, once per rig): every bundle adjustment of the run is a view of them
+  // ("keep tracks and packed observations resident and grow them instead of rebuilding")
+  ptz_rig* rig_ = nullptr;
   std::vector<std::vector<size_t>> by_dst_;  // table entries (indices into matches_info_, ascending) per destination image
   std::unordered_map<const MatchesInfo*, Attempt> attempt_cache_;  // valid until the next successful bundle adjustment
   std::vector<Event> events_;

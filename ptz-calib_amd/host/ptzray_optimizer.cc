@@ -306,12 +306,77 @@ bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras)
 
 bool PTZRayOptimizer::Solve(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>& rays) { return SolveImpl(cameras, &rays); }
 
+// Solve over a view of the resident rig: candidate cameras (ascending image id, SetUpInitialCameraParams' order :635-670) and their
+// R^-1 K^-1 for Pix2Ray (:786) are all the host prepares; residual blocks, weights, ray initialisation and the solve are the
+// device's (ptz_ba_batch_create_views, ptz_ba_batch_set_state_pix2ray).
+bool PTZRayOptimizer::SolveView(std::vector<Camera>& cameras)
+{
+  PackedBA& p = packed_;
+  p = PackedBA();
+  std::vector<int32_t> cam_image;
+  for (size_t i = 0; i < num_cams_; ++i) {
+    if (!isCandidate(static_cast<long>(i))) continue;
+    p.cam_image.push_back(static_cast<long>(i));
+    cam_image.push_back(static_cast<int32_t>(i));
+    const std::vector<double> v = cameras_[i].ToVector();
+    p.cam.insert(p.cam.end(), v.begin(), v.end());
+  }
+  if (cam_image.empty()) return false;
+  std::vector<double> rkinv(9 * cam_image.size());
+  for (size_t c = 0; c < cam_image.size(); ++c) {
+    const Mat33 m = Mul(Inverse(cameras_[cam_image[c]].R()), Inverse(cameras_[cam_image[c]].K()));  // as Pack() evaluates it
+    for (int k = 0; k < 9; ++k) rkinv[9 * c + k] = m[k];
+  }
+  ptz_lm_options opt;
+  ptz_lm_options_default(&opt);
+  opt.max_num_iterations = max_iter_;  // ptzray_optimizer.cc:470
+  opt.device_id = device_id_;
+  const int32_t ftype = (type_ == PTZRay) ? PTZ_BA_PTZRay : (type_ == PTZRayDist ? PTZ_BA_PTZRayDist : PTZ_BA_PTZRayFxfyDist);
+  ptz_rig_view view{rig_, static_cast<int32_t>(cam_image.size()), cam_image.data()};
+  std::vector<double> cam = p.cam;
+  tlw_init_ = p.tlw;
+  disp_ = {{0.0, 0.0, 0.0}};
+  const auto t_dev = std::chrono::steady_clock::now();
+  const int32_t rc = DeviceBaSolveView(&view, ftype, cam.data(), rkinv.data(), &opt, &summary_);
+  device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
+  if (rc == PTZ_EINVAL) return false;  // no track has a candidate view: no residual block, not a problem (the packed path returns false there too)
+  if (rc != PTZ_OK) {
+    fprintf(stderr, "[ptzcalib] PTZRayOptimizer::Solve: device solve not run, ptz_ba_batch_create_views / solve returned %d\n", (int)rc);
+    return false;
+  }
+  init_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.initial_cost) / summary_.num_residuals);
+  final_reproj_error_all_ = std::sqrt(2.0) * std::sqrt((2 * summary_.final_cost) / summary_.num_residuals);
+  p.cam = cam;
+  errors_ready_ = true;  // (the unweighted statistics need the packed residuals; callers of this path -- the incremental pipeline -- never read them)
+  final_reproj_error_2d2d_ = final_reproj_error_2d3d_ = std::numeric_limits<double>::quiet_NaN();
+  if (summary_.termination_type != PTZ_CONVERGENCE) return false;  // :482-488
+  // ObtainRefinedCameraParams (:672-766) with T_l_w = identity (no annotations on this path)
+  if (cameras.size() < num_cams_) cameras.resize(num_cams_);
+  for (size_t c = 0; c < p.cam_image.size(); ++c) {
+    std::vector<double> param(cam.begin() + 15 * c, cam.begin() + 15 * (c + 1));
+    if (type_ != PTZRayFxfyDist) param[1] = param[0];  // fy := fx (:705-706)
+    Camera& out = cameras[p.cam_image[c]];
+    out.FromVector(param);
+    // (the packed path composes with T_l_w = (I, 0) here: R I and R 0 + t, the same values)
+    const Mat33 R_l_w = Rodrigues({0.0, 0.0, 0.0});
+    const Vec3 Rt = Mul(out.R(), Vec3{0.0, 0.0, 0.0});
+    out.t() = {Rt[0] + out.t()[0], Rt[1] + out.t()[1], Rt[2] + out.t()[2]};
+    out.R() = Mul(out.R(), R_l_w);
+  }
+  return true;
+}
+
 bool PTZRayOptimizer::SolveImpl(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>* rays_out)
 {
   if (!CheckValid()) return false;
   FindTracks();
   SetInitTransLocalToWorld();
   if (type_ != PTZRay && type_ != PTZRayDist && type_ != PTZRayFxfyDist && type_ != PTZRayDistDisp) return false;
+  // A view of device-resident tracks (UseRig): nothing is packed on the host but the candidate cameras themselves.
+  bool view_path = rig_ != nullptr && rays_out == nullptr && pixels_.empty() && type_ != PTZRayDistDisp;
+  for (size_t i = 0; view_path && i < num_cams_; ++i)
+    if (isCandidate(static_cast<long>(i)) && shared_ic_ids_[i] != static_cast<long>(i)) view_path = false;
+  if (view_path) return SolveView(cameras);
   Pack();
   PackedBA& p = packed_;
   if (p.obs_cam.empty() || p.ray_track.empty()) return false;

@@ -68,6 +68,10 @@ class PTZRayOptimizer {
   // one match table (PtzIncrementalOptimizer) builds them once and shares them instead of repeating FindTracks().
   void UseTracks(std::shared_ptr<const SharedTracks> tracks) { shared_tracks_ = std::move(tracks); }
   static std::shared_ptr<const SharedTracks> BuildTracks(const std::vector<MatchesInfo>& matches_info);
+  // The same tracks resident on the device (ptz_rig_create): a solve over a candidate subset is then a VIEW of them -- the
+  // packed problem is built on the device, the host neither walks the tracks nor uploads observations (2D-2D residuals without
+  // shared intrinsics; anything else packs on the host as before).  Same arrays, same initial rays, same bits.
+  void UseRig(const ptz_rig* rig) { rig_ = rig; }
   // Same as the 2D-2D constructor but WITHOUT the deep copies of features / matches (ptzray_optimizer.h:145-149): the
   // caller keeps both alive until Solve returns.
   struct Borrow {};
@@ -77,6 +81,7 @@ class PTZRayOptimizer {
  private:
   bool CheckValid() const;
   bool SolveImpl(std::vector<Camera>& cameras, std::vector<std::vector<Ray>>* rays);
+  bool SolveView(std::vector<Camera>& cameras);
   void FindTracks();
   bool isCandidate(long image_id) const { return cam_ids_.count(image_id) != 0; }
   void Pack();
@@ -89,6 +94,7 @@ class PTZRayOptimizer {
   const std::vector<ImageFeatures>& features_;
   const std::vector<MatchesInfo>& matches_info_;
   std::shared_ptr<const SharedTracks> shared_tracks_;
+  const ptz_rig* rig_ = nullptr;
   std::vector<std::vector<Point2f>> pixels_;
   std::vector<std::vector<Point3d>> pts3d_;
   size_t num_cams_ = 0;

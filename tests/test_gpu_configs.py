@@ -266,3 +266,28 @@ def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg, monkeypatch):
         for a, b in zip(solo, again):
             assert b["ok"] and a["events"] == b["events"] and a["registered"] == b["registered"] and np.array_equal(a["cameras"], b["cameras"])
         assert st2["ba_problems"] == n_ba_solo
+
+
+def test_ptz_iba_over_resident_tracks_takes_the_decisions_of_host_packed_runs(pkg, monkeypatch):
+    """PtzIncrementalOptimizer keeps a rig's tracks resident on the device and asks for every bundle adjustment as a VIEW of them
+    (ptz_ba_batch_create_views builds the packed problem there, Pix2Ray included); PTZ_IBA_VIEWS=0 packs every bundle adjustment
+    on the host as the reference does (ptz_incremental_optimizer.cc:420-440 -> ptzray_optimizer.cc:537-552, 799-850).  Same
+    arrays, same initial rays: identical events (with LM iteration counts), registered sets and bit-identical cameras, solo and
+    in lock step."""
+    shapes = [(1, 20, True), (3, 24, False), (6, 40, True)]
+    tables, cam0 = [], []
+    for seed, n_views, bi in shapes:
+        tb = pkg.synth.make_match_table(pkg.synth.make_scene(seed, n_views, 100), bidirectional=bi)
+        tables.append(tb)
+        c = np.zeros((tb.n_img, 15)); c[:, 0] = c[:, 1] = 1.0
+        cam0.append(c)
+    views = [pkg.hostlib.incremental_solve(tb, c, max_iter=200) for tb, c in zip(tables, cam0)]
+    vbatch, vstats = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200)
+    monkeypatch.setenv("PTZ_IBA_VIEWS", "0")
+    packed = [pkg.hostlib.incremental_solve(tb, c, max_iter=200) for tb, c in zip(tables, cam0)]
+    for a, b, c in zip(views, packed, vbatch):
+        assert a["ok"] and b["ok"] and c["ok"]
+        assert a["events"] == b["events"] == c["events"]
+        assert a["registered"] == b["registered"] == c["registered"]
+        assert np.array_equal(a["cameras"], b["cameras"]) and np.array_equal(a["cameras"], c["cameras"])
+    assert vstats["ba_problems"] >= 3 * vstats["ba_batches"] - 2  # (three rigs in one lock step: a round's bundle adjustments are one batch)
