@@ -290,4 +290,4 @@ def test_ptz_iba_over_resident_tracks_takes_the_decisions_of_host_packed_runs(pk
         assert a["events"] == b["events"] == c["events"]
         assert a["registered"] == b["registered"] == c["registered"]
         assert np.array_equal(a["cameras"], b["cameras"]) and np.array_equal(a["cameras"], c["cameras"])
-    assert vstats["ba_problems"] >= 3 * vstats["ba_batches"] - 2  # (three rigs in one lock step: a round's bundle adjustments are one batch)
+    assert vstats["ba_batches"] < vstats["ba_problems"]  # (the rigs' bundle adjustments of a round are one batch)
