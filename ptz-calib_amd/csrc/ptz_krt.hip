@@ -112,8 +112,14 @@ template <int G> __device__ __forceinline__ double group_sum(double v)
 template <int G> struct KrtCache { static constexpr int N = G == 64 ? 256 : 128; };  // matches per query whose constant part is cached
 // P3: the queries also carry 2D-3D constraints (KRTOptimizer::Add2d3dConstraints, krt_optimizer.cc:350-383): world points,
 // moved into the local frame of the reference camera as the reference does (:357-362), one residual block each.
+#ifndef PTZ_KRT_OCC_DIST
+#define PTZ_KRT_OCC_DIST 2
+#endif
+#ifndef PTZ_KRT_OCC_PLAIN
+#define PTZ_KRT_OCC_PLAIN 2
+#endif
 template <int KTYPE, bool P3, int G>
-__global__ __launch_bounds__(256, 2) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
+__global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_PLAIN) void k_krt(int n_query, const long long* __restrict__ match_ptr, const float2* __restrict__ uv_ref,
                                              const float2* __restrict__ uv_cur, const long long* __restrict__ point_ptr,
                                              const float2* __restrict__ pt_uv, const double* __restrict__ pt_xyz,
                                              const double* __restrict__ cam_ref, double* __restrict__ cam_cur, KrtOpt o,
