@@ -181,12 +181,13 @@ std::vector<char> PtzIncrementalOptimizer::SolveBatch(const std::vector<PtzIncre
   cameras.resize(n);
   reg_image_ids.resize(n);
   std::vector<char> ok(n, 0);
-  // Cohorts: the rigs are dealt to a few independent lock steps (rig i -> cohort i % K), each with its own DeviceBatcher.  While
-  // one cohort's round is on the device (or in its host-side batch creation) the rigs of the others do their own host work --
-  // ranking, packing, bookkeeping -- which a single lock step leaves serialised with the rounds.  Results do not depend on it.
-  // Measured, 64 rigs x 200 views, ms inside this call: 1 cohort 1349, 2: 1100, 4: 816, 8: 634, 16: 603, 32: 1086, 64 (no
-  // batching at all, 64 streams): 2475 -- four rigs per cohort, at most one cohort per host core.
-  size_t n_cohorts = std::max<size_t>(1, std::min<size_t>(n / 4, std::max(1u, std::thread::hardware_concurrency())));
+  // ONE lock step over all rigs: with the rigs' tracks resident on the device a round's bundle adjustments are one device-built
+  // batch (~19 problems for 64 rigs of 200 views) and its registration attempts one launch beside it, and the host work of a round
+  // is what the rigs do themselves, in parallel.  (Round 3 packed every problem on the host and had to split the rigs into
+  // cohorts of four to overlap that work: 1.9 problems per batch.)  PTZ_IBA_COHORTS deals the rigs to several independent lock
+  // steps (rig i -> cohort i % K); measured, 64 rigs x 200 views, ms inside this call: 1: 444, 2: 408, 3: 396, 16: 610 -- a second
+  // cohort overlaps one's host work with the other's device rounds at half the batch size.  Results do not depend on it.
+  size_t n_cohorts = 1;
   if (const char* e = getenv("PTZ_IBA_COHORTS")) n_cohorts = static_cast<size_t>(std::max(1, atoi(e)));
   n_cohorts = std::max<size_t>(1, std::min(n_cohorts, n));
   std::vector<std::unique_ptr<DeviceBatcher>> batchers;
