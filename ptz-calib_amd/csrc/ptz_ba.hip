@@ -486,7 +486,11 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   // step is judged (k_lin_cam, Dev::spec_lin), and one control point per pass judges the step and opens the next iteration
   // (lm_step_wave) -- a launch of its own (k_lm_step), or in launch shapes of a few scenes the tail of k_lin_cam (Dev::fuse_ctl, with
   // the camera update in k_eval's prologue).  The others keep k_lm_post / k_lin_cam at the accepted point / k_lm_pre.
-  const bool fast = TYPE < 3 && !d.shared && !b->schur_w;  // (round 2's Schur kernel reads W rows of the CURRENT point, which are not double-buffered)
+  // (Not for large launch shapes: there the speculative linearisation of the steps that end up rejected costs more than the second
+  //  control launch it saves -- C4: linearise 19 -> 27 ms per solve against 3 ms of control.  Both forms take the same decisions
+  //  with the same bits, so a scene may change between them from pass to pass.  Round 2's Schur kernel reads W rows of the
+  //  CURRENT point, which are not double-buffered.)
+  const bool fast = TYPE < 3 && !d.shared && !b->schur_w && sh.fuse_ctl;
   const bool fuse = sh.fuse_ctl && fast;
   d.spec_lin = fast ? 1 : 0;
   d.fuse_ctl = fuse ? 1 : 0;
