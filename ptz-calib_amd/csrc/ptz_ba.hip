@@ -88,6 +88,8 @@ struct ptz_ba_batch {
   ptz_lm_options opt;
   Dev d;
   std::vector<void*> allocs;
+  std::vector<void*> staged_pinned;  // staging blocks of uploads still in flight on `io` (released behind the next wait for it)
+  void release_staged() { for (void* p : staged_pinned) ptzpool::pinned_release(p); staged_pinned.clear(); }
   hipStream_t stream = nullptr;   // stream of the group being enqueued (LAUNCH / prof_* use it)
   hipStream_t io = nullptr;       // uploads of ptz_ba_batch_create (before the group streams exist); see copy_on()
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -361,7 +363,9 @@ struct StagedUpload {
   {
     items.push_back({h.data(), sizeof(T) * h.size(), reinterpret_cast<const void**>(dev)});
   }
-  int commit(ptz_ba_batch* b)
+  // wait = false: the copy is left in flight on b->io (kernels enqueued there see the data; the caller's next wait for that stream
+  // -- followed by b->release_staged() -- ends it)
+  int commit(ptz_ba_batch* b, bool wait = true)
   {
     auto up = [](size_t x) { return (std::max<size_t>(x, 1) + 255) & ~(size_t)255; };
     size_t total = 0;
@@ -388,6 +392,7 @@ struct StagedUpload {
       off += up(it.bytes);
     }
     hipError_t e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, b->io);
+    if (e == hipSuccess && !wait) { b->staged_pinned.push_back(pinned); return PTZ_OK; }
     if (e == hipSuccess) e = stream_wait(b->io);
     ptzpool::pinned_release(pinned);
     return e == hipSuccess ? PTZ_OK : PTZ_ENODEVICE;
@@ -450,7 +455,7 @@ static void make_groups(ptz_ba_batch* b)
     d.host_ctl = b->h_ctl_dev + 4 * g;
     d.act = b->d_act + lo;
     d.use_act = 0;
-    if (d.chol.L) d.chol.L = b->d.chol.L + (size_t)g * std::min(b->n_scene, 8) * np * np;  // up to eight slots of finished L tiles per group
+    if (d.chol.L) d.chol.L = b->d.chol.L + (size_t)g * std::min(b->n_scene, CHOL_CHAIN_SLOTS) * np * np;  // slots of finished L tiles per group
     if (d.chol.chain_ctl) d.chol.chain_ctl = b->d.chol.chain_ctl + (size_t)g * chol_chain_ctl_ints((int)np);  // (a block per stream)
     if (d.chol.bs_items) { d.chol.bs_items += (size_t)lo * 4 * chol_backsolve_max_groups((int)np); d.chol.bs_groups += lo; }
     b->dg.push_back(d);
@@ -945,6 +950,7 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   for (auto st : b->streams) (void)stream_wait(st);
   for (auto st : b->aux) (void)stream_wait(st);
   if (b->io) (void)stream_wait(b->io);
+  b->release_staged();
   const int dv = b->device;
   for (void* p : b->allocs) ptzpool::dev_release(dv, p);
   for (auto e : b->ev_pool) ptzpool::event_release(dv, true, e);
@@ -1539,20 +1545,30 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       if (rg->n_track >= (1 << 24) || (int64_t)(rg->n_view / std::max(1, rg->n_track) + 64) * v.n_cam >= (1 << 22)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
     }
     const ViewDev* dviews_c = nullptr;
-    const int *d_map = nullptr, *d_camimg = nullptr;
+    const int *d_map = nullptr, *d_camimg = nullptr, *d_chunkoff = nullptr;
+    std::vector<int> h_chunkoff(n);
+    size_t chunk_total = 0;  // [chunks of 256 rays][cameras] counters of the views (k_view_hist), bounds from the rigs' track counts
+    for (int i = 0; i < n; ++i) {
+      h_chunkoff[i] = (int)chunk_total;
+      chunk_total += (size_t)((views[i].rig->n_track + 255) / 256) * views[i].n_cam;
+      if (chunk_total > 0x7fffffffu) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+    }
     {
       StagedUpload up;
       up.add(b->scenes, &d.scene);
       up.add(hv, &dviews_c);
       up.add(h_map, &d_map);
       up.add(h_camimg, &d_camimg);
-      TRY(up.commit(b));
+      up.add(h_chunkoff, &d_chunkoff);
+      TRY(up.commit(b, /*wait=*/false));
     }
     ViewBuild vb;
     memset(&vb, 0, sizeof(vb));
     vb.views = const_cast<ViewDev*>(dviews_c);
     vb.cam_of_image = d_map; vb.cam_image = d_camimg;
     vb.scene = const_cast<SceneDev*>(d.scene);
+    vb.chunk_off = d_chunkoff;
+    if (b->max_cam <= VIEW_LDS_CAMS) TRY(b->alloc(&vb.chunk_cnt, chunk_total));
     unsigned long long *key_out = nullptr;
     int* val_out = nullptr;
     TRY(b->alloc(&vb.t_len, trk_total)); TRY(b->alloc(&vb.t_first, trk_total)); TRY(b->alloc(&vb.t_ext, trk_total));
@@ -1582,9 +1598,16 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     }
     hipLaunchKernelGGL(k_view_rays, gtrk, dim3(256), 0, st, vb, (const int*)val_out);
     hipLaunchKernelGGL(k_view_rayscan, dim3(n), dim3(1024), 0, st, vb, b->ray_block);
-    hipLaunchKernelGGL(k_view_obs, gtrk, dim3(256), 0, st, vb);
-    hipLaunchKernelGGL(k_view_camscan, dim3(n), dim3(1024), 0, st, vb);
-    hipLaunchKernelGGL(k_view_camlists, dim3(b->max_cam, n), dim3(256), 0, st, vb);
+    if (b->max_cam <= VIEW_LDS_CAMS) {  // camera-major lists by counting: chunk histograms, running sums, placement
+      hipLaunchKernelGGL(k_view_hist, gtrk, dim3(256), sizeof(int) * (size_t)b->max_cam, st, vb);
+      hipLaunchKernelGGL(k_view_chunkscan, dim3(n), dim3(1024), 0, st, vb);
+      hipLaunchKernelGGL(k_view_place, gtrk, dim3(256), sizeof(unsigned long long) * 4 * (size_t)b->max_cam, st, vb);
+    }
+    else {
+      hipLaunchKernelGGL(k_view_obs, gtrk, dim3(256), 0, st, vb);
+      hipLaunchKernelGGL(k_view_camscan, dim3(n), dim3(1024), 0, st, vb);
+      hipLaunchKernelGGL(k_view_camlists_wide, dim3(b->max_cam, n), dim3(256), 0, st, vb);
+    }
     // camera pairs, entry lists, runs: k_pairs as for any batch, into arrays of the bounds' extents (no sizing read-back)
     PairsDev pa;
     memset(&pa, 0, sizeof(pa));
@@ -1630,6 +1653,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       if (e == hipSuccess) e = hipMemcpyAsync(h_tot.data(), d_tot, sizeof(int) * (6 * n + 1), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(h_adj.data(), d_adj, h_adj.size(), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = stream_wait(st);
+      b->release_staged();
       if (e == hipSuccess) e = hipGetLastError();
       if (e != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     }
@@ -1847,19 +1871,20 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   // reduced camera systems
   d.chol.count = n;
   d.chol.np = chol_padded_order(b->max_n);
-  {
-    std::vector<int> hn(n);
-    for (int i = 0; i < n; ++i) hn[i] = b->scenes[i].n;
-    const int* dn = nullptr;
-    TRY(upload(b, hn, &dn));
-    d.chol.n = dn;
-  }
+  // the systems' orders and (below) their tile structure, elimination order, step schedule and back-substitution lists: ONE upload
+  StagedUpload up2;
+  std::vector<int> hn(n);
+  for (int i = 0; i < n; ++i) hn[i] = b->scenes[i].n;
+  up2.add(hn, &d.chol.n);
+  std::vector<unsigned char> hm;
+  std::vector<int> h_tperm, h_sched, h_groups;
+  std::vector<BsItem> h_items;
   TRY(b->alloc(&d.chol.A, (size_t)n * d.chol.np * d.chol.np));
   {
     // the one-launch-per-column factorisation (a few scenes, or the last few active scenes of a large batch) publishes its
-    // finished L tiles in a second matrix, indexed by launch slot: eight slots per scene group
+    // finished L tiles in a second matrix, indexed by launch slot: up to CHOL_CHAIN_SLOTS slots per scene group
     const int groups = std::max(1, std::min(b->n_group_hint(n), n));
-    const size_t slots = (size_t)std::min(n, 8) * groups;
+    const size_t slots = (size_t)std::min(n, CHOL_CHAIN_SLOTS) * groups;
     TRY(b->alloc(&d.chol.L, slots * d.chol.np * d.chol.np));
     if (hipMemsetAsync(d.chol.L, 0, sizeof(double) * slots * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     TRY(b->alloc(&b->d_act, (size_t)n));
@@ -1883,8 +1908,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     bool dissect = true;
     bool nested = true;
     if (const char* e = getenv("PTZ_BA_ORDER")) { dissect = strcmp(e, "natural") != 0; nested = strcmp(e, "flat") != 0; }
-    std::vector<unsigned char> hm((size_t)n * nt * nt, 0);
-    std::vector<int> h_tperm((size_t)n * nt), h_sched((size_t)n * nt * CHOL_STEP_COLS, -1);
+    hm.assign((size_t)n * nt * nt, 0);
+    h_tperm.resize((size_t)n * nt); h_sched.assign((size_t)n * nt * CHOL_STEP_COLS, -1);
     int max_steps = 0;
     bool any_plan = false;
     std::vector<unsigned char> m0((size_t)nt * nt);
@@ -1947,16 +1972,10 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       for (int st = 0; st < steps; ++st) b->sched_kmin[st] = std::min(b->sched_kmin[st], sched[CHOL_STEP_COLS * st]);  // (slot 0 of a step holds its smallest column)
       if (dbg_t && i == 0) fprintf(stderr, "[ptz_ba_create] scene 0: %d tiles, elimination %s: lanes %d + %d, %d steps\n", nt, planned ? "dissected" : "natural", lane_a, lane_b, steps);
     }
-    const unsigned char* dm = nullptr;
-    TRY(upload(b, hm, &dm));
-    d.chol.tmask = dm;
+    up2.add(hm, &d.chol.tmask);
     if (any_plan) {
-      const int* dp = nullptr;
-      TRY(upload(b, h_tperm, &dp));
-      d.tperm = dp;
-      d.chol.xperm = dp;
-      TRY(upload(b, h_sched, &dp));
-      d.chol.sched = dp;
+      up2.add(h_tperm, &d.tperm);  // (d.chol.xperm = d.tperm once the upload has placed it)
+      up2.add(h_sched, &d.chol.sched);
       d.chol.n_steps = max_steps;
       d.chol.sched_kmin = b->sched_kmin.data();
     }
@@ -1964,22 +1983,20 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       const int mg = chol_backsolve_max_groups(d.chol.np);
       const char* e = getenv("PTZ_BA_BACKSOLVE_HOST_LIST");  // 0: the kernel makes the list itself (tests: the same list, the same bits)
       if ((!e || atoi(e) != 0) && sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
-        std::vector<BsItem> h_items((size_t)n * 4 * mg);
-        std::vector<int> h_groups(n);
+        h_items.resize((size_t)n * 4 * mg);
+        h_groups.resize(n);
         for (int i = 0; i < n; ++i)
           h_groups[i] = chol_backsolve_plan(d.chol.np, b->scenes[i].n, hm.data() + (size_t)i * nt * nt,
                                             any_plan ? h_sched.data() + (size_t)i * nt * CHOL_STEP_COLS : nullptr, max_steps, h_items.data() + (size_t)i * 4 * mg);
-        const BsItem* di = nullptr;
-        const int* dgp = nullptr;
-        TRY(upload(b, h_items, &di));
-        TRY(upload(b, h_groups, &dgp));
-        d.chol.bs_items = di;
-        d.chol.bs_groups = dgp;
+        up2.add(h_items, &d.chol.bs_items);
+        up2.add(h_groups, &d.chol.bs_groups);
       }
     }
     // tiles outside the structure are never written again: zero everything once (the block may be a recycled one)
     if (hipMemsetAsync(d.chol.A, 0, sizeof(double) * (size_t)n * d.chol.np * d.chol.np, b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
   }
+  TRY(up2.commit(b, /*wait=*/false));  // (the wait for the zero fills at the end of this function ends it)
+  d.chol.xperm = d.tperm;
 #undef TRY
   d.cam_x0 = b->cam0; d.ray_x0 = b->ray0;
   d.opt.max_num_iterations = o.max_num_iterations;
@@ -2040,8 +2057,10 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     sh.ray_block = slots <= 4 ? 128 : (slots <= 32 ? 256 : RAY_BLOCK);
     if (const char* e = getenv("PTZ_BA_RAY_BLOCK")) sh.ray_block = std::min(RAY_BLOCK, std::max(64, (atoi(e) / 64) * 64));
     sh.small_blocks = sh.ray_block <= 256;
-    sh.fused = slots <= 8;
-    if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) sh.fused = atoi(e) != 0 && slots <= 8;
+    // one launch per factorisation (chol_chain_kernel) or per step (chol_col_step_kernel) for a few systems; up to CHOL_CHAIN_SLOTS when
+    // the one-launch form takes them (chol_chain_fits)
+    sh.fused = slots <= 8 || chol_chain_fits(slots, b->d.chol.np);
+    if (const char* e = getenv("PTZ_BA_CHOL_FUSED")) sh.fused = atoi(e) != 0 && sh.fused;
     // a few scenes: LM control and the camera update ride in the tails / prologue of k_eval and k_lin_cam (three launches less per pass)
     sh.fuse_ctl = slots <= 8 && sh.small_blocks && !b->gtab;
     if (const char* e = getenv("PTZ_BA_FUSE_CTL")) sh.fuse_ctl = sh.fuse_ctl && atoi(e) != 0;
@@ -2117,7 +2136,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       attr_done[o.device_id] = 1;
     }
   }
-  if (stream_wait(b->io) != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // the zero fills
+  if (stream_wait(b->io) != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // the zero fills, the staged upload
+  b->release_staged();
   tc3 = now_ms();
   if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms (observations %.2f, pair entries %.2f), uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, ts_obs, ts_ent, tc2 - tc1, tc3 - tc2);
   *out = b;

@@ -1618,24 +1618,29 @@ void chol_col_step_launch(const CholBatch& cb, int step, hipStream_t stream)
   const int m = nt - kmin - 1;
   if (m > 0) launch(chol_col_step_kernel, dim3(m * (m + 1) / 2 + (cb.Linv ? (cb.sched ? CHOL_STEP_COLS : 1) : 0), cb.count), dim3(256), smem, stream, cb, step, kmin);
 }
-bool chol_chain_enabled(const CholBatch& cb)
+bool chol_chain_fits(int count, int np)
 {
   // PTZ_BA_CHOL_CHAIN=0 brings the one-launch-per-step path back (A/B measurements)
   const char* e = getenv("PTZ_BA_CHOL_CHAIN");
   const bool on = !e || atoi(e) != 0;
-  // Every tile's workgroup must be on the chip from the start (135 KB of LDS: one per compute unit, 91 tiles per 800 x 800
-  // system) -- a tile that starts late applies its whole update list in one go at the end of the chain (measured, 800 x 800:
-  // 8 systems 11.6 ms against 10.2 ms with one launch per step, 3 systems 8.66 / 8.55; 1 and 2 systems 7.7 / 8.0 against 8.0 / 8.3;
-  // 3-4 rigs of 80-110 views 1-2 % faster with it, 6 of 60 views even: tools/probes/probe_chain_small.py)
-  // -- i.e. as many systems as have all their tiles on the chip at once: two 800 x 800 systems, up to eight small ones (the growing
-  // rigs of the incremental pipeline)
-  const int nt = cb.np / NB;
-  // (a system so large that even one or two do not fit takes the per-step path: late tiles would sit in bounded waits)
-  const int tiles = cb.count * (nt * (nt + 1) / 2);
-  bool fits = cb.count <= 8 && tiles <= (cb.count <= 2 ? 256 : 192);
-  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) fits = cb.count <= std::max(1, std::min(8, atoi(m)));
-  return on && cb.L && cb.Linv && cb.chain_ctl && fits && nt <= 1024;
+  // The workgroups take their tiles in elimination order (ticket = tile ordinal x system), so a tile only ever waits for
+  // workgroups that started before it: any number of tiles is SAFE.  What it costs when the tiles are not all on the chip from
+  // the start (135 KB of LDS: one workgroup per compute unit; 91 tiles per 800 x 800 system): a tile that starts late applies
+  // its whole update list in one go at the end of the chain (measured, 800 x 800: 8 systems 11.6 ms against 10.2 ms with one
+  // launch per step, 3 systems 8.66 / 8.55; 1 and 2 systems 7.7 / 8.0 against 8.0 / 8.3; 3-4 rigs of 80-110 views 1-2 % faster
+  // with it, 6 of 60 views even: tools/probes/probe_chain_small.py).  Up to eight systems: as many as have all their tiles on
+  // the chip at once.  Nine to CHOL_CHAIN_SLOTS systems (the view batches of the incremental pipeline: ~20 growing rigs per lock
+  // step, each step of the per-step path a launch that 20 small systems cannot fill): one launch as well, up to a tile count
+  // beyond which the per-step kernels' throughput wins.
+  const int nt = np / NB;
+  const int tiles = count * (nt * (nt + 1) / 2);
+  int mid_tiles = 3072;
+  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_TILES")) mid_tiles = atoi(m);
+  bool fits = count <= 8 ? tiles <= (count <= 2 ? 256 : 192) : (count <= CHOL_CHAIN_SLOTS && tiles <= mid_tiles);
+  if (const char* m = getenv("PTZ_BA_CHOL_CHAIN_MAX")) fits = count <= std::max(1, std::min(CHOL_CHAIN_SLOTS, atoi(m)));
+  return on && fits && nt <= 1024;
 }
+bool chol_chain_enabled(const CholBatch& cb) { return cb.L && cb.Linv && cb.chain_ctl && chol_chain_fits(cb.count, cb.np); }
 void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
 {
   const int nt = cb.np / NB;

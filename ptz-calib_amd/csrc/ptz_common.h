@@ -298,9 +298,12 @@ inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int
   return g;
 }
 // ints behind CholBatch::chain_ctl: [0] next ticket, [1] workgroups done, [2] generation of the last finished launch, then for
-// each of up to 8 slots 4 nt "block b of diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
+// each of up to CHOL_CHAIN_SLOTS slots 4 nt "block b of diagonal tile k factored" flags and nt * nt "tile (i, k) final" flags (value = generation)
 // ("diagonal tile k factored" is FOUR flags, one per 16-column block of the tile: consumers take the blocks as they come)
-inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + 8 * (4 * nt + nt * nt); }
+constexpr int CHOL_CHAIN_SLOTS = 32;  // most systems one chol_chain_kernel launch factors (slots of finished L tiles and flags per stream)
+inline size_t chol_chain_ctl_ints(int np) { const size_t nt = (size_t)np / CHOL_NB; return 4 + (size_t)CHOL_CHAIN_SLOTS * (4 * nt + nt * nt); }
+// whether `count` systems of order np are factored by ONE launch (chol_chain_kernel) -- ptz_chol.hip
+bool chol_chain_fits(int count, int np);
 __device__ __forceinline__ int chol_system_of(const CholBatch& cb, int slot)
 {
   if (!cb.act) return slot;

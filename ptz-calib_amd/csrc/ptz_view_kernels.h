@@ -38,6 +38,9 @@ struct ViewBuild {  // batch-wide arrays of the build (device)
   int* ray_trk;              // [total_ray] track of internal ray j
   int* ray_len;              // [total_ray] its candidate views
   int* cam_cnt;              // [total_cam] observations of a camera
+  int* chunk_cnt;            // per view [chunks of 256 internal rays][n_cam]: observations of camera c in the chunk, then (k_view_camscan)
+                             // the number of its observations in the chunks in front
+  const int* chunk_off;      // [n_view] where a view's block of chunk_cnt starts
   SceneDev* scene;
   // outputs (the batch's structure arrays)
   float2* obs_uv; int* obs_cam; int* obs_ray; int* ray_ptr; int* cam_ptr; int* cam_obs; int* wpos; int* cam_ray; float2* cam_uv;
@@ -184,6 +187,109 @@ __global__ __launch_bounds__(256) void k_view_obs(ViewBuild vb)
   }
 }
 
+// ---- camera-major lists by counting (views of up to VIEW_LDS_CAMS cameras; wider ones take k_view_obs / k_view_camlists_wide) --------
+// The camera-major lists hold a camera's observations in ascending observation order, i.e. ascending internal ray: a stable
+// counting sort of the (ray, image)-ordered observations by camera.  Three launches: (1) per chunk of 256 rays, how many
+// observations every camera has in it (LDS histogram; integer sums: no order dependence); (2) per camera, the running sum
+// over the chunks (k_view_camscan); (3) per chunk again, an observation's slot = the camera's range + the chunks in front + its rank
+// inside the chunk -- the lanes in front of it in its wave that see the same camera (one 64-bit lane mask per wave and camera,
+// set with LDS atomics -- an OR, so no order dependence either) + the counts of the waves in front.
+constexpr int VIEW_LDS_CAMS = 2048;
+__global__ __launch_bounds__(256) void k_view_hist(ViewBuild vb)
+{
+  extern __shared__ int vh_lds[];
+  const ViewDev v = vb.views[blockIdx.y];
+  if ((int)blockIdx.x * 256 >= v.n_ray) return;
+  const SceneDev s = vb.scene[blockIdx.y];
+  for (int c = threadIdx.x; c < v.n_cam; c += 256) vh_lds[c] = 0;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < v.n_ray) {
+    const int t = vb.ray_trk[s.ray_off + j];
+    const int* map = vb.cam_of_image + v.map_off;
+    for (int e = v.trk_ptr[t]; e < v.trk_ptr[t + 1]; ++e) {
+      const int img = v.trk_img[e];
+      const int c = (img >= 0 && img < v.n_img) ? map[img] : -1;
+      if (c >= 0) atomicAdd(&vh_lds[c], 1);
+    }
+  }
+  __syncthreads();
+  int* out = vb.chunk_cnt + vb.chunk_off[blockIdx.y] + (size_t)blockIdx.x * v.n_cam;
+  for (int c = threadIdx.x; c < v.n_cam; c += 256) out[c] = vh_lds[c];
+}
+
+// one workgroup per view: per camera the running sum over the chunks (left in chunk_cnt), then the cameras' observation ranges
+__global__ __launch_bounds__(1024) void k_view_chunkscan(ViewBuild vb)
+{
+  __shared__ int wsum[17];
+  const ViewDev v = vb.views[blockIdx.x];
+  const SceneDev s = vb.scene[blockIdx.x];
+  int* cp = vb.cam_ptr + s.cam_off + s.idx;
+  int* cc = vb.chunk_cnt + vb.chunk_off[blockIdx.x];
+  const int nch = (v.n_ray + 255) / 256;
+  int base = 0;
+  for (int c0 = 0; c0 < v.n_cam; c0 += 1024) {
+    const int c = c0 + threadIdx.x;
+    int run = 0;
+    if (c < v.n_cam) {
+      int k = 0;
+      for (; k + 8 <= nch; k += 8) {  // eight loads in flight
+        int x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = cc[(size_t)(k + u) * v.n_cam + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { cc[(size_t)(k + u) * v.n_cam + c] = run; run += x[u]; }
+      }
+      for (; k < nch; ++k) { const int x = cc[(size_t)k * v.n_cam + c]; cc[(size_t)k * v.n_cam + c] = run; run += x; }
+    }
+    const int ex = block_excl_scan_1024(run, wsum, base);
+    if (c < v.n_cam) cp[c] = s.obs_off + ex;
+  }
+  if (threadIdx.x == 0) cp[v.n_cam] = s.obs_off + base;
+}
+
+// thread = internal ray: its observation records in (track, image) order and their places in the camera-major lists
+__global__ __launch_bounds__(256) void k_view_place(ViewBuild vb)
+{
+  extern __shared__ unsigned long long vp_mask[];  // [4][n_cam]
+  const ViewDev v = vb.views[blockIdx.y];
+  if ((int)blockIdx.x * 256 >= v.n_ray) return;
+  const SceneDev s = vb.scene[blockIdx.y];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < 4 * v.n_cam; c += 256) vp_mask[c] = 0ull;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int* map = vb.cam_of_image + v.map_off;
+  int e0 = 0, e1 = 0;
+  if (j < v.n_ray) {
+    const int t = vb.ray_trk[s.ray_off + j];
+    e0 = v.trk_ptr[t]; e1 = v.trk_ptr[t + 1];
+    for (int e = e0; e < e1; ++e) {
+      const int img = v.trk_img[e];
+      const int c = (img >= 0 && img < v.n_img) ? map[img] : -1;
+      if (c >= 0) atomicOr(&vp_mask[(size_t)w * v.n_cam + c], 1ull << lane);
+    }
+  }
+  __syncthreads();
+  if (j >= v.n_ray) return;
+  const int* cp = vb.cam_ptr + s.cam_off + s.idx;
+  const int* cb = vb.chunk_cnt + vb.chunk_off[blockIdx.y] + (size_t)blockIdx.x * v.n_cam;
+  int a = vb.ray_ptr[s.ray_off + s.idx + j];
+  for (int e = e0; e < e1; ++e) {
+    const int img = v.trk_img[e];
+    const int c = (img >= 0 && img < v.n_img) ? map[img] : -1;
+    if (c < 0) continue;
+    int rank = __popcll(vp_mask[(size_t)w * v.n_cam + c] & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) rank += __popcll(vp_mask[(size_t)k * v.n_cam + c]);
+    const int slot = cp[c] + cb[c] + rank;
+    const float2 uv = v.trk_uv[e];
+    vb.obs_uv[a] = uv; vb.obs_cam[a] = c; vb.obs_ray[a] = j;
+    vb.cam_obs[slot] = a; vb.cam_ray[slot] = s.ray_off + j; vb.cam_uv[slot] = uv; vb.wpos[a] = slot;
+    ++a;
+  }
+}
+
+
 // one workgroup per view: observation ranges of the cameras
 __global__ __launch_bounds__(1024) void k_view_camscan(ViewBuild vb)
 {
@@ -201,10 +307,10 @@ __global__ __launch_bounds__(1024) void k_view_camscan(ViewBuild vb)
   if (threadIdx.x == 0) cp[v.n_cam] = s.obs_off + base;
 }
 
-// one workgroup per (view, camera): the camera's observations in ascending observation order = ascending internal ray.
+// (views wider than VIEW_LDS_CAMS) one workgroup per (view, camera): the camera's observations in ascending observation order = ascending internal ray.
 // Every thread asks whether its ray's track has the camera's image (binary search: images ascend inside a track); the hits
 // of a sweep of 256 rays are ranked by ballot, waves in wave order.
-__global__ __launch_bounds__(256) void k_view_camlists(ViewBuild vb)
+__global__ __launch_bounds__(256) void k_view_camlists_wide(ViewBuild vb)
 {
   __shared__ int wcnt[4];
   __shared__ int out_s;

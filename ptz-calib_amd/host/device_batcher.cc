@@ -86,6 +86,10 @@ int32_t DeviceBatcher::KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, 
 void DeviceBatcher::RunRound()
 {
   ++stats_.rounds;
+  const double t_round = NowMs();
+  if (Trace() && last_end_ms_ > 0)
+    fprintf(stderr, "batcher round clients=%d ba=%zu views=%zu krt=%zu: the clients' own work since the last round %.2f ms\n", active_, ba_.size(), bav_.size(),
+            krt_.size(), t_round - last_end_ms_);
   // The round's registration launches and its bundle adjustments do not depend on each other (they belong to different rigs): the
   // registration side -- mostly host-side packing of the matches -- runs on a thread of its own beside the bundle adjustments.
   std::thread krt_thread;
@@ -136,6 +140,8 @@ void DeviceBatcher::RunRound()
     RunBaViews(group);
   }
   if (krt_thread.joinable()) krt_thread.join();
+  last_end_ms_ = NowMs();
+  if (Trace()) fprintf(stderr, "batcher round ran %.2f ms\n", last_end_ms_ - t_round);
   ba_.clear();
   bav_.clear();
   krt_.clear();

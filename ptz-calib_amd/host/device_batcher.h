@@ -76,6 +76,7 @@ class DeviceBatcher {
   std::vector<BaReq*> ba_;
   std::vector<KrtReq*> krt_;
   Stats stats_;
+  double last_end_ms_ = 0;  // PTZ_BATCHER_TRACE: when the previous round ended
 };
 
 // The device calls of the optimizer classes: through the calling thread's DeviceBatcher when it has one.
