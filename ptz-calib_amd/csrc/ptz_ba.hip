@@ -88,6 +88,7 @@ struct ptz_ba_batch {
   ptz_lm_options opt;
   Dev d;
   std::vector<void*> allocs;
+  hipEvent_t create_ev = nullptr;    // end of ptz_ba_batch_create's work on `io`
   std::vector<void*> staged_pinned;  // staging blocks of uploads still in flight on `io` (released behind the next wait for it)
   void release_staged() { for (void* p : staged_pinned) ptzpool::pinned_release(p); staged_pinned.clear(); }
   hipStream_t stream = nullptr;   // stream of the group being enqueued (LAUNCH / prof_* use it)
@@ -588,17 +589,12 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   for (int g = 0; g < G; ++g) __atomic_store_n(&b->h_ctl[4 * g + 2], b->group_count[g], __ATOMIC_RELEASE);
   PTZ_HIP_TRY(hipEventRecord(b->ev0, s0));
   // x <- initial state, scales <- 1, LM state reset (whole batch, stream 0)
-  PTZ_HIP_TRY(hipMemcpyAsync(d.cam_x, b->cam0, sizeof(double) * 15 * b->total_cam, hipMemcpyDeviceToDevice, s0));
-  PTZ_HIP_TRY(hipMemcpyAsync(d.ray_x, b->ray0, sizeof(double) * 3 * b->total_ray, hipMemcpyDeviceToDevice, s0));
-  if (d.dsp_x) PTZ_HIP_TRY(hipMemcpyAsync(d.dsp_x, b->dsp0, sizeof(double) * d.dsp_stride, hipMemcpyDeviceToDevice, s0));
-  LAUNCH(k_reset, dim3((B + 63) / 64), dim3(64), 0, d);
-  LAUNCH(k_fill, dim3(((size_t)b->total_cam * NC + 255) / 256), dim3(256), 0, d.scale_c, (size_t)b->total_cam * NC, 1.0);
-  LAUNCH(k_fill, dim3(((size_t)b->total_ray * 3 + 255) / 256), dim3(256), 0, d.scale_r, (size_t)b->total_ray * 3, 1.0);
-  // both halves of the double buffer: without annotation residuals no kernel ever writes the candidate half, and the
-  // accepted-step parity decides which half is read back
-  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x, b->tlw0, sizeof(double) * 6 * B, hipMemcpyDeviceToDevice, s0));
-  PTZ_HIP_TRY(hipMemcpyAsync(d.tlw_x + d.tlw_stride, b->tlw0, sizeof(double) * 6 * B, hipMemcpyDeviceToDevice, s0));
-  LAUNCH(k_fill, dim3((6 * B + 255) / 256), dim3(256), 0, d.scale_t, (size_t)6 * B, 1.0);
+  {
+    const size_t n15 = (size_t)15 * b->total_cam, n3 = (size_t)3 * b->total_ray, nnc = (size_t)b->total_cam * NC;
+    const size_t most = std::max(std::max(n15, n3), std::max(std::max(nnc, (size_t)6 * B), d.dsp_x ? d.dsp_stride : (size_t)0));
+    LAUNCH(k_solve_init, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, d, (const double*)b->cam0, (const double*)b->ray0, (const double*)b->dsp0,
+           (const double*)b->tlw0, n15, n3, nnc);
+  }
   // IterationZero: evaluate, Jacobi scales from the column norms, re-evaluate scaled
   enqueue_linearize<TYPE>(b);
   if (b->opt.jacobi_scaling) {
@@ -731,8 +727,21 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   }
   b->stream = s0;
   PTZ_HIP_TRY(hipEventRecord(b->ev1, s0));
-  PTZ_HIP_TRY(stream_wait(s0));
-  PTZ_HIP_TRY(hipGetLastError());  // a kernel launch that was refused (resources, arguments) must not pass for a solve
+  // the scenes' LM states come back behind the last pass, inside the solve's ONE wait
+  void* lm_pin = nullptr;
+  if (ptzpool::pinned_acquire(sizeof(LmState) * B, &lm_pin) == hipSuccess) {
+    if (hipMemcpyAsync(lm_pin, d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost, s0) != hipSuccess) { (void)hipGetLastError(); ptzpool::pinned_release(lm_pin); lm_pin = nullptr; }
+  }
+  else (void)hipGetLastError();
+  {
+    const hipError_t we = stream_wait(s0);
+    b->release_staged();  // (uploads of create / set_state that were left in flight)
+    if (we != hipSuccess) { if (lm_pin) ptzpool::pinned_release(lm_pin); PTZ_HIP_TRY(we); }
+  }
+  {
+    const hipError_t le = hipGetLastError();  // a kernel launch that was refused (resources, arguments) must not pass for a solve
+    if (le != hipSuccess) { if (lm_pin) ptzpool::pinned_release(lm_pin); PTZ_HIP_TRY(le); }
+  }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
   b->last_ms = ms;
@@ -740,7 +749,8 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   if (dbg) fprintf(stderr, "[ptz_ba] groups %d: total %.2f ms, enqueue %.2f ms, sync-wait %.2f ms, device %.2f ms\n", G, now() - t_start, t_enq, t_sync, ms);
   {
     std::vector<LmState> h(B);
-    PTZ_HIP_TRY(copy_on(b->stream, h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
+    if (lm_pin) { memcpy(h.data(), lm_pin, sizeof(LmState) * B); ptzpool::pinned_release(lm_pin); }
+    else PTZ_HIP_TRY(copy_on(b->stream, h.data(), d.lm, sizeof(LmState) * B, hipMemcpyDeviceToHost));
     int timeouts = 0;
     for (int i = 0; i < B; ++i) timeouts += h[i].chain_timeouts;
     if (timeouts) {  // never a silently different trajectory: a hand-over that did not arrive is a device problem, not a rejected step
@@ -958,6 +968,7 @@ void ptz_ba_batch_destroy(ptz_ba_batch* b)
   for (auto& v : b->pass_graph) for (auto ge : v) if (ge) (void)hipGraphExecDestroy(ge);
   ptzpool::event_release(dv, true, b->ev0);
   ptzpool::event_release(dv, true, b->ev1);
+  if (b->create_ev) ptzpool::event_release(dv, false, b->create_ev);
   for (auto st : b->streams) ptzpool::stream_release(dv, st);
   for (auto st : b->aux) ptzpool::stream_release(dv, st);
   ptzpool::stream_release(dv, b->io);
@@ -2023,6 +2034,9 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   // 141.9 -> 137.8 ms, single scene 16.4 -> 19.4 ms with the left-looking form)
   b->left_looking = n >= 8;
   if (const char* e = getenv("PTZ_BA_CHOL_LEFT")) b->left_looking = atoi(e) != 0;
+  // (small batches -- the view batches of the incremental pipeline converge in two or three passes -- run two ahead: every pass
+  //  enqueued beyond the last real one is a dozen empty launches; large batches, whose passes last milliseconds, keep three)
+  b->ahead = n <= 32 ? 2 : 3;
   if (const char* e = getenv("PTZ_BA_AHEAD")) b->ahead = std::max(1, atoi(e));
   if (const char* e = getenv("PTZ_BA_DEBUG_STALL")) b->d.debug_stall = std::max(0, atoi(e));
   if (const char* e = getenv("PTZ_BA_DEBUG_CHAIN_SPIN")) b->d.chol.chain_spin_limit = std::max(0, atoi(e));  // tests: hand-overs that time out
@@ -2136,8 +2150,13 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       attr_done[o.device_id] = 1;
     }
   }
-  if (stream_wait(b->io) != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }  // the zero fills, the staged upload
-  b->release_staged();
+  // The zero fills and the staged upload are still in flight on `io`: the batch's first stream waits for them ON THE DEVICE (every
+  // later entry point works on that stream or behind it), the host does not -- it goes on to the caller's set_state / solve while
+  // the device finishes the structure.  (The staging blocks are released behind the next host-side wait: solve, destroy.)
+  if (ptzpool::event_acquire(b->device, false, &b->create_ev) != hipSuccess || hipEventRecord(b->create_ev, b->io) != hipSuccess ||
+      hipStreamWaitEvent(b->stream, b->create_ev, 0) != hipSuccess) {
+    (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE;
+  }
   tc3 = now_ms();
   if (dbg_t) fprintf(stderr, "[ptz_ba_create] host structure %.2f ms (observations %.2f, pair entries %.2f), uploads + allocations %.2f ms, mask + rest %.2f ms\n", tc1 - tc0, ts_obs, ts_ent, tc2 - tc1, tc3 - tc2);
   *out = b;
@@ -2471,18 +2490,18 @@ int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const
   else { (void)hipGetLastError(); heap.resize(nc + nk); stg = heap.data(); }
   memcpy(stg, cam, sizeof(double) * nc);
   memcpy(stg + nc, rkinv, sizeof(double) * nk);
-  void* dk = nullptr;
-  if (ptzpool::dev_acquire(b->device, sizeof(double) * nk, &dk) != hipSuccess) { ptzpool::pinned_release(pin); return PTZ_ENOMEM; }
+  // (no wait: the solve that follows runs on the same stream; the staging block lives until that solve's wait, the R^-1 K^-1 block
+  //  until the batch goes)
+  double* dk = nullptr;
+  if (b->alloc(&dk, nk) != PTZ_OK) { if (pin) ptzpool::pinned_release(pin); return PTZ_ENOMEM; }
   hipError_t e = hipMemcpyAsync(b->cam0, stg, sizeof(double) * nc, hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dk, stg + nc, sizeof(double) * nk, hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) e = hipMemsetAsync(b->tlw0, 0, sizeof(double) * 6 * b->n_scene, b->stream);
-  if (e == hipSuccess) {
+  if (e == hipSuccess)
     hipLaunchKernelGGL(k_view_pix2ray, dim3((b->max_ray + 255) / 256, b->n_scene), dim3(256), 0, b->stream, b->d, (const double*)b->cam0, (const double*)dk, b->ray0);
-    e = stream_wait(b->stream);
-  }
+  if (e == hipSuccess && pin) b->staged_pinned.push_back(pin);  // (in flight)
+  else { (void)stream_wait(b->stream); if (pin) ptzpool::pinned_release(pin); }  // pageable staging or a refused copy: nothing may still read it
   if (e == hipSuccess) e = hipGetLastError();
-  ptzpool::dev_release(b->device, dk);
-  ptzpool::pinned_release(pin);
   PTZ_HIP_TRY(e);
   b->has_state = true;
   return PTZ_OK;

@@ -2461,6 +2461,38 @@ __global__ void k_reset(Dev d)
   d.ray_fail[sc] = 0;
   d.tail_cnt[2 * sc] = 0; d.tail_cnt[2 * sc + 1] = 0;  // (a solve the watchdog gave up on may have left them mid-count)
 }
+// x <- initial state, Jacobi scales <- 1, LM state reset: everything a solve starts from, in one launch (was: five device-to-device
+// copies, three fills and k_reset -- nine launches in front of every bundle adjustment of the incremental pipeline)
+__global__ __launch_bounds__(256) void k_solve_init(Dev d, const double* __restrict__ cam0, const double* __restrict__ ray0, const double* __restrict__ dsp0,
+                                                    const double* __restrict__ tlw0, size_t n_cam15, size_t n_ray3, size_t n_camnc)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_cam15) d.cam_x[i] = cam0[i];
+  if (i < n_ray3) { d.ray_x[i] = ray0[i]; d.scale_r[i] = 1.0; }
+  if (i < n_camnc) d.scale_c[i] = 1.0;
+  if (d.dsp_x && i < d.dsp_stride) d.dsp_x[i] = dsp0[i];
+  if (i < (size_t)6 * d.n_scene) {
+    // both halves of the double buffer: without annotation residuals no kernel ever writes the candidate half, and the
+    // accepted-step parity decides which half is read back
+    const double t = tlw0[i];
+    d.tlw_x[i] = t; d.tlw_x[d.tlw_stride + i] = t;
+    d.scale_t[i] = 1.0;
+  }
+  if (i < (size_t)d.n_scene) {
+    const int sc = (int)i;
+    LmState st;
+    memset(&st, 0, sizeof(st));
+    st.radius = d.opt.initial_radius;
+    st.decrease_factor = 2.0;
+    st.need_linearize = 1;
+    st.step_is_successful = 1;
+    st.termination = PTZ_NO_CONVERGENCE;
+    d.lm[sc] = st;
+    d.active[sc] = 1;
+    d.ray_fail[sc] = 0;
+    d.tail_cnt[2 * sc] = 0; d.tail_cnt[2 * sc + 1] = 0;  // (a solve the watchdog gave up on may have left them mid-count)
+  }
+}
 // control words of one scene group (see Dev::grp_ctl); the host zeroes its pinned mirror itself before it enqueues anything
 __global__ void k_ctl_reset(Dev d)
 {

@@ -12,7 +12,8 @@
 // (cohorts of four rigs) side by side, each with a DeviceBatcher of its own.
 #pragma once
 
-#include <condition_variable>
+#include <semaphore.h>
+
 #include <cstdint>
 #include <mutex>
 #include <vector>
@@ -63,14 +64,15 @@ class DeviceBatcher {
   void RunBaViews(std::vector<BavReq*>& reqs);
   static void RunBaViewBatch(std::vector<BavReq*>& reqs);  // one ptz_ba_batch_create_views for all of them
   std::vector<BavReq*> bav_;
-  void Arrive(std::unique_lock<std::mutex>& lk);  // called with the request already queued
+  void Arrive(std::unique_lock<std::mutex>& lk);  // called with the request already queued; returns with `lk` released
+  void ReleaseWaiters(std::unique_lock<std::mutex>& lk);  // after a round: wakes every waiting client (releases `lk` first)
   void RunRound();                                // executes and clears the queues (lock held: every other client is waiting)
   void RunBa(std::vector<BaReq*>& reqs);
   static void RunBaBatch(std::vector<BaReq*>& reqs);  // one ptz_ba_batch for all of them
   void RunKrt(std::vector<KrtReq*>& reqs);
 
   std::mutex mu_;
-  std::condition_variable cv_;
+  std::vector<sem_t*> waiters_;  // the clients asleep until the round has run (one semaphore each, on their stacks)
   int active_, waiting_ = 0;
   uint64_t generation_ = 0;
   std::vector<BaReq*> ba_;
