@@ -305,6 +305,24 @@ int32_t ptz_krt_solve_batch_device(int32_t n_query, const int64_t* d_match_ptr, 
                                    const double* d_cam_ref, double* d_cam_cur, int32_t factor_type, double max_reproj_error,
                                    const ptz_lm_options* opt, ptz_lm_summary* d_summaries, int32_t* d_accepted, void* hip_stream);
 
+/* Registration attempts over match tables that stay on the device:
+ *   replaces the loop body of PtzIncrementalOptimizer::RegisterNextImage (ptz_incremental_optimizer.cc:377-418) -- one
+ *   KRTOptimizer per table entry (registered image i -> image j) -- for callers that try many entries of the SAME tables again
+ *   and again while only the cameras change (the incremental pipeline: ~5 000 attempts per 200-view rig over ~8 500 entries).
+ * ptz_krt_table_create copies a table's matches to device `device_id` once: entry e owns matches [match_ptr[e], match_ptr[e+1])
+ * (match_ptr[0] = 0), uv_ref / uv_cur as in ptz_krt_solve_batch.  ptz_krt_solve_attempts then solves query q = entry
+ * attempts[q].entry of attempts[q].table with the cameras cam_ref / cam_cur [15 n_query] (in / out as in ptz_krt_solve_batch); the
+ * tables of one call may differ (several rigs in one launch) but live on one device, where the launch runs (opt->device_id, if
+ * non-zero, must name it).  Results are bit-identical to ptz_krt_solve_batch on the same matches. */
+typedef struct ptz_krt_table ptz_krt_table;
+typedef struct ptz_krt_attempt { const ptz_krt_table* table; int32_t entry; } ptz_krt_attempt;
+int32_t ptz_krt_table_create(int32_t n_entry, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, int32_t device_id,
+                             ptz_krt_table** out);
+void ptz_krt_table_destroy(ptz_krt_table* table);
+int32_t ptz_krt_solve_attempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur,
+                               int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries,
+                               int32_t* accepted, double* device_ms);
+
 /* The queries over the devices device_ids[0 .. n_devices) of one node, from one process: contiguous chunks of about equal
  * total match count, one host thread per device, results written into the caller's arrays in query order.  Host pointers
  * as in ptz_krt_solve_batch_2d3d (point_ptr = NULL: no 2D-3D constraints); opt->device_id is ignored. */

@@ -26,7 +26,8 @@ EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_
            "ptz_krt_solve_batch_2d3d", "ptz_krt_solve_batch_device", "ptz_trim_cache", "ptz_mfma_f64_peak", "ptz_ba_solve_sharded",
            "ptz_krt_solve_batch_sharded", "ptz_hbm_bandwidth", "ptz_ba_batch_set_disp", "ptz_ba_batch_get_disp", "ptz_ba_solve_disp",
            "ptz_ba_plan_tile_order", "ptz_rig_create", "ptz_rig_destroy", "ptz_ba_batch_create_views", "ptz_ba_batch_set_state_pix2ray",
-           "ptz_debug_batch_structure_hash", "ptz_debug_batch_initial_rays"]
+           "ptz_debug_batch_structure_hash", "ptz_debug_batch_initial_rays", "ptz_krt_table_create", "ptz_krt_table_destroy",
+           "ptz_krt_solve_attempts"]
 
 
 class PtzError(RuntimeError):
@@ -424,6 +425,50 @@ def krt_solve_batch(batch, max_reproj_error=100.0, **opt):
         _check(lib().ptz_krt_solve_batch(n, _p(ptr), _p(uvr), _p(uvc), _p(cref), _p(ccur), batch.factor_type,
                                          C.c_double(max_reproj_error), C.byref(o), summ, _p(acc), C.byref(ms)),
                "ptz_krt_solve_batch")
+    return ccur, [s.as_dict() for s in summ], acc, ms.value
+
+
+class KrtAttempt(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("entry", C.c_int32)]
+
+
+class KrtTable:
+    """ptz_krt_table: the matches of a rig's table entries, resident on a device (entry e owns matches
+    [match_ptr[e], match_ptr[e+1]) of uv_ref / uv_cur)."""
+
+    def __init__(self, match_ptr, uv_ref, uv_cur, device_id=0):
+        ptr = np.ascontiguousarray(match_ptr, dtype=np.int64)
+        uvr = np.ascontiguousarray(uv_ref, dtype=np.float32)
+        uvc = np.ascontiguousarray(uv_cur, dtype=np.float32)
+        self.n_entry = len(ptr) - 1
+        self.handle = C.c_void_p()
+        lib().ptz_krt_table_destroy.restype = None
+        _check(lib().ptz_krt_table_create(self.n_entry, _p(ptr), _p(uvr), _p(uvc), int(device_id), C.byref(self.handle)), "ptz_krt_table_create")
+
+    def close(self):
+        if self.handle:
+            lib().ptz_krt_table_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def krt_solve_attempts(attempts, cam_ref, cam_init, factor_type=0, max_reproj_error=100.0, **opt):
+    """ptz_krt_solve_attempts: attempts = [(KrtTable, entry), ...].  Returns (cam_world [n,15], summaries, accepted, device_ms)."""
+    o = default_options(**opt)
+    n = len(attempts)
+    att = (KrtAttempt * n)(*[KrtAttempt(t.handle.value, int(e)) for t, e in attempts])
+    cref = np.ascontiguousarray(cam_ref, dtype=np.float64)
+    ccur = np.array(cam_init, dtype=np.float64, order="C").copy()
+    summ = (LmSummary * n)()
+    acc = np.zeros(n, dtype=np.int32)
+    ms = C.c_double()
+    _check(lib().ptz_krt_solve_attempts(n, att, _p(cref), _p(ccur), int(factor_type), C.c_double(max_reproj_error), C.byref(o), summ, _p(acc),
+                                        C.byref(ms)), "ptz_krt_solve_attempts")
     return ccur, [s.as_dict() for s in summ], acc, ms.value
 
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
                                              const float2* __restrict__ uv_cur, const long long* __restrict__ point_ptr,
                                              const float2* __restrict__ pt_uv, const double* __restrict__ pt_xyz,
                                              const double* __restrict__ cam_ref, double* __restrict__ cam_cur, KrtOpt o,
-                                             ptz_lm_summary* __restrict__ summ, int* __restrict__ accepted)
+                                             ptz_lm_summary* __restrict__ summ, int* __restrict__ accepted,
+                                             const long long* __restrict__ cur_delta)
 {
   constexpr int NF = KrtDims<KTYPE>::NF;
   constexpr int NH = NF * (NF + 1) / 2;
@@ -131,8 +133,12 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
   const int q = blockIdx.x * QPB + (int)threadIdx.x / G;
   if (q >= n_query) return;
   const int lane = threadIdx.x % G;
-  const long long m0 = match_ptr[q], m1 = match_ptr[q + 1];
+  // cur_delta = nullptr: the queries' matches one after the other (CSR offsets).  Otherwise (ptz_krt_solve_attempts: matches of
+  // resident tables) match_ptr holds a [begin, end) PAIR per query, relative to uv_ref, and the query's current-image pixels
+  // start cur_delta[q] elements further on in uv_cur than its reference pixels in uv_ref (the tables are separate allocations).
+  const long long m0 = cur_delta ? match_ptr[2 * q] : match_ptr[q], m1 = cur_delta ? match_ptr[2 * q + 1] : match_ptr[q + 1];
   const int M = (int)(m1 - m0);
+  if (cur_delta) uv_cur += cur_delta[q];
   const long long p0 = P3 ? point_ptr[q] : 0;
   const int NP = P3 ? (int)(point_ptr[q + 1] - p0) : 0;
   // ---- world -> local frame of the reference camera (krt_optimizer.cc:269-284)
@@ -448,7 +454,7 @@ inline int krt_group_size(int n_query, int requested)
 // one launch over device-resident queries (all pointers are device pointers; d_pptr = nullptr: no 2D-3D constraints)
 void launch_krt(int n_query, const long long* d_ptr, const float2* d_ref, const float2* d_cur, const long long* d_pptr,
                 const float2* d_puv, const double* d_pxyz, const double* d_cref, double* d_ccur, int factor_type, const KrtOpt& ko,
-                ptz_lm_summary* d_sum, int* d_acc, hipStream_t st)
+                ptz_lm_summary* d_sum, int* d_acc, hipStream_t st, const long long* d_delta = nullptr)
 {
   const int G = krt_group_size(n_query, ko.lanes_per_query);
   const int qpb = 256 / G;
@@ -457,9 +463,9 @@ void launch_krt(int n_query, const long long* d_ptr, const float2* d_ref, const 
 #define PTZ_KRT_LAUNCH(T, P)                                                                                                   \
   do {                                                                                                                         \
     if (G == 16) hipLaunchKernelGGL((k_krt<T, P, 16>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, \
-                                    d_cref, d_ccur, ko, d_sum, d_acc);                                                         \
+                                    d_cref, d_ccur, ko, d_sum, d_acc, d_delta);                                                \
     else hipLaunchKernelGGL((k_krt<T, P, 64>), grid, block, 0, st, n_query, d_ptr, d_ref, d_cur, d_pptr, d_puv, d_pxyz, d_cref, \
-                            d_ccur, ko, d_sum, d_acc);                                                                         \
+                            d_ccur, ko, d_sum, d_acc, d_delta);                                                                \
   } while (0)
   switch (factor_type * 2 + (p3 ? 1 : 0)) {
     case 0: PTZ_KRT_LAUNCH(0, false); break;
@@ -629,6 +635,134 @@ extern "C" int32_t ptz_krt_solve_batch_2d3d(int32_t n_query, const int64_t* matc
     PTZ_HIP_TRY(stream_wait(h.st));
     PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
   }
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, h.e0, h.e1);
+  if (device_ms) *device_ms = ms;
+  return PTZ_OK;
+}
+
+// ---- registration attempts over RESIDENT match tables ------------------------------------------------------------------------
+// PtzIncrementalOptimizer::RegisterNextImage (ptz_incremental_optimizer.cc:377-418) solves, for an unregistered image j, one KRT
+// problem per table entry (registered i -> j): the entry's matches never change during a run, only the two cameras do.  A rig's
+// table goes to the device once (ptz_krt_table_create); an attempt is then {table, entry, reference camera, initial camera} --
+// thirty doubles instead of the entry's pixels packed, merged and staged again for every launch.  Same kernel, same bits.
+struct ptz_krt_table {
+  int device = 0;
+  int32_t n_entry = 0;
+  int64_t n_match = 0;
+  std::vector<int64_t> ptr;  // [n_entry + 1]
+  float2* d_ref = nullptr;   // [n_match]
+  float2* d_cur = nullptr;   // [n_match]
+};
+
+extern "C" int32_t ptz_krt_table_create(int32_t n_entry, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, int32_t device_id,
+                                        ptz_krt_table** out)
+{
+  if (!out) return PTZ_EINVAL;
+  *out = nullptr;
+  if (n_entry <= 0 || !match_ptr || match_ptr[0] != 0) return PTZ_EINVAL;
+  for (int32_t e = 0; e < n_entry; ++e)
+    if (match_ptr[e + 1] < match_ptr[e]) return PTZ_EINVAL;
+  const int64_t nm = match_ptr[n_entry];
+  if (nm > 0 && (!uv_ref || !uv_cur)) return PTZ_EINVAL;
+  clear_stale_error(__func__);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || ndev <= device_id) return PTZ_ENODEVICE;
+  PTZ_DEVICE_GUARD(device_id);
+  std::unique_ptr<ptz_krt_table> t(new ptz_krt_table());
+  t->device = device_id; t->n_entry = n_entry; t->n_match = nm;
+  t->ptr.assign(match_ptr, match_ptr + n_entry + 1);
+  const size_t bytes = sizeof(float2) * (size_t)std::max<int64_t>(nm, 1);
+  void* blk = nullptr;
+  if (ptzpool::dev_acquire(device_id, 2 * bytes, &blk) != hipSuccess) return PTZ_ENOMEM;
+  t->d_ref = static_cast<float2*>(blk);
+  t->d_cur = reinterpret_cast<float2*>(static_cast<char*>(blk) + bytes);
+  if (nm > 0) {
+    hipStream_t st = nullptr;
+    hipError_t e = ptzpool::stream_acquire(device_id, &st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_ref, uv_ref, sizeof(float2) * nm, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_cur, uv_cur, sizeof(float2) * nm, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = stream_wait(st);
+    if (st) ptzpool::stream_release(device_id, st);
+    if (e != hipSuccess) { (void)hipGetLastError(); ptzpool::dev_release(device_id, blk); return PTZ_ENODEVICE; }
+  }
+  *out = t.release();
+  return PTZ_OK;
+}
+
+extern "C" void ptz_krt_table_destroy(ptz_krt_table* t)
+{
+  if (!t) return;
+  DeviceGuard guard(t->device);
+  ptzpool::dev_release(t->device, t->d_ref);  // (one block: d_cur lies behind d_ref)
+  delete t;
+}
+
+extern "C" int32_t ptz_krt_solve_attempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur,
+                                          int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
+                                          ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  if (n_query <= 0 || !attempts || !cam_ref || !cam_cur || !summaries || !accepted) return PTZ_EINVAL;
+  if (factor_type < PTZ_KRT_F || factor_type > PTZ_KRT_FxfyDist) return PTZ_EUNSUPPORTED;
+  ptz_lm_options o;
+  if (opt) o = *opt; else ptz_lm_options_default(&o);
+  const ptz_krt_table* t0 = attempts[0].table;
+  if (!t0) return PTZ_EINVAL;
+  const int device = t0->device;  // the launch goes where the tables live
+  if (opt && opt->device_id != 0 && opt->device_id != device) return PTZ_EINVAL;
+  for (int q = 0; q < n_query; ++q) {
+    const ptz_krt_table* t = attempts[q].table;
+    if (!t || t->device != device || attempts[q].entry < 0 || attempts[q].entry >= t->n_entry) return PTZ_EINVAL;
+  }
+  clear_stale_error(__func__);
+  PTZ_DEVICE_GUARD(device);
+  // one pooled device block, one pinned staging block: [ranges | deltas | cam_ref | cam_cur (in / out) | summaries | accepted]
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_rng = 0, o_del = o_rng + up(sizeof(long long) * 2 * n_query), o_cref = o_del + up(sizeof(long long) * n_query),
+               o_ccur = o_cref + up(sizeof(double) * 15 * n_query), o_sum = o_ccur + up(sizeof(double) * 15 * n_query),
+               o_acc = o_sum + up(sizeof(ptz_lm_summary) * n_query), total = o_acc + up(sizeof(int) * n_query);
+  struct Held {
+    int dev; char* base = nullptr; void* pinned = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Held()
+    {
+      if (st) (void)stream_wait(st);
+      ptzpool::dev_release(dev, base);
+      ptzpool::pinned_release(pinned);
+      ptzpool::stream_release(dev, st);
+      ptzpool::event_release(dev, true, e0);
+      ptzpool::event_release(dev, true, e1);
+    }
+  } h;
+  h.dev = device;
+  if (ptzpool::dev_acquire(h.dev, total, (void**)&h.base) != hipSuccess) return PTZ_ENOMEM;
+  if (ptzpool::pinned_acquire(total, &h.pinned) != hipSuccess) { (void)hipGetLastError(); return PTZ_ENOMEM; }
+  PTZ_HIP_TRY(ptzpool::stream_acquire(h.dev, &h.st));
+  PTZ_HIP_TRY(ptzpool::event_acquire(h.dev, true, &h.e0));
+  PTZ_HIP_TRY(ptzpool::event_acquire(h.dev, true, &h.e1));
+  char* ps = (char*)h.pinned;
+  long long* rng = (long long*)(ps + o_rng);
+  long long* del = (long long*)(ps + o_del);
+  for (int q = 0; q < n_query; ++q) {
+    const ptz_krt_table* t = attempts[q].table;
+    const long long at = (long long)(t->d_ref - t0->d_ref);  // the table's reference pixels, in elements from the first table's
+    rng[2 * q] = at + t->ptr[attempts[q].entry];
+    rng[2 * q + 1] = at + t->ptr[attempts[q].entry + 1];
+    del[q] = (long long)(t->d_cur - t0->d_cur) - at;
+  }
+  memcpy(ps + o_cref, cam_ref, sizeof(double) * 15 * n_query);
+  memcpy(ps + o_ccur, cam_cur, sizeof(double) * 15 * n_query);
+  PTZ_HIP_TRY(hipMemcpyAsync(h.base, ps, o_sum, hipMemcpyHostToDevice, h.st));
+  PTZ_HIP_TRY(hipEventRecord(h.e0, h.st));
+  launch_krt(n_query, (const long long*)(h.base + o_rng), t0->d_ref, t0->d_cur, nullptr, nullptr, nullptr, (const double*)(h.base + o_cref),
+             (double*)(h.base + o_ccur), factor_type, make_krt_opt(o, max_reproj_error), (ptz_lm_summary*)(h.base + o_sum), (int*)(h.base + o_acc), h.st,
+             (const long long*)(h.base + o_del));
+  PTZ_HIP_TRY(hipEventRecord(h.e1, h.st));
+  PTZ_HIP_TRY(hipMemcpyAsync(ps + o_ccur, h.base + o_ccur, total - o_ccur, hipMemcpyDeviceToHost, h.st));
+  PTZ_HIP_TRY(stream_wait(h.st));
+  PTZ_HIP_TRY(hipGetLastError());  // a refused kernel launch must not pass for a solve
+  memcpy(cam_cur, ps + o_ccur, sizeof(double) * 15 * n_query);
+  memcpy(summaries, ps + o_sum, sizeof(ptz_lm_summary) * n_query);
+  memcpy(accepted, ps + o_acc, sizeof(int) * n_query);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, h.e0, h.e1);
   if (device_ms) *device_ms = ms;

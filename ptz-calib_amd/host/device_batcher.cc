@@ -81,6 +81,7 @@ int32_t DeviceBatcher::BaSolveView(const ptz_rig_view* view, int32_t factor_type
   BavReq req{view, factor_type, cam, rkinv, opt, summary, PTZ_EINVAL};
   std::unique_lock<std::mutex> lk(mu_);
   bav_.push_back(&req);
+  if (Trace() && last_end_ms_ > 0) trace_late_[1] = std::max(trace_late_[1], NowMs() - last_end_ms_);
   Arrive(lk);
   return req.rc;
 }
@@ -91,9 +92,23 @@ int32_t DeviceBatcher::KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, 
 {
   ptz_lm_options dflt;
   if (!opt) { ptz_lm_options_default(&dflt); opt = &dflt; }
-  KrtReq req{n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms, PTZ_EINVAL};
+  KrtReq req{n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms, PTZ_EINVAL, nullptr};
   std::unique_lock<std::mutex> lk(mu_);
   krt_.push_back(&req);
+  if (Trace() && last_end_ms_ > 0) { trace_late_[2] = std::max(trace_late_[2], NowMs() - last_end_ms_); if (trace_first_ == 0) trace_first_ = NowMs() - last_end_ms_; }
+  Arrive(lk);
+  return req.rc;
+}
+
+int32_t DeviceBatcher::KrtSolveAttempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur, int32_t factor_type,
+                                        double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  ptz_lm_options dflt;
+  if (!opt) { ptz_lm_options_default(&dflt); opt = &dflt; }
+  KrtReq req{n_query, nullptr, nullptr, nullptr, cam_ref, cam_cur, factor_type, max_reproj_error, opt, summaries, accepted, device_ms, PTZ_EINVAL, attempts};
+  std::unique_lock<std::mutex> lk(mu_);
+  krt_.push_back(&req);
+  if (Trace() && last_end_ms_ > 0) { trace_late_[2] = std::max(trace_late_[2], NowMs() - last_end_ms_); if (trace_first_ == 0) trace_first_ = NowMs() - last_end_ms_; }
   Arrive(lk);
   return req.rc;
 }
@@ -103,8 +118,9 @@ void DeviceBatcher::RunRound()
   ++stats_.rounds;
   const double t_round = NowMs();
   if (Trace() && last_end_ms_ > 0)
-    fprintf(stderr, "batcher round clients=%d ba=%zu views=%zu krt=%zu: the clients' own work since the last round %.2f ms\n", active_, ba_.size(), bav_.size(),
-            krt_.size(), t_round - last_end_ms_);
+    fprintf(stderr, "batcher round clients=%d ba=%zu views=%zu krt=%zu: the clients' own work since the last round %.2f ms (last view request after %.2f, last registration request after %.2f, first after %.2f)\n", active_, ba_.size(), bav_.size(),
+            krt_.size(), t_round - last_end_ms_, trace_late_[1], trace_late_[2], trace_first_);
+  trace_late_[0] = trace_late_[1] = trace_late_[2] = 0; trace_first_ = 0;
   // The round's registration launches and its bundle adjustments do not depend on each other (they belong to different rigs): the
   // registration side -- mostly host-side packing of the matches -- runs on a thread of its own beside the bundle adjustments.
   std::thread krt_thread;
@@ -117,7 +133,7 @@ void DeviceBatcher::RunRound()
         done_krt[i] = 1;
         for (size_t j = i + 1; j < krt_.size(); ++j) {
           if (done_krt[j] || krt_[j]->factor_type != krt_[i]->factor_type || krt_[j]->max_reproj_error != krt_[i]->max_reproj_error ||
-              !SameOptions(krt_[j]->opt, krt_[i]->opt))
+              !SameOptions(krt_[j]->opt, krt_[i]->opt) || (krt_[j]->attempts == nullptr) != (krt_[i]->attempts == nullptr))
             continue;
           group.push_back(krt_[j]);
           done_krt[j] = 1;
@@ -337,6 +353,42 @@ void DeviceBatcher::RunKrt(std::vector<KrtReq*>& reqs)
 {
   const double t0 = NowMs();
   ++stats_.krt_launches;
+  if (reqs[0]->attempts) {  // entries of resident tables: the launch's arguments are the (table, entry) pairs and the cameras, nothing else moves
+    size_t nq = 0;
+    for (const KrtReq* r : reqs) nq += static_cast<size_t>(r->n_query);
+    stats_.krt_queries += static_cast<long>(nq);
+    std::vector<ptz_krt_attempt> att(nq);
+    std::vector<double> cam_ref(15 * nq), cam_cur(15 * nq);
+    std::vector<ptz_lm_summary> summ(nq);
+    std::vector<int32_t> acc(nq, 0);
+    size_t q0 = 0;
+    for (const KrtReq* r : reqs) {
+      memcpy(att.data() + q0, r->attempts, sizeof(ptz_krt_attempt) * r->n_query);
+      memcpy(cam_ref.data() + 15 * q0, r->cam_ref, sizeof(double) * 15 * r->n_query);
+      memcpy(cam_cur.data() + 15 * q0, r->cam_cur, sizeof(double) * 15 * r->n_query);
+      q0 += static_cast<size_t>(r->n_query);
+    }
+    const double t1 = NowMs();
+    double dev_ms = 0;
+    ptz_lm_options opt = *reqs[0]->opt;
+    if (opt.krt_lanes_per_query == 0) opt.krt_lanes_per_query = 64;  // (the form of a rig's own launches: see DeviceKrtSolveBatch)
+    const int32_t rc = ptz_krt_solve_attempts(static_cast<int32_t>(nq), att.data(), cam_ref.data(), cam_cur.data(), reqs[0]->factor_type,
+                                              reqs[0]->max_reproj_error, &opt, summ.data(), acc.data(), &dev_ms);
+    if (Trace()) fprintf(stderr, "batcher krt reqs=%zu queries=%zu matches=resident pack %.2f call %.2f device %.3f ms\n", reqs.size(), nq, t1 - t0, NowMs() - t1, dev_ms);
+    q0 = 0;
+    for (KrtReq* r : reqs) {
+      r->rc = rc;
+      if (rc == PTZ_OK) {
+        memcpy(r->cam_cur, cam_cur.data() + 15 * q0, sizeof(double) * 15 * r->n_query);
+        if (r->summaries) memcpy(r->summaries, summ.data() + q0, sizeof(ptz_lm_summary) * r->n_query);
+        if (r->accepted) memcpy(r->accepted, acc.data() + q0, sizeof(int32_t) * r->n_query);
+        if (r->device_ms) *r->device_ms = dev_ms;
+      }
+      q0 += static_cast<size_t>(r->n_query);
+    }
+    stats_.krt_ms += NowMs() - t0;
+    return;
+  }
   if (reqs.size() == 1) {
     KrtReq& r = *reqs[0];
     stats_.krt_queries += r.n_query;
@@ -433,6 +485,17 @@ int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const flo
   if (DeviceBatcher* b = DeviceBatcher::Current())
     return b->KrtSolveBatch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
   return ptz_krt_solve_batch(n_query, match_ptr, uv_ref, uv_cur, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
+}
+
+int32_t DeviceKrtSolveAttempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur, int32_t factor_type,
+                               double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms)
+{
+  ptz_lm_options pinned;  // (one lane form for the orchestration's launches: see DeviceKrtSolveBatch)
+  if (opt) pinned = *opt; else ptz_lm_options_default(&pinned);
+  if (pinned.krt_lanes_per_query == 0) pinned.krt_lanes_per_query = 64;
+  if (DeviceBatcher* b = DeviceBatcher::Current())
+    return b->KrtSolveAttempts(n_query, attempts, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
+  return ptz_krt_solve_attempts(n_query, attempts, cam_ref, cam_cur, factor_type, max_reproj_error, &pinned, summaries, accepted, device_ms);
 }
 
 }  // namespace ptzcalib

@@ -30,6 +30,9 @@ class DeviceBatcher {
   int32_t KrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
                         double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                         ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+  // registration attempts over device-resident match tables (ptz_krt_solve_attempts): attempts [n_query], cameras as above
+  int32_t KrtSolveAttempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur, int32_t factor_type,
+                           double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
   // a bundle adjustment over a VIEW of device-resident tracks (ptz_ba_batch_create_views): cam [15 n_cam] in / out, rkinv [9 n_cam]
   int32_t BaSolveView(const ptz_rig_view* view, int32_t factor_type, double* cam, const double* rkinv, const ptz_lm_options* opt,
                       ptz_lm_summary* summary);
@@ -57,6 +60,7 @@ class DeviceBatcher {
     int32_t n_query; const int64_t* match_ptr; const float *uv_ref, *uv_cur; const double* cam_ref; double* cam_cur;
     int32_t factor_type; double max_reproj_error; const ptz_lm_options* opt; ptz_lm_summary* summaries; int32_t* accepted;
     double* device_ms; int32_t rc;
+    const ptz_krt_attempt* attempts;  // not null: the queries are entries of resident tables (match_ptr / uv_* unused)
   };
   struct BavReq {
     const ptz_rig_view* view; int32_t factor_type; double* cam; const double* rkinv; const ptz_lm_options* opt; ptz_lm_summary* summary; int32_t rc;
@@ -78,6 +82,7 @@ class DeviceBatcher {
   std::vector<BaReq*> ba_;
   std::vector<KrtReq*> krt_;
   Stats stats_;
+  double trace_late_[3] = {0, 0, 0}, trace_first_ = 0;  // PTZ_BATCHER_TRACE: latest arrival of a round by request type
   double last_end_ms_ = 0;  // PTZ_BATCHER_TRACE: when the previous round ended
 };
 
@@ -88,5 +93,7 @@ int32_t DeviceBaSolveView(const ptz_rig_view* view, int32_t factor_type, double*
 int32_t DeviceKrtSolveBatch(int32_t n_query, const int64_t* match_ptr, const float* uv_ref, const float* uv_cur, const double* cam_ref,
                             double* cam_cur, int32_t factor_type, double max_reproj_error, const ptz_lm_options* opt,
                             ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
+int32_t DeviceKrtSolveAttempts(int32_t n_query, const ptz_krt_attempt* attempts, const double* cam_ref, double* cam_cur, int32_t factor_type,
+                               double max_reproj_error, const ptz_lm_options* opt, ptz_lm_summary* summaries, int32_t* accepted, double* device_ms);
 
 }  // namespace ptzcalib

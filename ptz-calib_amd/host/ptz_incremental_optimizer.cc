@@ -76,6 +76,7 @@ PtzIncrementalOptimizer::PtzIncrementalOptimizer(const std::vector<ImageFeatures
 PtzIncrementalOptimizer::~PtzIncrementalOptimizer()
 {
   if (rig_) ptz_rig_destroy(rig_);
+  if (match_table_) ptz_krt_table_destroy(match_table_);
 }
 
 void PtzIncrementalOptimizer::SetSeedImageId(const std::vector<long>& image_ids) { seed_image_ids_ = image_ids; }
@@ -94,7 +95,11 @@ long PtzIncrementalOptimizer::ImagePairToPairId(long image_id1, long image_id2) 
 bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered_set<long>& reg_image_ids)
 {
   if (!CheckValid()) return false;
+  const bool trace_setup = getenv("PTZ_INC_TIMING") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double ts0 = now_ms();
   if (!tracks_) tracks_ = PTZRayOptimizer::BuildTracks(matches_info_);
+  const double ts1 = now_ms();
   if (!rig_ && !tracks_->id.empty() && !(getenv("PTZ_IBA_VIEWS") && atoi(getenv("PTZ_IBA_VIEWS")) == 0)) {
     // the tracks go to the device once: image id and pixel of every view (PTZ_IBA_VIEWS=0: pack every bundle adjustment on the host)
     const SharedTracks& st = *tracks_;
@@ -111,6 +116,33 @@ bool PtzIncrementalOptimizer::Solve(std::vector<Camera>& cameras, std::unordered
                              &rig_) != PTZ_OK)
       rig_ = nullptr;  // (the bundle adjustments then pack on the host)
   }
+  if (!match_table_ && !matches_info_.empty() && !(getenv("PTZ_IBA_MATCH_TABLE") && atoi(getenv("PTZ_IBA_MATCH_TABLE")) == 0)) {
+    // ... and so do the matched pixels of every table entry: a registration attempt is then its entry's number and two cameras
+    // (PTZ_IBA_MATCH_TABLE=0: the attempts' pixels are packed for every launch)
+    std::vector<int64_t> ptr(matches_info_.size() + 1, 0);
+    for (size_t e = 0; e < matches_info_.size(); ++e) ptr[e + 1] = ptr[e] + static_cast<int64_t>(matches_info_[e].matches.size());
+    std::vector<float> uv_ref(2 * static_cast<size_t>(ptr.back())), uv_cur(2 * static_cast<size_t>(ptr.back()));
+    bool ok = true;
+    for (size_t e = 0; e < matches_info_.size() && ok; ++e) {
+      const MatchesInfo& mi = matches_info_[e];
+      if (mi.matches.empty()) continue;
+      ok = mi.src_img_idx >= 0 && static_cast<size_t>(mi.src_img_idx) < features_.size() && mi.dst_img_idx >= 0 &&
+           static_cast<size_t>(mi.dst_img_idx) < features_.size();
+      if (!ok) break;
+      const std::vector<KeyPoint>& kr = features_[mi.src_img_idx].keypoints;
+      const std::vector<KeyPoint>& kc = features_[mi.dst_img_idx].keypoints;
+      float* pr = uv_ref.data() + 2 * ptr[e];
+      float* pc = uv_cur.data() + 2 * ptr[e];
+      for (const DMatch& m : mi.matches) {
+        if (m.queryIdx < 0 || static_cast<size_t>(m.queryIdx) >= kr.size() || m.trainIdx < 0 || static_cast<size_t>(m.trainIdx) >= kc.size()) { ok = false; break; }
+        const Point2f a = kr[m.queryIdx].pt, b = kc[m.trainIdx].pt;
+        *pr++ = a.x; *pr++ = a.y; *pc++ = b.x; *pc++ = b.y;
+      }
+    }
+    if (ok && ptz_krt_table_create(static_cast<int32_t>(matches_info_.size()), ptr.data(), uv_ref.data(), uv_cur.data(), device_id_, &match_table_) != PTZ_OK)
+      match_table_ = nullptr;  // (the attempts then pack their pixels)
+  }
+  if (trace_setup) fprintf(stderr, "[inc] setup: tracks %.2f ms, resident tracks + match table %.2f ms\n", ts1 - ts0, now_ms() - ts1);
   by_dst_.assign(features_.size(), {});
   for (size_t e = 0; e < matches_info_.size(); ++e) {
     const MatchesInfo& mi = matches_info_[e];
@@ -263,15 +295,18 @@ std::vector<long> PtzIncrementalOptimizer::FindNextImages() const
   ScopedMs tm(timing_ms_[0]);
   std::vector<float> score(features_.size(), 0.0f);
   const size_t kMaxRegTrials = 4;
-  auto exhausted = [&](long id) {
-    const auto it = num_reg_trials_.find(id);
-    return it != num_reg_trials_.end() && it->second > kMaxRegTrials;
-  };
+  // (per-image flags first: the loop below asks four questions per table entry, ~8 500 entries per 200-view rig, every cycle)
+  std::vector<char> is_exhausted(features_.size(), 0), is_reg(features_.size(), 0);
+  for (const auto& kv : num_reg_trials_)
+    if (kv.second > kMaxRegTrials && kv.first >= 0 && static_cast<size_t>(kv.first) < is_exhausted.size()) is_exhausted[kv.first] = 1;
+  for (long id : reg_image_ids_)
+    if (id >= 0 && static_cast<size_t>(id) < is_reg.size()) is_reg[id] = 1;
+  auto flag = [](const std::vector<char>& f, long id) { return id >= 0 && static_cast<size_t>(id) < f.size() && f[id] != 0; };
   for (const MatchesInfo& mi : matches_info_) {
     const long src = mi.src_img_idx, dst = mi.dst_img_idx;
     if (src == dst || mi.H_empty) continue;
-    if (exhausted(src) || exhausted(dst)) continue;
-    const bool src_in = IsRegistered(src), dst_in = IsRegistered(dst);
+    if (flag(is_exhausted, src) || flag(is_exhausted, dst)) continue;
+    const bool src_in = flag(is_reg, src), dst_in = flag(is_reg, dst);
     if (src_in == dst_in) continue;  // both registered, or neither
     score[src_in ? dst : src] += static_cast<float>(mi.confidence);
   }
@@ -355,11 +390,13 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
 {
   if (todo.empty()) return;
   const size_t n = todo.size();
+  const bool resident = match_table_ != nullptr;
   std::vector<int64_t> match_ptr(n + 1, 0);
   size_t total = 0;
-  for (const MatchesInfo* mi : todo) total += mi->matches.size();
+  if (!resident) for (const MatchesInfo* mi : todo) total += mi->matches.size();
   std::vector<float> uv_ref, uv_cur;
   uv_ref.reserve(2 * total); uv_cur.reserve(2 * total);
+  std::vector<ptz_krt_attempt> attempts(resident ? n : 0);
   std::vector<double> cam_ref(15 * n), cam_cur(15 * n);
   std::vector<Attempt> res(n);
   for (size_t q = 0; q < n; ++q) {
@@ -372,6 +409,11 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
     const std::vector<double> vr = cam_i.ToVector(), vc = init.ToVector();
     std::copy(vr.begin(), vr.end(), cam_ref.begin() + 15 * q);
     std::copy(vc.begin(), vc.end(), cam_cur.begin() + 15 * q);
+    if (resident) {  // the entry's pixels are on the device already
+      attempts[q].table = match_table_;
+      attempts[q].entry = static_cast<int32_t>(todo[q] - matches_info_.data());
+      continue;
+    }
     const std::vector<KeyPoint>& kr = features_[mi.src_img_idx].keypoints;
     const std::vector<KeyPoint>& kc = features_[mi.dst_img_idx].keypoints;
     for (const DMatch& m : mi.matches) {
@@ -388,9 +430,11 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
   std::vector<ptz_lm_summary> summaries(n);
   std::vector<int32_t> accepted(n, 0);
   const auto t_dev = std::chrono::steady_clock::now();
-  const int32_t rc = DeviceKrtSolveBatch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
-                                         cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
-                                         accepted.data(), nullptr);
+  const int32_t rc = resident ? DeviceKrtSolveAttempts(static_cast<int32_t>(n), attempts.data(), cam_ref.data(), cam_cur.data(), PTZ_KRT_F,
+                                                       /*max_reproj_error=*/100.0, &opt, summaries.data(), accepted.data(), nullptr)
+                              : DeviceKrtSolveBatch(static_cast<int32_t>(n), match_ptr.data(), uv_ref.data(), uv_cur.data(), cam_ref.data(),
+                                                    cam_cur.data(), PTZ_KRT_F, /*max_reproj_error=*/100.0, &opt, summaries.data(),
+                                                    accepted.data(), nullptr);
   timing_ms_[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
   for (size_t q = 0; q < n; ++q) {
     res[q].accepted = rc == PTZ_OK && accepted[q] != 0;

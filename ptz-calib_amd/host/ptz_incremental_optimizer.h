@@ -101,6 +101,7 @@ class PtzIncrementalOptimizer {
   // the same tracks resident on the device (ptz_rig_create, once per rig): every bundle adjustment of the run is a view of them
   // ("keep tracks and packed observations resident and grow them instead of rebuilding")
   ptz_rig* rig_ = nullptr;
+  ptz_krt_table* match_table_ = nullptr;  // the table entries' matched pixels, resident on the device (entry = index into matches_info_)
   std::vector<std::vector<size_t>> by_dst_;  // table entries (indices into matches_info_, ascending) per destination image
   std::unordered_map<const MatchesInfo*, Attempt> attempt_cache_;  // valid until the next successful bundle adjustment
   std::vector<Event> events_;

@@ -756,6 +756,44 @@ def test_krt_solve_sharded_matches_one_launch(pkg):
 
 
 @pytest.mark.parametrize("ftype", [0, 1])
+def test_krt_attempts_over_resident_tables_are_the_batch_queries(pkg, ftype):
+    """ptz_krt_table_create + ptz_krt_solve_attempts: the matches of two tables stay on the device, a launch names (table, entry)
+    pairs in any order -- entries repeated, skipped, an empty one, the tables interleaved.  Every attempt has the bits of the same
+    query solved through ptz_krt_solve_batch with its matches packed on the host (same kernel; only where the pixels lie differs)."""
+    rbs = [pkg.synth.make_reloc_batch(23, 48, seed_id=31 + k, factor_type=ftype) for k in range(2)]
+    for k, rb in enumerate(rbs):  # ragged entries, one of them without matches
+        keep = [(5 * q + 3 * k) % 40 + 8 for q in range(rb.n_query)]
+        keep[4] = 0
+        idx = np.concatenate([np.arange(rb.match_ptr[q], rb.match_ptr[q] + n) for q, n in enumerate(keep)]).astype(np.int64)
+        rb.uv_ref, rb.uv_cur = rb.uv_ref[idx], rb.uv_cur[idx]
+        rb.match_ptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    tables = [pkg.api.KrtTable(rb.match_ptr, rb.uv_ref, rb.uv_cur) for rb in rbs]
+    try:
+        rng = np.random.default_rng(5)
+        picks = [(int(rng.integers(2)), int(rng.integers(23))) for _ in range(61)] + [(0, 4), (1, 4), (1, 22), (0, 0)]
+        cam_ref = np.stack([rbs[t].cam_ref[e] for t, e in picks])
+        cam_init = np.stack([rbs[t].cam_init[e] for t, e in picks])
+        cam, summ, acc, _ = pkg.api.krt_solve_attempts([(tables[t], e) for t, e in picks], cam_ref, cam_init, factor_type=ftype)
+        # the same queries, packed
+        lens = [int(rbs[t].match_ptr[e + 1] - rbs[t].match_ptr[e]) for t, e in picks]
+        packed = pkg.synth.RelocBatch(
+            n_query=len(picks), match_ptr=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+            uv_ref=np.concatenate([rbs[t].uv_ref[rbs[t].match_ptr[e]:rbs[t].match_ptr[e + 1]] for t, e in picks]),
+            uv_cur=np.concatenate([rbs[t].uv_cur[rbs[t].match_ptr[e]:rbs[t].match_ptr[e + 1]] for t, e in picks]),
+            cam_ref=cam_ref, cam_init=cam_init, cam_gt=cam_init, factor_type=ftype)
+        want_cam, want_summ, want_acc, _ = pkg.api.krt_solve_batch(packed)
+        assert np.array_equal(acc, want_acc) and acc.sum() > 40
+        assert np.array_equal(cam, want_cam)
+        assert summ == want_summ
+        # argument checks: an entry outside the table
+        with pytest.raises(pkg.api.PtzError):
+            pkg.api.krt_solve_attempts([(tables[0], 23)], cam_ref[:1], cam_init[:1], factor_type=ftype)
+    finally:
+        for t in tables:
+            t.close()
+
+
+@pytest.mark.parametrize("ftype", [0, 1])
 def test_krt_more_matches_than_the_lds_cache(pkg, orc, ftype):
     """Queries with 700 matches: the kernel caches the constant part of the first 256 matches of a query in LDS and recomputes
     the rest on the fly (with the iterative undistortion for FDist); both paths must give the oracle's answer."""

@@ -21,3 +21,7 @@ for rep in range(2):
     reg = sum(len(r["registered"]) for r in res)
     print(json.dumps(dict(rigs=n, wall_total_ms=1e3 * d, views_per_s=reg / d, **st)), flush=True)
 assert res[0]["events"] == r1["events"] and np.array_equal(res[0]["cameras"], r1["cameras"])
+if os.environ.get("PTZ_PROBE_RIG_TIMING"):
+    keys = sorted(res[0]["timing_ms"].keys())
+    print("per-rig host timing, mean over rigs (ms):", {k: round(float(np.mean([r["timing_ms"][k] for r in res])), 2) for k in keys})
+    print("  max over rigs:", {k: round(float(np.max([r["timing_ms"][k] for r in res])), 2) for k in keys})
