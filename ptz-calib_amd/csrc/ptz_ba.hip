@@ -1601,11 +1601,14 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       while ((1u << (end_bit - 47)) < (unsigned)n) ++end_bit;
       size_t tmp_bytes = 0;
       void* tmp = nullptr;
-      if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, 0u, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+      // (the low 24 bits of a key are the track number and the keys are generated in (view, track) order: a STABLE sort on the bits
+      //  above them gives the same order in four digit passes instead of seven)
+      const unsigned begin_bit = 24;
+      if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, begin_bit, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
       char* tmpc = nullptr;
       TRY(b->alloc(&tmpc, tmp_bytes + 256));
       tmp = tmpc;
-      if (rocprim::radix_sort_pairs(tmp, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, 0u, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
+      if (rocprim::radix_sort_pairs(tmp, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, begin_bit, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     }
     hipLaunchKernelGGL(k_view_rays, gtrk, dim3(256), 0, st, vb, (const int*)val_out);
     hipLaunchKernelGGL(k_view_rayscan, dim3(n), dim3(1024), 0, st, vb, b->ray_block);

@@ -370,6 +370,32 @@ def test_ba_large_batch_matches_single_across_cholesky_variants(pkg):
         assert s1 == summ[i] and np.array_equal(cam1, cams[i]) and np.array_equal(ray1, rays[i])
 
 
+def test_ba_one_launch_factorisation_of_a_dozen_rigs(pkg, monkeypatch):
+    """Nine to 32 systems (the view batches of the incremental pipeline: ~20 growing rigs per lock step) are factored by ONE
+    chol_chain_kernel launch as well, with far more tiles than the chip holds workgroups: tickets are taken in elimination
+    order, so a tile only waits for workgroups that started before it.  PTZ_BA_CHOL_CHAIN_TILES=0 gives those batches the
+    per-step launches back: the same bits; and every rig of the batch has the bits of its solo solve."""
+    scenes = [pkg.synth.make_scene(60 + k, 40 + 25 * (k % 5), 150 + 40 * (k % 3)) for k in range(14)]
+    def run(group):
+        b = pkg.api.BaBatch(group); b.set_state()
+        summ = b.solve(); cams, rays = b.get_state()
+        summ2 = b.solve(); cams2, _ = b.get_state()   # (generation 2 of the flags)
+        b.close()
+        assert summ2 == summ and all(np.array_equal(a, c) for a, c in zip(cams, cams2))
+        return summ, cams, rays
+    monkeypatch.delenv("PTZ_BA_CHOL_CHAIN_TILES", raising=False)
+    s1, c1, r1 = run(scenes)
+    monkeypatch.setenv("PTZ_BA_CHOL_CHAIN_TILES", "0")
+    s0, c0, r0 = run(scenes)
+    monkeypatch.delenv("PTZ_BA_CHOL_CHAIN_TILES", raising=False)
+    assert s0 == s1
+    assert all(np.array_equal(a, c) for a, c in zip(c0, c1)) and all(np.array_equal(a, c) for a, c in zip(r0, r1))
+    assert len({s["num_iterations"] for s in s1}) > 1   # (rigs retire at different passes: compacted launch shapes in play)
+    for k in (0, 7, 13):
+        cam, ray, summ = pkg.api.ba_solve(scenes[k])
+        assert summ == s1[k] and np.array_equal(cam, c1[k]) and np.array_equal(ray, r1[k])
+
+
 def test_ba_one_launch_factorisation_has_the_bits_of_the_per_step_launches(pkg, monkeypatch):
     """A few rigs factor their reduced systems in ONE launch whose workgroups hand tiles on through flags
     (chol_chain_kernel, while all tiles of the launch fit on the chip at once); PTZ_BA_CHOL_CHAIN=0 brings back one launch per
