@@ -597,21 +597,38 @@ def main():
         batch.close()
     if rank == 0:
         cpu = None
+        def side_leg(name, fn):
+            # the legs beside the headline never take the line down with them: a leg that fails is reported as such, with its error
+            try:
+                body[name] = fn()
+            except Exception as e:  # noqa: BLE001 -- whatever it was, the headline measured above stands
+                body[name] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+
         if extras:
             pkg.api.trim_cache()
-            body["c2_single_rig"] = single_rig_leg(pkg, c2_scene, local_rank)
+            side_leg("c2_single_rig", lambda: single_rig_leg(pkg, c2_scene, local_rank))
             if args.config != "C5":
-                body["c5_reloc"] = RelocRun(pkg, pkg.synth.make_reloc_queries(args.queries, 128, seed_id=1, factor_type=0), local_rank).run(5)[1]  # configs[4] at full size
-                body["c5_reloc"]["note"] = "configs[4] at full size (--queries per GPU); `bench.py --config C5` makes it the headline"
-            body["ptz_iba"] = iba_leg(pkg, c2_scene)
+                def c5_leg():
+                    r = RelocRun(pkg, pkg.synth.make_reloc_queries(args.queries, 128, seed_id=1, factor_type=0), local_rank).run(5)[1]  # configs[4] at full size
+                    r["note"] = "configs[4] at full size (--queries per GPU); `bench.py --config C5` makes it the headline"
+                    return r
+                side_leg("c5_reloc", c5_leg)
+            side_leg("ptz_iba", lambda: iba_leg(pkg, c2_scene))
             if iba_tables:
-                body["ptz_iba_batch"] = iba_batch_leg(pkg, iba_scenes, iba_tables, local_rank)
+                side_leg("ptz_iba_batch", lambda: iba_batch_leg(pkg, iba_scenes, iba_tables, local_rank))
         if extras:
-            body["parity"] = parity_leg(pkg)
+            side_leg("parity", lambda: parity_leg(pkg))
         if world == 1 and extras and not args.no_cpu_baseline:
-            body["c5_reloc"]["cpu_baseline"] = reloc_cpu_baseline_leg(pkg)
+            if "error" not in body.get("c5_reloc", {"error": 1}):
+                try:
+                    body["c5_reloc"]["cpu_baseline"] = reloc_cpu_baseline_leg(pkg)
+                except Exception as e:  # noqa: BLE001
+                    body["c5_reloc"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             if args.config == "C5":
-                cpu = body["c5_reloc"]["cpu_baseline"]
+                cpu = body.get("c5_reloc", {}).get("cpu_baseline")
+                if cpu is not None and "error" in cpu:
+                    cpu = None
             else:
                 cpu = cpu_baseline_leg(base if base else [c2_scene])
         value = total_steps / t_max
@@ -619,15 +636,15 @@ def main():
         headline = {"c4_lm_iterations_per_s" if args.config == "C4" else "lm_iterations_per_s": value}
         if "default_pipeline" in body:
             headline["default_pipeline_lm_iterations_per_s"] = body["default_pipeline"]["lm_iterations_per_s"]
-        if "c2_single_rig" in body:
+        if "error" not in body.get("c2_single_rig", {"error": 1}):
             headline["c2_single_rig_lm_iterations_per_s"] = body["c2_single_rig"]["lm_iterations_per_s"]
             headline["c2_single_rig_us_per_lm_iteration"] = body["c2_single_rig"]["us_per_lm_iteration"]
             headline["c2_target_lm_iterations_per_s"] = 10000.0
-        if "c5_reloc" in body:
+        if "error" not in body.get("c5_reloc", {"error": 1}):
             headline["c5_queries_per_s"] = body["c5_reloc"]["queries_per_s"]
-        if "ptz_iba" in body:
+        if "error" not in body.get("ptz_iba", {"error": 1}):
             headline["ptz_iba_views_per_s"] = body["ptz_iba"]["views_per_s"]
-        if "ptz_iba_batch" in body:
+        if "error" not in body.get("ptz_iba_batch", {"error": 1}):
             headline["ptz_iba_batch_views_per_s"] = body["ptz_iba_batch"]["views_per_s"]
             headline["ptz_iba_batch_views_per_s_inside_the_call"] = body["ptz_iba_batch"]["views_per_s_solve_only"]
         if cpu is not None:

@@ -863,10 +863,13 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 // workgroups the chip holds at a time, the one with the smallest unfinished ticket can always run.  Waits are bounded: if a
 // flag does not come (a device fault elsewhere), the system is marked failed and the workgroup goes on -- never a hang.
 constexpr int CHAIN_SPIN_LIMIT = 1 << 21;
-__device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit)  // (one thread polls; the workgroup's acquire fence follows its barrier)
+// `fail`: the system's failure word.  Once ANY wait of the system has run out (bit 1), every other waiter of that system gives up
+// at its next look (every 1024 polls): a lost hand-over costs one bound, not one bound per tile behind it.
+__device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit, const int* fail = nullptr)  // (one thread polls; the workgroup's acquire fence follows its barrier)
 {
   for (int it = 0; it < limit; ++it) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) return true;
+    if (fail && (it & 1023) == 1023 && (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
   return false;
@@ -948,7 +951,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     const int k = klist[q];
     if (q > 0) __syncthreads();  // all waves are done with the operand tiles of the previous column
     if (threadIdx.x == 0) {
-      const bool ok = chain_wait(&T[ti * nt + k], gen, spin) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin));
+      const bool ok = chain_wait(&T[ti * nt + k], gen, spin, &cb.fail[sys]) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin, &cb.fail[sys]));
       if (!ok) atomicOr(&cb.fail[sys], 2);  // bit 1: a hand-over that did not come (reported to the host: LmState::chain_timeouts)
     }
     __syncthreads();
@@ -1027,7 +1030,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       if (ti != tj) trsm_block_pre<c>(xb, Lk, Bs + 16 * w * LD);
       if (c >= have) {  // (uniform)
         if (pk[c] != gen) {  // (the look taken while the previous block was fetched did not find it yet)
-          if (lane == 0 && !chain_wait(&F[4 * k + c], gen, spin)) atomicOr(&cb.fail[sys], 2);  // (every wave polls: no barrier to pass the news on)
+          if (lane == 0 && !chain_wait(&F[4 * k + c], gen, spin, &cb.fail[sys])) atomicOr(&cb.fail[sys], 2);  // (every wave polls: no barrier to pass the news on)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         rb[c] = fetch(cc);
