@@ -291,3 +291,14 @@ def test_ptz_iba_over_resident_tracks_takes_the_decisions_of_host_packed_runs(pk
         assert a["registered"] == b["registered"] == c["registered"]
         assert np.array_equal(a["cameras"], b["cameras"]) and np.array_equal(a["cameras"], c["cameras"])
     assert vstats["ba_batches"] < vstats["ba_problems"]  # (the rigs' bundle adjustments of a round are one batch)
+    # the registration attempts likewise: entries of a match table resident on the device (ptz_krt_table_create /
+    # ptz_krt_solve_attempts; default) against their pixels packed for every launch (PTZ_IBA_MATCH_TABLE=0), solo and in lock step
+    monkeypatch.delenv("PTZ_IBA_VIEWS", raising=False)
+    monkeypatch.setenv("PTZ_IBA_MATCH_TABLE", "0")
+    no_table = [pkg.hostlib.incremental_solve(tb, c, max_iter=200) for tb, c in zip(tables, cam0)]
+    nbatch, _ = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200)
+    monkeypatch.delenv("PTZ_IBA_MATCH_TABLE", raising=False)
+    for a, b, c in zip(views, no_table, nbatch):
+        assert b["ok"] and c["ok"]
+        assert a["events"] == b["events"] == c["events"]
+        assert np.array_equal(a["cameras"], b["cameras"]) and np.array_equal(a["cameras"], c["cameras"])
