@@ -399,6 +399,8 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
   std::vector<ptz_krt_attempt> attempts(resident ? n : 0);
   std::vector<double> cam_ref(15 * n), cam_cur(15 * n);
   std::vector<Attempt> res(n);
+  // (a registered camera is the reference of many attempts of one launch: its 15-vector -- an SVD inside -- is made once)
+  std::unordered_map<long, std::vector<double>> ref_vec;
   for (size_t q = 0; q < n; ++q) {
     const MatchesInfo& mi = *todo[q];
     const Camera& cam_i = cameras_[mi.src_img_idx];
@@ -406,7 +408,10 @@ void PtzIncrementalOptimizer::SolveAttempts(const std::vector<const MatchesInfo*
     const Camera init(cam_i.K(), RotationFromHomography(cam_i.K(), mi.H, cam_i), cam_j.t(), cam_j.dist());  // K_j := K_i (:392)
     res[q].init_K = init.K();
     res[q].init_R = init.R();
-    const std::vector<double> vr = cam_i.ToVector(), vc = init.ToVector();
+    auto rv = ref_vec.find(mi.src_img_idx);
+    if (rv == ref_vec.end()) rv = ref_vec.emplace(mi.src_img_idx, cam_i.ToVector()).first;
+    const std::vector<double>& vr = rv->second;
+    const std::vector<double> vc = init.ToVector();
     std::copy(vr.begin(), vr.end(), cam_ref.begin() + 15 * q);
     std::copy(vc.begin(), vc.end(), cam_cur.begin() + 15 * q);
     if (resident) {  // the entry's pixels are on the device already

@@ -66,6 +66,59 @@ void JacobiSVD(int m, int n, const std::vector<double>& A_in, std::vector<double
   }
 }
 
+void JacobiSVD3(const double* A_in, double* U, double* s, double* V)
+{
+  constexpr int m = 3, n = 3;
+  double A[9], W[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = A_in[i];
+  const double eps = 1e-15;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < m; ++i) {
+          const double ap = A[i * n + p], aq = A[i * n + q];
+          alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
+        }
+        if (std::fabs(gamma) <= eps * std::sqrt(alpha * beta) || gamma == 0.0) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < m; ++i) {
+          const double x = A[i * n + p], y = A[i * n + q];
+          A[i * n + p] = c * x - sn * y;
+          A[i * n + q] = sn * x + c * y;
+        }
+        for (int i = 0; i < n; ++i) {
+          const double x = W[i * n + p], y = W[i * n + q];
+          W[i * n + p] = c * x - sn * y;
+          W[i * n + q] = sn * x + c * y;
+        }
+      }
+    if (!rotated) break;
+  }
+  double norm[3];
+  for (int j = 0; j < n; ++j) {
+    double a = 0;
+    for (int i = 0; i < m; ++i) a += A[i * n + j] * A[i * n + j];
+    norm[j] = std::sqrt(a);
+  }
+  int order[3] = {0, 1, 2};
+  // stable descending sort of three (insertion: equal norms keep their order, as std::stable_sort does)
+  for (int a = 1; a < 3; ++a)
+    for (int b2 = a; b2 > 0 && norm[order[b2]] > norm[order[b2 - 1]]; --b2) std::swap(order[b2], order[b2 - 1]);
+  for (int i = 0; i < 9; ++i) { U[i] = 0.0; V[i] = 0.0; }
+  for (int j = 0; j < n; ++j) {
+    const int o = order[j];
+    s[j] = norm[o];
+    for (int i = 0; i < n; ++i) V[i * n + j] = W[i * n + o];
+    if (norm[o] > 0)
+      for (int i = 0; i < m; ++i) U[i * n + j] = A[i * n + o] / norm[o];
+  }
+}
+
 std::vector<double> SolveLeastSquares(int m, int n, const std::vector<double>& A, const std::vector<double>& b, double rcond)
 {
   std::vector<double> U, s, V;

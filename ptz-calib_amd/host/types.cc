@@ -45,13 +45,10 @@ Vec3 RodriguesInv(const Mat33& R_in)
   // near-rotation K_j^-1 H K_i of the registration step (ptz_incremental_optimizer.cc:391-394) into a rotation.
   Mat33 R = R_in;
   {
-    std::vector<double> U, s, V;
-    JacobiSVD(3, 3, std::vector<double>(R_in.begin(), R_in.end()), U, s, V);
-    if (s[2] > 0) {
-      Mat33 Um, Vm;
-      for (int i = 0; i < 9; ++i) { Um[i] = U[i]; Vm[i] = V[i]; }
-      R = Mul(Um, Transpose(Vm));
-    }
+    Mat33 Um, Vm;
+    double s[3];
+    JacobiSVD3(R_in.data(), Um.data(), s, Vm.data());  // (the 3 x 3 case of JacobiSVD without heap: same rotations, same bits)
+    if (s[2] > 0) R = Mul(Um, Transpose(Vm));
   }
   double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
   const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
