@@ -316,7 +316,8 @@ void* ptzh_inc_create(int32_t n_img, const int64_t* kp_ptr, const float* kp_xy, 
     r->mis[p].H_empty = h_valid[p] == 0;
     r->mis[p].confidence = confidence[p];
   }
-  r->opt.reset(new PtzIncrementalOptimizer(r->feats, r->mis, r->cams, max_iter));
+  // (the tables were built for this optimizer only: moved in, not copied a second time)
+  r->opt.reset(new PtzIncrementalOptimizer(PtzIncrementalOptimizer::TakeInputs{}, std::move(r->feats), std::move(r->mis), std::move(r->cams), max_iter));
   if (n_seeds > 0) r->opt->SetSeedImageId(std::vector<long>(seeds, seeds + n_seeds));
   return r;
 }
@@ -364,7 +365,7 @@ int32_t ptzh_inc_result(void* handle, double* cam15, int32_t* registered, int64_
   if (lm_iterations) *lm_iterations = r->opt->lm_iterations();
   if (solved) *solved = r->ok ? 1 : 0;
   if (!r->ok) return ne;
-  const int n_img = static_cast<int>(r->feats.size());
+  const int n_img = static_cast<int>(r->opt->NumImages());
   for (int i = 0; i < n_img; ++i) {
     registered[i] = r->reg.count(i) ? 1 : 0;
     const std::vector<double> v = r->out[i].ToVector();

@@ -73,6 +73,12 @@ PtzIncrementalOptimizer::PtzIncrementalOptimizer(const std::vector<ImageFeatures
 {
 }
 
+PtzIncrementalOptimizer::PtzIncrementalOptimizer(TakeInputs, std::vector<ImageFeatures>&& features, std::vector<MatchesInfo>&& matches_info,
+                                                 std::vector<Camera>&& cameras, int max_iter)
+    : cameras_(std::move(cameras)), features_(std::move(features)), matches_info_(std::move(matches_info)), max_iter_(max_iter)
+{
+}
+
 PtzIncrementalOptimizer::~PtzIncrementalOptimizer()
 {
   if (rig_) ptz_rig_destroy(rig_);

@@ -33,6 +33,12 @@ class PtzIncrementalOptimizer {
   PtzIncrementalOptimizer(const std::vector<ImageFeatures>& features, const std::vector<MatchesInfo>& matches_info,
                           const std::vector<Camera>& cameras, const std::vector<std::string>& names, int max_iter);
 
+  // the same with the inputs MOVED in (a caller that built them for this optimizer only: the C API of the batch driver) -- the
+  // reference's constructors deep-copy (ptz_incremental_optimizer.h:31-36), which for a 200-view rig is 12 MB of match lists
+  struct TakeInputs {};
+  PtzIncrementalOptimizer(TakeInputs, std::vector<ImageFeatures>&& features, std::vector<MatchesInfo>&& matches_info,
+                          std::vector<Camera>&& cameras, int max_iter);
+  size_t NumImages() const { return features_.size(); }
   ~PtzIncrementalOptimizer();
   PtzIncrementalOptimizer(const PtzIncrementalOptimizer&) = delete;
   PtzIncrementalOptimizer& operator=(const PtzIncrementalOptimizer&) = delete;

@@ -84,7 +84,7 @@ def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int 
         return dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)),
                     events=[tuple(int(x) for x in row) for row in ev[:max(ne, 0)]], lm_iterations=int(nit.value))
 
-    workers = max(1, min(16, len(tables), os.cpu_count() or 1))
+    workers = max(1, min(int(os.environ.get("PTZ_HOST_MARSHAL_THREADS", "16")), len(tables), os.cpu_count() or 1))  # (marshalling and tear-down of the rigs; measured, 64 rigs: 16 threads 383-430 ms for the whole call, 64 threads 547-598 -- they queue for the interpreter lock)
     with ThreadPoolExecutor(workers) as pool:
         handles = list(pool.map(create, zip(tables, cam15s)))
         arr = (C.c_void_p * len(handles))(*handles)
