@@ -89,6 +89,7 @@ struct ptz_ba_batch {
   Dev d;
   std::vector<void*> allocs;
   hipEvent_t create_ev = nullptr;    // end of ptz_ba_batch_create's work on `io`
+  double* rkinv_dev = nullptr;       // ptz_ba_batch_set_state_pix2ray: the cameras' R^-1 K^-1 [9 total_cam]
   std::vector<void*> staged_pinned;  // staging blocks of uploads still in flight on `io` (released behind the next wait for it)
   void release_staged() { for (void* p : staged_pinned) ptzpool::pinned_release(p); staged_pinned.clear(); }
   hipStream_t stream = nullptr;   // stream of the group being enqueued (LAUNCH / prof_* use it)
@@ -2495,8 +2496,8 @@ int32_t ptz_ba_batch_set_state_pix2ray(ptz_ba_batch* b, const double* cam, const
   memcpy(stg + nc, rkinv, sizeof(double) * nk);
   // (no wait: the solve that follows runs on the same stream; the staging block lives until that solve's wait, the R^-1 K^-1 block
   //  until the batch goes)
-  double* dk = nullptr;
-  if (b->alloc(&dk, nk) != PTZ_OK) { if (pin) ptzpool::pinned_release(pin); return PTZ_ENOMEM; }
+  if (!b->rkinv_dev && b->alloc(&b->rkinv_dev, nk) != PTZ_OK) { if (pin) ptzpool::pinned_release(pin); return PTZ_ENOMEM; }
+  double* dk = b->rkinv_dev;  // (one block per batch, reused by later calls: they are ordered on the batch's stream)
   hipError_t e = hipMemcpyAsync(b->cam0, stg, sizeof(double) * nc, hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dk, stg + nc, sizeof(double) * nk, hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) e = hipMemsetAsync(b->tlw0, 0, sizeof(double) * 6 * b->n_scene, b->stream);

@@ -10,6 +10,7 @@
 //   J^T J (4x4 or 5x5), J^T r and the cost are reduced with a fixed butterfly, every lane then solves the
 //   damped normal equations redundantly in registers.  DENSE_QR on [J; D] and Cholesky on J^T J + D^2
 //   give the same step up to round-off (the Jacobi-scaled 4-/5-column Jacobian is well conditioned).
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -744,10 +745,15 @@ extern "C" int32_t ptz_krt_solve_attempts(int32_t n_query, const ptz_krt_attempt
   long long* del = (long long*)(ps + o_del);
   for (int q = 0; q < n_query; ++q) {
     const ptz_krt_table* t = attempts[q].table;
-    const long long at = (long long)(t->d_ref - t0->d_ref);  // the table's reference pixels, in elements from the first table's
+    // the table's pixels, in elements from the first table's (the tables are separate allocations of one address space: the
+    // distances are taken on the addresses, not by pointer subtraction; every block of the pool is 256-byte aligned)
+    auto dist = [](const float2* a, const float2* b0) {
+      return (long long)((reinterpret_cast<intptr_t>(a) - reinterpret_cast<intptr_t>(b0)) / (intptr_t)sizeof(float2));
+    };
+    const long long at = dist(t->d_ref, t0->d_ref);
     rng[2 * q] = at + t->ptr[attempts[q].entry];
     rng[2 * q + 1] = at + t->ptr[attempts[q].entry + 1];
-    del[q] = (long long)(t->d_cur - t0->d_cur) - at;
+    del[q] = dist(t->d_cur, t0->d_cur) - at;
   }
   memcpy(ps + o_cref, cam_ref, sizeof(double) * 15 * n_query);
   memcpy(ps + o_ccur, cam_cur, sizeof(double) * 15 * n_query);
