@@ -1580,7 +1580,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     vb.cam_of_image = d_map; vb.cam_image = d_camimg;
     vb.scene = const_cast<SceneDev*>(d.scene);
     vb.chunk_off = d_chunkoff;
-    if (b->max_cam <= VIEW_LDS_CAMS) TRY(b->alloc(&vb.chunk_cnt, chunk_total));
+    if (b->max_cam <= VIEW_LDS_CAMS) TRY(b->alloc(&vb.chunk_cnt, chunk_total));  // (unused by the wide path)
     unsigned long long *key_out = nullptr;
     int* val_out = nullptr;
     TRY(b->alloc(&vb.t_len, trk_total)); TRY(b->alloc(&vb.t_first, trk_total)); TRY(b->alloc(&vb.t_ext, trk_total));
@@ -1613,7 +1613,9 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     }
     hipLaunchKernelGGL(k_view_rays, gtrk, dim3(256), 0, st, vb, (const int*)val_out);
     hipLaunchKernelGGL(k_view_rayscan, dim3(n), dim3(1024), 0, st, vb, b->ray_block);
-    if (b->max_cam <= VIEW_LDS_CAMS) {  // camera-major lists by counting: chunk histograms, running sums, placement
+    // (PTZ_BA_DEBUG_VIEW_WIDE=1: the path of views wider than VIEW_LDS_CAMS for any view -- tests: the same lists)
+    const bool view_wide = b->max_cam > VIEW_LDS_CAMS || (getenv("PTZ_BA_DEBUG_VIEW_WIDE") && atoi(getenv("PTZ_BA_DEBUG_VIEW_WIDE")) != 0);
+    if (!view_wide) {  // camera-major lists by counting: chunk histograms, running sums, placement
       hipLaunchKernelGGL(k_view_hist, gtrk, dim3(256), sizeof(int) * (size_t)b->max_cam, st, vb);
       hipLaunchKernelGGL(k_view_chunkscan, dim3(n), dim3(1024), 0, st, vb);
       hipLaunchKernelGGL(k_view_place, gtrk, dim3(256), sizeof(unsigned long long) * 4 * (size_t)b->max_cam, st, vb);

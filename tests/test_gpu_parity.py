@@ -1286,6 +1286,22 @@ def _pix2ray_reference_order(prob, rkinv):
     return rays
 
 
+def test_views_wider_than_the_counting_sort_take_the_same_lists(pkg, monkeypatch):
+    """The camera-major lists of a view are a counting sort through LDS (chunk histograms, per-wave lane masks) for views of up to
+    2048 cameras; wider ones sweep the rays once per camera.  PTZ_BA_DEBUG_VIEW_WIDE=1 sends any view down the wide path: the same
+    structure, word for word (hash), as the default path and as the host-packed problem."""
+    sc = pkg.synth.make_scene(4, 36, 110)
+    rig = pkg.api.Rig.from_scene(sc)
+    views = [list(range(36)), list(range(2, 30, 2)), [0, 1, 2]]
+    probs = [pkg.api.view_problem(sc, im) for im in views]
+    hb = pkg.api.BaBatch(probs); want = pkg.api.structure_hash(hb); hb.close()
+    vb = pkg.api.ViewBatch([rig] * 3, views); got_default = pkg.api.structure_hash(vb); vb.close()
+    monkeypatch.setenv("PTZ_BA_DEBUG_VIEW_WIDE", "1")
+    vb = pkg.api.ViewBatch([rig] * 3, views); got_wide = pkg.api.structure_hash(vb); vb.close()
+    monkeypatch.delenv("PTZ_BA_DEBUG_VIEW_WIDE", raising=False)
+    assert got_default == want and got_wide == want
+
+
 def test_views_of_resident_rigs_are_the_batches_of_their_packed_problems(pkg):
     """ptz_ba_batch_create_views: bundle adjustments over candidate subsets of rigs whose tracks are resident in HBM (what PTZ-IBA
     asks for ~2N times per rig, ptz_incremental_optimizer.cc:420-440), the packed problem built ON THE DEVICE.  Against
