@@ -82,6 +82,7 @@ struct ptz_ba_batch {
   int ray_block = RAY_BLOCK;
   bool schur_tg = false;         // a camera with more observations than k_schur's LDS table holds: table in global memory
   bool schur_w = false;          // PTZ_BA_SCHUR_W=1: round 2's Schur kernel over materialised W rows (kept for A/B measurements)
+  bool schur_f = false;          // PTZRay, table in LDS: k_schur_f (factored 8-double rows, three workgroups per compute unit; PTZ_BA_SCHUR_F=0: k_schur)
   bool gtab = false;             // camera tables too large for LDS: the GTAB instantiations read them from global memory
   int n_group_hint(int n) const { if (const char* e = getenv("PTZ_BA_STREAMS")) return std::max(1, atoi(e)); return n >= 32 ? 2 : 1; }
   int max_cam = 0, max_ray = 0, max_chunk = 0, max_pair = 0, max_n = 0, max_cam_obs = 0, max_cam_ent = 0, max_cam_pair = 0, max_cam_run = 0;
@@ -294,14 +295,14 @@ inline int level_schedule(int nt, const unsigned char* m, int* sched)
 inline int schur_threads_of(int factor_type) { (void)factor_type; return 256; }
 
 // NW: camera columns with a 2D-2D Jacobian (Dims<TYPE>::NW); max_ent: entries of the largest camera
-inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy, int threads, int NW = 0, int max_ent = 0)
+inline size_t schur_lds_bytes(int max_obs, int NC, int np, bool legacy, int threads, int NW = 0, int max_ent = 0, int row = 0)
 {
   // legacy (k_schur_w): T rows of the largest camera, the reduction strip, the scene's tile order (one int per 64 columns)
   if (legacy) return sizeof(double) * ((size_t)max_obs * NC * 3 + (size_t)(SCHUR_THREADS / 64) * (NC + NC * (NC + 1) / 2) + (size_t)(np / CHOL_NB + 1) / 2 + 1);
   // k_schur: the reduction strip, the tile order, then ONE region that first holds, per observation of the largest camera, its T'
   // row and the ray's direction (NW * 3 + 3 doubles rounded up to an odd count, NW <= NC) and later one sum per run (NW^2 | 1)
   if (NW <= 0) NW = NC;
-  const size_t table = (size_t)max_obs * ((NW * 3 + 3) | 1), sums = (size_t)threads * ((NW * NW) | 1);
+  const size_t table = (size_t)max_obs * (row > 0 ? row : ((NW * 3 + 3) | 1)), sums = (size_t)threads * ((NW * NW) | 1);  // row > 0: k_schur_f's factored rows
   return sizeof(double) * ((size_t)(threads / 64) * (NW + NW * (NW + 1) / 2) + (size_t)(np / CHOL_NB + 2) / 2 + std::max(table, sums) + 2) +
          2 * (size_t)((max_ent + 3) & ~3);
 }
@@ -504,7 +505,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   const int B = sh.slots;
   hipStream_t st = b->stream;
   const int schur_thr = schur_threads<TYPE>();
-  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w, schur_thr, Dims<TYPE>::NW, b->max_cam_ent);
+  const size_t schur_smem = schur_lds_bytes(b->schur_tg ? 0 : b->max_cam_obs, NC, d.chol.np, b->schur_w, schur_thr, Dims<TYPE>::NW, b->max_cam_ent,
+                                            b->schur_f ? SCHUR_F_ROW : 0);
   b->prof_begin(P_RAYPREP);
   {
     const int nt = d.chol.np / CHOL_NB;
@@ -521,6 +523,12 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   if (b->schur_w) {
     if (b->schur_tg) LAUNCH((k_schur_w<TYPE, true>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
     else LAUNCH((k_schur_w<TYPE, false>), dim3(b->max_cam, B), dim3(SCHUR_THREADS), schur_smem, d);
+  }
+  else if (b->schur_f) {
+    if constexpr (Dims<TYPE>::FACTOR == 0) {
+      if (b->schur_tg) LAUNCH((k_schur_f<TYPE, true>), dim3(b->max_cam, B), dim3(256), schur_smem, d);
+      else LAUNCH((k_schur_f<TYPE, false>), dim3(b->max_cam, B), dim3(256), schur_smem, d);
+    }
   }
   else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
   else {
@@ -2109,9 +2117,14 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   const int NW2d = NC - ((has3d && type != PTZ_BA_PTZRayFxfyDist) ? 1 : 0);  // Dims<TYPE>::NW
   b->d.schur_ent_cap = b->max_cam_ent;
   for (auto& dgp : b->dg) dgp.schur_ent_cap = b->max_cam_ent;
-  b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w, schur_threads_of(type), NW2d, b->max_cam_ent) > 160 * 1024 ||
+  // PTZRay: the factored rows of k_schur_f (8 doubles per observation instead of 15: three workgroups per compute unit, and
+  // the LDS table holds views of ~2000 observations); PTZ_BA_SCHUR_F=0 keeps k_schur (A/B measurements)
+  b->schur_f = type == PTZ_BA_PTZRay && !b->schur_w;
+  if (const char* e = getenv("PTZ_BA_SCHUR_F")) b->schur_f = b->schur_f && atoi(e) != 0;
+  const int frow = b->schur_f ? SCHUR_F_ROW : 0;
+  b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w, schur_threads_of(type), NW2d, b->max_cam_ent, frow) > 160 * 1024 ||
                 (!b->schur_w && b->max_cam_run > schur_threads_of(type));
-  if (!b->schur_w && schur_lds_bytes(0, NC, b->d.chol.np, false, schur_threads_of(type), NW2d, b->max_cam_ent) > 160 * 1024) {
+  if (!b->schur_w && schur_lds_bytes(0, NC, b->d.chol.np, false, schur_threads_of(type), NW2d, b->max_cam_ent, frow) > 160 * 1024) {
     ptz_ba_batch_destroy(b);  // a view with more pair entries than the LDS copy of its list holds (~60 000)
     return PTZ_ELIMIT;
   }
@@ -2148,6 +2161,10 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       raise_cap((const void*)k_lin_ray<T, true, false>);    \
       raise_cap((const void*)k_lin_ray<T, false, false>);
       raise_cap((const void*)k_eval<0, true, false, true>);
+      raise_cap((const void*)k_schur_f<0, false>);
+      raise_cap((const void*)k_schur_f<0, true>);
+      raise_cap((const void*)k_schur_f<4, false>);
+      raise_cap((const void*)k_schur_f<4, true>);
       raise_cap((const void*)k_eval<1, true, false, true>);
       raise_cap((const void*)k_eval<2, true, false, true>);
       PTZ_SET_ATTR(0) PTZ_SET_ATTR(1) PTZ_SET_ATTR(2) PTZ_SET_ATTR(3) PTZ_SET_ATTR(4) PTZ_SET_ATTR(5) PTZ_SET_ATTR(6) PTZ_SET_ATTR(7)

@@ -12,6 +12,7 @@ namespace {
 
 constexpr int RAY_BLOCK = 1024;  // most rays per workgroup in the ray-centric kernels (Dev::ray_block is the batch's actual value:
                                  // a few scenes use small workgroups so that one rig's 13 k rays spread over a hundred compute units)
+constexpr int SCHUR_F_ROW = 9;     // doubles per observation in k_schur_f's LDS table: 8, at an odd pitch
 constexpr int EZS = 16;           // doubles per ray in the record k_schur gathers once per observation: E (6), z = E g_r (3), the
                                   // functor's point Xn (3), a = sqrt(w) |X|^-1 s_r (3), sqrt(w) -- 128 bytes, one aligned line,
                                   // written whole by k_ray_prep every pass
@@ -1743,7 +1744,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
     double pJl[9], pS[NW];
     const bool pre = (int)threadIdx.x < npr * NW;
     {
-      const double* cbp = camtab + (size_t)pcj[pre ? (int)threadIdx.x / NW : 0] * CBS;
+      const double* cbp = camtab + (size_t)(pre ? pcj[(int)threadIdx.x / NW] : 0) * CBS;  // (a camera without pairs must not read pcj[0]: it may lie behind the array)
 #pragma unroll
       for (int k = 0; k < 9; ++k) pJl[k] = cbp[CB_JL + k];
 #pragma unroll
@@ -1804,6 +1805,414 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
            sc_t[1] - sc_t[0], sc_t[8] - sc_t[0], sc_t[9] - sc_t[8], sc_t[10] - sc_t[9], sc_t[11] - sc_t[10], sc_t[12] - sc_t[11], sc_t[1] - sc_t[12],
            sc_t[2] - sc_t[1], sc_t[3] - sc_t[2], sc_t[4] - sc_t[3], sc_t[5] - sc_t[4], sc_t[6] - sc_t[5]);
 #endif
+}
+
+// ---- schur (round 5): the table row in FACTORED form -- 8 doubles per observation instead of 15 -----------------------------
+// k_schur above keeps T'_a (NW x 3) and the functor's point Xn per observation: 15 doubles, 62 KB for a 514-observation view,
+// which is what holds it at two workgroups per compute unit.  But T_a = W_a E = Jc_a^T (Jr_a E) has rank two, and for PTZRay
+// (FACTOR 0: pinhole, no distortion) everything of observation a that an entry needs follows from its normalised image point
+// (x_a, y_a) in camera i:
+//   * G_a = Graw(x_a, y_a) diag(1, f_i, f_i, f_i),  Graw(x, y) = [[-x, xy, -(1 + x^2), y], [-y, 1 + y^2, -xy, -x]]  (ba_pair_side
+//     with its zeros and its common factors written out: M x P = f Pz^-1 ... Pz cancels);
+//   * the ray's direction is R_i^T (x_a, y_a, 1) up to the factor Pz_i, so camera j sees it at P' = R_j R_i^T (x_a, y_a, 1) --
+//     (x_b, y_b) = (P'x, P'y) / P'z exactly as from Xn, and 1 / Pz_j = (1 / Pz_i)(1 / P'z);
+//   * MR_b = f_j Pz_j^-1 [R_j(0) - x_b R_j(2); R_j(1) - y_b R_j(2)] = f_j Pz_j^-1 [Rji(0) - x_b Rji(2); Rji(1) - y_b Rji(2)] R_i.
+// With Q_a = sqrt(w) Pz_i^-1 [Jr_a E diag(sqrt(w) a)] R_i^T (2 x 3, phase 1) an entry's contribution is
+//     T'_a MR_b^T G_b = (F_i B_i)^T { Graw_a^T [P'z^-1 Q_a (Rji(0:1) - (x_b, y_b) Rji(2))^T] Graw_b } f_j F_j
+// (F = diag(1, f, f, f), B = blockdiag(1, Jl) diag(s)): the braces are what a run sums -- 8 doubles of LDS per entry (64 bytes
+// instead of 120) and about the same ~90 FP64 operations -- and everything outside them is constant over a camera pair and is
+// applied to the pair's sum in phase 3.  Table 514 x 9 doubles = 37 KB: three workgroups per compute unit.
+// Same sums in a fixed order (bits independent of batch, launch shape, scene group: the tests that hold k_schur to that hold this
+// kernel); its blocks differ from k_schur's in the last bits (regrouped products).  PTZRay only (with or without annotations);
+// the other factor types and views beyond the LDS table keep k_schur.
+// TG: the table in global memory (d.Tbuf) for views beyond the LDS table, and several rounds of runs for views with more runs than
+// threads -- the same arithmetic in the same order (a scene keeps its bits in a batch that needs them).
+template <int TYPE, bool TG>
+__global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
+{
+  constexpr int THREADS = 256;
+  constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, CBS = Dims<TYPE>::CBS;
+  static_assert(Dims<TYPE>::FACTOR == 0 && NW == 4, "k_schur_f: PTZRay only");
+  constexpr int NU = NW * (NW + 1) / 2;
+  constexpr int TS = SCHUR_F_ROW;   // 8 doubles at an odd pitch
+  int ci, slot;
+  xcd_remap(ci, slot);
+  const int sc = scene_of_slot(d, slot);
+  if (sc < 0 || !d.active[sc]) return;
+  const SceneDev s = d.scene[sc];
+  if (ci >= s.n_cam) return;
+  const LmState& st = d.lm[sc];
+  const int hh = st.cur;
+  const double* U_ = d.U + (size_t)hh * d.lin_cams * NC * NC;
+  const double* gc_ = d.gc + (size_t)hh * d.lin_cams * NC;
+  const double* diagc_ = d.diag_c + (size_t)hh * d.lin_cams * NC;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  const int o0 = cp[ci], no = cp[ci + 1] - o0;
+  // ---- the gathers first (see k_schur): ray ids, then the rays' 128-byte records of the first PF trips
+  typedef double d16 __attribute__((ext_vector_type(16)));
+  auto load_rec = [&](int gj) {
+    const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
+    d16 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    return v;
+  };
+  auto oclamp = [&](int q) { return max(o0 + min(q, no - 1), 0); };
+  constexpr int PF = 3;
+  int gid[PF];
+  d16 rcs[PF];
+#pragma unroll
+  for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * THREADS)];
+#pragma unroll
+  for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
+  constexpr int DIAG_NE = NC * (NC + 1) / 2;
+  const int dt = (int)threadIdx.x - (THREADS - 64);
+  int dp = 0, dq = 0;
+  double dv = 0, dDc = 0;
+  if (dt >= 0 && dt < DIAG_NE) {
+    dp = (int)((sqrtf(8.0f * dt + 1.0f) - 1.0f) * 0.5f);
+    while ((dp + 1) * (dp + 2) / 2 <= dt) ++dp;
+    while (dp * (dp + 1) / 2 > dt) --dp;
+    dq = dt - dp * (dp + 1) / 2;
+    dv = U_[(size_t)(s.cam_off + ci) * NC * NC + dp * NC + dq];
+    if (dp == dq) dDc = diagc_[(size_t)(s.cam_off + ci) * NC + dp];
+  }
+  else if (dt >= DIAG_NE && dt < DIAG_NE + NC) dv = gc_[(size_t)(s.cam_off + ci) * NC + (dt - DIAG_NE)];
+  const int* cpair = d.cam_pair + s.cam_off + s.idx;
+  const int pr0 = cpair[ci], npr = cpair[ci + 1] - pr0;
+  constexpr int PS = (NW * NW) | 1;
+  const int ntl = d.chol.np / CHOL_NB;
+  double* strip = lds;                                         // [waves][NW + NU]
+  int* tord = reinterpret_cast<int*>(strip + (THREADS / 64) * (NW + NU));
+  unsigned short* eslot = reinterpret_cast<unsigned short*>(strip + (THREADS / 64) * (NW + NU) + (ntl + 2) / 2);
+  const int* crun = d.cam_run + s.cam_off + s.idx;
+  const int run0 = crun[ci], nrun = crun[ci + 1] - run0;
+  const uint2* runs = d.run_rec + s.run_off + run0;
+  const int* ppt = d.pair_ptr + s.pair_off + s.idx + pr0;
+  const int ent0 = npr > 0 ? ppt[0] : 0;
+  const int nent = npr > 0 ? ppt[npr] - ent0 : 0;
+  double* tab = reinterpret_cast<double*>(eslot + ((d.schur_ent_cap + 3) & ~3));  // the table [no][TS], later the run sums [THREADS][PS]
+  double* T = TG ? d.Tbuf + (size_t)o0 * TS : tab;
+  double* part = tab;
+  auto scol = [&](int c) { return tord[c / CHOL_NB] * CHOL_NB + c % CHOL_NB; };
+  const double* camtab = cur_camblk(d, st) + (size_t)s.cam_off * CBS;
+  const int* pcj = d.pair_cj + s.pair_off + pr0;
+  uint2 rr = make_uint2(0u, 0u);
+  const double* cbi = camtab + (size_t)ci * CBS;  // uniform: scalar loads
+  double Ri[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ri[k] = cbi[CB_R + k];
+  const double fi = cbi[CB_F];
+  double Rji[9];
+  // ---- phase 1
+  {
+    double Jli[9], sci[NW];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Jli[k] = cbi[CB_JL + k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sci[k] = cbi[CB_S + Dims<TYPE>::pos(k)];
+    double bsum[NW], D[NU];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bsum[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) D[k] = 0;
+    auto process = [&](const d16& rc, int q) {
+      const double e0 = rc[0], e1 = rc[1], e2 = rc[2], e3 = rc[3], e4 = rc[4], e5 = rc[5];
+      const double z0 = rc[6], z1 = rc[7], z2 = rc[8];
+      const double Xn[3] = {rc[9], rc[10], rc[11]};
+      const double al[3] = {rc[12], rc[13], rc[14]};
+      const double sw = rc[15];
+      const double Px = Ri[0] * Xn[0] + Ri[1] * Xn[1] + Ri[2] * Xn[2];
+      const double Py = Ri[3] * Xn[0] + Ri[4] * Xn[1] + Ri[5] * Xn[2];
+      const double Pz = Ri[6] * Xn[0] + Ri[7] * Xn[1] + Ri[8] * Xn[2];
+      const double iz = rcp_nr(Pz);
+      const double x = Px * iz, y = Py * iz, fiz = fi * iz;
+      // Jr = -MR diag(a), MR = fiz [R(0) - x R(2); R(1) - y R(2)]
+      double Jr[2][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Jr[0][k] = -(fiz * (Ri[k] - x * Ri[6 + k])) * al[k];
+        Jr[1][k] = -(fiz * (Ri[3 + k] - y * Ri[6 + k])) * al[k];
+      }
+      // camera columns: sqrt(w) Graw F_i blockdiag(1, Jl_i) diag(s_i)
+      const double xy = x * y, ox = fma(x, x, 1.0), oy = fma(y, y, 1.0);
+      const double g0[3] = {fi * xy, -(fi * ox), fi * y}, g1[3] = {fi * oy, -(fi * xy), -(fi * x)};
+      double Jc[2][NW];
+      Jc[0][0] = -x * (sw * sci[0]);
+      Jc[1][0] = -y * (sw * sci[0]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Jc[0][1 + k] = (g0[0] * Jli[k] + g0[1] * Jli[3 + k] + g0[2] * Jli[6 + k]) * (sw * sci[1 + k]);
+        Jc[1][1 + k] = (g1[0] * Jli[k] + g1[1] * Jli[3 + k] + g1[2] * Jli[6 + k]) * (sw * sci[1 + k]);
+      }
+      // Q = Jr E (2 x 3);  N = Q Jr^T;  S_ii -= Jc^T N Jc;  b_i -= Jc^T (Jr z)
+      double Q[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        Q[r][0] = Jr[r][0] * e0 + Jr[r][1] * e1 + Jr[r][2] * e3;
+        Q[r][1] = Jr[r][0] * e1 + Jr[r][1] * e2 + Jr[r][2] * e4;
+        Q[r][2] = Jr[r][0] * e3 + Jr[r][1] * e4 + Jr[r][2] * e5;
+      }
+      const double n00 = Q[0][0] * Jr[0][0] + Q[0][1] * Jr[0][1] + Q[0][2] * Jr[0][2];
+      const double n01 = Q[0][0] * Jr[1][0] + Q[0][1] * Jr[1][1] + Q[0][2] * Jr[1][2];
+      const double n11 = Q[1][0] * Jr[1][0] + Q[1][1] * Jr[1][1] + Q[1][2] * Jr[1][2];
+      const double jz0 = Jr[0][0] * z0 + Jr[0][1] * z1 + Jr[0][2] * z2;
+      const double jz1 = Jr[1][0] * z0 + Jr[1][1] * z1 + Jr[1][2] * z2;
+      int e = 0;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) {
+        bsum[p] += Jc[0][p] * jz0 + Jc[1][p] * jz1;
+        const double a0 = Jc[0][p] * n00 + Jc[1][p] * n01, a1 = Jc[0][p] * n01 + Jc[1][p] * n11;
+#pragma unroll
+        for (int qq = 0; qq <= p; ++qq) D[e++] += a0 * Jc[0][qq] + a1 * Jc[1][qq];
+      }
+      // the row: Q_a = sqrt(w) Pz^-1 [Q diag(sqrt(w) a)] R_i^T, and (x, y)
+      const double c0 = sw * iz * (sw * al[0]), c1 = sw * iz * (sw * al[1]), c2 = sw * iz * (sw * al[2]);
+      double* Tq = T + (size_t)q * TS;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double q0 = Q[r][0] * c0, q1 = Q[r][1] * c1, q2 = Q[r][2] * c2;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) Tq[3 * r + m] = q0 * Ri[3 * m] + q1 * Ri[3 * m + 1] + q2 * Ri[3 * m + 2];
+      }
+      Tq[6] = x; Tq[7] = y;
+    };
+    if ((int)threadIdx.x < nrun) rr = runs[threadIdx.x];
+    const int cjx = npr > 0 ? pcj[rr.y & 0xffffu] : 0;
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      const int q = (int)threadIdx.x + t * THREADS;
+      if (q < no) process(rcs[t], q);
+    }
+    for (int q = (int)threadIdx.x + PF * THREADS; q < no; q += THREADS) process(load_rec(d.cam_ray[o0 + q]), q);
+    {  // Rji = R_j R_i^T of this thread's run (on its way during the reductions and the barrier below)
+      const double* cbj = camtab + (size_t)cjx * CBS;
+      double Rj[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rji[3 * r + c] = Rj[3 * r] * Ri[3 * c] + Rj[3 * r + 1] * Ri[3 * c + 1] + Rj[3 * r + 2] * Ri[3 * c + 2];
+    }
+    int tord_v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int t = (int)threadIdx.x + u * THREADS; tord_v[u] = d.tperm ? d.tperm[(size_t)sc * ntl + min(t, ntl - 1)] : t; }
+    unsigned ent_v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ent_v[u] = d.ent[ent0 + max(min(u * THREADS + (int)threadIdx.x, nent - 1), 0)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NV = NW + NU;
+    constexpr int PAD = 16;
+    static_assert(NV <= PAD, "reduce-scatter width");
+    double v[PAD];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) v[k] = bsum[k];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) v[NW + k] = D[k];
+#pragma unroll
+    for (int k = NV; k < PAD; ++k) v[k] = 0.0;
+    int vidx = 0;
+    {
+      int off = 32;
+#pragma unroll
+      for (int h = PAD / 2; h >= 1; h >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+          const double keep = up ? v[i + h] : v[i];
+          const double send = up ? v[i] : v[i + h];
+          v[i] = keep + __shfl_xor(send, off, WAVE);
+        }
+        if (up) vidx += h;
+      }
+#pragma unroll
+      for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, WAVE);
+    }
+    constexpr int LOWMASK = 64 / PAD - 1;
+    if ((lane & LOWMASK) == 0 && vidx < NV) strip[wv * NV + vidx] = v[0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int t = (int)threadIdx.x + u * THREADS; if (t < ntl) tord[t] = tord_v[u]; }
+    for (int t = (int)threadIdx.x + 2 * THREADS; t < ntl; t += THREADS) tord[t] = d.tperm ? d.tperm[(size_t)sc * ntl + t] : t;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = u * THREADS + (int)threadIdx.x; if (e < nent) eslot[e] = (unsigned short)(ent_v[u] & 0xffffu); }
+    for (int e0 = 8 * THREADS; e0 < nent; e0 += 8 * THREADS) {
+      unsigned v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = d.ent[ent0 + min(e0 + u * THREADS + (int)threadIdx.x, nent - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * THREADS + (int)threadIdx.x; if (e < nent) eslot[e] = (unsigned short)(v8[u] & 0xffffu); }
+    }
+    __syncthreads();
+  }
+  const int np = d.chol.np;
+  double* A = d.chol.A + (size_t)sc * np * np;
+  auto schur_diag_finish = [&]() {
+    constexpr int NV = NW + NU;
+    auto ipos = [](int c) { return Dims<TYPE>::NC != Dims<TYPE>::NW ? (c == 0 ? 0 : (c == 1 ? -1 : c - 1)) : c; };
+    auto strip_sum = [&](int k) { double r = 0; for (int i = 0; i < THREADS / 64; ++i) r += strip[i * NV + k]; return r; };
+    if (dt >= 0 && dt < DIAG_NE) {
+      double v = dv;
+      if (dp == dq) {
+        const double Dd = sqrt(dDc / st.radius);
+        v += Dd * Dd;
+      }
+      const int ip = ipos(dp), iq = ipos(dq);
+      if (ip >= 0 && iq >= 0) v -= strip_sum(NW + ip * (ip + 1) / 2 + iq);
+      const int rp = scol(ci * NC + dp), rq = scol(ci * NC + dq);
+      A[(size_t)rp * np + rq] = v;
+      A[(size_t)rq * np + rp] = v;
+    }
+    else if (dt >= DIAG_NE && dt < DIAG_NE + NC) {
+      const int p = dt - DIAG_NE, ip = ipos(p);
+      double v = dv;
+      if (ip >= 0) v -= strip_sum(ip);
+      A[(size_t)s.n * np + scol(ci * NC + p)] = v;
+    }
+  };
+  // ---- phase 2: one run of entries per thread.  Views whose table is in LDS have at most THREADS runs: ONE round, after which
+  // the table is dead and its space takes the run sums; with the table in global memory the runs may need several rounds, and a
+  // pair that continues from the previous round adds to what that round stored.
+  const int* prun = d.pair_run + s.pair_off + s.idx + pr0;
+  for (int base = 0; base < nrun; base += THREADS) {
+    const int r = base + (int)threadIdx.x;
+    double acc[NW * NW];
+#pragma unroll
+    for (int k = 0; k < NW * NW; ++k) acc[k] = 0;
+    if (r < nrun) {
+      if (base > 0) {  // (a later round: the first round's run and camera were fetched ahead)
+        rr = runs[r];
+        const double* cbj = camtab + (size_t)pcj[rr.y & 0xffffu] * CBS;
+        double Rj[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rj[k] = cbj[CB_R + k];
+#pragma unroll
+        for (int rw = 0; rw < 3; ++rw)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Rji[3 * rw + c] = Rj[3 * rw] * Ri[3 * c] + Rj[3 * rw + 1] * Ri[3 * c + 1] + Rj[3 * rw + 2] * Ri[3 * c + 2];
+      }
+      const int cnt = (int)(rr.y >> 16);
+      const unsigned short* es = eslot + ((int)rr.x - ent0);
+      double Tn[8];
+      {
+        const double* Ta = T + (size_t)es[0] * TS;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Tn[k] = Ta[k];
+      }
+      for (int k = 0; k < cnt; ++k) {
+        double Tc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Tc[i] = Tn[i];
+        {
+          const double* Ta = T + (size_t)es[min(k + 1, cnt - 1)] * TS;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) Tn[i] = Ta[i];
+        }
+        const double xa = Tc[6], ya = Tc[7];
+        const double px = fma(Rji[0], xa, fma(Rji[1], ya, Rji[2]));
+        const double py = fma(Rji[3], xa, fma(Rji[4], ya, Rji[5]));
+        const double pz = fma(Rji[6], xa, fma(Rji[7], ya, Rji[8]));
+        const double iz = rcp_nr(pz);
+        const double xb = px * iz, yb = py * iz;
+        double K[2][2];
+        {
+          const double m00 = fma(-xb, Rji[6], Rji[0]), m01 = fma(-xb, Rji[7], Rji[1]), m02 = fma(-xb, Rji[8], Rji[2]);
+          const double m10 = fma(-yb, Rji[6], Rji[3]), m11 = fma(-yb, Rji[7], Rji[4]), m12 = fma(-yb, Rji[8], Rji[5]);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            K[q][0] = (Tc[3 * q] * m00 + Tc[3 * q + 1] * m01 + Tc[3 * q + 2] * m02) * iz;
+            K[q][1] = (Tc[3 * q] * m10 + Tc[3 * q + 1] * m11 + Tc[3 * q + 2] * m12) * iz;
+          }
+        }
+        const double xyb = xb * yb, oxb = fma(xb, xb, 1.0), oyb = fma(yb, yb, 1.0);
+        const double Gb0[4] = {-xb, xyb, -oxb, yb}, Gb1[4] = {-yb, oyb, -xyb, -xb};
+        double KG[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          KG[0][q] = K[0][0] * Gb0[q] + K[0][1] * Gb1[q];
+          KG[1][q] = K[1][0] * Gb0[q] + K[1][1] * Gb1[q];
+        }
+        const double xya = xa * ya, oxa = fma(xa, xa, 1.0), oya = fma(ya, ya, 1.0);
+        const double Ga0[4] = {-xa, xya, -oxa, ya}, Ga1[4] = {-ya, oya, -xya, -xa};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p * 4 + q] = fma(Ga1[p], KG[1][q], fma(Ga0[p], KG[0][q], acc[p * 4 + q]));
+      }
+    }
+    // ---- phase 3: run sums -> pair sums -> (F_i B_i)^T . f_j F_j B_j -> the reduced system
+    if (!TG) __syncthreads();  // every thread is done with the table
+    if (r < nrun) {
+#pragma unroll
+      for (int k = 0; k < NW * NW; ++k) part[threadIdx.x * PS + k] = acc[k];
+    }
+    __syncthreads();
+    double pJl[9], pS[NW], pf = 0;
+    const bool pre = (int)threadIdx.x < npr * NW;
+    {
+      const double* cbp = camtab + (size_t)(pre ? pcj[(int)threadIdx.x / NW] : 0) * CBS;  // (a camera without pairs must not read pcj[0]: it may lie behind the array)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) pJl[k] = cbp[CB_JL + k];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) pS[k] = cbp[CB_S + Dims<TYPE>::pos(k)];
+      pf = cbp[CB_F];
+    }
+    for (int it = threadIdx.x; it < npr * NW * NW; it += THREADS) {
+      const int pl = it / (NW * NW), el = it % (NW * NW);
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, THREADS);
+      if (ra >= rb) continue;  // (the pair has no run in this round)
+      double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+      int q = ra;
+      for (; q + 3 < rb; q += 4) {
+        v0 += part[q * PS + el]; v1 += part[(q + 1) * PS + el]; v2 += part[(q + 2) * PS + el]; v3 += part[(q + 3) * PS + el];
+      }
+      for (; q < rb; ++q) v0 += part[q * PS + el];
+      part[ra * PS + el] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    // thread = (pair, row p of the block): rows through (F_i B_i)^T, columns through f_j F_j B_j, every element stored once
+    for (int it = threadIdx.x; it < npr * NW; it += THREADS) {
+      const int pl = it / NW, p = it % NW;
+      const int ra = max(prun[pl] - run0 - base, 0), rb = min(prun[pl + 1] - run0 - base, THREADS);
+      if (ra >= rb) continue;
+      const bool first = prun[pl] - run0 >= base;  // else the pair continues from the previous round
+      const int cj = pcj[pl];
+      if (it != (int)threadIdx.x) {
+        const double* cbj = camtab + (size_t)cj * CBS;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pJl[k] = cbj[CB_JL + k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) pS[k] = cbj[CB_S + Dims<TYPE>::pos(k)];
+        pf = cbj[CB_F];
+      }
+      const double* blk = part + ra * PS;
+      double row[NW];
+      if (p == 0) {
+        const double sl = cbi[CB_S + Dims<TYPE>::pos(0)];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) row[q] = blk[q] * sl;
+      }
+      else {
+        const int k = p - 1;
+        const double sl = fi * cbi[CB_S + Dims<TYPE>::pos(p)];
+        const double l0 = cbi[CB_JL + k], l1 = cbi[CB_JL + 3 + k], l2 = cbi[CB_JL + 6 + k];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) row[q] = (l0 * blk[NW + q] + l1 * blk[2 * NW + q] + l2 * blk[3 * NW + q]) * sl;
+      }
+      const double a0 = row[1], a1 = row[2], a2 = row[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) row[1 + k] = (a0 * pJl[k] + a1 * pJl[3 + k] + a2 * pJl[6 + k]) * pf;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const double v = row[q] * (pf * pS[q]);
+        double& dst = sys_at(A, np, scol(ci * NC + Dims<TYPE>::pos(p)), scol(cj * NC + Dims<TYPE>::pos(q)));
+        dst = first ? v : dst + v;
+      }
+    }
+    if (base + THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
+  }
+  schur_diag_finish();
 }
 
 // ---- schur_3d: rows of the T_l_w block in the reduced system (it is not coupled to the rays) ---------------------
