@@ -1870,7 +1870,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   TRY(b->alloc(&d.V, 2 * d.V_stride));
   TRY(b->alloc(&d.gr, 2 * d.gr_stride));
   TRY(b->alloc(&d.diag_r, (size_t)b->total_ray * 3));
-  TRY(b->alloc(&d.E, (size_t)b->total_ray * EZS));  // (E, z) records
+  TRY(b->alloc(&d.E, (size_t)b->total_ray * EZS));  // the rays' records, as EZS / 2 planes of 16-byte pieces (e_piece)
+  d.e_stride = (size_t)b->total_ray;
   d.shared = any_shared ? 1 : 0;
   if (any_shared) {
     TRY(upload(b, h_grpptr, &d.grp_ptr));

@@ -110,6 +110,7 @@ struct Dev {
   double* V;         // [total_ray][6]
   double* gr;        // [total_ray][3]
   double* diag_r;    // [total_ray][3]
+  size_t e_stride;   // rays of the batch: E is stored as EZS / 2 PLANES of 16-byte pieces, piece p of ray gj at ((double2*)E)[p * e_stride + gj]
   double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), then what k_schur needs to
                      // rebuild an observation's Jacobians (Xn, the ray-side factors, sqrt(w)) -- ONE record, one gather per observation
   double* W;         // [total_obs][Dims::WS] rows W_a = Jc^T Jr (NW x 3), camera-major
@@ -190,6 +191,14 @@ __device__ __forceinline__ int sys_col(const Dev& d, int sc, int c)
 // element (r, c) of the symmetric system, r and c already mapped, in its lower-triangular storage
 __device__ __forceinline__ double& sys_at(double* A, int np, int r, int c) { return r >= c ? A[(size_t)r * np + c] : A[(size_t)c * np + r]; }
 
+
+// The rays' records {E (6), z (3), Xn (3), a (3), sqrt(w)} as eight planes of 16-byte pieces (round 5; one 128-byte record per
+// ray before): the ray-centric kernels (k_ray_prep's stores, k_eval's reads of E) become unit-stride -- ray preparation 20.7 ->
+// 17.2 ms, evaluation 41 -> 38.7 ms per C4 solve -- and a camera's rays are dense clusters of the internal ray order (by track
+// length, then first camera), so the 64 lanes of k_schur's gather touch ~21 lines per plane.  (k_schur itself does not gain: its
+// 24 record loads per lane take 5-9 us to ISSUE on a loaded chip with either layout -- the gather runs at what a compute unit
+// can keep in flight, NOTES_r05.)
+__device__ __forceinline__ double2* e_piece(const Dev& d, int p, size_t gj) { return reinterpret_cast<double2*>(d.E) + (size_t)p * d.e_stride + gj; }
 
 __device__ __forceinline__ const double* cur_cam(const Dev& d, const SceneDev& s, const LmState& st)
 {
@@ -1155,9 +1164,8 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
   const double rec[EZS] = {E[0], E[1], E[2], E[3], E[4], E[5],
                            E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2,
                            Xn[0], Xn[1], Xn[2], swn * rb.y, swn * rc.x, swn * rc.y, sw};
-  double2* out = reinterpret_cast<double2*>(d.E + (size_t)gj * EZS);
 #pragma unroll
-  for (int k = 0; k < EZS / 2; ++k) out[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+  for (int k = 0; k < EZS / 2; ++k) *e_piece(d, k, gj) = make_double2(rec[2 * k], rec[2 * k + 1]);
 }
 
 // ---- schur: one workgroup per camera ci -------------------------------------------------------------------
@@ -1221,9 +1229,9 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
   for (int k = 0; k < NU; ++k) D[k] = 0;
   for (int q = threadIdx.x; q < no; q += SCHUR_THREADS) {
     const int gj = d.cam_ray[o0 + q];  // global ray id of the q-th observation of this camera
-    const double* E = d.E + (size_t)gj * EZS;  // one 80-byte record per ray: E (6), z (3)
-    const double z0 = E[6], z1 = E[7], z2 = E[8];
-    const double e0 = E[0], e1 = E[1], e2 = E[2], e3 = E[3], e4 = E[4], e5 = E[5];
+    const double2 q0 = *e_piece(d, 0, gj), q1 = *e_piece(d, 1, gj), q2 = *e_piece(d, 2, gj), q3 = *e_piece(d, 3, gj), q4 = *e_piece(d, 4, gj);  // E (6), z (3)
+    const double z0 = q3.x, z1 = q3.y, z2 = q4.x;
+    const double e0 = q0.x, e1 = q0.y, e2 = q1.x, e3 = q1.y, e4 = q2.x, e5 = q2.y;
     double w[NT];
     const double* Wa = d.W + (size_t)(o0 + q) * Dims<TYPE>::WS;  // camera-major rows: sequential stream
 #pragma unroll
@@ -1452,10 +1460,9 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
   // data unused.
   typedef double d16 __attribute__((ext_vector_type(16)));
   auto load_rec = [&](int gj) {
-    const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
     d16 v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    for (int k = 0; k < 8; ++k) { const double2 t = *e_piece(d, k, gj); v[2 * k] = t.x; v[2 * k + 1] = t.y; }
     return v;
   };
   // (a camera WITHOUT observations is legal -- a candidate image none of whose tracks survived: then o0 may equal the batch's
@@ -1849,23 +1856,38 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
   const int o0 = cp[ci], no = cp[ci + 1] - o0;
+#ifdef PTZ_SCHUR_STAMPS
+  const bool stamp_on = slot == 0 && ci == (s.n_cam * 3) / 4 && threadIdx.x == 0;
+  long long sc_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  SC_STAMP(0);
   // ---- the gathers first (see k_schur): ray ids, then the rays' 128-byte records of the first PF trips
   typedef double d16 __attribute__((ext_vector_type(16)));
   auto load_rec = [&](int gj) {
-    const double2* rec = reinterpret_cast<const double2*>(d.E + (size_t)gj * EZS);
     d16 v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    for (int k = 0; k < 8; ++k) { const double2 t = *e_piece(d, k, gj); v[2 * k] = t.x; v[2 * k + 1] = t.y; }
     return v;
   };
   auto oclamp = [&](int q) { return max(o0 + min(q, no - 1), 0); };
   constexpr int PF = 3;
   int gid[PF];
   d16 rcs[PF];
+#ifdef PTZ_SCHUR_STAMPS  // (probe builds: the waits make the stamps mean "arrived"; they cost nothing the loads do not wait for anyway)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  SC_STAMP(13);
+#endif
 #pragma unroll
   for (int t = 0; t < PF; ++t) gid[t] = d.cam_ray[oclamp((int)threadIdx.x + t * THREADS)];
+#ifdef PTZ_SCHUR_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SC_STAMP(14);
+#endif
 #pragma unroll
   for (int t = 0; t < PF; ++t) rcs[t] = load_rec(gid[t]);
+#ifdef PTZ_SCHUR_STAMPS
+  SC_STAMP(15);
+#endif
   constexpr int DIAG_NE = NC * (NC + 1) / 2;
   const int dt = (int)threadIdx.x - (THREADS - 64);
   int dp = 0, dq = 0;
@@ -1980,10 +2002,12 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
     };
     if ((int)threadIdx.x < nrun) rr = runs[threadIdx.x];
     const int cjx = npr > 0 ? pcj[rr.y & 0xffffu] : 0;
+    SC_STAMP(8);
 #pragma unroll
     for (int t = 0; t < PF; ++t) {
       const int q = (int)threadIdx.x + t * THREADS;
       if (q < no) process(rcs[t], q);
+      SC_STAMP(9 + t);
     }
     for (int q = (int)threadIdx.x + PF * THREADS; q < no; q += THREADS) process(load_rec(d.cam_ray[o0 + q]), q);
     {  // Rji = R_j R_i^T of this thread's run (on its way during the reductions and the barrier below)
@@ -2044,8 +2068,10 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int e = e0 + u * THREADS + (int)threadIdx.x; if (e < nent) eslot[e] = (unsigned short)(v8[u] & 0xffffu); }
     }
+    SC_STAMP(12);
     __syncthreads();
   }
+  SC_STAMP(1);
   const int np = d.chol.np;
   double* A = d.chol.A + (size_t)sc * np * np;
   auto schur_diag_finish = [&]() {
@@ -2075,7 +2101,8 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
   // the table is dead and its space takes the run sums; with the table in global memory the runs may need several rounds, and a
   // pair that continues from the previous round adds to what that round stored.
   const int* prun = d.pair_run + s.pair_off + s.idx + pr0;
-  for (int base = 0; base < nrun; base += THREADS) {
+  SC_STAMP(2);
+  for (int base = 0; base < (TG ? nrun : min(nrun, 1)); base += THREADS) {
     const int r = base + (int)threadIdx.x;
     double acc[NW * NW];
 #pragma unroll
@@ -2142,7 +2169,9 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
       }
     }
     // ---- phase 3: run sums -> pair sums -> (F_i B_i)^T . f_j F_j B_j -> the reduced system
+    SC_STAMP(3);
     if (!TG) __syncthreads();  // every thread is done with the table
+    SC_STAMP(4);
     if (r < nrun) {
 #pragma unroll
       for (int k = 0; k < NW * NW; ++k) part[threadIdx.x * PS + k] = acc[k];
@@ -2171,6 +2200,7 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
       part[ra * PS + el] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
+    SC_STAMP(5);
     // thread = (pair, row p of the block): rows through (F_i B_i)^T, columns through f_j F_j B_j, every element stored once
     for (int it = threadIdx.x; it < npr * NW; it += THREADS) {
       const int pl = it / NW, p = it % NW;
@@ -2213,6 +2243,13 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
     if (base + THREADS < nrun) __syncthreads();  // the next round's sums go to the same rows
   }
   schur_diag_finish();
+#ifdef PTZ_SCHUR_STAMPS
+  SC_STAMP(6);
+  if (stamp_on)
+    printf("k_schur_f cam %d: obs %d pairs %d runs %d | x10 ns: scalars %lld ids %lld issue %lld | phase1 %lld (issue+stage %lld, trips %lld %lld %lld, reduce %lld, barrier %lld), diag %lld, runs(thread 0) %lld, wait %lld, sums %lld, store %lld\n", ci, no, npr, nrun,
+           sc_t[13] - sc_t[0], sc_t[14] - sc_t[13], sc_t[15] - sc_t[14], sc_t[1] - sc_t[0], sc_t[8] - sc_t[0], sc_t[9] - sc_t[8], sc_t[10] - sc_t[9], sc_t[11] - sc_t[10], sc_t[12] - sc_t[11], sc_t[1] - sc_t[12],
+           sc_t[2] - sc_t[1], sc_t[3] - sc_t[2], sc_t[4] - sc_t[3], sc_t[5] - sc_t[4], sc_t[6] - sc_t[5]);
+#endif
 }
 
 // ---- schur_3d: rows of the T_l_w block in the reduced system (it is not coupled to the rays) ---------------------
@@ -2514,7 +2551,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
       t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
     });
     EV_STAMP(4);
-    const double* E = d.E + (size_t)gj * EZS;
+    const double2 E01 = *e_piece(d, 0, gj), E23 = *e_piece(d, 1, gj), E45 = *e_piece(d, 2, gj);
+    const double E[6] = {E01.x, E01.y, E23.x, E23.y, E45.x, E45.y};
     // step = -y_r (Ceres solves J y = r and negates)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
     Xn[0] = Xr[0] + ds[0] * sr[0]; Xn[1] = Xr[1] + ds[1] * sr[1]; Xn[2] = Xr[2] + ds[2] * sr[2];
