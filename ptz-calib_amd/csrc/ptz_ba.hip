@@ -2123,6 +2123,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   b->schur_f = type == PTZ_BA_PTZRay && !b->schur_w;
   if (const char* e = getenv("PTZ_BA_SCHUR_F")) b->schur_f = b->schur_f && atoi(e) != 0;
   const int frow = b->schur_f ? SCHUR_F_ROW : 0;
+  b->d.e_fold = b->schur_f ? 1 : 0;
+  for (auto& dgp : b->dg) dgp.e_fold = b->d.e_fold;
   b->schur_tg = schur_lds_bytes(b->max_cam_obs, NC, b->d.chol.np, b->schur_w, schur_threads_of(type), NW2d, b->max_cam_ent, frow) > 160 * 1024 ||
                 (!b->schur_w && b->max_cam_run > schur_threads_of(type));
   if (!b->schur_w && schur_lds_bytes(0, NC, b->d.chol.np, false, schur_threads_of(type), NW2d, b->max_cam_ent, frow) > 160 * 1024) {

@@ -13,9 +13,9 @@ namespace {
 constexpr int RAY_BLOCK = 1024;  // most rays per workgroup in the ray-centric kernels (Dev::ray_block is the batch's actual value:
                                  // a few scenes use small workgroups so that one rig's 13 k rays spread over a hundred compute units)
 constexpr int SCHUR_F_ROW = 9;     // doubles per observation in k_schur_f's LDS table: 8, at an odd pitch
-constexpr int EZS = 16;           // doubles per ray in the record k_schur gathers once per observation: E (6), z = E g_r (3), the
-                                  // functor's point Xn (3), a = sqrt(w) |X|^-1 s_r (3), sqrt(w) -- 128 bytes, one aligned line,
-                                  // written whole by k_ray_prep every pass
+constexpr int EZS = 18;           // doubles per ray in the record k_schur gathers once per observation: E (6), z = E g_r (3), the
+                                  // functor's point Xn (3), a = sqrt(w) |X|^-1 s_r (3), sqrt(w) -- eight 16-byte pieces (e_piece) written by k_ray_prep every
+                                  // pass; batches of k_schur_f (Dev::e_fold) carry {E, z'', Xn, E''} in nine pieces instead
 // LDS / global stride of a camera block and of a candidate block: Dims<TYPE>::CBS (35 doubles: odd -> no same-field bank
 // conflicts; 41 with the displacement block) and Dims<TYPE>::CDS (19; 41)
 // W row stride: see Dims<TYPE>::WS
@@ -110,6 +110,8 @@ struct Dev {
   double* V;         // [total_ray][6]
   double* gr;        // [total_ray][3]
   double* diag_r;    // [total_ray][3]
+  int e_fold;        // 1 (PTZRay batches of k_schur_f): pieces 3..8 hold the PRE-SCALED record {z'' = c z, Xn, E'' = diag(c) E diag(c)}, c = sqrt(w) a: six
+                     // pieces per observation to gather instead of eight (k_ray_prep); pieces 0..2 stay the plain E of k_eval
   size_t e_stride;   // rays of the batch: E is stored as EZS / 2 PLANES of 16-byte pieces, piece p of ray gj at ((double2*)E)[p * e_stride + gj]
   double* E;         // [total_ray][EZS] per ray: E = (V + D^2)^-1 (6 unique entries), z = E g_r (3), then what k_schur needs to
                      // rebuild an observation's Jacobians (Xn, the ray-side factors, sqrt(w)) -- ONE record, one gather per observation
@@ -1161,11 +1163,23 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_ray_prep(Dev d, int n_ray_blocks)
   double Xn[3], inv_n;
   ba_ray_point<Dims<TYPE>::FACTOR>(Xray, Xn, inv_n);
   const double sw = sqrt(rd.x), swn = sw * inv_n;
-  const double rec[EZS] = {E[0], E[1], E[2], E[3], E[4], E[5],
-                           E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2,
-                           Xn[0], Xn[1], Xn[2], swn * rb.y, swn * rc.x, swn * rc.y, sw};
+  const double z[3] = {E[0] * g0 + E[1] * g1 + E[3] * g2, E[1] * g0 + E[2] * g1 + E[4] * g2, E[3] * g0 + E[4] * g1 + E[5] * g2};
+  const double al[3] = {swn * rb.y, swn * rc.x, swn * rc.y};
+  if (Dims<TYPE>::FACTOR == 0 && d.e_fold) {
+    // k_schur_f's record: every use of (E, z) there carries the factors c_k = sqrt(w) a_k of the ray -- Jr = Jr0 diag(a), Jc = sqrt(w) Jc0
+    // -- so they are folded in here, once per ray instead of once per observation, and a and sqrt(w) need not travel
+    const double c0 = sw * al[0], c1 = sw * al[1], c2 = sw * al[2];
+    const double rec[18] = {E[0], E[1], E[2], E[3], E[4], E[5],
+                            c0 * z[0], c1 * z[1], c2 * z[2], Xn[0], Xn[1], Xn[2],
+                            c0 * E[0] * c0, c0 * E[1] * c1, c1 * E[2] * c1, c0 * E[3] * c2, c1 * E[4] * c2, c2 * E[5] * c2};
 #pragma unroll
-  for (int k = 0; k < EZS / 2; ++k) *e_piece(d, k, gj) = make_double2(rec[2 * k], rec[2 * k + 1]);
+    for (int k = 0; k < 9; ++k) *e_piece(d, k, gj) = make_double2(rec[2 * k], rec[2 * k + 1]);
+  }
+  else {
+    const double rec[16] = {E[0], E[1], E[2], E[3], E[4], E[5], z[0], z[1], z[2], Xn[0], Xn[1], Xn[2], al[0], al[1], al[2], sw};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *e_piece(d, k, gj) = make_double2(rec[2 * k], rec[2 * k + 1]);
+  }
 }
 
 // ---- schur: one workgroup per camera ci -------------------------------------------------------------------
@@ -1824,7 +1838,8 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
 //   * the ray's direction is R_i^T (x_a, y_a, 1) up to the factor Pz_i, so camera j sees it at P' = R_j R_i^T (x_a, y_a, 1) --
 //     (x_b, y_b) = (P'x, P'y) / P'z exactly as from Xn, and 1 / Pz_j = (1 / Pz_i)(1 / P'z);
 //   * MR_b = f_j Pz_j^-1 [R_j(0) - x_b R_j(2); R_j(1) - y_b R_j(2)] = f_j Pz_j^-1 [Rji(0) - x_b Rji(2); Rji(1) - y_b Rji(2)] R_i.
-// With Q_a = sqrt(w) Pz_i^-1 [Jr_a E diag(sqrt(w) a)] R_i^T (2 x 3, phase 1) an entry's contribution is
+// With Q_a = sqrt(w) Pz_i^-1 [Jr_a E diag(sqrt(w) a)] R_i^T = Pz_i^-1 [Jr0_a E''] R_i^T (2 x 3, phase 1; E'' = diag(c) E diag(c), c = sqrt(w) a,
+// comes pre-scaled from k_ray_prep, Dev::e_fold: 96 bytes per observation to gather instead of 128) an entry's contribution is
 //     T'_a MR_b^T G_b = (F_i B_i)^T { Graw_a^T [P'z^-1 Q_a (Rji(0:1) - (x_b, y_b) Rji(2))^T] Graw_b } f_j F_j
 // (F = diag(1, f, f, f), B = blockdiag(1, Jl) diag(s)): the braces are what a run sums -- 8 doubles of LDS per entry (64 bytes
 // instead of 120) and about the same ~90 FP64 operations -- and everything outside them is constant over a camera pair and is
@@ -1862,17 +1877,17 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
 #endif
   SC_STAMP(0);
   // ---- the gathers first (see k_schur): ray ids, then the rays' 128-byte records of the first PF trips
-  typedef double d16 __attribute__((ext_vector_type(16)));
+  struct Rec { double v[12]; };  // {z'' (3), Xn (3), E'' (6)}: pieces 3..8 of the ray (Dev::e_fold)
   auto load_rec = [&](int gj) {
-    d16 v;
+    Rec r;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const double2 t = *e_piece(d, k, gj); v[2 * k] = t.x; v[2 * k + 1] = t.y; }
-    return v;
+    for (int k = 0; k < 6; ++k) { const double2 t = *e_piece(d, 3 + k, gj); r.v[2 * k] = t.x; r.v[2 * k + 1] = t.y; }
+    return r;
   };
   auto oclamp = [&](int q) { return max(o0 + min(q, no - 1), 0); };
   constexpr int PF = 3;
   int gid[PF];
-  d16 rcs[PF];
+  Rec rcs[PF];
 #ifdef PTZ_SCHUR_STAMPS  // (probe builds: the waits make the stamps mean "arrived"; they cost nothing the loads do not wait for anyway)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   SC_STAMP(13);
@@ -1939,34 +1954,32 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
     for (int k = 0; k < NW; ++k) bsum[k] = 0;
 #pragma unroll
     for (int k = 0; k < NU; ++k) D[k] = 0;
-    auto process = [&](const d16& rc, int q) {
-      const double e0 = rc[0], e1 = rc[1], e2 = rc[2], e3 = rc[3], e4 = rc[4], e5 = rc[5];
-      const double z0 = rc[6], z1 = rc[7], z2 = rc[8];
-      const double Xn[3] = {rc[9], rc[10], rc[11]};
-      const double al[3] = {rc[12], rc[13], rc[14]};
-      const double sw = rc[15];
+    auto process = [&](const Rec& rc, int q) {
+      const double z0 = rc.v[0], z1 = rc.v[1], z2 = rc.v[2];
+      const double Xn[3] = {rc.v[3], rc.v[4], rc.v[5]};
+      const double e0 = rc.v[6], e1 = rc.v[7], e2 = rc.v[8], e3 = rc.v[9], e4 = rc.v[10], e5 = rc.v[11];
       const double Px = Ri[0] * Xn[0] + Ri[1] * Xn[1] + Ri[2] * Xn[2];
       const double Py = Ri[3] * Xn[0] + Ri[4] * Xn[1] + Ri[5] * Xn[2];
       const double Pz = Ri[6] * Xn[0] + Ri[7] * Xn[1] + Ri[8] * Xn[2];
       const double iz = rcp_nr(Pz);
       const double x = Px * iz, y = Py * iz, fiz = fi * iz;
-      // Jr = -MR diag(a), MR = fiz [R(0) - x R(2); R(1) - y R(2)]
+      // Jr0 = -MR, MR = fiz [R(0) - x R(2); R(1) - y R(2)]   (the ray-side factors a live in E'', z'')
       double Jr[2][3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        Jr[0][k] = -(fiz * (Ri[k] - x * Ri[6 + k])) * al[k];
-        Jr[1][k] = -(fiz * (Ri[3 + k] - y * Ri[6 + k])) * al[k];
+        Jr[0][k] = -(fiz * (Ri[k] - x * Ri[6 + k]));
+        Jr[1][k] = -(fiz * (Ri[3 + k] - y * Ri[6 + k]));
       }
-      // camera columns: sqrt(w) Graw F_i blockdiag(1, Jl_i) diag(s_i)
+      // camera columns Jc0 = Graw F_i blockdiag(1, Jl_i) diag(s_i)   (sqrt(w) lives in E'', z'')
       const double xy = x * y, ox = fma(x, x, 1.0), oy = fma(y, y, 1.0);
       const double g0[3] = {fi * xy, -(fi * ox), fi * y}, g1[3] = {fi * oy, -(fi * xy), -(fi * x)};
       double Jc[2][NW];
-      Jc[0][0] = -x * (sw * sci[0]);
-      Jc[1][0] = -y * (sw * sci[0]);
+      Jc[0][0] = -x * sci[0];
+      Jc[1][0] = -y * sci[0];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        Jc[0][1 + k] = (g0[0] * Jli[k] + g0[1] * Jli[3 + k] + g0[2] * Jli[6 + k]) * (sw * sci[1 + k]);
-        Jc[1][1 + k] = (g1[0] * Jli[k] + g1[1] * Jli[3 + k] + g1[2] * Jli[6 + k]) * (sw * sci[1 + k]);
+        Jc[0][1 + k] = (g0[0] * Jli[k] + g0[1] * Jli[3 + k] + g0[2] * Jli[6 + k]) * sci[1 + k];
+        Jc[1][1 + k] = (g1[0] * Jli[k] + g1[1] * Jli[3 + k] + g1[2] * Jli[6 + k]) * sci[1 + k];
       }
       // Q = Jr E (2 x 3);  N = Q Jr^T;  S_ii -= Jc^T N Jc;  b_i -= Jc^T (Jr z)
       double Q[2][3];
@@ -1989,12 +2002,11 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
 #pragma unroll
         for (int qq = 0; qq <= p; ++qq) D[e++] += a0 * Jc[0][qq] + a1 * Jc[1][qq];
       }
-      // the row: Q_a = sqrt(w) Pz^-1 [Q diag(sqrt(w) a)] R_i^T, and (x, y)
-      const double c0 = sw * iz * (sw * al[0]), c1 = sw * iz * (sw * al[1]), c2 = sw * iz * (sw * al[2]);
+      // the row: Q_a = Pz^-1 [Jr0 E''] R_i^T, and (x, y)
       double* Tq = T + (size_t)q * TS;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const double q0 = Q[r][0] * c0, q1 = Q[r][1] * c1, q2 = Q[r][2] * c2;
+        const double q0 = Q[r][0] * iz, q1 = Q[r][1] * iz, q2 = Q[r][2] * iz;
 #pragma unroll
         for (int m = 0; m < 3; ++m) Tq[3 * r + m] = q0 * Ri[3 * m] + q1 * Ri[3 * m + 1] + q2 * Ri[3 * m + 2];
       }
