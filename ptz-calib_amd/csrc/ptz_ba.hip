@@ -885,6 +885,7 @@ struct ptz_rig {
   const int* d_trk_img = nullptr;
   const float2* d_trk_uv = nullptr;
   int64_t ent_bound = 0;           // camera-pair entries of the whole rig: sum over the tracks of L (L - 1) / 2
+  int max_track_len = 0;           // views of the rig's longest track: bounds the length field of a view batch's sort key (ptz_ba_batch_create_views)
   std::vector<int> img_obs, img_ent;  // per image: its views, and its entries as the HIGHER camera of a pair
   std::vector<void*> allocs;
 };
@@ -1561,8 +1562,11 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       for (int c = 0; c < v.n_cam; ++c) { h_map[v.map_off + views[i].cam_image[c]] = c; h_camimg.push_back(views[i].cam_image[c]); }
       trk_total += (size_t)rg->n_track;
       max_trk = std::max(max_trk, rg->n_track);
-      // the sort key of the internal ray order holds (longest - length) * cameras + first camera in 22 bits, the track in 24
-      if (rg->n_track >= (1 << 24) || (int64_t)(rg->n_view / std::max(1, rg->n_track) + 64) * v.n_cam >= (1 << 22)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+      // the sort key of the internal ray order holds (longest - length) * cameras + first camera in 22 bits, the track in 24.  What
+      // k_view_keys puts there is below (the view's longest candidate track) * cameras, and a candidate track is no longer than the
+      // rig's longest track or the number of candidate images -- NOT the rig's mean length: one long track in a wide view would
+      // otherwise spill into the bits of the view number, and the batch-wide sort would silently be a different order.
+      if (rg->n_track >= (1 << 24) || (int64_t)std::min(rg->max_track_len, v.n_cam) * v.n_cam + v.n_cam >= (1 << 22)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
     }
     const ViewDev* dviews_c = nullptr;
     const int *d_map = nullptr, *d_camimg = nullptr, *d_chunkoff = nullptr;
@@ -2468,6 +2472,7 @@ int32_t ptz_rig_create(int32_t n_img, int32_t n_track, const int64_t* trk_ptr, c
     const int64_t L = trk_ptr[t + 1] - trk_ptr[t];
     if (L <= 0) { delete r; return PTZ_EINVAL; }
     r->ent_bound += L * (L - 1) / 2;
+    r->max_track_len = (int)std::max<int64_t>(r->max_track_len, L);
     for (int64_t e = trk_ptr[t]; e < trk_ptr[t + 1]; ++e) {
       const int im = trk_img[e];
       if (im < 0 || im >= n_img || (e > trk_ptr[t] && im <= trk_img[e - 1])) { delete r; return PTZ_EINVAL; }  // images ascend inside a track

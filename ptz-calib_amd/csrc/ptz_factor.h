@@ -41,8 +41,17 @@ constexpr int CB_R = 0, CB_F = 9, CB_CX = 10, CB_CY = 11, CB_FY = 12, CB_K = 13,
 constexpr double kDblEps = 2.220446049250313e-16;
 
 // 1 / d for the throughput kernels: hardware seed + two Newton steps (5 instructions; the IEEE division is 12).  Within an ulp
-// or so of the quotient, not correctly rounded: used where the result feeds products that are summed anyway, never where the
-// reference's own arithmetic is reproduced bit for bit (residuals).  The host harness divides.
+// or so of the quotient, not correctly rounded.  Where it is used, exactly:
+//   * Jacobian entries and the factored forms of k_schur (products that are summed anyway): always;
+//   * the RESIDUALS of the bundle-adjustment functors on the device: as a * rcp_nr(z) (PTZ_PDIV below) -- an ulp or so from the
+//     reference's quotient; the parity tests hold costs to 1e-12 and parameters to 1e-6;
+//   * the residuals of the single-view LM (krt_eval), whose final cost feeds KRTOptimizer::CheckResults' accept test
+//     (krt_optimizer.cc:504-533): as PTZ_PDIVQ below -- the reciprocal product with one residual correction, which is the quotient
+//     itself except for double rounding in rare halfway cases;
+//   * the host harness (tests/cpu_harness) divides everywhere.
+// A zero denominator gives NaN here where the division gives +-inf (or NaN for 0 / 0): non-finite either way, and the only thing
+// the LM loops ask of such a cost is isfinite() -- a non-finite INITIAL cost is FAILURE, a non-finite candidate a rejected step, as
+// in Ceres 1.14 (tests: test_krt_nonfinite_input_fails_like_the_oracle).
 PTZ_HD double rcp_nr(double d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -56,15 +65,26 @@ PTZ_HD double rcp_nr(double d)
 }
 
 // The quotient of the perspective division, a / z with iz = rcp_nr(z).  HOST build: the division, as the reference's functors
-// have it (tests/cpu_harness holds these functions to the oracle bit for bit).  DEVICE: a * iz -- an IEEE division is 12
+// have it (tests/cpu_harness holds these functions to the oracle bit for bit).  DEVICE, PTZ_PDIV: a * iz -- an IEEE division is 12
 // instructions on this chip and the functors had five of them per observation, a third of the instruction stream of the
-// issue-bound k_eval / k_lin_ray / k_lin_cam loops.  The device's residual then differs from the quotient form by an ulp or so
-// (it never had the bits of a CPU's: the device contracts multiply-adds); parity tests hold it to the oracle to 1e-12 in cost.
+// issue-bound k_eval / k_lin_ray / k_lin_cam loops.  DEVICE, PTZ_PDIVQ (single-view LM): q = a * iz corrected once by its own
+// residual, q + (a - q z) iz -- two more multiply-adds, and the result is the correctly rounded quotient but for halfway cases.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PTZ_PDIV(a, z, iz) ((a) * (iz))
 #else
 #define PTZ_PDIV(a, z, iz) ((a) / (z))
 #endif
+PTZ_HD double pdiv_q(double a, double z, double iz)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q = a * iz;
+  return fma(fma(-q, z, a), iz, q);
+#else
+  (void)iz;
+  return a / z;
+#endif
+}
+#define PTZ_PDIVQ(a, z, iz) pdiv_q((a), (z), (iz))
 
 // cv::Rodrigues vector -> matrix (OpenCV 4.5.3 cvRodrigues2): theta < DBL_EPSILON -> I
 PTZ_HD void rodrigues(const double r[3], double R[9])
@@ -606,11 +626,12 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, do
   const double Px = R[0] * ray1[0] + R[1] * ray1[1] + R[2] * ray1[2];
   const double Py = R[3] * ray1[0] + R[4] * ray1[1] + R[5] * ray1[2];
   const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
-  const double iz = rcp_nr(Pz), x = PTZ_PDIV(Px, Pz, iz), y = PTZ_PDIV(Py, Pz, iz);  // (host build: the reference functor's divisions, PTZ_PDIV)
+  // (the residual's quotients corrected to the last bit, PTZ_PDIVQ: the final cost decides KRTOptimizer::CheckResults' accept test)
+  const double iz = rcp_nr(Pz), x = DIST ? PTZ_PDIVQ(Px, Pz, iz) : PTZ_PDIV(Px, Pz, iz), y = DIST ? PTZ_PDIVQ(Py, Pz, iz) : PTZ_PDIV(Py, Pz, iz);
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (!DIST) {
-    res[0] = (double)u2 - PTZ_PDIV(fx * Px + cx * Pz, Pz, iz);
-    res[1] = (double)v2 - PTZ_PDIV(fy * Py + cy * Pz, Pz, iz);
+    res[0] = (double)u2 - PTZ_PDIVQ(fx * Px + cx * Pz, Pz, iz);
+    res[1] = (double)v2 - PTZ_PDIVQ(fy * Py + cy * Pz, Pz, iz);
   }
   else {
     brown(x, y, kd, xd, yd);

@@ -280,12 +280,15 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
   double grad_max = 0;
 #pragma unroll
   for (int k = 0; k < NF; ++k) grad_max = fmax(grad_max, fabs(g[k]));
-  const double initial_cost = x_cost;
-  double final_cost = x_cost, it_cost = x_cost;
-  int iteration = 0, n_summaries = 0, termination = PTZ_NO_CONVERGENCE;
+  // [Ceres 1.14] a non-finite cost at the initial point (a non-finite pixel, a ray in the image plane) is FAILURE before any
+  // iteration: nothing is refined, the summary carries zeros (the oracle's lm_minimize, IterationZero)
+  const bool bad0 = !isfinite(x_cost);
+  const double initial_cost = bad0 ? 0.0 : x_cost;
+  double final_cost = initial_cost, it_cost = initial_cost;
+  int iteration = 0, n_summaries = bad0 ? 1 : 0, termination = bad0 ? PTZ_FAILURE : PTZ_NO_CONVERGENCE;
   int n_succ = 0, n_unsucc = 0, n_steps = 0, n_solves = 0, n_jac = 1, consec_invalid = 0;
   bool step_ok = true;
-  for (;;) {
+  for (; !bad0;) {
     if (step_ok) ++n_succ; else ++n_unsucc;
     if (it_cost < final_cost) final_cost = it_cost;
     ++n_summaries;

@@ -677,6 +677,62 @@ def test_krt_batch_parity(pkg, orc, ftype):
     assert n_acc >= rb.n_query * 0.8
 
 
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_krt_accept_gate_next_to_the_threshold(pkg, orc, ftype):
+    """KRTOptimizer::CheckResults accepts a refinement when final_reproj < max_reproj_error (krt_optimizer.cc:504-533).  The device's
+    residual quotients are reciprocal products corrected by their own residual (ptz_factor.h PTZ_PDIVQ), not IEEE divisions: with the
+    threshold set a relative 1e-9 ABOVE / BELOW the oracle's own final reprojection error of every query, the device must accept /
+    reject exactly as the oracle does -- its final cost sits within 1e-9 of the reference arithmetic's where the decision is made."""
+    rb = pkg.synth.make_reloc_batch(24, 128, seed_id=30 + ftype, factor_type=ftype)
+    reproj = []
+    for q in range(rb.n_query):
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        loc0 = orc.krt_world_to_local(rb.cam_ref[q], rb.cam_init[q])
+        # (closed-form Jacobians in the oracle as on the device: the two then walk the same iterates, and what is compared is the
+        #  arithmetic of the final cost, not two trajectories that stop a function_tolerance apart)
+        loc, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[q], loc0, factor_type=ftype, jacobian_mode=orc.JAC_ANALYTIC)
+        reproj.append((np.sqrt(2.0) * np.sqrt(2.0 * osumm["final_cost"] / osumm["num_residuals"]), osumm, loc))
+    import copy
+    checked = 0
+    for q in range(rb.n_query):
+        r, osumm, loc = reproj[q]
+        if osumm["termination_type"] != 0 or not orc.krt_check(osumm, loc, 1e9):
+            continue  # (not converged or outside the field-of-view gate: the threshold does not decide)
+        one = copy.copy(rb)
+        one.n_query = 1
+        s = slice(rb.match_ptr[q], rb.match_ptr[q + 1])
+        one.match_ptr = np.array([0, s.stop - s.start], dtype=np.int64)
+        one.uv_ref, one.uv_cur = rb.uv_ref[s], rb.uv_cur[s]
+        one.cam_ref, one.cam_init = rb.cam_ref[q:q + 1], rb.cam_init[q:q + 1]
+        for thr, want in ((r * (1 + 1e-9), True), (r * (1 - 1e-9), False)):
+            assert orc.krt_check(osumm, loc, thr) == want
+            _, summ, acc, _ = pkg.api.krt_solve_batch(one, max_reproj_error=thr)
+            assert bool(acc[0]) == want, (q, thr, summ[0]["final_cost"], osumm["final_cost"])
+        checked += 1
+    assert checked >= 12
+
+
+def test_krt_nonfinite_input_fails_like_the_oracle(pkg, orc):
+    """A non-finite cost at the initial point -- here a matched pixel that is +inf -- is FAILURE before any iteration in Ceres 1.14
+    (and in the oracle): no step is taken, the camera is not written.  The device's quotients turn a zero denominator into NaN where
+    the division gives +-inf; both are "not finite", which is all the loop asks.  The other queries of the batch are not disturbed."""
+    rb = pkg.synth.make_reloc_batch(6, 64, seed_id=77, factor_type=0)
+    clean_cam, clean_summ, clean_acc, _ = pkg.api.krt_solve_batch(rb)
+    rb.uv_cur = rb.uv_cur.copy()
+    bad = 2
+    rb.uv_cur[rb.match_ptr[bad] + 5, 0] = np.inf
+    cam_w, summ, acc, _ = pkg.api.krt_solve_batch(rb)
+    s = slice(rb.match_ptr[bad], rb.match_ptr[bad + 1])
+    loc0 = orc.krt_world_to_local(rb.cam_ref[bad], rb.cam_init[bad])
+    _, osumm, _ = orc.krt_solve(rb.uv_ref[s], rb.uv_cur[s], rb.cam_ref[bad], loc0, factor_type=0, jacobian_mode=orc.JAC_NUMERIC)
+    assert osumm["termination_type"] == 2 and summ[bad]["termination_type"] == 2   # FAILURE
+    assert summ[bad]["num_iterations"] == osumm["num_iterations"] == 0 and summ[bad]["num_lm_steps"] == 0
+    assert not acc[bad] and np.array_equal(cam_w[bad], rb.cam_init[bad])
+    for q in range(rb.n_query):
+        if q != bad:
+            assert summ[q] == clean_summ[q] and acc[q] == clean_acc[q] and np.array_equal(cam_w[q], clean_cam[q])
+
+
 @pytest.mark.parametrize("ftype", [0, 1, 2, 3])
 def test_krt_2d3d_batch_parity(pkg, orc, ftype):
     """Single-view LM with 2D-3D constraints on top of the matches (KRTOptimizer::Add2d3dConstraints,
@@ -1300,6 +1356,33 @@ def test_views_wider_than_the_counting_sort_take_the_same_lists(pkg, monkeypatch
     vb = pkg.api.ViewBatch([rig] * 3, views); got_wide = pkg.api.structure_hash(vb); vb.close()
     monkeypatch.delenv("PTZ_BA_DEBUG_VIEW_WIDE", raising=False)
     assert got_default == want and got_wide == want
+
+
+def test_view_sort_key_overflow_is_refused(pkg):
+    """The batch-wide sort key of a view batch holds (longest candidate track - length) * cameras + first camera in 22 bits.  The
+    guard used the rig's MEAN track length: one track through all 2100 images of a wide view (2100 * 2100 > 2^22) passed it and
+    spilled into the view-number bits -- a silently different ray order.  Now the rig keeps its longest track: that view is refused
+    with PTZ_ELIMIT, while the same images with the long track cut to 1500 views are accepted."""
+    n_img, n_short = 2100, 3000
+    rng = np.random.default_rng(3)
+
+    def rig_with(long_len):
+        imgs = [np.arange(long_len, dtype=np.int32)]
+        for _ in range(n_short):
+            imgs.append(np.sort(rng.choice(n_img, 4, replace=False)).astype(np.int32))
+        ptr = np.concatenate([[0], np.cumsum([len(i) for i in imgs])]).astype(np.int64)
+        img = np.concatenate(imgs)
+        uv = rng.uniform(50, 1000, (len(img), 2)).astype(np.float32)
+        return pkg.api.Rig(n_img, ptr, img, uv)
+
+    rig = rig_with(n_img)
+    with pytest.raises(Exception) as ei:
+        pkg.api.ViewBatch([rig], [list(range(n_img))])
+    assert "PTZ_ELIMIT" in str(ei.value)
+    rig.close()
+    rig = rig_with(1500)   # 1500 * 2100 + 2100 < 2^22
+    vb = pkg.api.ViewBatch([rig], [list(range(n_img))])
+    vb.close(); rig.close()
 
 
 def test_views_of_resident_rigs_are_the_batches_of_their_packed_problems(pkg):
