@@ -408,6 +408,9 @@ def main():
                     help="directory for generated scenes (.npz, keyed by seed and shape; '' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iba-rigs", type=int, default=64, help="rigs of the batched PTZ-IBA leg (0 skips it)")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="rank 0 writes the gathered result blocks (one row per scene of the whole job: 15 doubles per view, then termination, "
+                         "iterations, final cost) to this .npy file -- what the multi-rank test compares with solo solves")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps: no single-rig / reloc / orchestration / CPU legs, so that a rocprofv3 --stats "
                          "summary of this command averages over the timed launch shape alone")
@@ -523,6 +526,8 @@ def main():
             barrier()
             gather_ms = 1e3 * (time.perf_counter() - tg)
             assert gathered.shape[0] == n_total
+            if rank == 0 and args.dump_gathered:
+                np.save(args.dump_gathered, gathered)
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ws = torch.tensor([float(lm_steps), units_done, float(sum(1 for s in summ if s["termination_type"] == 0))], dtype=torch.float64, device=dev)
@@ -538,7 +543,8 @@ def main():
 
     if rank == 0:
         par = {"world_size": world, "backend": backend or "none", "ranks_ms_per_step": per_rank, "gather_ms": gather_ms,
-               "world_size_seen_by_collective": (dist.get_world_size() if dist is not None else 1)}
+               "world_size_seen_by_collective": (dist.get_world_size() if dist is not None else 1),
+               "first_scene_of_rank0": first_scene, "scenes_of_rank0": n_scenes}
         body = {}  # everything behind the contract keys, in the order it is printed
         if args.config == "C5":
             config = {"workload": f"C5 (BASELINE configs[4]): {args.queries} relocalization queries x 128 matches per GPU, F factor, "
@@ -597,12 +603,14 @@ def main():
         batch.close()
     if rank == 0:
         cpu = None
+        legs_failed = []  # side legs that raised: reported at the top level of the line (a regression in a leg must not pass unnoticed)
         def side_leg(name, fn):
             # the legs beside the headline never take the line down with them: a leg that fails is reported as such, with its error
             try:
                 body[name] = fn()
             except Exception as e:  # noqa: BLE001 -- whatever it was, the headline measured above stands
                 body[name] = {"error": f"{type(e).__name__}: {e}"}
+                legs_failed.append(name)
                 print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
         if extras:
@@ -662,10 +670,10 @@ def main():
             "ms_per_step": 1e3 * t_max / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling,
-            # BASELINE.md publishes no number for this metric: the ratio is to the CPU port of the reference algorithm timed on
-            # this box's host cores (cpu_baseline below), as the round-2 review asked; null when that leg did not run
-            "vs_baseline": (value / cpu["value"]) if cpu else None,
-            "vs_baseline_kind": "cpu_baseline (port of the reference algorithm, this box's host cores); BASELINE.md has no published number",
+            # BASELINE.md publishes no number for this metric, so the contract's ratio is null; the ratio to the CPU port of the
+            # reference algorithm timed on this box's host cores (cpu_baseline below) is reported beside it under its own name
+            "vs_baseline": None,
+            "vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
             "dtype": "f64",
             "data": "synthetic",
             "config": config,
@@ -673,6 +681,9 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if "default_pipeline" in body:  # what a caller of the library gets (graph-replayed passes, two scene groups): top-level, beside `value`
+            out["value_default_pipeline"] = body["default_pipeline"]["lm_iterations_per_s"]
+        out["legs_failed"] = legs_failed
         out.update(body)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -531,15 +531,7 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
     }
   }
   else if (b->schur_tg) LAUNCH((k_schur<TYPE, true>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
-  else {
-#ifdef PTZ_SCHUR_FAKE_ROWS  // probe builds: the small-table kernel is what P_SCHUR times; the real one (under P_RHS) overwrites its output
-    LAUNCH((k_schur<TYPE, false, PTZ_SCHUR_FAKE_ROWS>), dim3(b->max_cam, B), dim3(schur_thr),
-           schur_lds_bytes(std::min(b->max_cam_obs, PTZ_SCHUR_FAKE_ROWS), NC, d.chol.np, false, schur_thr, Dims<TYPE>::NW, b->max_cam_ent), d);
-    b->prof_end();
-    b->prof_begin(P_RHS);
-#endif
-    LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
-  }
+  else LAUNCH((k_schur<TYPE, false>), dim3(b->max_cam, B), dim3(schur_thr), schur_smem, d);
   if (Dims<TYPE>::HAS3D) LAUNCH(k_schur_3d<TYPE>, dim3(B), dim3(64), 0, d);
   if (d.shared) LAUNCH(k_fold_system<TYPE>, dim3(B), dim3(1024), sizeof(double) * (size_t)(b->max_n + 4) + (size_t)(d.chol.np / CHOL_NB) * (d.chol.np / CHOL_NB), d);
   b->prof_end();

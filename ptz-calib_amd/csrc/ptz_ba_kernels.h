@@ -1429,12 +1429,10 @@ __global__ __launch_bounds__(SCHUR_THREADS, Dims<TYPE>::DISP ? 2 : PTZ_SCHUR_WAV
 // for PTZRay (4 waves per SIMD): 42.5 ms against 41.9 ms per 256-scene solve -- the registers that the prefetches below need
 // are worth more than the occupancy.
 template <int TYPE> constexpr int schur_threads() { return 256; }
-// FAKE_ROWS > 0 (probe builds only, -DPTZ_SCHUR_FAKE_ROWS=n; WRONG results, overwritten by a real launch right after): the LDS table
-// holds n rows and every row index wraps around -- what the kernel would run at if its table were that small (occupancy
-// experiments)
-#define SCHUR_ROW(q) (FAKE_ROWS > 0 ? (q) % (FAKE_ROWS > 0 ? FAKE_ROWS : 1) : (q))
-template <int TYPE, bool TG, int FAKE_ROWS = 0>
-__global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512 ? 4 : (FAKE_ROWS > 0 ? 3 : 2)) void k_schur(Dev d)  // (threads, waves per SIMD)
+// (the wrong-result occupancy probe of round 3 -- a table of n wrapped rows, three workgroups per compute unit -- is kept as a patch:
+//  tools/probes/hip/schur_fake_rows_r3.patch)
+template <int TYPE, bool TG>
+__global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512 ? 4 : 2) void k_schur(Dev d)  // (threads, waves per SIMD)
 {
   constexpr int THREADS = schur_threads<TYPE>();
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR, CBS = Dims<TYPE>::CBS;
@@ -1590,7 +1588,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
         for (int l = 0; l < 3; ++l) w[3 * k + l] = Jc[0][k] * Jr[0][l] + Jc[1][k] * Jr[1][l];
       // T'_a = T_a diag(sqrt(w) a): the second observation's ray-side factors, folded into the row once
       const double f0 = sw * al[0], f1 = sw * al[1], f2 = sw * al[2];
-      double* Tq = T + (size_t)SCHUR_ROW(q) * TS;
+      double* Tq = T + (size_t)q * TS;
       int e = 0;
 #pragma unroll
       for (int p = 0; p < NW; ++p) {
@@ -1724,7 +1722,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
       // the row of the NEXT entry is read from LDS while the current one is worked on (past the end the last row again)
       double Tn[NT + 3];
       {
-        const double* Ta = T + (size_t)SCHUR_ROW(es[0]) * TS;
+        const double* Ta = T + (size_t)es[0] * TS;
 #pragma unroll
         for (int k = 0; k < NT + 3; ++k) Tn[k] = Ta[k];
       }
@@ -1733,7 +1731,7 @@ __global__ __launch_bounds__(schur_threads<TYPE>(), schur_threads<TYPE>() == 512
 #pragma unroll
         for (int i = 0; i < NT + 3; ++i) Tc[i] = Tn[i];
         {
-          const double* Ta = T + (size_t)SCHUR_ROW(es[min(k + 1, cnt - 1)]) * TS;
+          const double* Ta = T + (size_t)es[min(k + 1, cnt - 1)] * TS;
 #pragma unroll
           for (int i = 0; i < NT + 3; ++i) Tn[i] = Ta[i];
         }

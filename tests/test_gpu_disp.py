@@ -72,6 +72,33 @@ def test_ba_dist_disp_parity(pkg, orc, seed, views, obs):
     assert np.array_equal(cam[:, [1, 2, 3, 7, 8, 9, 11, 12, 13, 14]], sc.cam_init[:, [1, 2, 3, 7, 8, 9, 11, 12, 13, 14]])
 
 
+@pytest.mark.parametrize("seed,views,obs", [(2, 20, 100), (5, 40, 200)])
+def test_ba_dist_disp_deviation_from_the_numeric_reference_has_a_number(pkg, orc, seed, views, obs):
+    """What the documented deviation of this variant amounts to.  The reference differentiates PTZRayDistDisp numerically, and its
+    central difference for d2 is a percent off (module docstring): the device (closed form) and the reference-faithful oracle
+    (JAC_NUMERIC) therefore walk different paths -- and this model has a flat valley in (f, k1, delta(f)): focal length and the z
+    displacement trade against each other, so different paths stop at different points of it.  Measured (probe_r5_disp_dev.py), default
+    tolerances: seed 5 agrees to 5e-6 in f / 2e-6 in k1 / 5e-6 in delta after 19 iterations on both sides; seed 2 stops after 114
+    (device) against 7 (numeric) iterations 8 % apart in f, 0.03 in k1, 0.11 in delta -- with final costs 1.6e-4 apart, the device's
+    the LOWER one.  Tightening function_tolerance does not close the gap (both run along the valley until max_num_iterations).
+    The bound this test can honestly hold: same termination type, the device's minimum is at least as good as the reference's to
+    5e-4 in cost, and the parameters stay inside the valley's measured extent."""
+    sc = pkg.synth.make_scene(seed, views, obs, factor_type=3)
+    cam, ray, summ, _, disp = pkg.api.ba_solve_disp(sc)
+    od = np.zeros(3)
+    ocam, oray, _, osumm, _ = orc.ba_solve(sc, jacobian_mode=orc.JAC_NUMERIC, disp=od, num_threads=8)
+    assert summ["termination_type"] == osumm["termination_type"] == 0
+    assert summ["final_cost"] <= osumm["final_cost"] * (1 + 5e-4)
+    assert abs(summ["final_cost"] - osumm["final_cost"]) / osumm["final_cost"] < 5e-4
+    f = ocam[:, 0]
+    delta = disp[0] + disp[1] * f + disp[2] * f * f
+    odelta = od[0] + od[1] * f + od[2] * f * f
+    df, dk1, dd = np.abs(cam[:, 0] / f - 1).max(), np.abs(cam[:, 10] - ocam[:, 10]).max(), np.abs(delta - odelta).max()
+    assert df < 0.15 and dk1 < 0.06 and dd < 0.25, (df, dk1, dd)
+    if seed == 5:  # where both sides take the same number of steps the variant meets the north-star tolerance scale
+        assert summ["num_iterations"] == osumm["num_iterations"] and df < 2e-5 and dk1 < 1e-5 and dd < 2e-5, (df, dk1, dd)
+
+
 def test_ba_dist_disp_with_annotations(pkg, orc):
     """With georeferencing residuals (Reproj2d3dDispFactor): fy live, the T_l_w block in the reduced system, the displacement
     block shared by the 2D-2D and the 2D-3D residuals."""

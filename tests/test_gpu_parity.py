@@ -181,10 +181,13 @@ def test_pix2ray_vs_oracle(pkg, orc, scene_c1):
     b = pkg.api.BaBatch([scene_c1])
     b.set_state(None, [np.zeros_like(scene_c1.ray_init)])
     b.pix2ray()
-    # read back through a linearize-free path: solve() starts from the stored state, so compare via get after 0 work
     want = orc.pix2ray(scene_c1, scene_c1.cam_init)
     assert _rel(scene_c1.ray_init, want) < 1e-12  # generator vs oracle
-    # device result: run a solve and check it matches a solve started from the oracle's rays
+    # the device's rays themselves, read back before anything else touches them, against the oracle's (SetUpInitialCameraParams /
+    # Pix2Ray, ptzray_optimizer.cc:635-670, 768-797): every ray, every component
+    rays = pkg.api.initial_rays(b, scene_c1.n_ray)  # (the batch's initial-state buffer, in the caller's ray order)
+    assert rays.shape == want.shape and np.abs(rays - want).max() <= 1e-13 * np.abs(want).max()
+    # ... and a solve started from them matches a solve started from the oracle's rays
     s1 = b.solve()
     b2 = pkg.api.BaBatch([scene_c1]); b2.set_state(None, [want]); s2 = b2.solve()
     assert s1[0]["num_iterations"] == s2[0]["num_iterations"]
