@@ -194,6 +194,46 @@ __device__ __forceinline__ int sys_col(const Dev& d, int sc, int c)
 __device__ __forceinline__ double& sys_at(double* A, int np, int r, int c) { return r >= c ? A[(size_t)r * np + c] : A[(size_t)c * np + r]; }
 
 
+// ---- cross-lane exchanges without the LDS crossbar (gfx950) ------------------------------------------------------------------
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd 16-lane rows) of one register with the lower half (the even
+// rows) of another: exactly the trade of a reduce-scatter's halving step at lane distance 32 / 16 -- after the swap a + b is, in the
+// lower lanes, a(l) + a(l + d) and, in the upper lanes, b(l - d) + b(l): the sums the shuffle form (keep + shfl_xor(send)) makes, same
+// operands, same bits.  Distances 8, 4, 2, 1 are DPP moves inside a row of 16 lanes.
+__device__ __forceinline__ void swap_halves32(double& a, double& b)
+{
+  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap_rows16(double& a, double& b)
+{
+  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// the value of lane (l ^ D) for D = 8, 4, 2, 1 (all lanes active)
+template <int D> __device__ __forceinline__ double lane_xor_dpp(double v)
+{
+  static_assert(D == 8 || D == 4 || D == 2 || D == 1, "inside a row of 16 lanes");
+  if (D == 8) return dpp_mov<0x128>(v);       // row_ror:8
+  if (D == 2) return dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  if (D == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  // D == 4: lanes of the even banks of four read four lanes up (row_shl:4), those of the odd banks four lanes down (row_shr:4)
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x104, 0xf, 0x5, false);
+  lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114, 0xf, 0xa, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x104, 0xf, 0x5, false);
+  hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xf, 0xa, false);
+  return __hiloint2double(hi, lo);
+}
+
 // The rays' records {E (6), z (3), Xn (3), a (3), sqrt(w)} as eight planes of 16-byte pieces (round 5; one 128-byte record per
 // ray before): the ray-centric kernels (k_ray_prep's stores, k_eval's reads of E) become unit-stride -- ray preparation 20.7 ->
 // 17.2 ms, evaluation 41 -> 38.7 ms per C4 solve -- and a camera's rays are dense clusters of the internal ray order (by track
@@ -2047,22 +2087,33 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
     for (int k = 0; k < NU; ++k) v[NW + k] = D[k];
 #pragma unroll
     for (int k = NV; k < PAD; ++k) v[k] = 0.0;
+    // reduce-scatter over the wave (see k_schur) with register swaps and DPP moves instead of 34 trips through the LDS crossbar,
+    // which phase 2 of the neighbouring workgroups keeps busy: the same sums of the same operands
     int vidx = 0;
     {
-      int off = 32;
 #pragma unroll
-      for (int h = PAD / 2; h >= 1; h >>= 1, off >>= 1) {
-        const bool up = (lane & off) != 0;
+      for (int i = 0; i < 8; ++i) { swap_halves32(v[i], v[i + 8]); v[i] += v[i + 8]; }   // distance 32: lanes >= 32 now hold values 8..15
+      if (lane & 32) vidx += 8;
 #pragma unroll
-        for (int i = 0; i < h; ++i) {
-          const double keep = up ? v[i + h] : v[i];
-          const double send = up ? v[i] : v[i + h];
-          v[i] = keep + __shfl_xor(send, off, WAVE);
+      for (int i = 0; i < 4; ++i) { swap_rows16(v[i], v[i + 4]); v[i] += v[i + 4]; }     // distance 16
+      if (lane & 16) vidx += 4;
+      {  // distance 8
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+          v[i] = keep + lane_xor_dpp<8>(send);
         }
-        if (up) vidx += h;
+        if (up) vidx += 2;
       }
-#pragma unroll
-      for (; off >= 1; off >>= 1) v[0] += __shfl_xor(v[0], off, WAVE);
+      {  // distance 4
+        const bool up = (lane & 4) != 0;
+        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + lane_xor_dpp<4>(send);
+        if (up) vidx += 1;
+      }
+      v[0] += lane_xor_dpp<2>(v[0]);
+      v[0] += lane_xor_dpp<1>(v[0]);
     }
     constexpr int LOWMASK = 64 / PAD - 1;
     if ((lane & LOWMASK) == 0 && vidx < NV) strip[wv * NV + vidx] = v[0];
