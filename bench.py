@@ -90,11 +90,11 @@ def family_models(scene, nc):
         "eval": dict(bound="hbm", bytes=16.0 * n_obs + 96.0 * n_ray, unit="lm_step"),                     # K4
         "ray_prep": dict(bound="hbm", bytes=96.0 * n_ray, unit="lm_step"),
         "schur": dict(bound="hbm", bytes=s_bytes, unit="lm_step",                                         # K2: S written once
-                      # the kernel's own FP64 vector work (ptz_ba_kernels.h k_schur): per observation of phase 1 ba_pair_side, W = Jc^T Jr,
-                      # T = W E, the diagonal block's sums (~700 flop); per camera-pair entry ba_pair_side of the other camera and
-                      # the NW x NW block update (~150 flop) -- priced against the FP64 vector peak, because that, not HBM, is
-                      # what the counters say bounds it (49 % of wave cycles waiting, 33 % issuing FP64: profiles/)
-                      valu_flops=700.0 * n_obs + 150.0 * n_ent),
+                      # the kernel's own FP64 vector work (ptz_ba_kernels.h k_schur_f), priced against the FP64 vector peak, because that,
+                      # not HBM, is what the counters say bounds it (profiles/)
+                      # (round 5, k_schur_f: ~330 flop per observation -- Jr0, Jc0, Q = Jr0 E'', N = Q Jr0^T, the sums, the 8-double row --
+                      #  and ~160 per entry -- P' = Rji (x, y, 1), the reciprocal, K = Q Mr^T, K Graw_b, Graw_a^T (.), counted from the source)
+                      valu_flops=330.0 * n_obs + 160.0 * n_ent),
         "chol_syrk": dict(bound="mfma", flops=upd * 2.0 * nb ** 3 + nt * nb ** 3 / 3.0, unit="lm_step",   # tile updates + diagonal tiles
                           flops_dense=n ** 3 / 3.0 + 2.0 * n * n),
         "chol_panel": dict(bound="mfma", flops=trsm * 1.0 * nb ** 3, unit="lm_step"),                     # tile triangular solves
@@ -294,7 +294,7 @@ def iba_batch_leg(pkg, scenes, tables, device_id):
         cam0.append(c)
     pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id)  # warm-up at full size (resource pool: pinned and device blocks of every size class the rounds ask for)
     t1 = time.perf_counter()
-    res, st = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id)
+    res, st = pkg.hostlib.incremental_solve_batch(tables, cam0, max_iter=200, device_id=device_id, events_as_array=True)
     d1 = time.perf_counter() - t1
     reg = sum(len(r["registered"]) for r in res)
     ferr = [float(np.abs(r["cameras"][r["registered"], 0] / sc.cam_gt[r["registered"], 0] - 1).max()) for r, sc in zip(res, scenes) if r["registered"]]

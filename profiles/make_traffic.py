@@ -29,12 +29,12 @@ for f in args.summaries:
 # bytes a kernel reads as STREAMS per active scene and pass (C2-shaped scene; data layout of DESIGN.md section 3)
 STREAMS = {
     # round 3: no W rows any more -- ray ids (4 B) per observation, 4-byte entry records, 8-byte run records (<= 256 per view);
-    # the 128-byte per-ray records are gathered.  (--schur-w: round 2's kernel, a camera's W rows (96 B) streamed as well)
+    # the per-ray records (round 5: six 16-byte pieces of planes) are gathered.  (--schur-w: round 2's kernel, a camera's W rows (96 B) streamed as well)
     "k_schur": (100.0 if args.schur_w else 4.0) * args.n_obs + 4.0 * args.n_ent + (0.0 if args.schur_w else 8.0 * 256 * 200),
     "k_lin_cam": 12.0 * args.n_obs,                               # pixel (8 B) + ray id (4 B) per observation; the 64-byte ray records are gathered
-    "k_eval": 2 * 16.0 * args.n_obs + 200.0 * args.n_ray,         # observation records twice, per-ray arrays
+    "k_eval": 2 * 16.0 * args.n_obs + 248.0 * args.n_ray,         # observation records twice, per-ray arrays (round 5: E is three unit-stride planes, 48 B)
     "k_lin_ray": 16.0 * args.n_obs + 100.0 * args.n_ray,
-    "k_ray_prep": 96.0 * args.n_ray,
+    "k_ray_prep": 160.0 * args.n_ray,                             # V (48), g_r (24), the ray's record of the linearisation (64), the LM diagonal (24)
 }
 FAMILY = {"schur": ["k_schur"], "linearize": ["k_lin_ray", "k_lin_cam"], "eval": ["k_eval"], "ray_prep": ["k_ray_prep"],
           "chol_syrk": ["chol_update_col"], "chol_panel": ["chol_trsm"], "chol_backsolve": ["chol_backsolve", "chol_tile_inverse"]}

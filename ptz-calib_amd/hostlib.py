@@ -52,7 +52,7 @@ def incremental_solve(table, cam15, max_iter: int = 200, seeds=()):
                                registration_device=timing[4], construct=timing[5], solve=timing[6]))
 
 
-def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int = 0):
+def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int = 0, events_as_array: bool = False):
     """N rigs in lock step on one GPU (PtzIncrementalOptimizer::SolveBatch, host/device_batcher.h): every rig's optimizer on a
     host thread of its own, the bundle adjustments and registration attempts of each round batched into one library call each.
     Returns (list of per-rig dicts as incremental_solve gives them, without timing; batch statistics)."""
@@ -81,8 +81,11 @@ def incremental_solve_batch(tables, cam15s, max_iter: int = 200, device_id: int 
         solved = C.c_int32(0)
         ne = L.ptzh_inc_result(h, _p(cam), _p(reg), _p(ev), max_events, C.byref(nit), C.byref(solved))
         L.ptzh_inc_destroy(h)
-        return dict(ok=bool(solved.value), cameras=cam, registered=sorted(int(i) for i in np.flatnonzero(reg)),
-                    events=[tuple(int(x) for x in row) for row in ev[:max(ne, 0)]], lm_iterations=int(nit.value))
+        # (events_as_array: the int64 [n, 4] rows themselves -- turning ~3000 rows per rig into Python tuples is a third of this
+        #  function's time outside the library call for 64 rigs, all of it under the interpreter lock)
+        events = ev[:max(ne, 0)].copy() if events_as_array else [tuple(int(x) for x in row) for row in ev[:max(ne, 0)]]
+        return dict(ok=bool(solved.value), cameras=cam, registered=np.flatnonzero(reg).tolist(),
+                    events=events, lm_iterations=int(nit.value))
 
     workers = max(1, min(int(os.environ.get("PTZ_HOST_MARSHAL_THREADS", "16")), len(tables), os.cpu_count() or 1))  # (marshalling and tear-down of the rigs; measured, 64 rigs: 16 threads 383-430 ms for the whole call, 64 threads 547-598 -- they queue for the interpreter lock)
     with ThreadPoolExecutor(workers) as pool:
