@@ -113,6 +113,79 @@ def write_reloc_set(root: str, rb, width: int = 1920, height: int = 1080) -> dic
                 ref_names=ref_names, test_names=test_names)
 
 
+def _online_set(rng, sc, kps, names, n_online: int, n_match: int, prefix: str = "q_"):
+    """n_online query images that look from the rig centre near one of the rig's views (pan / tilt within a few degrees, other
+    zoom); their matches point into extra key points APPENDED to that view's key points (kps is updated in place).
+    Returns (image names, key points per image, pairs (ref image, query image, [(ref kp, query kp)]), ground-truth cameras)."""
+    from . import synth
+    w, h = int(sc.width), int(sc.height)
+    Rlw = synth.rodrigues(sc.tlw_gt[:3]); tlw = sc.tlw_gt[3:]
+    n_views = len(names)
+    gt_entries = {}
+    q_names, q_feats, q_pairs = [], [], []
+    for q in range(n_online):
+        v = int(rng.integers(0, n_views))
+        cv = sc.cam_gt[v]
+        Rv = synth.rodrigues(cv[4:7])
+        dR = synth.rodrigues(np.deg2rad(rng.uniform(-3, 3, 3)) * np.array([1.0, 1.0, 0.2]))
+        Rq = dR @ Rv
+        fq = cv[0] * rng.uniform(0.8, 1.25)
+        pu = rng.uniform(60, w - 60, 6 * n_match); pv = rng.uniform(60, h - 60, 6 * n_match)
+        ray = np.stack([(pu - cv[2]) / cv[0], (pv - cv[3]) / cv[1], np.ones_like(pu)], 1) @ Rv  # local frame
+        pc = ray @ Rq.T
+        qu = fq * pc[:, 0] / pc[:, 2] + 0.5 * w; qv = fq * pc[:, 1] / pc[:, 2] + 0.5 * h
+        ok = np.flatnonzero((pc[:, 2] > 0) & (qu > 10) & (qu < w - 10) & (qv > 10) & (qv < h - 10))[:n_match]
+        ref_pts = np.stack([pu[ok], pv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
+        cur_pts = np.stack([qu[ok], qv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
+        off = len(kps[v])
+        kps[v] = np.concatenate([kps[v], ref_pts.astype(np.float32)])
+        qn = f"{prefix}{q:05d}.png"
+        q_names.append(qn); q_feats.append(cur_pts.astype(np.float32))
+        q_pairs.append((names[v], qn, [(off + k, k) for k in range(len(ok))]))
+        cq = np.zeros(15); cq[0] = cq[1] = fq; cq[2], cq[3] = 0.5 * w, 0.5 * h
+        Rw = Rq @ Rlw
+        cq[4:7] = synth.rodrigues_inv(Rw); cq[7:10] = Rq @ tlw
+        gt_entries[os.path.splitext(qn)[0]] = camera_json_entry(os.path.splitext(qn)[0], cq, w, h)
+    return q_names, q_feats, q_pairs, gt_entries
+
+
+def _write_offline(root: str, tag: str, sc, tb, kps, names) -> dict:
+    """<root>/offline/<tag>/{images, <tag>.json} and <root>/offline_matches/<tag>/{features, pairs_matches.txt}; returns the
+    ground-truth entries (world-frame cameras) of the rig's images."""
+    from . import synth
+    w, h = int(sc.width), int(sc.height)
+    Rlw = synth.rodrigues(sc.tlw_gt[:3]); tlw = sc.tlw_gt[3:]
+    img_dir = os.path.join(root, "offline", tag); feat_dir = os.path.join(root, "offline_matches", tag)
+    os.makedirs(img_dir, exist_ok=True); os.makedirs(feat_dir, exist_ok=True)
+    for n in names:
+        write_png(os.path.join(img_dir, n), w, h)
+    kp_ptr = np.concatenate([[0], np.cumsum([len(k) for k in kps])]).astype(np.int64)
+    write_features(feat_dir, names, kp_ptr, np.concatenate(kps))
+    write_matches(os.path.join(feat_dir, "pairs_matches.txt"), [(names[a], names[b], ms) for a, b, ms in tb.pairs()])
+    entries, gt_entries = {}, {}
+    for i, n in enumerate(names):
+        sel = np.flatnonzero(sc.obs3d["cam"] == i)
+        root_n = os.path.splitext(n)[0]
+        cw = sc.cam_gt[i].copy()
+        Ri = synth.rodrigues(cw[4:7])
+        cw[4:7] = synth.rodrigues_inv(Ri @ Rlw); cw[7:10] = Ri @ tlw
+        entries[root_n] = camera_json_entry(root_n, cw, w, h, sc.obs3d["uv"][sel], sc.obs3d["xyz"][sel])
+        gt_entries[root_n] = camera_json_entry(root_n, cw, w, h)
+    with open(os.path.join(img_dir, tag + ".json"), "w") as f:
+        json.dump({"cameras": entries}, f, indent=4)
+    return gt_entries
+
+
+def _write_online(root: str, tag: str, sc, q_names, q_feats, q_pairs) -> None:
+    on_img = os.path.join(root, "online", tag); on_feat = os.path.join(root, "online_matches", tag)
+    os.makedirs(on_img, exist_ok=True); os.makedirs(on_feat, exist_ok=True)
+    for n in q_names:
+        write_png(os.path.join(on_img, n), int(sc.width), int(sc.height))
+    q_ptr = np.concatenate([[0], np.cumsum([len(k) for k in q_feats])]).astype(np.int64)
+    write_features(on_feat, q_names, q_ptr, np.concatenate(q_feats))
+    write_matches(os.path.join(on_feat, "pairs_matches.txt"), q_pairs)
+
+
 def write_synthetic_dataset(root: str, n_scenes: int = 10, n_views: int = 16, obs_per_view: int = 80, n_online: int = 6,
                             n_match: int = 96, seed0: int = 40) -> dict:
     """A data set in the directory layout the reference's run_ptzba_synthetic.sh / run_reloc_synthetic.sh expect:
@@ -125,68 +198,58 @@ def write_synthetic_dataset(root: str, n_scenes: int = 10, n_views: int = 16, ob
     from . import synth
     rng = np.random.default_rng(seed0)
     out = {"scenes": []}
+    os.makedirs(os.path.join(root, "gt"), exist_ok=True)
     for s in range(1, n_scenes + 1):
         tag = f"scene_{s:02d}"
         sc = synth.add_annotations(synth.make_scene(seed0 + s, n_views, obs_per_view), n_annotated=8, pts_per_cam=14)
         tb = synth.make_match_table(sc, min_pair_matches=6)
         names = [image_name(i) for i in range(n_views)]
-        w, h = int(sc.width), int(sc.height)
-        Rlw = synth.rodrigues(sc.tlw_gt[:3]); tlw = sc.tlw_gt[3:]
-        img_dir = os.path.join(root, "offline", tag); feat_dir = os.path.join(root, "offline_matches", tag)
-        on_img = os.path.join(root, "online", tag); on_feat = os.path.join(root, "online_matches", tag)
-        for d in (img_dir, feat_dir, on_img, on_feat, os.path.join(root, "gt")):
-            os.makedirs(d, exist_ok=True)
-        # online queries
         kps = [tb.kp_xy[tb.kp_ptr[i]:tb.kp_ptr[i + 1]].astype(np.float32) for i in range(n_views)]
-        gt_entries = {}
-        q_names, q_feats, q_pairs = [], [], []
-        for q in range(n_online):
-            v = int(rng.integers(0, n_views))
-            cv = sc.cam_gt[v]
-            Rv = synth.rodrigues(cv[4:7])
-            dR = synth.rodrigues(np.deg2rad(rng.uniform(-3, 3, 3)) * np.array([1.0, 1.0, 0.2]))
-            Rq = dR @ Rv
-            fq = cv[0] * rng.uniform(0.8, 1.25)
-            pu = rng.uniform(60, w - 60, 6 * n_match); pv = rng.uniform(60, h - 60, 6 * n_match)
-            ray = np.stack([(pu - cv[2]) / cv[0], (pv - cv[3]) / cv[1], np.ones_like(pu)], 1) @ Rv  # local frame
-            pc = ray @ Rq.T
-            qu = fq * pc[:, 0] / pc[:, 2] + 0.5 * w; qv = fq * pc[:, 1] / pc[:, 2] + 0.5 * h
-            ok = np.flatnonzero((pc[:, 2] > 0) & (qu > 10) & (qu < w - 10) & (qv > 10) & (qv < h - 10))[:n_match]
-            ref_pts = np.stack([pu[ok], pv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
-            cur_pts = np.stack([qu[ok], qv[ok]], 1) + rng.normal(size=(len(ok), 2)) * 0.5
-            off = len(kps[v])
-            kps[v] = np.concatenate([kps[v], ref_pts.astype(np.float32)])
-            qn = f"q_{q:05d}.png"
-            q_names.append(qn); q_feats.append(cur_pts.astype(np.float32))
-            q_pairs.append((names[v], qn, [(off + k, k) for k in range(len(ok))]))
-            cq = np.zeros(15); cq[0] = cq[1] = fq; cq[2], cq[3] = 0.5 * w, 0.5 * h
-            Rw = Rq @ Rlw
-            cq[4:7] = synth.rodrigues_inv(Rw); cq[7:10] = Rq @ tlw
-            gt_entries[os.path.splitext(qn)[0]] = camera_json_entry(os.path.splitext(qn)[0], cq, w, h)
-        # offline files
-        for i, n in enumerate(names):
-            write_png(os.path.join(img_dir, n), w, h)
-        kp_ptr = np.concatenate([[0], np.cumsum([len(k) for k in kps])]).astype(np.int64)
-        write_features(feat_dir, names, kp_ptr, np.concatenate(kps))
-        write_matches(os.path.join(feat_dir, "pairs_matches.txt"), [(names[a], names[b], ms) for a, b, ms in tb.pairs()])
-        entries = {}
-        for i, n in enumerate(names):
-            sel = np.flatnonzero(sc.obs3d["cam"] == i)
-            root_n = os.path.splitext(n)[0]
-            cw = sc.cam_gt[i].copy()
-            Ri = synth.rodrigues(cw[4:7])
-            cw[4:7] = synth.rodrigues_inv(Ri @ Rlw); cw[7:10] = Ri @ tlw
-            entries[root_n] = camera_json_entry(root_n, cw, w, h, sc.obs3d["uv"][sel], sc.obs3d["xyz"][sel])
-            gt_entries[root_n] = camera_json_entry(root_n, cw, w, h)
-        with open(os.path.join(img_dir, tag + ".json"), "w") as f:
-            json.dump({"cameras": entries}, f, indent=4)
-        # online files
-        for n in q_names:
-            write_png(os.path.join(on_img, n), w, h)
-        q_ptr = np.concatenate([[0], np.cumsum([len(k) for k in q_feats])]).astype(np.int64)
-        write_features(on_feat, q_names, q_ptr, np.concatenate(q_feats))
-        write_matches(os.path.join(on_feat, "pairs_matches.txt"), q_pairs)
+        q_names, q_feats, q_pairs, gt_entries = _online_set(rng, sc, kps, names, n_online, n_match)
+        gt_entries.update(_write_offline(root, tag, sc, tb, kps, names))
+        _write_online(root, tag, sc, q_names, q_feats, q_pairs)
         with open(os.path.join(root, "gt", tag + ".json"), "w") as f:
             json.dump({"cameras": gt_entries}, f, indent=4)
         out["scenes"].append(dict(tag=tag, n_views=n_views, n_online=n_online))
     return out
+
+
+# the reference's WorldCup14 runs (run_ptzba_worldcup14.sh, run_reloc_worldcup14.sh): four recorded matches are calibrated, seven test
+# sequences are relocalised against them
+WORLDCUP14_MATCHES = ("GER_ARG", "GER_POR", "NED_ARG", "USA_GER")
+WORLDCUP14_TESTS = (("GER_ARG", "ESP_CHI"), ("GER_ARG", "FRA_GER"), ("GER_POR", "SUI_FRA"), ("NED_ARG", "ARG_SUI"),
+                    ("NED_ARG", "BRA_CRO"), ("NED_ARG", "URU_ENG"), ("USA_GER", "CRO_MEX"))
+
+
+def write_worldcup14_layout(root: str, views=(20, 28, 24, 16), obs_per_view: int = 90, n_online: int = 4, n_match: int = 96,
+                            seed0: int = 70) -> dict:
+    """A data set in the directory layout of the reference's WorldCup14 runs -- <root>/offline/<MATCH>/, offline_matches/<MATCH>/,
+    online/<TEST>/, online_matches/<TEST>/ with the reference's match and test-sequence names -- filled with synthetic rigs that
+    look like a broadcast camera (1280 x 720, 120 degrees of pan, matches of different size).  The real recordings are not in
+    this repository; with them under data/worldcup14 the same scripts run on them unchanged.  Also writes <root>/gt/<name>.json
+    (ground-truth world-frame cameras) for the offline matches and the test sequences, which the real data set does not have in
+    this form (its ground truth are homographies for the IoU evaluation)."""
+    from . import synth
+    rng = np.random.default_rng(seed0)
+    os.makedirs(os.path.join(root, "gt"), exist_ok=True)
+    rigs = {}
+    for k, tag in enumerate(WORLDCUP14_MATCHES):
+        sc = synth.add_annotations(synth.make_scene(seed0 + k, views[k], obs_per_view, width=1280, height=720, pan_range_deg=120.0),
+                                   n_annotated=8, pts_per_cam=14)
+        tb = synth.make_match_table(sc, min_pair_matches=6)
+        names = [image_name(i) for i in range(views[k])]
+        kps = [tb.kp_xy[tb.kp_ptr[i]:tb.kp_ptr[i + 1]].astype(np.float32) for i in range(views[k])]
+        rigs[tag] = (sc, tb, names, kps)
+    online = {}
+    for ref, test in WORLDCUP14_TESTS:  # (every test sequence appends its reference key points to the match it is registered against)
+        sc, tb, names, kps = rigs[ref]
+        online[test] = (ref,) + _online_set(rng, sc, kps, names, n_online, n_match, prefix=test.lower() + "_")
+    for tag, (sc, tb, names, kps) in rigs.items():
+        gt = _write_offline(root, tag, sc, tb, kps, names)
+        with open(os.path.join(root, "gt", tag + ".json"), "w") as f:
+            json.dump({"cameras": gt}, f, indent=4)
+    for test, (ref, q_names, q_feats, q_pairs, gt_entries) in online.items():
+        _write_online(root, test, rigs[ref][0], q_names, q_feats, q_pairs)
+        with open(os.path.join(root, "gt", test + ".json"), "w") as f:
+            json.dump({"cameras": gt_entries}, f, indent=4)
+    return dict(matches={t: len(rigs[t][2]) for t in rigs}, tests={t: len(online[t][1]) for t in online})

@@ -1609,6 +1609,46 @@ def test_dataset_scripts_offline_then_online(pkg, tmp_path):
     assert n_total >= 45  # of 50 online images
 
 
+def test_worldcup14_layout_scripts_offline_then_online(pkg, tmp_path):
+    """BASELINE configs[2] through the reference's own entry points: run_ptzba_worldcup14.sh calibrates the four matches GER_ARG,
+    GER_POR, NED_ARG, USA_GER (PTZ-IBA + georeferencing, one process per match, dealt to the GPUs), run_reloc_worldcup14.sh
+    relocalises the seven test sequences against them.  The recordings are not in the container: the directory tree the scripts
+    read (data/worldcup14/{offline,offline_matches,online,online_matches}/<NAME>) is filled with broadcast-like synthetic rigs of
+    different size (1280 x 720, 120 degrees of pan).  With the real data set at DATA the same commands run on it unchanged.
+    Checked: every match and every test sequence produces its result file, all offline views are registered and georeferenced to the
+    accuracy of the synthetic data set's test, and the online cameras land on their ground truth."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data" / "worldcup14")
+    info = pkg.dataset_io.write_worldcup14_layout(data, views=(20, 28, 24, 16), obs_per_view=90, n_online=4)
+    env = dict(os.environ, DATA=data, NGPU="1")
+    off = str(tmp_path / "output-worldcup14-offline"); on = str(tmp_path / "output-worldcup14-online")
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "run_ptzba_worldcup14.sh")], env=dict(env, OUT=off), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def cams_of(path):
+        return json.load(open(path))["cameras"]
+
+    def f_of(e):  # the reference's camera record keeps K as a 3 x 3 list (data_io.cc)
+        K = np.asarray(e["K"], dtype=np.float64).reshape(3, 3)
+        return K[0, 0]
+
+    for tag, n_views in info["matches"].items():
+        pred, gt = cams_of(os.path.join(off, tag + ".json")), cams_of(os.path.join(data, "gt", tag + ".json"))
+        assert len(pred) == n_views == len(gt), tag
+        err = [abs(f_of(pred[k]) - f_of(gt[k])) for k in gt]
+        assert np.mean(err) < 8.0, (tag, np.mean(err))  # px, as the synthetic data set's test
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "run_reloc_worldcup14.sh")], env=dict(env, REF=off, OUT=on), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_total = 0
+    for test, n_q in info["tests"].items():
+        pred, gt = cams_of(os.path.join(on, test + ".json")), cams_of(os.path.join(data, "gt", test + ".json"))
+        n_total += len(pred)
+        err = [abs(f_of(pred[k]) - f_of(gt[k])) for k in pred]
+        assert len(pred) >= n_q - 1 and np.mean(err) < 15.0, (test, len(pred), np.mean(err))
+    assert n_total >= 26  # of 28 online images
+
+
 # ---------------------------------------------------------------------------------------- shared intrinsics (next-4)
 @pytest.mark.parametrize("n_groups,ftype,seed", [(1, 0, 5), (3, 0, 5), (1, 1, 6), (4, 1, 7)])
 def test_ba_shared_intrinsics_parity(pkg, orc, n_groups, ftype, seed):
