@@ -1261,13 +1261,7 @@ __device__ __forceinline__ d8 half_fetch(const double* __restrict__ g, int ld)
   }
   return r;
 }
-// DIAG: the launch of the diagonal tiles (one workgroup per system; the tile is factored on the spot).  !DIAG: the tiles below
-// (bx0 = 1) -- or all tiles of the column when the diagonal is not fused (bx0 = 0) -- WITHOUT the factorisation's code, registers and
-// LDS: 37 KB and <= 128 registers, FOUR workgroups per compute unit instead of three.  A column update is a short dependent chain per
-// workgroup (its C tile, two to five half steps of operand tiles two memory round trips deep, its store): what it is short of is
-// workgroups in flight, not matrix-core time (MFMA busy 30 %, NOTES_r05 section 3).  Same MFMAs per accumulator in the same order.
-template <bool DIAG>
-__global__ __launch_bounds__(256, DIAG ? 3 : 4) void chol_update_col_h_kernel(CholBatch cb, int j, int fuse_diag, int bx0)
+__global__ __launch_bounds__(256, 3) void chol_update_col_h_kernel(CholBatch cb, int j, int fuse_diag)
 {
   int bx, slot;
   xcd_remap(bx, slot);
@@ -1275,7 +1269,7 @@ __global__ __launch_bounds__(256, DIAG ? 3 : 4) void chol_update_col_h_kernel(Ch
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
   const int np = cb.np, nt = np / NB;
   const int n = cb.n[sys];
-  const int ti = j + bx + bx0;
+  const int ti = j + bx;
   if (ti >= nt || ti * NB > n || j * NB > n) return;
   const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
   if (tm && !tm[ti * nt + j]) return;
@@ -1357,20 +1351,18 @@ __global__ __launch_bounds__(256, DIAG ? 3 : 4) void chol_update_col_h_kernel(Ch
     step(ra, rb, u + 2);
     step(ra1, rb1, u + 3);
   }
-  if constexpr (DIAG) {
-    if (fuse_diag && ti == j) {
-      // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
-      __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
-      __shared__ int okflag;
-      __syncthreads();
+  if (fuse_diag && ti == j) {
+    // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
+    __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
+    __shared__ int okflag;
+    __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
-      __syncthreads();
-      diag_factor_tile(Ls, Dv, &okflag, cb, sys, j, n);
-      return;
-    }
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+    __syncthreads();
+    diag_factor_tile(Ls, Dv, &okflag, cb, sys, j, n);
+    return;
   }
   if (!any) return;
 #pragma unroll
@@ -1607,13 +1599,7 @@ void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool
   // PTZ_BA_CHOL_HALFK=0 brings the whole-tile kernel back (A/B measurements)
   static const bool halfk = [] { const char* e = getenv("PTZ_BA_CHOL_HALFK"); return !e || atoi(e) != 0; }();
   if (j > 0 && m > 0) {
-    if (halfk) {
-      if (fuse_diag) {  // the diagonal tiles first (the panel's solves wait for them), then the lean kernel for the tiles below
-        launch(chol_update_col_h_kernel<true>, dim3(1, cb.count), dim3(256), 0, stream, cb, j, 1, 0);
-        if (m > 1) launch(chol_update_col_h_kernel<false>, dim3(m - 1, cb.count), dim3(256), 0, stream, cb, j, 0, 1);
-      }
-      else launch(chol_update_col_h_kernel<false>, dim3(m, cb.count), dim3(256), 0, stream, cb, j, 0, 0);
-    }
+    if (halfk) launch(chol_update_col_h_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
     else launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
   }
 }
