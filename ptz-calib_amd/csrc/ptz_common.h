@@ -125,11 +125,57 @@ __device__ __forceinline__ void xcd_remap(int& bx, int& by)
 }
 
 // ---- deterministic reductions ----------------------------------------------------------------------
-// Butterfly over the 64 lanes of a wave: every lane ends with the same, order-fixed sum.
+// ---- cross-lane exchanges without the LDS crossbar (gfx950) ------------------------------------------------------------------
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd 16-lane rows) of one register with the lower half (the even
+// rows) of another: exactly the trade of a reduce-scatter's halving step at lane distance 32 / 16 -- after the swap a + b is, in the
+// lower lanes, a(l) + a(l + d) and, in the upper lanes, b(l - d) + b(l): the sums the shuffle form (keep + shfl_xor(send)) makes, same
+// operands, same bits.  Distances 8, 4, 2, 1 are DPP moves inside a row of 16 lanes.
+__device__ __forceinline__ void swap_halves32(double& a, double& b)
+{
+  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap_rows16(double& a, double& b)
+{
+  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// the value of lane (l ^ D) for D = 8, 4, 2, 1 (all lanes active)
+template <int D> __device__ __forceinline__ double lane_xor_dpp(double v)
+{
+  static_assert(D == 8 || D == 4 || D == 2 || D == 1, "inside a row of 16 lanes");
+  if (D == 8) return dpp_mov<0x128>(v);       // row_ror:8
+  if (D == 2) return dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  if (D == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  // D == 4: lanes of the even banks of four read four lanes up (row_shl:4), those of the odd banks four lanes down (row_shr:4)
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x104, 0xf, 0x5, false);
+  lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114, 0xf, 0xa, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x104, 0xf, 0x5, false);
+  hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xf, 0xa, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Butterfly over the 64 lanes of a wave: every lane ends with the same, order-fixed sum -- lane l adds the value of lane l ^ 32, then
+// l ^ 16, .. l ^ 1.  Round 5: the exchanges are register swaps (distance 32, 16) and DPP moves (8 .. 1) instead of twelve
+// ds_bpermute_b32 through the LDS crossbar; the tree and therefore the bits are the shuffle form's.  ALL 64 lanes must be active.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  { double t = v; swap_halves32(v, t); v += t; }   // v = [lo, lo], t = [hi, hi]
+  { double t = v; swap_rows16(v, t); v += t; }
+  v += lane_xor_dpp<8>(v);
+  v += lane_xor_dpp<4>(v);
+  v += lane_xor_dpp<2>(v);
+  v += lane_xor_dpp<1>(v);
   return v;
 }
 __device__ __forceinline__ double wave_max(double v)
