@@ -701,3 +701,24 @@ def test_batch_structure_is_pinned_and_thread_independent(pkg):
     assert gsh.all_hashes(pkg) == want
     scenes = [pkg.synth.make_scene(**c) for c in gsh.CASES if c.get("factor_type", 0) == 0] + [gsh.shuffled_tracks(pkg)]
     assert len({gsh.structure_hash(pkg, scenes, t) for t in (1, 2, 5, 8)}) == 1
+
+
+def test_worldcup14_layout_writer(pkg, tmp_path):
+    """dataset_io.write_worldcup14_layout: the directory tree the reference's run_ptzba_worldcup14.sh / run_reloc_worldcup14.sh read
+    (offline/<MATCH>, offline_matches/<MATCH>, online/<TEST>, online_matches/<TEST> under the reference's names), every test sequence
+    matched against images of the match it is relocalised against."""
+    import json
+    import os
+    root = str(tmp_path / "worldcup14")
+    info = pkg.dataset_io.write_worldcup14_layout(root, views=(8, 10, 8, 6), obs_per_view=50, n_online=2)
+    assert set(info["matches"]) == {"GER_ARG", "GER_POR", "NED_ARG", "USA_GER"} and len(info["tests"]) == 7
+    for tag, n in info["matches"].items():
+        assert os.path.exists(os.path.join(root, "offline", tag, tag + ".json"))
+        assert os.path.exists(os.path.join(root, "offline_matches", tag, "pairs_matches.txt"))
+        cams = json.load(open(os.path.join(root, "offline", tag, tag + ".json")))["cameras"]
+        assert len(cams) == n and all(c["res"] == [1280, 720] for c in cams.values())
+    for ref, test in pkg.dataset_io.WORLDCUP14_TESTS:
+        lines = open(os.path.join(root, "online_matches", test, "pairs_matches.txt")).read().split()
+        ref_images = set(os.listdir(os.path.join(root, "offline", ref)))
+        assert any(tok in ref_images for tok in lines), (ref, test)  # the pairs name images of the reference match
+        assert len([f for f in os.listdir(os.path.join(root, "online", test)) if f.endswith(".png")]) == info["tests"][test]
