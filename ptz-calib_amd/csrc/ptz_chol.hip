@@ -143,6 +143,57 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // columns up to date on the matrix cores (one 16-row block each, C -= X X^T over the finished column blocks); during a
 // sweep wave 1 inverts the previous 16 x 16 diagonal block (for the MFMA triangular solves of chol_trsm and the
 // back-substitution) and wave 2 stores the previous column block of L.
+// ---- the same sweep with DPP broadcasts (round 5; chol_chain_kernel) ----------------------------------------------------------
+// What a pivot of the sweep below pays for is the way a scalar of the pivot column reaches the other lanes: v_readlane into a
+// scalar register and from there into the multiply-add -- 30 cycles per dependent step (tools/probes/hip/dep_probe.hip: a dependent
+// FP64 multiply-add alone is 6).  v_fmac_f64_dpp row_newbcast broadcasts inside a row of 16 lanes in the multiply-add itself.  So
+// every row of 16 lanes carries a REPLICA of the diagonal block's rows (ar: lane r of the row holds block row r) beside its own rows
+// of the tile (a: lane 16 g + r holds tile row 16 (b + g) + r): the replicas are factored side by side -- same chain, same
+// operations, same bits -- and the own rows take their column updates with the replica's broadcasts.  Same products and sums per
+// element as the v_readlane form: the values are bit-identical (tools/probes/hip/sweep16_probe.hip: 171 against 207 cycles per
+// pivot for the 64 x 16 column block, 0 of 1040 values differ); twice the multiply-adds, hence only for the kernel whose critical
+// path the sweep is on (one rig, a few rigs) and which has the registers for it.
+#define PTZ_DPP_BC(dst, src, q) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:" #q " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
+#define PTZ_DPP_FD(acc, bsrc, m, q) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #q " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m))
+template <int Q> __device__ __forceinline__ void dpp_fd(double& acc, const double& l, const double& ml)
+{
+  if constexpr (Q == 1) PTZ_DPP_FD(acc, l, ml, 1); else if constexpr (Q == 2) PTZ_DPP_FD(acc, l, ml, 2); else if constexpr (Q == 3) PTZ_DPP_FD(acc, l, ml, 3);
+  else if constexpr (Q == 4) PTZ_DPP_FD(acc, l, ml, 4); else if constexpr (Q == 5) PTZ_DPP_FD(acc, l, ml, 5); else if constexpr (Q == 6) PTZ_DPP_FD(acc, l, ml, 6);
+  else if constexpr (Q == 7) PTZ_DPP_FD(acc, l, ml, 7); else if constexpr (Q == 8) PTZ_DPP_FD(acc, l, ml, 8); else if constexpr (Q == 9) PTZ_DPP_FD(acc, l, ml, 9);
+  else if constexpr (Q == 10) PTZ_DPP_FD(acc, l, ml, 10); else if constexpr (Q == 11) PTZ_DPP_FD(acc, l, ml, 11); else if constexpr (Q == 12) PTZ_DPP_FD(acc, l, ml, 12);
+  else if constexpr (Q == 13) PTZ_DPP_FD(acc, l, ml, 13); else if constexpr (Q == 14) PTZ_DPP_FD(acc, l, ml, 14); else PTZ_DPP_FD(acc, l, ml, 15);
+}
+template <int Q> __device__ __forceinline__ void dpp_bc(double& d, const double& s)
+{
+  if constexpr (Q == 0) PTZ_DPP_BC(d, s, 0); else if constexpr (Q == 1) PTZ_DPP_BC(d, s, 1); else if constexpr (Q == 2) PTZ_DPP_BC(d, s, 2); else if constexpr (Q == 3) PTZ_DPP_BC(d, s, 3);
+  else if constexpr (Q == 4) PTZ_DPP_BC(d, s, 4); else if constexpr (Q == 5) PTZ_DPP_BC(d, s, 5); else if constexpr (Q == 6) PTZ_DPP_BC(d, s, 6); else if constexpr (Q == 7) PTZ_DPP_BC(d, s, 7);
+  else if constexpr (Q == 8) PTZ_DPP_BC(d, s, 8); else if constexpr (Q == 9) PTZ_DPP_BC(d, s, 9); else if constexpr (Q == 10) PTZ_DPP_BC(d, s, 10); else if constexpr (Q == 11) PTZ_DPP_BC(d, s, 11);
+  else if constexpr (Q == 12) PTZ_DPP_BC(d, s, 12); else if constexpr (Q == 13) PTZ_DPP_BC(d, s, 13); else if constexpr (Q == 14) PTZ_DPP_BC(d, s, 14); else PTZ_DPP_BC(d, s, 15);
+}
+template <int Q> __device__ __forceinline__ void dpp_updates(double (&ar)[DB], double (&a)[DB], const double& lr, const double& mlr, const double& mlp)
+{
+  if constexpr (Q < DB) { dpp_fd<Q>(ar[Q], lr, mlr); dpp_fd<Q>(a[Q], lr, mlp); dpp_updates<Q + 1>(ar, a, lr, mlr, mlp); }
+}
+template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], double (&a)[DB], double (&ird)[DB], int live_cols, double& dmin, bool& bad)
+{
+  if constexpr (J < DB) {
+    double d;
+    dpp_bc<J>(d, ar[J]);                 // A[j][j] of the (partly eliminated) block, from lane j of every row of lanes
+    const bool live = J < live_cols;
+    dmin = fmin(dmin, live ? d : 1.0);   // NaN pivots: fmin keeps the other operand, caught by `bad`
+    bad |= (d != d) && live;
+    const double r = rsqrt_nr(d);
+    ird[J] = r;
+    const double lr = ar[J] * r, lp = a[J] * r;   // replica lane j: sqrt(d), below: L[r][j], above: 0; own rows likewise
+    ar[J] = lr; a[J] = lp;
+    const double mlr = -lr, mlp = -lp;
+    asm volatile("s_nop 1");             // (a freshly written register must not be a DPP source in the next instruction)
+    dpp_updates<J + 1>(ar, a, lr, mlr, mlp);
+    dpp_sweep<J + 1>(ar, a, ird, live_cols, dmin, bad);
+  }
+}
+
+template <bool DPP = false>
 __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, int n, double& dmin, bool& bad)
 {
   const int lane = threadIdx.x & 63;
@@ -159,6 +210,21 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
       a[q + 1] = (lane < DB && q + 1 > lane) ? 0.0 : v.y;
     }
   }
+  if constexpr (DPP) {
+    double ar[DB];
+    {
+      const int r = lane & (DB - 1);
+      const double* src = As + (DB * b + r) * LD + DB * b;
+#pragma unroll
+      for (int q = 0; q < DB; q += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(src + q);
+        ar[q] = q > r ? 0.0 : v.x;
+        ar[q + 1] = q + 1 > r ? 0.0 : v.y;
+      }
+    }
+    dpp_sweep<0>(ar, a, ird, n - (kbase + DB * b), dmin, bad);
+  }
+  else {
   // Software-pipelined by hand: the chain d_j -> 1/sqrt(d_j) -> L[:, j] -> A[:, j+1] -> d_{j+1} is issued first in every
   // step, the updates of the columns further right fill its latency.  The scheduling fences keep the compiler from
   // deferring those updates (it otherwise turns the sweep left-looking: a dependent chain of j products in front of
@@ -213,6 +279,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+  }
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < DB; ++j) As[(DB * b + j) * LD + NB] = ird[j];  // 1 / L[j][j] in the padding column of the tile image, for the block inverses
@@ -311,6 +378,7 @@ __device__ __forceinline__ void tile_inverse(const double* Ls, const double* Dis
 // Fk (chol_chain_kernel only): four flags of this tile; flag b is raised with `gen` once column block b of L_kk (its rows below the
 // diagonal block) and the inverse of its diagonal block are in global memory -- blocks 0..2 here, beside the chain (by the idle
 // fourth wave, a sweep after the block was stored); block 3 by the wave that inverts the last diagonal block.
+template <bool DPP = false>
 __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n,
                                                  int* Fk = nullptr, int gen = 0)
 {
@@ -351,7 +419,7 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
       }
       __syncthreads();
     }
-    if (w == 0) diag_sweep_block(As, b, k * NB, n, dmin, bad);
+    if (w == 0) diag_sweep_block<DPP>(As, b, k * NB, n, dmin, bad);
     else if (w == 1 && b > 0) diag_block_inverse(As, b - 1, Dg + (b - 1) * (DB * DB), Dv[b - 1]);
     else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
     __syncthreads();
@@ -831,7 +899,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
     __syncthreads();
     CS_STAMP(5);
-    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
+    diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
 #ifdef PTZ_CHOL_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     CS_STAMP(6);
@@ -1074,7 +1142,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
     __syncthreads();
     CS_STAMP(4);
-    diag_factor_tile(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
+    diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
     CS_STAMP(5);
     // (F[4 ti + 3] was raised inside, by the wave that inverted the last diagonal block)
 #ifdef PTZ_CHOL_STAMPS
