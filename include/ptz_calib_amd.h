@@ -39,6 +39,8 @@ extern "C" {
                                one batch.  The number of views and tracks is bounded by device memory only (the reduced camera
                                system is stored as dense tiles: 8 (NC n_views + 64)^2 bytes per scene).  Never a silent failure:
                                the C++ classes report it on stderr and return false. */
+#define PTZ_ENOOBS (-6)     /* ptz_ba_batch_create_views: a view none of whose tracks has a candidate observation -- no residual block, not a problem
+                               (the reference's Solve returns false there, ptzray_optimizer.cc:517); every other malformed view is PTZ_EINVAL */
 
 /* enum FACTOR_TYPE { PTZRay, PTZRayDist, PTZRayFxfyDist, PTZRayDistDisp }  (ptzray_optimizer.h:110) */
 #define PTZ_BA_PTZRay 0

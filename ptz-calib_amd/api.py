@@ -17,7 +17,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 BA_PTZRay, BA_PTZRayDist, BA_PTZRayFxfyDist, BA_PTZRayDistDisp = 0, 1, 2, 3
 KRT_F, KRT_FDist, KRT_Fxfy, KRT_FxfyDist = 0, 1, 2, 3
 PROF_SLOTS = 16
-_ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUPPORTED", -5: "PTZ_ELIMIT"}
+_ERR = {-1: "PTZ_EINVAL", -2: "PTZ_ENODEVICE", -3: "PTZ_ENOMEM", -4: "PTZ_EUNSUPPORTED", -5: "PTZ_ELIMIT", -6: "PTZ_ENOOBS"}
 
 EXPORTS = ["ptz_lm_options_default", "ptz_version", "ptz_device_count", "ptz_ba_batch_create", "ptz_ba_batch_destroy",
            "ptz_ba_batch_set_state", "ptz_ba_batch_solve", "ptz_ba_batch_get_state", "ptz_ba_batch_last_solve_ms",

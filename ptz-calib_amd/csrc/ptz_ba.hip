@@ -1681,7 +1681,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     if (h_tot[(size_t)6 * n]) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // an image twice in one track (tracks.cc:77)
     b->max_pair = 0; b->max_cam_pair = 0; b->max_cam_ent = 0; b->max_cam_run = 0;
     for (int i = 0; i < n; ++i) {
-      if (hv[i].n_obs <= 0 || hv[i].n_ray <= 0) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }  // no candidate observation: not a problem (:517)
+      if (hv[i].n_obs <= 0 || hv[i].n_ray <= 0) { ptz_ba_batch_destroy(b); return PTZ_ENOOBS; }  // no candidate observation: not a problem (:517); its own code, so that callers can tell it from a malformed view
       SceneDev& sd = b->scenes[i];
       const int* t = h_tot.data() + 6 * (size_t)i;
       sd.n_ray = hv[i].n_ray; sd.n_obs = hv[i].n_obs;

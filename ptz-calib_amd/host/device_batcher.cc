@@ -334,6 +334,8 @@ void DeviceBatcher::RunBaViewBatch(std::vector<BavReq*>& reqs)
             NowMs() - t4);
   if (rc != PTZ_OK && rc != PTZ_ENODEVICE && rc != PTZ_ENOMEM) {
     // a view without candidate observations (or an oversized one) must not fail its neighbours: every request gets its own verdict
+    // (an empty view is an everyday event of the incremental pipeline; anything else doubles the round's device work and says so)
+    if (rc != PTZ_ENOOBS) fprintf(stderr, "[ptzcalib] view batch of %d refused with code %d: its views are solved one by one\n", (int)n, (int)rc);
     for (BavReq* r : reqs) r->rc = SolveOneView(r->view, r->factor_type, r->cam, r->rkinv, r->opt, r->summary);
     return;
   }

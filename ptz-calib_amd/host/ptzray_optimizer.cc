@@ -339,7 +339,7 @@ bool PTZRayOptimizer::SolveView(std::vector<Camera>& cameras)
   const auto t_dev = std::chrono::steady_clock::now();
   const int32_t rc = DeviceBaSolveView(&view, ftype, cam.data(), rkinv.data(), &opt, &summary_);
   device_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev).count();
-  if (rc == PTZ_EINVAL) return false;  // no track has a candidate view: no residual block, not a problem (the packed path returns false there too)
+  if (rc == PTZ_ENOOBS) return false;  // no track has a candidate view: no residual block, not a problem (the packed path returns false there too)
   if (rc != PTZ_OK) {
     fprintf(stderr, "[ptzcalib] PTZRayOptimizer::Solve: device solve not run, ptz_ba_batch_create_views / solve returned %d\n", (int)rc);
     return false;

@@ -1296,6 +1296,26 @@ def test_ba_trailing_camera_without_observations_in_the_last_scene(pkg, scene_c1
         assert s2[1] == summ and np.array_equal(cams[1], cam) and np.array_equal(rays[1], ray)
 
 
+def test_chain_handover_soak(pkg):
+    """The one-launch factorisation hands tiles on through flags in global memory (relaxed agent-scope stores behind a write-back or
+    an s_waitcnt; ADVICE round 4: correct on gfx950 today, fragile by the letter of the memory model).  A hand-over that went wrong
+    would show as different bits or as a bounded wait running out (PTZ_ENODEVICE): 90 solves of one, two and five multi-tile rigs
+    must all have the bits of the first."""
+    rigs = [pkg.synth.make_scene(30 + i, 70, 300) for i in range(5)]   # 5 tiles each: hand-overs at every level
+    for n in (1, 2, 5):
+        b = pkg.api.BaBatch(rigs[:n]); b.set_state()
+        first = None
+        for it in range(30):
+            summ = b.solve(); cams, rays = b.get_state()
+            got = (summ, [c.copy() for c in cams], [r.copy() for r in rays])
+            if first is None:
+                first = got
+                continue
+            assert got[0] == first[0], (n, it)
+            assert all(np.array_equal(a, c) for a, c in zip(got[1], first[1])) and all(np.array_equal(a, c) for a, c in zip(got[2], first[2])), (n, it)
+        b.close()
+
+
 def test_ba_lost_chain_handover_is_reported_not_absorbed(pkg, scene_c1, monkeypatch):
     """chol_chain_kernel's waits are bounded (never a hang).  A wait that runs out used to mark the linear solve failed, which
     k_lm_post treats as an invalid step: a silently different, still "successful" trajectory.  With PTZ_BA_DEBUG_CHAIN_SPIN=1
@@ -1386,6 +1406,29 @@ def test_view_sort_key_overflow_is_refused(pkg):
     rig = rig_with(1500)   # 1500 * 2100 + 2100 < 2^22
     vb = pkg.api.ViewBatch([rig], [list(range(n_img))])
     vb.close(); rig.close()
+
+
+def test_view_without_candidate_observations_has_its_own_code(pkg):
+    """A view none of whose tracks has a candidate observation is an everyday event of the incremental pipeline (the reference's Solve
+    returns false, ptzray_optimizer.cc:517): ptz_ba_batch_create_views reports it as PTZ_ENOOBS, so that callers can tell it from a
+    malformed view (images not ascending: PTZ_EINVAL), which they must not pass over silently."""
+    # images 0..3; tracks only ever join images {0, 1} or {2, 3}
+    ptr = np.array([0, 2, 4, 6], dtype=np.int64)
+    img = np.array([0, 1, 0, 1, 2, 3], dtype=np.int32)
+    uv = np.full((6, 2), 100.0, dtype=np.float32)
+    rig = pkg.api.Rig(4, ptr, img, uv)
+    # a one-camera view of image 3: its only track has ONE candidate view there -- observations exist: accepted by create
+    vb = pkg.api.ViewBatch([rig], [[3]]); vb.close()
+    with pytest.raises(Exception) as ei:
+        pkg.api.ViewBatch([rig], [[1, 0]])  # not ascending
+    assert "PTZ_EINVAL" in str(ei.value)
+    rig.close()
+    # a rig whose image 2 appears in no track at all: a view of {2} alone has no observation
+    rig = pkg.api.Rig(3, np.array([0, 2], dtype=np.int64), np.array([0, 1], dtype=np.int32), np.full((2, 2), 50.0, dtype=np.float32))
+    with pytest.raises(Exception) as ei:
+        pkg.api.ViewBatch([rig], [[2]])
+    assert "PTZ_ENOOBS" in str(ei.value)
+    rig.close()
 
 
 def test_views_of_resident_rigs_are_the_batches_of_their_packed_problems(pkg):
