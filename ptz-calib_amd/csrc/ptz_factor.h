@@ -45,9 +45,9 @@ constexpr double kDblEps = 2.220446049250313e-16;
 //   * Jacobian entries and the factored forms of k_schur (products that are summed anyway): always;
 //   * the RESIDUALS of the bundle-adjustment functors on the device: as a * rcp_nr(z) (PTZ_PDIV below) -- an ulp or so from the
 //     reference's quotient; the parity tests hold costs to 1e-12 and parameters to 1e-6;
-//   * the residuals of the single-view LM (krt_eval), whose final cost feeds KRTOptimizer::CheckResults' accept test
-//     (krt_optimizer.cc:504-533): as PTZ_PDIVQ below -- the reciprocal product with one residual correction, which is the quotient
-//     itself except for double rounding in rare halfway cases;
+//   * the residuals of the single-view LM (krt_eval) inside its iterations: likewise; but the FINAL cost, which decides
+//     KRTOptimizer::CheckResults' accept test (krt_optimizer.cc:504-533), is evaluated once more at the final point with IEEE divisions
+//     (krt_eval<.., EXACT>): the gate sees the reference functor's own arithmetic (up to the order of the sum over the matches);
 //   * the host harness (tests/cpu_harness) divides everywhere.
 // A zero denominator gives NaN here where the division gives +-inf (or NaN for 0 / 0): non-finite either way, and the only thing
 // the LM loops ask of such a cost is isfinite() -- a non-finite INITIAL cost is FAILURE, a non-finite candidate a rejected step, as
@@ -67,24 +67,12 @@ PTZ_HD double rcp_nr(double d)
 // The quotient of the perspective division, a / z with iz = rcp_nr(z).  HOST build: the division, as the reference's functors
 // have it (tests/cpu_harness holds these functions to the oracle bit for bit).  DEVICE, PTZ_PDIV: a * iz -- an IEEE division is 12
 // instructions on this chip and the functors had five of them per observation, a third of the instruction stream of the
-// issue-bound k_eval / k_lin_ray / k_lin_cam loops.  DEVICE, PTZ_PDIVQ (single-view LM): q = a * iz corrected once by its own
-// residual, q + (a - q z) iz -- two more multiply-adds, and the result is the correctly rounded quotient but for halfway cases.
+// issue-bound k_eval / k_lin_ray / k_lin_cam loops.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PTZ_PDIV(a, z, iz) ((a) * (iz))
 #else
 #define PTZ_PDIV(a, z, iz) ((a) / (z))
 #endif
-PTZ_HD double pdiv_q(double a, double z, double iz)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-  const double q = a * iz;
-  return fma(fma(-q, z, a), iz, q);
-#else
-  (void)iz;
-  return a / z;
-#endif
-}
-#define PTZ_PDIVQ(a, z, iz) pdiv_q((a), (z), (iz))
 
 // cv::Rodrigues vector -> matrix (OpenCV 4.5.3 cvRodrigues2): theta < DBL_EPSILON -> I
 PTZ_HD void rodrigues(const double r[3], double R[9])
@@ -612,7 +600,7 @@ template <int KTYPE> struct KrtDims {
   static constexpr int ROT0 = 1 + FXFY;  // first rotation column
 };
 
-template <int KTYPE, bool JAC>
+template <int KTYPE, bool JAC, bool EXACT = false>
 PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, double cx, double cy, const double* kd,
                      const double ray1[3], bool skip, float u2, float v2, double res[2],
                      double J[2][KrtDims<KTYPE>::NF])
@@ -626,12 +614,12 @@ PTZ_HD void krt_eval(const double* R, const double* Jl, double fx, double fy, do
   const double Px = R[0] * ray1[0] + R[1] * ray1[1] + R[2] * ray1[2];
   const double Py = R[3] * ray1[0] + R[4] * ray1[1] + R[5] * ray1[2];
   const double Pz = R[6] * ray1[0] + R[7] * ray1[1] + R[8] * ray1[2];
-  // (the residual's quotients corrected to the last bit, PTZ_PDIVQ: the final cost decides KRTOptimizer::CheckResults' accept test)
-  const double iz = rcp_nr(Pz), x = DIST ? PTZ_PDIVQ(Px, Pz, iz) : PTZ_PDIV(Px, Pz, iz), y = DIST ? PTZ_PDIVQ(Py, Pz, iz) : PTZ_PDIV(Py, Pz, iz);
+  // (EXACT: IEEE divisions, as the reference functor has them -- the final cost's evaluation, which decides the accept test)
+  const double iz = rcp_nr(Pz), x = EXACT ? Px / Pz : PTZ_PDIV(Px, Pz, iz), y = EXACT ? Py / Pz : PTZ_PDIV(Py, Pz, iz);
   double xd = x, yd = y, B[4] = {1, 0, 0, 1}, dk1[2] = {0, 0};
   if (!DIST) {
-    res[0] = (double)u2 - PTZ_PDIVQ(fx * Px + cx * Pz, Pz, iz);
-    res[1] = (double)v2 - PTZ_PDIVQ(fy * Py + cy * Pz, Pz, iz);
+    res[0] = (double)u2 - (EXACT ? (fx * Px + cx * Pz) / Pz : PTZ_PDIV(fx * Px + cx * Pz, Pz, iz));
+    res[1] = (double)v2 - (EXACT ? (fy * Py + cy * Pz) / Pz : PTZ_PDIV(fy * Py + cy * Pz, Pz, iz));
   }
   else {
     brown(x, y, kd, xd, yd);

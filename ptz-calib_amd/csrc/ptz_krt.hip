@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
     else { const float2 a = uv_ref[m0 + m]; MatchEval<KTYPE>::ray1(kref, dref, a.x, a.y, r1, skip); }
   };
 
-  // residual-only pass at a camera vector
-  auto eval_cost = [&](const double* c) -> double {
+  // residual-only pass at a camera vector.  exact: the 2D-2D quotients as IEEE divisions (the final cost's evaluation, below)
+  auto eval_cost_impl = [&](const double* c, auto exact_tag) -> double {
+    constexpr bool EXACT = decltype(exact_tag)::value;
     double R[9];
     rodrigues(c + 4, R);
     double cost = 0;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
       double r1[3], res[2], J[2][NF];
       bool skip;
       match_ray(m, r1, skip);
-      krt_eval<KTYPE, false>(R, nullptr, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
+      krt_eval<KTYPE, false, EXACT>(R, nullptr, c[0], (KTYPE & 2) ? c[1] : c[0], c[2], c[3], c + 10, r1, skip, bq.x, bq.y, res, J);
       cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
     }
     if (P3) {
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
     }
     return group_sum<G>(cost);
   };
+  auto eval_cost = [&](const double* c) -> double { return eval_cost_impl(c, std::false_type{}); };
   // full linearisation: H = J^T J (packed lower), g = J^T r, cost
   double H[NH], g[NF];
   auto linearize = [&](const double* c) -> double {
@@ -280,15 +282,12 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
   double grad_max = 0;
 #pragma unroll
   for (int k = 0; k < NF; ++k) grad_max = fmax(grad_max, fabs(g[k]));
-  // [Ceres 1.14] a non-finite cost at the initial point (a non-finite pixel, a ray in the image plane) is FAILURE before any
-  // iteration: nothing is refined, the summary carries zeros (the oracle's lm_minimize, IterationZero)
-  const bool bad0 = !isfinite(x_cost);
-  const double initial_cost = bad0 ? 0.0 : x_cost;
-  double final_cost = initial_cost, it_cost = initial_cost;
-  int iteration = 0, n_summaries = bad0 ? 1 : 0, termination = bad0 ? PTZ_FAILURE : PTZ_NO_CONVERGENCE;
+  const double initial_cost = x_cost;
+  double final_cost = x_cost, it_cost = x_cost;
+  int iteration = 0, n_summaries = 0, termination = PTZ_NO_CONVERGENCE;
   int n_succ = 0, n_unsucc = 0, n_steps = 0, n_solves = 0, n_jac = 1, consec_invalid = 0;
   bool step_ok = true;
-  for (; !bad0;) {
+  for (;;) {
     if (step_ok) ++n_succ; else ++n_unsucc;
     if (it_cost < final_cost) final_cost = it_cost;
     ++n_summaries;
@@ -384,6 +383,16 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
     }
   }
   // ---- CheckResults (krt_optimizer.cc:504-533) + ObtainRefinedCameraParams (:535-567)
+  // The accept test compares the final reprojection error with max_reproj_error: the final cost is evaluated once more at the final
+  // point with the reference functor's own divisions (the iterations use reciprocal products, ptz_factor.h); one residual pass of the
+  // ~16 a query takes.  (Ceres' final_cost is the cost of the point it returns.)
+  if (termination == PTZ_CONVERGENCE) final_cost = eval_cost_impl(x, std::true_type{});
+  // [Ceres 1.14] a non-finite cost at the initial point (a non-finite pixel, a ray in the image plane) is FAILURE before any iteration:
+  // nothing is refined, the summary carries zeros (the oracle's lm_minimize, IterationZero).  The loop above has then spent its
+  // max_consecutive_invalid steps on not-a-numbers without moving x (a branch in front of it costs every query 136 bytes of scratch);
+  // its bookkeeping is replaced here.
+  const bool bad0 = !isfinite(initial_cost);
+  if (bad0) { termination = PTZ_FAILURE; n_summaries = 1; n_steps = 0; n_succ = 0; n_unsucc = 0; n_solves = 0; n_jac = 1; final_cost = 0.0; }
   const int num_residuals = 2 * (M + NP);
   const double final_reproj = sqrt(2.0) * sqrt((2 * final_cost) / num_residuals);
   bool ok = (termination == PTZ_CONVERGENCE) && !(final_reproj >= o.max_reproj_error);
@@ -401,10 +410,10 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
     s.num_residuals = num_residuals;
     s.num_linear_solves = n_solves;
     s.num_jacobian_evals = n_jac;
-    s.initial_cost = initial_cost;
+    s.initial_cost = bad0 ? 0.0 : initial_cost;
     s.final_cost = final_cost;
-    s.final_radius = radius;
-    s.final_gradient_max_norm = grad_max;
+    s.final_radius = bad0 ? o.initial_radius : radius;
+    s.final_gradient_max_norm = bad0 ? 0.0 : grad_max;
     summ[q] = s;
     accepted[q] = ok ? 1 : 0;
     if (ok) {
