@@ -682,10 +682,10 @@ def test_krt_batch_parity(pkg, orc, ftype):
 
 @pytest.mark.parametrize("ftype", [0, 1])
 def test_krt_accept_gate_next_to_the_threshold(pkg, orc, ftype):
-    """KRTOptimizer::CheckResults accepts a refinement when final_reproj < max_reproj_error (krt_optimizer.cc:504-533).  The device's
-    residual quotients are reciprocal products corrected by their own residual (ptz_factor.h PTZ_PDIVQ), not IEEE divisions: with the
-    threshold set a relative 1e-9 ABOVE / BELOW the oracle's own final reprojection error of every query, the device must accept /
-    reject exactly as the oracle does -- its final cost sits within 1e-9 of the reference arithmetic's where the decision is made."""
+    """KRTOptimizer::CheckResults accepts a refinement when final_reproj < max_reproj_error (krt_optimizer.cc:504-533).  Inside its
+    iterations the device's residual quotients are reciprocal products, not IEEE divisions; the FINAL cost, which this test decides on,
+    is evaluated once more with divisions (krt_eval<.., EXACT>, ptz_factor.h).  With the threshold set a relative 1e-9 ABOVE / BELOW the
+    oracle's own final reprojection error of every query, the device must accept / reject exactly as the oracle does."""
     rb = pkg.synth.make_reloc_batch(24, 128, seed_id=30 + ftype, factor_type=ftype)
     reproj = []
     for q in range(rb.n_query):
