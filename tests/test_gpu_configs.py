@@ -132,7 +132,10 @@ def test_c4_full_batch(pkg, orc):
     print(f"C4 oracle sample {spread}: LM steps {[int(its[k]) for k in spread]}, worst {worst}; scenes on which the oracle's own two "
           f"Jacobian modes take different step counts (device, numeric oracle): {sensitive}")
     assert worst["cost"] < 1e-9 and worst["f"] < 1e-6 and worst["rot"] < 1e-6, worst
-    assert len(sensitive) <= 2 and all(its[k] > 60 for k, _, _ in sensitive), sensitive  # only the long valley trajectories
+    # which scenes were held to the closed-form oracle instead of the reference-faithful one is PINNED: scene 609 (the straggler of this
+    # seed stream, 121 LM steps through a flat valley) is the only one known to be sensitive.  Any other scene turning up here is a change
+    # of the device's (or the oracle's) arithmetic and must be looked at, not absorbed.
+    assert {k for k, _, _ in sensitive} <= {609} and all(its[k] > 60 for k, _, _ in sensitive), sensitive
 
 
 def test_c4_cycled_seeds(pkg):
