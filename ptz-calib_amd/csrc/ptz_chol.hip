@@ -1478,7 +1478,12 @@ __device__ __forceinline__ void bs_load(const BsItem it, const double* Lm, const
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const double2*>(col + (size_t)r * it.ld);
 }
-__device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red, int n, int sl, int q, int c2, const double2 (&v)[16])
+// Round 5: the four quarter sums of a column meet INSIDE a wave -- a wave is (quarter = lane / 16) x (16 column pairs), so (s0 + s1)
+// is one v_permlane16_swap away and (s0 + s1) + (s2 + s3) one v_permlane32_swap further: the same sums in the same order as the LDS
+// meeting place they replace, without its two barriers per group.  What still needs a barrier is the vector t itself: an inverse
+// group (kind 1) reads t_k in all its lanes and writes x_k over it (barrier before, between and after), the update groups of a row
+// (kind 2) only read x_k and write distinct t_j -- no barrier among them.  C2: 24 barriers per back-substitution instead of 50.
+__device__ __forceinline__ void bs_partial(const BsItem it, const double* t, int q, const double2 (&v)[16], double& suma, double& sumb)
 {
   double pa = 0, pb = 0;
   if (it.kind != 0) {
@@ -1498,18 +1503,30 @@ __device__ __forceinline__ void bs_apply(const BsItem it, double* t, double* red
     pa = (a0 + a1) + (a2 + a3);
     pb = (b0 + b1) + (b2 + b3);
   }
-  double* rs = red + sl * 256;
-  *reinterpret_cast<double2*>(rs + q * 64 + c2) = make_double2(pa, pb);
-  __syncthreads();
+  // quarters q and q ^ 1 (lane distance 16), then the pairs (distance 32): lanes of quarter 0 end with (s0 + s1) + (s2 + s3)
+  { double u = pa; swap_rows16(pa, u); pa += u; }
+  { double u = pb; swap_rows16(pb, u); pb += u; }
+  { double u = pa; swap_halves32(pa, u); pa += u; }
+  { double u = pb; swap_halves32(pb, u); pb += u; }
+  suma = pa; sumb = pb;
+}
+__device__ __forceinline__ void bs_store(const BsItem it, double* t, int n, int q, int c2, double suma, double sumb)
+{
   if (q == 0 && it.kind != 0) {
-    const double2 s0 = *reinterpret_cast<const double2*>(rs + c2), s1 = *reinterpret_cast<const double2*>(rs + 64 + c2),
-                  s2 = *reinterpret_cast<const double2*>(rs + 128 + c2), s3 = *reinterpret_cast<const double2*>(rs + 192 + c2);
-    const double suma = (s0.x + s1.x) + (s2.x + s3.x), sumb = (s0.y + s1.y) + (s2.y + s3.y);
     double* out = t + it.out_off + c2;
     if (it.kind == 1) { out[0] = (it.out_off + c2 < n) ? suma : 0.0; out[1] = (it.out_off + c2 + 1 < n) ? sumb : 0.0; }
     else { out[0] -= suma; out[1] -= sumb; }
   }
-  __syncthreads();
+}
+// one group: group_kind = kind of its first item (a group is all inverses or all updates); prev_kind = the group before it (0: none)
+__device__ __forceinline__ void bs_apply(const BsItem it, int group_kind, int prev_kind, double* t, int n, int q, int c2, const double2 (&v)[16])
+{
+  if (group_kind == 1 && prev_kind != 1) __syncthreads();  // the updates of the rows above are in t (behind an inverse group the barrier is already there)
+  double suma, sumb;
+  bs_partial(it, t, q, v, suma, sumb);
+  if (group_kind == 1) __syncthreads();                    // every lane has read t_k before x_k goes over it
+  bs_store(it, t, n, q, c2, suma, sumb);
+  if (group_kind == 1) __syncthreads();                    // x_k is there for the updates that follow
 }
 
 // LIST: the work list is built once in LDS and the loads run two groups ahead.  Systems with so many block columns that the
@@ -1530,7 +1547,8 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   BsItem* items = reinterpret_cast<BsItem*>(red + BI_RED);  // LIST: [max_groups][4]
   __shared__ int n_groups;
   const int tid = threadIdx.x;
-  const int c = (tid & 31) * 2, q = (tid >> 5) & 3, sl = tid >> 7;  // c: the first of this thread's two columns
+  // wave w: slot w / 2, column half w % 2; lane: quarter of the rows = lane / 16, column pair lane % 16 (c: the first of the two columns)
+  const int c = 32 * ((tid >> 6) & 1) + 2 * (tid & 15), q = (tid >> 4) & 3, sl = tid >> 7;
   if (LIST && cb.bs_items) {  // the list was made with the structure (chol_backsolve_plan): one coalesced copy instead of wave 0's walk
     const int G = cb.bs_groups[sys];
     const long long* src = reinterpret_cast<const long long*>(cb.bs_items + (size_t)sys * 4 * max_groups);
@@ -1591,16 +1609,18 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     double2 r0[16], r1[16], r2[16];
     if (0 < G) bs_load(items[sl], Lm, Li, q, c, r0);
     if (1 < G) bs_load(items[4 + sl], Lm, Li, q, c, r1);
+    auto kind_of = [&](int g) { return g >= 0 && g < G ? (int)items[4 * g].kind : 0; };
     for (int g = 0; g < G; g += 3) {
       if (g + 2 < G) bs_load(items[4 * (g + 2) + sl], Lm, Li, q, c, r2);
-      bs_apply(items[4 * g + sl], t, red, n, sl, q, c, r0);
+      bs_apply(items[4 * g + sl], kind_of(g), kind_of(g - 1), t, n, q, c, r0);
       if (g + 1 >= G) break;
       if (g + 3 < G) bs_load(items[4 * (g + 3) + sl], Lm, Li, q, c, r0);
-      bs_apply(items[4 * (g + 1) + sl], t, red, n, sl, q, c, r1);
+      bs_apply(items[4 * (g + 1) + sl], kind_of(g + 1), kind_of(g), t, n, q, c, r1);
       if (g + 2 >= G) break;
       if (g + 4 < G) bs_load(items[4 * (g + 4) + sl], Lm, Li, q, c, r1);
-      bs_apply(items[4 * (g + 2) + sl], t, red, n, sl, q, c, r2);
+      bs_apply(items[4 * (g + 2) + sl], kind_of(g + 2), kind_of(g + 1), t, n, q, c, r2);
     }
+    __syncthreads();  // the last updates are in t before it is copied out
   }
   else {
     double2 r0[16];
@@ -1609,7 +1629,7 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
       if (c0 >= n) continue;
       BsItem it = BsItem{(long long)k * (NB * NB), NB, c0, c0, sl == 0 ? 1 : 0};
       bs_load(it, Lm, Li, q, c, r0);
-      bs_apply(it, t, red, n, sl, q, c, r0);
+      bs_apply(it, 1, 2, t, n, q, c, r0);
       for (int tj = 0; tj < k;) {  // tiles (k, tj) of the structure, four at a time, in the order the list would hold them
         int mine = -1, ns = 0;
         while (tj < k && ns < 4) {
@@ -1619,9 +1639,10 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
         if (ns == 0) break;
         it = BsItem{(long long)c0 * np + (long long)(mine < 0 ? 0 : mine) * NB, np, c0, (mine < 0 ? 0 : mine) * NB, mine >= 0 ? 2 : 0};
         bs_load(it, Lm, Li, q, c, r0);
-        bs_apply(it, t, red, n, sl, q, c, r0);
+        bs_apply(it, 2, 1, t, n, q, c, r0);
       }
     }
+    __syncthreads();
   }
   if (cb.xperm) {  // in the caller's numbering (CholBatch::xperm)
     const int* xp = cb.xperm + (size_t)sys * nt;
