@@ -193,8 +193,14 @@ template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], dou
   }
 }
 
+// DPP, b > 0: the fourth row of lanes has no rows of the tile left and carries the rows of the IDENTITY instead -- what the sweep
+// makes of them is L_bb^-T, lane r holding column r of L_bb^-1: the block's inverse is there when the sweep ends, by the same
+// multiply-adds in the same order as diag_block_inverse (bit-identical), and no wave has to compute it afterwards.  It goes to
+// dv (LDS, [16][LDD]) and, if dg is given (the last block: nothing else of it is needed by a consumer), to global memory --
+// with `flag`, as stores that go through to memory, followed by the flag itself.
 template <bool DPP = false>
-__device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, int n, double& dmin, bool& bad)
+__device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, int n, double& dmin, bool& bad, double* dv = nullptr, double* dg = nullptr,
+                                                 int* flag = nullptr, int gen = 0)
 {
   const int lane = threadIdx.x & 63;
   const int rows = NB - DB * b;  // rows 16 b .. 63 of the tile live in lanes 0 .. rows - 1
@@ -222,7 +228,28 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
         ar[q + 1] = q + 1 > r ? 0.0 : v.y;
       }
     }
+    const bool inv_rows = b > 0 && lane >= 3 * DB;
+    if (inv_rows) {
+#pragma unroll
+      for (int q = 0; q < DB; ++q) a[q] = (q == (lane & (DB - 1))) ? 1.0 : 0.0;
+    }
     dpp_sweep<0>(ar, a, ird, n - (kbase + DB * b), dmin, bad);
+    if (inv_rows) {
+      const int r = lane & (DB - 1);
+#pragma unroll
+      for (int i = 0; i < DB; ++i) dv[i * LDD + r] = a[i];
+      if (dg) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+          if (flag) __hip_atomic_store(&dg[i * DB + r], a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else dg[i * DB + r] = a[i];
+        }
+      }
+    }
+    if (dg && flag) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      if (lane == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   else {
   // Software-pipelined by hand: the chain d_j -> 1/sqrt(d_j) -> L[:, j] -> A[:, j+1] -> d_{j+1} is issued first in every
@@ -293,30 +320,29 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 
 // inverse of the 16 x 16 diagonal block b of the factored tile by forward substitution, one wave, lane c = column c of
 // X = L_bb^-1:  X[i][c] = (delta_ic - sum_{m < i} L[i][m] X[m][c]) / L[i][i]   (the L entries are LDS broadcasts)
-// (THROUGH: the stores go through to memory -- agent-scope stores -- so that a flag raised by this wave behind them, after an
-//  s_waitcnt, publishes the block without a write-back of the whole L2: the last hand-over of a tile in chol_chain_kernel)
-template <bool THROUGH = false>
 __device__ __forceinline__ void diag_block_inverse(const double* As, int b, double* out, double* out_lds)
 {
   const int lane = threadIdx.x & 63, fr = lane & 15;
   const double* Lb = As + (DB * b) * LD + DB * b;
+  // ONE chain of multiply-adds per element, m ascending: the order in which the DPP sweep (diag_sweep_block<true>) arrives at the
+  // same inverse in its spare rows of lanes -- the two must agree in every bit, the paths share their results
   double x[DB];
 #pragma unroll
   for (int i = 0; i < DB; ++i) {
-    double s0 = (i == fr) ? 1.0 : 0.0, s1 = 0.0;
+    double s = (i == fr) ? 1.0 : 0.0;
 #pragma unroll
     for (int m = 0; m + 1 < i; m += 2) {
       const double2 lv = *reinterpret_cast<const double2*>(Lb + i * LD + m);
-      s0 -= lv.x * x[m]; s1 -= lv.y * x[m + 1];
+      s = fma(lv.x, -x[m], s);
+      s = fma(lv.y, -x[m + 1], s);
     }
-    if (i & 1) s0 -= Lb[i * LD + i - 1] * x[i - 1];
-    x[i] = (s0 + s1) * As[(DB * b + i) * LD + NB];
+    if (i & 1) s = fma(Lb[i * LD + i - 1], -x[i - 1], s);
+    x[i] = s * As[(DB * b + i) * LD + NB];
   }
   if (lane < DB) {
 #pragma unroll
     for (int i = 0; i < DB; ++i) {
-      if (THROUGH) __hip_atomic_store(&out[i * DB + fr], x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else out[i * DB + fr] = x[i];
+      out[i * DB + fr] = x[i];
       out_lds[i * LDD + fr] = x[i];
     }
   }
@@ -376,29 +402,26 @@ __device__ __forceinline__ void tile_inverse(const double* Ls, const double* Dis
 }
 
 // Fk (chol_chain_kernel only): four flags of this tile; flag b is raised with `gen` once column block b of L_kk (its rows below the
-// diagonal block) and the inverse of its diagonal block are in global memory -- blocks 0..2 here, beside the chain (by the idle
-// fourth wave, a sweep after the block was stored); block 3 by the wave that inverts the last diagonal block.
+// diagonal block) and the inverse of its diagonal block are in global memory.
+// DPP (the kernels whose critical path this is: chol_chain_kernel, chol_col_step_kernel): the sweep itself leaves the inverses of
+// blocks 1..3 (diag_sweep_block), so a block is published one phase after its sweep -- the idle fourth wave stores it while the
+// others bring the next column block up to date, and fences + flags it during the next sweep; only block 0's inverse is still a
+// wave's own work (beside sweep 1).  The last block's inverse and flag leave from the sweeping wave's registers.  A consumer that
+// chases this tile is then one block round behind the end of the last sweep, not two and the inverse.
 template <bool DPP = false>
 __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * LDD], int* okflag_p, const CholBatch& cb, int sys, int k, int n,
                                                  int* Fk = nullptr, int gen = 0)
 {
   const int np = cb.np, nt = np / NB;
-  int& okflag = *okflag_p;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
   double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
   double dmin = 1.0;
   bool bad = false;
+  if (DPP && Fk && threadIdx.x == 0) *okflag_p = 0;  // block 0 has two publishers (its rows: wave 3, its inverse: wave 1): the second one raises the flag
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
-    if (w == 3 && Fk && b >= 2) {
-      // Block b - 2 was stored by waves 1 and 2 during the previous sweep and the barrier at its end lies behind them (their stores
-      // are in this XCD's L2): the fourth wave, which has no rows left to update, writes the L2 back and raises the block's flag.
-      // (A fence in the storing waves made them miss that barrier -- inverse + fence outlast a sweep.)
-      __threadfence();
-      if (lane == 0) __hip_atomic_store(&Fk[b - 2], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (b > 0) {
       // bring column block b up to date: wave w takes the 16-row block ri = b + w:  C(ri, b) -= sum_{m < b} X(ri, m) X(b, m)^T
       const int ri = b + w;
@@ -417,31 +440,44 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
 #pragma unroll
         for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = acc[i];
       }
+      if (DPP && w == 3) {  // (never has a row block to update) column block b - 1 and, behind block 0, its inverse on their way to global memory
+        diag_store_block(As, b - 1, Lg);
+        if (b - 1 > 0) {
+          const double* dv = Dv[b - 1];
+          double* dg = Dg + (b - 1) * (DB * DB);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) dg[(4 * p + fq) * DB + fr] = dv[(4 * p + fq) * LDD + fr];
+        }
+      }
       __syncthreads();
     }
-    if (w == 0) diag_sweep_block<DPP>(As, b, k * NB, n, dmin, bad);
-    else if (w == 1 && b > 0) diag_block_inverse(As, b - 1, Dg + (b - 1) * (DB * DB), Dv[b - 1]);
-    else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
+    if constexpr (DPP) {
+      if (w == 0) {
+        const bool last = b == NB / DB - 1;
+        diag_sweep_block<true>(As, b, k * NB, n, dmin, bad, Dv[b], last ? Dg + b * (DB * DB) : nullptr, (last && Fk) ? &Fk[b] : nullptr, gen);
+      }
+      else if (w == 1 && b == 1) {
+        diag_block_inverse(As, 0, Dg, Dv[0]);
+        if (Fk) {
+          __threadfence();
+          if (lane == 0 && atomicAdd(okflag_p, 1) == 1) __hip_atomic_store(&Fk[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      else if (w == 3 && b > 0 && Fk) {
+        __threadfence();
+        if (lane == 0 && (b - 1 > 0 || atomicAdd(okflag_p, 1) == 1)) __hip_atomic_store(&Fk[b - 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    else {
+      if (w == 0) diag_sweep_block<false>(As, b, k * NB, n, dmin, bad);
+      else if (w == 1 && b > 0) diag_block_inverse(As, b - 1, Dg + (b - 1) * (DB * DB), Dv[b - 1]);
+      else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
+    }
     __syncthreads();
   }
   if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
-  if (w == 1) {
-    if (Fk) {
-      // the LAST block's flag: all a consumer still needs is the inverse of the last diagonal block (the block column has no rows
-      // below it), so the wave that computes it publishes it itself -- stores through to memory, wait for them, flag -- instead of
-      // the workgroup-wide fence + barrier + flag that every other hand-over takes
-      diag_block_inverse<true>(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-      if (lane == 0) __hip_atomic_store(&Fk[NB / DB - 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    else diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
-  }
+  if (!DPP && w == 1) diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
   else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
-  else if (w == 3 && Fk) {
-    __threadfence();
-    if (lane == 0) __hip_atomic_store(&Fk[NB / DB - 2], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  (void)okflag;
   if (cb.L && cb.Linv && k == nt - 1) {
     // the last diagonal tile has no later launch whose spare workgroup could invert it
     __syncthreads();
