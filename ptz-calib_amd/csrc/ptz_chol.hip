@@ -212,20 +212,19 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 #pragma unroll
     for (int q = 0; q < DB; q += 2) {
       const double2 v = *reinterpret_cast<const double2*>(src + q);
-      a[q] = (lane < DB && q > lane) ? 0.0 : v.x;
-      a[q + 1] = (lane < DB && q + 1 > lane) ? 0.0 : v.y;
+      a[q] = (!DPP && lane < DB && q > lane) ? 0.0 : v.x;
+      a[q + 1] = (!DPP && lane < DB && q + 1 > lane) ? 0.0 : v.y;
     }
   }
   if constexpr (DPP) {
     double ar[DB];
     {
-      const int r = lane & (DB - 1);
-      const double* src = As + (DB * b + r) * LD + DB * b;
+      // (the image's diagonal blocks are zero above the diagonal: the writers of diag_factor_tile<true> and of its callers see to it)
+      const double* src = As + (DB * b + (lane & (DB - 1))) * LD + DB * b;
 #pragma unroll
       for (int q = 0; q < DB; q += 2) {
         const double2 v = *reinterpret_cast<const double2*>(src + q);
-        ar[q] = q > r ? 0.0 : v.x;
-        ar[q + 1] = q + 1 > r ? 0.0 : v.y;
+        ar[q] = v.x; ar[q + 1] = v.y;
       }
     }
     const bool inv_rows = b > 0 && lane >= 3 * DB;
@@ -307,7 +306,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
   }
 #endif
   }
-  if (lane == 0) {
+  if (lane == 0 && (!DPP || b == 0)) {  // (DPP: only block 0's inverse is still computed from the image)
 #pragma unroll
     for (int j = 0; j < DB; ++j) As[(DB * b + j) * LD + NB] = ird[j];  // 1 / L[j][j] in the padding column of the tile image, for the block inverses
   }
@@ -422,10 +421,28 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
   if (DPP && Fk && threadIdx.x == 0) *okflag_p = 0;  // block 0 has two publishers (its rows: wave 3, its inverse: wave 1): the second one raises the flag
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
+    // C(ri, c) -= X(ri, m) X(c, m)^T on the matrix cores, one wave; `diag`: the finished diagonal block goes back with zeros above its diagonal
+    auto rank16 = [&](int ri, int c, int m, bool diag) {
+      double* C = As + (DB * ri) * LD + DB * c;
+      const double* Xi = As + (DB * ri) * LD + DB * m;
+      const double* Xj = As + (DB * c) * LD + DB * m;
+      d4 acc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = C[(fq + 4 * i) * LD + fr];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[fr * LD + 4 * ks + fq], Xj[fr * LD + 4 * ks + fq], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = (diag && fr > fq + 4 * i) ? 0.0 : acc[i];
+    };
     if (b > 0) {
       // bring column block b up to date: wave w takes the 16-row block ri = b + w:  C(ri, b) -= sum_{m < b} X(ri, m) X(b, m)^T
+      // (DPP: only m = b - 1 is left to do here -- the earlier column blocks' shares were applied beside the sweeps, see below; the
+      //  same products added in the same order, the block in LDS between them)
       const int ri = b + w;
       if (ri < NB / DB) {
+        if constexpr (DPP) rank16(ri, b, b - 1, ri == b);
+        else {
         double* C = As + (DB * ri) * LD + DB * b;
         d4 acc;
 #pragma unroll
@@ -439,6 +456,7 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = acc[i];
+        }
       }
       if (DPP && w == 3) {  // (never has a row block to update) column block b - 1 and, behind block 0, its inverse on their way to global memory
         diag_store_block(As, b - 1, Lg);
@@ -466,6 +484,12 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
       else if (w == 3 && b > 0 && Fk) {
         __threadfence();
         if (lane == 0 && (b - 1 > 0 || atomicAdd(okflag_p, 1) == 1)) __hip_atomic_store(&Fk[b - 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      else if (w == 2 && b > 0) {
+        // beside the sweep of column block b: the share of column block b - 1 in the column blocks BEHIND b, which the chain does
+        // not need yet (right-looking for them, so that what stands between two sweeps is one rank-16 update, not b of them)
+        for (int c = b + 1; c < NB / DB; ++c)
+          for (int ri = c; ri < NB / DB; ++ri) rank16(ri, c, b - 1, false);
       }
     }
     else {
@@ -932,7 +956,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = (c == w && fr > fq + 4 * i) ? 0.0 : acc[c][i];  // (diag_factor_tile<true>: zero above the diagonal)
     __syncthreads();
     CS_STAMP(5);
     diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
@@ -1175,7 +1199,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc[c][i];
+      for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = (c == w && fr > fq + 4 * i) ? 0.0 : acc[c][i];  // (diag_factor_tile<true>: zero above the diagonal)
     __syncthreads();
     CS_STAMP(4);
     diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
