@@ -177,6 +177,30 @@ def load_traffic(tag):
     return tj.get("families")
 
 
+def c2_floor_model():
+    """What ONE LM iteration of the C2 rig costs at least with the present structure, term by term (profiles/NOTES_r05.md section 4d-4f:
+    every constant is a probe's measurement on MI355X, none is fitted to the bench figure).  The 800 x 800 reduced camera system is
+    13 tiles of 64 columns in 8 levels of the dissected elimination order; a level is one diagonal tile's factorisation (four 16-pivot
+    sweeps of one wave, a rank-16 update between two sweeps) plus the hand-over to the next level's tile on another compute unit."""
+    levels, sweeps, pivots = 8, 4, 16
+    ns_pivot = 200 / 2.4                 # 200 cycles per pivot of the DPP sweep in the product (sweep16_probe: 171 alone) at 2.4 GHz
+    t = {
+        "chain_pivots": levels * sweeps * pivots * ns_pivot * 1e-3,      # the dependent chain itself
+        "chain_sweep_lds": levels * sweeps * 0.45,                       # a sweep's column block from LDS and back (1 100 cycles)
+        "chain_rank16_updates": levels * (sweeps - 1) * 0.40,            # MFMA update + two barriers between two sweeps
+        "chain_hand_overs": (levels - 1) * 4.0,                          # flag + block across compute units, solve, update, to LDS
+        "chain_second_ready_column": 2 * 5.5,                            # levels 2 and 4: two producers end together, applied in turn
+        "chain_last_tile_inverse": 3.0,
+        "back_substitution": 2.4e6 / 142e9 * 1e6 + 9 * 0.9 + 2.5,        # 2.4 MB through ONE compute unit at 142 GB/s, nine inverse groups, start
+        "k_eval": 27.0, "k_lin_cam_and_control": 17.0, "k_schur_f": 16.0, "k_ray_prep": 7.0,   # longest thread's work, one wave per SIMD
+    }
+    out = {k: round(v, 1) for k, v in t.items()}
+    out["total_us"] = round(sum(t.values()), 1)
+    out["note"] = ("sum of the dependent stretches of one pass; launch boundaries inside the replayed graph not counted.  The north star's "
+                   "10 k it/s is 100 us per iteration: below this structure's floor -- NOTES_r05 4f says what would have to change")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------ legs
 def single_rig_leg(pkg, scene, device_id):
     """BASELINE configs[1]: ONE 200 x 500 rig alone on the GPU.  Wall time of a whole solve (graph-replayed passes, nothing
@@ -193,11 +217,15 @@ def single_rig_leg(pkg, scene, device_id):
     dev_ms = b1.last_solve_ms()
     b1.close()
     per_pass = {k: round(1e3 * v["ms"] / steps, 2) for k, v in prof.items() if v["launches"] > 0}
+    us = 1e6 * best / steps
+    floor = c2_floor_model()
+    floor.update(measured_us_per_lm_iteration=round(us, 1), measured_over_floor=round(us / floor["total_us"], 2))
     return {"workload": f"C2: one rig, {scene.n_cam} views x {scene.n_obs // scene.n_cam} obs/view ({scene.n_obs} observations, "
                         f"{scene.n_ray} rays), solved alone",
             "lm_iterations_per_s": steps / best, "views_per_s": scene.n_cam / best, "ms_per_solve": 1e3 * best, "lm_steps": steps,
             "us_per_lm_iteration": 1e6 * best / steps,
             "per_pass_critical_path_us": per_pass,
+            "floor_model": floor,
             "per_pass_critical_path_note": "HIP events around every kernel family of an eagerly enqueued solve (event pairs add "
                                            f"a few us per family); that profiled solve took {dev_ms:.2f} ms on the device",
             "termination_type": s1[0]["termination_type"]}
