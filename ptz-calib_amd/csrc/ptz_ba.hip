@@ -71,6 +71,7 @@ struct PassShape {
   int ray_block = 1024;   // rays per workgroup of the ray-centric kernels
   bool small_blocks = false, fused = false;  // SMALL kernel variants; one-launch-per-column factorisation
   bool fuse_ctl = false;  // LM control and the camera update inside k_eval / k_lin_cam (no k_lm_pre / k_lm_post / k_cam_update launches)
+  int eval_lanes = 1;     // lanes per ray in k_eval (4: the form of a few scenes, see k_eval)
   int max_chunk = 0;
   size_t lin_smem = 0, eval_smem = 0;
 };
@@ -544,7 +545,8 @@ template <int TYPE> void enqueue_pass(ptz_ba_batch* b, const Dev& dgrp, const Pa
   }
   b->prof_begin(P_EVAL);
   if constexpr (TYPE < 3) {
-    if (fuse) LAUNCH((k_eval<TYPE, true, false, true>), dim3(sh.max_chunk, B), dim3(sh.ray_block), sh.eval_smem, d);
+    if (fuse && sh.eval_lanes == 4) LAUNCH((k_eval<TYPE, true, false, true, 4>), dim3(sh.max_chunk, B), dim3(sh.ray_block * 4), sh.eval_smem, d);
+    else if (fuse) LAUNCH((k_eval<TYPE, true, false, true>), dim3(sh.max_chunk, B), dim3(sh.ray_block), sh.eval_smem, d);
     else PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
   }
   else PTZ_LAUNCH_RAY(k_eval, dim3(sh.max_chunk, B), sh.eval_smem, d);
@@ -2089,6 +2091,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     // a few scenes: LM control and the camera update ride in the tails / prologue of k_eval and k_lin_cam (three launches less per pass)
     sh.fuse_ctl = slots <= 8 && sh.small_blocks && !b->gtab;
     if (const char* e = getenv("PTZ_BA_FUSE_CTL")) sh.fuse_ctl = sh.fuse_ctl && atoi(e) != 0;
+    sh.eval_lanes = (sh.fuse_ctl && sh.ray_block <= 128) ? 4 : 1;
+    if (const char* e = getenv("PTZ_BA_EVAL_LANES")) sh.eval_lanes = (atoi(e) == 4 && sh.fuse_ctl && sh.ray_block <= 128) ? 4 : 1;  // (tests: the same bits either way)
     sh.max_chunk = (b->max_ray + sh.ray_block - 1) / sh.ray_block;
     const size_t obs_lds = sh.small_blocks ? (size_t)OBS_PREFETCH_BYTES * sh.ray_block : 0;
     if (b->gtab) { sh.eval_smem = sizeof(double) * 16 + obs_lds + 16; sh.lin_smem = obs_lds + 16; }
@@ -2160,6 +2164,9 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       raise_cap((const void*)k_lin_ray<T, true, false>);    \
       raise_cap((const void*)k_lin_ray<T, false, false>);
       raise_cap((const void*)k_eval<0, true, false, true>);
+      raise_cap((const void*)k_eval<0, true, false, true, 4>);
+      raise_cap((const void*)k_eval<1, true, false, true, 4>);
+      raise_cap((const void*)k_eval<2, true, false, true, 4>);
       raise_cap((const void*)k_schur_f<0, false>);
       raise_cap((const void*)k_schur_f<0, true>);
       raise_cap((const void*)k_schur_f<4, false>);

@@ -2469,7 +2469,7 @@ __global__ void k_cam_update(Dev d)
 #ifdef PTZ_EVAL_STAMPS  // probe builds only: where k_eval's time goes (block 0, thread 0; 100 MHz wall clock)
 #define EV_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ev_t[i] = wall_clock64(); } while (0)
 #define EV_STAMP_DECL long long ev_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define EV_STAMP_PRINT do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) printf("k_eval stamps (x10 ns): stage %lld, step table %lld, ray prologue %lld, pass1 %lld, mid %lld, pass2 %lld, reduce %lld\n", ev_t[1] - ev_t[0], ev_t[2] - ev_t[1], ev_t[3] - ev_t[2], ev_t[4] - ev_t[3], ev_t[5] - ev_t[4], ev_t[6] - ev_t[5], ev_t[7] - ev_t[6]); } while (0)
+#define EV_STAMP_PRINT do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) printf("k_eval stamps (x10 ns): stage (FUSE: inputs asked for + table staged) %lld, step table (FUSE: candidates computed) %lld, ray prologue (FUSE: + barrier) %lld, pass1 %lld, mid %lld, pass2 %lld, reduce %lld\n", ev_t[1] - ev_t[0], ev_t[2] - ev_t[1], ev_t[3] - ev_t[2], ev_t[4] - ev_t[3], ev_t[5] - ev_t[4], ev_t[6] - ev_t[5], ev_t[7] - ev_t[6]); } while (0)
 #else
 #define EV_STAMP(i) do { } while (0)
 #define EV_STAMP_DECL do { } while (0)
@@ -2478,9 +2478,18 @@ __global__ void k_cam_update(Dev d)
 // FUSE (launch shapes of a few scenes, Dev::fuse_ctl): the launch also does what k_cam_update does before it -- every workgroup
 // computes the scene's candidate cameras into its LDS tables, the first one stores them.  (The step is judged behind the
 // speculative camera-side linearisation of the candidate, in k_lin_cam's tail: lm_step_wave.)
-template <int TYPE, bool SMALL, bool GTAB, bool FUSE = false>
-__global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
+// LANES = 4 (a few scenes, FUSE): FOUR lanes per ray.  One rig alone keeps one wave per SIMD busy and a kernel lasts as long as its
+// longest ray's observations one after the other (19 of them, twice); here a quad of lanes takes four observations at a time -- the
+// functor, which is nearly all of the work, in parallel -- and then every lane of the quad adds the four observations' terms to its
+// own copy of the ray's sums IN THE ORDER OF THE OBSERVATIONS (quad broadcasts): the same terms, added in the same order by the same
+// expressions as the one-lane form, so a scene keeps its bits whatever form its batch runs in.
+template <int Q> __device__ __forceinline__ double quad_bc(double v) { return dpp_mov<Q * 0x55>(v); }  // lane Q of the quad, in all four
+template <int TYPE, bool SMALL, bool GTAB, bool FUSE = false, int LANES = 1>
+__global__ __launch_bounds__(LANES > 1 ? 128 * LANES : (SMALL ? 256 : RAY_BLOCK)) void k_eval(Dev d)
 {
+  static_assert(LANES == 1 || (LANES == 4 && FUSE), "four lanes per ray: the form of a few scenes");
+  const int RB = blockDim.x / LANES;         // rays per workgroup
+  const int lp = threadIdx.x & (LANES - 1);  // this lane's place in its ray's group of lanes
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
@@ -2491,7 +2500,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
   if (!d.active[sc]) return;
   const SceneDev s = d.scene[sc];
   const LmState& st = d.lm[sc];
-  if ((int)(blockIdx.x * blockDim.x) >= s.n_ray) return;
+  if ((int)(blockIdx.x * RB) >= s.n_ray) return;
   EV_STAMP_DECL;
   EV_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2515,17 +2524,22 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     if constexpr (FUSE) {
       // The candidates of ALL the scene's cameras, by every workgroup: the inputs of a thread's first camera are asked for in
       // front of the table's staging loads (one memory round trip for both), the arithmetic runs behind them
+      // (the ONE workgroup that also stores them -- with the SO(3) Jacobians, the full blocks, the step norms: three times the work
+      //  of the others -- is the scene's LAST: rays are ordered by falling track length, so it is the one with the least to do after)
+      const bool store_cand = (int)blockIdx.x == (s.n_ray - 1) / RB;
       CamIn<TYPE> in;
       cam_update_load<TYPE>(d, s, st, sc, min((int)threadIdx.x, s.n_cam - 1), in);
       tab = tab0 + stage_flat<16>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
+      EV_STAMP(1);
       if ((int)threadIdx.x < s.n_cam)
-        cam_update_apply<TYPE>(d, s, st, sc, threadIdx.x, in, blockIdx.x == 0, ctab0 + threadIdx.x * CDS, dct0 + threadIdx.x * DCS);
+        cam_update_apply<TYPE>(d, s, st, sc, threadIdx.x, in, store_cand, ctab0 + threadIdx.x * CDS, dct0 + threadIdx.x * DCS);
       for (int i = threadIdx.x + blockDim.x; i < s.n_cam; i += blockDim.x) {
         cam_update_load<TYPE>(d, s, st, sc, i, in);
-        cam_update_apply<TYPE>(d, s, st, sc, i, in, blockIdx.x == 0, ctab0 + i * CDS, dct0 + i * DCS);
+        cam_update_apply<TYPE>(d, s, st, sc, i, in, store_cand, ctab0 + i * CDS, dct0 + i * DCS);
       }
       ctab = ctab0;
       dct = dct0;
+      EV_STAMP(2);
     }
     else {
       tab = tab0 + stage_flat<SMALL ? 16 : 8>(cur_camblk(d, st) + (size_t)s.cam_off * CBS, tab0, s.n_cam * CBS);
@@ -2534,9 +2548,8 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     }
     __syncthreads();
   }
-  EV_STAMP(1);
-  EV_STAMP(2);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (!FUSE) { EV_STAMP(1); EV_STAMP(2); }
+  const int j = blockIdx.x * RB + (int)threadIdx.x / LANES;
   double mcc = 0, cost = 0, dn = 0, cn = 0;
   double lgm = 0;  // the candidate's share of the gradient max-norm (k_lm_pre, if the step is accepted; its |x|^2 share is cn)
   const int gj = s.ray_off + j;
@@ -2561,16 +2574,48 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     double Xu[3], inv_n;  // the functor's point for this ray, once for all of its observations
     ba_ray_point<F>(Xr, Xu, inv_n);
     EV_STAMP(3);
-    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
+    // one observation's terms: what it adds to s1 and (before the ray's scales) to t
+    auto terms1 = [&](float2 uv, int ci, double& X, double (&Y)[3]) {
       const double* cb = tab + ci * CBS;
       double res[2], pd[2], Jr[2][3];
       ba_step_dir_unit<F>(cb, Xu, inv_n, uv.x, uv.y, dct + ci * DCS, dct + ci * DCS + (NW - 3), res, pd, Jr);
       const double m0 = sw * pd[0], m1 = sw * pd[1];
-      s1 += m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
-      t0 += sw * sr[0] * (Jr[0][0] * m0 + Jr[1][0] * m1);
-      t1 += sw * sr[1] * (Jr[0][1] * m0 + Jr[1][1] * m1);
-      t2 += sw * sr[2] * (Jr[0][2] * m0 + Jr[1][2] * m1);
-    });
+      X = m0 * (res[0] * sw + m0 / 2.0) + m1 * (res[1] * sw + m1 / 2.0);
+      Y[0] = Jr[0][0] * m0 + Jr[1][0] * m1;
+      Y[1] = Jr[0][1] * m0 + Jr[1][1] * m1;
+      Y[2] = Jr[0][2] * m0 + Jr[1][2] * m1;
+    };
+    auto add1 = [&](double X, double Y0, double Y1, double Y2) {
+      s1 += X;
+      t0 += sw * sr[0] * Y0;
+      t1 += sw * sr[1] * Y1;
+      t2 += sw * sr[2] * Y2;
+    };
+    if constexpr (LANES == 1) {
+      for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
+        double X, Y[3];
+        terms1(uv, ci, X, Y);
+        add1(X, Y[0], Y[1], Y[2]);
+      });
+    }
+    else {
+      const int len = a1 - a0;
+      int an = min(a0 + lp, a1 - 1);
+      float2 uvn = d.obs_uv[an];
+      int cin = d.obs_cam[an];
+      for (int base = 0; base < len; base += LANES) {
+        const float2 uv = uvn;
+        const int ci = cin;
+        an = min(a0 + base + LANES + lp, a1 - 1);   // the next round's record is on its way (past the end: the last one again, unused)
+        uvn = d.obs_uv[an]; cin = d.obs_cam[an];
+        double X, Y[3];
+        terms1(uv, ci, X, Y);
+        add1(quad_bc<0>(X), quad_bc<0>(Y[0]), quad_bc<0>(Y[1]), quad_bc<0>(Y[2]));
+        if (base + 1 < len) add1(quad_bc<1>(X), quad_bc<1>(Y[0]), quad_bc<1>(Y[1]), quad_bc<1>(Y[2]));
+        if (base + 2 < len) add1(quad_bc<2>(X), quad_bc<2>(Y[0]), quad_bc<2>(Y[1]), quad_bc<2>(Y[2]));
+        if (base + 3 < len) add1(quad_bc<3>(X), quad_bc<3>(Y[0]), quad_bc<3>(Y[1]), quad_bc<3>(Y[2]));
+      }
+    }
     EV_STAMP(4);
     const double2 E01 = *e_piece(d, 0, gj), E23 = *e_piece(d, 1, gj), E45 = *e_piece(d, 2, gj);
     const double E[6] = {E01.x, E01.y, E23.x, E23.y, E45.x, E45.y};
@@ -2578,7 +2623,7 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     const double ds[3] = {-(E[0] * t0 + E[1] * t1 + E[3] * t2), -(E[1] * t0 + E[2] * t1 + E[4] * t2), -(E[3] * t0 + E[4] * t1 + E[5] * t2)};
     Xn[0] = Xr[0] + ds[0] * sr[0]; Xn[1] = Xr[1] + ds[1] * sr[1]; Xn[2] = Xr[2] + ds[2] * sr[2];
     double* xc = d.ray_x + (size_t)(st.cur ^ 1) * d.ray_stride + (size_t)gj * 3;
-    xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2];
+    if (lp == 0) { xc[0] = Xn[0]; xc[1] = Xn[1]; xc[2] = Xn[2]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { dn += (Xr[k] - Xn[k]) * (Xr[k] - Xn[k]); cn += Xn[k] * Xn[k]; }  // |x - x_c|^2, |x_c|^2 (k_lm_post)
     {
@@ -2590,13 +2635,15 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     }
   }
   // the first pass's sums leave the registers now: one partial per wave of 64 rays (fixed butterfly), whatever the workgroup size
-  mcc = wave_sum(mcc);
-  dn = wave_sum(dn);
-  cn = wave_sum(cn);
-  if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
-    double* pp = d.partial + (size_t)(s.part_off + (j >> 6)) * 4;
-    pp[0] = mcc; pp[2] = dn; pp[3] = cn;
-    lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2 + 1] = cn;  // |x_c|^2 is the accepted point's |x|^2 (k_lm_pre)
+  if constexpr (LANES == 1) {
+    mcc = wave_sum(mcc);
+    dn = wave_sum(dn);
+    cn = wave_sum(cn);
+    if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
+      double* pp = d.partial + (size_t)(s.part_off + (j >> 6)) * 4;
+      pp[0] = mcc; pp[2] = dn; pp[3] = cn;
+      lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2 + 1] = cn;  // |x_c|^2 is the accepted point's |x|^2 (k_lm_pre)
+    }
   }
   if (j < s.n_ray) {
     // pass 2: candidate cost, and -- for the price of the ray Jacobian on top of the residual -- the ray side of the candidate's
@@ -2607,23 +2654,70 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     ba_ray_point<F>(Xn, Xcu, inv_nc);
     EV_STAMP(5);
     double Vc[6] = {0, 0, 0, 0, 0, 0}, gc3[3] = {0, 0, 0};
-    for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
+    // T[0]: the squared residual; T[1..6]: the observation's share of V; T[7..9]: of g_r
+    auto terms2 = [&](float2 uv, int ci, double (&T)[10]) {
       double rc[2], Jr[2][3];
       ba_res_jr_unit<F>(ctab + ci * CDS, Xcu, inv_nc, uv.x, uv.y, rc, Jr);
-      cost += 0.5 * (w * (rc[0] * rc[0] + rc[1] * rc[1]));
+      T[0] = rc[0] * rc[0] + rc[1] * rc[1];
       rc[0] *= sw; rc[1] *= sw;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { const double m = sw * sr[k]; Jr[0][k] *= m; Jr[1][k] *= m; }
-      Vc[0] += Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
-      Vc[1] += Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
-      Vc[2] += Jr[0][1] * Jr[0][1] + Jr[1][1] * Jr[1][1];
-      Vc[3] += Jr[0][2] * Jr[0][0] + Jr[1][2] * Jr[1][0];
-      Vc[4] += Jr[0][2] * Jr[0][1] + Jr[1][2] * Jr[1][1];
-      Vc[5] += Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
+      T[1] = Jr[0][0] * Jr[0][0] + Jr[1][0] * Jr[1][0];
+      T[2] = Jr[0][1] * Jr[0][0] + Jr[1][1] * Jr[1][0];
+      T[3] = Jr[0][1] * Jr[0][1] + Jr[1][1] * Jr[1][1];
+      T[4] = Jr[0][2] * Jr[0][0] + Jr[1][2] * Jr[1][0];
+      T[5] = Jr[0][2] * Jr[0][1] + Jr[1][2] * Jr[1][1];
+      T[6] = Jr[0][2] * Jr[0][2] + Jr[1][2] * Jr[1][2];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) gc3[k] += Jr[0][k] * rc[0] + Jr[1][k] * rc[1];
-    });
-    {
+      for (int k = 0; k < 3; ++k) T[7 + k] = Jr[0][k] * rc[0] + Jr[1][k] * rc[1];
+    };
+    auto add2 = [&](const double (&T)[10]) {
+      cost += 0.5 * (w * T[0]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Vc[k] += T[1 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gc3[k] += T[7 + k];
+    };
+    if constexpr (LANES == 1) {
+      for_each_obs<SMALL>(d, a0, a1, obsbuf, [&](float2 uv, int ci) {
+        double T[10];
+        terms2(uv, ci, T);
+        add2(T);
+      });
+    }
+    else {
+      const int len = a1 - a0;
+      int an = min(a0 + lp, a1 - 1);
+      float2 uvn = d.obs_uv[an];
+      int cin = d.obs_cam[an];
+      for (int base = 0; base < len; base += LANES) {
+        const float2 uv = uvn;
+        const int ci = cin;
+        an = min(a0 + base + LANES + lp, a1 - 1);
+        uvn = d.obs_uv[an]; cin = d.obs_cam[an];
+        double T[10], B[10];
+        terms2(uv, ci, T);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) B[k] = quad_bc<0>(T[k]);
+        add2(B);
+        if (base + 1 < len) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) B[k] = quad_bc<1>(T[k]);
+          add2(B);
+        }
+        if (base + 2 < len) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) B[k] = quad_bc<2>(T[k]);
+          add2(B);
+        }
+        if (base + 3 < len) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) B[k] = quad_bc<3>(T[k]);
+          add2(B);
+        }
+      }
+    }
+    if (lp == 0) {
       const int hc = st.cur ^ 1;
       double* Vo = lin_V(d, hc) + (size_t)gj * 6;
       double* go = lin_gr(d, hc) + (size_t)gj * 3;
@@ -2638,11 +2732,34 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_eval(Dev d)
     }
   }
   EV_STAMP(6);
-  lgm = wave_max(lgm);
-  cost = wave_sum(cost);
-  if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
-    lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2] = lgm;
-    d.partial[(size_t)(s.part_off + (j >> 6)) * 4 + 1] = cost;
+  if constexpr (LANES == 1) {
+    lgm = wave_max(lgm);
+    cost = wave_sum(cost);
+    if ((threadIdx.x & 63) == 0 && j < s.n_ray) {
+      lin_partial(d, st.cur ^ 1)[(size_t)(s.part_off - s.idx + (j >> 6)) * 2] = lgm;
+      d.partial[(size_t)(s.part_off + (j >> 6)) * 4 + 1] = cost;
+    }
+  }
+  else {
+    // the partials of a wave of 64 RAYS, as the one-lane form sums them (the same butterfly over the same 64 values): the rays' values
+    // meet in LDS, ray r of the workgroup in lane r of the first waves
+    double* red = reinterpret_cast<double*>(obsbuf);  // [5][RB] (the observation slots of the one-lane form, unused here: 128 bytes per ray)
+    if (lp == 0) {
+      const int r = threadIdx.x / LANES;
+      red[r] = mcc; red[RB + r] = dn; red[2 * RB + r] = cn; red[3 * RB + r] = cost; red[4 * RB + r] = lgm;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < RB) {
+      const int r = threadIdx.x, jr = blockIdx.x * RB + r;
+      double v0 = wave_sum(red[r]), v2 = wave_sum(red[RB + r]), v3 = wave_sum(red[2 * RB + r]), v1 = wave_sum(red[3 * RB + r]);
+      const double vm = wave_max(red[4 * RB + r]);
+      if ((r & 63) == 0 && jr < s.n_ray) {
+        double* pp = d.partial + (size_t)(s.part_off + (jr >> 6)) * 4;
+        pp[0] = v0; pp[1] = v1; pp[2] = v2; pp[3] = v3;
+        double* pl = lin_partial(d, st.cur ^ 1) + (size_t)(s.part_off - s.idx + (jr >> 6)) * 2;
+        pl[0] = vm; pl[1] = v3;
+      }
+    }
   }
   (void)scratch;
   EV_STAMP(7);

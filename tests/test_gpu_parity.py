@@ -1572,6 +1572,20 @@ def test_ba_global_memory_variants_reproduce_the_bits(pkg, monkeypatch):
         assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), var
 
 
+def test_ba_eval_with_four_lanes_per_ray_reproduces_the_bits(pkg, monkeypatch):
+    """A few scenes run k_eval with four lanes per ray (the functor of four observations side by side, their terms then added to the
+    ray's sums in the order of the observations by quad broadcasts); one lane per ray (PTZ_BA_EVAL_LANES=1, the form of every larger
+    batch) gives the same bits -- for the three 2D-2D factor types the form exists for, with rays of every length from 2 up and a
+    ray count that is no multiple of the workgroup's."""
+    for ft, views, obs in ((0, 200, 500), (1, 60, 300), (2, 40, 257)):
+        sc = pkg.synth.make_scene(21 + ft, views, obs, factor_type=ft)
+        four = pkg.api.ba_solve(sc)
+        monkeypatch.setenv("PTZ_BA_EVAL_LANES", "1")
+        one = pkg.api.ba_solve(sc)
+        monkeypatch.delenv("PTZ_BA_EVAL_LANES")
+        assert four[2] == one[2] and np.array_equal(four[0], one[0]) and np.array_equal(four[1], one[1]), ft
+
+
 def test_ba_elimination_orders_agree(pkg, orc, monkeypatch):
     """The dissected elimination order of the reduced camera system (two arcs of the ring side by side, separators last) is a
     symmetric permutation of the same exact factorisation: against the images' own order (PTZ_BA_ORDER=natural) the LM
