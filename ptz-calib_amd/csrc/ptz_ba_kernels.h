@@ -475,6 +475,13 @@ __global__ __launch_bounds__(SMALL ? 256 : RAY_BLOCK) void k_lin_ray(Dev d)
 template <int TYPE, bool WRITE_W>
 __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 {
+#ifdef PTZ_LINCAM_STAMPS  // probe builds only (block 0, thread 0; 100 MHz wall clock)
+  long long lc_t[6] = {0, 0, 0, 0, 0, 0};
+#define LC_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lc_t[i] = wall_clock64(); } while (0)
+#else
+#define LC_STAMP(i) do { } while (0)
+#endif
+  LC_STAMP(0);
   constexpr int CBS = Dims<TYPE>::CBS, CDS = Dims<TYPE>::CDS, CAMBLK = Dims<TYPE>::CAMBLK, CANDBLK = Dims<TYPE>::CANDBLK;
   (void)CBS; (void)CDS; (void)CAMBLK; (void)CANDBLK;
   constexpr int NC = Dims<TYPE>::NC, NW = Dims<TYPE>::NW, F = Dims<TYPE>::FACTOR;
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 #pragma unroll
   for (int k = 0; k < CAMBLK; ++k) cb[k] = camblk_h[(size_t)gi * CBS + k];
   const int* cp = d.cam_ptr + s.cam_off + s.idx;
+  LC_STAMP(1);
   double U[NW * (NW + 1) / 2], g[NW], cost = 0;
 #pragma unroll
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = 0;
@@ -579,6 +587,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
       __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is rewritten in the next trip
     }
   }
+  LC_STAMP(2);
   cost = wave_sum(cost);
 #pragma unroll
   for (int k = 0; k < NW; ++k) g[k] = wave_sum(g[k]);
@@ -621,11 +630,18 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
     }
   }
   }
+  LC_STAMP(3);
   if constexpr (!Dims<TYPE>::HAS3D) {
     if (!d.fuse_ctl) return;
     // the last workgroup of the scene judges the step and opens the next iteration (what a k_lm_step launch would do)
     __shared__ int tail_flag;
-    if (tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag)) lm_step_wave<TYPE>(d, sc);
+    const bool last_wg = tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag);
+    LC_STAMP(4);
+    if (last_wg) lm_step_wave<TYPE>(d, sc);
+#ifdef PTZ_LINCAM_STAMPS
+    LC_STAMP(5);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) printf("k_lin_cam stamps (x10 ns): camera block %lld, trips %lld, sums + stores %lld, tail counter %lld\n", lc_t[1] - lc_t[0], lc_t[2] - lc_t[1], lc_t[3] - lc_t[2], lc_t[4] - lc_t[3]);
+#endif
   }
 }
 
