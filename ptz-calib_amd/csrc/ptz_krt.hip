@@ -105,10 +105,16 @@ struct MatchEval {
 // matches each, reduce in four steps, and a wave's redundant solves serve four queries.  The two forms sum in different
 // orders: a query's bits depend on the form, never on its neighbours in the launch (ptz_krt_solve_batch picks the form from
 // the launch size alone, krt_group_size()).
+// (the butterfly v += v[lane ^ off], off = G / 2 .. 1, with the partners fetched by v_permlane32/16_swap and DPP instead of
+//  ds_bpermute -- 21 sums of four to six steps per linearisation: the same partners, the same sums, the same bits)
 template <int G> __device__ __forceinline__ double group_sum(double v)
 {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+  static_assert(G == 64 || G == 16, "a wave or a DPP row of lanes per query");
+  if (G == 64) return wave_sum(v);
+  v += lane_xor_dpp<8>(v);
+  v += lane_xor_dpp<4>(v);
+  v += lane_xor_dpp<2>(v);
+  v += lane_xor_dpp<1>(v);
   return v;
 }
 template <int G> struct KrtCache { static constexpr int N = G == 64 ? 256 : 128; };  // matches per query whose constant part is cached
