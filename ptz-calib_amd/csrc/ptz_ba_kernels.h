@@ -637,8 +637,12 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
     __shared__ int tail_flag;
     const bool last_wg = tail_last_workgroup(d.tail_cnt + 2 * sc + 1, (s.n_cam + 3) / 4, &tail_flag);
     LC_STAMP(4);
+#ifdef PTZ_LINCAM_STAMPS
+    const long long lc_s0 = wall_clock64();
+#endif
     if (last_wg) lm_step_wave<TYPE>(d, sc);
 #ifdef PTZ_LINCAM_STAMPS
+    if (last_wg && threadIdx.x == 0) printf("k_lin_cam: lm_step_wave in the last workgroup (%d) %lld x10 ns\n", (int)blockIdx.x, wall_clock64() - lc_s0);
     LC_STAMP(5);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) printf("k_lin_cam stamps (x10 ns): camera block %lld, trips %lld, sums + stores %lld, tail counter %lld\n", lc_t[1] - lc_t[0], lc_t[2] - lc_t[1], lc_t[3] - lc_t[2], lc_t[4] - lc_t[3]);
 #endif
