@@ -958,6 +958,9 @@ int32_t ptz_ba_batch_cam_block_dim(const ptz_ba_batch* b) { return b ? b->nc : P
 
 void ptz_ba_batch_destroy(ptz_ba_batch* b)
 {
+#ifdef PTZ_CHOL_TIMELINE
+  if (b && b->d.chol.np > 0) chol_chain_timeline_print(b->d.chol.np / 64);
+#endif
   if (!b) return;
   DeviceGuard guard(b->device);
   // nothing of this batch may still be running when its memory is handed to the next one

@@ -1012,6 +1012,28 @@ __device__ __forceinline__ void chain_post(int* flag, int gen)
   if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef PTZ_CHOL_TIMELINE  // probe builds: where every tile of system 0 was when, in the REPLAYED graph (a few stores, no printf in the kernel)
+__device__ long long chain_tl[128][36];
+#define TL_STAMP(i) do { if (threadIdx.x == 0 && tl_row) tl_row[i] = wall_clock64(); } while (0)
+__global__ void chol_chain_tl_print(int nt)
+{
+  long long t0 = 0x7fffffffffffffffll;
+  for (int o = 0; o < nt * (nt + 1) / 2; ++o) if (chain_tl[o][0] > 0 && chain_tl[o][0] < t0) t0 = chain_tl[o][0];
+  int o = 0;
+  for (int tj = 0; tj < nt; ++tj)
+    for (int ti = tj; ti < nt; ++ti, ++o) {
+      const long long* r = chain_tl[o];
+      if (r[0] <= 0) continue;
+      printf("tl tile (%2d,%2d) start %7.2f  operands done %7.2f  end %7.2f |", ti, tj, (r[0] - t0) / 100.0, r[1] > 0 ? (r[1] - t0) / 100.0 : -1.0, (r[2] - t0) / 100.0);
+      for (int q = 0; q < 12 && r[4 + 2 * q] > 0; ++q) printf(" c%lld %.2f-%.2f", r[3] >> (5 * q) & 31, (r[4 + 2 * q] - t0) / 100.0, (r[5 + 2 * q] - t0) / 100.0);
+      if (r[28] > 0) printf(" | last column: flags looked at %.2f (have %lld), blocks reached %.2f %.2f %.2f %.2f", (r[28] - t0) / 100.0, r[35], (r[29] - t0) / 100.0, (r[30] - t0) / 100.0, (r[31] - t0) / 100.0, (r[32] - t0) / 100.0);
+      printf("\n");
+    }
+}
+#else
+#define TL_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, int* wg, short* klist, int ticket, int gen)
 {
   const int np = cb.np, nt = np / NB;
@@ -1019,6 +1041,11 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   int ord = ticket / cb.count;  // the tile's number in column-major order over the lower triangle
   const int sys = chol_system_of(cb, slot);
   if (sys < 0 || (cb.active && !cb.active[sys])) return;
+#ifdef PTZ_CHOL_TIMELINE
+  long long* tl_row = (slot == 0 && ord < 128) ? chain_tl[ord] : nullptr;
+  if (threadIdx.x == 0 && tl_row) for (int i = 0; i < 36; ++i) tl_row[i] = 0;
+  TL_STAMP(0);
+#endif
   const int spin = cb.chain_spin_limit > 0 ? cb.chain_spin_limit : CHAIN_SPIN_LIMIT;
   int tj = 0;
   while (tj < nt && ord >= nt - tj) { ord -= nt - tj; ++tj; }
@@ -1087,6 +1114,9 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #ifdef PTZ_CHOL_STAMPS
     if (threadIdx.x == 0 && q < 16) cs_q[0][q] = wall_clock64();
 #endif
+#ifdef PTZ_CHOL_TIMELINE
+    if (q < 12) { TL_STAMP(4 + 2 * q); if (threadIdx.x == 0 && tl_row) tl_row[3] |= (long long)(k & 31) << (5 * q); }
+#endif
     // the rows to be solved for are on their way while the workgroup waits for L_kk
     const d16v rik = trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
     d16v rjk = rik;
@@ -1118,6 +1148,9 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #pragma unroll
     for (int c = 0; c < 4; ++c) { pk[c] = __builtin_amdgcn_readfirstlane(pk[c]); if (have == c && pk[c] == gen) have = c + 1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef PTZ_CHOL_TIMELINE
+    if (q == Q - 1) { TL_STAMP(28); if (threadIdx.x == 0 && tl_row) tl_row[35] = have; }
+#endif
     auto fetch = [&](auto cc) {  // block column c of L_kk below its diagonal block (rows 16 (c + 1) .. 63) and the inverse of that diagonal block
       constexpr int c = decltype(cc)::value;
       constexpr int rows = NB - DB * (c + 1), items = rows * (DB / 2);
@@ -1168,6 +1201,9 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
         }
       }
       CS_STAMP(8 + c);  // (of the last column of the list)
+#ifdef PTZ_CHOL_TIMELINE
+      if (q == Q - 1) TL_STAMP(29 + c);  // block c: pre done, its flag seen, its fetch issued
+#endif
       if (c == 3) CS_STAMP(1);
 #ifdef PTZ_CHOL_STAMPS
       if (c == 0 && threadIdx.x == 0 && q < 16) cs_q[1][q] = wall_clock64();
@@ -1193,7 +1229,11 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #ifdef PTZ_CHOL_STAMPS
     if (threadIdx.x == 0 && q < 16) cs_q[2][q] = wall_clock64();
 #endif
+#ifdef PTZ_CHOL_TIMELINE
+    if (q < 12) TL_STAMP(5 + 2 * q);
+#endif
   }
+  TL_STAMP(1);
   if (ti == tj) {
     __syncthreads();  // all waves are done reading the operand tiles
 #pragma unroll
@@ -1204,6 +1244,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     CS_STAMP(4);
     diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
     CS_STAMP(5);
+    TL_STAMP(2);
     // (F[4 ti + 3] was raised inside, by the wave that inverted the last diagonal block)
 #ifdef PTZ_CHOL_STAMPS
     CS_STAMP(6);
@@ -1226,6 +1267,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
   chain_post(&T[ti * nt + tj], gen);
+  TL_STAMP(2);
 }
 
 __global__ __launch_bounds__(256) void chol_chain_kernel(CholBatch cb)
@@ -1809,6 +1851,9 @@ void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
   }
   launch(chol_chain_kernel, dim3(nt * (nt + 1) / 2 * cb.count), dim3(256), smem, stream, cb);
 }
+#ifdef PTZ_CHOL_TIMELINE
+void chol_chain_timeline_print(int nt) { hipLaunchKernelGGL(chol_chain_tl_print, dim3(1), dim3(1), 0, 0, nt); (void)hipDeviceSynchronize(); }
+#endif
 void chol_diag_launch(const CholBatch& cb, int k, hipStream_t stream)
 {
   launch(chol_diag_kernel, dim3(k < 0 && cb.sched ? CHOL_STEP_COLS : 1, cb.count), dim3(256), 0, stream, cb, k);

@@ -371,5 +371,8 @@ void chol_col_step_launch(const CholBatch& cb, int k, hipStream_t stream);   // 
 void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool fuse_diag = false);  // left-looking: column j -= all earlier columns; fuse_diag: also factor tile (j, j)
 // helper kernel launcher: zero A, set padding identity / CHOL_BIG (rows >= n_i) for all systems
 void chol_clear(const CholBatch& cb, hipStream_t stream);
+#ifdef PTZ_CHOL_TIMELINE
+void chol_chain_timeline_print(int nt);  // probe builds: the tiles' times of the LAST chol_chain_kernel launch (system 0), printed by a kernel of its own
+#endif
 
 }  // namespace ptz
