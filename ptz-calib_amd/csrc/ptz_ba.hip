@@ -1605,8 +1605,21 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     const dim3 gtrk((max_trk + 255) / 256, n);
     hipLaunchKernelGGL(k_view_tracks, gtrk, dim3(256), 0, st, vb);
     hipLaunchKernelGGL(k_view_scan, dim3(n), dim3(1024), 0, st, vb);
-    hipLaunchKernelGGL(k_view_keys, gtrk, dim3(256), 0, st, vb);
-    {
+    // the views' internal ray order: one launch (a workgroup per view sorts its tracks) when every view fits, else the batch-wide sort
+    const bool block_sort = max_trk <= 16384 && !(getenv("PTZ_BA_VIEW_BLOCK_SORT") && atoi(getenv("PTZ_BA_VIEW_BLOCK_SORT")) == 0);
+    if (block_sort) {
+      {
+        static std::mutex sort_mu;
+        static bool sort_cap[64] = {};
+        std::lock_guard<std::mutex> lk(sort_mu);
+        const int dv = b->device & 63;
+        if (!sort_cap[dv]) { (void)hipFuncSetAttribute((const void*)k_view_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); sort_cap[dv] = true; }
+      }
+      if (max_trk <= 4096) hipLaunchKernelGGL(k_view_sort<4>, dim3(n), dim3(1024), sizeof(rocprim::block_radix_sort<unsigned, 1024, 4, int>::storage_type), st, vb, val_out);
+      else hipLaunchKernelGGL(k_view_sort<16>, dim3(n), dim3(1024), sizeof(rocprim::block_radix_sort<unsigned, 1024, 16, int>::storage_type), st, vb, val_out);
+    }
+    else {
+      hipLaunchKernelGGL(k_view_keys, gtrk, dim3(256), 0, st, vb);
       unsigned end_bit = 47;
       while ((1u << (end_bit - 47)) < (unsigned)n) ++end_bit;
       size_t tmp_bytes = 0;

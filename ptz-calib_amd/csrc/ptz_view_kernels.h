@@ -11,6 +11,7 @@
 // The camera pairs, entry lists and runs then come from k_pairs as for any batch.
 #ifndef PTZ_VIEW_KERNELS_H
 #define PTZ_VIEW_KERNELS_H
+#include <rocprim/block/block_radix_sort.hpp>
 #include "ptz_ba_kernels.h"
 
 namespace ptz {
@@ -125,6 +126,42 @@ __global__ __launch_bounds__(256) void k_view_keys(ViewBuild vb)
   key |= (unsigned long long)blockIdx.y << 47;  // views one after the other in the batch-wide sort
   vb.key_in[v.trk_off + t] = key;
   vb.val_in[v.trk_off + t] = t;
+}
+
+// One workgroup per view: keys and sort in ONE launch (views of up to 1024 * IPT tracks; the batch-wide rocprim::radix_sort_pairs over
+// k_view_keys' 64-bit keys is 22 launches of a few microseconds each, a third of a view batch's build).  The same order: the key is
+// (longest - length) * cameras + first camera, tracks without a candidate observation behind all others, ties in track order --
+// rocprim::block_radix_sort is stable over the blocked arrangement (item = thread * IPT + i = track number).  Only the bits the
+// view's largest key has are sorted.
+template <int IPT>
+__global__ __launch_bounds__(1024) void k_view_sort(ViewBuild vb, int* __restrict__ val_out)
+{
+  using Sort = rocprim::block_radix_sort<unsigned, 1024, IPT, int>;
+  extern __shared__ __attribute__((aligned(16))) char view_sort_smem[];
+  typename Sort::storage_type& st = *reinterpret_cast<typename Sort::storage_type*>(view_sort_smem);
+  const ViewDev v = vb.views[blockIdx.x];
+  const unsigned top = (unsigned)v.max_len * (unsigned)v.n_cam + (unsigned)v.n_cam;  // above every valid key (guarded < 2^22 by the host)
+  int nb = 1;
+  while ((1u << nb) <= top) ++nb;
+  unsigned k[IPT];
+  int t_of[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int t = threadIdx.x * IPT + i;
+    t_of[i] = t;
+    unsigned key = 2u << nb;  // slots past the view's tracks: behind everything
+    if (t < v.n_track) {
+      const int len = vb.t_len[v.trk_off + t];
+      key = len > 0 ? (unsigned)((v.max_len - len) * v.n_cam + vb.t_first[v.trk_off + t]) : (1u << nb);
+    }
+    k[i] = key;
+  }
+  Sort().sort(k, t_of, st, 0, nb + 2);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int r = threadIdx.x * IPT + i;
+    if (r < v.n_track) val_out[v.trk_off + r] = t_of[i];
+  }
 }
 
 // thread = internal ray: its track, candidate views, weight, the caller's number

@@ -1381,6 +1381,28 @@ def test_views_wider_than_the_counting_sort_take_the_same_lists(pkg, monkeypatch
     assert got_default == want and got_wide == want
 
 
+def test_view_ray_order_by_one_workgroup_per_view_is_the_batch_wide_sort(pkg, monkeypatch):
+    """The internal ray order of a view batch (longest track first, then first camera, ties in track order) is one launch -- a
+    workgroup per view sorting its tracks in LDS (rocprim::block_radix_sort, 4 or 16 items per thread) -- when every rig has at most
+    16 384 tracks, and the batch-wide radix sort otherwise (PTZ_BA_VIEW_BLOCK_SORT=0 forces it): the same structure word for word
+    (hash) either way and as the host-packed problems, for a rig below 4 096 tracks, a rig above, and both in one batch."""
+    small = pkg.synth.make_scene(4, 36, 110)       # ~ 1 000 tracks
+    large = pkg.synth.make_scene(5, 120, 400)      # ~ 6 000 tracks
+    assert small.n_ray < 4096 < large.n_ray <= 16384
+    rs, rl = pkg.api.Rig.from_scene(small), pkg.api.Rig.from_scene(large)
+    cases = [([rs] * 2, [small] * 2, [list(range(36)), [0, 1, 2, 7]]),
+             ([rl] * 2, [large] * 2, [list(range(120)), list(range(3, 90, 3))]),
+             ([rs, rl, rs], [small, large, small], [list(range(2, 30, 2)), list(range(10, 70)), [5, 6]])]
+    for rigs, scs, views in cases:
+        hb = pkg.api.BaBatch([pkg.api.view_problem(sc, im) for sc, im in zip(scs, views)]); want = pkg.api.structure_hash(hb); hb.close()
+        vb = pkg.api.ViewBatch(rigs, views); one = pkg.api.structure_hash(vb); vb.close()
+        monkeypatch.setenv("PTZ_BA_VIEW_BLOCK_SORT", "0")
+        vb = pkg.api.ViewBatch(rigs, views); wide = pkg.api.structure_hash(vb); vb.close()
+        monkeypatch.delenv("PTZ_BA_VIEW_BLOCK_SORT")
+        assert one == want and wide == want
+    rs.close(); rl.close()
+
+
 def test_view_sort_key_overflow_is_refused(pkg):
     """The batch-wide sort key of a view batch holds (longest candidate track - length) * cameras + first camera in 22 bits.  The
     guard used the rig's MEAN track length: one track through all 2100 images of a wide view (2100 * 2100 > 2^22) passed it and
