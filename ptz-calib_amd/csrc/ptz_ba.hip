@@ -417,6 +417,19 @@ struct StagedUpload {
     }                                                                                                               \
   } while (0)
 
+// k_pairs' dynamic LDS beyond 64 KiB (very wide rigs): the attribute is set ONCE per device (hipFuncSetAttribute under a lock on every
+// batch creation was a measurable share of a view batch's 0.4 ms of enqueueing in the 64-rig lock step)
+static void pairs_lds_cap(int device)
+{
+  static std::mutex mu;
+  static bool done[64] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  if (done[device & 63]) return;
+  (void)hipFuncSetAttribute((const void*)k_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+  (void)hipFuncSetAttribute((const void*)k_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+  done[device & 63] = true;
+}
+
 template <int TYPE> void enqueue_linearize(ptz_ba_batch* b)
 {
   const Dev& d = b->d;
@@ -1603,6 +1616,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     d.wpos = vb.wpos; d.cam_ray = vb.cam_ray; d.cam_uv = vb.cam_uv; d.ray_w = vb.ray_w; b->d_ray_perm = vb.ray_perm;
     hipStream_t st = b->io;
     const dim3 gtrk((max_trk + 255) / 256, n);
+    const double tv0 = now_ms();
     hipLaunchKernelGGL(k_view_tracks, gtrk, dim3(256), 0, st, vb);
     hipLaunchKernelGGL(k_view_scan, dim3(n), dim3(1024), 0, st, vb);
     // the views' internal ray order: one launch (a workgroup per view sorts its tracks) when every view fits, else the batch-wide sort
@@ -1633,6 +1647,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       tmp = tmpc;
       if (rocprim::radix_sort_pairs(tmp, tmp_bytes, vb.key_in, key_out, vb.val_in, val_out, trk_total, begin_bit, end_bit, st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     }
+    const double tva = now_ms();
     hipLaunchKernelGGL(k_view_rays, gtrk, dim3(256), 0, st, vb, (const int*)val_out);
     hipLaunchKernelGGL(k_view_rayscan, dim3(n), dim3(1024), 0, st, vb, b->ray_block);
     // (PTZ_BA_DEBUG_VIEW_WIDE=1: the path of views wider than VIEW_LDS_CAMS for any view -- tests: the same lists)
@@ -1647,6 +1662,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       hipLaunchKernelGGL(k_view_camscan, dim3(n), dim3(1024), 0, st, vb);
       hipLaunchKernelGGL(k_view_camlists_wide, dim3(b->max_cam, n), dim3(256), 0, st, vb);
     }
+    const double tvb = now_ms();
     // camera pairs, entry lists, runs: k_pairs as for any batch, into arrays of the bounds' extents (no sizing read-back)
     PairsDev pa;
     memset(&pa, 0, sizeof(pa));
@@ -1670,12 +1686,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     TRY(b->alloc(&pa.camrun, (size_t)b->total_cam + n));
     TRY(b->alloc(&pa.runs, (size_t)b->total_run));
     TRY(b->alloc(&pa.ent, (size_t)b->total_ent));
-    {
-      static std::mutex cap_mu;
-      std::lock_guard<std::mutex> lk(cap_mu);
-      (void)hipFuncSetAttribute((const void*)k_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      (void)hipFuncSetAttribute((const void*)k_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    }
+    pairs_lds_cap(b->device);
+    const double tvc = now_ms();
     if (hipMemsetAsync(d_err, 0, sizeof(int), st) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     hipLaunchKernelGGL(k_pairs<false>, dim3(b->max_cam, n), dim3(256), pairs_lds, st, pa);
     hipLaunchKernelGGL(k_pair_scan, dim3((n + 63) / 64), dim3(64), 0, st, d.scene, n, (const int*)d_cnt, d_off3, d_tot);
@@ -1685,13 +1697,17 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     d.pair_ci = pa.pci; d.pair_cj = pa.pcj; d.pair_brow = pa.pbrow; d.pair_ptr = pa.pptr; d.pair_run = pa.prun;
     d.cam_pair = pa.campair; d.cam_run = pa.camrun; d.run_rec = pa.runs; d.ent = pa.ent;
     // the one read-back: the views' counts, the pair totals, the error word, the tile adjacency
+    const double tvd = now_ms();
     std::vector<int> h_tot((size_t)6 * n + 1);
     h_adj.resize((size_t)n * nt_e * nt_e);
     {
       hipError_t e = hipMemcpyAsync(hv.data(), dviews_c, sizeof(ViewDev) * n, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(h_tot.data(), d_tot, sizeof(int) * (6 * n + 1), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(h_adj.data(), d_adj, h_adj.size(), hipMemcpyDeviceToHost, st);
+      const double tv1 = now_ms();
       if (e == hipSuccess) e = stream_wait(st);
+      if (dbg_t) fprintf(stderr, "[ptz_ba_create] views: allocations + upload %.3f ms, build enqueued in %.3f ms, waited %.3f ms for it | tracks..sort %.3f, rays..place %.3f, pair arrays %.3f, memset + pairs launches %.3f, copies back %.3f\n", tv0 - tc1, tv1 - tv0, now_ms() - tv1,
+                         tva - tv0, tvb - tva, tvc - tvb, tvd - tvc, tv1 - tvd);
       b->release_staged();
       if (e == hipSuccess) e = hipGetLastError();
       if (e != hipSuccess) { (void)hipGetLastError(); ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
@@ -1754,12 +1770,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     TRY(b->alloc(&d_tot, (size_t)6 * n));
     TRY(b->alloc(&d_err, 1));
     pa.cam_cnt = d_cnt; pa.cam_off3 = d_off3; pa.scene_tot = d_tot; pa.err = d_err;
-    static std::mutex cap_mu;
-    {  // dynamic LDS beyond 64 KiB for very wide rigs
-      std::lock_guard<std::mutex> lk(cap_mu);
-      (void)hipFuncSetAttribute((const void*)k_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      (void)hipFuncSetAttribute((const void*)k_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    }
+    pairs_lds_cap(b->device);  // dynamic LDS beyond 64 KiB for very wide rigs
     if (hipMemsetAsync(d_err, 0, sizeof(int), b->io) != hipSuccess) { ptz_ba_batch_destroy(b); return PTZ_ENODEVICE; }
     hipLaunchKernelGGL(k_pairs<false>, dim3(b->max_cam, n), dim3(256), pairs_lds, b->io, pa);
     hipLaunchKernelGGL(k_pair_scan, dim3((n + 63) / 64), dim3(64), 0, b->io, d.scene, n, (const int*)d_cnt, d_off3, d_tot);

@@ -25,3 +25,13 @@ for i, k in enumerate(("groups", "total", "enqueue", "sync-wait", "device")):
     v = [r[i] for r in rows]; print(f"solve {k:12s} sum {sum(v):7.1f} ms  mean {st.mean(v):.3f}  max {max(v):.3f}")
 PY
 grep "passes enqueued" /tmp/iba_dbg.txt | tail -128 | sed 's/.*: \([0-9]*\) passes enqueued, \([0-9]*\) reached.*/\1 \2/' | sort | uniq -c | sort -rn | head -8
+python3 - <<'PY'
+import re, statistics as st
+rows = []
+for l in open("/tmp/iba_dbg.txt"):
+    m = re.search(r"views: allocations \+ upload ([0-9.]+) ms, build enqueued in ([0-9.]+) ms, waited ([0-9.]+) ms", l)
+    if m: rows.append(list(map(float, m.groups())))
+rows = rows[-128:]
+for i, k in enumerate(("allocations + upload", "build enqueued", "waited for the build")):
+    v = [r[i] for r in rows]; print(f"views {k:24s} sum {sum(v):7.1f} ms  mean {st.mean(v):.3f}  max {max(v):.3f}")
+PY
