@@ -178,10 +178,14 @@ __device__ __forceinline__ double wave_sum(double v)
   v += lane_xor_dpp<1>(v);
   return v;
 }
-__device__ __forceinline__ double wave_max(double v)
+__device__ __forceinline__ double wave_max(double v)  // (the same butterfly as wave_sum: no trip through the LDS crossbar)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, WAVE));
+  { double t = v; swap_halves32(v, t); v = fmax(v, t); }
+  { double t = v; swap_rows16(v, t); v = fmax(v, t); }
+  v = fmax(v, lane_xor_dpp<8>(v));
+  v = fmax(v, lane_xor_dpp<4>(v));
+  v = fmax(v, lane_xor_dpp<2>(v));
+  v = fmax(v, lane_xor_dpp<1>(v));
   return v;
 }
 
