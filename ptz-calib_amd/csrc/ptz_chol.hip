@@ -142,7 +142,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // FP64 FMA per updated column).  Everything else happens beside the chain: before a sweep the four waves bring its 16
 // columns up to date on the matrix cores (one 16-row block each, C -= X X^T over the finished column blocks); during a
 // sweep wave 1 inverts the previous 16 x 16 diagonal block (for the MFMA triangular solves of chol_trsm and the
-// back-substitution) and wave 2 stores the previous column block of L.
+// back-substitution) and wave 2 stores the previous column block of L.  (That is the batch path's form, diag_factor_tile<false>;
+// the chain kernels' form, <true>, is described in front of it.)
 // ---- the same sweep with DPP broadcasts (round 5; chol_chain_kernel) ----------------------------------------------------------
 // What a pivot of the sweep below pays for is the way a scalar of the pivot column reaches the other lanes: v_readlane into a
 // scalar register and from there into the multiply-add -- 30 cycles per dependent step (tools/probes/hip/dep_probe.hip: a dependent
@@ -1245,7 +1246,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
     CS_STAMP(5);
     TL_STAMP(2);
-    // (F[4 ti + 3] was raised inside, by the wave that inverted the last diagonal block)
+    // (F[4 ti + 3] was raised inside, by the sweeping wave, whose spare lanes hold the last diagonal block's inverse)
 #ifdef PTZ_CHOL_STAMPS
     CS_STAMP(6);
     if (threadIdx.x == 0 && slot == 0)
