@@ -722,3 +722,24 @@ def test_worldcup14_layout_writer(pkg, tmp_path):
         ref_images = set(os.listdir(os.path.join(root, "offline", ref)))
         assert any(tok in ref_images for tok in lines), (ref, test)  # the pairs name images of the reference match
         assert len([f for f in os.listdir(os.path.join(root, "online", test)) if f.endswith(".png")]) == info["tests"][test]
+
+
+def test_bench_floor_model_of_the_one_rig_iteration_adds_up():
+    """bench.py prints, beside the measured microseconds per LM iteration of the C2 rig, the floor of the present structure term by
+    term ("so the remaining gap is arithmetic, not prose"): the terms are all there, positive, and the total
+    is their sum; the north star's 100 us is below it, which the note says."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_for_floor_model", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    m = bench.c2_floor_model()
+    terms = {k: v for k, v in m.items() if k not in ("total_us", "note")}
+    assert {"chain_pivots", "chain_hand_overs", "back_substitution", "k_eval", "k_schur_f"} <= set(terms)
+    assert all(isinstance(v, float) and v > 0 for v in terms.values())
+    assert abs(sum(terms.values()) - m["total_us"]) < 0.5 and m["total_us"] > 100.0 and "100 us" in m["note"]
