@@ -191,7 +191,7 @@ def c2_floor_model():
         "chain_hand_overs": (levels - 1) * 4.0,                          # flag + block across compute units, solve, update, to LDS
         "chain_second_ready_column": 2 * 5.5,                            # levels 2 and 4: two producers end together, applied in turn
         "chain_last_tile_inverse": 3.0,
-        "back_substitution": 2.4e6 / 142e9 * 1e6 + 9 * 0.9 + 2.5,        # 2.4 MB through ONE compute unit at 142 GB/s, nine inverse groups, start
+        "back_substitution": 45 * 32768 / 142e9 * 1e6 + 9 * 0.9 + 2.5,   # 45 of the 76 tiles through a compute unit at 142 GB/s (the two arcs on a workgroup each), nine inverse groups, start
         "k_eval": 14.0, "k_lin_cam_and_control": 17.0, "k_schur_f": 16.0, "k_ray_prep": 7.0,   # longest thread's work, one wave per SIMD (k_eval: four lanes per ray)
     }
     out = {k: round(v, 1) for k, v in t.items()}

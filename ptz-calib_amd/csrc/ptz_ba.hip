@@ -2036,9 +2036,16 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       if ((!e || atoi(e) != 0) && sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
         h_items.resize((size_t)n * 4 * mg);
         h_groups.resize(n);
-        for (int i = 0; i < n; ++i)
+        // a few systems: the two arcs of a dissected system on a workgroup each (chol_backsolve_arcs); PTZ_BA_BACKSOLVE_SPLIT=0: one workgroup
+        const char* es = getenv("PTZ_BA_BACKSOLVE_SPLIT");
+        const bool want_split = any_plan && n <= 8 && nt <= 64 && !(es && atoi(es) == 0);
+        for (int i = 0; i < n; ++i) {
+          bool split = false;
           h_groups[i] = chol_backsolve_plan(d.chol.np, b->scenes[i].n, hm.data() + (size_t)i * nt * nt,
-                                            any_plan ? h_sched.data() + (size_t)i * nt * CHOL_STEP_COLS : nullptr, max_steps, h_items.data() + (size_t)i * 4 * mg);
+                                            any_plan ? h_sched.data() + (size_t)i * nt * CHOL_STEP_COLS : nullptr, max_steps, h_items.data() + (size_t)i * 4 * mg,
+                                            want_split, &split);
+          if (split) d.chol.bs_split = 1;
+        }
         up2.add(h_items, &d.chol.bs_items);
         up2.add(h_groups, &d.chol.bs_groups);
       }

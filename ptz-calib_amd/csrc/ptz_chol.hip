@@ -1649,9 +1649,19 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
   double* red = t + np;      // [BI_RED]
   BsItem* items = reinterpret_cast<BsItem*>(red + BI_RED);  // LIST: [max_groups][4]
   __shared__ int n_groups;
+  // Two workgroups per system (CholBatch::bs_split, chol_backsolve_arcs): this one skips the items the OTHER arc owns -- they become
+  // empty slots, whose loads and sums are not made -- and writes the solution of the tiles it owns (the separator's: workgroup 0).
+  const int wgi = blockIdx.x;             // 0, or 1 when the launch has two workgroups per system
+  __shared__ unsigned char tile_owner[64];
+  __shared__ unsigned char group_kind_s[1024];  // kind of a group's first item as the list has it (the barriers of an inverse group are every workgroup's)
+  __shared__ int has_owners;
   const int tid = threadIdx.x;
   // wave w: slot w / 2, column half w % 2; lane: quarter of the rows = lane / 16, column pair lane % 16 (c: the first of the two columns)
   const int c = 32 * ((tid >> 6) & 1) + 2 * (tid & 15), q = (tid >> 4) & 3, sl = tid >> 7;
+  if (!(LIST && cb.bs_items)) {  // owners come with the host's list only
+    if (wgi == 1) return;
+    if (tid == 0) has_owners = 0;
+  }
   if (LIST && cb.bs_items) {  // the list was made with the structure (chol_backsolve_plan): one coalesced copy instead of wave 0's walk
     const int G = cb.bs_groups[sys];
     const long long* src = reinterpret_cast<const long long*>(cb.bs_items + (size_t)sys * 4 * max_groups);
@@ -1659,6 +1669,21 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     static_assert(sizeof(BsItem) == 24, "three 8-byte words per item");
     for (int i = tid; i < 12 * G; i += BI_THREADS) dst[i] = src[i];
     if (tid == 0) n_groups = G;
+    if (tid < 64) tile_owner[tid] = 0;
+    if (tid == 0) has_owners = 0;
+    __syncthreads();
+    for (int i = tid; i < 4 * G; i += BI_THREADS) {  // owners out of the kinds: the item keeps its kind if this workgroup takes it
+      const int kd = items[i].kind, ow = kd >> 4;
+      if (ow) { has_owners = 1; if ((kd & 15) == 1) tile_owner[items[i].out_off / NB] = (unsigned char)ow; }
+    }
+    __syncthreads();
+    if (!has_owners && wgi == 1) return;  // (a system without two arcs in a launch that has them: one workgroup does it all)
+    for (int g = tid; g < G && g < 1024; g += BI_THREADS) group_kind_s[g] = (unsigned char)(items[4 * g].kind & 15);
+    __syncthreads();
+    for (int i = tid; i < 4 * G; i += BI_THREADS) {
+      const int kd = items[i].kind, ow = kd >> 4;
+      items[i].kind = (ow == 0 || ow == wgi + 1) ? (kd & 15) : 0;
+    }
   }
   else if (LIST && tid < 64) {  // the work list, in execution order; made by wave 0, 64 candidate tiles at a time (ballot compaction)
     // Backward over the steps of the factorisation.  The block columns of one step (the two arcs of a dissected system) do not
@@ -1712,7 +1737,8 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     double2 r0[16], r1[16], r2[16];
     if (0 < G) bs_load(items[sl], Lm, Li, q, c, r0);
     if (1 < G) bs_load(items[4 + sl], Lm, Li, q, c, r1);
-    auto kind_of = [&](int g) { return g >= 0 && g < G ? (int)items[4 * g].kind : 0; };
+    const bool host_list = cb.bs_items != nullptr;
+    auto kind_of = [&](int g) { return g >= 0 && g < G ? (host_list ? (int)group_kind_s[g] : (int)items[4 * g].kind) : 0; };
     for (int g = 0; g < G; g += 3) {
       if (g + 2 < G) bs_load(items[4 * (g + 2) + sl], Lm, Li, q, c, r2);
       bs_apply(items[4 * g + sl], kind_of(g), kind_of(g - 1), t, n, q, c, r0);
@@ -1747,12 +1773,19 @@ __global__ __launch_bounds__(BI_THREADS) void chol_backsolve_kernel(CholBatch cb
     }
     __syncthreads();
   }
+  // (two workgroups: each writes the solution of the tiles it owns; the separator's tiles and the padding are workgroup 0's)
+  const bool split = has_owners != 0;
+  auto mine = [&](int e) { return !split || (tile_owner[e & 63] == 0 ? wgi == 0 : (int)tile_owner[e & 63] == wgi + 1); };
   if (cb.xperm) {  // in the caller's numbering (CholBatch::xperm)
     const int* xp = cb.xperm + (size_t)sys * nt;
-    for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[xp[j / NB] * NB + j % NB] : 0.0;
+    for (int j = tid; j < np; j += BI_THREADS) {
+      const int e = xp[j / NB];
+      if (mine(e)) xout[(size_t)sys * np + j] = (j < n) ? t[e * NB + j % NB] : 0.0;
+    }
     return;
   }
-  for (int j = tid; j < np; j += BI_THREADS) xout[(size_t)sys * np + j] = (j < n) ? t[j] : 0.0;
+  for (int j = tid; j < np; j += BI_THREADS)
+    if (mine(j / NB)) xout[(size_t)sys * np + j] = (j < n) ? t[j] : 0.0;
 }
 
 }  // namespace
@@ -1877,12 +1910,17 @@ void chol_backsolve_launch(const CholBatch& cb, double* x, hipStream_t stream)
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      (void)hipFuncSetAttribute((const void*)chol_backsolve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      auto raise = [](const void* fn) {  // (the statically declared part counts against the same 160 KB)
+        hipFuncAttributes fa;
+        const int stat = hipFuncGetAttributes(&fa, fn) == hipSuccess ? (int)fa.sharedSizeBytes : 4096;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - stat);
+      };
+      raise((const void*)chol_backsolve_kernel<true>);
+      raise((const void*)chol_backsolve_kernel<false>);
       done.fetch_or(bit, std::memory_order_release);
     }
   }
-  if (use_list) launch(chol_backsolve_kernel<true>, dim3(1, cb.count), dim3(BI_THREADS), base + list, stream, cb, x, max_groups);
+  if (use_list) launch(chol_backsolve_kernel<true>, dim3((cb.bs_items && cb.bs_split) ? 2 : 1, cb.count), dim3(BI_THREADS), base + list, stream, cb, x, max_groups);
   else launch(chol_backsolve_kernel<false>, dim3(1, cb.count), dim3(BI_THREADS), base + 64, stream, cb, x, 0);
 }
 

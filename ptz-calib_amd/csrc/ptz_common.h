@@ -295,6 +295,9 @@ struct CholBatch {
   // group counts (chol_backsolve_plan, made on the host with the structure), or nullptr: the kernel makes the list itself
   const struct BsItem* bs_items = nullptr;
   const int* bs_groups = nullptr;
+  // 1: the host's list carries owners (BsItem::kind's bits 4 and 5, chol_backsolve_plan) for some system of the batch -- the
+  // back-substitution then runs TWO workgroups per system, see chol_backsolve_arcs
+  int bs_split = 0;
   // device [count][np / NB] or nullptr: elimination order of the tiles (the bundle adjustment's Dev::tperm).  With it the
   // back-substitution writes x in the CALLER's numbering -- x[c] = solution of row tperm[c / NB] * NB + c % NB -- so that the
   // reader of the solution (the camera update, on the critical path of a pass) needs no lookup in front of its loads
@@ -309,9 +312,54 @@ inline int chol_backsolve_max_groups(int np)
   for (int k = 0; k < nt; ++k) g += (k + 3) / 4;
   return g;
 }
+// The two arcs of a dissected system (ptz_ba.hip's elimination plan) do not couple: below the separator tiles -- the single-column
+// steps at the end of the schedule -- the tiles fall into two connected components of the structure, and the back-substitution of
+// one never reads what the other's writes.  One compute unit takes the factor in at 64 bytes per clock, which is what the
+// back-substitution of one rig is bound by, so the list is dealt to TWO workgroups: both walk the separator tiles' chain (its 15 of 76
+// tiles twice, but no word passes between them -- each finds the same x_k, bit for bit), each then only the tiles whose results land
+// in ITS arc.  owner[t]: 0 separator / padding (both), 1 / 2 the arcs; false: no such split (natural order, one arc, more components).
+inline bool chol_backsolve_arcs(int nt, int n, const unsigned char* tm, const int* sched, int n_steps_sched, unsigned char* owner)
+{
+  const int NB = CHOL_NB;
+  for (int t = 0; t < nt; ++t) owner[t] = 0;
+  if (!sched || !tm || nt > 64) return false;
+  int first_top_step = n_steps_sched;  // steps [first_top_step, n_steps) have one column each
+  for (int st = n_steps_sched - 1; st >= 0; --st) {
+    int cols = 0;
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) cols += sched[st * CHOL_STEP_COLS + c] >= 0 && sched[st * CHOL_STEP_COLS + c] * NB < n;
+    if (cols > 1) break;
+    first_top_step = st;
+  }
+  if (first_top_step <= 0) return false;
+  int comp[64];
+  for (int t = 0; t < nt; ++t) comp[t] = -2;  // -2: separator / padding, -1: arc tile not yet labelled
+  for (int st = 0; st < first_top_step; ++st)
+    for (int c = 0; c < CHOL_STEP_COLS; ++c) { const int k = sched[st * CHOL_STEP_COLS + c]; if (k >= 0 && k * NB < n) comp[k] = -1; }
+  int n_comp = 0;
+  for (int t0 = 0; t0 < nt; ++t0) {
+    if (comp[t0] != -1) continue;
+    int stack[64], sp = 0;
+    stack[sp++] = t0; comp[t0] = n_comp;
+    while (sp) {
+      const int a = stack[--sp];
+      for (int b = 0; b < nt; ++b) {
+        if (comp[b] != -1) continue;
+        const bool coupled = a > b ? tm[a * nt + b] != 0 : tm[b * nt + a] != 0;
+        if (coupled) { comp[b] = n_comp; stack[sp++] = b; }
+      }
+    }
+    ++n_comp;
+  }
+  if (n_comp != 2) return false;
+  for (int t = 0; t < nt; ++t) owner[t] = comp[t] < 0 ? 0 : (unsigned char)(comp[t] + 1);
+  return true;
+}
 // The list chol_backsolve_kernel would make for itself (same items, same order), made once on the host: backward over the steps of
 // the factorisation, the diagonal inverses of a step in one group, the tiles of its rows four to a group.  Returns the groups.
-inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int* sched, int n_steps_sched, BsItem* items)
+// split (may be null): set to whether the items carry owners -- kind | owner << 4, owner = chol_backsolve_arcs of the tile the item
+// WRITES (0: both workgroups) -- which they do when the system has two arcs and `want_split`.
+inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int* sched, int n_steps_sched, BsItem* items, bool want_split = false,
+                               bool* split = nullptr)
 {
   const int nt = np / CHOL_NB, NB = CHOL_NB;
   const int n_steps = sched ? n_steps_sched : nt;
@@ -344,6 +392,13 @@ inline int chol_backsolve_plan(int np, int n, const unsigned char* tm, const int
     const int padded = (filled + 3) & ~3;
     for (int i = filled; i < padded; ++i) items[4 * g + i] = BsItem{0, 0, 0, 0, 0};
     g += padded / 4;
+  }
+  if (split) *split = false;
+  unsigned char owner[64];
+  if (want_split && chol_backsolve_arcs(nt, n, tm, sched, n_steps_sched, owner)) {
+    for (int i = 0; i < 4 * g; ++i)
+      if (items[i].kind != 0) items[i].kind |= (int)owner[items[i].out_off / NB] << 4;
+    if (split) *split = true;
   }
   return g;
 }

@@ -1594,6 +1594,26 @@ def test_ba_global_memory_variants_reproduce_the_bits(pkg, monkeypatch):
         assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), var
 
 
+def test_ba_back_substitution_on_two_workgroups_reproduces_the_bits(pkg, monkeypatch):
+    """The two arcs of a dissected system do not couple below the separator tiles: for a few systems the back-substitution runs TWO
+    workgroups per system -- both walk the separator's chain (each finds the same x_k), each then only the tiles whose results land in
+    its arc -- because one compute unit's 64 bytes per clock is what the back-substitution of one rig is bound by.  Same sums in the
+    same order: the bits of the one-workgroup form (PTZ_BA_BACKSOLVE_SPLIT=0), on the 360-degree ring, on a PTZRayDist ring whose
+    camera blocks straddle the tiles, for two rigs side by side; a band that does not close has one arc and is not split."""
+    cases = [[pkg.synth.make_scene(3, 200, 500)],
+             [pkg.synth.make_scene(5, 150, 300, factor_type=1)],
+             [pkg.synth.make_scene(8, 200, 500), pkg.synth.make_scene(9, 180, 400)],
+             [pkg.synth.make_scene(4, 160, 300, pan_range_deg=120.0)]]
+    for scs in cases:
+        b = pkg.api.BaBatch(scs); b.set_state(); two = b.solve(); c2, r2 = b.get_state(); b.close()
+        monkeypatch.setenv("PTZ_BA_BACKSOLVE_SPLIT", "0")
+        b = pkg.api.BaBatch(scs); b.set_state(); one = b.solve(); c1, r1 = b.get_state(); b.close()
+        monkeypatch.delenv("PTZ_BA_BACKSOLVE_SPLIT")
+        assert two == one
+        assert all(np.array_equal(a, c) for a, c in zip(c2, c1)) and all(np.array_equal(a, c) for a, c in zip(r2, r1))
+        assert all(s["termination_type"] == 0 for s in two)
+
+
 def test_ba_eval_with_four_lanes_per_ray_reproduces_the_bits(pkg, monkeypatch):
     """A few scenes run k_eval with four lanes per ray (the functor of four observations side by side, their terms then added to the
     ray's sums in the order of the observations by quad broadcasts); one lane per ray (PTZ_BA_EVAL_LANES=1, the form of every larger
