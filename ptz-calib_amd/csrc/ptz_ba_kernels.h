@@ -272,6 +272,8 @@ template <int TYPE> __device__ __forceinline__ void lm_pre_wave(const Dev& d, in
 template <int TYPE> __device__ __forceinline__ void lm_post_wave(const Dev& d, int sc);
 template <int TYPE> __device__ __forceinline__ void lm_step_wave(const Dev& d, int sc);
 __device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int* lds_flag);
+__device__ __forceinline__ void tail_store(double* p, double v);
+__device__ __forceinline__ double tail_load(const double* p);
 __device__ __forceinline__ void post_progress(const Dev& d);
 
 __device__ __forceinline__ void fill_camblk(const double* c15, double* cb, bool with_jl, const double* dsp = nullptr)
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
 #pragma unroll
   for (int k = 0; k < NW * (NW + 1) / 2; ++k) U[k] = wave_sum(U[k]);
   if (lane == 0) {
-    costc_[gi] = cost;
+    tail_store(&costc_[gi], cost);  // (read by the scene's closing workgroup in this launch when the control is fused: tail_last_workgroup)
     if (NC == NW) {
       // what LM control needs of this block, left with it: the gradient's share of the max-norm (k_lm_pre) and the LM diagonal
       // clamp(diag(J^T J)) (LevenbergMarquardtStrategy; refreshed exactly when the blocks are).  With annotation residuals later
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256) void k_lin_cam(Dev d)
         e2 += k;  // index of U[k][k] in the packed lower triangle: k (k + 1) / 2 + k
         diagc_[(size_t)gi * NC + k] = fmin(fmax(U[e2 + k], d.opt.min_lm_diagonal), d.opt.max_lm_diagonal);
       }
-      gmax_[gi] = gmx;
+      tail_store(&gmax_[gi], gmx);
     }
     if (NC != NW) {  // the fy row/column has no 2D-2D contribution; k_lin_3d adds the annotation terms
 #pragma unroll
@@ -2942,8 +2944,8 @@ __device__ __forceinline__ void lm_step_wave(const Dev& d, int sc)
     const int gi = s.cam_off + i;
     const double2 v = *reinterpret_cast<const double2*>(d.camstep + (size_t)gi * 2);
     dn += v.x; cn += v.y;
-    c2 += costc_[gi];
-    gm2 = fmax(gm2, gmax_[gi]);
+    c2 += tail_load(&costc_[gi]);   // (k_lin_cam of this very launch may have written these two: sc1 loads, see tail_last_workgroup)
+    gm2 = fmax(gm2, tail_load(&gmax_[gi]));
   }
   mcc = -wave_sum(mcc); cost = wave_sum(cost); dn = wave_sum(dn); cn = wave_sum(cn);
   c2 = wave_sum(c2); gm2 = wave_max(gm2);
@@ -3034,9 +3036,16 @@ __global__ __launch_bounds__(LM_THREADS) void k_lm_step(Dev d)
 // The last workgroup of a scene to get here runs the scene's LM control in its first wave (Dev::fuse_ctl): every thread makes its
 // stores visible device-wide, one thread counts the workgroup in; `expected` workgroups of the scene pass here per launch.
 // Returns true in the first wave of the workgroup that closes the count (which has reset it for the next pass).
+// Round 6: what the closing workgroup reads of the OTHER workgroups of this launch (k_lin_cam: the candidate's per-camera cost and
+// gradient max-norm share) is stored write-through (tail_store: sc1) and read with L1-bypassing sc1 loads (tail_load), so the count
+// needs neither an L2 write-back in front of it (__threadfence by 256 threads: ~3.5 us) nor an invalidate behind it (~1.7 us):
+// every storing wave waits for its stores' acknowledgement, the barrier collects the waves, one lane counts the workgroup in.
+// Everything else the launch stores is read by later launches only.
+__device__ __forceinline__ void tail_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double tail_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int* lds_flag)
 {
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const int prev = atomicAdd(cnt, 1);
@@ -3045,7 +3054,7 @@ __device__ __forceinline__ bool tail_last_workgroup(int* cnt, int expected, int*
   }
   __syncthreads();
   if (!*lds_flag || threadIdx.x >= 64) return false;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: the loads below stay behind the count)
   return true;
 }
 

@@ -31,6 +31,22 @@ constexpr int LD = NB + 2;  // LDS row stride in doubles: 16-byte aligned rows, 
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// ---- hand-overs INSIDE a launch (chol_chain_kernel): write-through stores, L1-bypassing loads -----------------------------------
+// A tile handed from one workgroup to another inside the launch is stored with sc1 stores (write-through: the bytes leave the
+// storing XCD's L2 with the store, no release fence / L2 write-back in front of the flag), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)) before the flag is raised, and EVERY load of such bytes is an sc1 load (served by the L2, never by this
+// compute unit's L1), so the consumer needs no agent-scope acquire (a buffer_inv sc1 and its ~1.7 us) between its poll and its
+// loads -- only the compiler must not hoist the loads over the poll (wavefront-scope fence: no instruction).
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef double d2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_2(double* p, double2 v)  // 16 bytes (the stores are drained by the caller's drain_stores())
+{
+  const d2n x = {v.x, v.y};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // 1/sqrt(d): hardware seed (v_rsq_f64) + two Newton steps; d <= 0 propagates NaN/inf (flagged by the caller)
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
@@ -247,7 +263,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
       }
     }
     if (dg && flag) {
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      drain_stores();  // vmcnt(0) (inline asm: the compiler's waitcnt pass never drops it)
       if (lane == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -320,7 +336,7 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 
 // inverse of the 16 x 16 diagonal block b of the factored tile by forward substitution, one wave, lane c = column c of
 // X = L_bb^-1:  X[i][c] = (delta_ic - sum_{m < i} L[i][m] X[m][c]) / L[i][i]   (the L entries are LDS broadcasts)
-__device__ __forceinline__ void diag_block_inverse(const double* As, int b, double* out, double* out_lds)
+__device__ __forceinline__ void diag_block_inverse(const double* As, int b, double* out, double* out_lds, bool wt = false)
 {
   const int lane = threadIdx.x & 63, fr = lane & 15;
   const double* Lb = As + (DB * b) * LD + DB * b;
@@ -342,14 +358,15 @@ __device__ __forceinline__ void diag_block_inverse(const double* As, int b, doub
   if (lane < DB) {
 #pragma unroll
     for (int i = 0; i < DB; ++i) {
-      out[i * DB + fr] = x[i];
+      if (wt) st_sc1(&out[i * DB + fr], x[i]); else out[i * DB + fr] = x[i];
       out_lds[i * LDD + fr] = x[i];
     }
   }
 }
 
 // column block b of the factored tile (16 columns, all 64 rows; the rows above the diagonal block are zero) to global, one wave
-__device__ __forceinline__ void diag_store_block(const double* As, int b, double* __restrict__ Lg)
+// wt: the block is handed on inside this launch (chol_chain_kernel) -- write-through stores, see st_sc1_2
+__device__ __forceinline__ void diag_store_block(const double* As, int b, double* __restrict__ Lg, bool wt = false)
 {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -358,7 +375,8 @@ __device__ __forceinline__ void diag_store_block(const double* As, int b, double
     const int row = idx >> 3, c2 = (idx & 7) * 2;
     double2 v = make_double2(0.0, 0.0);
     if (row >= DB * b) v = *reinterpret_cast<const double2*>(As + row * LD + DB * b + c2);
-    *reinterpret_cast<double2*>(Lg + (size_t)row * NB + DB * b + c2) = v;
+    if (wt) st_sc1_2(Lg + (size_t)row * NB + DB * b + c2, v);
+    else *reinterpret_cast<double2*>(Lg + (size_t)row * NB + DB * b + c2) = v;
   }
 }
 
@@ -460,12 +478,15 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
         }
       }
       if (DPP && w == 3) {  // (never has a row block to update) column block b - 1 and, behind block 0, its inverse on their way to global memory
-        diag_store_block(As, b - 1, Lg);
+        diag_store_block(As, b - 1, Lg, Fk != nullptr);
         if (b - 1 > 0) {
           const double* dv = Dv[b - 1];
           double* dg = Dg + (b - 1) * (DB * DB);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) dg[(4 * p + fq) * DB + fr] = dv[(4 * p + fq) * LDD + fr];
+          for (int p = 0; p < 4; ++p) {
+            if (Fk) st_sc1(&dg[(4 * p + fq) * DB + fr], dv[(4 * p + fq) * LDD + fr]);
+            else dg[(4 * p + fq) * DB + fr] = dv[(4 * p + fq) * LDD + fr];
+          }
         }
       }
       __syncthreads();
@@ -476,14 +497,14 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
         diag_sweep_block<true>(As, b, k * NB, n, dmin, bad, Dv[b], last ? Dg + b * (DB * DB) : nullptr, (last && Fk) ? &Fk[b] : nullptr, gen);
       }
       else if (w == 1 && b == 1) {
-        diag_block_inverse(As, 0, Dg, Dv[0]);
+        diag_block_inverse(As, 0, Dg, Dv[0], Fk != nullptr);
         if (Fk) {
-          __threadfence();
+          drain_stores();  // (write-through stores: once this wave's are acknowledged, the bytes are where every XCD reads them)
           if (lane == 0 && atomicAdd(okflag_p, 1) == 1) __hip_atomic_store(&Fk[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       else if (w == 3 && b > 0 && Fk) {
-        __threadfence();
+        drain_stores();  // this wave stored the block (and, behind block 0, its inverse) one phase ago, write-through
         if (lane == 0 && (b - 1 > 0 || atomicAdd(okflag_p, 1) == 1)) __hip_atomic_store(&Fk[b - 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       else if (w == 2 && b > 0) {
@@ -743,6 +764,7 @@ __device__ __forceinline__ d16 tile_fetch(const double* __restrict__ g, int ld)
 // this wave's 16 rows of a tile in accumulator layout, asked for ahead of the solve (one vector value: an array would be kept in
 // scratch across the barrier in between)
 typedef double d16v __attribute__((ext_vector_type(16)));
+template <bool SC1 = false>  // SC1: the tile was written by another workgroup of THIS launch (chol_chain_kernel), see ld_sc1
 __device__ __forceinline__ d16v trsm_rows_fetch(const double* __restrict__ Tg, int ldg)
 {
   const int lane = threadIdx.x & 63;
@@ -751,7 +773,7 @@ __device__ __forceinline__ d16v trsm_rows_fetch(const double* __restrict__ Tg, i
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[4 * c + i] = Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr];
+    for (int i = 0; i < 4; ++i) r[4 * c + i] = SC1 ? ld_sc1(&Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr]) : Tg[(size_t)(fq + 4 * i) * ldg + 16 * c + fr];
   return r;
 }
 __device__ __forceinline__ void trsm_rows_to_lds(const d16v rows, int ldg, const double* Lk, const double* Di, double* xs,
@@ -1003,13 +1025,12 @@ __device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit, 
   }
   return false;
 }
-// raise a flag behind this workgroup's global stores: every thread makes its own stores visible device-wide first
+// raise a flag behind this workgroup's global stores, which were all write-through (st_sc1): every wave waits until its own are
+// acknowledged, the barrier collects the waves, one lane stores the flag (no L2 write-back: round 6, was __threadfence())
 __device__ __forceinline__ void chain_post(int* flag, int gen)
 {
-  __threadfence();
+  drain_stores();
   __syncthreads();
-  // (relaxed: thread 0's own fence above already stands between the workgroup's stores and this one -- a release store would
-  //  write the L2 back a second time, ~0.5 us on the chain)
   if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1080,7 +1101,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   __syncthreads();
   const int Q = wg[2];
   if (ti != tj && Q == 0) {  // final as assembled
-    if (threadIdx.x == 0) __hip_atomic_store(&T[ti * nt + tj], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&T[ti * nt + tj], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nothing of this launch to publish)
     return;
   }
   double* A = cb.A + (size_t)sys * np * np;
@@ -1111,7 +1132,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       if (!ok) atomicOr(&cb.fail[sys], 2);  // bit 1: a hand-over that did not come (reported to the host: LmState::chain_timeouts)
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (every load of handed-over bytes below is an sc1 load: no invalidate needed, see ld_sc1)
 #ifdef PTZ_CHOL_STAMPS
     if (threadIdx.x == 0 && q < 16) cs_q[0][q] = wall_clock64();
 #endif
@@ -1119,9 +1140,9 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     if (q < 12) { TL_STAMP(4 + 2 * q); if (threadIdx.x == 0 && tl_row) tl_row[3] |= (long long)(k & 31) << (5 * q); }
 #endif
     // the rows to be solved for are on their way while the workgroup waits for L_kk
-    const d16v rik = trsm_rows_fetch(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
+    const d16v rik = trsm_rows_fetch<true>(A + (size_t)(ti * NB + 16 * w) * np + k * NB, np);
     d16v rjk = rik;
-    if (ti != tj) rjk = trsm_rows_fetch(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np);
+    if (ti != tj) rjk = trsm_rows_fetch<true>(A + (size_t)(tj * NB + 16 * w) * np + k * NB, np);
     // L_kk comes in four 16-column blocks, each with its flag (diag_factor_tile raises them as the blocks reach global memory):
     // block c is staged, X_c = (A_c - sum_{q<c} X_q L_cq^T) Dinv_c^T solved for and its share of the update applied while the
     // producer still works on the blocks behind it -- when the LAST block arrives, all that is left on the chain is its 16 x 16
@@ -1148,7 +1169,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     int have = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) { pk[c] = __builtin_amdgcn_readfirstlane(pk[c]); if (have == c && pk[c] == gen) have = c + 1; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef PTZ_CHOL_TIMELINE
     if (q == Q - 1) { TL_STAMP(28); if (threadIdx.x == 0 && tl_row) tl_row[35] = have; }
 #endif
@@ -1159,13 +1180,15 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       r.l0 = make_double2(0.0, 0.0); r.l1 = r.l0;
       if (items > 0) {
         const int i0 = min((int)threadIdx.x, max(items - 1, 0));
-        r.l0 = *reinterpret_cast<const double2*>(Lg + (size_t)(DB * (c + 1) + i0 / (DB / 2)) * NB + DB * c + (i0 % (DB / 2)) * 2);
+        const double* src = Lg + (size_t)(DB * (c + 1) + i0 / (DB / 2)) * NB + DB * c + (i0 % (DB / 2)) * 2;
+        r.l0 = make_double2(ld_sc1(src), ld_sc1(src + 1));
       }
       if (items > 256) {
         const int i1 = min((int)threadIdx.x + 256, max(items - 1, 0));
-        r.l1 = *reinterpret_cast<const double2*>(Lg + (size_t)(DB * (c + 1) + i1 / (DB / 2)) * NB + DB * c + (i1 % (DB / 2)) * 2);
+        const double* src = Lg + (size_t)(DB * (c + 1) + i1 / (DB / 2)) * NB + DB * c + (i1 % (DB / 2)) * 2;
+        r.l1 = make_double2(ld_sc1(src), ld_sc1(src + 1));
       }
-      r.di = Dg[c * (DB * DB) + threadIdx.x];
+      r.di = ld_sc1(&Dg[c * (DB * DB) + threadIdx.x]);
       return r;
     };
     auto stash = [&](auto cc, const Blk& r) {
@@ -1194,7 +1217,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
         if (pk[c] != gen) {  // (the look taken while the previous block was fetched did not find it yet)
           if (lane == 0 && !chain_wait(&F[4 * k + c], gen, spin, &cb.fail[sys])) atomicOr(&cb.fail[sys], 2);  // (every wave polls: no barrier to pass the news on)
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         rb[c] = fetch(cc);
         if (c < 3) {  // a look at the next flag rides with this block's fetch
           int nf = lane == 0 ? __hip_atomic_load(&F[4 * k + (c < 3 ? c + 1 : 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -1266,7 +1289,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
+    for (int i = 0; i < 4; ++i) st_sc1(&C[(size_t)(fq + 4 * i) * np + 16 * c + fr], acc[c][i]);  // (handed on inside the launch: write-through)
   chain_post(&T[ti * nt + tj], gen);
   TL_STAMP(2);
 }
