@@ -187,26 +187,76 @@ template <int Q> __device__ __forceinline__ void dpp_bc(double& d, const double&
   else if constexpr (Q == 8) PTZ_DPP_BC(d, s, 8); else if constexpr (Q == 9) PTZ_DPP_BC(d, s, 9); else if constexpr (Q == 10) PTZ_DPP_BC(d, s, 10); else if constexpr (Q == 11) PTZ_DPP_BC(d, s, 11);
   else if constexpr (Q == 12) PTZ_DPP_BC(d, s, 12); else if constexpr (Q == 13) PTZ_DPP_BC(d, s, 13); else if constexpr (Q == 14) PTZ_DPP_BC(d, s, 14); else PTZ_DPP_BC(d, s, 15);
 }
-template <int Q> __device__ __forceinline__ void dpp_updates(double (&ar)[DB], double (&a)[DB], const double& lr, const double& mlr, const double& mlp)
+// Round 6: the sweep SOFTWARE-PIPELINED, every instruction of it in inline asm so that the order below IS the issue order.  The sweep is
+// bound by instruction issue (tools/probes/hip/issue_probe.hip: 4.75 cycles per FP64 instruction, 19.4 for v_rsq_f64), and the form
+// before this one paid the latency of pivot J's chain -- broadcast of the pivot, rsq + two Newton steps, scaling of column J: eleven
+// dependent instructions -- on top of it, because the column updates of pivot J - 1 all stood in front of that chain.  Only column J's
+// update has to: the updates of the columns behind J are issued BETWEEN the chain's instructions, in its latency shadows, and what
+// does not fit behind it.  The negated copies of the column are gone (neg modifier of the DPP multiply-add).  Same operations on the
+// same operands in the same order per element: the bits of the form before (tools/probes/hip/sweep16_probe.hip: 0 of 1040 values
+// differ, 171 -> 165 cycles per pivot there; in the product 200 -> ...).
+//   Hazards kept by hand (the compiler's hazard recogniser does not look inside inline asm): a DPP read of a register needs two
+// instructions between it and the VALU write of that register (the broadcast source ar[J] behind its scaling, ar[J + 1] behind its
+// last update); the result of v_rsq_f64 is not read by the next instruction.  tests/test_cpu_abi_host.py checks the disassembly.
+#define PTZ_A_RSQ(y, d)        asm volatile("v_rsq_f64 %0, %1" : "=v"(y) : "v"(d))
+#define PTZ_A_MULH(h, d)       asm volatile("v_mul_f64 %0, %1, 0.5" : "=v"(h) : "v"(d))
+#define PTZ_A_MUL(o, a, b)     asm volatile("v_mul_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b))
+#define PTZ_A_FNMA(o, y, t, c) asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(o) : "v"(y), "v"(t), "s"(c))
+#define PTZ_A_MULIP(x, r)      asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(r))
+#define PTZ_DPP_FDN(acc, bsrc, m, q) asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #q " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m))
+template <int Q> __device__ __forceinline__ void dpp_fdn(double& acc, const double& l, const double& m)  // acc -= (lane Q of the row's l) * m
 {
-  if constexpr (Q < DB) { dpp_fd<Q>(ar[Q], lr, mlr); dpp_fd<Q>(a[Q], lr, mlp); dpp_updates<Q + 1>(ar, a, lr, mlr, mlp); }
+  if constexpr (Q == 1) PTZ_DPP_FDN(acc, l, m, 1); else if constexpr (Q == 2) PTZ_DPP_FDN(acc, l, m, 2); else if constexpr (Q == 3) PTZ_DPP_FDN(acc, l, m, 3);
+  else if constexpr (Q == 4) PTZ_DPP_FDN(acc, l, m, 4); else if constexpr (Q == 5) PTZ_DPP_FDN(acc, l, m, 5); else if constexpr (Q == 6) PTZ_DPP_FDN(acc, l, m, 6);
+  else if constexpr (Q == 7) PTZ_DPP_FDN(acc, l, m, 7); else if constexpr (Q == 8) PTZ_DPP_FDN(acc, l, m, 8); else if constexpr (Q == 9) PTZ_DPP_FDN(acc, l, m, 9);
+  else if constexpr (Q == 10) PTZ_DPP_FDN(acc, l, m, 10); else if constexpr (Q == 11) PTZ_DPP_FDN(acc, l, m, 11); else if constexpr (Q == 12) PTZ_DPP_FDN(acc, l, m, 12);
+  else if constexpr (Q == 13) PTZ_DPP_FDN(acc, l, m, 13); else if constexpr (Q == 14) PTZ_DPP_FDN(acc, l, m, 14); else PTZ_DPP_FDN(acc, l, m, 15);
 }
-template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], double (&a)[DB], double (&ird)[DB], int live_cols, double& dmin, bool& bad)
+// item I of pivot P's update list: column q = P + 1 + I / 2 of the replica's rows (I even) or of the own rows (I odd)
+template <int P, int I> __device__ __forceinline__ void dpp_item(double (&ar)[DB], double (&a)[DB])
+{
+  constexpr int q = P + 1 + I / 2;
+  if constexpr (P >= 0 && q < DB) {
+    if constexpr ((I & 1) == 0) dpp_fdn<q>(ar[q], ar[P], ar[P]); else dpp_fdn<q>(a[q], ar[P], a[P]);
+  }
+}
+template <int P, int I0, int I1> __device__ __forceinline__ void dpp_fill(double (&ar)[DB], double (&a)[DB])
+{
+  if constexpr (I0 < I1) { dpp_item<P, I0>(ar, a); dpp_fill<P, I0 + 1, I1>(ar, a); }
+}
+template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], double (&a)[DB], double (&ird)[DB], int live_cols, double& dmin, bool& bad, const double c15 = 1.5)
 {
   if constexpr (J < DB) {
-    double d;
+    constexpr int P = J - 1;                       // the pivot whose remaining updates fill this one's chain
+    constexpr int NP = P >= 0 ? 2 * (DB - 1 - P) : 0;  // its items; 0 and 1 (column J) went out at the end of its own stage
+    double d, y, h, t;
+    if constexpr (NP > 2) dpp_item<P, 2>(ar, a); else asm volatile("s_nop 0");
     dpp_bc<J>(d, ar[J]);                 // A[j][j] of the (partly eliminated) block, from lane j of every row of lanes
+    dpp_fill<P, 3, 4>(ar, a);
+    PTZ_A_RSQ(y, d);                     // rsqrt_nr(d), instruction by instruction as the compiler makes it (the other paths' bits)
+    PTZ_A_MULH(h, d);
+    dpp_fill<P, 4, 6>(ar, a);
+    PTZ_A_MUL(t, h, y);
+    dpp_fill<P, 6, 7>(ar, a);
+    PTZ_A_FNMA(t, y, t, c15);
+    dpp_fill<P, 7, 8>(ar, a);
+    PTZ_A_MUL(y, y, t);
+    dpp_fill<P, 8, 9>(ar, a);
+    PTZ_A_MUL(t, h, y);
+    dpp_fill<P, 9, 10>(ar, a);
+    PTZ_A_FNMA(t, y, t, c15);
+    dpp_fill<P, 10, 11>(ar, a);
+    PTZ_A_MUL(y, y, t);
+    dpp_fill<P, 11, 12>(ar, a);
+    PTZ_A_MULIP(ar[J], y);               // replica lane j: sqrt(d), below: L[r][j], above: 0
+    PTZ_A_MULIP(a[J], y);                // own rows likewise
+    if constexpr (NP > 12) dpp_fill<P, 12, NP>(ar, a); else asm volatile("s_nop 0");
+    dpp_fill<J, 0, 2>(ar, a);            // column J + 1 is final
+    ird[J] = y;
     const bool live = J < live_cols;
     dmin = fmin(dmin, live ? d : 1.0);   // NaN pivots: fmin keeps the other operand, caught by `bad`
     bad |= (d != d) && live;
-    const double r = rsqrt_nr(d);
-    ird[J] = r;
-    const double lr = ar[J] * r, lp = a[J] * r;   // replica lane j: sqrt(d), below: L[r][j], above: 0; own rows likewise
-    ar[J] = lr; a[J] = lp;
-    const double mlr = -lr, mlp = -lp;
-    asm volatile("s_nop 1");             // (a freshly written register must not be a DPP source in the next instruction)
-    dpp_updates<J + 1>(ar, a, lr, mlr, mlp);
-    dpp_sweep<J + 1>(ar, a, ird, live_cols, dmin, bad);
+    dpp_sweep<J + 1>(ar, a, ird, live_cols, dmin, bad, c15);
   }
 }
 
@@ -1130,8 +1180,13 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
     if (threadIdx.x == 0) {
       const bool ok = chain_wait(&T[ti * nt + k], gen, spin, &cb.fail[sys]) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin, &cb.fail[sys]));
       if (!ok) atomicOr(&cb.fail[sys], 2);  // bit 1: a hand-over that did not come (reported to the host: LmState::chain_timeouts)
+      // is the whole column there already?  ONE thread decides for the workgroup (the waves' own looks below may differ by a flag)
+      int all = cb.chain_ready_whole;
+      for (int c = 0; c < 4; ++c) all &= __hip_atomic_load(&F[4 * k + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
+      wg[3] = all;
     }
     __syncthreads();
+    const bool whole = wg[3] != 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (every load of handed-over bytes below is an sc1 load: no invalidate needed, see ld_sc1)
 #ifdef PTZ_CHOL_STAMPS
     if (threadIdx.x == 0 && q < 16) cs_q[0][q] = wall_clock64();
@@ -1204,6 +1259,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       }
       Di[c * DB * LDD + (threadIdx.x >> 4) * LDD + (threadIdx.x & 15)] = r.di;
     };
+    if (whole) have = 4;
     if (have > 0) rb[0] = fetch(std::integral_constant<int, 0>{});
     if (have > 1) rb[1] = fetch(std::integral_constant<int, 1>{});
     if (have > 2) rb[2] = fetch(std::integral_constant<int, 2>{});
@@ -1244,10 +1300,42 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
         for (int q4 = 0; q4 < 4; ++q4) acc[q4] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * q4) * LD + 4 * kk], acc[q4], 0, 0, 0);
       }
     };
+    if (whole) {
+      // A column whose producer finished before this workgroup looked (all four flags up, all four blocks asked for above): the whole
+      // column at once -- the blocks to LDS together, every wave solves its 16 rows block after block (they are its own: no barrier),
+      // ONE barrier, then the 64 update MFMAs.  Same operations on the same operands in the same order per accumulator as the four
+      // block rounds (same bits); what it drops is their eight barriers and four dependent LDS hand-overs, which is what a tile with
+      // a long list of finished columns -- every tile of the separator's rows -- is paced by (a round: ~1.5 us; its MFMAs: ~0.7).
+      stash(std::integral_constant<int, 0>{}, rb[0]); stash(std::integral_constant<int, 1>{}, rb[1]);
+      stash(std::integral_constant<int, 2>{}, rb[2]); stash(std::integral_constant<int, 3>{}, rb[3]);
+      __syncthreads();
+      double* xsa = As + 16 * w * LD;
+      double* xsb = Bs + 16 * w * LD;
+      trsm_block_solve<0>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
+      if (ti != tj) trsm_block_solve<0>(xb, np, Di, xsb, nullptr);
+      trsm_block_pre<1>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<1>(xb, Lk, xsb);
+      trsm_block_solve<1>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
+      if (ti != tj) trsm_block_solve<1>(xb, np, Di, xsb, nullptr);
+      trsm_block_pre<2>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<2>(xb, Lk, xsb);
+      trsm_block_solve<2>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
+      if (ti != tj) trsm_block_solve<2>(xb, np, Di, xsb, nullptr);
+      trsm_block_pre<3>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<3>(xb, Lk, xsb);
+      trsm_block_solve<3>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
+      if (ti != tj) trsm_block_solve<3>(xb, np, Di, xsb, nullptr);
+      __syncthreads();  // X of every wave is in LDS
+#pragma unroll
+      for (int kk = 0; kk < NB / 4; ++kk) {
+        const double av = -ap[4 * kk];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) acc[q4] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * q4) * LD + 4 * kk], acc[q4], 0, 0, 0);
+      }
+    }
+    else {
     block(std::integral_constant<int, 0>{});
     block(std::integral_constant<int, 1>{});
     block(std::integral_constant<int, 2>{});
     block(std::integral_constant<int, 3>{});
+    }
     CS_STAMP(2);
     CS_STAMP(3);
 #ifdef PTZ_CHOL_STAMPS

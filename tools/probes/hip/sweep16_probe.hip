@@ -85,6 +85,69 @@ template <int MODE, int J> __device__ __forceinline__ void sweep2(double (&ar)[1
     sweep2<MODE, J + 1>(ar, ap, ird);
   }
 }
+
+// ---- round 6: the fused sweep SOFTWARE-PIPELINED, every instruction of it in inline asm so that the order below IS the issue order:
+// pivot J's chain (broadcast of the pivot, rsq + two Newton steps, the scaling of column J) is issued between the column updates of
+// pivot J - 1 that it does not depend on (those of the columns behind J), which fill the chain's latency shadows; the negated copies of
+// the column are gone (neg modifier of the DPP multiply-add).  Same operations on the same operands: same bits as sweep2.
+#define A_RSQ(y, d)        asm volatile("v_rsq_f64 %0, %1" : "=v"(y) : "v"(d))
+#define A_MULH(h, d)       asm volatile("v_mul_f64 %0, %1, 0.5" : "=v"(h) : "v"(d))
+#define A_MUL(o, a, b)     asm volatile("v_mul_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b))
+#define A_FNMA(o, y, t, c) asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(o) : "v"(y), "v"(t), "s"(c))
+#define A_MULIP(x, r)      asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(r))
+#define FDN(acc, bsrc, m, q) asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #q " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m))
+template <int Q> __device__ __forceinline__ void fdn_q(double& acc, const double& l, const double& m)
+{
+  if constexpr (Q == 1) FDN(acc, l, m, 1); else if constexpr (Q == 2) FDN(acc, l, m, 2); else if constexpr (Q == 3) FDN(acc, l, m, 3);
+  else if constexpr (Q == 4) FDN(acc, l, m, 4); else if constexpr (Q == 5) FDN(acc, l, m, 5); else if constexpr (Q == 6) FDN(acc, l, m, 6);
+  else if constexpr (Q == 7) FDN(acc, l, m, 7); else if constexpr (Q == 8) FDN(acc, l, m, 8); else if constexpr (Q == 9) FDN(acc, l, m, 9);
+  else if constexpr (Q == 10) FDN(acc, l, m, 10); else if constexpr (Q == 11) FDN(acc, l, m, 11); else if constexpr (Q == 12) FDN(acc, l, m, 12);
+  else if constexpr (Q == 13) FDN(acc, l, m, 13); else if constexpr (Q == 14) FDN(acc, l, m, 14); else FDN(acc, l, m, 15);
+}
+// item I of pivot P's update list: column q = P + 1 + I / 2, the replica's row (I even) or the own row (I odd)
+template <int P, int I> __device__ __forceinline__ void pf_item(double (&ar)[16], double (&ap)[16])
+{
+  constexpr int q = P + 1 + I / 2;
+  if constexpr (P >= 0 && q < 16) {
+    if constexpr ((I & 1) == 0) fdn_q<q>(ar[q], ar[P], ar[P]); else fdn_q<q>(ap[q], ar[P], ap[P]);
+  }
+}
+template <int P, int I0, int I1> __device__ __forceinline__ void pf_fill(double (&ar)[16], double (&ap)[16])
+{
+  if constexpr (I0 < I1) { pf_item<P, I0>(ar, ap); pf_fill<P, I0 + 1, I1>(ar, ap); }
+}
+template <int J> __device__ __forceinline__ void sweep2p(double (&ar)[16], double (&ap)[16], double (&ird)[16], const double c15)
+{
+  if constexpr (J < 16) {
+    constexpr int P = J - 1;                      // the pivot whose remaining updates fill this one's chain
+    constexpr int NP = P >= 0 ? 2 * (15 - P) : 0; // items 0, 1 (column J) are out already
+    double d, y, h, t;
+    if constexpr (NP > 2) pf_item<P, 2>(ar, ap); else asm volatile("s_nop 0");   // (a DPP read needs two instructions between it and the write of its source)
+    bc_q<J>(d, ar[J]);
+    pf_fill<P, 3, 4>(ar, ap);
+    A_RSQ(y, d);
+    A_MULH(h, d);
+    pf_fill<P, 4, 6>(ar, ap);
+    A_MUL(t, h, y);
+    pf_fill<P, 6, 7>(ar, ap);
+    A_FNMA(t, y, t, c15);
+    pf_fill<P, 7, 8>(ar, ap);
+    A_MUL(y, y, t);
+    pf_fill<P, 8, 9>(ar, ap);
+    A_MUL(t, h, y);
+    pf_fill<P, 9, 10>(ar, ap);
+    A_FNMA(t, y, t, c15);
+    pf_fill<P, 10, 11>(ar, ap);
+    A_MUL(y, y, t);
+    ird[J] = y;
+    pf_fill<P, 11, 12>(ar, ap);
+    A_MULIP(ar[J], y);
+    A_MULIP(ap[J], y);
+    if constexpr (NP > 12) pf_fill<P, 12, NP>(ar, ap); else asm volatile("s_nop 0");
+    pf_fill<J, 0, 2>(ar, ap);                     // column J + 1 is final
+    sweep2p<J + 1>(ar, ap, ird, c15);
+  }
+}
 // reference: the product's sweep (lane = row of the 64 x 16 column block, v_readlane broadcasts)
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
@@ -123,7 +186,7 @@ __global__ __launch_bounds__(64) void k_block(const double* A /* [64][16] */, do
 #pragma unroll
     for (int q = 0; q < 16; ++q) { ap[q] = own0[q]; ar[q] = rep0[q]; }
     const long long t0 = clock64();
-    if (WHICH == 0) sweep_ref(ap, ird); else sweep2<0, 0>(ar, ap, ird);
+    if (WHICH == 0) sweep_ref(ap, ird); else if (WHICH == 1) sweep2<0, 0>(ar, ap, ird); else sweep2p<0>(ar, ap, ird, 1.5);
     t += clock64() - t0;
   }
   for (int q = 0; q < 16; ++q) L[lane * 16 + q] = ap[q];
@@ -172,23 +235,25 @@ int main()
     printf("%s: %.0f cycles per 16-pivot block (%.1f per pivot), |LL^T - A| / |A| = %.2e\n", mode ? "cubic rsqrt" : "rsq + 2 Newton", (double)c / reps, (double)c / reps / 16, err / amax);
   }
   {  // the 64 x 16 column block: reference against fused, bit for bit
-    std::vector<double> B(64 * 16), L0(64 * 16 + 16), L1(64 * 16 + 16);
+    std::vector<double> B(64 * 16), L0(64 * 16 + 16), L1(64 * 16 + 16), L2(64 * 16 + 16);
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) B[i * 16 + j] = A[i * 16 + j];
     for (int i = 16; i < 64; ++i) for (int j = 0; j < 16; ++j) { s = s * 6364136223846793005ull + 1442695040888963407ull; B[i * 16 + j] = ((double)(s >> 11) / 9007199254740992.0) - 0.5; }
     double *dB, *dLL;
     hipMalloc(&dB, B.size() * 8); hipMalloc(&dLL, L0.size() * 8);
     hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 3; ++which) {
       for (int w = 0; w < 2; ++w) {
-        if (which == 0) hipLaunchKernelGGL(k_block<0>, dim3(1), dim3(64), 0, 0, dB, dLL, dc, reps); else hipLaunchKernelGGL(k_block<1>, dim3(1), dim3(64), 0, 0, dB, dLL, dc, reps);
+        if (which == 0) hipLaunchKernelGGL(k_block<0>, dim3(1), dim3(64), 0, 0, dB, dLL, dc, reps);
+        else if (which == 1) hipLaunchKernelGGL(k_block<1>, dim3(1), dim3(64), 0, 0, dB, dLL, dc, reps);
+        else hipLaunchKernelGGL(k_block<2>, dim3(1), dim3(64), 0, 0, dB, dLL, dc, reps);
         hipDeviceSynchronize();
       }
       long long c; hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
-      hipMemcpy((which ? L1 : L0).data(), dLL, L0.size() * 8, hipMemcpyDeviceToHost);
-      printf("64 x 16 column block, %s: %.0f cycles (%.1f per pivot)\n", which ? "fused DPP sweep (replica + own rows)" : "product's sweep (v_readlane)", (double)c / reps, (double)c / reps / 16);
+      hipMemcpy((which == 2 ? L2 : which ? L1 : L0).data(), dLL, L0.size() * 8, hipMemcpyDeviceToHost);
+      printf("64 x 16 column block, %s: %.0f cycles (%.1f per pivot)\n", which == 2 ? "fused DPP sweep, software-pipelined (round 6)" : which ? "fused DPP sweep (replica + own rows)" : "product's sweep (v_readlane)", (double)c / reps, (double)c / reps / 16);
     }
-    int diff = 0; for (size_t i = 0; i < L0.size(); ++i) diff += L0[i] != L1[i];
-    printf("values that differ between the two: %d of %zu\n", diff, L0.size());
+    int diff = 0, diff2 = 0; for (size_t i = 0; i < L0.size(); ++i) { diff += L0[i] != L1[i]; diff2 += L1[i] != L2[i]; }
+    printf("values that differ between the first two: %d of %zu; between the fused sweep and its pipelined form: %d\n", diff, L0.size(), diff2);
   }
   return 0;
 }
