@@ -871,7 +871,9 @@ __device__ __forceinline__ void trsm_rows_to_lds(const d16v rows, int ldg, const
 //   trsm_block_pre<C>    acc[C] -= sum_{q < C} X_q L_Cq^T        needs the blocks (C, q), q < C, of L_kk and X_0 .. X_{C-1} in xs
 //   trsm_block_solve<C>  X_C = acc[C] Dinv_C^T -> xs (and store_to)  needs Dinv_C
 // Same operations in the same order as trsm_rows_to_lds.
-template <int C>
+// SW: block (C, q) of L_kk lies at block position (q, C) of the image -- the SECOND column's blocks of a pair of columns taken side by
+// side (chain_tile), which share the image with the first column's: the solve reads the blocks below the diagonal blocks only.
+template <int C, bool SW = false>
 __device__ __forceinline__ void trsm_block_pre(d4 (&acc)[4], const double* Lk, const double* xs)
 {
   const int lane = threadIdx.x & 63;
@@ -881,9 +883,43 @@ __device__ __forceinline__ void trsm_block_pre(d4 (&acc)[4], const double* Lk, c
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const double av = -xs[fr * LD + 16 * q + 4 * ks + fq];
-      const double bv = Lk[(16 * C + fr) * LD + 16 * q + 4 * ks + fq];
+      const double bv = SW ? Lk[(16 * q + fr) * LD + 16 * C + 4 * ks + fq] : Lk[(16 * C + fr) * LD + 16 * q + 4 * ks + fq];
       acc[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[C], 0, 0, 0);
     }
+}
+// block column C of a factored diagonal tile as its consumers take it (chol_chain_kernel): the rows below its diagonal block
+// (16 (C + 1) .. 63) and the inverse of that diagonal block -- asked for with sc1 loads (chain_fetch), staged in LDS (chain_stash)
+struct ChainBlk { double2 l0, l1; double di; };
+template <int C>
+__device__ __forceinline__ ChainBlk chain_fetch(const double* Lg, const double* Dg)
+{
+  constexpr int rows = NB - DB * (C + 1), items = rows * (DB / 2);
+  ChainBlk r;
+  r.l0 = make_double2(0.0, 0.0); r.l1 = r.l0;
+  if (items > 0) {
+    const int i0 = min((int)threadIdx.x, max(items - 1, 0));
+    const double* src = Lg + (size_t)(DB * (C + 1) + i0 / (DB / 2)) * NB + DB * C + (i0 % (DB / 2)) * 2;
+    r.l0 = make_double2(ld_sc1(src), ld_sc1(src + 1));
+  }
+  if (items > 256) {
+    const int i1 = min((int)threadIdx.x + 256, max(items - 1, 0));
+    const double* src = Lg + (size_t)(DB * (C + 1) + i1 / (DB / 2)) * NB + DB * C + (i1 % (DB / 2)) * 2;
+    r.l1 = make_double2(ld_sc1(src), ld_sc1(src + 1));
+  }
+  r.di = ld_sc1(&Dg[C * (DB * DB) + threadIdx.x]);
+  return r;
+}
+template <int C, bool SW = false>
+__device__ __forceinline__ void chain_stash(const ChainBlk& r, double* Lk, double* Di)
+{
+  constexpr int rows = NB - DB * (C + 1), items = rows * (DB / 2);
+  auto at = [&](int i) {  // piece i: row 16 (C + 1) + i / 8 of the tile, columns 16 C + 2 (i % 8) ..
+    const int rr = i / (DB / 2), c2 = (i % (DB / 2)) * 2;
+    return SW ? Lk + (DB * C + (rr & 15)) * LD + DB * (C + 1 + (rr >> 4)) + c2 : Lk + (DB * (C + 1) + rr) * LD + DB * C + c2;
+  };
+  if (items > 0 && (int)threadIdx.x < items) *reinterpret_cast<double2*>(at(threadIdx.x)) = r.l0;
+  if (items > 256 && (int)threadIdx.x + 256 < items) *reinterpret_cast<double2*>(at(threadIdx.x + 256)) = r.l1;
+  Di[C * DB * LDD + (threadIdx.x >> 4) * LDD + (threadIdx.x & 15)] = r.di;
 }
 template <int C>
 __device__ __forceinline__ void trsm_block_solve(const d4 (&acc)[4], int ldg, const double* Di, double* xs, double* __restrict__ store_to)
@@ -905,6 +941,36 @@ __device__ __forceinline__ void trsm_block_solve(const d4 (&acc)[4], int ldg, co
   for (int i = 0; i < 4; ++i) {
     xs[(fq + 4 * i) * LD + 16 * C + fr] = xc[i];
     if (store_to) store_to[(size_t)(fq + 4 * i) * ldg + 16 * C + fr] = xc[i];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+// two such solves side by side (chain_tile's pairs of columns): the same operations per solve, the two streams interleaved so that
+// one's LDS round trips and dependent MFMAs stand in the other's shadow
+template <int C>
+__device__ __forceinline__ void trsm_block_solve2(const d4 (&acc1)[4], const d4 (&acc2)[4], int ldg, const double* Di1, const double* Di2, double* xs1, double* xs2,
+                                                  double* __restrict__ st1, double* __restrict__ st2)
+{
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { xs1[(fq + 4 * i) * LD + 16 * C + fr] = acc1[C][i]; xs2[(fq + 4 * i) * LD + 16 * C + fr] = acc2[C][i]; }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): these rows are private to this wave
+  d4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const double a1 = xs1[fr * LD + 16 * C + 4 * ks + fq], b1 = Di1[C * DB * LDD + fr * LDD + 4 * ks + fq];
+    const double a2 = xs2[fr * LD + 16 * C + 4 * ks + fq], b2 = Di2[C * DB * LDD + fr * LDD + 4 * ks + fq];
+    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x1, 0, 0, 0);
+    x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, x2, 0, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xs1[(fq + 4 * i) * LD + 16 * C + fr] = x1[i];
+    xs2[(fq + 4 * i) * LD + 16 * C + fr] = x2[i];
+    if (st1) st1[(size_t)(fq + 4 * i) * ldg + 16 * C + fr] = x1[i];
+    if (st2) st2[(size_t)(fq + 4 * i) * ldg + 16 * C + fr] = x2[i];
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
 }
@@ -1108,6 +1174,7 @@ __global__ void chol_chain_tl_print(int nt)
 
 __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, int* wg, short* klist, int ticket, int gen)
 {
+  short* kstep = klist + 1024;  // step of the schedule each list entry is a column of
   const int np = cb.np, nt = np / NB;
   const int slot = ticket % cb.count;
   int ord = ticket / cb.count;  // the tile's number in column-major order over the lower triangle
@@ -1143,7 +1210,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       const bool ok = in && (!tm || (tm[ti * nt + (in ? kc : 0)] && tm[tj * nt + (in ? kc : 0)]));
       const unsigned long long m = __ballot(ok);
       const int pos = cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull));
-      if (ok && pos < 1024) klist[pos] = (short)kc;
+      if (ok && pos < 1024) { klist[pos] = (short)kc; kstep[pos] = (short)(sq ? qq / CHOL_STEP_COLS : qq); }
       cnt += __popcll(m);
     }
     if (threadIdx.x == 0) wg[2] = min(cnt, 1024);
@@ -1174,14 +1241,25 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   cs_t[0] = wall_clock64();
   __shared__ long long cs_q[3][16];  // per column of the list: T flags seen, block 0 seen, update done
 #endif
+  // TWO columns of a diagonal tile's list side by side (round 6), when their producers are columns of ONE step of the schedule --
+  // the two halves of a dissected arc, the two arcs in front of the separator: they end together, and taken one after the other
+  // the second costs a finished column's ~6 us behind the first on the chain.  Side by side: both columns' blocks are taken as
+  // they come, round by round; the first column's rows are solved for and applied as always (As), the second column's are only
+  // SOLVED for (into Bs, which a diagonal tile does not otherwise use; its L blocks share the image Lk -- the block positions
+  // above the diagonal, trsm_block_pre<.., true> -- and its block inverses lie in Dv, which is idle until the tile is factored),
+  // and its 64 update MFMAs follow the first column's last round.  Every accumulator takes the same products in the same order
+  // as one column after the other: same bits.  PTZ_BA_CHAIN_PAIR=0: one after the other.
+  const bool pairs_on = cb.chain_pair && ti == tj && cb.sched;
   for (int q = 0; q < Q; ++q) {
     const int k = klist[q];
+    const bool pair = pairs_on && q + 1 < Q && kstep[q] == kstep[q + 1];
     if (q > 0) __syncthreads();  // all waves are done with the operand tiles of the previous column
     if (threadIdx.x == 0) {
-      const bool ok = chain_wait(&T[ti * nt + k], gen, spin, &cb.fail[sys]) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin, &cb.fail[sys]));
+      bool ok = chain_wait(&T[ti * nt + k], gen, spin, &cb.fail[sys]) && (ti == tj || chain_wait(&T[tj * nt + k], gen, spin, &cb.fail[sys]));
+      if (pair) ok = ok && chain_wait(&T[ti * nt + klist[q + 1]], gen, spin, &cb.fail[sys]);
       if (!ok) atomicOr(&cb.fail[sys], 2);  // bit 1: a hand-over that did not come (reported to the host: LmState::chain_timeouts)
       // is the whole column there already?  ONE thread decides for the workgroup (the waves' own looks below may differ by a flag)
-      int all = cb.chain_ready_whole;
+      int all = cb.chain_ready_whole && !pair;
       for (int c = 0; c < 4; ++c) all &= __hip_atomic_load(&F[4 * k + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
       wg[3] = all;
     }
@@ -1212,11 +1290,112 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       for (int i = 0; i < 4; ++i) { xa[c][i] = rik[4 * c + i]; xb[c][i] = rjk[4 * c + i]; }
     const double* ap = As + (16 * w + fr) * LD + fq;
     const double* bp = Bop + fr * LD + fq;
+    if (pair) {
+      const int k2 = klist[q + 1];
+#ifdef PTZ_CHOL_TIMELINE
+      if (q + 1 < 12) { TL_STAMP(4 + 2 * (q + 1)); if (threadIdx.x == 0 && tl_row) tl_row[3] |= (long long)(k2 & 31) << (5 * (q + 1)); }
+#endif
+      {
+        const d16v r2 = trsm_rows_fetch<true>(A + (size_t)(ti * NB + 16 * w) * np + k2 * NB, np);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xb[c][i] = r2[4 * c + i];
+      }
+      const double* Lg2 = cb.Ldiag + ((size_t)sys * nt + k2) * (NB * NB);
+      const double* Dg2 = cb.Dinv + ((size_t)sys * nt + k2) * 4 * (DB * DB);
+      double* Lik2 = cb.L + (size_t)slot * np * np + (size_t)(ti * NB + 16 * w) * np + k2 * NB;
+      double* Di2 = &Dv[0][0];
+      double* xs1 = As + 16 * w * LD;
+      double* xs2 = Bs + 16 * w * LD;
+      ChainBlk r1[4], r2[4];
+      int p1[4], p2[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        p1[c] = lane == 0 ? __hip_atomic_load(&F[4 * k + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        p2[c] = lane == 0 ? __hip_atomic_load(&F[4 * k2 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      }
+      int h1 = 0, h2 = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        p1[c] = __builtin_amdgcn_readfirstlane(p1[c]); if (h1 == c && p1[c] == gen) h1 = c + 1;
+        p2[c] = __builtin_amdgcn_readfirstlane(p2[c]); if (h2 == c && p2[c] == gen) h2 = c + 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (h1 > 0) r1[0] = chain_fetch<0>(Lg, Dg);
+      if (h2 > 0) r2[0] = chain_fetch<0>(Lg2, Dg2);
+      if (h1 > 1) r1[1] = chain_fetch<1>(Lg, Dg);
+      if (h2 > 1) r2[1] = chain_fetch<1>(Lg2, Dg2);
+      if (h1 > 2) r1[2] = chain_fetch<2>(Lg, Dg);
+      if (h2 > 2) r2[2] = chain_fetch<2>(Lg2, Dg2);
+      if (h1 > 3) r1[3] = chain_fetch<3>(Lg, Dg);
+      if (h2 > 3) r2[3] = chain_fetch<3>(Lg2, Dg2);
+#ifdef PTZ_CHOL_TIMELINE
+      if (q + 2 >= Q) { TL_STAMP(28); if (threadIdx.x == 0 && tl_row) tl_row[35] = 10 * h1 + h2; }
+#endif
+      auto take = [&](auto cc, int kk2, const double* Lgx, const double* Dgx, int (&pp)[4], int hh, ChainBlk (&rr)[4]) {  // block c of one of the two columns: wait, ask
+        constexpr int c = decltype(cc)::value;
+        if (c >= hh) {  // (uniform)
+          if (pp[c] != gen) {
+            if (lane == 0 && !chain_wait(&F[4 * kk2 + c], gen, spin, &cb.fail[sys])) atomicOr(&cb.fail[sys], 2);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          rr[c] = chain_fetch<c>(Lgx, Dgx);
+          if (c < 3) {
+            int nf = lane == 0 ? __hip_atomic_load(&F[4 * kk2 + (c < 3 ? c + 1 : 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            pp[c < 3 ? c + 1 : 3] = __builtin_amdgcn_readfirstlane(nf);
+          }
+        }
+      };
+      auto pround = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        trsm_block_pre<c, false>(xa, Lk, xs1);
+        trsm_block_pre<c, true>(xb, Lk, xs2);
+        take(cc, k, Lg, Dg, p1, h1, r1);
+        take(cc, k2, Lg2, Dg2, p2, h2, r2);
+#ifdef PTZ_CHOL_TIMELINE
+        if (q + 2 >= Q) TL_STAMP(29 + c);
+#endif
+        chain_stash<c, false>(r1[c], Lk, Di);
+        chain_stash<c, true>(r2[c], Lk, Di2);
+        __syncthreads();
+        trsm_block_solve2<c>(xa, xb, np, Di, Di2, xs1, xs2, Lik, Lik2);
+        __syncthreads();  // X_c of every wave, both columns, is in LDS
+#pragma unroll
+        for (int kk = 4 * c; kk < 4 * c + 4; ++kk) {
+          const double av = -ap[4 * kk];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) acc[q4] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[(16 * q4) * LD + 4 * kk], acc[q4], 0, 0, 0);
+        }
+      };
+      pround(std::integral_constant<int, 0>{});
+      pround(std::integral_constant<int, 1>{});
+      pround(std::integral_constant<int, 2>{});
+      pround(std::integral_constant<int, 3>{});
+#ifdef PTZ_CHOL_TIMELINE
+      if (q < 12) TL_STAMP(5 + 2 * q);
+#endif
+      {  // the second column's update: its X is complete in Bs (the barrier behind the last solve)
+        const double* ap2 = Bs + (16 * w + fr) * LD + fq;
+        const double* bp2 = Bs + fr * LD + fq;
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+          const double av = -ap2[4 * kk];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) acc[q4] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp2[(16 * q4) * LD + 4 * kk], acc[q4], 0, 0, 0);
+        }
+      }
+#ifdef PTZ_CHOL_TIMELINE
+      if (q + 1 < 12) TL_STAMP(5 + 2 * (q + 1));
+#endif
+      ++q;  // both columns are applied
+      continue;
+    }
     // One look at all four flags first (a look is a memory round trip): the blocks that are there already are asked for at once, so
     // that a column whose producer finished long ago costs two round trips, not eight; only the blocks still to come are waited for
     // one by one -- and while one of those is fetched, the next flag is looked at, so that a consumer on the critical chain keeps
     // up with its producer's sweeps.
-    struct Blk { double2 l0, l1; double di; };
+    typedef ChainBlk Blk;
     Blk rb[4];
     int pk[4];
 #pragma unroll
@@ -1228,37 +1407,8 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #ifdef PTZ_CHOL_TIMELINE
     if (q == Q - 1) { TL_STAMP(28); if (threadIdx.x == 0 && tl_row) tl_row[35] = have; }
 #endif
-    auto fetch = [&](auto cc) {  // block column c of L_kk below its diagonal block (rows 16 (c + 1) .. 63) and the inverse of that diagonal block
-      constexpr int c = decltype(cc)::value;
-      constexpr int rows = NB - DB * (c + 1), items = rows * (DB / 2);
-      Blk r;
-      r.l0 = make_double2(0.0, 0.0); r.l1 = r.l0;
-      if (items > 0) {
-        const int i0 = min((int)threadIdx.x, max(items - 1, 0));
-        const double* src = Lg + (size_t)(DB * (c + 1) + i0 / (DB / 2)) * NB + DB * c + (i0 % (DB / 2)) * 2;
-        r.l0 = make_double2(ld_sc1(src), ld_sc1(src + 1));
-      }
-      if (items > 256) {
-        const int i1 = min((int)threadIdx.x + 256, max(items - 1, 0));
-        const double* src = Lg + (size_t)(DB * (c + 1) + i1 / (DB / 2)) * NB + DB * c + (i1 % (DB / 2)) * 2;
-        r.l1 = make_double2(ld_sc1(src), ld_sc1(src + 1));
-      }
-      r.di = ld_sc1(&Dg[c * (DB * DB) + threadIdx.x]);
-      return r;
-    };
-    auto stash = [&](auto cc, const Blk& r) {
-      constexpr int c = decltype(cc)::value;
-      constexpr int rows = NB - DB * (c + 1), items = rows * (DB / 2);
-      if (items > 0 && (int)threadIdx.x < items) {
-        const int i0 = threadIdx.x;
-        *reinterpret_cast<double2*>(Lk + (DB * (c + 1) + i0 / (DB / 2)) * LD + DB * c + (i0 % (DB / 2)) * 2) = r.l0;
-      }
-      if (items > 256 && (int)threadIdx.x + 256 < items) {
-        const int i1 = threadIdx.x + 256;
-        *reinterpret_cast<double2*>(Lk + (DB * (c + 1) + i1 / (DB / 2)) * LD + DB * c + (i1 % (DB / 2)) * 2) = r.l1;
-      }
-      Di[c * DB * LDD + (threadIdx.x >> 4) * LDD + (threadIdx.x & 15)] = r.di;
-    };
+    auto fetch = [&](auto cc) { return chain_fetch<decltype(cc)::value>(Lg, Dg); };
+    auto stash = [&](auto cc, const Blk& r) { chain_stash<decltype(cc)::value>(r, Lk, Di); };
     if (whole) have = 4;
     if (have > 0) rb[0] = fetch(std::integral_constant<int, 0>{});
     if (have > 1) rb[1] = fetch(std::integral_constant<int, 1>{});
@@ -1388,7 +1538,7 @@ __global__ __launch_bounds__(256) void chol_chain_kernel(CholBatch cb)
   const int nt = cb.np / NB;
   const int total = nt * (nt + 1) / 2 * cb.count;
   int* wg = reinterpret_cast<int*>(smem + 3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2);  // [ticket, generation, list length, -]
-  short* klist = reinterpret_cast<short*>(wg + 4);                                          // [1024]
+  short* klist = reinterpret_cast<short*>(wg + 4);                                          // [1024] + the entries' steps [1024]
   int* ctl = cb.chain_ctl;
   if (threadIdx.x == 0) {
     wg[0] = atomicAdd(&ctl[0], 1);
@@ -1983,7 +2133,7 @@ bool chol_chain_enabled(const CholBatch& cb) { return cb.L && cb.Linv && cb.chai
 void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
 {
   const int nt = cb.np / NB;
-  const size_t smem = sizeof(double) * (3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2) + sizeof(int) * 4 + sizeof(short) * 1024;
+  const size_t smem = sizeof(double) * (3 * NB * LD + 4 * DB * LDD + 4 * DB * LDD + 2) + sizeof(int) * 4 + sizeof(short) * 2048;  // (klist + kstep)
   {  // > 64 KiB of dynamic LDS: the cap is raised once per device
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
