@@ -250,16 +250,21 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
         X = np.stack([cos_el * np.sin(az), sin_el, cos_el * np.cos(az)], axis=1)  # unit, z forward at pan 0
         vi, pi_ = _candidate_pairs(az, pan, window)  # view-major, rays ascending inside a view
         # exact projections and visibility (>= 8 px inside the frame)
-        X0, X1, X2 = X[pi_, 0], X[pi_, 1], X[pi_, 2]
-        Pc = [Rgt[:, i, 0][vi] * X0 + Rgt[:, i, 1][vi] * X1 + Rgt[:, i, 2][vi] * X2 for i in range(3)]
+        # (the pairs are view-major: a camera's entries are np.repeat of its value over its run of pairs -- the gathers'
+        #  values, at a third of their cost; the rays' coordinates are taken from contiguous columns)
+        runs = np.bincount(vi, minlength=N)
+        per_view = lambda a: np.repeat(a, runs)  # noqa: E731
+        X0, X1, X2 = np.take(np.ascontiguousarray(X[:, 0]), pi_), np.take(np.ascontiguousarray(X[:, 1]), pi_), np.take(np.ascontiguousarray(X[:, 2]), pi_)
+        Pc = [per_view(Rgt[:, i, 0]) * X0 + per_view(Rgt[:, i, 1]) * X1 + per_view(Rgt[:, i, 2]) * X2 for i in range(3)]
         z = Pc[2]
         with np.errstate(divide="ignore", invalid="ignore"):
             x = Pc[0] / z
             y = Pc[1] / z
             r2 = x * x + y * y
-            rad = 1.0 + k1[vi] * r2
-            u = focal[vi] * x * rad + cx
-            v = focal[vi] * y * rad + cy
+            rad = 1.0 + per_view(k1) * r2
+            fv = per_view(focal)
+            u = fv * x * rad + cx
+            v = fv * y * rad + cy
         vis = (z > 0.1) & (u >= 8) & (u <= width - 8) & (v >= 8) & (v <= height - 8) & (r2 < 1.5)
         ratio = 2.2 * target_total / max(int(vis.sum()), 1)
         if 0.92 < ratio < 1.08 or _attempt == 3:

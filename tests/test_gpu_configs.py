@@ -279,6 +279,88 @@ def test_two_ranks_on_the_real_kernels(pkg, tmp_path, scaling, scenes, want_tota
         assert g[sid, 15 * n_views + 2] == summ["final_cost"]
 
 
+def _run_bench_ranks(n_ranks, extra, timeout=900):
+    """bench.py under torch.distributed.run with n_ranks ranks sharing device 0 (PTZ_BENCH_SHARED_GPU=1, gloo): the parsed JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["PTZ_BENCH_SHARED_GPU"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--headline-only", "--scene-cache", ""] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_c5_as_headline_on_two_ranks(pkg):
+    """`bench.py --config C5 --gpus 2` (the query-sharded branch, which no other test runs): every rank solves ITS queries
+    (seed 1 + rank), the line counts the queries and LM iterations of both ranks over the slowest rank's time, and the figures of
+    rank 0's launch are those of the same queries solved through the batch API."""
+    nq, steps = 3000, 2
+    d = _run_bench_ranks(2, ["--config", "C5", "--queries", str(nq), "--steps", str(steps), "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["metric"].startswith("LM iterations/sec (PTZ-Reloc") and d["config"]["queries_per_gpu"] == nq
+    assert d["config"]["parallelism"] == "query-sharded x2"
+    par = d["parallel"]
+    assert par["world_size"] == 2 and par["world_size_seen_by_collective"] == 2 and len(par["ranks_ms_per_step"]) == 2
+    t = 1e-3 * d["ms_per_step"] * steps
+    assert abs(d["queries_per_s"] * t - 2 * nq * steps) < 1e-6 * nq  # both ranks' queries over the slowest rank's time
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel"] == "k_krt" and 0 < d["roofline"]["frac"] < 1
+    # LM iterations of BOTH ranks: rank r solves the queries of seed 1 + r
+    its = 0
+    for r in range(2):
+        rb = pkg.synth.make_reloc_queries(nq, 128, seed_id=1 + r, factor_type=0)
+        _, summ, _, _ = pkg.api.krt_solve_batch(rb)
+        its += sum(x["num_lm_steps"] for x in summ)
+    assert abs(d["value"] * t - its * steps) <= 1e-6 * its * steps
+
+
+def test_bench_c2_as_headline_on_two_ranks(pkg, tmp_path):
+    """`bench.py --config C2 --gpus 2`: ONE rig per rank (launch shapes of one system: the one-launch factorisation, the fused
+    control), rank 1's rig is seed 1, and both gathered blocks have the bits of solo solves."""
+    dump = str(tmp_path / "gathered.npy")
+    n_views, n_obs = 40, 120
+    d = _run_bench_ranks(2, ["--config", "C2", "--steps", "1", "--warmup", "0", "--views", str(n_views), "--obs", str(n_obs), "--dump-gathered", dump])
+    assert d["n_gpus"] == 2 and d["scenes_total"] == 2 and d["converged_scenes"] == 2
+    assert d["config"]["scenes_per_gpu"] == 1 and d["config"]["workload"].startswith("C2 (BASELINE configs[1])")
+    g = np.load(dump)
+    assert g.shape == (2, 15 * n_views + 3)
+    its = 0
+    for sid in range(2):
+        cam, _, summ = pkg.api.ba_solve(pkg.synth.make_scene(sid, n_views, n_obs))
+        assert np.array_equal(g[sid, :15 * n_views].reshape(n_views, 15), cam), sid
+        assert g[sid, 15 * n_views + 1] == summ["num_iterations"] and g[sid, 15 * n_views + 2] == summ["final_cost"]
+        its += summ["num_lm_steps"]
+    assert abs(d["value"] * 1e-3 * d["ms_per_step"] - its) < 1e-6 * its
+
+
+def test_eight_ranks_strong_scaling_uneven_shards(pkg, tmp_path):
+    """The launch the driver's scaling run makes at N = 8, on one shared GPU: 1003 small scenes dealt to eight ranks (three shards of
+    126, five of 125), gathered in scene order -- first contact with `--gpus 8` must not be the driver's."""
+    dump = str(tmp_path / "gathered.npy")
+    n_views, n_obs, total = 12, 60, 1003
+    d = _run_bench_ranks(8, ["--scaling", "strong", "--scenes", str(total), "--steps", "1", "--warmup", "0", "--views", str(n_views), "--obs", str(n_obs),
+                             "--workers", "2", "--dump-gathered", dump], timeout=1500)
+    par = d["parallel"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["scenes_total"] == total
+    assert par["world_size_seen_by_collective"] == 8 and len(par["ranks_ms_per_step"]) == 8
+    assert par["first_scene_of_rank0"] == 0 and par["scenes_of_rank0"] == 126
+    g = np.load(dump)
+    assert g.shape == (total, 15 * n_views + 3)
+    for sid in (0, 125, 126, 251, 252, 377, 378, 502, 503, 627, 628, 752, 753, 877, 878, 1002):  # both sides of every shard boundary
+        cam, _, summ = pkg.api.ba_solve(pkg.synth.make_scene(sid, n_views, n_obs))
+        assert np.array_equal(g[sid, :15 * n_views].reshape(n_views, 15), cam), sid
+        assert g[sid, 15 * n_views] == summ["termination_type"] and g[sid, 15 * n_views + 1] == summ["num_iterations"]
+
+
 def test_ptz_iba_batch_takes_the_decisions_of_solo_runs(pkg, monkeypatch):
     """PtzIncrementalOptimizer::SolveBatch (host/device_batcher.h): rigs of different size in lock step -- all pending bundle
     adjustments of a round in ONE ptz_ba_batch, all pending registration attempts in ONE ptz_krt_solve_batch launch -- against
