@@ -1560,6 +1560,7 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     std::vector<int> h_map, h_camimg;
     size_t trk_total = 0;
     int max_trk = 0;
+    int64_t view_key_top = 0;  // largest (longest candidate track bound) * cameras + cameras of the views: what the sort keys must hold
     for (int i = 0; i < n; ++i) {
       const ptz_rig* rg = views[i].rig;
       if (rg->device != b->device) { ptz_ba_batch_destroy(b); return PTZ_EINVAL; }
@@ -1576,8 +1577,13 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
       // k_view_keys puts there is below (the view's longest candidate track) * cameras, and a candidate track is no longer than the
       // rig's longest track or the number of candidate images -- NOT the rig's mean length: one long track in a wide view would
       // otherwise spill into the bits of the view number, and the batch-wide sort would silently be a different order.
-      if (rg->n_track >= (1 << 24) || (int64_t)std::min(rg->max_track_len, v.n_cam) * v.n_cam + v.n_cam >= (1 << 22)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
+      // That bound belongs to the BATCH-WIDE sort (k_view_keys, taken below when a rig has more than 16 384 tracks or on request);
+      // the one-launch sort (k_view_sort) keeps a 32-bit key of its own per view, whose padding value 2 << bits(top) must fit: top < 2^29.
+      view_key_top = std::max(view_key_top, (int64_t)std::min(rg->max_track_len, v.n_cam) * v.n_cam + v.n_cam);
+      if (rg->n_track >= (1 << 24)) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
     }
+    const bool block_sort = max_trk <= 16384 && !(getenv("PTZ_BA_VIEW_BLOCK_SORT") && atoi(getenv("PTZ_BA_VIEW_BLOCK_SORT")) == 0);
+    if (view_key_top >= (block_sort ? ((int64_t)1 << 29) : ((int64_t)1 << 22))) { ptz_ba_batch_destroy(b); return PTZ_ELIMIT; }
     const ViewDev* dviews_c = nullptr;
     const int *d_map = nullptr, *d_camimg = nullptr, *d_chunkoff = nullptr;
     std::vector<int> h_chunkoff(n);
@@ -1620,7 +1626,6 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     hipLaunchKernelGGL(k_view_tracks, gtrk, dim3(256), 0, st, vb);
     hipLaunchKernelGGL(k_view_scan, dim3(n), dim3(1024), 0, st, vb);
     // the views' internal ray order: one launch (a workgroup per view sorts its tracks) when every view fits, else the batch-wide sort
-    const bool block_sort = max_trk <= 16384 && !(getenv("PTZ_BA_VIEW_BLOCK_SORT") && atoi(getenv("PTZ_BA_VIEW_BLOCK_SORT")) == 0);
     if (block_sort) {
       {
         static std::mutex sort_mu;
@@ -2033,7 +2038,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
     {  // the back-substitution's work list, per scene (the kernel would otherwise make it itself, every launch: ~6 us of one wave)
       const int mg = chol_backsolve_max_groups(d.chol.np);
       const char* e = getenv("PTZ_BA_BACKSOLVE_HOST_LIST");  // 0: the kernel makes the list itself (tests: the same list, the same bits)
-      if ((!e || atoi(e) != 0) && sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
+      // (mg <= 1024: chol_backsolve_kernel keeps the kinds of the host list's groups in a fixed array of that many)
+      if ((!e || atoi(e) != 0) && mg <= 1024 && sizeof(double) * ((size_t)d.chol.np + 1024) + sizeof(BsItem) * 4 * (size_t)mg <= 150 * 1024) {  // (the kernel's own list form applies)
         h_items.resize((size_t)n * 4 * mg);
         h_groups.resize(n);
         // a few systems: the two arcs of a dissected system on a workgroup each (chol_backsolve_arcs); PTZ_BA_BACKSOLVE_SPLIT=0: one workgroup

@@ -743,3 +743,31 @@ def test_bench_floor_model_of_the_one_rig_iteration_adds_up():
     assert {"chain_pivots", "chain_hand_overs", "back_substitution", "k_eval", "k_schur_f"} <= set(terms)
     assert all(isinstance(v, float) and v > 0 for v in terms.values())
     assert abs(sum(terms.values()) - m["total_us"]) < 0.5 and m["total_us"] > 100.0 and "100 us" in m["note"]
+
+
+def test_inline_asm_dpp_sequences_keep_their_wait_states(tmp_path):
+    """the pivot sweep of the diagonal tile (ptz_chol.hip dpp_sweep) is inline asm, which the compiler's hazard
+    recogniser does not look into -- a DPP read of a VGPR needs two wait states behind the VALU write of it.  The device code is
+    compiled to assembly (cross-compiles without a GPU) and every DPP instruction's source is checked against the two
+    instructions before it (tools/check_dpp_hazards.py)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "chol.s")
+    src = os.path.join(ROOT, "ptz-calib_amd", "csrc", "ptz_chol.hip")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-S", src, "-o", out],
+                          stderr=subprocess.DEVNULL)
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_dpp, bad = mod.scan(out)
+    assert n_dpp >= 512, n_dpp   # two kernels carry the sweep: 16 broadcasts + 240 multiply-adds each
+    assert not bad, bad[:5]
+    # and the checker sees a violation when there is one
+    hz = tmp_path / "hazard.s"
+    hz.write_text("x:\n\tv_mul_f64 v[2:3], v[2:3], v[4:5]\n\tv_mul_f64 v[8:9], v[2:3], v[4:5]\n"
+                  "\tv_fmac_f64_dpp v[6:7], v[2:3], -v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
+    assert len(mod.scan(str(hz))[1]) == 1

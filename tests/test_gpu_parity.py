@@ -1403,7 +1403,7 @@ def test_view_ray_order_by_one_workgroup_per_view_is_the_batch_wide_sort(pkg, mo
     rs.close(); rl.close()
 
 
-def test_view_sort_key_overflow_is_refused(pkg):
+def test_view_sort_key_overflow_is_refused(pkg, monkeypatch):
     """The batch-wide sort key of a view batch holds (longest candidate track - length) * cameras + first camera in 22 bits.  The
     guard used the rig's MEAN track length: one track through all 2100 images of a wide view (2100 * 2100 > 2^22) passed it and
     spilled into the view-number bits -- a silently different ray order.  Now the rig keeps its longest track: that view is refused
@@ -1420,11 +1420,17 @@ def test_view_sort_key_overflow_is_refused(pkg):
         uv = rng.uniform(50, 1000, (len(img), 2)).astype(np.float32)
         return pkg.api.Rig(n_img, ptr, img, uv)
 
+    # (round 6: the bound belongs to the batch-wide sort only; the one-launch sort of a view's tracks -- the default up to 16 384
+    #  tracks per rig -- keeps a 32-bit key of its own and takes the wide view)
+    monkeypatch.setenv("PTZ_BA_VIEW_BLOCK_SORT", "0")
     rig = rig_with(n_img)
     with pytest.raises(Exception) as ei:
         pkg.api.ViewBatch([rig], [list(range(n_img))])
     assert "PTZ_ELIMIT" in str(ei.value)
-    rig.close()
+    monkeypatch.delenv("PTZ_BA_VIEW_BLOCK_SORT")
+    vb = pkg.api.ViewBatch([rig], [list(range(n_img))])
+    vb.close(); rig.close()
+    monkeypatch.setenv("PTZ_BA_VIEW_BLOCK_SORT", "0")
     rig = rig_with(1500)   # 1500 * 2100 + 2100 < 2^22
     vb = pkg.api.ViewBatch([rig], [list(range(n_img))])
     vb.close(); rig.close()
