@@ -1803,6 +1803,161 @@ __global__ __launch_bounds__(256, 3) void chol_update_col_h_kernel(CholBatch cb,
     for (int i = 0; i < 4; ++i) C[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc[c][i];
 }
 
+// ---- the same update, TWO row tiles per workgroup against one L_jk (round 6; PTZ_BA_CHOL_ROWS2) --------------------------------------
+// chol_update_col_h_kernel moves 32 KB of operand half tiles per 64 x 64 x 32 product (8 flop per byte) and was measured bound by
+// that traffic and by the latency behind it, not by the matrix cores (MFMA busy 30-34 %).  Here a workgroup takes two tiles (i0, j),
+// (i1, j) of the column's structure and multiplies both against the same L_jk: 48 KB per two products (10.7 flop per byte), twice
+// the MFMAs between two barriers, six LDS fragment reads per eight MFMAs instead of five per four.  The list of block columns is
+// the union of the two tiles' lists in schedule order with a mask per entry; each tile's accumulators take exactly the products of
+// its own list in its own order: same bits as one tile per workgroup.
+__global__ __launch_bounds__(256, 2) void chol_update_col_h2_kernel(CholBatch cb, int j, int fuse_diag)
+{
+  int bx, slot;
+  xcd_remap(bx, slot);
+  const int sys = chol_system_of(cb, slot);
+  if (sys < 0 || (cb.active && !cb.active[sys])) return;
+  const int np = cb.np, nt = np / NB;
+  const int n = cb.n[sys];
+  if (j * NB > n) return;
+  const unsigned char* tm = cb.tmask ? cb.tmask + (size_t)sys * nt * nt : nullptr;
+  // the (2 bx)-th and (2 bx + 1)-th tiles of column j's structure, top down (the diagonal tile is the first)
+  int ti0 = -1, ti1 = -1;
+  {
+    int cnt = 0;
+    for (int t = j; t < nt && t * NB <= n; ++t) {
+      if (tm && !tm[t * nt + j]) continue;
+      if (cnt == 2 * bx) ti0 = t;
+      if (cnt == 2 * bx + 1) { ti1 = t; break; }
+      ++cnt;
+    }
+  }
+  if (ti0 < 0) return;
+  const bool two = ti1 >= 0;
+  double* A = cb.A + (size_t)sys * np * np;
+  __shared__ __attribute__((aligned(16))) double Ls[3 * NB * LDH];  // -L_i0k, -L_i1k, L_jk halves; afterwards (fuse_diag) the diagonal tile at stride LD
+  static_assert(3 * NB * LDH >= NB * LD, "the diagonal tile is factored in the operand buffers");
+  double* As0 = Ls;
+  double* As1 = Ls + NB * LDH;
+  double* Bs = Ls + 2 * NB * LDH;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  double* C0 = A + (size_t)(ti0 * NB + 16 * w) * np + j * NB;
+  double* C1 = A + (size_t)((two ? ti1 : ti0) * NB + 16 * w) * np + j * NB;
+  d4 acc0[4], acc1[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc0[c][i] = C0[(size_t)(fq + 4 * i) * np + 16 * c + fr]; acc1[c][i] = C1[(size_t)(fq + 4 * i) * np + 16 * c + fr]; }
+  const double* ap0 = As0 + (16 * w + fr) * LDH + fq;
+  const double* ap1 = As1 + (16 * w + fr) * LDH + fq;
+  const double* bp = Bs + fr * LDH + fq;
+  __shared__ short klist[1024];
+  __shared__ unsigned char kmask[1024];  // bit 0: the entry is in tile i0's list, bit 1: in tile i1's
+  __shared__ int kcount;
+  if (threadIdx.x < 64) {
+    const int nq = cb.sched ? CHOL_STEP_COLS * cb.n_steps : j;
+    const int* sq = cb.sched ? cb.sched + (size_t)sys * nt * CHOL_STEP_COLS : nullptr;
+    int cnt = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int qq = q0 + (int)threadIdx.x;
+      const int kc = qq < nq ? (sq ? sq[qq] : qq) : -1;
+      const bool in = kc >= 0 && kc < j;
+      const int kk = in ? kc : 0;
+      const bool inj = in && (!tm || tm[j * nt + kk]);
+      const int m = inj ? ((!tm || tm[ti0 * nt + kk]) ? 1 : 0) | ((two && (!tm || tm[ti1 * nt + kk])) ? 2 : 0) : 0;
+      const bool ok = m != 0;
+      const unsigned long long bal = __ballot(ok);
+      const int pos = cnt + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+      if (ok && pos < 1024) { klist[pos] = (short)kc; kmask[pos] = (unsigned char)m; }
+      cnt += __popcll(bal);
+    }
+    if (threadIdx.x == 0) kcount = min(cnt, 1024);
+  }
+  __syncthreads();
+  const int Q = kcount;
+  const bool any = Q > 0;
+  auto kq = [&](int qq) { return any ? (int)klist[qq < Q ? qq : Q - 1] : 0; };
+  auto mq = [&](int qq) { return any ? (int)kmask[qq < Q ? qq : Q - 1] : 0; };
+  // unit u = half (u & 1) of the operand tiles of list entry u >> 1; a tile outside the entry's mask is not fetched (uniform branch)
+  auto fetch_a0 = [&](int u) { return half_fetch(A + (size_t)(ti0 * NB) * np + kq(u >> 1) * NB + KH * (u & 1), np); };
+  auto fetch_a1 = [&](int u) { return half_fetch(A + (size_t)((two ? ti1 : ti0) * NB) * np + kq(u >> 1) * NB + KH * (u & 1), np); };
+  auto fetch_b = [&](int u) { return half_fetch(A + (size_t)(j * NB) * np + kq(u >> 1) * NB + KH * (u & 1), np); };
+  d8 ra0 = fetch_a0(0), ra1 = fetch_a1(0), rb = fetch_b(0), sa0 = fetch_a0(1), sa1 = fetch_a1(1), sb = fetch_b(1);
+  auto step = [&](d8& xa0, d8& xa1, d8& xb, int ucur, int uf) {
+    const int m = mq(ucur >> 1);
+    __syncthreads();  // the previous step's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < (NB * KH / 2) / 256; ++p) {
+      const int idx = p * 256 + threadIdx.x;
+      const int row = idx >> 4, c2 = (idx & 15) * 2;
+      *reinterpret_cast<double2*>(As0 + row * LDH + c2) = make_double2(-xa0[2 * p], -xa0[2 * p + 1]);
+      *reinterpret_cast<double2*>(As1 + row * LDH + c2) = make_double2(-xa1[2 * p], -xa1[2 * p + 1]);
+      *reinterpret_cast<double2*>(Bs + row * LDH + c2) = make_double2(xb[2 * p], xb[2 * p + 1]);
+    }
+    __syncthreads();
+    xa0 = fetch_a0(uf);
+    xa1 = fetch_a1(uf);
+    xb = fetch_b(uf);
+    if (m == 3) {
+#pragma unroll
+      for (int kk = 0; kk < KH / 4; ++kk) {
+        const double av0 = ap0[4 * kk], av1 = ap1[4 * kk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double bv = bp[(16 * c) * LDH + 4 * kk];
+          acc0[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv, acc0[c], 0, 0, 0);
+          acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv, acc1[c], 0, 0, 0);
+        }
+      }
+    }
+    else if (m == 1) {
+#pragma unroll
+      for (int kk = 0; kk < KH / 4; ++kk) {
+        const double av0 = ap0[4 * kk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc0[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bp[(16 * c) * LDH + 4 * kk], acc0[c], 0, 0, 0);
+      }
+    }
+    else {
+#pragma unroll
+      for (int kk = 0; kk < KH / 4; ++kk) {
+        const double av1 = ap1[4 * kk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bp[(16 * c) * LDH + 4 * kk], acc1[c], 0, 0, 0);
+      }
+    }
+  };
+  for (int u = 0; u < 2 * Q; u += 2) {  // the two register sets take turns: first and second half of a list entry
+    step(ra0, ra1, rb, u, u + 2);
+    step(sa0, sa1, sb, u + 1, u + 3);
+  }
+  const bool diag = fuse_diag && ti0 == j;
+  if (two && any) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) C1[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc1[c][i];
+  }
+  if (diag) {
+    // the diagonal tile of this block column is complete: factor it here, no separate diagonal launch for step j
+    __shared__ __attribute__((aligned(16))) double Dv[4][DB * LDD];
+    __shared__ int okflag;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Ls[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = acc0[c][i];
+    __syncthreads();
+    diag_factor_tile(Ls, Dv, &okflag, cb, sys, j, n);
+    return;
+  }
+  if (!any) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C0[(size_t)(fq + 4 * i) * np + 16 * c + fr] = acc0[c][i];
+}
+
 // ---- full inverses of the factored diagonal tiles, all at once (the multi-launch paths; the one-launch-per-column path
 //      computes them in a spare workgroup of every launch) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_tile_inverse_kernel(CholBatch cb)
@@ -2084,6 +2239,11 @@ void chol_update_col_launch(const CholBatch& cb, int j, hipStream_t stream, bool
   // operand tiles in halves (three workgroups per compute unit): 81.5 -> 73.4 ms of column updates per C4 solve, same bits;
   // PTZ_BA_CHOL_HALFK=0 brings the whole-tile kernel back (A/B measurements)
   static const bool halfk = [] { const char* e = getenv("PTZ_BA_CHOL_HALFK"); return !e || atoi(e) != 0; }();
+  // two row tiles per workgroup (round 6): built, bit-identical, and SLOWER -- chol_syrk 18.3 -> 24.3 ms per 256-scene solve (A/B on one
+  // box, tools/probes/probe_r6_rows2.sh): 256 registers with 160 B of scratch and 64.5 KB of LDS leave two workgroups per compute unit
+  // with half as many workgroups in flight, and the fewer operand bytes do not pay for that.  PTZ_BA_CHOL_ROWS2=1 runs it.
+  static const bool rows2 = [] { const char* e = getenv("PTZ_BA_CHOL_ROWS2"); return e && atoi(e) != 0; }();
+  if (j > 0 && m > 0 && halfk && rows2) { launch(chol_update_col_h2_kernel, dim3((m + 1) / 2, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0); return; }
   if (j > 0 && m > 0) {
     if (halfk) launch(chol_update_col_h_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
     else launch(chol_update_col_kernel, dim3(m, cb.count), dim3(256), 0, stream, cb, j, fuse_diag ? 1 : 0);
