@@ -640,6 +640,12 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
   // batch is solved once, as every bundle adjustment of the incremental pipeline is)
   const bool graph = b->use_graph && !b->profiling && !b->lookahead && b->d.chol.tmask != nullptr && b->n_solves > 0;
   ++b->n_solves;
+  // Passes per replayed graph.  Between two graph launches on a stream the device idles ~8.4 us (kernel trace of the one-rig solve:
+  // the six kernels of a pass abut, the next pass's first kernel starts 8.4-8.8 us behind the last) -- 4 % of a one-rig pass.  Launch
+  // shapes of a few scenes therefore replay graphs of SEVERAL passes (PTZ_BA_GRAPH_PASSES; the passes past a scene's end are the empty
+  // launches they always were: at most that many more of them per solve).
+  static const int graph_passes_few = [] { const char* e = getenv("PTZ_BA_GRAPH_PASSES"); return e ? std::max(1, std::min(16, atoi(e))) : 1; }();
+  auto graph_passes = [&](const PassShape& sh) { return sh.slots <= 8 ? graph_passes_few : 1; };
   auto graph_of = [&](int g, int si) -> hipGraphExec_t {  // built on first use: one node per launch, a linear chain
     if (b->pass_graph[g][si]) return b->pass_graph[g][si];
     GraphRecorder rec;
@@ -649,7 +655,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       g_recorder = &rec;
       PassShape shg = b->shapes[si];
       if (si == 0) shg.slots = b->group_count[g];
-      enqueue_pass<TYPE>(b, b->dg[g], shg);
+      for (int rep = 0; rep < graph_passes(shg); ++rep) enqueue_pass<TYPE>(b, b->dg[g], shg);
       g_recorder = nullptr;
       ok = rec.ok && hipGraphInstantiate(&b->pass_graph[g][si], rec.graph, nullptr, nullptr, 0) == hipSuccess;
     }
@@ -676,7 +682,7 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
     for (int g = 0; g < G; ++g) {
       if (!galive[g]) continue;
       if (__atomic_load_n(&b->h_ctl[4 * g + 1], __ATOMIC_ACQUIRE)) { galive[g] = 0; --alive; progressed = true; continue; }
-      if (enq[g] == max_it) { galive[g] = 0; --alive; progressed = true; continue; }  // every step the options allow is enqueued (the last pass's k_lm_pre closes the books)
+      if (enq[g] >= max_it) { galive[g] = 0; --alive; progressed = true; continue; }  // every step the options allow is enqueued (the last pass's k_lm_pre closes the books)
       if (enq[g] - std::max(__atomic_load_n(&b->h_ctl[4 * g], __ATOMIC_ACQUIRE), credit[g]) >= b->ahead) continue;
       const double te0 = now();
       b->stream = b->streams[g];
@@ -692,10 +698,14 @@ template <int TYPE> int solve_impl(ptz_ba_batch* b, ptz_lm_summary* out)
       PassShape sh = b->shapes[si];
       if (si == 0) { sh.slots = b->group_count[g]; }
       if (dbg) { if (shape_used.size() < b->shapes.size()) shape_used.resize(b->shapes.size(), 0); ++shape_used[si]; }
-      hipGraphExec_t ge = (!last && graph && b->use_graph) ? graph_of(g, si) : nullptr;
+      // (one or two rigs: the passes are enqueued as they are -- a pass is ~200 us of device time against ~25 us of host time for its
+      //  six launches, and between two REPLAYED graphs the device idles 8.4 us: 5.20 -> 5.09 ms per 25-iteration solve of the C2 rig,
+      //  A/B on one box; PTZ_BA_GRAPH_FEW=1 replays graphs there too)
+      static const bool graph_few = [] { const char* e = getenv("PTZ_BA_GRAPH_FEW"); return e && atoi(e) != 0; }();
+      hipGraphExec_t ge = (!last && graph && b->use_graph && (sh.slots > 2 || graph_few)) ? graph_of(g, si) : nullptr;
       if (ge) PTZ_HIP_TRY(hipGraphLaunch(ge, b->streams[g]));
       else { b->stream = b->streams[g]; enqueue_pass<TYPE>(b, b->dg[g], sh); }
-      ++enq[g];
+      enq[g] += ge ? graph_passes(sh) : 1;
       progressed = true;
       t_enq += now() - te0;
     }
