@@ -1440,8 +1440,8 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
 #endif
       stash(cc, rb[c]);
       __syncthreads();
-      trsm_block_solve<c>(xa, np, Di, As + 16 * w * LD, ti == tj ? Lik : nullptr);
-      if (ti != tj) trsm_block_solve<c>(xb, np, Di, Bs + 16 * w * LD, nullptr);
+      if (ti != tj) trsm_block_solve2<c>(xa, xb, np, Di, Di, As + 16 * w * LD, Bs + 16 * w * LD, nullptr, nullptr);
+      else trsm_block_solve<c>(xa, np, Di, As + 16 * w * LD, Lik);
       __syncthreads();  // X_c of every wave is in LDS
 #pragma unroll
       for (int kk = 4 * c; kk < 4 * c + 4; ++kk) {
@@ -1461,17 +1461,17 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       __syncthreads();
       double* xsa = As + 16 * w * LD;
       double* xsb = Bs + 16 * w * LD;
-      trsm_block_solve<0>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
-      if (ti != tj) trsm_block_solve<0>(xb, np, Di, xsb, nullptr);
+      if (ti != tj) trsm_block_solve2<0>(xa, xb, np, Di, Di, xsa, xsb, nullptr, nullptr);  // (the two solves of an off-diagonal tile side by side)
+      else trsm_block_solve<0>(xa, np, Di, xsa, Lik);
       trsm_block_pre<1>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<1>(xb, Lk, xsb);
-      trsm_block_solve<1>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
-      if (ti != tj) trsm_block_solve<1>(xb, np, Di, xsb, nullptr);
+      if (ti != tj) trsm_block_solve2<1>(xa, xb, np, Di, Di, xsa, xsb, nullptr, nullptr);  // (the two solves of an off-diagonal tile side by side)
+      else trsm_block_solve<1>(xa, np, Di, xsa, Lik);
       trsm_block_pre<2>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<2>(xb, Lk, xsb);
-      trsm_block_solve<2>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
-      if (ti != tj) trsm_block_solve<2>(xb, np, Di, xsb, nullptr);
+      if (ti != tj) trsm_block_solve2<2>(xa, xb, np, Di, Di, xsa, xsb, nullptr, nullptr);  // (the two solves of an off-diagonal tile side by side)
+      else trsm_block_solve<2>(xa, np, Di, xsa, Lik);
       trsm_block_pre<3>(xa, Lk, xsa); if (ti != tj) trsm_block_pre<3>(xb, Lk, xsb);
-      trsm_block_solve<3>(xa, np, Di, xsa, ti == tj ? Lik : nullptr);
-      if (ti != tj) trsm_block_solve<3>(xb, np, Di, xsb, nullptr);
+      if (ti != tj) trsm_block_solve2<3>(xa, xb, np, Di, Di, xsa, xsb, nullptr, nullptr);  // (the two solves of an off-diagonal tile side by side)
+      else trsm_block_solve<3>(xa, np, Di, xsa, Lik);
       __syncthreads();  // X of every wave is in LDS
 #pragma unroll
       for (int kk = 0; kk < NB / 4; ++kk) {
