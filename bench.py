@@ -178,33 +178,39 @@ def load_traffic(tag):
 
 
 def c2_floor_model():
-    """What ONE LM iteration of the C2 rig costs at least with the present structure, term by term (profiles/NOTES_r05.md section 4d-4f:
-    every constant is a probe's measurement on MI355X, none is fitted to the bench figure).  The 800 x 800 reduced camera system is
-    13 tiles of 64 columns in 8 levels of the dissected elimination order; a level is one diagonal tile's factorisation (four 16-pivot
-    sweeps of one wave, a rank-16 update between two sweeps) plus the hand-over to the next level's tile on another compute unit."""
+    """What ONE LM iteration of the C2 rig costs at least with the present structure, term by term (profiles/NOTES_r06.md section 1:
+    every constant is a probe's or the chain timeline's measurement on MI355X at the ~2.45 GHz the shader clock holds during the chain,
+    none is fitted to the bench figure; on another part or clock they go stale).  The 800 x 800 reduced camera system is 13 tiles of 64
+    columns in 8 levels of the dissected elimination order; a level is one diagonal tile's factorisation (four 16-pivot sweeps of one
+    wave, a rank-16 update between two sweeps) plus the hand-over to the next level's tile on another compute unit."""
     levels, sweeps, pivots = 8, 4, 16
-    ns_pivot = 200 / 2.4                 # 200 cycles per pivot of the DPP sweep in the product (sweep16_probe: 171 alone) at 2.4 GHz
+    ns_pivot = 165 / 2.45                # 165 cycles per pivot of the software-pipelined DPP sweep (sweep16_probe; issue-bound: issue_probe)
     t = {
         "chain_pivots": levels * sweeps * pivots * ns_pivot * 1e-3,      # the dependent chain itself
         "chain_sweep_lds": levels * sweeps * 0.45,                       # a sweep's column block from LDS and back (1 100 cycles)
         "chain_rank16_updates": levels * (sweeps - 1) * 0.40,            # MFMA update + two barriers between two sweeps
-        "chain_hand_overs": (levels - 1) * 4.0,                          # flag + block across compute units, solve, update, to LDS
-        "chain_second_ready_column": 2 * 5.5,                            # levels 2 and 4: two producers end together, applied in turn
+        "chain_tile_in_and_out_of_lds": levels * 1.3,                    # accumulators -> image, last block's publication
+        "chain_hand_overs": 5 * 2.2,                                     # chased columns: sc1 flag + block fetch, last solve round, a quarter of the update
+        "chain_two_producer_levels": 2 * 6.5,                            # levels 2 and 4: two producers end together -- taken side by side, then the second's 64 update MFMAs
+        "chain_late_off_diagonal_tile": 5.0,                             # tile (9, 8): six columns of two solves + an update each pace it (FP64 MFMA: 64 cycles each)
         "chain_last_tile_inverse": 3.0,
         "back_substitution": 45 * 32768 / 142e9 * 1e6 + 9 * 0.9 + 2.5,   # 45 of the 76 tiles through a compute unit at 142 GB/s (the two arcs on a workgroup each), nine inverse groups, start
-        "k_eval": 14.0, "k_lin_cam_and_control": 17.0, "k_schur_f": 16.0, "k_ray_prep": 7.0,   # longest thread's work, one wave per SIMD (k_eval: four lanes per ray)
+        "k_eval": 14.0, "k_lin_cam_and_control": 11.0, "k_schur_f": 14.0, "k_ray_prep": 5.0,   # longest thread's work, one wave per SIMD (k_eval: four lanes per ray)
+        "launch_boundaries": 6 * 1.6,                                    # six dependent kernels per pass, enqueued eagerly
     }
     out = {k: round(v, 1) for k, v in t.items()}
     out["total_us"] = round(sum(t.values()), 1)
-    out["note"] = ("sum of the dependent stretches of one pass; launch boundaries inside the replayed graph not counted.  The north star's "
-                   "10 k it/s is 100 us per iteration: below this structure's floor -- NOTES_r05 4f says what would have to change")
+    out["measured_on"] = "MI355X (gfx950), shader clock ~2.45 GHz during the chain kernel; round-6 probes (tools/probes/hip/issue_probe.hip, sweep16_probe.hip, probe_r6_tl.sh)"
+    out["note"] = ("sum of the dependent stretches of one pass.  The north star's 10 k it/s is 100 us per iteration: below this "
+                   "structure's floor -- NOTES_r06 section 1 says what the round removed (L2 write-backs and invalidates of the hand-overs) and what is left")
     return out
 
 
 # ------------------------------------------------------------------------------------------------------------------ legs
 def single_rig_leg(pkg, scene, device_id):
-    """BASELINE configs[1]: ONE 200 x 500 rig alone on the GPU.  Wall time of a whole solve (graph-replayed passes, nothing
-    profiled), then the same solve with HIP events around every kernel family: the per-pass critical path in microseconds."""
+    """BASELINE configs[1]: ONE 200 x 500 rig alone on the GPU.  Wall time of a whole solve (the library's defaults: for one rig the
+    passes are enqueued as they are, nothing profiled), then the same solve with HIP events around every kernel family: the per-pass
+    critical path in microseconds."""
     import torch
     b1 = pkg.api.BaBatch([scene], device_id=device_id)
     b1.set_state(); b1.solve()
