@@ -48,7 +48,11 @@ extern "C" {
 #define PTZ_BA_PTZRayFxfyDist 2 /* fx, fy, k1 free (ptzray_optimizer.cc:136-191); camera block of 6 columns */
 #define PTZ_BA_PTZRayDistDisp 3 /* fx, k1 free + ONE 3-parameter displacement block shared by every residual of the problem
                                  * (ptzray_optimizer.cc:195-265, disp_param_ :655; with annotations Reproj2d3dDispFactor :334-396);
-                                 * closed-form Jacobians -- the reference's central differences are not reproduced, DESIGN.md section 7 */
+                                 * CLOSED-FORM JACOBIANS ONLY, a documented deviation (type 3 is dead from the reference's tools): the
+                                 * reference differentiates the d2 column numerically with delta = 1.49e-8 against f^2 ~ 6e6, so ITS
+                                 * column is a per cent off and its trajectory follows that through the flat valley of (f, k1, disp);
+                                 * this library converges to the closed-form oracle's point (1e-6) and may stop up to 8 % in f from the
+                                 * numeric-differentiation reference at equal cost (tests/test_gpu_disp.py holds the number) */
 /* KRTOptimizer::FACTOR_TYPE { F, FDist, Fxfy, FxfyDist }  (krt_optimizer.h:110) */
 #define PTZ_KRT_F 0
 #define PTZ_KRT_FDist 1

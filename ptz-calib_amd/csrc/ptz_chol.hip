@@ -253,10 +253,18 @@ template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], dou
     if constexpr (NP > 12) dpp_fill<P, 12, NP>(ar, a); else asm volatile("s_nop 0");
     dpp_fill<J, 0, 2>(ar, a);            // column J + 1 is final
     ird[J] = y;
-    const bool live = J < live_cols;
-    dmin = fmin(dmin, live ? d : 1.0);   // NaN pivots: fmin keeps the other operand, caught by `bad`
-    bad |= (d != d) && live;
     dpp_sweep<J + 1>(ar, a, ird, live_cols, dmin, bad, c15);
+  }
+  else {
+    // A pivot that is not positive (or not a number) leaves a NaN as its 1 / sqrt(d): rsq of a negative number or of a NaN is a NaN,
+    // of a zero an infinity that the Newton steps turn into one -- so the sixteen checks of the pivots are ONE sum of the live pivots'
+    // reciprocal roots behind the sweep (was: a compare, a minimum and their masks per pivot, 150 instructions that the compiler
+    // gathered behind the asm block, on the chain).  (An infinite pivot, which the old test let pass, is reported as well.)
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < DB; ++j) acc += (j < live_cols) ? ird[j] : 0.0;
+    bad |= acc != acc;
+    (void)dmin;
   }
 }
 
@@ -265,10 +273,16 @@ template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], dou
 // multiply-adds in the same order as diag_block_inverse (bit-identical), and no wave has to compute it afterwards.  It goes to
 // dv (LDS, [16][LDD]) and, if dg is given (the last block: nothing else of it is needed by a consumer), to global memory --
 // with `flag`, as stores that go through to memory, followed by the flag itself.
+#ifdef PTZ_CHOL_TIMELINE
+__device__ long long dft_sw[64][8];   // per diagonal tile and block: pivots begin, pivots end
+#endif
 template <bool DPP = false>
 __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, int n, double& dmin, bool& bad, double* dv = nullptr, double* dg = nullptr,
                                                  int* flag = nullptr, int gen = 0)
 {
+#ifdef PTZ_CHOL_TIMELINE
+  long long* flag_dbg_row = (DPP && kbase / NB < 64) ? &dft_sw[kbase / NB][2 * b] : nullptr;
+#endif
   const int lane = threadIdx.x & 63;
   const int rows = NB - DB * b;  // rows 16 b .. 63 of the tile live in lanes 0 .. rows - 1
   // The rows of the diagonal block start with a zero upper triangle, so that L[r][j] = A[r][j] / sqrt(d) needs no case
@@ -299,7 +313,13 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 #pragma unroll
       for (int q = 0; q < DB; ++q) a[q] = (q == (lane & (DB - 1))) ? 1.0 : 0.0;
     }
+#ifdef PTZ_CHOL_TIMELINE
+    if (threadIdx.x == 0 && flag_dbg_row) flag_dbg_row[0] = wall_clock64();
+#endif
     dpp_sweep<0>(ar, a, ird, n - (kbase + DB * b), dmin, bad);
+#ifdef PTZ_CHOL_TIMELINE
+    if (threadIdx.x == 0 && flag_dbg_row) flag_dbg_row[1] = wall_clock64();
+#endif
     if (inv_rows) {
       const int r = lane & (DB - 1);
 #pragma unroll
@@ -469,6 +489,12 @@ __device__ __forceinline__ void tile_inverse(const double* Ls, const double* Dis
   }
 }
 
+#ifdef PTZ_CHOL_TIMELINE  // probe builds: inside the diagonal tiles' factorisation (system 0), per block: update phase done, sweep phase done
+__device__ long long dft_tl[64][12];
+#define DFT_STAMP(i) do { if (threadIdx.x == 0 && Fk && sys == 0 && k < 64) dft_tl[k][i] = wall_clock64(); } while (0)
+#else
+#define DFT_STAMP(i) do { } while (0)
+#endif
 // Fk (chol_chain_kernel only): four flags of this tile; flag b is raised with `gen` once column block b of L_kk (its rows below the
 // diagonal block) and the inverse of its diagonal block are in global memory.
 // DPP (the kernels whose critical path this is: chol_chain_kernel, chol_col_step_kernel): the sweep itself leaves the inverses of
@@ -488,6 +514,7 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
   double dmin = 1.0;
   bool bad = false;
   if (DPP && Fk && threadIdx.x == 0) *okflag_p = 0;  // block 0 has two publishers (its rows: wave 3, its inverse: wave 1): the second one raises the flag
+  DFT_STAMP(0);
 #pragma unroll 1
   for (int b = 0; b < NB / DB; ++b) {
     // C(ri, c) -= X(ri, m) X(c, m)^T on the matrix cores, one wave; `diag`: the finished diagonal block goes back with zeros above its diagonal
@@ -541,6 +568,7 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
       }
       __syncthreads();
     }
+    DFT_STAMP(1 + 2 * b);  // column block b is up to date
     if constexpr (DPP) {
       if (w == 0) {
         const bool last = b == NB / DB - 1;
@@ -569,8 +597,10 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
       else if (w == 1 && b > 0) diag_block_inverse(As, b - 1, Dg + (b - 1) * (DB * DB), Dv[b - 1]);
       else if (w == 2 && b > 0) diag_store_block(As, b - 1, Lg);
     }
+    if (w == 0) DFT_STAMP(2 + 2 * b);  // the sweep of block b is done (before the barrier)
     __syncthreads();
   }
+  DFT_STAMP(9);
   if (w == 0 && lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
   if (!DPP && w == 1) diag_block_inverse(As, NB / DB - 1, Dg + (NB / DB - 1) * (DB * DB), Dv[NB / DB - 1]);
   else if (w == 2) diag_store_block(As, NB / DB - 1, Lg);
@@ -1157,6 +1187,15 @@ __global__ void chol_chain_tl_print(int nt)
 {
   long long t0 = 0x7fffffffffffffffll;
   for (int o = 0; o < nt * (nt + 1) / 2; ++o) if (chain_tl[o][0] > 0 && chain_tl[o][0] < t0) t0 = chain_tl[o][0];
+  for (int k = 0; k < nt && k < 64; ++k) {
+    const long long* r = dft_tl[k];
+    if (r[0] <= 0) continue;
+    printf("tl dft tile %2d: in %.2f |", k, (r[0] - t0) / 100.0);
+    for (int b = 0; b < 4; ++b) printf(" b%d updated %.2f swept %.2f", b, (r[1 + 2 * b] - t0) / 100.0, (r[2 + 2 * b] - t0) / 100.0);
+    printf(" | out %.2f | pivots", (r[9] - t0) / 100.0);
+    for (int b = 0; b < 4; ++b) printf(" %.2f-%.2f", (dft_sw[k][2 * b] - t0) / 100.0, (dft_sw[k][2 * b + 1] - t0) / 100.0);
+    printf("\n");
+  }
   int o = 0;
   for (int tj = 0; tj < nt; ++tj)
     for (int ti = tj; ti < nt; ++ti, ++o) {
