@@ -45,20 +45,28 @@ template <int KTYPE> struct KFree {
 template <int NF>
 __device__ __forceinline__ bool spd_solve(double* A, double* b)
 {
+  double inv[NF];  // 1 / L_jj
 #pragma unroll
   for (int j = 0; j < NF; ++j) {
     double d = A[j * NF + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * NF + k] * A[j * NF + k];
     if (!(d > 0.0)) return false;
-    d = sqrt(d);
-    A[j * NF + j] = d;
+    // (round 6) ONE reciprocal per column -- 1 / sqrt(d) to working precision (rsq + two Newton steps) -- instead of a square root and
+    // 2 (NF - 1 - j) + 2 IEEE divisions by it: a division is ~18 instructions on this chip and the solve had twenty of them, every
+    // lane of the group its own copy.  The factor and the solution differ from the divided form in the last bits (the step is held
+    // to the oracle's QR step at 1e-6 either way).
+    double rs = __builtin_amdgcn_rsq(d);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    inv[j] = rs;
+    A[j * NF + j] = d * rs;
 #pragma unroll
     for (int i = j + 1; i < NF; ++i) {
       double v = A[i * NF + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) v -= A[i * NF + k] * A[j * NF + k];
-      A[i * NF + j] = v / d;
+      A[i * NF + j] = v * rs;
     }
   }
 #pragma unroll
@@ -66,14 +74,14 @@ __device__ __forceinline__ bool spd_solve(double* A, double* b)
     double v = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) v -= A[i * NF + k] * b[k];
-    b[i] = v / A[i * NF + i];
+    b[i] = v * inv[i];
   }
 #pragma unroll
   for (int i = NF - 1; i >= 0; --i) {
     double v = b[i];
 #pragma unroll
     for (int k = i + 1; k < NF; ++k) v -= A[k * NF + i] * b[k];
-    b[i] = v / A[i * NF + i];
+    b[i] = v * inv[i];
   }
   return true;
 }
