@@ -326,11 +326,10 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
 #pragma unroll
       for (int k = 0; k < NF; ++k) diag[k] = fmin(fmax(A[k * NF + k], o.min_lm_diagonal), o.max_lm_diagonal);
     }
-    double Hs[NF * NF], gs[NF];
+    // (the scaled system is not kept beside the solve's working copy: the model cost change below takes its entries from the packed
+    //  H and the scales again -- the same products, H_kl s_k s_l and g_k s_k -- which frees 30 doubles of registers across the solve)
 #pragma unroll
-    for (int k = 0; k < NF * NF; ++k) Hs[k] = A[k];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) { gs[k] = b[k]; const double D = sqrt(diag[k] / radius); A[k * NF + k] += D * D; }
+    for (int k = 0; k < NF; ++k) { const double D = sqrt(diag[k] / radius); A[k * NF + k] += D * D; }
     const bool solved = spd_solve<NF>(A, b);
     ++n_solves;
     reuse_diagonal = true;
@@ -343,10 +342,13 @@ __global__ __launch_bounds__(256, (KTYPE & 1) ? PTZ_KRT_OCC_DIST : PTZ_KRT_OCC_P
       double sg = 0, shs = 0;
 #pragma unroll
       for (int k = 0; k < NF; ++k) {
-        sg += step[k] * gs[k];
+        sg += step[k] * (g[k] * scale[k]);
         double t = 0;
 #pragma unroll
-        for (int l = 0; l < NF; ++l) t += Hs[k * NF + l] * step[l];
+        for (int l = 0; l < NF; ++l) {
+          const int hi = k > l ? k : l, lo = k > l ? l : k;
+          t += (H[hi * (hi + 1) / 2 + lo] * scale[hi] * scale[lo]) * step[l];
+        }
         shs += step[k] * t;
       }
       mcc = -(sg + 0.5 * shs);
