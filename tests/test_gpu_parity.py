@@ -1316,6 +1316,46 @@ def test_chain_handover_soak(pkg):
         b.close()
 
 
+def test_chain_handover_soak_under_load(pkg):
+    """Round 6 took the fences out of the chain kernel's hand-overs (write-through sc1 stores, drained, sc1 loads; no L2 write-back,
+    no L1 invalidate).  A stale hand-over hides on an idle chip: here another host thread keeps the device busy with relocalization
+    launches and a batch of its own on other streams while a 13-tile rig and a pair of them are solved over and over -- every solve
+    must have the bits of the first (tools/probes/probe_r6_soak.py ran 3.4 million LM iterations of this; profiles/r06_soak.txt)."""
+    import threading
+    stop = threading.Event()
+
+    def load():
+        rb = pkg.synth.make_reloc_queries(6000, 128, seed_id=5, factor_type=1)
+        big = pkg.api.BaBatch([pkg.synth.make_scene(40 + i, 40, 150) for i in range(24)]); big.set_state()
+        k = 0
+        while not stop.is_set():
+            pkg.api.krt_solve_batch(rb)
+            if k % 3 == 0:
+                big.solve()
+            k += 1
+        big.close()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        rigs = [pkg.synth.make_scene(3 + i, 200, 500) for i in range(2)]
+        for n, reps in ((1, 60), (2, 30)):
+            b = pkg.api.BaBatch(rigs[:n]); b.set_state()
+            first = None
+            for it in range(reps):
+                summ = b.solve(); cams, rays = b.get_state()
+                got = (summ, [c.copy() for c in cams], [r.copy() for r in rays])
+                if first is None:
+                    first = got
+                    continue
+                assert got[0] == first[0], (n, it)
+                assert all(np.array_equal(a, c) for a, c in zip(got[1], first[1])) and all(np.array_equal(a, c) for a, c in zip(got[2], first[2])), (n, it)
+            b.close()
+    finally:
+        stop.set()
+        th.join()
+
+
 def test_ba_lost_chain_handover_is_reported_not_absorbed(pkg, scene_c1, monkeypatch):
     """chol_chain_kernel's waits are bounded (never a hang).  A wait that runs out used to mark the linear solve failed, which
     k_lm_post treats as an invalid step: a silently different, still "successful" trajectory.  With PTZ_BA_DEBUG_CHAIN_SPIN=1
