@@ -2105,6 +2105,8 @@ static int32_t create_impl(int32_t n, const ptz_ba_problem* problems, const ptz_
   if (const char* e = getenv("PTZ_BA_DEBUG_CHAIN_SPIN")) b->d.chol.chain_spin_limit = std::max(0, atoi(e));  // tests: hand-overs that time out
   b->d.chol.chain_ready_whole = 1;  // (Dev is zero-filled at creation)
   b->d.chol.chain_pair = 1;
+  b->d.chol.chain_w0 = 1;
+  if (const char* e = getenv("PTZ_BA_CHAIN_W0")) b->d.chol.chain_w0 = atoi(e) != 0;
   if (const char* e = getenv("PTZ_BA_CHAIN_PAIR")) b->d.chol.chain_pair = atoi(e) != 0;
   if (const char* e = getenv("PTZ_BA_CHAIN_READY_WHOLE")) b->d.chol.chain_ready_whole = atoi(e) != 0;       // A/B: 0 = four block rounds also for finished columns
   if (const char* e = getenv("PTZ_BA_GRAPH")) b->use_graph = atoi(e) != 0;

@@ -611,6 +611,134 @@ __device__ __forceinline__ void diag_factor_tile(double* As, double (*Dv)[DB * L
   }
 }
 
+// ---- round 6: the diagonal tile of the chain kernels with ONE wave on the chain and no barrier on it ----------------------------------
+// diag_factor_tile<true> above puts, between two sweeps, a rank-16 update spread over the four waves behind a barrier and in front of
+// another: per 16-column block 0.24 us of loads + 1.1 of pivots + 0.48 of stores + 0.56 of update (stamps, NOTES_r06 1c) -- the pivots
+// are less than half of a tile's 9.3 us.  Here wave 0 alone walks the chain: it sweeps block b, stores the panel, applies block b's
+// share to column block b + 1 itself (3 - b rank-16 products on ITS matrix core, read from and written to LDS by the same wave: LDS
+// operations of one wave complete in order, no barrier), loads and sweeps block b + 1.  Beside it, synchronised through two counters in
+// LDS that the chain never waits on while they keep up: wave 2 applies block b's share to the column blocks behind b + 1 (as before),
+// wave 3 stores the finished column blocks and the inverses to global memory and raises their flags, wave 1 inverts diagonal block 0.
+// The same products in the same order per element as diag_factor_tile<true> (and therefore as every other path): same bits.
+// ctl: three ints in LDS -- [0] the two publishers of block 0, [1] panels stored by wave 0, [2] blocks whose far updates wave 2 has done.
+__device__ __forceinline__ void diag_factor_tile_w0(double* As, double (*Dv)[DB * LDD], int* ctl, const CholBatch& cb, int sys, int k, int n,
+                                                    int* Fk = nullptr, int gen = 0)
+{
+  const int np = cb.np, nt = np / NB;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  double* Lg = cb.Ldiag + ((size_t)sys * nt + k) * (NB * NB);
+  double* Dg = cb.Dinv + ((size_t)sys * nt + k) * 4 * (DB * DB);
+  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+  __syncthreads();
+  volatile int* vctl = ctl;
+  auto wait_ge = [&](int idx, int v) { while (vctl[idx] < v) __builtin_amdgcn_s_sleep(1); };
+  // C(ri, c) -= X(ri, m) X(c, m)^T on the matrix cores, one wave; `diag`: the finished diagonal block goes back with zeros above its diagonal
+  auto rank16 = [&](int ri, int c, int m, bool diag) {
+    double* C = As + (DB * ri) * LD + DB * c;
+    const double* Xi = As + (DB * ri) * LD + DB * m;
+    const double* Xj = As + (DB * c) * LD + DB * m;
+    d4 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = C[(fq + 4 * i) * LD + fr];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[fr * LD + 4 * ks + fq], Xj[fr * LD + 4 * ks + fq], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(fq + 4 * i) * LD + fr] = (diag && fr > fq + 4 * i) ? 0.0 : acc[i];
+  };
+  // block b - 1's share in column block b, all N = 4 - b row blocks at once: every LDS read first (X(b, b - 1) is every product's second
+  // operand), the N x 4 MFMAs interleaved over the N accumulators, then the stores -- one LDS latency and N x 4 MFMA issue slots where
+  // N calls of rank16 pay N latencies and N dependent chains of four (the same products in the same order per accumulator)
+  auto near_update = [&](auto nn, int b) {
+    constexpr int N = decltype(nn)::value;
+    const double* Xj = As + (DB * b) * LD + DB * (b - 1);
+    double xj[4], xi[N][4];
+    d4 acc[N];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xj[ks] = Xj[fr * LD + 4 * ks + fq];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double* Xi = As + (DB * (b + i)) * LD + DB * (b - 1);
+      const double* C = As + (DB * (b + i)) * LD + DB * b;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xi[i][ks] = Xi[fr * LD + 4 * ks + fq];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][q] = C[(fq + 4 * q) * LD + fr];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[i][ks], xj[ks], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double* C = As + (DB * (b + i)) * LD + DB * b;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) C[(fq + 4 * q) * LD + fr] = (i == 0 && fr > fq + 4 * q) ? 0.0 : acc[i][q];  // (the diagonal block: zeros above its diagonal)
+    }
+  };
+  DFT_STAMP(0);
+  if (w == 0) {
+    double dmin = 1.0;
+    bool bad = false;
+#pragma unroll 1
+    for (int b = 0; b < NB / DB; ++b) {
+      if (b > 0) {
+        if (b >= 2) wait_ge(2, b - 1);  // column block b holds the shares of blocks 0 .. b - 2 (wave 2)
+        if (b == 1) near_update(std::integral_constant<int, 3>{}, b);
+        else if (b == 2) near_update(std::integral_constant<int, 2>{}, b);
+        else near_update(std::integral_constant<int, 1>{}, b);
+      }
+      DFT_STAMP(1 + 2 * b);  // column block b is up to date
+      const bool last = b == NB / DB - 1;
+      diag_sweep_block<true>(As, b, k * NB, n, dmin, bad, Dv[b], last ? Dg + b * (DB * DB) : nullptr, (last && Fk) ? &Fk[b] : nullptr, gen);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS stores of the panel (and of the block's inverse) are done
+      if (lane == 0) vctl[1] = b + 1;
+      DFT_STAMP(2 + 2 * b);
+    }
+    if (lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
+  }
+  else if (w == 2) {
+    for (int b = 0; b + 2 < NB / DB; ++b) {  // block b's share in the column blocks behind b + 1
+      wait_ge(1, b + 1);
+      for (int c = b + 2; c < NB / DB; ++c)
+        for (int ri = c; ri < NB / DB; ++ri) rank16(ri, c, b, false);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (lane == 0) vctl[2] = b + 1;
+    }
+  }
+  else if (w == 3) {
+    for (int b = 0; b < NB / DB; ++b) {  // the finished column blocks (and, behind block 0, their inverses) on their way to global memory
+      wait_ge(1, b + 1);
+      diag_store_block(As, b, Lg, Fk != nullptr);
+      if (b > 0 && b + 1 < NB / DB) {  // (block 0's inverse is wave 1's, the last block's left from the sweeping wave's registers)
+        const double* dv = Dv[b];
+        double* dg = Dg + b * (DB * DB);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (Fk) st_sc1(&dg[(4 * p + fq) * DB + fr], dv[(4 * p + fq) * LDD + fr]);
+          else dg[(4 * p + fq) * DB + fr] = dv[(4 * p + fq) * LDD + fr];
+        }
+      }
+      if (Fk && b + 1 < NB / DB) {
+        drain_stores();
+        if (lane == 0 && (b > 0 || atomicAdd(&ctl[0], 1) == 1)) __hip_atomic_store(&Fk[b], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  else {  // w == 1: the inverse of diagonal block 0 (the sweep leaves the others')
+    wait_ge(1, 1);
+    diag_block_inverse(As, 0, Dg, Dv[0], Fk != nullptr);
+    if (Fk) {
+      drain_stores();
+      if (lane == 0 && atomicAdd(&ctl[0], 1) == 1) __hip_atomic_store(&Fk[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  DFT_STAMP(9);
+  if (cb.L && cb.Linv && k == nt - 1) tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + k) * (NB * NB));  // the last diagonal tile has no later launch whose spare workgroup could invert it
+}
+
 // block columns of step `step` of system `sys` (one-launch-per-step path)
 __device__ __forceinline__ void chol_step_columns(const CholBatch& cb, int sys, int step, int nt, int (&col)[CHOL_STEP_COLS])
 {
@@ -1128,7 +1256,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = (c == w && fr > fq + 4 * i) ? 0.0 : acc[c][i];  // (diag_factor_tile<true>: zero above the diagonal)
     __syncthreads();
     CS_STAMP(5);
-    diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
+    diag_factor_tile_w0(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n);  // (no static LDS: the dynamic base stays 16-byte aligned)
 #ifdef PTZ_CHOL_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     CS_STAMP(6);
@@ -1211,6 +1339,7 @@ __global__ void chol_chain_tl_print(int nt)
 #define TL_STAMP(i) do { } while (0)
 #endif
 
+template <bool W0>  // W0: the diagonal tile with one wave on the chain (diag_factor_tile_w0); a template parameter, not a run-time switch: the kernel's code must stay inside the instruction cache
 __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, int* wg, short* klist, int ticket, int gen)
 {
   short* kstep = klist + 1024;  // step of the schedule each list entry is a column of
@@ -1288,7 +1417,11 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   // above the diagonal, trsm_block_pre<.., true> -- and its block inverses lie in Dv, which is idle until the tile is factored),
   // and its 64 update MFMAs follow the first column's last round.  Every accumulator takes the same products in the same order
   // as one column after the other: same bits.  PTZ_BA_CHAIN_PAIR=0: one after the other.
+#ifdef PTZ_PROBE_NO_PAIR  // probe builds: the kernel without the paired-columns path (code size experiment)
+  constexpr bool pairs_on = false;
+#else
   const bool pairs_on = cb.chain_pair && ti == tj && cb.sched;
+#endif
   for (int q = 0; q < Q; ++q) {
     const int k = klist[q];
     const bool pair = pairs_on && q + 1 < Q && kstep[q] == kstep[q + 1];
@@ -1543,7 +1676,8 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
       for (int i = 0; i < 4; ++i) As[(16 * w + fq + 4 * i) * LD + 16 * c + fr] = (c == w && fr > fq + 4 * i) ? 0.0 : acc[c][i];  // (diag_factor_tile<true>: zero above the diagonal)
     __syncthreads();
     CS_STAMP(4);
-    diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
+    if constexpr (W0) diag_factor_tile_w0(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);
+    else diag_factor_tile<true>(As, Dv, reinterpret_cast<int*>(Dv + 4), cb, sys, ti, n, &F[4 * ti], gen);  // (the last tile also inverts itself there)
     CS_STAMP(5);
     TL_STAMP(2);
     // (F[4 ti + 3] was raised inside, by the sweeping wave, whose spare lanes hold the last diagonal block's inverse)
@@ -1571,6 +1705,7 @@ __device__ __forceinline__ void chain_tile(const CholBatch& cb, double* smem, in
   TL_STAMP(2);
 }
 
+template <bool W0>
 __global__ __launch_bounds__(256) void chol_chain_kernel(CholBatch cb)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1585,7 +1720,7 @@ __global__ __launch_bounds__(256) void chol_chain_kernel(CholBatch cb)
   }
   __syncthreads();
   const int ticket = wg[0], gen = wg[1];
-  chain_tile(cb, smem, wg, klist, ticket, gen);
+  chain_tile<W0>(cb, smem, wg, klist, ticket, gen);
   // the last workgroup to finish closes the launch: tickets start at zero again, the generation moves on (nobody reads
   // either any more: every workgroup has taken its ticket and read the generation before it counted itself done)
   if (threadIdx.x == 0) {
@@ -2339,11 +2474,13 @@ void chol_chain_launch(const CholBatch& cb, hipStream_t stream)
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-      (void)hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)chol_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)chol_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       done.fetch_or(bit, std::memory_order_release);
     }
   }
-  launch(chol_chain_kernel, dim3(nt * (nt + 1) / 2 * cb.count), dim3(256), smem, stream, cb);
+  if (cb.chain_w0) launch(chol_chain_kernel<true>, dim3(nt * (nt + 1) / 2 * cb.count), dim3(256), smem, stream, cb);
+  else launch(chol_chain_kernel<false>, dim3(nt * (nt + 1) / 2 * cb.count), dim3(256), smem, stream, cb);
 }
 #ifdef PTZ_CHOL_TIMELINE
 void chol_chain_timeline_print(int nt) { hipLaunchKernelGGL(chol_chain_tl_print, dim3(1), dim3(1), 0, 0, nt); (void)hipDeviceSynchronize(); }

@@ -291,6 +291,7 @@ struct CholBatch {
   // one block per stream that factors)
   int* chain_ctl = nullptr;
   int chain_spin_limit = 0;  // polls a chain hand-over waits for before it gives up (0: the default, 2^21; tests shorten it)
+  int chain_w0 = 1;          // the chain kernels' diagonal tile with one wave on the chain and no barrier on it (diag_factor_tile_w0; PTZ_BA_CHAIN_W0=0: the four-wave form)
   int chain_pair = 1;        // chol_chain_kernel: the last two columns of a diagonal tile side by side when their producers end together (PTZ_BA_CHAIN_PAIR=0: in turn)
   int chain_ready_whole = 1; // chol_chain_kernel: a column found finished is applied in one go (PTZ_BA_CHAIN_READY_WHOLE=0: block rounds, A/B)
   // device [count][4 * chol_backsolve_max_groups(np)] work items of the back-substitution in execution order and [count] their

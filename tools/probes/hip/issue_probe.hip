@@ -36,6 +36,27 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, int reps)
   out[threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[0] = t;
 }
+typedef double pd4 __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64 from ONE wave: NACC independent accumulators used round-robin (NACC = 1: a dependent chain)
+template <int NACC>
+__global__ __launch_bounds__(256) void km(double* out, long long* cyc, int reps)
+{
+  pd4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = pd4{0, 0, 0, 0};
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  long long t = 0;
+  for (int it = 0; it < reps; ++it) {
+    const long long t0 = clock64();
+#pragma unroll
+    for (int r = 0; r < 48 / NACC; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    t += clock64() - t0;
+  }
+  double s = 0; for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[0] = t;
+}
 int main()
 {
   double* o; long long* c; hipMalloc(&o, 64 * 8); hipMalloc(&c, 8);
@@ -62,6 +83,22 @@ int main()
     }
     long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
     printf("%-30s %.2f cycles per instruction (64 independent, one wave)\n", names[kind], (double)cy / reps / 64);
+  }
+  for (int nacc = 1; nacc <= 4; ++nacc) {
+    for (int w = 0; w < 2; ++w) {
+      if (nacc == 1) hipLaunchKernelGGL(km<1>, dim3(1), dim3(64), 0, 0, o, c, reps);
+      else if (nacc == 2) hipLaunchKernelGGL(km<2>, dim3(1), dim3(64), 0, 0, o, c, reps);
+      else if (nacc == 3) hipLaunchKernelGGL(km<3>, dim3(1), dim3(64), 0, 0, o, c, reps);
+      else hipLaunchKernelGGL(km<4>, dim3(1), dim3(64), 0, 0, o, c, reps);
+      hipDeviceSynchronize();
+    }
+    long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
+    printf("v_mfma_f64_16x16x4_f64, %d accumulator(s) in turn: %.1f cycles per instruction (one wave)\n", nacc, (double)cy / reps / 48);
+  }
+  for (int waves = 2; waves <= 4; waves += 2) {  // the same from 2 / 4 waves of ONE workgroup (a SIMD each): is the FP64 matrix rate per SIMD or per compute unit?
+    for (int w = 0; w < 2; ++w) { hipLaunchKernelGGL(km<4>, dim3(1), dim3(64 * waves), 0, 0, o, c, reps); hipDeviceSynchronize(); }
+    long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
+    printf("v_mfma_f64_16x16x4_f64, %d waves of one workgroup at once: %.1f cycles per instruction of wave 0\n", waves, (double)cy / reps / 48);
   }
   return 0;
 }
