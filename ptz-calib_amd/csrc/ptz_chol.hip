@@ -256,14 +256,15 @@ template <int J> __device__ __forceinline__ void dpp_sweep(double (&ar)[DB], dou
     dpp_sweep<J + 1>(ar, a, ird, live_cols, dmin, bad, c15);
   }
   else {
-    // A pivot that is not positive (or not a number) leaves a NaN as its 1 / sqrt(d): rsq of a negative number or of a NaN is a NaN,
-    // of a zero an infinity that the Newton steps turn into one -- so the sixteen checks of the pivots are ONE sum of the live pivots'
-    // reciprocal roots behind the sweep (was: a compare, a minimum and their masks per pivot, 150 instructions that the compiler
-    // gathered behind the asm block, on the chain).  (An infinite pivot, which the old test let pass, is reported as well.)
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < DB; ++j) acc += (j < live_cols) ? ird[j] : 0.0;
-    bad |= acc != acc;
+    // A pivot that is not positive (or not a number) leaves a NaN as its 1 / sqrt(d) -- rsq of a negative number or of a NaN is a NaN,
+    // of a zero an infinity that the Newton steps turn into one -- and a NaN column of L makes every later pivot of the system a NaN
+    // (every row below takes 0 x NaN or worse into its diagonal).  So the sixteen checks of a block are ONE compare of its LAST
+    // reciprocal root (was: a compare, a minimum and their masks per pivot, ~150 instructions that the compiler gathered behind the
+    // asm block, on the chain; then a sum of sixteen masked roots, ~80).  What the masks left out -- the row of the right-hand side and
+    // the padding behind it -- is in now: a NaN there (a non-finite gradient) fails the solve here, where it used to fail the step's
+    // finiteness test a kernel later; the LM control takes the same branch (an invalid step) either way.
+    bad |= ird[DB - 1] != ird[DB - 1];
+    (void)live_cols;
     (void)dmin;
   }
 }
