@@ -317,7 +317,11 @@ __device__ __forceinline__ void diag_sweep_block(double* As, int b, int kbase, i
 #ifdef PTZ_CHOL_TIMELINE
     if (threadIdx.x == 0 && flag_dbg_row) flag_dbg_row[0] = wall_clock64();
 #endif
+#ifndef PTZ_TP_NO_SWEEP  // (tools/probes/hip/tile_probe.hip: the phases' costs by knock-out)
     dpp_sweep<0>(ar, a, ird, n - (kbase + DB * b), dmin, bad);
+#else
+    for (int j = 0; j < DB; ++j) ird[j] = 1.0;
+#endif
 #ifdef PTZ_CHOL_TIMELINE
     if (threadIdx.x == 0 && flag_dbg_row) flag_dbg_row[1] = wall_clock64();
 #endif
@@ -685,10 +689,14 @@ __device__ __forceinline__ void diag_factor_tile_w0(double* As, double (*Dv)[DB 
 #pragma unroll 1
     for (int b = 0; b < NB / DB; ++b) {
       if (b > 0) {
+#ifndef PTZ_TP_NO_HELPERS
         if (b >= 2) wait_ge(2, b - 1);  // column block b holds the shares of blocks 0 .. b - 2 (wave 2)
+#endif
+#ifndef PTZ_TP_NO_NEAR
         if (b == 1) near_update(std::integral_constant<int, 3>{}, b);
         else if (b == 2) near_update(std::integral_constant<int, 2>{}, b);
         else near_update(std::integral_constant<int, 1>{}, b);
+#endif
       }
       DFT_STAMP(1 + 2 * b);  // column block b is up to date
       const bool last = b == NB / DB - 1;
@@ -699,6 +707,7 @@ __device__ __forceinline__ void diag_factor_tile_w0(double* As, double (*Dv)[DB 
     }
     if (lane == 0 && (bad || !(dmin > 0.0))) atomicOr(&cb.fail[sys], 1);
   }
+#ifndef PTZ_TP_NO_HELPERS
   else if (w == 2) {
     for (int b = 0; b + 2 < NB / DB; ++b) {  // block b's share in the column blocks behind b + 1
       wait_ge(1, b + 1);
@@ -735,6 +744,7 @@ __device__ __forceinline__ void diag_factor_tile_w0(double* As, double (*Dv)[DB 
       if (lane == 0 && atomicAdd(&ctl[0], 1) == 1) __hip_atomic_store(&Fk[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#endif
   __syncthreads();
   DFT_STAMP(9);
   if (cb.L && cb.Linv && k == nt - 1) tile_inverse(As, &Dv[0][0], cb.Linv + ((size_t)sys * nt + k) * (NB * NB));  // the last diagonal tile has no later launch whose spare workgroup could invert it
