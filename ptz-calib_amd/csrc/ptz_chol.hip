@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(256) void chol_col_step_kernel(CholBatch cb, int st
 constexpr int CHAIN_SPIN_LIMIT = 1 << 21;
 // `fail`: the system's failure word.  Once ANY wait of the system has run out (bit 1), every other waiter of that system gives up
 // at its next look (every 1024 polls): a lost hand-over costs one bound, not one bound per tile behind it.
-__device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit, const int* fail = nullptr)  // (one thread polls; the workgroup's acquire fence follows its barrier)
+__device__ __forceinline__ bool chain_wait(const int* flag, int gen, int limit, const int* fail = nullptr)  // (one thread polls with an sc1 load; the bytes the flag stands for are read with sc1 loads: see ld_sc1)
 {
   for (int it = 0; it < limit; ++it) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) return true;
