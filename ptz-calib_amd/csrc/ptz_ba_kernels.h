@@ -2276,6 +2276,18 @@ __global__ __launch_bounds__(256, 3) void k_schur_f(Dev d)
       const double a0 = row[1], a1 = row[2], a2 = row[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) row[1 + k] = (a0 * pJl[k] + a1 * pJl[3 + k] + a2 * pJl[6 + k]) * pf;
+      if constexpr (NC == NW) {
+        // (round 6) the block row lies in ONE row of the stored triangle when camera i's tile comes behind camera j's: its four
+        // values are 32 contiguous, 32-byte aligned bytes -- two 16-byte stores instead of four 8-byte ones (the same values)
+        const int rr_ = scol(ci * NC + p), c0 = scol(cj * NC);
+        if (rr_ > c0) {
+          double2* d2 = reinterpret_cast<double2*>(A + (size_t)rr_ * np + c0);
+          const double v0 = row[0] * (pf * pS[0]), v1 = row[1] * (pf * pS[1]), v2 = row[2] * (pf * pS[2]), v3 = row[3] * (pf * pS[3]);
+          if (first) { d2[0] = make_double2(v0, v1); d2[1] = make_double2(v2, v3); }
+          else { const double2 o0 = d2[0], o1 = d2[1]; d2[0] = make_double2(o0.x + v0, o0.y + v1); d2[1] = make_double2(o1.x + v2, o1.y + v3); }
+          continue;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         const double v = row[q] * (pf * pS[q]);
