@@ -472,7 +472,7 @@ def main():
         distinct = max(1, min(n_scenes, args.distinct or n_scenes))
         workers = args.workers
         if workers is None and world > 1:
-            workers = max(1, min(16, (os.cpu_count() or 8) // world))
+            workers = max(1, min(16, pkg.synth.usable_cores() // world))  # (the cgroup quota, not the logical CPU count: eight ranks share it)
         base = pkg.synth.make_scenes([first_scene + i for i in range(distinct)], args.views, args.obs, workers=workers,
                                      cache_dir=args.scene_cache or None)
         scenes = [base[i % distinct] for i in range(n_scenes)]

@@ -20,6 +20,20 @@ _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: min(affinity, cgroup CPU quota).  A GPU box shows hundreds of logical CPUs and caps
+    the container at a CFS quota; pools sized by os.cpu_count() oversubscribe it several times over (eight ranks x 16 workers)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class SplitMix64:
     """Counter-based SplitMix64 stream; draw(n) returns the next n outputs."""
 
@@ -598,10 +612,7 @@ def make_scenes(scene_ids, n_views: int = 200, obs_per_view: int = 500, workers:
         return [out[i] for i in ids]
     cache_to = kw.pop("_cache_to", None)
     if workers is None:
-        try:
-            workers = len(os.sched_getaffinity(0))
-        except AttributeError:
-            workers = os.cpu_count() or 1
+        workers = usable_cores()
         workers = min(workers, 16)
     workers = max(1, min(workers, len(ids)))
     jobs = [((i, n_views, obs_per_view), kw, cache_to) for i in ids]
@@ -802,10 +813,7 @@ def make_match_tables(scenes, workers: int | None = None, **kw) -> list:
     import os
     scenes = list(scenes)
     if workers is None:
-        try:
-            workers = len(os.sched_getaffinity(0))
-        except AttributeError:
-            workers = os.cpu_count() or 1
+        workers = usable_cores()
         workers = min(workers, 16)
     workers = max(1, min(workers, len(scenes)))
     if workers == 1:
