@@ -767,6 +767,19 @@ def test_inline_asm_dpp_sequences_keep_their_wait_states(tmp_path):
     n_dpp, bad = mod.scan(out)
     assert n_dpp >= 512, n_dpp   # two kernels carry the sweep: 16 broadcasts + 240 multiply-adds each
     assert not bad, bad[:5]
+    # Round 6: the chain kernel's hand-overs carry no fence -- every handed-over byte is stored write-through (sc1), drained, and read
+    # with sc1 loads (ptz_chol.hip ld_sc1 / st_sc1).  What the compiler made of it: no L2 write-back and no L1 invalidate in the kernel,
+    # and its plain vector loads are the launch's own inputs only (structure words, bytes, and the workgroup's own C tile: sixteen
+    # 8-byte loads) -- a plain load of handed-over bytes added later would read this compute unit's stale L1 copy.
+    text = open(out).read()
+    for form in ("ILb1EEEvNS_9CholBatchE", "ILb0EEEvNS_9CholBatchE"):
+        begin = text.index("\n_ZN3ptz12_GLOBAL__N_117chol_chain_kernel" + form + ":")
+        body = text[begin:text.index("s_endpgm", begin)]
+        assert "buffer_inv" not in body and "buffer_wbl2" not in body, form
+        plain = [l.split()[0] for l in body.splitlines() if ("global_load" in l or "flat_load" in l or "buffer_load" in l) and " sc1" not in l]
+        assert sum(op == "global_load_dwordx2" for op in plain) == 16, plain        # the workgroup's own C tile (accumulator layout)
+        assert all(op in ("global_load_dwordx2", "global_load_dword", "global_load_ubyte", "global_load_ushort", "global_load_sshort") for op in plain), plain
+        assert body.count(" sc1") > 100
     # and the checker sees a violation when there is one
     hz = tmp_path / "hazard.s"
     hz.write_text("x:\n\tv_mul_f64 v[2:3], v[2:3], v[4:5]\n\tv_mul_f64 v[8:9], v[2:3], v[4:5]\n"
