@@ -20,6 +20,33 @@ _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
 
 
+_SYNTH_LIB = False
+
+
+def _synth_lib(name: str = "ptz_synth_project"):
+    """A function of libptzsynth.so (host/synth_kernels.c, built by __graft_entry__.build() / host/Makefile), or None: numpy does the
+    same arithmetic (PTZ_SYNTH_NUMPY=1 forces that; tests hold both paths to the same scene hashes)."""
+    global _SYNTH_LIB
+    if _SYNTH_LIB is False:
+        import ctypes
+        import os
+        _SYNTH_LIB = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptzsynth.so")
+        if os.environ.get("PTZ_SYNTH_NUMPY") != "1" and os.path.exists(path):
+            try:
+                dll = ctypes.CDLL(path)
+                fn = dll.ptz_synth_project
+                fn.restype = None
+                fn.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 6 + [ctypes.c_double] * 4 + [ctypes.c_void_p] * 3
+                fc = dll.ptz_synth_candidates
+                fc.restype = None
+                fc.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 6
+                _SYNTH_LIB = {"ptz_synth_project": fn, "ptz_synth_candidates": fc}
+            except (OSError, AttributeError):
+                _SYNTH_LIB = None
+    return _SYNTH_LIB.get(name) if _SYNTH_LIB else None
+
+
 def usable_cores() -> int:
     """CPU cores this process may actually use: min(affinity, cgroup CPU quota).  A GPU box shows hundreds of logical CPUs and caps
     the container at a CFS quota; pools sized by os.cpu_count() oversubscribe it several times over (eight ranks x 16 workers)."""
@@ -143,6 +170,28 @@ def _candidate_pairs(az: np.ndarray, pan: np.ndarray, window: float):
     a = np.mod(az, two_pi)
     idx = np.argsort(a, kind="stable")
     a_sorted = a[idx]
+    cand = _synth_lib("ptz_synth_candidates")
+    if cand is not None:
+        # the three slices of every view by vectorised searchsorted, their union in ascending ray order by a bitmap in C
+        # (host/synth_kernels.c) instead of a Python loop over the views with a sort each: the same pairs in the same order
+        c = np.array([(-pn) % two_pi for pn in pan], dtype=np.float64)
+        lo, hi = c - window, c + window
+        n_v = len(pan)
+        L = np.zeros((n_v, 3), dtype=np.int64); H = np.zeros((n_v, 3), dtype=np.int64)
+        wl, wh = lo < 0.0, hi > two_pi
+        L[wl, 0] = np.searchsorted(a_sorted, lo[wl] + two_pi, "left"); H[wl, 0] = n_ray
+        H[wh, 1] = np.searchsorted(a_sorted, hi[wh] - two_pi, "right")
+        lo_c, hi_c = np.where(wl, 0.0, lo), np.where(wh, two_pi, hi)
+        L[:, 2] = np.searchsorted(a_sorted, lo_c, "left"); H[:, 2] = np.searchsorted(a_sorted, hi_c, "right")
+        H = np.maximum(H, L)
+        counts = (H - L).sum(axis=1)
+        offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        total = int(counts.sum())
+        vi = np.empty(total, dtype=np.int64); pi_ = np.empty(total, dtype=np.int64)
+        bitmap = np.zeros((n_ray + 63) // 64, dtype=np.uint64)
+        idx64 = np.ascontiguousarray(idx, dtype=np.int64); L = np.ascontiguousarray(L); H = np.ascontiguousarray(H)
+        cand(n_ray, idx64.ctypes.data, n_v, L.ctypes.data, H.ctypes.data, offs.ctypes.data, bitmap.ctypes.data, vi.ctypes.data, pi_.ctypes.data)
+        return vi, pi_
     vi, pi_ = [], []
     for i, pn in enumerate(pan):
         c = (-pn) % two_pi  # the azimuth this view looks at
@@ -264,6 +313,21 @@ def make_scene(scene_id: int = 0, n_views: int = 200, obs_per_view: int = 500, f
         X = np.stack([cos_el * np.sin(az), sin_el, cos_el * np.cos(az)], axis=1)  # unit, z forward at pan 0
         vi, pi_ = _candidate_pairs(az, pan, window)  # view-major, rays ascending inside a view
         # exact projections and visibility (>= 8 px inside the frame)
+        proj = _synth_lib()
+        if proj is not None:
+            # the same arithmetic in C (host/synth_kernels.c, -ffp-contract=off: every product and sum rounded where numpy rounds it)
+            vi = np.ascontiguousarray(vi, dtype=np.int64); pi_ = np.ascontiguousarray(pi_, dtype=np.int64)
+            u = np.empty(len(vi)); v = np.empty(len(vi)); vis8 = np.empty(len(vi), dtype=np.uint8)
+            Rflat = np.ascontiguousarray(Rgt.reshape(N, 9)); Xc = np.ascontiguousarray(X)
+            fc = np.ascontiguousarray(focal, dtype=np.float64); kc = np.ascontiguousarray(k1, dtype=np.float64)
+            proj(len(vi), vi.ctypes.data, pi_.ctypes.data, Rflat.ctypes.data, Xc.ctypes.data, fc.ctypes.data, kc.ctypes.data,
+                 float(cx), float(cy), float(width), float(height), u.ctypes.data, v.ctypes.data, vis8.ctypes.data)
+            vis = vis8.view(np.bool_)
+            ratio = 2.2 * target_total / max(int(vis.sum()), 1)
+            if 0.92 < ratio < 1.08 or _attempt == 3:
+                break
+            P = max(16, int(round(P * ratio)))
+            continue
         # (the pairs are view-major: a camera's entries are np.repeat of its value over its run of pairs -- the gathers'
         #  values, at a third of their cost; the rays' coordinates are taken from contiguous columns)
         runs = np.bincount(vi, minlength=N)

@@ -785,3 +785,27 @@ def test_inline_asm_dpp_sequences_keep_their_wait_states(tmp_path):
     hz.write_text("x:\n\tv_mul_f64 v[2:3], v[2:3], v[4:5]\n\tv_mul_f64 v[8:9], v[2:3], v[4:5]\n"
                   "\tv_fmac_f64_dpp v[6:7], v[2:3], -v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
     assert len(mod.scan(str(hz))[1]) == 1
+
+
+def test_scene_generator_c_inner_loops_reproduce_the_numpy_form(pkg):
+    """Round 6: the generator's two inner loops (candidate pairs, projection + visibility) also exist in C (host/synth_kernels.c,
+    -ffp-contract=off) -- 0.37 -> 0.16 s per 200 x 500 scene.  Every array of a scene must have the bits of the numpy form, over the
+    shapes the tests and the benchmark use (ring and sector rigs, distortion, shared intrinsics, the dense-window case of tiny rigs)."""
+    if pkg.synth._synth_lib() is None:
+        pytest.skip("libptzsynth.so not built")
+    cfgs = [dict(scene_id=0, n_views=200, obs_per_view=500), dict(scene_id=7, n_views=20, obs_per_view=100),
+            dict(scene_id=3, n_views=60, obs_per_view=300, factor_type=1, width=1280, height=720, pan_range_deg=120.0),
+            dict(scene_id=11, n_views=40, obs_per_view=150, factor_type=2), dict(scene_id=9, n_views=70, obs_per_view=250, n_intrinsics_groups=3),
+            dict(scene_id=21, n_views=2, obs_per_view=40)]
+    fields = ("obs_uv", "obs_cam", "obs_ray", "ray_weight", "cam_gt", "cam_init", "ray_gt", "ray_init")
+    with_c = [pkg.synth.make_scene(**c) for c in cfgs]
+    saved = pkg.synth._SYNTH_LIB
+    pkg.synth._SYNTH_LIB = None  # the numpy form
+    try:
+        plain = [pkg.synth.make_scene(**c) for c in cfgs]
+    finally:
+        pkg.synth._SYNTH_LIB = saved
+    for a, b in zip(with_c, plain):
+        assert a.n_ray == b.n_ray
+        for f in fields:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
